@@ -1,0 +1,115 @@
+"""ctypes loader of the C-ABI shared library ``libfiesta_hip.so`` (see include/fiesta_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or no gfx950 device is usable the
+product path fails loudly (``FiestaHipError``).  Nothing under ``oracle/`` is ever imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfiesta_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fiesta_hip.h")
+
+
+class FiestaHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"fiesta_hip error {code}: {message}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("device", C.c_int32), ("origin", C.c_double * 3),
+                ("resolution", C.c_double), ("map_size", C.c_double * 3), ("reserve_size", C.c_int32),
+                ("tile_shape", C.c_int32), ("shard_lo", C.c_int32 * 3), ("global_grid", C.c_int32 * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("inserted", C.c_int64), ("deleted", C.c_int64), ("invalidated", C.c_int64),
+                ("rounds", C.c_int64), ("tile_visits", C.c_int64), ("sweeps", C.c_int64),
+                ("voxel_writes", C.c_int64), ("device_ms", C.c_double), ("host_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RaycastParams(C.Structure):
+    _fields_ = [("min_ray_length", C.c_double), ("max_ray_length", C.c_double), ("l_cornor", C.c_double * 3),
+                ("r_cornor", C.c_double * 3), ("dedup", C.c_int32), ("reserved", C.c_int32)]
+
+
+def declared_symbols(header_path: str = HEADER_PATH):
+    """Names of every function include/fiesta_hip.h declares (used by the CPU export test)."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fiesta_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load():
+    """Load libfiesta_hip.so (raises FiestaHipError if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FiestaHipError(-1, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    sig = {
+        "fiesta_hip_last_error": (C.c_char_p, []),
+        "fiesta_hip_version": (C.c_int, []),
+        "fiesta_hip_device_count": (C.c_int, []),
+        "fiesta_hip_create": (C.c_int, [vp, vp]),
+        "fiesta_hip_destroy": (C.c_int, [vp]),
+        "fiesta_hip_grid_size": (C.c_int, [vp, vp]),
+        "fiesta_hip_grid_total_size": (C.c_int, [vp, vp]),
+        "fiesta_hip_set_prob_params": (C.c_int, [vp, dbl, dbl, dbl, dbl, dbl]),
+        "fiesta_hip_set_update_range": (C.c_int, [vp, vp, vp, C.c_int]),
+        "fiesta_hip_set_original_range": (C.c_int, [vp]),
+        "fiesta_hip_set_occupancy_vox": (C.c_int, [vp, vp, vp, i64, vp]),
+        "fiesta_hip_set_occupancy_pos": (C.c_int, [vp, vp, vp, i64, vp]),
+        "fiesta_hip_set_occupancy_vox_dev": (C.c_int, [vp, vp, vp, i64]),
+        "fiesta_hip_raycast_frame": (C.c_int, [vp, vp, i64, vp, vp, vp]),
+        "fiesta_hip_raycast_frame_dev": (C.c_int, [vp, vp, i64, vp, vp, vp]),
+        "fiesta_hip_raycast_depth": (C.c_int, [vp, vp, i32, i32, dbl, dbl, dbl, dbl, vp, vp, vp]),
+        "fiesta_hip_raycast_single": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i32]),
+        "fiesta_hip_check_update": (C.c_int, [vp, vp]),
+        "fiesta_hip_update_occupancy": (C.c_int, [vp, i32, vp, vp, vp]),
+        "fiesta_hip_update_esdf": (C.c_int, [vp, vp]),
+        "fiesta_hip_get_distance_vox": (C.c_int, [vp, vp, i64, vp]),
+        "fiesta_hip_get_distance_pos": (C.c_int, [vp, vp, i64, vp]),
+        "fiesta_hip_get_dist_grad": (C.c_int, [vp, vp, i64, vp, vp]),
+        "fiesta_hip_get_dist_grad_dev": (C.c_int, [vp, vp, i64, vp, vp]),
+        "fiesta_hip_get_occupancy_vox": (C.c_int, [vp, vp, i64, vp]),
+        "fiesta_hip_get_occupancy_pos": (C.c_int, [vp, vp, i64, vp]),
+        "fiesta_hip_download_field": (C.c_int, [vp, vp, vp, vp, vp]),
+        "fiesta_hip_download_hash": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        "fiesta_hip_snapshot_save": (C.c_int, [vp, i32]),
+        "fiesta_hip_snapshot_restore": (C.c_int, [vp, i32]),
+        "fiesta_hip_snapshot_count_updated": (C.c_int, [vp, i32, vp]),
+        "fiesta_hip_halo_pack_dev": (C.c_int, [vp, vp, vp, i32, vp, i64, vp]),
+        "fiesta_hip_halo_apply_dev": (C.c_int, [vp, vp, vp, vp, i64, vp]),
+        "fiesta_hip_relax_pending": (C.c_int, [vp, vp, vp]),
+        "fiesta_hip_synchronize": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._fiesta_signatures = sig
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != 0:
+        raise FiestaHipError(status, load().fiesta_hip_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return int(load().fiesta_hip_device_count())

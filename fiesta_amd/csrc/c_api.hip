@@ -1,0 +1,337 @@
+// fiesta_amd/csrc/c_api.hip -- the extern "C" boundary declared in include/fiesta_hip.h.
+// Every entry point converts C++ exceptions into a status code + thread-local message; nothing throws
+// across the ABI and no HIP / C++ type appears in a signature.
+#include <cstring>
+#include <string>
+
+#include "../../include/fiesta_hip.h"
+#include "dense_map.hpp"
+#include "hash_map.hpp"
+
+using fiesta::DenseMap;
+using fiesta::Error;
+using fiesta::HashMap;
+
+struct fiesta_hip_map {
+  int mode = 0;
+  DenseMap *dense = nullptr;
+  HashMap *hash = nullptr;
+};
+
+namespace {
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F &&f) {
+  try {
+    f();
+    return FIESTA_HIP_OK;
+  } catch (const Error &e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return FIESTA_HIP_ERR_DEVICE;
+  } catch (...) {
+    g_last_error = "unknown error";
+    return FIESTA_HIP_ERR_DEVICE;
+  }
+}
+void need(bool ok, const char *msg) {
+  if (!ok) throw Error(FIESTA_HIP_ERR_INVALID, msg);
+}
+DenseMap &dense(fiesta_hip_map *m, const char *what) {
+  need(m != nullptr, "null map handle");
+  if (!m->dense) throw Error(FIESTA_HIP_ERR_INVALID, std::string(what) + ": only available on array-mode maps");
+  return *m->dense;
+}
+}  // namespace
+
+extern "C" {
+
+const char *fiesta_hip_last_error(void) { return g_last_error.c_str(); }
+int fiesta_hip_version(void) { return 100; }
+
+int fiesta_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+int fiesta_hip_create(const fiesta_hip_config *cfg, fiesta_hip_map **out) {
+  return guarded([&] {
+    need(cfg && out, "null argument");
+    *out = nullptr;
+    auto *m = new fiesta_hip_map;
+    try {
+      m->mode = cfg->mode;
+      if (cfg->mode == FIESTA_HIP_MODE_ARRAY)
+        m->dense = new DenseMap(*cfg);
+      else if (cfg->mode == FIESTA_HIP_MODE_HASH)
+        m->hash = new HashMap(*cfg);
+      else
+        throw Error(FIESTA_HIP_ERR_INVALID, "unknown mode");
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    *out = m;
+  });
+}
+
+int fiesta_hip_destroy(fiesta_hip_map *m) {
+  return guarded([&] {
+    if (!m) return;
+    delete m->dense;
+    delete m->hash;
+    delete m;
+  });
+}
+
+int fiesta_hip_grid_size(fiesta_hip_map *m, int32_t out[3]) {
+  return guarded([&] {
+    need(m && out, "null argument");
+    if (m->dense) {
+      out[0] = m->dense->geom().nx;
+      out[1] = m->dense->geom().ny;
+      out[2] = m->dense->geom().nz;
+    } else {
+      out[0] = out[1] = out[2] = 0;
+    }
+  });
+}
+int fiesta_hip_grid_total_size(fiesta_hip_map *m, int64_t *out) {
+  return guarded([&] {
+    need(m && out, "null argument");
+    *out = m->dense ? m->dense->total() : m->hash->allocated_voxels();
+  });
+}
+
+int fiesta_hip_set_prob_params(fiesta_hip_map *m, double p_hit, double p_miss, double p_min, double p_max,
+                               double p_occ) {
+  return guarded([&] {
+    need(m != nullptr, "null map handle");
+    if (m->dense)
+      m->dense->set_prob_params(p_hit, p_miss, p_min, p_max, p_occ);
+    else
+      m->hash->set_prob_params(p_hit, p_miss, p_min, p_max, p_occ);
+  });
+}
+int fiesta_hip_set_update_range(fiesta_hip_map *m, const double mn[3], const double mx[3], int new_vec) {
+  return guarded([&] {
+    need(m && mn && mx, "null argument");
+    if (m->dense)
+      m->dense->set_update_range(mn, mx, new_vec != 0);
+    else
+      m->hash->set_update_range(mn, mx, new_vec != 0);
+  });
+}
+int fiesta_hip_set_original_range(fiesta_hip_map *m) {
+  return guarded([&] {
+    need(m != nullptr, "null map handle");
+    if (m->dense)
+      m->dense->set_original_range();
+    else
+      m->hash->set_original_range();
+  });
+}
+
+int fiesta_hip_set_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret) {
+  return guarded([&] {
+    need(m && (n == 0 || (vox && occ)) && n >= 0, "bad argument");
+    if (m->dense)
+      m->dense->observe_vox(vox, occ, n, ret, false);
+    else
+      m->hash->observe_vox(vox, occ, n, ret);
+  });
+}
+int fiesta_hip_set_occupancy_pos(fiesta_hip_map *m, const double *pos, const int32_t *occ, int64_t n, int32_t *ret) {
+  return guarded([&] {
+    need(m && (n == 0 || (pos && occ)) && n >= 0, "bad argument");
+    if (m->dense)
+      m->dense->observe_pos(pos, occ, n, ret);
+    else
+      m->hash->observe_pos(pos, occ, n, ret);
+  });
+}
+int fiesta_hip_set_occupancy_vox_dev(fiesta_hip_map *m, const int32_t *vox_dev, const int32_t *occ_dev, int64_t n) {
+  return guarded([&] {
+    need(m && (n == 0 || (vox_dev && occ_dev)) && n >= 0, "bad argument");
+    dense(m, "set_occupancy_vox_dev").observe_vox(vox_dev, occ_dev, n, nullptr, true);
+  });
+}
+
+int fiesta_hip_raycast_frame(fiesta_hip_map *m, const float *points, int64_t n, const double T[16],
+                             const double origin[3], const fiesta_hip_raycast_params *p) {
+  return guarded([&] {
+    need(m && (n == 0 || points) && T && origin && p && n >= 0, "bad argument");
+    if (m->dense)
+      m->dense->raycast_frame(points, n, T, origin, p, false);
+    else
+      m->hash->raycast_frame(points, n, T, origin, p);
+  });
+}
+int fiesta_hip_raycast_frame_dev(fiesta_hip_map *m, const float *points_dev, int64_t n, const double T[16],
+                                 const double origin[3], const fiesta_hip_raycast_params *p) {
+  return guarded([&] {
+    need(m && (n == 0 || points_dev) && T && origin && p && n >= 0, "bad argument");
+    dense(m, "raycast_frame_dev").raycast_frame(points_dev, n, T, origin, p, true);
+  });
+}
+int fiesta_hip_raycast_depth(fiesta_hip_map *m, const uint16_t *depth, int32_t rows, int32_t cols, double fx,
+                             double fy, double cx, double cy, const double T[16], const double origin[3],
+                             const fiesta_hip_raycast_params *p) {
+  return guarded([&] {
+    need(m && depth && rows > 0 && cols > 0 && T && origin && p, "bad argument");
+    dense(m, "raycast_depth").raycast_depth(depth, rows, cols, fx, fy, cx, cy, T, origin, p);
+  });
+}
+int fiesta_hip_raycast_single(const double start[3], const double end[3], const double minv[3],
+                              const double maxv[3], double *out, int32_t cap, int32_t *n_out, int32_t device) {
+  return guarded([&] {
+    need(start && end && minv && maxv && n_out && (cap == 0 || out), "bad argument");
+    fiesta::raycast_single(start, end, minv, maxv, out, cap, n_out, device);
+  });
+}
+
+int fiesta_hip_check_update(fiesta_hip_map *m, int32_t *out) {
+  return guarded([&] {
+    need(m && out, "null argument");
+    *out = (m->dense ? m->dense->check_update() : m->hash->check_update()) ? 1 : 0;
+  });
+}
+int fiesta_hip_update_occupancy(fiesta_hip_map *m, int32_t global_map, int64_t *n_insert, int64_t *n_delete,
+                                int32_t *any) {
+  return guarded([&] {
+    need(m != nullptr, "null map handle");
+    const bool r = m->dense ? m->dense->update_occupancy(global_map != 0, n_insert, n_delete)
+                            : m->hash->update_occupancy(global_map != 0, n_insert, n_delete);
+    if (any) *any = r ? 1 : 0;
+  });
+}
+int fiesta_hip_update_esdf(fiesta_hip_map *m, fiesta_hip_stats *stats) {
+  return guarded([&] {
+    need(m != nullptr, "null map handle");
+    if (m->dense)
+      m->dense->update_esdf(stats);
+    else
+      m->hash->update_esdf(stats);
+  });
+}
+
+int fiesta_hip_get_distance_vox(fiesta_hip_map *m, const int32_t *vox, int64_t n, double *out) {
+  return guarded([&] {
+    need(m && (n == 0 || (vox && out)) && n >= 0, "bad argument");
+    if (m->dense)
+      m->dense->get_distance_vox(vox, n, out);
+    else
+      m->hash->get_distance_vox(vox, n, out);
+  });
+}
+int fiesta_hip_get_distance_pos(fiesta_hip_map *m, const double *pos, int64_t n, double *out) {
+  return guarded([&] {
+    need(m && (n == 0 || (pos && out)) && n >= 0, "bad argument");
+    if (m->dense)
+      m->dense->get_distance_pos(pos, n, out);
+    else
+      m->hash->get_distance_pos(pos, n, out);
+  });
+}
+int fiesta_hip_get_dist_grad(fiesta_hip_map *m, const double *pos, int64_t n, double *dist, double *grad) {
+  return guarded([&] {
+    need(m && (n == 0 || (pos && dist)) && n >= 0, "bad argument");
+    if (m->dense)
+      m->dense->get_dist_grad(pos, n, dist, grad, false);
+    else
+      m->hash->get_dist_grad(pos, n, dist, grad);
+  });
+}
+int fiesta_hip_get_dist_grad_dev(fiesta_hip_map *m, const double *pos_dev, int64_t n, double *dist_dev,
+                                 double *grad_dev) {
+  return guarded([&] {
+    need(m && (n == 0 || (pos_dev && dist_dev)) && n >= 0, "bad argument");
+    dense(m, "get_dist_grad_dev").get_dist_grad(pos_dev, n, dist_dev, grad_dev, true);
+  });
+}
+int fiesta_hip_get_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32_t *out) {
+  return guarded([&] {
+    need(m && (n == 0 || (vox && out)) && n >= 0, "bad argument");
+    if (m->dense)
+      m->dense->get_occupancy_vox(vox, n, out);
+    else
+      m->hash->get_occupancy_vox(vox, n, out);
+  });
+}
+int fiesta_hip_get_occupancy_pos(fiesta_hip_map *m, const double *pos, int64_t n, int32_t *out) {
+  return guarded([&] {
+    need(m && (n == 0 || (pos && out)) && n >= 0, "bad argument");
+    if (m->dense)
+      m->dense->get_occupancy_pos(pos, n, out);
+    else
+      m->hash->get_occupancy_pos(pos, n, out);
+  });
+}
+
+int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds) {
+  return guarded([&] { dense(m, "download_field").download_field(d2, coc, occ, logodds); });
+}
+int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
+                             uint8_t *occ) {
+  return guarded([&] {
+    need(m && n_out, "null argument");
+    if (!m->hash) throw Error(FIESTA_HIP_ERR_INVALID, "download_hash: only available on hash-mode maps");
+    *n_out = m->hash->download(vox, d2, coc, occ);
+  });
+}
+
+int fiesta_hip_snapshot_save(fiesta_hip_map *m, int32_t slot) {
+  return guarded([&] { dense(m, "snapshot_save").snapshot_save(slot); });
+}
+int fiesta_hip_snapshot_restore(fiesta_hip_map *m, int32_t slot) {
+  return guarded([&] { dense(m, "snapshot_restore").snapshot_restore(slot); });
+}
+int fiesta_hip_snapshot_count_updated(fiesta_hip_map *m, int32_t slot, int64_t *updated) {
+  return guarded([&] {
+    need(updated != nullptr, "null argument");
+    *updated = dense(m, "snapshot_count_updated").snapshot_count_updated(slot);
+  });
+}
+
+int fiesta_hip_halo_pack_dev(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], int32_t only_changed,
+                             uint32_t *entries_dev, int64_t capacity, int64_t *n_out) {
+  return guarded([&] {
+    need(lo && hi && n_out, "null argument");
+    *n_out = dense(m, "halo_pack").halo_pack(lo, hi, only_changed != 0, entries_dev, capacity);
+  });
+}
+int fiesta_hip_halo_apply_dev(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3],
+                              const uint32_t *entries_dev, int64_t n, int64_t *n_improved) {
+  return guarded([&] {
+    need(lo && hi, "null argument");
+    const int64_t k = dense(m, "halo_apply").halo_apply(lo, hi, entries_dev, n);
+    if (n_improved) *n_improved = k;
+  });
+}
+int fiesta_hip_relax_pending(fiesta_hip_map *m, fiesta_hip_stats *stats, int64_t *pending) {
+  return guarded([&] { dense(m, "relax_pending").relax_pending(stats, pending); });
+}
+
+int fiesta_hip_synchronize(fiesta_hip_map *m) {
+  return guarded([&] {
+    need(m != nullptr, "null map handle");
+    if (m->dense)
+      m->dense->synchronize();
+    else
+      m->hash->synchronize();
+  });
+}
+
+}  // extern "C"

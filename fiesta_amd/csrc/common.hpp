@@ -1,0 +1,104 @@
+// fiesta_amd/csrc/common.hpp -- shared host/device definitions of the gfx950 ESDF engine.
+//
+// Voxel state in HBM is ONE 32-bit word per voxel: the packed GLOBAL coordinates of the closest
+// obstacle (the reference's closest_obstacle_, include/ESDFMap.h:90). The reference's
+// distance_buffer_ (f64) is not stored: Dist() (src/ESDFMap.cpp:122-124) is a pure function of
+// (voxel, closest obstacle), so d^2 is recomputed in registers and a query returns
+// sqrt((double)d2) * resolution, which is bit-identical to the reference's value. The per-obstacle
+// doubly-linked lists (head_/prev_/next_) do not exist here at all -- see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace fiesta {
+
+// ---- voxel word encoding -------------------------------------------------------------------------
+//   bit 31 = 1 : no closest obstacle
+//        0xFFFFFFFF  never observed   (reference: distance_buffer_ == -10000)
+//        0x80000000  observed, no obstacle reached (reference: +10000, closest_obstacle_ undefined)
+//        0xC0000000  as above, and freshly invalidated by a delete (transient seed of the frontier)
+//   bit 31 = 0 : bits 29..0 = x<<20 | y<<10 | z of the closest obstacle (global voxel coordinates)
+//   bit 30     : ACT, "this voxel belongs to the frontier" -- a transient tag that is only ever set in
+//                HBM by the seeding kernels and consumed by the first relaxation round; inside LDS it is
+//                the per-sweep frontier bit.
+typedef uint32_t vox_t;
+constexpr vox_t kUnobserved = 0xFFFFFFFFu;
+constexpr vox_t kNoCoc = 0x80000000u;  // bit: word carries no obstacle
+constexpr vox_t kInf = 0x80000000u;
+constexpr vox_t kAct = 0x40000000u;
+constexpr vox_t kReset = kInf | kAct;
+constexpr int32_t kD2Inf = 0x7FFFFFFF;
+constexpr int kCoordBits = 10;
+constexpr int kMaxDim = 1 << kCoordBits;
+
+__host__ __device__ inline vox_t pack_coc(int x, int y, int z) {
+  return ((vox_t)x << 20) | ((vox_t)y << 10) | (vox_t)z;
+}
+__host__ __device__ inline void unpack_coc(vox_t c, int &x, int &y, int &z) {
+  x = (c >> 20) & 1023;
+  y = (c >> 10) & 1023;
+  z = c & 1023;
+}
+// squared voxel distance; exact in int32 (<= 3 * 1023^2)
+__host__ __device__ inline int32_t dist2(int x, int y, int z, vox_t c) {
+  const int dx = x - (int)((c >> 20) & 1023), dy = y - (int)((c >> 10) & 1023), dz = z - (int)(c & 1023);
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// The 24-direction stencil (include/parameters.h:54-68): 6 faces, 12 edges, 6 two-step faces.
+// Order is the reference's; it is irrelevant for the fixed point.
+#define FIESTA_STENCIL24(X)                                                                             \
+  X(-1, 0, 0) X(1, 0, 0) X(0, -1, 0) X(0, 1, 0) X(0, 0, -1) X(0, 0, 1) X(-1, -1, 0) X(1, 1, 0)          \
+  X(0, -1, -1) X(0, 1, 1) X(-1, 0, -1) X(1, 0, 1) X(-1, 1, 0) X(1, -1, 0) X(0, -1, 1) X(0, 1, -1)       \
+  X(1, 0, -1) X(-1, 0, 1) X(-2, 0, 0) X(2, 0, 0) X(0, -2, 0) X(0, 2, 0) X(0, 0, -2) X(0, 0, 2)
+
+// ---- geometry of one (shard of a) dense grid -------------------------------------------------------
+struct Geom {
+  int nx, ny, nz;     // local array extent (owned box + ghost layers when sharded)
+  int nzw;            // 32-bit words per z-row in the bitmaps = ceil(nz/32)
+  int64_t n;          // nx*ny*nz
+  int gx0, gy0, gz0;  // global coordinates of local voxel (0,0,0)
+  int ox0, oy0, oz0, ox1, oy1, oz1;  // owned box, local coords, inclusive (== whole array if unsharded)
+  int wx0, wy0, wz0, wx1, wy1, wz1;  // update window (VoxInRange), local coords, inclusive
+  int px0, py0, pz0, px1, py1, pz1;  // previous window (last_min_vec_/last_max_vec_)
+  double org[3], res, res_inv;
+  double lo[3], hi[3];  // min_range_/max_range_
+  __host__ __device__ inline int64_t idx(int x, int y, int z) const { return ((int64_t)x * ny + y) * nz + z; }
+  __host__ __device__ inline int64_t bitword(int x, int y, int z) const {
+    return ((int64_t)x * ny + y) * nzw + (z >> 5);
+  }
+  __host__ __device__ inline bool in_grid(int x, int y, int z) const {
+    return (unsigned)x < (unsigned)nx && (unsigned)y < (unsigned)ny && (unsigned)z < (unsigned)nz;
+  }
+  __host__ __device__ inline bool in_window(int x, int y, int z) const {
+    return x >= wx0 && x <= wx1 && y >= wy0 && y <= wy1 && z >= wz0 && z <= wz1;
+  }
+  __host__ __device__ inline bool in_prev_window(int x, int y, int z) const {
+    return x >= px0 && x <= px1 && y >= py0 && y <= py1 && z >= pz0 && z <= pz1;
+  }
+  __host__ __device__ inline bool owned(int x, int y, int z) const {
+    return x >= ox0 && x <= ox1 && y >= oy0 && y <= oy1 && z >= oz0 && z <= oz1;
+  }
+};
+
+struct ProbParams {
+  double l_hit, l_miss, l_min, l_max, l_occ;
+};
+
+// ---- errors -------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+#define FIESTA_HIP_CHECK(expr)                                                                          \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess)                                                                               \
+      throw ::fiesta::Error(_e == hipErrorOutOfMemory ? 3 : 2, std::string(#expr) + ": " +              \
+                                                                   hipGetErrorString(_e));              \
+  } while (0)
+
+}  // namespace fiesta

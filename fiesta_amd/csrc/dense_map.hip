@@ -1,0 +1,1073 @@
+// fiesta_amd/csrc/dense_map.hip -- gfx950 kernels + host driver of the dense-array incremental ESDF map.
+//
+// What replaces what (reference = HKUST-Aerial-Robotics/FIESTA, paths into its tree):
+//   SetOccupancy x2            src/ESDFMap.cpp:401-437  -> k_observe_vox / k_observe_pos (atomic counters,
+//                                                          first toucher appends to the touched list)
+//   UpdateOccupancy            src/ESDFMap.cpp:235-271  -> k_fuse (one lane per touched voxel)
+//   UpdateESDF                 src/ESDFMap.cpp:273-398  -> k_seed_insert, k_invalidate, k_relax rounds
+//   GetDistance/Trilinear/...  src/ESDFMap.cpp:452-540  -> k_query_*
+//
+// UpdateESDF, restated for a GPU.  The reference is a FIFO work-list algorithm: a voxel is put on the
+// queue when it is seeded (inserted obstacle, or orphaned by a delete) or when its distance improves; a
+// queued voxel first PULLS the closest obstacles of its 24 stencil neighbours and, if that did not help,
+// PUSHES its own closest obstacle to them.  Voxels that are never queued never change -- in particular a
+// freshly observed free voxel keeps distance "infinity" until a wave passes by.  The fixed point it
+// reaches is characterised by: every voxel v that was ever queued ("the frontier set R") ends with
+//     d(v) <= |v - coc(n)|   and   d(n) <= |n - coc(v)|      for all observed stencil neighbours n,
+// and voxels outside R keep their old state unless a member of R improves them.
+// Here the grid is cut into TX x TY x 32 tiles (z, the fastest axis of the reference's layout, is the
+// 32-lane axis).  A work-group stages one tile plus its 2-voxel halo (the stencil radius) in LDS,
+// carries one "frontier" bit per voxel next to the 30-bit packed obstacle, and runs Jacobi sweeps in
+// which voxel n evaluates candidate coc(v) only if v or n is on the frontier; an improved voxel is on
+// the next sweep's frontier.  When the tile is quiescent the changed words are written back, the
+// tile's members of R are recorded in a bitmap, and neighbouring tiles whose halo saw a frontier voxel
+// are appended to the next round's tile list (level-synchronous rounds, one launch per round).
+#include "dense_map.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace fiesta {
+
+// =====================================================================================================
+// small kernels
+// =====================================================================================================
+template <typename T>
+__global__ void k_fill(T *p, T v, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+__device__ inline bool occ_test(const uint32_t *occbits, const Geom &g, int x, int y, int z) {
+  return (occbits[g.bitword(x, y, z)] >> (z & 31)) & 1u;
+}
+
+// ---- SetOccupancy(Vector3i,int), PROBABILISTIC branch (src/ESDFMap.cpp:417-437) ----
+// vox are map (global) voxel coordinates. No validation of occ here: the reference's Vector3i overload
+// does none either.
+__global__ void k_observe_vox(Geom g, const int32_t *vox, const int32_t *occ, int64_t n,
+                              unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = vox[3 * i] - g.gx0, y = vox[3 * i + 1] - g.gy0, z = vox[3 * i + 2] - g.gz0;
+  if (!g.in_grid(x, y, z) || !g.in_window(x, y, z) || !g.owned(x, y, z)) return;  // VoxInRange (:420)
+  const int64_t idx = g.idx(x, y, z);
+  const unsigned long long add = ((unsigned long long)(uint32_t)occ[i] << 32) | 1ull;
+  const unsigned long long old = atomicAdd(&cnt[idx], add);
+  if ((uint32_t)old == 0) {  // num_miss_ became 1: first touch since the last fusion (:426)
+    const unsigned long long slot = atomicAdd(&counters[C_TOUCHED], 1ull);
+    touched[slot] = (uint32_t)idx;
+  }
+}
+
+// ---- SetOccupancy(Vector3d,int) (src/ESDFMap.cpp:401-415) ----
+__global__ void k_observe_pos(Geom g, const double *pos, const int32_t *occ, int64_t n,
+                              unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = occ[i];
+  if (o != 0 && o != 1) return;  // "occ value error!" (:402-405)
+  const double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+  if (px < g.lo[0] || py < g.lo[1] || pz < g.lo[2] || px > g.hi[0] || py > g.hi[1] || pz > g.hi[2]) return;
+  const int x = (int)floor((px - g.org[0]) / g.res) - g.gx0;  // Pos2Vox (:74-77)
+  const int y = (int)floor((py - g.org[1]) / g.res) - g.gy0;
+  const int z = (int)floor((pz - g.org[2]) / g.res) - g.gz0;
+  if (!g.in_grid(x, y, z) || !g.in_window(x, y, z) || !g.owned(x, y, z)) return;
+  const int64_t idx = g.idx(x, y, z);
+  const unsigned long long old = atomicAdd(&cnt[idx], ((unsigned long long)(uint32_t)o << 32) | 1ull);
+  if ((uint32_t)old == 0) {
+    const unsigned long long slot = atomicAdd(&counters[C_TOUCHED], 1ull);
+    touched[slot] = (uint32_t)idx;
+  }
+}
+
+// ---- UpdateOccupancy (src/ESDFMap.cpp:235-271): one lane per touched voxel ----
+__global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *touched, int64_t n,
+                       unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *ins,
+                       uint32_t *del, unsigned long long *counters) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t idx = touched[i];
+  const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
+  const unsigned long long c = cnt[idx];
+  cnt[idx] = 0;  // num_hit_ = num_miss_ = 0 (:245)
+  const int64_t hits = (int64_t)(int32_t)(c >> 32), seen = (int64_t)(uint32_t)c;
+  const double step = (hits >= seen - hits) ? pp.l_hit : pp.l_miss;  // majority vote (:243)
+  double L = logodds[idx];
+  const bool was = L > pp.l_occ;  // Exist (:16-22)
+  if (coc[idx] == kUnobserved) coc[idx] = kInf;  // first observation: -10000 -> +10000 (:246-249)
+  if ((step >= 0 && L >= pp.l_max) || (step <= 0 && L <= pp.l_min)) return;  // already clamped (:250-255)
+  if (!global_map && !g.in_prev_window(x, y, z)) {  // local-map reset (:256-259); see DESIGN.md
+    L = 0;
+    coc[idx] = kInf;
+  }
+  L = fmin(fmax(L + step, pp.l_min), pp.l_max);  // (:260-262)
+  logodds[idx] = L;
+  const bool now = L > pp.l_occ;
+  const uint32_t bit = 1u << (z & 31);
+  if (now && !was) {  // free -> occupied: insert_queue_ (:263-264)
+    atomicOr(&occbits[g.bitword(x, y, z)], bit);
+    ins[atomicAdd(&counters[C_INSERT], 1ull)] = idx;
+  } else if (!now && was) {  // occupied -> free: delete_queue_ (:265-266)
+    atomicAnd(&occbits[g.bitword(x, y, z)], ~bit);
+    del[atomicAdd(&counters[C_DELETE], 1ull)] = idx;
+  }
+}
+
+// =====================================================================================================
+// UpdateESDF
+// =====================================================================================================
+struct TileGrid {
+  int tx, ty;  // tile extent in x and y (z extent is 32)
+  int ntx, nty, ntz;
+  __device__ inline int tile_of(int x, int y, int z) const { return ((x / tx) * nty + (y / ty)) * ntz + (z >> 5); }
+};
+
+__device__ inline void activate_tile(uint32_t t, uint32_t *flag, uint32_t *list, unsigned long long *count) {
+  if (atomicExch(&flag[t], 1u) == 0u) list[atomicAdd(count, 1ull)] = t;
+}
+
+// Insert drain (src/ESDFMap.cpp:278-291): a queued voxel that is still occupied becomes its own closest
+// obstacle at distance 0 and joins the frontier (ACT tag, consumed by the first relaxation round).
+__global__ void k_seed_insert(Geom g, TileGrid tg, const uint32_t *ins, int64_t n, vox_t *coc,
+                              const uint32_t *occbits, uint32_t *flag, uint32_t *list, unsigned long long *count) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t idx = ins[i];
+  const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
+  if (!occ_test(occbits, g, x, y, z)) return;  // "Exist after a whole bunch of updates" (:282)
+  coc[idx] = pack_coc(x + g.gx0, y + g.gy0, z + g.gz0) | kAct;
+  activate_tile(tg.tile_of(x, y, z), flag, list, count);
+}
+
+// Delete drain (src/ESDFMap.cpp:292-337). The reference walks the vanished obstacle's linked list; with
+// no lists here, every voxel whose closest obstacle is no longer occupied is found by one coalesced scan
+// of the 4-byte state (the obstacle's occupancy bit is an L2-resident gather: neighbouring voxels point
+// at the same obstacle). Such a voxel is reset to "no obstacle" and tagged as frontier seed; its re-seed
+// from the neighbourhood (:308-321) is simply its first pull in k_relax.
+__global__ void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits, uint32_t *flag,
+                             uint32_t *list, unsigned long long *count, unsigned long long *counters) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    const vox_t w = coc[i];
+    if (w & kNoCoc) continue;
+    int cx, cy, cz;
+    unpack_coc(w, cx, cy, cz);
+    cx -= g.gx0;
+    cy -= g.gy0;
+    cz -= g.gz0;
+    // an obstacle that lives on another shard is invalidated by the halo protocol, not here
+    if (!g.in_grid(cx, cy, cz)) continue;
+    if (occ_test(occbits, g, cx, cy, cz)) continue;
+    const int z = i % g.nz, y = (i / g.nz) % g.ny, x = i / ((int64_t)g.nz * g.ny);
+    if (!g.owned(x, y, z)) continue;
+    coc[i] = kReset;
+    ++local;
+    activate_tile(tg.tile_of(x, y, z), flag, list, count);
+  }
+  if (local) atomicAdd(&counters[C_INVALIDATED], local);
+}
+
+struct RelaxArgs {
+  Geom g;
+  TileGrid tg;
+  vox_t *coc;
+  uint32_t *rbits;
+  uint32_t *tile_epoch;
+  uint32_t epoch;
+  const uint32_t *list_cur;
+  uint32_t n_cur;
+  uint32_t *flag_cur;
+  uint32_t *flag_next;
+  uint32_t *list_next;
+  unsigned long long *count_next;
+  unsigned long long *counters;
+};
+
+// One work-group relaxes one tile to local quiescence. 256 threads = 8 half-waves; a half-wave owns a
+// 32-voxel z-row (128 B in HBM, 32 consecutive LDS banks), so every stencil read is conflict-free.
+template <int TX, int TY>
+__global__ __launch_bounds__(256) void k_relax(RelaxArgs a) {
+  constexpr int TZ = 32, H = 2;
+  constexpr int RX = TX + 2 * H, RY = TY + 2 * H, RZ = TZ + 2 * H;
+  constexpr int RSIZE = RX * RY * RZ;
+  constexpr int ROWS = TX * TY;
+  constexpr int RPT = ROWS / 8;  // rows (= voxels) per thread
+  static_assert(ROWS % 8 == 0 && RPT <= 32, "tile shape");
+  __shared__ vox_t L[RSIZE];
+  __shared__ int nbr_dirty[27];
+
+  const Geom &g = a.g;
+  const int tid = threadIdx.x;
+  const int lz = tid & 31, slot = tid >> 5;
+
+  for (uint32_t li = blockIdx.x; li < a.n_cur; li += gridDim.x) {
+    const uint32_t t = a.list_cur[li];
+    const int tz = t % a.tg.ntz, ty = (t / a.tg.ntz) % a.tg.nty, tx = t / (a.tg.ntz * a.tg.nty);
+    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+    if (tid == 0) a.flag_cur[t] = 0;
+    if (tid < 27) nbr_dirty[tid] = 0;
+
+    // ---- stage tile + halo. Out-of-grid / out-of-window voxels become "unobserved": neither a source
+    //      nor a target (VoxInRange gates both the pull and the push, src/ESDFMap.cpp:351,378).
+    for (int i = tid; i < RSIZE; i += 256) {
+      const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
+      const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
+      vox_t w = kUnobserved;
+      if (g.in_grid(x, y, z) && g.in_window(x, y, z)) {
+        w = a.coc[g.idx(x, y, z)];
+        const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
+                              (unsigned)(rz - H) < (unsigned)TZ;
+        if (!interior && w != kUnobserved) {
+          // a halo voxel is a frontier source iff it joined the frontier earlier in THIS update
+          const uint32_t ot = a.tg.tile_of(x, y, z);
+          if (a.tile_epoch[ot] == a.epoch && ((a.rbits[g.bitword(x, y, z)] >> (z & 31)) & 1u)) w |= kAct;
+        }
+      }
+      L[i] = w;
+    }
+    __syncthreads();
+
+    // ---- per-thread bookkeeping for the voxels this thread owns
+    uint32_t updmask = 0, ever = 0;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int row = slot + 8 * r, lx = row / TY, ly = row % TY;
+      const vox_t w = L[((lx + H) * RY + (ly + H)) * RZ + (lz + H)];
+      if (w != kUnobserved && g.owned(x0 + lx, y0 + ly, z0 + lz)) {
+        updmask |= 1u << r;
+        if (w & kAct) ever |= 1u << r;
+      }
+    }
+
+    // ---- Jacobi sweeps with a frontier bit per voxel
+    vox_t res[RPT];
+    uint32_t nsweeps = 0;
+    bool first = true;
+    for (;;) {
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int row = slot + 8 * r, lx = row / TY, ly = row % TY;
+        const int c0 = ((lx + H) * RY + (ly + H)) * RZ + (lz + H);
+        const vox_t w = L[c0];
+        vox_t out = w;
+        if ((updmask >> r) & 1u) {
+          const bool selfact = (w & kAct) != 0;
+          const vox_t cur = w & ~kAct;
+          vox_t best = cur;
+          const int gx = g.gx0 + x0 + lx, gy = g.gy0 + y0 + ly, gz = g.gz0 + z0 + lz;
+          int32_t bestd = (cur & kNoCoc) ? kD2Inf : dist2(gx, gy, gz, cur);
+#define FIESTA_PULL(DX, DY, DZ)                                             \
+  {                                                                         \
+    const vox_t u = L[c0 + ((DX)*RY + (DY)) * RZ + (DZ)];                   \
+    if (!(u & kNoCoc) && (selfact || (u & kAct))) {                         \
+      const vox_t c = u & ~kAct;                                            \
+      if (c != best) {                                                      \
+        const int32_t d = dist2(gx, gy, gz, c);                             \
+        if (d < bestd) {                                                    \
+          bestd = d;                                                        \
+          best = c;                                                         \
+        }                                                                   \
+      }                                                                     \
+    }                                                                       \
+  }
+          FIESTA_STENCIL24(FIESTA_PULL)
+#undef FIESTA_PULL
+          const bool improved = best != cur;
+          out = improved ? (best | kAct) : cur;
+          if (improved) {
+            ever |= 1u << r;
+            any = true;
+          }
+        }
+        res[r] = out;
+      }
+      __syncthreads();  // every read of this sweep is done
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        if ((updmask >> r) & 1u) {
+          const int row = slot + 8 * r, lx = row / TY, ly = row % TY;
+          L[((lx + H) * RY + (ly + H)) * RZ + (lz + H)] = res[r];
+        }
+      }
+      if (first) {  // halo frontier bits have now been seen by everyone: retire them
+        for (int i = tid; i < RSIZE; i += 256) {
+          const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
+          const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
+                                (unsigned)(rz - H) < (unsigned)TZ;
+          if (!interior) {
+            const vox_t w = L[i];
+            if (w != kUnobserved && (w & kAct)) L[i] = w & ~kAct;
+          }
+        }
+        first = false;
+      }
+      ++nsweeps;
+      if (!__syncthreads_or(any)) break;
+    }
+
+    // ---- write back what changed, publish the tile's frontier members, wake the neighbours
+    const bool had_epoch = a.tile_epoch[t] == a.epoch;
+    uint32_t nwrites = 0;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int row = slot + 8 * r, lx = row / TY, ly = row % TY;
+      const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+      const bool e = (ever >> r) & 1u;
+      if (e) {  // (e implies updatable, hence in grid)
+        a.coc[g.idx(x, y, z)] = L[((lx + H) * RY + (ly + H)) * RZ + (lz + H)] & ~kAct;
+        ++nwrites;
+#define FIESTA_WAKE(DX, DY, DZ)                                                          \
+  {                                                                                      \
+    const int ox = (lx + (DX) < 0) ? -1 : ((lx + (DX) >= TX) ? 1 : 0);                   \
+    const int oy = (ly + (DY) < 0) ? -1 : ((ly + (DY) >= TY) ? 1 : 0);                   \
+    const int oz = (lz + (DZ) < 0) ? -1 : ((lz + (DZ) >= TZ) ? 1 : 0);                   \
+    if (ox | oy | oz) nbr_dirty[(ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)] = 1;             \
+  }
+        if (lx < H || lx >= TX - H || ly < H || ly >= TY - H || lz < H || lz >= TZ - H) {
+          FIESTA_STENCIL24(FIESTA_WAKE)
+        }
+#undef FIESTA_WAKE
+      }
+      const unsigned long long b = __ballot(e);
+      if (lz == 0 && x < g.nx && y < g.ny && z < g.nz) {
+        const uint32_t bits = (tid & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+        const int64_t wi = g.bitword(x, y, z);
+        a.rbits[wi] = had_epoch ? (a.rbits[wi] | bits) : bits;
+      }
+    }
+    // stats (one atomic per wave)
+    {
+      uint32_t v = nwrites;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if ((tid & 63) == 0 && v) atomicAdd(&a.counters[C_WRITES], (unsigned long long)v);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      a.tile_epoch[t] = a.epoch;
+      atomicAdd(&a.counters[C_SWEEPS], (unsigned long long)nsweeps);
+      atomicAdd(&a.counters[C_VISITS], 1ull);
+    }
+    if (tid < 27 && nbr_dirty[tid]) {
+      const int ox = tid / 9 - 1, oy = (tid / 3) % 3 - 1, oz = tid % 3 - 1;
+      const int ntx_ = tx + ox, nty_ = ty + oy, ntz_ = tz + oz;
+      if ((unsigned)ntx_ < (unsigned)a.tg.ntx && (unsigned)nty_ < (unsigned)a.tg.nty &&
+          (unsigned)ntz_ < (unsigned)a.tg.ntz)
+        activate_tile((ntx_ * a.tg.nty + nty_) * a.tg.ntz + ntz_, a.flag_next, a.list_next, a.count_next);
+    }
+    __syncthreads();  // L and nbr_dirty are reused by the next tile of this work-group
+  }
+}
+
+// =====================================================================================================
+// queries
+// =====================================================================================================
+__device__ inline double word_distance(const Geom &g, vox_t w, int x, int y, int z) {
+  // GetDistance(Vector3i) (src/ESDFMap.cpp:477-479): unobserved (-10000) reads as +10000
+  if (w & kNoCoc) return (double)FIESTA_HIP_INFINITY;
+  const int32_t d2 = dist2(x + g.gx0, y + g.gy0, z + g.gz0, w);
+  return sqrt((double)d2) * g.res;  // Dist (:122-124)
+}
+__device__ inline double vox_distance(const Geom &g, const vox_t *coc, int x, int y, int z) {
+  if (!g.in_grid(x, y, z)) return (double)FIESTA_HIP_INFINITY;  // the reference reads out of bounds here
+  return word_distance(g, coc[g.idx(x, y, z)] & ~kAct, x, y, z);
+}
+__device__ inline bool pos_in_map(const Geom &g, double px, double py, double pz) {  // PosInMap (:46-61)
+  return !(px < g.lo[0] || py < g.lo[1] || pz < g.lo[2] || px > g.hi[0] || py > g.hi[1] || pz > g.hi[2]);
+}
+
+__global__ void k_query_dist_vox(Geom g, const vox_t *coc, const int32_t *vox, int64_t n, double *out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = vox_distance(g, coc, vox[3 * i] - g.gx0, vox[3 * i + 1] - g.gy0, vox[3 * i + 2] - g.gz0);
+}
+__global__ void k_query_dist_pos(Geom g, const vox_t *coc, const double *pos, int64_t n, double *out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+  if (!pos_in_map(g, px, py, pz)) {
+    out[i] = (double)FIESTA_HIP_UNDEFINED;
+    return;
+  }
+  out[i] = vox_distance(g, coc, (int)floor((px - g.org[0]) / g.res) - g.gx0,
+                        (int)floor((py - g.org[1]) / g.res) - g.gy0, (int)floor((pz - g.org[2]) / g.res) - g.gz0);
+}
+// GetDistWithGradTrilinear (src/ESDFMap.cpp:481-540), same operation order in f64 (compiled with
+// -ffp-contract=off so no FMA contraction changes the last bit).
+__global__ void k_query_trilinear(Geom g, const vox_t *coc, const double *pos, int64_t n, double *dist,
+                                  double *grad) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  if (!pos_in_map(g, p[0], p[1], p[2])) {
+    dist[i] = -1;
+    if (grad) grad[3 * i] = grad[3 * i + 1] = grad[3 * i + 2] = 0;
+    return;
+  }
+  int b[3];
+  double f[3];
+  for (int k = 0; k < 3; ++k) {
+    const double pm = p[k] - 0.5 * g.res * 1.0;
+    b[k] = (int)floor((pm - g.org[k]) / g.res);
+    const double c = (b[k] + 0.5) * g.res + g.org[k];
+    f[k] = (p[k] - c) * g.res_inv;
+  }
+  double v[2][2][2];
+  for (int ix = 0; ix < 2; ++ix)
+    for (int iy = 0; iy < 2; ++iy)
+      for (int iz = 0; iz < 2; ++iz)
+        v[ix][iy][iz] = vox_distance(g, coc, b[0] + ix - g.gx0, b[1] + iy - g.gy0, b[2] + iz - g.gz0);
+  const double v00 = (1 - f[0]) * v[0][0][0] + f[0] * v[1][0][0];
+  const double v01 = (1 - f[0]) * v[0][0][1] + f[0] * v[1][0][1];
+  const double v10 = (1 - f[0]) * v[0][1][0] + f[0] * v[1][1][0];
+  const double v11 = (1 - f[0]) * v[0][1][1] + f[0] * v[1][1][1];
+  const double v0 = (1 - f[1]) * v00 + f[1] * v10;
+  const double v1 = (1 - f[1]) * v01 + f[1] * v11;
+  dist[i] = (1 - f[2]) * v0 + f[2] * v1;
+  if (grad) {
+    grad[3 * i + 2] = (v1 - v0) * g.res_inv;
+    grad[3 * i + 1] = ((1 - f[2]) * (v10 - v00) + f[2] * (v11 - v01)) * g.res_inv;
+    double gx = (1 - f[2]) * (1 - f[1]) * (v[1][0][0] - v[0][0][0]);
+    gx += (1 - f[2]) * f[1] * (v[1][1][0] - v[0][1][0]);
+    gx += f[2] * (1 - f[1]) * (v[1][0][1] - v[0][0][1]);
+    gx += f[2] * f[1] * (v[1][1][1] - v[0][1][1]);
+    grad[3 * i] = gx * g.res_inv;
+  }
+}
+// GetOccupancy x2 (src/ESDFMap.cpp:452-465)
+__global__ void k_query_occ_vox(Geom g, const uint32_t *occbits, const int32_t *vox, int64_t n, int32_t *out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = vox[3 * i] - g.gx0, y = vox[3 * i + 1] - g.gy0, z = vox[3 * i + 2] - g.gz0;
+  out[i] = g.in_grid(x, y, z) ? (int)occ_test(occbits, g, x, y, z) : 0;
+}
+__global__ void k_query_occ_pos(Geom g, const uint32_t *occbits, const double *pos, int64_t n, int32_t *out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+  if (!pos_in_map(g, px, py, pz)) {
+    out[i] = FIESTA_HIP_UNDEFINED;
+    return;
+  }
+  const int x = (int)floor((px - g.org[0]) / g.res) - g.gx0, y = (int)floor((py - g.org[1]) / g.res) - g.gy0,
+            z = (int)floor((pz - g.org[2]) / g.res) - g.gz0;
+  out[i] = g.in_grid(x, y, z) ? (int)occ_test(occbits, g, x, y, z) : 0;
+}
+
+// ---- whole-field export ----
+__global__ void k_export(Geom g, const vox_t *coc, const uint32_t *occbits, int32_t *d2, int32_t *cxyz,
+                         uint8_t *occ) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    const int z = i % g.nz, y = (i / g.nz) % g.ny, x = i / ((int64_t)g.nz * g.ny);
+    const vox_t w = coc[i];
+    if (d2) d2[i] = (w == kUnobserved) ? -1 : ((w & kNoCoc) ? kD2Inf : dist2(x + g.gx0, y + g.gy0, z + g.gz0, w));
+    if (cxyz) {
+      int cx = FIESTA_HIP_UNDEFINED, cy = FIESTA_HIP_UNDEFINED, cz = FIESTA_HIP_UNDEFINED;
+      if (!(w & kNoCoc)) unpack_coc(w, cx, cy, cz);
+      cxyz[3 * i] = cx;
+      cxyz[3 * i + 1] = cy;
+      cxyz[3 * i + 2] = cz;
+    }
+    if (occ) occ[i] = occ_test(occbits, g, x, y, z);
+  }
+}
+
+// "updated voxel" as SURVEY.md 8d defines it: d^2 differs, or the old closest obstacle vanished.
+__global__ void k_count_updated(Geom g, const vox_t *before, const vox_t *now, const uint32_t *occbits,
+                                unsigned long long *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    const vox_t a = before[i] & ~kAct, b = now[i] & ~kAct;
+    if (a == b) continue;
+    const int z = i % g.nz, y = (i / g.nz) % g.ny, x = i / ((int64_t)g.nz * g.ny);
+    const int gx = x + g.gx0, gy = y + g.gy0, gz = z + g.gz0;
+    const int32_t da = (a == kUnobserved) ? -1 : ((a & kNoCoc) ? kD2Inf : dist2(gx, gy, gz, a));
+    const int32_t db = (b == kUnobserved) ? -1 : ((b & kNoCoc) ? kD2Inf : dist2(gx, gy, gz, b));
+    bool upd = da != db;
+    if (!upd && !(a & kNoCoc)) {
+      int cx, cy, cz;
+      unpack_coc(a, cx, cy, cz);
+      cx -= g.gx0, cy -= g.gy0, cz -= g.gz0;
+      upd = g.in_grid(cx, cy, cz) && !occ_test(occbits, g, cx, cy, cz);
+    }
+    local += upd;
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static inline int grid_for(int64_t n, int block = 256, int cap = 1 << 20) {
+  int64_t b = (n + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+void DenseMap::use_device() const { FIESTA_HIP_CHECK(hipSetDevice(device_)); }
+
+DenseMap::DenseMap(const fiesta_hip_config &cfg) {
+  device_ = cfg.device;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    throw Error(FIESTA_HIP_ERR_DEVICE, "no HIP device available (this engine has no CPU fallback)");
+  if (device_ < 0 || device_ >= ndev) throw Error(FIESTA_HIP_ERR_INVALID, "device ordinal out of range");
+  use_device();
+  if (!(cfg.resolution > 0)) throw Error(FIESTA_HIP_ERR_INVALID, "resolution must be positive");
+  Geom &g = g_;
+  memset(&g, 0, sizeof(g));
+  g.res = cfg.resolution;
+  g.res_inv = 1 / cfg.resolution;  // src/ESDFMap.cpp:173
+  int gs[3];
+  for (int i = 0; i < 3; ++i) {
+    g.org[i] = cfg.origin[i];
+    gs[i] = (int)std::ceil(cfg.map_size[i] / cfg.resolution);  // src/ESDFMap.cpp:175-176
+    g.lo[i] = cfg.origin[i];
+    g.hi[i] = cfg.origin[i] + cfg.map_size[i];
+    if (gs[i] <= 0) throw Error(FIESTA_HIP_ERR_INVALID, "map_size must be positive");
+  }
+  const bool sharded = cfg.global_grid[0] > 0;
+  int gg[3];
+  for (int i = 0; i < 3; ++i) gg[i] = sharded ? cfg.global_grid[i] : gs[i];
+  for (int i = 0; i < 3; ++i)
+    if (gg[i] > kMaxDim)
+      throw Error(FIESTA_HIP_ERR_INVALID,
+                  "grid extent exceeds 1024 voxels per axis (32-bit closest-obstacle words, see DESIGN.md)");
+  g.nx = gs[0];
+  g.ny = gs[1];
+  g.nz = gs[2];
+  g.gx0 = sharded ? cfg.shard_lo[0] : 0;
+  g.gy0 = sharded ? cfg.shard_lo[1] : 0;
+  g.gz0 = sharded ? cfg.shard_lo[2] : 0;
+  g.n = (int64_t)g.nx * g.ny * g.nz;
+  if (g.n >= (1ll << 32)) throw Error(FIESTA_HIP_ERR_INVALID, "grid too large for 32-bit voxel indices");
+  g.nzw = (g.nz + 31) / 32;
+  g.ox0 = g.oy0 = g.oz0 = 0;
+  g.ox1 = g.nx - 1;
+  g.oy1 = g.ny - 1;
+  g.oz1 = g.nz - 1;
+  nbitwords_ = (int64_t)g.nx * g.ny * g.nzw;
+
+  switch (cfg.tile_shape) {
+    case 0:
+    case 1: tx_ = 8, ty_ = 8; break;
+    case 2: tx_ = 16, ty_ = 8; break;
+    case 3: tx_ = 16, ty_ = 16; break;
+    case 4: tx_ = 4, ty_ = 8; break;
+    default: throw Error(FIESTA_HIP_ERR_INVALID, "unknown tile_shape");
+  }
+  ntx_ = (g.nx + tx_ - 1) / tx_;
+  nty_ = (g.ny + ty_ - 1) / ty_;
+  ntz_ = (g.nz + 31) / 32;
+  ntiles_ = ntx_ * nty_ * ntz_;
+
+  FIESTA_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  FIESTA_HIP_CHECK(hipEventCreate(&ev0_));
+  FIESTA_HIP_CHECK(hipEventCreate(&ev1_));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&coc_, g.n * sizeof(vox_t)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&logodds_, g.n * sizeof(double)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&cnt_, g.n * sizeof(unsigned long long)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&occbits_, nbitwords_ * sizeof(uint32_t)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&rbits_, nbitwords_ * sizeof(uint32_t)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&tile_epoch_, ntiles_ * sizeof(uint32_t)));
+  for (int k = 0; k < 2; ++k) {
+    FIESTA_HIP_CHECK(hipMalloc((void **)&tile_flag_[k], ntiles_ * sizeof(uint32_t)));
+    FIESTA_HIP_CHECK(hipMalloc((void **)&tile_list_[k], ntiles_ * sizeof(uint32_t)));
+    FIESTA_HIP_CHECK(hipMemsetAsync(tile_flag_[k], 0, ntiles_ * sizeof(uint32_t), stream_));
+  }
+  FIESTA_HIP_CHECK(hipMalloc((void **)&counters_, C_COUNT * sizeof(unsigned long long)));
+  FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_counters_, C_COUNT * sizeof(unsigned long long)));
+  FIESTA_HIP_CHECK(hipMemsetAsync(counters_, 0, C_COUNT * sizeof(unsigned long long), stream_));
+  hipLaunchKernelGGL(k_fill<vox_t>, dim3(grid_for(g.n, 256, 4096)), dim3(256), 0, stream_, coc_, kUnobserved, g.n);
+  FIESTA_HIP_CHECK(hipMemsetAsync(logodds_, 0, g.n * sizeof(double), stream_));
+  FIESTA_HIP_CHECK(hipMemsetAsync(cnt_, 0, g.n * sizeof(unsigned long long), stream_));
+  FIESTA_HIP_CHECK(hipMemsetAsync(occbits_, 0, nbitwords_ * sizeof(uint32_t), stream_));
+  FIESTA_HIP_CHECK(hipMemsetAsync(rbits_, 0, nbitwords_ * sizeof(uint32_t), stream_));
+  FIESTA_HIP_CHECK(hipMemsetAsync(tile_epoch_, 0, ntiles_ * sizeof(uint32_t), stream_));
+  set_original_range();
+  pp_ = ProbParams{0, 0, 0, 0, 0};
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+DenseMap::~DenseMap() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  void *ptrs[] = {coc_,          logodds_,      cnt_,          occbits_,      rbits_,     tile_epoch_,
+                  tile_flag_[0], tile_flag_[1], tile_list_[0], tile_list_[1], counters_, stamp_occ_, stamp_free_};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h_counters_) (void)hipHostFree(h_counters_);
+  if (ev0_) (void)hipEventDestroy(ev0_);
+  if (ev1_) (void)hipEventDestroy(ev1_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void DenseMap::set_prob_params(double p_hit, double p_miss, double p_min, double p_max, double p_occ) {
+  auto logit = [](double x) { return std::log(x / (1 - x)); };  // Logit (src/ESDFMap.cpp:12-14)
+  pp_.l_hit = logit(p_hit);
+  pp_.l_miss = logit(p_miss);
+  pp_.l_min = logit(p_min);
+  pp_.l_max = logit(p_max);
+  pp_.l_occ = logit(p_occ);
+}
+
+void DenseMap::set_original_range() {  // SetOriginalRange (src/ESDFMap.cpp:812-824), array flavour
+  Geom &g = g_;
+  g.wx0 = g.wy0 = g.wz0 = 0;
+  g.wx1 = g.nx - 1;
+  g.wy1 = g.ny - 1;
+  g.wz1 = g.nz - 1;
+  g.px0 = g.wx0, g.py0 = g.wy0, g.pz0 = g.wz0;
+  g.px1 = g.wx1, g.py1 = g.wy1, g.pz1 = g.wz1;
+}
+
+void DenseMap::set_update_range(const double *mn, const double *mx, bool new_vec) {  // SetUpdateRange (:792-810)
+  Geom &g = g_;
+  double a[3], b[3];
+  for (int i = 0; i < 3; ++i) {
+    a[i] = std::max(mn[i], g.lo[i]);
+    b[i] = std::min(mx[i], g.hi[i]);
+  }
+  if (new_vec) {
+    g.px0 = g.wx0, g.py0 = g.wy0, g.pz0 = g.wz0;
+    g.px1 = g.wx1, g.py1 = g.wy1, g.pz1 = g.wz1;
+  }
+  auto p2v = [&](double p, int i) { return (int)std::floor((p - g.org[i]) / g.res); };
+  const int g0[3] = {g.gx0, g.gy0, g.gz0};
+  int lo[3], hi[3];
+  for (int i = 0; i < 3; ++i) {
+    lo[i] = p2v(a[i], i) - g0[i];
+    hi[i] = p2v(b[i] - g.res / 2, i) - g0[i];
+  }
+  g.wx0 = lo[0], g.wy0 = lo[1], g.wz0 = lo[2];
+  g.wx1 = hi[0], g.wy1 = hi[1], g.wz1 = hi[2];
+}
+
+unsigned long long DenseMap::read_counter(int which) {
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[which], &counters_[which], sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  return h_counters_[which];
+}
+void DenseMap::zero_counter(int which) {
+  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[which], 0, sizeof(unsigned long long), stream_));
+}
+
+void DenseMap::ensure_touched_capacity(int64_t extra) {
+  touched_upper_ = std::min<int64_t>(g_.n, touched_upper_ + extra);
+  if ((size_t)touched_upper_ > touched_.cap) {
+    // entries beyond the true count are garbage but harmless to copy
+    const size_t keep = touched_.cap;
+    touched_.ensure(std::min<size_t>((size_t)g_.n, std::max<size_t>((size_t)touched_upper_, 2 * touched_.cap)),
+                    stream_, keep);
+  }
+}
+
+void DenseMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret, bool dev) {
+  use_device();
+  if (n <= 0) return;
+  const Geom &g = g_;
+  const int32_t *dv = vox, *docc_in = occ;
+  if (!dev) {
+    stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
+    stage_b_.ensure(n * sizeof(int32_t), stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(stage_b_.p, occ, n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    dv = (const int32_t *)stage_a_.p;
+    docc_in = (const int32_t *)stage_b_.p;
+  }
+  ensure_touched_capacity(n);
+  hipLaunchKernelGGL(k_observe_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g, dv, docc_in, n, cnt_, touched_.p,
+                     counters_);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  if (ret && !dev) {  // what each SetOccupancy(Vector3i,int) call returns: Vox2Idx(vox) (:418,421,437)
+    const int gny = g.ny, gnz = g.nz;  // (shards report indices in their local array)
+    for (int64_t i = 0; i < n; ++i)
+      ret[i] = (vox[3 * i] - g.gx0) * (gny * gnz) + (vox[3 * i + 1] - g.gy0) * gnz + (vox[3 * i + 2] - g.gz0);
+  }
+  if (!dev) FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));  // staging buffers are reused
+}
+
+void DenseMap::observe_pos(const double *pos, const int32_t *occ, int64_t n, int32_t *ret) {
+  use_device();
+  if (n <= 0) return;
+  const Geom &g = g_;
+  stage_a_.ensure(n * 3 * sizeof(double), stream_);
+  stage_b_.ensure(n * sizeof(int32_t), stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_b_.p, occ, n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+  ensure_touched_capacity(n);
+  hipLaunchKernelGGL(k_observe_pos, dim3(grid_for(n)), dim3(256), 0, stream_, g, (const double *)stage_a_.p,
+                     (const int32_t *)stage_b_.p, n, cnt_, touched_.p, counters_);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  if (ret) {  // SetOccupancy(Vector3d,int) return value (:401-415)
+    for (int64_t i = 0; i < n; ++i) {
+      const double *p = pos + 3 * i;
+      if ((occ[i] != 0 && occ[i] != 1) || p[0] < g.lo[0] || p[1] < g.lo[1] || p[2] < g.lo[2] || p[0] > g.hi[0] ||
+          p[1] > g.hi[1] || p[2] > g.hi[2]) {
+        ret[i] = FIESTA_HIP_UNDEFINED;
+        continue;
+      }
+      const int x = (int)std::floor((p[0] - g.org[0]) / g.res) - g.gx0;
+      const int y = (int)std::floor((p[1] - g.org[1]) / g.res) - g.gy0;
+      const int z = (int)std::floor((p[2] - g.org[2]) / g.res) - g.gz0;
+      ret[i] = x * (g.ny * g.nz) + y * g.nz + z;
+    }
+  }
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+bool DenseMap::check_update() {  // CheckUpdate (src/ESDFMap.cpp:227-233)
+  use_device();
+  if (touched_upper_ == 0) return false;
+  return read_counter(C_TOUCHED) != 0;
+}
+
+bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
+  use_device();
+  unsigned long long nt = touched_upper_ ? read_counter(C_TOUCHED) : 0;
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
+  if (nt) {
+    ins_.ensure(ni + nt, stream_, ni);
+    del_.ensure(nd + nt, stream_, nd);
+    hipLaunchKernelGGL(k_fuse, dim3(grid_for((int64_t)nt)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
+                       (const uint32_t *)touched_.p, (int64_t)nt, cnt_, logodds_, coc_, occbits_, ins_.p, del_.p,
+                       counters_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    zero_counter(C_TOUCHED);
+    touched_upper_ = 0;
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    ni = h_counters_[C_INSERT];
+    nd = h_counters_[C_DELETE];
+  }
+  if (n_ins) *n_ins = (int64_t)ni;
+  if (n_del) *n_del = (int64_t)nd;
+  return ni != 0 || nd != 0;  // (:270)
+}
+
+void DenseMap::reset_stats_counters() {
+  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INVALIDATED], 0, (C_COUNT - C_INVALIDATED) * sizeof(unsigned long long),
+                                  stream_));
+}
+
+void DenseMap::collect_stats(fiesta_hip_stats *st) {
+  FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (st) {
+    st->invalidated = (int64_t)h_counters_[C_INVALIDATED];
+    st->sweeps = (int64_t)h_counters_[C_SWEEPS];
+    st->voxel_writes = (int64_t)h_counters_[C_WRITES];
+    st->tile_visits = (int64_t)h_counters_[C_VISITS];
+  }
+}
+
+template <int TX, int TY>
+static void launch_relax(const RelaxArgs &a, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((k_relax<TX, TY>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list) {
+  int cur = first_list;
+  uint32_t ncur = first_count;
+  int64_t rounds = 0;
+  TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
+  while (ncur) {
+    const int nxt = cur ^ 1;
+    zero_counter(C_LIST0 + nxt);
+    RelaxArgs a;
+    a.g = g_;
+    a.tg = tg;
+    a.coc = coc_;
+    a.rbits = rbits_;
+    a.tile_epoch = tile_epoch_;
+    a.epoch = epoch_;
+    a.list_cur = tile_list_[cur];
+    a.n_cur = ncur;
+    a.flag_cur = tile_flag_[cur];
+    a.flag_next = tile_flag_[nxt];
+    a.list_next = tile_list_[nxt];
+    a.count_next = &counters_[C_LIST0 + nxt];
+    a.counters = counters_;
+    const int blocks = (int)std::min<uint32_t>(ncur, 8192u);
+    if (tx_ == 8 && ty_ == 8)
+      launch_relax<8, 8>(a, blocks, stream_);
+    else if (tx_ == 16 && ty_ == 8)
+      launch_relax<16, 8>(a, blocks, stream_);
+    else if (tx_ == 16 && ty_ == 16)
+      launch_relax<16, 16>(a, blocks, stream_);
+    else
+      launch_relax<4, 8>(a, blocks, stream_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    ++rounds;
+    ncur = (uint32_t)read_counter(C_LIST0 + nxt);
+    cur = nxt;
+  }
+  if (st) st->rounds = rounds;
+}
+
+void DenseMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
+  use_device();
+  const auto h0 = std::chrono::steady_clock::now();
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  const unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
+  if (st) {
+    memset(st, 0, sizeof(*st));
+    st->inserted = (int64_t)ni;
+    st->deleted = (int64_t)nd;
+  }
+  if (ni == 0 && nd == 0) {
+    if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+    return;
+  }
+  ++epoch_;
+  TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
+  FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+  reset_stats_counters();
+  zero_counter(C_LIST0);
+  if (ni) {
+    hipLaunchKernelGGL(k_seed_insert, dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, g_, tg,
+                       (const uint32_t *)ins_.p, (int64_t)ni, coc_, (const uint32_t *)occbits_, tile_flag_[0],
+                       tile_list_[0], &counters_[C_LIST0]);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  if (nd) {
+    hipLaunchKernelGGL(k_invalidate, dim3(grid_for(g_.n, 256, 8192)), dim3(256), 0, stream_, g_, tg, coc_,
+                       (const uint32_t *)occbits_, tile_flag_[0], tile_list_[0], &counters_[C_LIST0], counters_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  zero_counter(C_INSERT);
+  zero_counter(C_DELETE);
+  const uint32_t n0 = (uint32_t)read_counter(C_LIST0);
+  run_rounds(st, n0, 0);
+  FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
+  collect_stats(st);
+  FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  if (st) {
+    float ms = 0;
+    FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    st->device_ms = ms;
+    st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+  }
+}
+
+void DenseMap::relax_pending(fiesta_hip_stats *st, int64_t *pending) {
+  use_device();
+  if (st) memset(st, 0, sizeof(*st));
+  reset_stats_counters();
+  const uint32_t n0 = (uint32_t)read_counter(C_LIST0);
+  if (pending) *pending = n0;
+  FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+  run_rounds(st, n0, 0);
+  zero_counter(C_LIST0);
+  FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
+  collect_stats(st);
+  FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  if (st) {
+    float ms = 0;
+    FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    st->device_ms = ms;
+  }
+}
+
+// ---- queries ----
+void DenseMap::get_distance_vox(const int32_t *vox, int64_t n, double *out) {
+  use_device();
+  if (n <= 0) return;
+  stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
+  stage_c_.ensure(n * sizeof(double), stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_query_dist_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
+                     (const int32_t *)stage_a_.p, n, (double *)stage_c_.p);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+void DenseMap::get_distance_pos(const double *pos, int64_t n, double *out) {
+  use_device();
+  if (n <= 0) return;
+  stage_a_.ensure(n * 3 * sizeof(double), stream_);
+  stage_c_.ensure(n * sizeof(double), stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_query_dist_pos, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
+                     (const double *)stage_a_.p, n, (double *)stage_c_.p);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+void DenseMap::get_dist_grad(const double *pos, int64_t n, double *dist, double *grad, bool dev) {
+  use_device();
+  if (n <= 0) return;
+  if (dev) {
+    hipLaunchKernelGGL(k_query_trilinear, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, pos, n,
+                       dist, grad);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  stage_a_.ensure(n * 3 * sizeof(double), stream_);
+  stage_b_.ensure(n * 3 * sizeof(double), stream_);
+  stage_c_.ensure(n * sizeof(double), stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_query_trilinear, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
+                     (const double *)stage_a_.p, n, (double *)stage_c_.p, (double *)stage_b_.p);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(dist, stage_c_.p, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  if (grad) FIESTA_HIP_CHECK(hipMemcpyAsync(grad, stage_b_.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+void DenseMap::get_occupancy_vox(const int32_t *vox, int64_t n, int32_t *out) {
+  use_device();
+  if (n <= 0) return;
+  stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
+  stage_c_.ensure(n * sizeof(int32_t), stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_query_occ_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
+                     (const int32_t *)stage_a_.p, n, (int32_t *)stage_c_.p);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+void DenseMap::get_occupancy_pos(const double *pos, int64_t n, int32_t *out) {
+  use_device();
+  if (n <= 0) return;
+  stage_a_.ensure(n * 3 * sizeof(double), stream_);
+  stage_c_.ensure(n * sizeof(int32_t), stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_query_occ_pos, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
+                     (const double *)stage_a_.p, n, (int32_t *)stage_c_.p);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void DenseMap::download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds) {
+  use_device();
+  const int64_t n = g_.n;
+  int32_t *dd2 = nullptr, *dc = nullptr;
+  uint8_t *docc = nullptr;
+  if (d2) {
+    stage_a_.ensure(n * sizeof(int32_t), stream_);
+    dd2 = (int32_t *)stage_a_.p;
+  }
+  if (coc) {
+    stage_b_.ensure(n * 3 * sizeof(int32_t), stream_);
+    dc = (int32_t *)stage_b_.p;
+  }
+  if (occ) {
+    stage_c_.ensure(n, stream_);
+    docc = (uint8_t *)stage_c_.p;
+  }
+  if (d2 || coc || occ) {
+    hipLaunchKernelGGL(k_export, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
+                       (const uint32_t *)occbits_, dd2, dc, docc);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  if (d2) FIESTA_HIP_CHECK(hipMemcpyAsync(d2, dd2, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+  if (coc) FIESTA_HIP_CHECK(hipMemcpyAsync(coc, dc, n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+  if (occ) FIESTA_HIP_CHECK(hipMemcpyAsync(occ, docc, n, hipMemcpyDeviceToHost, stream_));
+  if (logodds) FIESTA_HIP_CHECK(hipMemcpyAsync(logodds, logodds_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// ---- snapshots ----
+void DenseMap::snapshot_save(int slot) {
+  use_device();
+  if (slot < 0 || slot >= 4) throw Error(FIESTA_HIP_ERR_INVALID, "snapshot slot out of range");
+  Snapshot &s = snaps_[slot];
+  const int64_t n = g_.n;
+  FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  memcpy(s.counters, h_counters_, sizeof(s.counters));
+  s.coc.ensure(n, stream_);
+  s.logodds.ensure(n, stream_);
+  s.cnt.ensure(n, stream_);
+  s.occbits.ensure(nbitwords_, stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(s.coc.p, coc_, n * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(s.logodds.p, logodds_, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(s.cnt.p, cnt_, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(s.occbits.p, occbits_, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  const size_t nt = s.counters[C_TOUCHED], ni = s.counters[C_INSERT], nd = s.counters[C_DELETE];
+  if (nt) {
+    s.touched.ensure(nt, stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(s.touched.p, touched_.p, nt * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  if (ni) {
+    s.ins.ensure(ni, stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(s.ins.p, ins_.p, ni * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  if (nd) {
+    s.del.ensure(nd, stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(s.del.p, del_.p, nd * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  s.g = g_;
+  s.valid = true;
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void DenseMap::snapshot_restore(int slot) {
+  use_device();
+  if (slot < 0 || slot >= 4 || !snaps_[slot].valid) throw Error(FIESTA_HIP_ERR_STATE, "no such snapshot");
+  Snapshot &s = snaps_[slot];
+  const int64_t n = g_.n;
+  FIESTA_HIP_CHECK(hipMemcpyAsync(coc_, s.coc.p, n * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(logodds_, s.logodds.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(cnt_, s.cnt.p, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(occbits_, s.occbits.p, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  const size_t nt = s.counters[C_TOUCHED], ni = s.counters[C_INSERT], nd = s.counters[C_DELETE];
+  if (nt) {
+    touched_.ensure(nt, stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(touched_.p, s.touched.p, nt * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  if (ni) {
+    ins_.ensure(ni, stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(ins_.p, s.ins.p, ni * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  if (nd) {
+    del_.ensure(nd, stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(del_.p, s.del.p, nd * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  unsigned long long c[C_COUNT];
+  memcpy(c, s.counters, sizeof(c));
+  c[C_LIST0] = c[C_LIST1] = 0;
+  memcpy(h_counters_, c, sizeof(c));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
+  touched_upper_ = (int64_t)nt;
+  g_ = s.g;
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+int64_t DenseMap::snapshot_count_updated(int slot) {
+  use_device();
+  if (slot < 0 || slot >= 4 || !snaps_[slot].valid) throw Error(FIESTA_HIP_ERR_STATE, "no such snapshot");
+  zero_counter(C_SCRATCH);
+  hipLaunchKernelGGL(k_count_updated, dim3(grid_for(g_.n, 256, 8192)), dim3(256), 0, stream_, g_,
+                     (const vox_t *)snaps_[slot].coc.p, (const vox_t *)coc_, (const uint32_t *)occbits_,
+                     &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  return (int64_t)read_counter(C_SCRATCH);
+}
+
+int64_t DenseMap::halo_pack(const int32_t *, const int32_t *, bool, uint32_t *, int64_t) {
+  throw Error(FIESTA_HIP_ERR_INVALID, "halo exchange is not available in this build");
+}
+int64_t DenseMap::halo_apply(const int32_t *, const int32_t *, const uint32_t *, int64_t) {
+  throw Error(FIESTA_HIP_ERR_INVALID, "halo exchange is not available in this build");
+}
+
+void DenseMap::synchronize() {
+  use_device();
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+}  // namespace fiesta

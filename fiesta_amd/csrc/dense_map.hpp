@@ -1,0 +1,156 @@
+// fiesta_amd/csrc/dense_map.hpp -- dense-array ESDF map resident in HBM (host-side class).
+// Replaces the dense flavour of fiesta::ESDFMap (include/ESDFMap.h:37-166, src/ESDFMap.cpp).
+#pragma once
+#include <vector>
+
+#include "../../include/fiesta_hip.h"
+#include "common.hpp"
+
+namespace fiesta {
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  // Grow to at least n elements; optionally preserve the first `keep` elements.
+  void ensure(size_t n, hipStream_t s, size_t keep = 0) {
+    if (n <= cap) return;
+    size_t ncap = cap ? cap : 1024;
+    while (ncap < n) ncap *= 2;
+    T *q = nullptr;
+    FIESTA_HIP_CHECK(hipMalloc((void **)&q, ncap * sizeof(T)));
+    if (p && keep) FIESTA_HIP_CHECK(hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (p) {
+      FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+      (void)hipFree(p);
+    }
+    p = q;
+    cap = ncap;
+  }
+};
+
+// Device-side counters, one 64-bit word each.
+enum Counter {
+  C_TOUCHED = 0,   // length of the touched-voxel list (the reference's occupancy_queue_)
+  C_INSERT,        // insert_queue_
+  C_DELETE,        // delete_queue_
+  C_LIST0,         // active-tile list, even rounds
+  C_LIST1,         // active-tile list, odd rounds
+  C_INVALIDATED,   // stats
+  C_SWEEPS,
+  C_WRITES,
+  C_VISITS,
+  C_SCRATCH,
+  C_COUNT
+};
+
+struct Snapshot {
+  DevBuf<vox_t> coc;
+  DevBuf<double> logodds;
+  DevBuf<unsigned long long> cnt;
+  DevBuf<uint32_t> occbits;
+  DevBuf<uint32_t> touched, ins, del;
+  unsigned long long counters[C_COUNT];
+  Geom g;
+  bool valid = false;
+};
+
+class DenseMap {
+ public:
+  explicit DenseMap(const fiesta_hip_config &cfg);
+  ~DenseMap();
+
+  const Geom &geom() const { return g_; }
+  int64_t total() const { return g_.n; }
+
+  void set_prob_params(double p_hit, double p_miss, double p_min, double p_max, double p_occ);
+  void set_update_range(const double *mn, const double *mx, bool new_vec);
+  void set_original_range();
+
+  void observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret, bool dev);
+  void observe_pos(const double *pos, const int32_t *occ, int64_t n, int32_t *ret);
+
+  bool check_update();
+  bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
+  void update_esdf(fiesta_hip_stats *st);
+  // continue relaxing tiles that are already flagged (after ghost entries were applied)
+  void relax_pending(fiesta_hip_stats *st, int64_t *pending);
+
+  void get_distance_vox(const int32_t *vox, int64_t n, double *out);
+  void get_distance_pos(const double *pos, int64_t n, double *out);
+  void get_dist_grad(const double *pos, int64_t n, double *dist, double *grad, bool dev);
+  void get_occupancy_vox(const int32_t *vox, int64_t n, int32_t *out);
+  void get_occupancy_pos(const double *pos, int64_t n, int32_t *out);
+
+  void download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds);
+  void snapshot_save(int slot);
+  void snapshot_restore(int slot);
+  int64_t snapshot_count_updated(int slot);
+
+  int64_t halo_pack(const int32_t *lo, const int32_t *hi, bool only_changed, uint32_t *entries, int64_t cap);
+  int64_t halo_apply(const int32_t *lo, const int32_t *hi, const uint32_t *entries, int64_t n);
+
+  void synchronize();
+
+  // raycast front end (raycast.hip)
+  void raycast_frame(const float *points, int64_t n, const double *T, const double *origin,
+                     const fiesta_hip_raycast_params *p, bool dev);
+  void raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
+                     const double *T, const double *origin, const fiesta_hip_raycast_params *p);
+
+  hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
+
+ private:
+  void use_device() const;
+  unsigned long long read_counter(int which);
+  void zero_counter(int which);
+  void ensure_touched_capacity(int64_t extra);
+  void run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list);
+  void reset_stats_counters();
+  void collect_stats(fiesta_hip_stats *st);
+
+  Geom g_;
+  ProbParams pp_;
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+
+  // per-voxel state
+  vox_t *coc_ = nullptr;               // 4 B/voxel, hot
+  double *logodds_ = nullptr;          // 8 B/voxel, cold (occupancy_buffer_)
+  unsigned long long *cnt_ = nullptr;  // 8 B/voxel, cold: hits<<32 | observations (num_hit_/num_miss_)
+  uint32_t *occbits_ = nullptr;        // 1 bit/voxel: Exist(idx)
+  uint32_t *rbits_ = nullptr;          // 1 bit/voxel: voxel joined the frontier during the current update
+  int64_t nbitwords_ = 0;
+
+  // tiles
+  int tx_ = 8, ty_ = 8;  // tile extent in x,y (z extent is always 32)
+  int ntx_ = 0, nty_ = 0, ntz_ = 0, ntiles_ = 0;
+  uint32_t *tile_epoch_ = nullptr;
+  uint32_t *tile_flag_[2] = {nullptr, nullptr};
+  uint32_t *tile_list_[2] = {nullptr, nullptr};
+  uint32_t epoch_ = 0;
+
+  // queues
+  DevBuf<uint32_t> touched_, ins_, del_;
+  int64_t touched_upper_ = 0;  // host-side upper bound of C_TOUCHED
+  unsigned long long *counters_ = nullptr;
+  unsigned long long *h_counters_ = nullptr;  // pinned
+
+  // staging
+  DevBuf<unsigned char> stage_a_, stage_b_, stage_c_;
+  // raycast per-frame stamp arrays (Fiesta::set_occ_/set_free_, include/Fiesta.h:107-110), lazily allocated
+  uint32_t *stamp_occ_ = nullptr, *stamp_free_ = nullptr;
+  uint32_t frame_ = 0;
+
+  Snapshot snaps_[4];
+};
+
+}  // namespace fiesta

@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's operator API for the ESDF hot path.
+
+``ESDFMap`` keeps the public method names, argument meaning and error conventions of
+``class fiesta::ESDFMap`` (reference include/ESDFMap.h:111-166, src/ESDFMap.cpp) and forwards every
+call through the C ABI of ``libfiesta_hip.so`` (include/fiesta_hip.h) to the HIP kernels.  Methods
+accept either one voxel/position (scalar result, like the C++ class) or an (n,3) batch (array result);
+the batch form is the fast path.  The reference is compiled C++; the C++ facade with the identical
+class signature is include/fiesta/ESDFMap.h -- this module exists so that the parity tests and the
+bench read like the reference's own driver (test/test_ESDF_Map.cpp:42-104).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, FiestaHipError, RaycastParams, Stats, check
+
+UNDEFINED = -10000   # undefined_  (src/ESDFMap.cpp:182)
+INFINITY = 10000     # infinity_   (src/ESDFMap.cpp:181)
+D2_INF = 0x7FFFFFFF
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _d3(v):
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(3))
+
+
+class ESDFMap:
+    """Drop-in for ``fiesta::ESDFMap``; array mode by default, hash-block mode with ``mode="hash"``."""
+
+    def __init__(self, origin, resolution, map_size=None, reserve_size=0, mode="array", device=0,
+                 tile_shape=0, shard_lo=None, global_grid=None):
+        self._lib = _lib.load()
+        cfg = Config()
+        cfg.mode = 0 if mode == "array" else 1
+        cfg.device = int(device)
+        cfg.origin[:] = list(_d3(origin))
+        cfg.resolution = float(resolution)
+        cfg.map_size[:] = list(_d3(map_size if map_size is not None else (0, 0, 0)))
+        cfg.reserve_size = int(reserve_size)
+        cfg.tile_shape = int(tile_shape)
+        if shard_lo is not None:
+            cfg.shard_lo[:] = [int(v) for v in shard_lo]
+            cfg.global_grid[:] = [int(v) for v in global_grid]
+        self.mode = mode
+        self.resolution = float(resolution)
+        self.origin = _d3(origin)
+        self._h = C.c_void_p()
+        check(self._lib.fiesta_hip_create(C.byref(cfg), C.byref(self._h)))
+        gs = np.zeros(3, np.int32)
+        check(self._lib.fiesta_hip_grid_size(self._h, _p(gs)))
+        self.grid_size = tuple(int(v) for v in gs)
+        self.last_insert = self.last_delete = 0
+
+    # -- life cycle ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fiesta_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def grid_total_size_(self) -> int:  # public data member of the array build (include/ESDFMap.h:115)
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_grid_total_size(self._h, C.byref(n)))
+        return n.value
+
+    # -- parameters / window ------------------------------------------------------------------------
+    def SetParameters(self, p_hit, p_miss, p_min, p_max, p_occ):
+        check(self._lib.fiesta_hip_set_prob_params(self._h, p_hit, p_miss, p_min, p_max, p_occ))
+
+    def SetUpdateRange(self, min_pos, max_pos, new_vec=True):
+        check(self._lib.fiesta_hip_set_update_range(self._h, _p(_d3(min_pos)), _p(_d3(max_pos)), int(bool(new_vec))))
+
+    def SetOriginalRange(self):
+        check(self._lib.fiesta_hip_set_original_range(self._h))
+
+    # -- occupancy ingest ----------------------------------------------------------------------------
+    def SetOccupancy(self, where, occ, want_ret=True):
+        """SetOccupancy(Vector3i|Vector3d, int).  Integer input -> voxel overload, float -> position."""
+        a = np.asarray(where)
+        scalar = a.ndim == 1
+        if np.issubdtype(a.dtype, np.integer):
+            v = np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 3)
+            fn = self._lib.fiesta_hip_set_occupancy_vox
+        else:
+            v = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 3)
+            fn = self._lib.fiesta_hip_set_occupancy_pos
+        o = np.ascontiguousarray(np.broadcast_to(np.asarray(occ, dtype=np.int32), (len(v),)))
+        ret = np.empty(len(v), np.int32) if want_ret else None
+        check(fn(self._h, _p(v), _p(o), len(v), _p(ret)))
+        if ret is None:
+            return None
+        return int(ret[0]) if scalar else ret
+
+    def SetOccupancyDevice(self, vox_dev_ptr: int, occ_dev_ptr: int, n: int):
+        """Batch already resident in HBM (n x 3 int32 voxels, n int32 flags)."""
+        check(self._lib.fiesta_hip_set_occupancy_vox_dev(self._h, C.c_void_p(vox_dev_ptr), C.c_void_p(occ_dev_ptr), n))
+
+    def CheckUpdate(self) -> bool:
+        out = C.c_int32(0)
+        check(self._lib.fiesta_hip_check_update(self._h, C.byref(out)))
+        return bool(out.value)
+
+    def UpdateOccupancy(self, global_map=True) -> bool:
+        ni, nd, any_ = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        check(self._lib.fiesta_hip_update_occupancy(self._h, int(bool(global_map)), C.byref(ni), C.byref(nd),
+                                                    C.byref(any_)))
+        self.last_insert, self.last_delete = ni.value, nd.value
+        return bool(any_.value)
+
+    def UpdateESDF(self) -> dict:
+        st = Stats()
+        check(self._lib.fiesta_hip_update_esdf(self._h, C.byref(st)))
+        return st.as_dict()
+
+    # -- ray casting -----------------------------------------------------------------------------------
+    def RaycastFrame(self, points, transform, origin, min_ray_length, max_ray_length, l_cornor, r_cornor,
+                     dedup=1):
+        """One frame of Fiesta::RaycastProcess (include/Fiesta.h:194-278) on sensor-frame points."""
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        T = np.ascontiguousarray(transform, dtype=np.float64).reshape(16)
+        prm = RaycastParams(min_ray_length, max_ray_length, (C.c_double * 3)(*l_cornor),
+                            (C.c_double * 3)(*r_cornor), int(dedup), 0)
+        check(self._lib.fiesta_hip_raycast_frame(self._h, _p(pts), len(pts), _p(T), _p(_d3(origin)), C.byref(prm)))
+
+    def RaycastDepth(self, depth_mm, fx, fy, cx, cy, transform, origin, min_ray_length, max_ray_length,
+                     l_cornor, r_cornor, dedup=1):
+        """uint16 millimetre depth image -> points (include/Fiesta.h:341-351) -> ray cast, all on device."""
+        d = np.ascontiguousarray(depth_mm, dtype=np.uint16)
+        T = np.ascontiguousarray(transform, dtype=np.float64).reshape(16)
+        prm = RaycastParams(min_ray_length, max_ray_length, (C.c_double * 3)(*l_cornor),
+                            (C.c_double * 3)(*r_cornor), int(dedup), 0)
+        check(self._lib.fiesta_hip_raycast_depth(self._h, _p(d), d.shape[0], d.shape[1], fx, fy, cx, cy, _p(T),
+                                                 _p(_d3(origin)), C.byref(prm)))
+
+    # -- queries ------------------------------------------------------------------------------------------
+    def _query(self, where, fn_vox, fn_pos, out_dtype):
+        a = np.asarray(where)
+        scalar = a.ndim == 1
+        if np.issubdtype(a.dtype, np.integer):
+            v = np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 3)
+            fn = fn_vox
+        else:
+            v = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 3)
+            fn = fn_pos
+        out = np.empty(len(v), out_dtype)
+        check(fn(self._h, _p(v), len(v), _p(out)))
+        return out[0].item() if scalar else out
+
+    def GetDistance(self, where):
+        return self._query(where, self._lib.fiesta_hip_get_distance_vox, self._lib.fiesta_hip_get_distance_pos,
+                           np.float64)
+
+    def GetOccupancy(self, where):
+        return self._query(where, self._lib.fiesta_hip_get_occupancy_vox, self._lib.fiesta_hip_get_occupancy_pos,
+                           np.int32)
+
+    def GetDistWithGradTrilinear(self, pos):
+        a = np.asarray(pos, dtype=np.float64)
+        scalar = a.ndim == 1
+        v = np.ascontiguousarray(a).reshape(-1, 3)
+        dist = np.empty(len(v), np.float64)
+        grad = np.zeros((len(v), 3), np.float64)
+        check(self._lib.fiesta_hip_get_dist_grad(self._h, _p(v), len(v), _p(dist), _p(grad)))
+        return (float(dist[0]), grad[0]) if scalar else (dist, grad)
+
+    # -- whole field -----------------------------------------------------------------------------------------
+    def download_field(self, want=("d2", "coc", "occ", "logodds")):
+        n = self.grid_total_size_
+        d2 = np.empty(n, np.int32) if "d2" in want else None
+        coc = np.empty((n, 3), np.int32) if "coc" in want else None
+        occ = np.empty(n, np.uint8) if "occ" in want else None
+        lo = np.empty(n, np.float64) if "logodds" in want else None
+        check(self._lib.fiesta_hip_download_field(self._h, _p(d2), _p(coc), _p(occ), _p(lo)))
+        return {"d2": d2, "coc": coc, "occ": occ, "logodds": lo}
+
+    def download_hash(self):
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_download_hash(self._h, C.byref(n), None, None, None, None))
+        vox = np.empty((n.value, 3), np.int32)
+        d2 = np.empty(n.value, np.int32)
+        coc = np.empty((n.value, 3), np.int32)
+        occ = np.empty(n.value, np.uint8)
+        check(self._lib.fiesta_hip_download_hash(self._h, C.byref(n), _p(vox), _p(d2), _p(coc), _p(occ)))
+        return {"vox": vox, "d2": d2, "coc": coc, "occ": occ}
+
+    def distance_from_d2(self, d2):
+        """distance_buffer_ as the reference stores it: -10000 / +10000 sentinels, else sqrt(d2)*res."""
+        d2 = np.asarray(d2)
+        out = np.sqrt(np.maximum(d2, 0).astype(np.float64)) * self.resolution
+        out[d2 < 0] = UNDEFINED
+        out[d2 == D2_INF] = INFINITY
+        return out
+
+    def snapshot_save(self, slot=0):
+        check(self._lib.fiesta_hip_snapshot_save(self._h, slot))
+
+    def snapshot_restore(self, slot=0):
+        check(self._lib.fiesta_hip_snapshot_restore(self._h, slot))
+
+    def snapshot_count_updated(self, slot=0) -> int:
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_snapshot_count_updated(self._h, slot, C.byref(n)))
+        return n.value
+
+    def synchronize(self):
+        check(self._lib.fiesta_hip_synchronize(self._h))

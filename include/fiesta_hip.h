@@ -1,0 +1,194 @@
+/* fiesta_hip.h -- the drop-in boundary of the MI355X-native incremental ESDF engine.
+ *
+ * A plain C ABI (no C++ types, no HIP types, no torch types) exported by fiesta_amd/libfiesta_hip.so.
+ * The reference (HKUST-Aerial-Robotics/FIESTA) has no FFI/plugin layer: its operator API for this path IS
+ * the public section of `class fiesta::ESDFMap` (include/ESDFMap.h:111-166) plus the free function
+ * `Raycast` (include/raycast.h:16-18) and the per-frame driver `Fiesta::RaycastProcess`
+ * (include/Fiesta.h:194-278). Every entry point below names the reference interface it replaces; the C++
+ * facade include/fiesta/ESDFMap.h re-creates the reference's class on top of these calls, so a maintainer
+ * swaps the implementation file, not the callers.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = FIESTA_HIP_OK, otherwise an error code; the message of
+ *     the last failure on the calling thread is fiesta_hip_last_error(). Nothing throws across the ABI.
+ *   - "vox" arrays are n x 3 int32 (x,y,z voxel coordinates), "pos" arrays are n x 3 double (metres);
+ *     linear voxel index = x*Ny*Nz + y*Nz + z (src/ESDFMap.cpp:91), z fastest.
+ *   - pointers are HOST pointers unless the function name ends in _dev (device pointers on the map's GPU).
+ *   - one host thread drives one map (the reference is single-threaded by contract). All work of a map is
+ *     ordered on one HIP stream; calls return after the device work they need has completed unless stated.
+ *   - there is NO CPU fallback: if no gfx950 device is usable, fiesta_hip_create fails.
+ */
+#ifndef FIESTA_HIP_H
+#define FIESTA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIESTA_HIP_OK 0
+#define FIESTA_HIP_ERR_INVALID 1  /* bad argument / unsupported configuration */
+#define FIESTA_HIP_ERR_DEVICE 2   /* a HIP runtime call failed */
+#define FIESTA_HIP_ERR_NOMEM 3    /* device allocation failed */
+#define FIESTA_HIP_ERR_STATE 4    /* call sequence error */
+
+/* Reference sentinels (src/ESDFMap.cpp:181-182). */
+#define FIESTA_HIP_UNDEFINED (-10000)
+#define FIESTA_HIP_INFINITY 10000
+
+#define FIESTA_HIP_MODE_ARRAY 0 /* ESDFMap(origin,res,map_size)  src/ESDFMap.cpp:171  */
+#define FIESTA_HIP_MODE_HASH 1  /* ESDFMap(origin,res,reserve)   src/ESDFMap.cpp:130  (HASH_TABLE+BLOCK+BITWISE) */
+
+typedef struct fiesta_hip_map fiesta_hip_map; /* opaque */
+
+typedef struct fiesta_hip_config {
+  int32_t mode;         /* FIESTA_HIP_MODE_* (array vs hash is a RUNTIME choice here, a macro upstream) */
+  int32_t device;       /* HIP device ordinal */
+  double origin[3];     /* l_cornor_ / origin_ */
+  double resolution;    /* metres per voxel */
+  double map_size[3];   /* array mode: grid = ceil(map_size/resolution) (src/ESDFMap.cpp:175-176) */
+  int32_t reserve_size; /* hash mode: initial voxel reserve (src/ESDFMap.cpp:141-145) */
+  int32_t tile_shape;   /* 0 = default; engine tuning knob, results do not depend on it */
+  /* Spatial sharding. A map may be one shard of a larger global grid: it owns the global
+   * voxel box [shard_lo, shard_lo + grid) and stores closest-obstacle ids in GLOBAL coordinates. For an
+   * unsharded map leave these zero. */
+  int32_t shard_lo[3];
+  int32_t global_grid[3];
+} fiesta_hip_config;
+
+/* Counters of one UpdateESDF; the reference only prints its counters (src/ESDFMap.cpp:277,394). */
+typedef struct fiesta_hip_stats {
+  int64_t inserted;      /* insert-queue length at entry */
+  int64_t deleted;       /* delete-queue length at entry */
+  int64_t invalidated;   /* voxels reset because their closest obstacle vanished */
+  int64_t rounds;        /* level-synchronous frontier rounds */
+  int64_t tile_visits;   /* tiles relaxed, summed over rounds */
+  int64_t sweeps;        /* in-LDS relaxation sweeps, summed over tile visits */
+  int64_t voxel_writes;  /* voxel states written back to HBM (a voxel may be written in several rounds) */
+  double device_ms;      /* HIP-event time from first to last kernel of the update */
+  double host_ms;        /* wall time of the call */
+} fiesta_hip_stats;
+
+const char *fiesta_hip_last_error(void);
+int fiesta_hip_version(void);
+/* Number of usable gfx950 devices (0 on a box without a GPU; never an error). */
+int fiesta_hip_device_count(void);
+
+/* ---- life cycle: ESDFMap::ESDFMap / ~ESDFMap (include/ESDFMap.h:112-121) ---- */
+int fiesta_hip_create(const fiesta_hip_config *cfg, fiesta_hip_map **out);
+int fiesta_hip_destroy(fiesta_hip_map *m);
+/* array mode: grid_size_ and grid_total_size_ (include/ESDFMap.h:78,115); hash mode: allocated voxels. */
+int fiesta_hip_grid_size(fiesta_hip_map *m, int32_t out[3]);
+int fiesta_hip_grid_total_size(fiesta_hip_map *m, int64_t *out);
+
+/* ---- parameters and window ---- */
+/* ESDFMap::SetParameters (src/ESDFMap.cpp:218-224). */
+int fiesta_hip_set_prob_params(fiesta_hip_map *m, double p_hit, double p_miss, double p_min, double p_max,
+                               double p_occ);
+/* ESDFMap::SetUpdateRange (src/ESDFMap.cpp:792-810) / SetOriginalRange (:812-824). */
+int fiesta_hip_set_update_range(fiesta_hip_map *m, const double min_pos[3], const double max_pos[3],
+                                int new_vec);
+int fiesta_hip_set_original_range(fiesta_hip_map *m);
+
+/* ---- occupancy ingest: ESDFMap::SetOccupancy x2 (src/ESDFMap.cpp:401-437), batched ----
+ * Observations are applied as if SetOccupancy had been called once per entry; hit/total counters are
+ * accumulated with atomics so the order inside a batch is irrelevant. ret (nullable, host) receives what
+ * each individual call would have returned (the linear index, or FIESTA_HIP_UNDEFINED). */
+int fiesta_hip_set_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, const int32_t *occ, int64_t n,
+                                 int32_t *ret);
+int fiesta_hip_set_occupancy_pos(fiesta_hip_map *m, const double *pos, const int32_t *occ, int64_t n,
+                                 int32_t *ret);
+/* Same, inputs already resident in HBM; no return values, no host synchronisation. */
+int fiesta_hip_set_occupancy_vox_dev(fiesta_hip_map *m, const int32_t *vox_dev, const int32_t *occ_dev,
+                                     int64_t n);
+
+/* ---- ray casting: Raycast (src/raycast.cpp:56-158) + Fiesta::RaycastProcess (include/Fiesta.h:194-278) ---- */
+typedef struct fiesta_hip_raycast_params {
+  double min_ray_length, max_ray_length; /* parameters_.min/max_ray_length_ (src/parameters.cpp:9-10) */
+  double l_cornor[3], r_cornor[3];       /* ray clipping box in metres (parameters_.l_cornor_/r_cornor_) */
+  int32_t dedup;                         /* 1: per-frame de-dup of end points and free-space voxels with
+                                            the reference's early ray termination made order-independent
+                                            (see DESIGN.md); 0: every ray marks every voxel it crosses */
+  int32_t reserved;
+} fiesta_hip_raycast_params;
+/* One sensor frame: points are n x 3 float (sensor frame), transform the row-major 4x4 transform_,
+ * origin the raycast_origin_. Equivalent to RaycastMultithread with ray_cast_num_thread_ == 0. */
+int fiesta_hip_raycast_frame(fiesta_hip_map *m, const float *points, int64_t n, const double transform[16],
+                             const double origin[3], const fiesta_hip_raycast_params *p);
+int fiesta_hip_raycast_frame_dev(fiesta_hip_map *m, const float *points_dev, int64_t n,
+                                 const double transform[16], const double origin[3],
+                                 const fiesta_hip_raycast_params *p);
+/* Depth-image front end (pinhole part of Fiesta::DepthConversion, include/Fiesta.h:341-351): uint16
+ * millimetre depth, rows x cols, converted to sensor-frame points on the device, then ray cast. */
+int fiesta_hip_raycast_depth(fiesta_hip_map *m, const uint16_t *depth, int32_t rows, int32_t cols,
+                             double fx, double fy, double cx, double cy, const double transform[16],
+                             const double origin[3], const fiesta_hip_raycast_params *p);
+/* The free function Raycast itself, for one ray (voxel units); returns the voxel count in *n_out
+ * (FIESTA_HIP_ERR_INVALID if the reference would throw: more than 1500 voxels). out is cap x 3 doubles. */
+int fiesta_hip_raycast_single(const double start[3], const double end[3], const double minv[3],
+                              const double maxv[3], double *out, int32_t cap, int32_t *n_out, int32_t device);
+
+/* ---- occupancy fusion and the ESDF update ---- */
+/* ESDFMap::CheckUpdate (src/ESDFMap.cpp:227-233): *out = 1 iff some voxel was observed since the last
+ * UpdateOccupancy. */
+int fiesta_hip_check_update(fiesta_hip_map *m, int32_t *out);
+/* ESDFMap::UpdateOccupancy (src/ESDFMap.cpp:235-271). n_insert/n_delete (nullable) receive the lengths of
+ * the insert and delete queues after the call, *any (nullable) the reference's bool return value. */
+int fiesta_hip_update_occupancy(fiesta_hip_map *m, int32_t global_map, int64_t *n_insert, int64_t *n_delete,
+                                int32_t *any);
+/* ESDFMap::UpdateESDF (src/ESDFMap.cpp:273-398). stats is nullable. */
+int fiesta_hip_update_esdf(fiesta_hip_map *m, fiesta_hip_stats *stats);
+
+/* ---- queries, batched ---- */
+/* ESDFMap::GetDistance(Vector3i) (src/ESDFMap.cpp:477-479); out-of-grid voxels read as +10000. */
+int fiesta_hip_get_distance_vox(fiesta_hip_map *m, const int32_t *vox, int64_t n, double *out);
+/* ESDFMap::GetDistance(Vector3d) (:467-475): -10000 outside the map. */
+int fiesta_hip_get_distance_pos(fiesta_hip_map *m, const double *pos, int64_t n, double *out);
+/* ESDFMap::GetDistWithGradTrilinear (:481-540): dist -1 outside the map; grad is n x 3. */
+int fiesta_hip_get_dist_grad(fiesta_hip_map *m, const double *pos, int64_t n, double *dist, double *grad);
+/* ESDFMap::GetOccupancy x2 (:452-465). */
+int fiesta_hip_get_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32_t *out);
+int fiesta_hip_get_occupancy_pos(fiesta_hip_map *m, const double *pos, int64_t n, int32_t *out);
+/* Device-resident query: pos_dev n x 3 double, dist_dev n double, grad_dev n x 3 double (nullable). */
+int fiesta_hip_get_dist_grad_dev(fiesta_hip_map *m, const double *pos_dev, int64_t n, double *dist_dev,
+                                 double *grad_dev);
+
+/* ---- whole-field access (tests, visualisation, checkpoints) ----
+ * Dense dump in the reference's linear order; each output is nullable.
+ *   d2      int32  squared voxel distance to the closest obstacle; -1 never observed; INT32_MAX observed
+ *                  but no obstacle reachable. distance_buffer_ == sqrt(d2) * resolution.
+ *   coc     3 x int32 closest_obstacle_ (global voxel coordinates; -10000 undefined)
+ *   occ     uint8  Exist(idx)
+ *   logodds double occupancy_buffer_ */
+int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds);
+/* Hash mode: allocated voxels in allocation order (vox n x 3); with all outputs NULL only *n_out is set. */
+int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
+                             uint8_t *occ);
+
+/* Device-side snapshots of the complete map state (benchmark repetitions, tests). slot in [0,3]. */
+int fiesta_hip_snapshot_save(fiesta_hip_map *m, int32_t slot);
+int fiesta_hip_snapshot_restore(fiesta_hip_map *m, int32_t slot);
+/* Number of voxels whose (d2, closest obstacle) differs between snapshot `slot` and the current state,
+ * counted as SURVEY.md 8d defines an "updated voxel": d2 differs, or the old closest obstacle is no longer
+ * occupied. */
+int fiesta_hip_snapshot_count_updated(fiesta_hip_map *m, int32_t slot, int64_t *updated);
+
+/* ---- multi-GPU halo exchange; used by the sharded driver ----
+ * A shard owns its box plus a 2-voxel ghost layer. After a local UpdateESDF the driver packs the owned
+ * boundary voxels that changed, sends them to the neighbouring ranks (RCCL via torch.distributed), and
+ * applies received entries into the ghost layer, which re-activates the adjacent tiles. Entries are
+ * 2 x uint32: {global linear-in-box index of the voxel, packed closest obstacle}. */
+int fiesta_hip_halo_pack_dev(fiesta_hip_map *m, const int32_t box_lo[3], const int32_t box_hi[3],
+                             int32_t only_changed, uint32_t *entries_dev, int64_t capacity, int64_t *n_out);
+int fiesta_hip_halo_apply_dev(fiesta_hip_map *m, const int32_t box_lo[3], const int32_t box_hi[3],
+                              const uint32_t *entries_dev, int64_t n, int64_t *n_improved);
+/* Continue relaxation after ghost entries were applied (no queues consumed). */
+int fiesta_hip_relax_pending(fiesta_hip_map *m, fiesta_hip_stats *stats, int64_t *pending_tiles);
+
+/* Blocks until all device work of the map has finished. */
+int fiesta_hip_synchronize(fiesta_hip_map *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIESTA_HIP_H */

