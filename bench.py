@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native incremental ESDF engine.
+
+Metric (BASELINE.json): ESDF updated-voxels/sec (+ UpdateESDF p50 latency) on the 512^3 dense grid with a
+50k-voxel insert+delete delta.  A *step* is one full pass of the hot path over one synthetic batch whose
+inputs are already resident in HBM:
+
+    2 x { SetOccupancy(new 25k, hit) ; UpdateOccupancy }                       (log-odds need 3 hits)
+    1 x { SetOccupancy(new 25k, hit) + SetOccupancy(oldest 25k, miss) ; UpdateOccupancy }   -> 25k inserts + 25k deletes
+    UpdateESDF()                                                               <- the 50k-voxel delta lands here
+
+on top of a fully observed 512^3 map that holds 50k scattered obstacle voxels (scene A of SURVEY.md 8d);
+the obstacle population is stationary (oldest 25k leave, 25k new arrive each step).  `value` = voxels
+whose (d^2, closest obstacle) changed, summed over the K timed steps, divided by the wall time of the K
+steps (barrier + synchronize on both sides, max over ranks).  The updated-voxel counts come from an
+identical *untimed* replay of the same K steps from a device snapshot (the diff kernel would otherwise sit
+inside the timed region).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel k_relax: algorithmic bytes (16 B per updated voxel) over the
+                sum of its launch durations, measured live with HIP events on the map's own stream.
+  cpu_baseline  the CPU oracle (verbatim-compiled reference when oracle/_ref is present, else the pinned
+                restatement) timed on one host core on a bounded sample of the same workload (same obstacle
+                density on a 192^3 grid); rank 0, N=1 only.  A reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+P_DEFAULT = (0.70, 0.35, 0.12, 0.97, 0.80)  # src/parameters.cpp:28-32
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+ALGO_BYTES_PER_UPDATED_VOXEL = 16           # read 8 B + write 8 B of {d^2:int32, coc:int32}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--obstacles", type=int, default=50000)
+    ap.add_argument("--tile-shape", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-grid", type=int, default=192)
+    return ap.parse_args()
+
+
+class Workload:
+    """Deterministic stationary scatter workload: `n_obs` live obstacle voxels, half replaced per step."""
+
+    def __init__(self, grid, n_obs, seed=12345):
+        self.grid, self.n_obs, self.half = grid, n_obs, n_obs // 2
+        self.rng = np.random.RandomState(seed)
+        self.live = self._fresh(n_obs, set())
+        self.step_id = 0
+
+    def _fresh(self, k, taken):
+        out = []
+        seen = set(taken)
+        while len(out) < k:
+            c = self.rng.randint(0, self.grid, (k - len(out), 3))
+            for v in map(tuple, c):
+                if v not in seen:
+                    seen.add(v)
+                    out.append(v)
+        return np.array(out, dtype=np.int32)
+
+    def initial(self):
+        return self.live.copy()
+
+    def next_step(self):
+        """(new voxels to occupy, old voxels to free); the oldest half leaves."""
+        old = self.live[: self.half]
+        keep = self.live[self.half:]
+        new = self._fresh(self.half, set(map(tuple, self.live)))
+        self.live = np.concatenate([keep, new])
+        self.step_id += 1
+        return new, old.copy()
+
+
+def run_cpu_baseline(args):
+    """The oracle on one host core, same obstacle density on a smaller grid, one steady-state step timed."""
+    from oracle import pyoracle
+    pyoracle.build("port")
+    kind = "ref" if pyoracle.available("ref", "array") else "port"
+    g = args.cpu_grid
+    n_obs = max(2, int(round(args.obstacles * (g / args.grid) ** 3)))
+    res = 0.1
+    m = pyoracle.OracleMap((0, 0, 0), res, ((g - 0.5) * res,) * 3, kind=kind)  # ceil() rounding, SURVEY 7.3-G
+    assert m.grid_total_size == g ** 3
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    idx = np.arange(g ** 3, dtype=np.int64)
+    allv = np.stack([idx // (g * g), (idx // g) % g, idx % g], -1).astype(np.int32)
+    m.SetOccupancyVox(allv, 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    w = Workload(g, n_obs)
+    for _ in range(3):
+        m.SetOccupancyVox(w.initial(), 1)
+        m.UpdateOccupancy(True)
+    st_scatter = m.UpdateESDF()
+    before = m.dump_dense(("dist", "coc", "occ"))
+    new, old = w.next_step()
+    for c in range(3):
+        m.SetOccupancyVox(new, 1)
+        if c == 2:
+            m.SetOccupancyVox(old, 0)
+        m.UpdateOccupancy(True)
+    st = m.UpdateESDF()
+    after = m.dump_dense(("dist", "coc", "occ"))
+    changed = before["dist"] != after["dist"]
+    bc = before["coc"].astype(np.int64)
+    has = bc[:, 0] >= 0
+    lin = (bc[:, 0] * g + bc[:, 1]) * g + bc[:, 2]
+    gone = np.zeros(len(lin), bool)
+    gone[has] = after["occ"][lin[has]] == 0
+    updated = int((changed | gone).sum())
+    m.close()
+    return {
+        "value": updated / st["seconds"], "unit": "voxels/s", "cores": 1, "kind": "reference" if kind == "ref" else "port",
+        "sample": f"{g}^3 grid at the same obstacle density ({n_obs} obstacles), one steady-state UpdateESDF "
+                  f"({st['inserted']} inserts + {st['deleted']} deletes, {updated} updated voxels, {st['seconds']:.3f} s); "
+                  f"full scatter insert of the sample: {g ** 3} voxels in {st_scatter['seconds']:.3f} s",
+        "update_esdf_s": st["seconds"], "updated_voxels": updated, "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import fiesta_amd
+
+    if not torch.cuda.is_available() or fiesta_amd.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    G, res = args.grid, 0.1
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, device=local_rank, tile_shape=args.tile_shape)
+    assert m.grid_total_size_ == G ** 3, "grid rounding (SURVEY.md 7.3-G)"
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+
+    def dev_batch(vox, occ):
+        v = torch.from_numpy(np.ascontiguousarray(vox, dtype=np.int32)).to(dev)
+        o = torch.from_numpy(np.ascontiguousarray(occ, dtype=np.int32)).to(dev)
+        return v, o
+
+    def observe(batch):
+        v, o = batch
+        m.SetOccupancyDevice(v.data_ptr(), o.data_ptr(), v.shape[0])
+
+    # ---- prologue: observe every voxel free once (nothing propagates through unobserved voxels)
+    chunk = 64
+    for x0 in range(0, G, chunk):
+        xs = torch.arange(x0, min(G, x0 + chunk), device=dev, dtype=torch.int32)
+        ys = torch.arange(G, device=dev, dtype=torch.int32)
+        zs = torch.arange(G, device=dev, dtype=torch.int32)
+        v = torch.stack(torch.meshgrid(xs, ys, zs, indexing="ij"), -1).reshape(-1, 3).contiguous()
+        o = torch.zeros(v.shape[0], dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        m.SetOccupancyDevice(v.data_ptr(), o.data_ptr(), v.shape[0])
+        m.synchronize()
+        del v, o
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+
+    # ---- scene A: scatter insert of all obstacles into the empty observed grid (reported, not the step)
+    w = Workload(G, args.obstacles, seed=12345 + 1000 * rank)
+    init = dev_batch(w.initial(), np.ones(args.obstacles, np.int32))
+    for _ in range(3):
+        observe(init)
+        m.UpdateOccupancy(True)
+    m.snapshot_save(0)
+    st_scatter = m.UpdateESDF()
+    scatter_updated = m.snapshot_count_updated(0)
+
+    # ---- pre-stage every step's input in HBM
+    nsteps = args.warmup + args.steps
+    staged = []
+    for _ in range(nsteps):
+        new, old = w.next_step()
+        hits = dev_batch(new, np.ones(len(new), np.int32))
+        both = dev_batch(np.concatenate([new, old]), np.concatenate([np.ones(len(new), np.int32), np.zeros(len(old), np.int32)]))
+        staged.append((hits, both))
+    torch.cuda.synchronize()
+
+    def step(k, account=False):
+        hits, both = staged[k]
+        observe(hits)
+        m.UpdateOccupancy(True)
+        observe(hits)
+        m.UpdateOccupancy(True)
+        observe(both)
+        m.UpdateOccupancy(True)
+        if account:
+            m.snapshot_save(2)
+        st = m.UpdateESDF()
+        if account:
+            st["updated"] = m.snapshot_count_updated(2)
+        return st
+
+    for k in range(args.warmup):
+        step(k)
+    m.snapshot_save(1)
+
+    # ---- timed region: exactly K steps
+    m.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    timed = [step(args.warmup + k) for k in range(args.steps)]
+    m.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- untimed accounting replay of the same K steps
+    m.snapshot_restore(1)
+    replay = [step(args.warmup + k, account=True) for k in range(args.steps)]
+    updated = [r["updated"] for r in replay]
+    total_updated = float(sum(updated))
+    if dist:
+        t = torch.tensor([total_updated], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_updated = float(t.item())
+
+    if rank == 0:
+        relax_ms = sum(s["relax_ms"] for s in timed)
+        launches = sum(s["relax_launches"] for s in timed)
+        my_updated = float(sum(updated))
+        achieved = my_updated * ALGO_BYTES_PER_UPDATED_VOXEL / (relax_ms * 1e-3) / 1e9 if relax_ms > 0 else 0.0
+        out = {
+            "metric": "esdf_updated_voxels_per_sec",
+            "value": total_updated / elapsed,
+            "unit": "voxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: {G}^3 dense-array grid @0.1 m fully observed, {args.obstacles} scattered obstacle voxels, "
+                            f"per step a {args.obstacles}-voxel delta = {args.obstacles // 2} inserts + {args.obstacles // 2} deletes "
+                            "landing in one UpdateESDF (ingest: 3 SetOccupancy+UpdateOccupancy cycles, inputs resident in HBM)",
+                "grid": [G, G, G], "delta_voxels": args.obstacles,
+                "parallelism": "single GPU" if world == 1 else f"{world} independent map replicas (one per GPU)",
+                "tile_shape": args.tile_shape,
+            },
+            "update_esdf_p50_ms": statistics.median(s["host_ms"] for s in timed),
+            "update_esdf_device_p50_ms": statistics.median(s["device_ms"] for s in timed),
+            "updated_voxels_per_step": my_updated / args.steps,
+            "update_esdf_voxels_per_sec": my_updated / (sum(s["host_ms"] for s in timed) * 1e-3),
+            "rounds_per_update": statistics.mean(s["rounds"] for s in timed),
+            "scatter_full_update": {"updated_voxels": scatter_updated, "device_ms": st_scatter["device_ms"],
+                                    "host_ms": st_scatter["host_ms"], "rounds": st_scatter["rounds"],
+                                    "relax_ms": st_scatter["relax_ms"],
+                                    "voxels_per_sec": scatter_updated / (st_scatter["host_ms"] * 1e-3),
+                                    "roofline_frac": scatter_updated * 16 / (st_scatter["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "roofline": {
+                "bound": "hbm", "kernel": "k_relax", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launches": launches, "avg_launch_us": relax_ms * 1e3 / max(1, launches),
+                "algorithmic_bytes_per_launch": my_updated * ALGO_BYTES_PER_UPDATED_VOXEL / max(1, launches),
+                "frac_of_measured_copy_6.29TBs": achieved / 6290.0,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = run_cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    m.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -600,11 +600,13 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
 DenseMap::~DenseMap() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  free_raycast_state();
   void *ptrs[] = {coc_,          logodds_,      cnt_,          occbits_,      rbits_,     tile_epoch_,
-                  tile_flag_[0], tile_flag_[1], tile_list_[0], tile_list_[1], counters_, stamp_occ_, stamp_free_};
+                  tile_flag_[0], tile_flag_[1], tile_list_[0], tile_list_[1], counters_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
+  for (hipEvent_t e : evpool_) (void)hipEventDestroy(e);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -780,6 +782,15 @@ static void launch_relax(const RelaxArgs &a, int blocks, hipStream_t s) {
   hipLaunchKernelGGL((k_relax<TX, TY>), dim3(blocks), dim3(256), 0, s, a);
 }
 
+hipEvent_t DenseMap::pool_event(size_t i) {
+  while (evpool_.size() <= i) {
+    hipEvent_t e;
+    FIESTA_HIP_CHECK(hipEventCreate(&e));
+    evpool_.push_back(e);
+  }
+  return evpool_[i];
+}
+
 void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list) {
   int cur = first_list;
   uint32_t ncur = first_count;
@@ -803,6 +814,7 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     a.count_next = &counters_[C_LIST0 + nxt];
     a.counters = counters_;
     const int blocks = (int)std::min<uint32_t>(ncur, 8192u);
+    FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
     if (tx_ == 8 && ty_ == 8)
       launch_relax<8, 8>(a, blocks, stream_);
     else if (tx_ == 16 && ty_ == 8)
@@ -812,11 +824,22 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     else
       launch_relax<4, 8>(a, blocks, stream_);
     FIESTA_HIP_CHECK(hipGetLastError());
+    FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds + 1), stream_));
     ++rounds;
     ncur = (uint32_t)read_counter(C_LIST0 + nxt);
     cur = nxt;
   }
-  if (st) st->rounds = rounds;
+  if (st) {
+    st->rounds = rounds;
+    double sum = 0;
+    for (int64_t r = 0; r < rounds; ++r) {
+      float ms = 0;
+      FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, evpool_[2 * r], evpool_[2 * r + 1]));
+      sum += ms;
+    }
+    st->relax_ms = sum;
+    st->relax_launches = rounds;
+  }
 }
 
 void DenseMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cpp:273-398)

@@ -121,6 +121,8 @@ class DenseMap {
   int device_ = 0;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  std::vector<hipEvent_t> evpool_;  // per-launch timing of the relaxation kernel
+  hipEvent_t pool_event(size_t i);
 
   // per-voxel state
   vox_t *coc_ = nullptr;               // 4 B/voxel, hot
@@ -146,9 +148,12 @@ class DenseMap {
 
   // staging
   DevBuf<unsigned char> stage_a_, stage_b_, stage_c_;
-  // raycast per-frame stamp arrays (Fiesta::set_occ_/set_free_, include/Fiesta.h:107-110), lazily allocated
-  uint32_t *stamp_occ_ = nullptr, *stamp_free_ = nullptr;
-  uint32_t frame_ = 0;
+  // raycast front-end state (per-frame stamp arrays = Fiesta::set_occ_/set_free_, include/Fiesta.h:107-110;
+  // per-ray traversal lists), lazily allocated by raycast.hip
+  struct RaycastState;
+  RaycastState *rc_ = nullptr;
+  void free_raycast_state();
+  friend struct RaycastAccess;
 
   Snapshot snaps_[4];
 };

@@ -67,6 +67,8 @@ typedef struct fiesta_hip_stats {
   int64_t voxel_writes;  /* voxel states written back to HBM (a voxel may be written in several rounds) */
   double device_ms;      /* HIP-event time from first to last kernel of the update */
   double host_ms;        /* wall time of the call */
+  double relax_ms;       /* sum of the HIP-event durations of the relaxation launches (k_relax) */
+  int64_t relax_launches;
 } fiesta_hip_stats;
 
 const char *fiesta_hip_last_error(void);
