@@ -283,6 +283,9 @@ int fiesta_hip_get_occupancy_pos(fiesta_hip_map *m, const double *pos, int64_t n
 int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds) {
   return guarded([&] { dense(m, "download_field").download_field(d2, coc, occ, logodds); });
 }
+int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num_miss) {
+  return guarded([&] { dense(m, "download_counts").download_counts(num_hit, num_miss); });
+}
 int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
                              uint8_t *occ) {
   return guarded([&] {

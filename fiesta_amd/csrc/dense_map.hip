@@ -1002,6 +1002,17 @@ void DenseMap::download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *l
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
+void DenseMap::download_counts(int32_t *num_hit, int32_t *num_miss) {
+  use_device();
+  std::vector<unsigned long long> h(g_.n);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(h.data(), cnt_, g_.n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (int64_t i = 0; i < g_.n; ++i) {
+    if (num_hit) num_hit[i] = (int32_t)(h[i] >> 32);
+    if (num_miss) num_miss[i] = (int32_t)(uint32_t)h[i];
+  }
+}
+
 // ---- snapshots ----
 void DenseMap::snapshot_save(int slot) {
   use_device();

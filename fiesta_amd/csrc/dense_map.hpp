@@ -89,6 +89,7 @@ class DenseMap {
   void get_occupancy_pos(const double *pos, int64_t n, int32_t *out);
 
   void download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds);
+  void download_counts(int32_t *num_hit, int32_t *num_miss);
   void snapshot_save(int slot);
   void snapshot_restore(int slot);
   int64_t snapshot_count_updated(int slot);

@@ -1,14 +1,434 @@
-// placeholder, replaced below in this round
+// fiesta_amd/csrc/raycast.hip -- per-ray HIP kernels that turn one sensor frame into the occupancy delta.
+//
+// Replaces (reference = HKUST-Aerial-Robotics/FIESTA):
+//   Raycast(start,end,min,max,&out)          src/raycast.cpp:56-158   -> dda_walk (device, one ray per lane)
+//   Fiesta::RaycastProcess / Multithread     include/Fiesta.h:194-303 -> k_ray_prepare / k_ray_winner /
+//                                                                       k_ray_resolve / k_ray_apply
+//   pinhole part of Fiesta::DepthConversion  include/Fiesta.h:341-351 -> k_depth_points
+//
+// The reference processes the cloud sequentially and de-duplicates per frame with two stamp arrays:
+//   set_occ_  : only the FIRST point (cloud order) that falls into an end-point voxel casts a ray;
+//   set_free_ : a ray walks its voxels far -> near, counts a "miss" in each, and STOPS at the first voxel
+//               that an EARLIER ray of the frame already stamped (that voxel is still counted once more).
+// Which voxels a ray touches therefore depends on all earlier rays. Both rules are
+// reproduced exactly, not approximated, by making "earlier" explicit:
+//   * end points: atomicMin of the ray index per end-point voxel; the minimum index wins;
+//   * free space: let F[v] be the smallest index of a ray whose (truncated) walk contains v. Ray i is
+//     truncated at the first voxel with F[v] < i. F and the truncations are a fixed point of each other and
+//     the fixed point is unique (ray 0 is never truncated, ray 1 only depends on ray 0, ...), so iterating
+//     "truncate with the previous F, rebuild F with atomicMin" from "nobody is truncated" converges to
+//     exactly the sequential result; the loop stops when no ray's truncation changed (a few rounds in
+//     practice, each a cheap replay of the per-ray voxel lists that k_ray_prepare stored).
+// Counters are applied once, by k_ray_apply, along the final truncated walks.
+// All ray arithmetic is f64 in the reference's operation order and this file is compiled with
+// -ffp-contract=off, so voxel decisions (floor, comparisons with min/max ray length) match bit for bit.
+#include <cmath>
+#include <cstring>
+
 #include "dense_map.hpp"
 #include "hash_map.hpp"
+
 namespace fiesta {
-void DenseMap::raycast_frame(const float *, int64_t, const double *, const double *, const fiesta_hip_raycast_params *, bool) {
-  throw Error(FIESTA_HIP_ERR_INVALID, "raycast: not built yet");
+
+constexpr uint32_t kCodeSkip = 0xFFFFFFFFu;      // no-op entry: beyond max range or outside the map
+constexpr uint32_t kCodeMinBreak = 0xFFFFFFFEu;  // closer than min_ray_length: the walk ends here
+constexpr uint32_t kCodeNoCount = 0x40000000u;   // inside the map but outside the update window
+constexpr uint32_t kCodeIdxMask = 0x3FFFFFFFu;
+constexpr int kMaxRayVoxels = 1500;              // src/raycast.cpp:127-130
+
+struct RayArgs {
+  double T[16];
+  double o[3];
+  double minr, maxr;
+  double lc[3], rc[3];  // l_cornor / r_cornor in metres
+  int dedup;
+};
+
+__device__ inline int sgn_i(int v) { return v == 0 ? 0 : (v < 0 ? -1 : 1); }            // signum (:6-8)
+__device__ inline double wrap1(double v) { return fmod(fmod(v, 1.0) + 1.0, 1.0); }      // mod (:10-12)
+__device__ inline double first_crossing(double s, double ds) {                          // intbound (:14-23)
+  if (ds < 0) {
+    s = -s;
+    ds = -ds;
+  }
+  return (1 - wrap1(s)) / ds;
 }
-void DenseMap::raycast_depth(const uint16_t *, int, int, double, double, double, double, const double *, const double *, const fiesta_hip_raycast_params *) {
-  throw Error(FIESTA_HIP_ERR_INVALID, "raycast: not built yet");
+
+// Amanatides-Woo traversal with the reference's arithmetic (src/raycast.cpp:56-158). `emit(x,y,z,k)` is
+// called for every voxel the reference pushes; returns the count, or -1 if it would exceed 1500 voxels.
+template <typename Emit>
+__device__ inline int dda_walk(const double *a, const double *b, const double *lo, const double *hi, Emit emit) {
+  int c[3] = {(int)floor(a[0]), (int)floor(a[1]), (int)floor(a[2])};
+  const int e[3] = {(int)floor(b[0]), (int)floor(b[1]), (int)floor(b[2])};
+  const double r0 = b[0] - a[0], r1 = b[1] - a[1], r2 = b[2] - a[2];
+  const double reach2 = r0 * r0 + r1 * r1 + r2 * r2;
+  double tmax[3], tstep[3];
+  int step[3];
+  for (int i = 0; i < 3; ++i) {
+    const double delta = e[i] - c[i];  // NB: integer voxel delta, not the true ray direction (:89-91)
+    step[i] = sgn_i((int)delta);
+    tmax[i] = first_crossing(a[i], delta);
+    tstep[i] = ((double)step[i]) / delta;
+  }
+  if (step[0] == 0 && step[1] == 0 && step[2] == 0) return 0;
+  int count = 0;
+  for (int guard = 0; guard < 8192; ++guard) {
+    if (c[0] >= lo[0] && c[0] < hi[0] && c[1] >= lo[1] && c[1] < hi[1] && c[2] >= lo[2] && c[2] < hi[2]) {
+      emit(c[0], c[1], c[2], count);
+      ++count;
+      const double q0 = c[0] - a[0], q1 = c[1] - a[1], q2 = c[2] - a[2];
+      if (q0 * q0 + q1 * q1 + q2 * q2 > reach2) return count;
+      if (count > kMaxRayVoxels) return -1;
+    }
+    if (c[0] == e[0] && c[1] == e[1] && c[2] == e[2]) break;
+    int ax;  // strict '<' tie rules (:139-157)
+    if (tmax[0] < tmax[1])
+      ax = (tmax[0] < tmax[2]) ? 0 : 2;
+    else
+      ax = (tmax[1] < tmax[2]) ? 1 : 2;
+    c[ax] += step[ax];
+    tmax[ax] += tstep[ax];
+  }
+  return count;
 }
-void raycast_single(const double *, const double *, const double *, const double *, double *, int32_t, int32_t *, int32_t) {
-  throw Error(FIESTA_HIP_ERR_INVALID, "raycast: not built yet");
+
+__device__ inline bool ray_pos_in_map(const Geom &g, const double *p) {
+  return !(p[0] < g.lo[0] || p[1] < g.lo[1] || p[2] < g.lo[2] || p[0] > g.hi[0] || p[1] > g.hi[1] || p[2] > g.hi[2]);
 }
+
+__device__ inline void count_observation(int64_t idx, int occ, unsigned long long *cnt, uint32_t *touched,
+                                         unsigned long long *counters) {
+  const unsigned long long old = atomicAdd(&cnt[idx], ((unsigned long long)(uint32_t)occ << 32) | 1ull);
+  if ((uint32_t)old == 0) touched[atomicAdd(&counters[C_TOUCHED], 1ull)] = (uint32_t)idx;
 }
+
+// flags: bit0 valid ray, bit1 casts (winner of its end-point voxel), bit2 traversal overflow
+__global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, int stride, uint32_t *entries,
+                              int32_t *end_idx, int32_t *m_count, uint8_t *flags, uint32_t *stamp_occ,
+                              uint32_t tagged, unsigned long long *cnt, uint32_t *touched,
+                              unsigned long long *counters, int *err) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flags[i] = 0;
+  m_count[i] = 0;
+  end_idx[i] = -1;
+  const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+  if (isnan(px) || isnan(py) || isnan(pz)) return;  // include/Fiesta.h:202
+  double h[4];
+  for (int r = 0; r < 4; ++r) h[r] = ra.T[4 * r] * px + ra.T[4 * r + 1] * py + ra.T[4 * r + 2] * pz + ra.T[4 * r + 3] * 1.0;
+  double q[3] = {h[0] / h[3], h[1] / h[3], h[2] / h[3]};  // :204-205
+  double d0 = q[0] - ra.o[0], d1 = q[1] - ra.o[1], d2 = q[2] - ra.o[2];
+  double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  if (len < ra.minr) return;  // :209
+  int occ = 1;
+  if (len > ra.maxr) {  // clip to max range and mark the clipped end point FREE (:211-213)
+    for (int k = 0; k < 3; ++k) q[k] = (q[k] - ra.o[k]) / len * ra.maxr + ra.o[k];
+    occ = 0;
+  }
+  // SetOccupancy(point, occ) (src/ESDFMap.cpp:401-437); every valid point counts its end point
+  int eidx = -1;
+  if (ray_pos_in_map(g, q)) {
+    const int x = (int)floor((q[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((q[1] - g.org[1]) / g.res) - g.gy0,
+              z = (int)floor((q[2] - g.org[2]) / g.res) - g.gz0;
+    if (g.in_grid(x, y, z)) {
+      eidx = (int)g.idx(x, y, z);
+      if (g.in_window(x, y, z) && g.owned(x, y, z)) count_observation(eidx, occ, cnt, touched, counters);
+    }
+  }
+  end_idx[i] = eidx;
+  if (ra.dedup && eidx >= 0) atomicMin(&stamp_occ[eidx], tagged | (uint32_t)i);  // set_occ_ (:221-232)
+  // Raycast(origin/res, point/res, l_cornor/res, r_cornor/res) (:233-237)
+  double a[3], b[3], lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) {
+    a[k] = ra.o[k] / g.res;
+    b[k] = q[k] / g.res;
+    lo[k] = ra.lc[k] / g.res;
+    hi[k] = ra.rc[k] / g.res;
+  }
+  bool overflow = false;
+  const int m = dda_walk(a, b, lo, hi, [&](int vx, int vy, int vz, int k) {
+    if (k >= stride) {
+      overflow = true;
+      return;
+    }
+    // the free-space visit of this voxel, as RaycastProcess would do it (:240-248)
+    const double c[3] = {(vx + 0.5) * g.res, (vy + 0.5) * g.res, (vz + 0.5) * g.res};
+    const double e0 = c[0] - ra.o[0], e1 = c[1] - ra.o[1], e2 = c[2] - ra.o[2];
+    const double l2 = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+    uint32_t code = kCodeSkip;
+    if (l2 < ra.minr)
+      code = kCodeMinBreak;
+    else if (!(l2 > ra.maxr) && ray_pos_in_map(g, c)) {
+      const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
+                z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
+      if (g.in_grid(x, y, z))
+        code = (uint32_t)g.idx(x, y, z) | ((g.in_window(x, y, z) && g.owned(x, y, z)) ? 0u : kCodeNoCount);
+    }
+    entries[(int64_t)k * n + i] = code;
+  });
+  if (m < 0 || overflow) {
+    atomicExch(err, 1);
+    flags[i] = 4;
+    return;
+  }
+  m_count[i] = m;
+  flags[i] = 1;
+}
+
+__global__ void k_ray_winner(int64_t n, int dedup, const int32_t *end_idx, const int32_t *m_count, uint8_t *flags,
+                             const uint32_t *stamp_occ, uint32_t tagged, int32_t *last_k) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t f = flags[i];
+  if ((f & 1) && (!dedup || end_idx[i] < 0 || stamp_occ[end_idx[i]] == (tagged | (uint32_t)i))) f |= 2;
+  flags[i] = f;
+  last_k[i] = m_count[i];  // "nothing visited yet"
+}
+
+// One fixed-point round: truncate every casting ray with the previous round's first-stamper array and rebuild
+// the array for the next round.
+__global__ void k_ray_resolve(int64_t n, const uint32_t *entries, const int32_t *m_count, const uint8_t *flags,
+                              int32_t *last_k, int have_prev, int stamp, const uint32_t *fprev, uint32_t tag_prev,
+                              uint32_t *fnext, uint32_t tag_next, int ibits, int *changed) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!(flags[i] & 2)) return;
+  const int m = m_count[i];
+  const uint32_t imask = (1u << ibits) - 1u;
+  int lk = m;  // lowest visited entry
+  for (int k = m - 2; k >= 0; --k) {
+    const uint32_t code = entries[(int64_t)k * n + i];
+    if (code == kCodeMinBreak) break;  // include/Fiesta.h:243-244
+    lk = k;
+    if (code == kCodeSkip) continue;   // :245-246 and the "-10000" case of :253
+    const uint32_t idx = code & kCodeIdxMask;
+    if (stamp) atomicMin(&fnext[idx], (tag_next << ibits) | (uint32_t)i);
+    if (have_prev) {
+      const uint32_t v = fprev[idx];
+      if ((v >> ibits) == tag_prev && (v & imask) < (uint32_t)i) break;  // set_free_[idx] == tt (:265-269)
+    }
+  }
+  if (lk != last_k[i]) {
+    last_k[i] = lk;
+    *changed = 1;
+  }
+}
+
+__global__ void k_ray_apply(int64_t n, const uint32_t *entries, const int32_t *m_count, const uint8_t *flags,
+                            const int32_t *last_k, unsigned long long *cnt, uint32_t *touched,
+                            unsigned long long *counters) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!(flags[i] & 2)) return;
+  const int m = m_count[i], lk = last_k[i];
+  for (int k = m - 2; k >= lk; --k) {
+    const uint32_t code = entries[(int64_t)k * n + i];
+    if (code == kCodeSkip || (code & kCodeNoCount)) continue;
+    count_observation(code & kCodeIdxMask, 0, cnt, touched, counters);  // SetOccupancy(tmp, 0) (:248)
+  }
+}
+
+// Pinhole back-projection (include/Fiesta.h:341-351): uint16 millimetres -> float sensor-frame points.
+__global__ void k_depth_points(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
+                               float *pts) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int v = i / cols, u = i % cols;
+  const double d = depth[i] / 1000.0;  // k_depth_scaling_factor (:328)
+  pts[3 * i] = (float)((u - cx) * d / fx);
+  pts[3 * i + 1] = (float)((v - cy) * d / fy);
+  pts[3 * i + 2] = (float)d;
+}
+
+__global__ void k_raycast_one(const double *io, double *out, int cap, int *n_out) {
+  int cnt = dda_walk(io, io + 3, io + 6, io + 9, [&](int x, int y, int z, int k) {
+    if (k < cap) {
+      out[3 * k] = x;
+      out[3 * k + 1] = y;
+      out[3 * k + 2] = z;
+    }
+  });
+  *n_out = cnt;
+}
+
+// =====================================================================================================
+struct DenseMap::RaycastState {
+  DevBuf<uint32_t> entries;
+  DevBuf<int32_t> end_idx, m_count, last_k;
+  DevBuf<uint8_t> flags;
+  DevBuf<float> points;
+  DevBuf<uint16_t> depth;
+  uint32_t *stamp_occ = nullptr, *fa = nullptr, *fb = nullptr;
+  int ibits = 0;
+  uint32_t tag = 0;
+  int *d_flags = nullptr;  // [0] changed, [1] error
+  int *h_flags = nullptr;
+  int64_t last_iterations = 0;
+};
+
+void DenseMap::free_raycast_state() {
+  if (!rc_) return;
+  if (rc_->stamp_occ) (void)hipFree(rc_->stamp_occ);
+  if (rc_->fa) (void)hipFree(rc_->fa);
+  if (rc_->fb) (void)hipFree(rc_->fb);
+  if (rc_->d_flags) (void)hipFree(rc_->d_flags);
+  if (rc_->h_flags) (void)hipHostFree(rc_->h_flags);
+  delete rc_;
+  rc_ = nullptr;
+}
+
+static inline int rgrid(int64_t n) { return (int)std::max<int64_t>(1, (n + 255) / 256); }
+
+void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, const double *origin,
+                             const fiesta_hip_raycast_params *p, bool dev) {
+  use_device();
+  if (n <= 0) return;
+  if (n >= (1ll << 26)) throw Error(FIESTA_HIP_ERR_INVALID, "more than 2^26 points in one frame");
+  if (!(p->max_ray_length > 0) || !(p->min_ray_length >= 0))
+    throw Error(FIESTA_HIP_ERR_INVALID, "bad ray length window");
+  if (!rc_) {
+    rc_ = new RaycastState;
+    FIESTA_HIP_CHECK(hipMalloc((void **)&rc_->d_flags, 2 * sizeof(int)));
+    FIESTA_HIP_CHECK(hipHostMalloc((void **)&rc_->h_flags, 2 * sizeof(int)));
+  }
+  RaycastState &rc = *rc_;
+  const Geom &g = g_;
+  // a ray of length <= max_ray_length crosses at most |dx|+|dy|+|dz|+1 voxels
+  const int per_axis = (int)std::ceil(p->max_ray_length / g.res) + 2;
+  const int stride = std::min(kMaxRayVoxels + 1, 3 * per_axis + 2);
+  rc.entries.ensure((size_t)stride * n, stream_);
+  rc.end_idx.ensure(n, stream_);
+  rc.m_count.ensure(n, stream_);
+  rc.last_k.ensure(n, stream_);
+  rc.flags.ensure(n, stream_);
+  const float *dpts = points;
+  if (!dev) {
+    rc.points.ensure(3 * n, stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(rc.points.p, points, 3 * n * sizeof(float), hipMemcpyHostToDevice, stream_));
+    dpts = rc.points.p;
+  }
+  const int dedup = p->dedup ? 1 : 0;
+  // tagged per-frame stamps (set_occ_/set_free_): value = tag << ibits | ray index, newer tags are smaller
+  int ibits = 20;
+  while ((1ll << ibits) < n) ++ibits;
+  if (dedup) {
+    const bool fresh = rc.stamp_occ == nullptr;
+    if (fresh) {
+      FIESTA_HIP_CHECK(hipMalloc((void **)&rc.stamp_occ, g.n * sizeof(uint32_t)));
+      FIESTA_HIP_CHECK(hipMalloc((void **)&rc.fa, g.n * sizeof(uint32_t)));
+      FIESTA_HIP_CHECK(hipMalloc((void **)&rc.fb, g.n * sizeof(uint32_t)));
+    }
+    if (fresh || ibits != rc.ibits || rc.tag < 4096) {
+      FIESTA_HIP_CHECK(hipMemsetAsync(rc.stamp_occ, 0xFF, g.n * sizeof(uint32_t), stream_));
+      FIESTA_HIP_CHECK(hipMemsetAsync(rc.fa, 0xFF, g.n * sizeof(uint32_t), stream_));
+      FIESTA_HIP_CHECK(hipMemsetAsync(rc.fb, 0xFF, g.n * sizeof(uint32_t), stream_));
+      rc.ibits = ibits;
+      rc.tag = (0xFFFFFFFFu >> ibits) - 1u;
+    }
+  }
+  RayArgs ra;
+  memcpy(ra.T, T, sizeof(ra.T));
+  for (int k = 0; k < 3; ++k) {
+    ra.o[k] = origin[k];
+    ra.lc[k] = p->l_cornor[k];
+    ra.rc[k] = p->r_cornor[k];
+  }
+  ra.minr = p->min_ray_length;
+  ra.maxr = p->max_ray_length;
+  ra.dedup = dedup;
+  // worst case every ray touches `stride` new voxels
+  ensure_touched_capacity(std::min<int64_t>(g.n, n * (int64_t)(stride + 1)));
+  FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, 2 * sizeof(int), stream_));
+  const uint32_t tag_occ = dedup ? rc.tag-- : 0;
+  hipLaunchKernelGGL(k_ray_prepare, dim3(rgrid(n)), dim3(256), 0, stream_, g, ra, dpts, n, stride, rc.entries.p,
+                     rc.end_idx.p, rc.m_count.p, rc.flags.p, rc.stamp_occ, dedup ? (tag_occ << ibits) : 0u, cnt_,
+                     touched_.p, counters_, rc.d_flags + 1);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_ray_winner, dim3(rgrid(n)), dim3(256), 0, stream_, n, dedup, (const int32_t *)rc.end_idx.p,
+                     (const int32_t *)rc.m_count.p, rc.flags.p, (const uint32_t *)rc.stamp_occ,
+                     dedup ? (tag_occ << ibits) : 0u, rc.last_k.p);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  int64_t iters = 0;
+  if (!dedup) {
+    hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
+                       (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, 0, 0,
+                       (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u, ibits, rc.d_flags);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  } else {
+    uint32_t *fprev = rc.fa, *fnext = rc.fb;
+    uint32_t tag_prev = 0;
+    for (;;) {
+      const uint32_t tag_next = rc.tag--;
+      FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, sizeof(int), stream_));
+      hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
+                         (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, iters > 0 ? 1 : 0, 1,
+                         (const uint32_t *)fprev, tag_prev, fnext, tag_next, ibits, rc.d_flags);
+      FIESTA_HIP_CHECK(hipGetLastError());
+      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+      ++iters;
+      if (rc.h_flags[1]) break;
+      // round 1 always "changes" (from nothing visited to the full walk); stop when a round changes nothing
+      if (iters > 1 && !rc.h_flags[0]) break;
+      std::swap(fprev, fnext);
+      tag_prev = tag_next;
+      if (rc.tag < 16) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup did not converge");
+    }
+  }
+  rc.last_iterations = iters;
+  hipLaunchKernelGGL(k_ray_apply, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
+                     (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, (const int32_t *)rc.last_k.p, cnt_,
+                     touched_.p, counters_);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (rc.h_flags[1])  // the reference throws std::out_of_range("Too many RaycasMultithread voxels")
+    throw Error(FIESTA_HIP_ERR_INVALID, "Too many raycast voxels (a ray crosses more than 1500 voxels)");
+}
+
+void DenseMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
+                             const double *T, const double *origin, const fiesta_hip_raycast_params *p) {
+  use_device();
+  if (!rc_) {
+    rc_ = new RaycastState;
+    FIESTA_HIP_CHECK(hipMalloc((void **)&rc_->d_flags, 2 * sizeof(int)));
+    FIESTA_HIP_CHECK(hipHostMalloc((void **)&rc_->h_flags, 2 * sizeof(int)));
+  }
+  const int64_t n = (int64_t)rows * cols;
+  rc_->depth.ensure(n, stream_);
+  rc_->points.ensure(3 * n, stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(rc_->depth.p, depth, n * sizeof(uint16_t), hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(k_depth_points, dim3(rgrid(n)), dim3(256), 0, stream_, (const uint16_t *)rc_->depth.p, rows, cols,
+                     fx, fy, cx, cy, rc_->points.p);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  raycast_frame(rc_->points.p, n, T, origin, p, true);
+}
+
+void raycast_single(const double *start, const double *end, const double *minv, const double *maxv, double *out,
+                    int32_t cap, int32_t *n_out, int32_t device) {
+  FIESTA_HIP_CHECK(hipSetDevice(device));
+  double io[12];
+  memcpy(io, start, 24);
+  memcpy(io + 3, end, 24);
+  memcpy(io + 6, minv, 24);
+  memcpy(io + 9, maxv, 24);
+  double *d_io = nullptr, *d_out = nullptr;
+  int *d_n = nullptr;
+  const int c = std::max(1, (int)cap);
+  FIESTA_HIP_CHECK(hipMalloc((void **)&d_io, sizeof(io)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&d_out, (size_t)c * 3 * sizeof(double)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&d_n, sizeof(int)));
+  FIESTA_HIP_CHECK(hipMemcpy(d_io, io, sizeof(io), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_raycast_one, dim3(1), dim3(1), 0, 0, (const double *)d_io, d_out, (int)cap, d_n);
+  int cnt = 0;
+  FIESTA_HIP_CHECK(hipMemcpy(&cnt, d_n, sizeof(int), hipMemcpyDeviceToHost));
+  if (cnt > 0 && cap > 0)
+    FIESTA_HIP_CHECK(hipMemcpy(out, d_out, (size_t)std::min(cnt, (int)cap) * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(d_io);
+  (void)hipFree(d_out);
+  (void)hipFree(d_n);
+  if (cnt < 0) throw Error(FIESTA_HIP_ERR_INVALID, "Too many raycast voxels (more than 1500)");
+  *n_out = cnt;
+}
+
+}  // namespace fiesta

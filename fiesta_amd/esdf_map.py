@@ -191,6 +191,14 @@ class ESDFMap:
         check(self._lib.fiesta_hip_download_field(self._h, _p(d2), _p(coc), _p(occ), _p(lo)))
         return {"d2": d2, "coc": coc, "occ": occ, "logodds": lo}
 
+    def download_counts(self):
+        """Pending (num_hit_, num_miss_) per voxel; num_miss_ counts all observations (src/ESDFMap.cpp:424)."""
+        n = self.grid_total_size_
+        hit = np.empty(n, np.int32)
+        miss = np.empty(n, np.int32)
+        check(self._lib.fiesta_hip_download_counts(self._h, _p(hit), _p(miss)))
+        return hit, miss
+
     def download_hash(self):
         n = C.c_int64(0)
         check(self._lib.fiesta_hip_download_hash(self._h, C.byref(n), None, None, None, None))

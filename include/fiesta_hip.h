@@ -163,6 +163,9 @@ int fiesta_hip_get_dist_grad_dev(fiesta_hip_map *m, const double *pos_dev, int64
  *   occ     uint8  Exist(idx)
  *   logodds double occupancy_buffer_ */
 int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds);
+/* Pending observation counters num_hit_ / num_miss_ (include/ESDFMap.h:89; num_miss_ counts ALL observations
+ * since the last UpdateOccupancy), dense order; each output nullable. */
+int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num_miss);
 /* Hash mode: allocated voxels in allocation order (vox n x 3); with all outputs NULL only *n_out is set. */
 int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
                              uint8_t *occ);

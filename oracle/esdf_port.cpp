@@ -543,6 +543,14 @@ void oracle_dump_dense(oracle_map *m, double *dist, int32_t *coc, uint8_t *occ, 
     if (logodds) logodds[i] = p.logodds[i];
   }
 }
+void oracle_dump_counts(oracle_map *m, int32_t *num_hit, int32_t *num_miss) {
+  Port &p = m->p;
+  if (p.mode != 0) return;
+  for (int64_t i = 0; i < p.total; ++i) {
+    if (num_hit) num_hit[i] = p.hits[i];
+    if (num_miss) num_miss[i] = p.seen[i];
+  }
+}
 int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc, uint8_t *occ) {
   Port &p = m->p;
   if (p.mode != 1) return 0;

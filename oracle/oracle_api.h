@@ -64,6 +64,8 @@ void oracle_get_occupancy_pos(oracle_map *m, const double *pos, int64_t n, int32
  *   occ    Exist(idx) as 0/1
  *   logodds occupancy_buffer_ */
 void oracle_dump_dense(oracle_map *m, double *dist, int32_t *coc, uint8_t *occ, double *logodds);
+/* num_hit_ / num_miss_ (dense order, array mode). */
+void oracle_dump_counts(oracle_map *m, int32_t *num_hit, int32_t *num_miss);
 /* Hash dump: entries 1..count-1 of the block store in allocation order; returns count-1. With all
  * outputs NULL it only returns the count. */
 int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc, uint8_t *occ);

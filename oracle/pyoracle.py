@@ -86,6 +86,7 @@ def _load(kind: str, mode: str):
         "oracle_get_occupancy_vox": (None, [vp, vp, i64, vp]),
         "oracle_get_occupancy_pos": (None, [vp, vp, i64, vp]),
         "oracle_dump_dense": (None, [vp, vp, vp, vp, vp]),
+        "oracle_dump_counts": (None, [vp, vp, vp]),
         "oracle_dump_hash": (i64, [vp, vp, vp, vp, vp]),
         "oracle_check_consistency": (i32, [vp]),
         "oracle_raycast": (i32, [vp, vp, vp, vp, vp, i32]),
@@ -219,6 +220,13 @@ class OracleMap:
         lo = np.empty(n, np.float64) if "logodds" in want else None
         self.lib.oracle_dump_dense(self.h, _p(dist), _p(coc), _p(occ), _p(lo))
         return {"dist": dist, "coc": coc, "occ": occ, "logodds": lo}
+
+    def dump_counts(self):
+        n = self.grid_total_size
+        hit = np.empty(n, np.int32)
+        miss = np.empty(n, np.int32)
+        self.lib.oracle_dump_counts(self.h, _p(hit), _p(miss))
+        return hit, miss
 
     def dump_hash(self):
         n = int(self.lib.oracle_dump_hash(self.h, None, None, None, None))

@@ -213,6 +213,17 @@ void oracle_dump_dense(oracle_map *m, double *dist, int32_t *coc, uint8_t *occ, 
 #endif
 }
 
+void oracle_dump_counts(oracle_map *m, int32_t *num_hit, int32_t *num_miss) {
+#ifndef HASH_TABLE
+  for (int64_t i = 0; i < m->map->grid_total_size_; ++i) {
+    if (num_hit) num_hit[i] = m->map->num_hit_[i];
+    if (num_miss) num_miss[i] = m->map->num_miss_[i];
+  }
+#else
+  (void)m; (void)num_hit; (void)num_miss;
+#endif
+}
+
 int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc, uint8_t *occ) {
 #ifdef HASH_TABLE
   fiesta::ESDFMap &e = *m->map;

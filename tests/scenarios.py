@@ -123,3 +123,52 @@ def compare_dense(gpu_map, cpu_map, check_logodds=True):
 
 def assert_exact(report):
     assert report["d2_mismatch"] == 0, f"d^2 differs from the reference: {report}"
+
+
+# ---- synthetic depth frames -------------------------------------------------
+INTRINSICS = dict(fx=384.4, fy=384.4, cx=323.1, cy=235.5)  # shape of src/parameters.cpp:21-24 (values arbitrary)
+
+
+def yaw_pose(yaw_deg, position):
+    """Camera-to-world transform_: camera z forward/x right/y down, sensor yawed about world z."""
+    a = np.deg2rad(yaw_deg)
+    fwd = np.array([np.cos(a), np.sin(a), 0.0])
+    right = np.array([np.sin(a), -np.cos(a), 0.0])
+    down = np.array([0.0, 0.0, -1.0])
+    T = np.eye(4)
+    T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = right, down, fwd, position
+    return T
+
+
+def render_depth(T, rows=480, cols=640, room=((-3.0, -3.0, -1.5), (3.0, 3.0, 1.5)), spheres=(), intr=INTRINSICS):
+    """uint16 millimetre depth image of a box room (seen from inside) with spheres; pinhole model."""
+    v, u = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    d_cam = np.stack([(u - intr["cx"]) / intr["fx"], (v - intr["cy"]) / intr["fy"], np.ones_like(u, float)], -1)
+    R, o = T[:3, :3], T[:3, 3]
+    d = d_cam @ R.T
+    lo, hi = np.array(room[0]), np.array(room[1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_hi = np.where(d > 0, (hi - o) / d, np.inf)
+        t_lo = np.where(d < 0, (lo - o) / d, np.inf)
+    t = np.minimum(t_hi, t_lo).min(-1)
+    for (c, r) in spheres:
+        oc = o - np.array(c)
+        a = (d * d).sum(-1)
+        b = 2 * (d * oc).sum(-1)
+        cc = (oc * oc).sum() - r * r
+        disc = b * b - 4 * a * cc
+        ts = np.where(disc > 0, (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a), np.inf)
+        ts = np.where(ts > 0, ts, np.inf)
+        t = np.minimum(t, ts)
+    z = t  # d_cam.z == 1 -> depth along the optical axis equals t
+    return np.clip(np.round(z * 1000.0), 0, 65535).astype(np.uint16)
+
+
+def depth_to_points(depth, intr=INTRINSICS):
+    """The pinhole part of Fiesta::DepthConversion (include/Fiesta.h:341-351), f64 then float32 like PCL."""
+    rows, cols = depth.shape
+    v, u = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    d = depth.astype(np.float64) / 1000.0
+    x = (u - intr["cx"]) * d / intr["fx"]
+    y = (v - intr["cy"]) * d / intr["fy"]
+    return np.stack([x, y, d], -1).reshape(-1, 3).astype(np.float32)
