@@ -172,3 +172,60 @@ def depth_to_points(depth, intr=INTRINSICS):
     x = (u - intr["cx"]) * d / intr["fx"]
     y = (v - intr["cy"]) * d / intr["fy"]
     return np.stack([x, y, d], -1).reshape(-1, 3).astype(np.float32)
+
+
+# ---- adapter: the HIP map behind the oracle's method names (for the golden programs) -----------------
+class GpuAsOracle:
+    def __init__(self, origin, res, size, **kw):
+        import fiesta_amd
+        self.m = fiesta_amd.ESDFMap(origin, res, size, **kw)
+        self.grid_size = self.m.grid_size
+        self.resolution = self.m.resolution
+        self.last_insert = self.last_delete = 0
+
+    def SetParameters(self, *p):
+        self.m.SetParameters(*p)
+
+    def SetOriginalRange(self):
+        self.m.SetOriginalRange()
+
+    def SetUpdateRange(self, a, b, new_vec=True):
+        self.m.SetUpdateRange(a, b, new_vec)
+
+    def SetOccupancyVox(self, vox, occ):
+        return self.m.SetOccupancy(np.ascontiguousarray(vox, dtype=np.int32).reshape(-1, 3), occ)
+
+    def SetOccupancyPos(self, pos, occ):
+        return self.m.SetOccupancy(np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3), occ)
+
+    def UpdateOccupancy(self, global_map=True):
+        r = self.m.UpdateOccupancy(global_map)
+        self.last_insert, self.last_delete = self.m.last_insert, self.m.last_delete
+        return r
+
+    def UpdateESDF(self):
+        return self.m.UpdateESDF()
+
+    def raycast_frame(self, pts, T, origin, min_ray, max_ray, lc, rc):
+        self.m.RaycastFrame(pts, T, origin, min_ray, max_ray, lc, rc, dedup=1)
+
+    def dump_counts(self):
+        return self.m.download_counts()
+
+    def GetDistancePos(self, pos):
+        return self.m.GetDistance(np.asarray(pos, dtype=np.float64))
+
+    def GetOccupancyPos(self, pos):
+        return self.m.GetOccupancy(np.asarray(pos, dtype=np.float64))
+
+    def GetDistWithGradTrilinear(self, pos):
+        return self.m.GetDistWithGradTrilinear(pos)
+
+
+def compare_gpu_to_golden(gpu_map, gold, cp):
+    """Same contract as compare_dense, against arrays the verbatim reference produced (tests/golden)."""
+    class _Gold:
+        def dump_dense(self_inner):
+            return {"dist": gold[f"{cp}/dist"], "coc": gold[f"{cp}/coc"].astype(np.int32), "occ": gold[f"{cp}/occ"],
+                    "logodds": gold[f"{cp}/logodds"]}
+    return compare_dense(gpu_map, _Gold())

@@ -1,0 +1,76 @@
+"""CPU-side checks of the drop-in boundary: libfiesta_hip.so loads without a GPU, exports every symbol
+include/fiesta_hip.h declares (and nothing is declared that the Python mirror does not bind), reports zero
+devices instead of crashing, and FAILS LOUDLY -- no CPU fallback -- when asked to create a map without one.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build_hip()
+    import fiesta_amd
+    return fiesta_amd.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from fiesta_amd import _lib
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/fiesta_hip.h but not exported"
+    assert sorted(lib._fiesta_signatures) == declared, "python binding and header disagree"
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (fiesta_hip_[a-z0-9_]+)", nm))
+    assert exported == set(declared), exported ^ set(declared)
+
+
+def test_struct_layouts_match_header():
+    from fiesta_amd import _lib
+    text = open(_lib.HEADER_PATH).read()
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for nm_ in decl.split(None, 1)[1].split(","):
+                out.append(re.sub(r"\[.*?\]", "", nm_).strip())
+        return out
+    assert fields("fiesta_hip_config") == [f[0] for f in _lib.Config._fields_]
+    assert fields("fiesta_hip_stats") == [f[0] for f in _lib.Stats._fields_]
+    assert fields("fiesta_hip_raycast_params") == [f[0] for f in _lib.RaycastParams._fields_]
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    import torch
+    import fiesta_amd
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible; the no-device behaviour is checked on the CPU container")
+    assert fiesta_amd.device_count() == 0
+    with pytest.raises(fiesta_amd.FiestaHipError):
+        fiesta_amd.ESDFMap((0, 0, 0), 0.1, (1.0, 1.0, 1.0))
+    assert b"no HIP device" in lib.fiesta_hip_last_error() or lib.fiesta_hip_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under fiesta_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("fiesta_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    src = open(os.path.join(dp, f), errors="replace").read()
+                    if re.search(r"(from|import)\s+oracle|oracle_api\.h|pyoracle|libfiesta_port|libfiesta_ref", src):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,46 @@
+"""The HIP engine against the committed golden fixtures (arrays produced by the verbatim-compiled reference,
+tests/golden/make_golden.py), through the C ABI.  Contract: d^2 / occupancy / log-odds / queue sizes /
+hit-miss counters bit-exact; closest obstacle tie-equivalent; f64 queries bit-exact.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from golden_programs import PROGRAMS, golden_rays
+from scenarios import GpuAsOracle, assert_exact, compare_gpu_to_golden
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(PROGRAMS))
+def test_hip_matches_reference_fixture(hip_lib, name):
+    gold = np.load(os.path.join(GOLD, f"{name}.npz"))
+    for cp, m, extra in PROGRAMS[name](GpuAsOracle):
+        assert tuple(gold[f"{cp}/grid_size"]) == m.grid_size
+        assert_exact(compare_gpu_to_golden(m.m, gold, cp))
+        for k, v in extra.items():
+            if k == "stats":
+                assert (v["inserted"], v["deleted"]) == tuple(gold[f"{cp}/stats"][:2])
+            elif k == "pos":
+                assert np.array_equal(m.GetDistancePos(v), gold[f"{cp}/GetDistance"])
+                dist, grad = m.GetDistWithGradTrilinear(v)
+                assert np.array_equal(dist, gold[f"{cp}/TrilinearDist"])
+                assert np.array_equal(grad, gold[f"{cp}/TrilinearGrad"])
+                assert np.array_equal(m.GetOccupancyPos(v), gold[f"{cp}/GetOccupancy"])
+            else:
+                assert np.array_equal(np.asarray(v), gold[f"{cp}/{k}"]), (name, cp, k)
+
+
+def test_raycast_known_answers(hip_lib):
+    gold = np.load(os.path.join(GOLD, "raycast_kat.npz"))
+    rays, lo, hi = golden_rays()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for i, (a, b) in enumerate(rays):
+        out = np.empty((2048, 3))
+        n = C.c_int32(0)
+        st = hip_lib.fiesta_hip_raycast_single(p(a), p(b), p(lo), p(hi), p(out), 2048, C.byref(n), 0)
+        assert st == 0, hip_lib.fiesta_hip_last_error()
+        assert np.array_equal(out[: n.value], gold[f"v{i}"].astype(np.float64)), i
