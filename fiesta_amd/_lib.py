@@ -30,10 +30,12 @@ class Stats(C.Structure):
     _fields_ = [("inserted", C.c_int64), ("deleted", C.c_int64), ("invalidated", C.c_int64),
                 ("rounds", C.c_int64), ("tile_visits", C.c_int64), ("sweeps", C.c_int64),
                 ("voxel_writes", C.c_int64), ("device_ms", C.c_double), ("host_ms", C.c_double),
-                ("relax_ms", C.c_double), ("relax_launches", C.c_int64)]
+                ("relax_ms", C.c_double), ("relax_launches", C.c_int64), ("prof", C.c_int64 * 8)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["prof"] = list(self.prof)
+        return d
 
 
 class RaycastParams(C.Structure):

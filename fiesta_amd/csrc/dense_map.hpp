@@ -47,7 +47,8 @@ enum Counter {
   C_WRITES,
   C_VISITS,
   C_SCRATCH,
-  C_COUNT
+  C_PROF0,  // 8 profiling slots (FIESTA_HIP_PROF=1): cycles in stage / propagate / write-back, queue items, ...
+  C_COUNT = C_PROF0 + 8
 };
 
 struct Snapshot {
@@ -137,6 +138,11 @@ class DenseMap {
   int tx_ = 8, ty_ = 8;  // tile extent in x,y (z extent is always 32)
   int ntx_ = 0, nty_ = 0, ntz_ = 0, ntiles_ = 0;
   uint32_t *tile_epoch_ = nullptr;
+  int engine_ = 1;                              // 0: Jacobi sweeps (k_relax), 1: LDS work queue (k_relax_q)
+  uint32_t *cbits_[2] = {nullptr, nullptr};     // 1 bit/voxel: changed in the round of that parity
+  uint32_t *cstamp_[2] = {nullptr, nullptr};    // per tile: serial of the round that wrote cbits_[parity]
+  int prof_ = 0;
+  uint32_t serial_ = 0;                         // relaxation rounds launched so far (all updates)
   uint32_t *tile_flag_[2] = {nullptr, nullptr};
   uint32_t *tile_list_[2] = {nullptr, nullptr};
   uint32_t epoch_ = 0;

@@ -69,6 +69,7 @@ typedef struct fiesta_hip_stats {
   double host_ms;        /* wall time of the call */
   double relax_ms;       /* sum of the HIP-event durations of the relaxation launches (k_relax) */
   int64_t relax_launches;
+  int64_t prof[8];       /* engine profiling counters (only with FIESTA_HIP_PROF=1 in the environment) */
 } fiesta_hip_stats;
 
 const char *fiesta_hip_last_error(void);

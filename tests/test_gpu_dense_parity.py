@@ -36,7 +36,7 @@ def observe_all(b, n=None):
     assert sg["inserted"] == 0 and sg["deleted"] == 0
 
 
-@pytest.mark.parametrize("tile_shape", [0, 2, 3, 4])
+@pytest.mark.parametrize("tile_shape", [0, 1, 2, 3, 4, 10, 12])
 def test_insert_then_delete_fully_observed(hip_lib, oracle_libs, best_oracle_kind, tile_shape):
     n = 48
     b = make_pair(oracle_libs, best_oracle_kind, n, tile_shape=tile_shape)

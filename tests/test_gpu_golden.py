@@ -20,7 +20,15 @@ def test_hip_matches_reference_fixture(hip_lib, name):
     gold = np.load(os.path.join(GOLD, f"{name}.npz"))
     for cp, m, extra in PROGRAMS[name](GpuAsOracle):
         assert tuple(gold[f"{cp}/grid_size"]) == m.grid_size
-        assert_exact(compare_gpu_to_golden(m.m, gold, cp))
+        rep = compare_gpu_to_golden(m.m, gold, cp)
+        if name == "raycast_frames":
+            # partially observed map: the reference's own distances depend on its FIFO order there
+            # (SURVEY.md 7.3-B).  Measured on the verbatim reference for THIS fixture: replaying the same
+            # observations in another first-touch order changes 116-214 of 13766 finite distances
+            # (0.8-1.6 %), see tests/test_oracle_order_sensitivity.py.  Budget 2 %.
+            assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]), rep
+        else:
+            assert_exact(rep)
         for k, v in extra.items():
             if k == "stats":
                 assert (v["inserted"], v["deleted"]) == tuple(gold[f"{cp}/stats"][:2])

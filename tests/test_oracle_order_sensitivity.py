@@ -1,0 +1,81 @@
+"""How order-dependent is the reference algorithm itself?  (CPU, oracle only.)
+
+The GPU engine cannot reproduce the reference's serial FIFO order, so on PARTIALLY observed maps -- where
+the reference's fixed point depends on that order -- the parity tests allow a small d^2
+mismatch budget.  This test pins that budget to a measurement instead of a guess: the observations of the
+golden raycast fixture are replayed through SetOccupancy in the natural voxel order and in shuffled orders
+(identical hit/miss counters, identical occupancy, only the queue order differs) and the distance fields of
+the oracle are compared with each other.  On fully observed maps the same experiment changes no distance.
+"""
+import numpy as np
+
+from golden_programs import SMALL_INTR
+from scenarios import P_DEFAULT, all_voxels, depth_to_points, render_depth, yaw_pose
+
+
+def _mk(oracle_libs, kind, origin, res, size):
+    m = oracle_libs.OracleMap(origin, res, size, kind=kind)
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    return m
+
+
+def test_partially_observed_distances_depend_on_queue_order(oracle_libs, best_oracle_kind):
+    res, origin, size = 0.1, (-4.0, -4.0, -2.0), (8.0, 8.0, 4.0)
+    src = _mk(oracle_libs, best_oracle_kind, origin, res, size)
+    maps = [_mk(oracle_libs, best_oracle_kind, origin, res, size) for _ in range(3)]
+    rng = np.random.RandomState(0)
+    spheres = [((1.5, 0.5, 0.0), 0.6), ((-1.0, -1.5, -0.3), 0.5)]
+    gs = src.grid_size
+    worst = 0.0
+    for f in range(3):
+        T = yaw_pose(20.0 * f, (0.1 * f, -0.05 * f, 0.02))
+        pts = depth_to_points(render_depth(T, rows=60, cols=80, spheres=spheres, intr=SMALL_INTR), intr=SMALL_INTR)
+        src.raycast_frame(pts, T, T[:3, 3], 0.5, 5.0, origin, np.add(origin, size))
+        hit, miss = src.dump_counts()
+        src.UpdateOccupancy(True)
+        src.UpdateESDF()
+        idx = np.flatnonzero(miss > 0)
+        vox = np.stack([idx // (gs[1] * gs[2]), (idx // gs[2]) % gs[1], idx % gs[2]], -1).astype(np.int32)
+        for k, m in enumerate(maps):
+            order = np.arange(len(idx)) if k == 0 else rng.permutation(len(idx))
+            reps = miss[idx][order]
+            v = np.repeat(vox[order], reps, 0)
+            occ = np.concatenate([np.r_[np.ones(h, np.int32), np.zeros(t - h, np.int32)]
+                                  for h, t in zip(hit[idx][order], reps)])
+            m.SetOccupancyVox(v, occ)
+            m.UpdateOccupancy(True)
+            m.UpdateESDF()
+        dumps = [m.dump_dense(("dist", "occ", "logodds")) for m in maps]
+        for d in dumps[1:]:  # same counters -> same occupancy, bit for bit
+            assert np.array_equal(d["occ"], dumps[0]["occ"]) and np.array_equal(d["logodds"], dumps[0]["logodds"])
+        finite = int(((dumps[0]["dist"] >= 0) & (dumps[0]["dist"] < 10000)).sum())
+        diffs = [int((d["dist"] != dumps[0]["dist"]).sum()) for d in dumps[1:]]
+        diffs.append(int((src.dump_dense(("dist",))["dist"] != dumps[0]["dist"]).sum()))
+        if finite:
+            worst = max(worst, max(diffs) / finite)
+            assert max(diffs) <= 0.03 * finite, (f, finite, diffs)
+    assert 0.002 < worst < 0.03, worst  # measured 0.8-1.6 % with the verbatim reference
+
+
+def test_fully_observed_distances_do_not_depend_on_queue_order(oracle_libs, best_oracle_kind):
+    n, res = 32, 0.1
+    maps = [_mk(oracle_libs, best_oracle_kind, (0, 0, 0), res, (n * res,) * 3) for _ in range(3)]
+    rng = np.random.RandomState(4)
+    S = rng.randint(0, n, (400, 3)).astype(np.int32)
+    ties = 0
+    for k, m in enumerate(maps):
+        m.SetOccupancyVox(all_voxels(m.grid_size), 0)
+        m.UpdateOccupancy(True)
+        m.UpdateESDF()
+        order = np.arange(len(S)) if k == 0 else rng.permutation(len(S))
+        for _ in range(3):
+            m.SetOccupancyVox(S[order], 1)
+            m.UpdateOccupancy(True)
+        m.UpdateESDF()
+    d0 = maps[0].dump_dense(("dist", "coc"))
+    for m in maps[1:]:
+        d = m.dump_dense(("dist", "coc"))
+        assert np.array_equal(d["dist"], d0["dist"])          # distances: order-independent
+        ties += int((d["coc"] != d0["coc"]).any(-1).sum())    # ids: NOT order-independent
+    assert ties > 0
