@@ -77,6 +77,7 @@ def load():
         "fiesta_hip_set_occupancy_vox": (C.c_int, [vp, vp, vp, i64, vp]),
         "fiesta_hip_set_occupancy_pos": (C.c_int, [vp, vp, vp, i64, vp]),
         "fiesta_hip_set_occupancy_vox_dev": (C.c_int, [vp, vp, vp, i64]),
+        "fiesta_hip_set_occupancy_box": (C.c_int, [vp, vp, vp, i32]),
         "fiesta_hip_raycast_frame": (C.c_int, [vp, vp, i64, vp, vp, vp]),
         "fiesta_hip_raycast_frame_dev": (C.c_int, [vp, vp, i64, vp, vp, vp]),
         "fiesta_hip_raycast_depth": (C.c_int, [vp, vp, i32, i32, dbl, dbl, dbl, dbl, vp, vp, vp]),

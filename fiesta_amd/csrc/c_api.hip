@@ -169,6 +169,13 @@ int fiesta_hip_set_occupancy_vox_dev(fiesta_hip_map *m, const int32_t *vox_dev, 
   });
 }
 
+int fiesta_hip_set_occupancy_box(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], int32_t occ) {
+  return guarded([&] {
+    need(m && lo && hi && (occ == 0 || occ == 1), "bad argument");
+    dense(m, "set_occupancy_box").observe_box(lo, hi, occ);
+  });
+}
+
 int fiesta_hip_raycast_frame(fiesta_hip_map *m, const float *points, int64_t n, const double T[16],
                              const double origin[3], const fiesta_hip_raycast_params *p) {
   return guarded([&] {

@@ -63,6 +63,20 @@ __global__ void k_observe_vox(Geom g, const int32_t *vox, const int32_t *occ, in
   }
 }
 
+// SetOccupancy(Vector3i, occ) for EVERY voxel of a box (map coordinates, inclusive), e.g. "observe the whole
+// grid free once": same effect as one call per voxel, without materialising the coordinate list.
+__global__ void k_observe_box(Geom g, int bx0, int by0, int bz0, int ex, int ey, int ez, int occ,
+                              unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
+  const int64_t n = (int64_t)ex * ey * ez;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int z = bz0 + (int)(i % ez) - g.gz0, y = by0 + (int)((i / ez) % ey) - g.gy0, x = bx0 + (int)(i / ((int64_t)ez * ey)) - g.gx0;
+    if (!g.in_grid(x, y, z) || !g.in_window(x, y, z) || !g.owned(x, y, z)) continue;
+    const int64_t idx = g.idx(x, y, z);
+    const unsigned long long old = atomicAdd(&cnt[idx], ((unsigned long long)(uint32_t)occ << 32) | 1ull);
+    if ((uint32_t)old == 0) touched[atomicAdd(&counters[C_TOUCHED], 1ull)] = (uint32_t)idx;
+  }
+}
+
 // ---- SetOccupancy(Vector3d,int) (src/ESDFMap.cpp:401-415) ----
 __global__ void k_observe_pos(Geom g, const double *pos, const int32_t *occ, int64_t n,
                               unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
@@ -1097,6 +1111,17 @@ void DenseMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, in
       ret[i] = (vox[3 * i] - g.gx0) * (gny * gnz) + (vox[3 * i + 1] - g.gy0) * gnz + (vox[3 * i + 2] - g.gz0);
   }
   if (!dev) FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));  // staging buffers are reused
+}
+
+void DenseMap::observe_box(const int32_t *lo, const int32_t *hi, int occ) {
+  use_device();
+  const int64_t ex = (int64_t)hi[0] - lo[0] + 1, ey = (int64_t)hi[1] - lo[1] + 1, ez = (int64_t)hi[2] - lo[2] + 1;
+  if (ex <= 0 || ey <= 0 || ez <= 0) return;
+  if (ex > 4096 || ey > 4096 || ez > 4096) throw Error(FIESTA_HIP_ERR_INVALID, "box too large");
+  ensure_touched_capacity(ex * ey * ez);
+  hipLaunchKernelGGL(k_observe_box, dim3(grid_for(ex * ey * ez, 256, 65536)), dim3(256), 0, stream_, g_, lo[0], lo[1],
+                     lo[2], (int)ex, (int)ey, (int)ez, occ, cnt_, touched_.p, counters_);
+  FIESTA_HIP_CHECK(hipGetLastError());
 }
 
 void DenseMap::observe_pos(const double *pos, const int32_t *occ, int64_t n, int32_t *ret) {

@@ -76,6 +76,7 @@ class DenseMap {
 
   void observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret, bool dev);
   void observe_pos(const double *pos, const int32_t *occ, int64_t n, int32_t *ret);
+  void observe_box(const int32_t *lo, const int32_t *hi, int occ);
 
   bool check_update();
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);

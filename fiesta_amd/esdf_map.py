@@ -113,6 +113,12 @@ class ESDFMap:
         """Batch already resident in HBM (n x 3 int32 voxels, n int32 flags)."""
         check(self._lib.fiesta_hip_set_occupancy_vox_dev(self._h, C.c_void_p(vox_dev_ptr), C.c_void_p(occ_dev_ptr), n))
 
+    def SetOccupancyBox(self, lo, hi, occ):
+        """SetOccupancy(Vector3i, occ) for every voxel of the inclusive voxel box [lo, hi], on the device."""
+        a = np.ascontiguousarray(lo, dtype=np.int32).reshape(3)
+        b = np.ascontiguousarray(hi, dtype=np.int32).reshape(3)
+        check(self._lib.fiesta_hip_set_occupancy_box(self._h, _p(a), _p(b), int(occ)))
+
     def CheckUpdate(self) -> bool:
         out = C.c_int32(0)
         check(self._lib.fiesta_hip_check_update(self._h, C.byref(out)))

@@ -105,6 +105,10 @@ int fiesta_hip_set_occupancy_pos(fiesta_hip_map *m, const double *pos, const int
 int fiesta_hip_set_occupancy_vox_dev(fiesta_hip_map *m, const int32_t *vox_dev, const int32_t *occ_dev,
                                      int64_t n);
 
+/* SetOccupancy(Vector3i, occ) for every voxel of the inclusive box [lo, hi] (map voxel coordinates), device
+ * side: the usual way to mark a whole region observed-free (the reference's callers loop over voxels). */
+int fiesta_hip_set_occupancy_box(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], int32_t occ);
+
 /* ---- ray casting: Raycast (src/raycast.cpp:56-158) + Fiesta::RaycastProcess (include/Fiesta.h:194-278) ---- */
 typedef struct fiesta_hip_raycast_params {
   double min_ray_length, max_ray_length; /* parameters_.min/max_ray_length_ (src/parameters.cpp:9-10) */

@@ -54,9 +54,9 @@ def run(G, n_obs, ts):
         st = m.UpdateESDF()
         st["updated"] = m.snapshot_count_updated(0)
         out[f"steady{k}"] = st
-    d2 = m.download_field(("d2",))["d2"]
+    f = m.download_field(("d2", "occ"))
     m.close()
-    return out, d2
+    return out, f["d2"], f["occ"]
 
 
 def show(tag, st):
@@ -76,15 +76,25 @@ def main():
     ap.add_argument("--compare", type=int, default=None)
     a = ap.parse_args()
     n_obs = a.obstacles or int(round(50000 * (a.grid / 512) ** 3))
-    o1, d1 = run(a.grid, n_obs, a.tile_shape)
+    o1, d1, occ1 = run(a.grid, n_obs, a.tile_shape)
     for k, st in o1.items():
         show(f"ts{a.tile_shape}:{k}", st)
     if a.compare is not None:
-        o2, d2 = run(a.grid, n_obs, a.compare)
+        o2, d2, occ2 = run(a.grid, n_obs, a.compare)
         for k, st in o2.items():
             show(f"ts{a.compare}:{k}", st)
-        bad = int((d1 != d2).sum())
+        assert np.array_equal(occ1, occ2)
+        idx = np.flatnonzero(d1 != d2)
+        bad = len(idx)
         print(f"d2 fields differ at {bad} of {d1.size} voxels")
+        if bad:  # which one is the exact Euclidean distance transform there?
+            G = a.grid
+            obs = np.flatnonzero(occ1).astype(np.int64)
+            O = np.stack([obs // (G * G), (obs // G) % G, obs % G], -1)
+            for i in idx[:20]:
+                v = np.array([i // (G * G), (i // G) % G, i % G])
+                exact = int(((O - v) ** 2).sum(-1).min())
+                print(f"  voxel {tuple(v)}: ts{a.tile_shape} d2={d1[i]} ts{a.compare} d2={d2[i]} exact EDT d2={exact}")
         sys.exit(1 if bad else 0)
 
 
