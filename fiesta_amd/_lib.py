@@ -38,6 +38,11 @@ class Stats(C.Structure):
         return d
 
 
+class ShardInfo(C.Structure):
+    _fields_ = [("local_dims", C.c_int32 * 3), ("local_origin", C.c_int32 * 3), ("owned_lo", C.c_int32 * 3),
+                ("owned_hi", C.c_int32 * 3), ("global_grid", C.c_int32 * 3)]
+
+
 class RaycastParams(C.Structure):
     _fields_ = [("min_ray_length", C.c_double), ("max_ray_length", C.c_double), ("l_cornor", C.c_double * 3),
                 ("r_cornor", C.c_double * 3), ("dedup", C.c_int32), ("reserved", C.c_int32)]
@@ -97,8 +102,16 @@ def load():
         "fiesta_hip_snapshot_save": (C.c_int, [vp, i32]),
         "fiesta_hip_snapshot_restore": (C.c_int, [vp, i32]),
         "fiesta_hip_snapshot_count_updated": (C.c_int, [vp, i32, vp]),
-        "fiesta_hip_halo_pack_dev": (C.c_int, [vp, vp, vp, i32, vp, i64, vp]),
-        "fiesta_hip_halo_apply_dev": (C.c_int, [vp, vp, vp, vp, i64, vp]),
+        "fiesta_hip_shard_info_get": (C.c_int, [vp, vp]),
+        "fiesta_hip_halo_pack_dev": (C.c_int, [vp, vp, vp, vp]),
+        "fiesta_hip_halo_apply_dev": (C.c_int, [vp, vp, vp, vp, vp]),
+        "fiesta_hip_export_transitions_dev": (C.c_int, [vp, vp, i64, vp]),
+        "fiesta_hip_apply_transitions_dev": (C.c_int, [vp, vp, i64]),
+        "fiesta_hip_halo_pack": (C.c_int, [vp, vp, vp, vp]),
+        "fiesta_hip_halo_apply": (C.c_int, [vp, vp, vp, vp, vp]),
+        "fiesta_hip_export_transitions": (C.c_int, [vp, vp, i64, vp]),
+        "fiesta_hip_apply_transitions": (C.c_int, [vp, vp, i64]),
+        "fiesta_hip_esdf_seed": (C.c_int, [vp, vp]),
         "fiesta_hip_relax_pending": (C.c_int, [vp, vp, vp]),
         "fiesta_hip_synchronize": (C.c_int, [vp]),
     }

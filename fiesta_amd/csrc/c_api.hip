@@ -315,20 +315,92 @@ int fiesta_hip_snapshot_count_updated(fiesta_hip_map *m, int32_t slot, int64_t *
   });
 }
 
-int fiesta_hip_halo_pack_dev(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], int32_t only_changed,
-                             uint32_t *entries_dev, int64_t capacity, int64_t *n_out) {
+int fiesta_hip_shard_info_get(fiesta_hip_map *m, fiesta_hip_shard_info *out) {
   return guarded([&] {
-    need(lo && hi && n_out, "null argument");
-    *n_out = dense(m, "halo_pack").halo_pack(lo, hi, only_changed != 0, entries_dev, capacity);
+    need(out != nullptr, "null argument");
+    const fiesta::Geom &g = dense(m, "shard_info").geom();
+    out->local_dims[0] = g.nx, out->local_dims[1] = g.ny, out->local_dims[2] = g.nz;
+    out->local_origin[0] = g.gx0, out->local_origin[1] = g.gy0, out->local_origin[2] = g.gz0;
+    out->owned_lo[0] = g.ox0, out->owned_lo[1] = g.oy0, out->owned_lo[2] = g.oz0;
+    out->owned_hi[0] = g.ox1, out->owned_hi[1] = g.oy1, out->owned_hi[2] = g.oz1;
+    out->global_grid[0] = g.GX, out->global_grid[1] = g.GY, out->global_grid[2] = g.GZ;
   });
 }
-int fiesta_hip_halo_apply_dev(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3],
-                              const uint32_t *entries_dev, int64_t n, int64_t *n_improved) {
+int fiesta_hip_halo_pack_dev(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], uint32_t *out_dev) {
   return guarded([&] {
-    need(lo && hi, "null argument");
-    const int64_t k = dense(m, "halo_apply").halo_apply(lo, hi, entries_dev, n);
-    if (n_improved) *n_improved = k;
+    need(lo && hi && out_dev, "null argument");
+    dense(m, "halo_pack").halo_pack(lo, hi, out_dev);
   });
+}
+int fiesta_hip_halo_apply_dev(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], const uint32_t *in_dev,
+                              int64_t *n_changed) {
+  return guarded([&] {
+    need(lo && hi && in_dev, "null argument");
+    const int64_t k = dense(m, "halo_apply").halo_apply(lo, hi, in_dev);
+    if (n_changed) *n_changed = k;
+  });
+}
+int fiesta_hip_export_transitions_dev(fiesta_hip_map *m, uint32_t *out_dev, int64_t capacity, int64_t *n_out) {
+  return guarded([&] {
+    need(n_out != nullptr, "null argument");
+    *n_out = dense(m, "export_transitions").export_transitions(out_dev, capacity);
+  });
+}
+int fiesta_hip_apply_transitions_dev(fiesta_hip_map *m, const uint32_t *entries_dev, int64_t n) {
+  return guarded([&] {
+    need(n == 0 || entries_dev, "null argument");
+    dense(m, "apply_transitions").apply_transitions(entries_dev, n);
+  });
+}
+int fiesta_hip_halo_pack(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], uint32_t *out) {
+  return guarded([&] {
+    need(lo && hi && out, "null argument");
+    DenseMap &d = dense(m, "halo_pack");
+    const int64_t n = (int64_t)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+    need(n > 0, "empty box");
+    uint32_t *buf = d.scratch_u32(n);
+    d.halo_pack(lo, hi, buf);
+    d.copy_to_host(out, buf, n * sizeof(uint32_t));
+  });
+}
+int fiesta_hip_halo_apply(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], const uint32_t *in,
+                          int64_t *n_changed) {
+  return guarded([&] {
+    need(lo && hi && in, "null argument");
+    DenseMap &d = dense(m, "halo_apply");
+    const int64_t n = (int64_t)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+    need(n > 0, "empty box");
+    uint32_t *buf = d.scratch_u32(n);
+    d.copy_to_device(buf, in, n * sizeof(uint32_t));
+    const int64_t k = d.halo_apply(lo, hi, buf);
+    if (n_changed) *n_changed = k;
+  });
+}
+int fiesta_hip_export_transitions(fiesta_hip_map *m, uint32_t *out, int64_t capacity, int64_t *n_out) {
+  return guarded([&] {
+    need(n_out != nullptr, "null argument");
+    DenseMap &d = dense(m, "export_transitions");
+    const int64_t n = d.export_transitions(nullptr, 0);
+    *n_out = n;
+    if (!out || n == 0) return;
+    need(n <= capacity, "transition buffer too small");
+    uint32_t *buf = d.scratch_u32(n);
+    d.export_transitions(buf, n);
+    d.copy_to_host(out, buf, n * sizeof(uint32_t));
+  });
+}
+int fiesta_hip_apply_transitions(fiesta_hip_map *m, const uint32_t *entries, int64_t n) {
+  return guarded([&] {
+    need(n == 0 || entries, "null argument");
+    if (n == 0) return;
+    DenseMap &d = dense(m, "apply_transitions");
+    uint32_t *buf = d.scratch_u32(n);
+    d.copy_to_device(buf, entries, n * sizeof(uint32_t));
+    d.apply_transitions(buf, n);
+  });
+}
+int fiesta_hip_esdf_seed(fiesta_hip_map *m, fiesta_hip_stats *stats) {
+  return guarded([&] { dense(m, "esdf_seed").update_esdf(stats, true); });
 }
 int fiesta_hip_relax_pending(fiesta_hip_map *m, fiesta_hip_stats *stats, int64_t *pending) {
   return guarded([&] { dense(m, "relax_pending").relax_pending(stats, pending); });

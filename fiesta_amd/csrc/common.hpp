@@ -64,6 +64,8 @@ struct Geom {
   int ox0, oy0, oz0, ox1, oy1, oz1;  // owned box, local coords, inclusive (== whole array if unsharded)
   int wx0, wy0, wz0, wx1, wy1, wz1;  // update window (VoxInRange), local coords, inclusive
   int px0, py0, pz0, px1, py1, pz1;  // previous window (last_min_vec_/last_max_vec_)
+  int sharded;           // 1: this array is one shard (owned box + 2-voxel ghost layers) of a GX x GY x GZ grid
+  int GX, GY, GZ, GZW;   // global grid and words per z-row of the replicated global occupancy bitmap
   double org[3], res, res_inv;
   double lo[3], hi[3];  // min_range_/max_range_
   __host__ __device__ inline int64_t idx(int x, int y, int z) const { return ((int64_t)x * ny + y) * nz + z; }
@@ -78,6 +80,9 @@ struct Geom {
   }
   __host__ __device__ inline bool in_prev_window(int x, int y, int z) const {
     return x >= px0 && x <= px1 && y >= py0 && y <= py1 && z >= pz0 && z <= pz1;
+  }
+  __host__ __device__ inline int64_t gbitword(int gx, int gy, int gz) const {
+    return ((int64_t)gx * GY + gy) * GZW + (gz >> 5);
   }
   __host__ __device__ inline bool owned(int x, int y, int z) const {
     return x >= ox0 && x <= ox1 && y >= oy0 && y <= oy1 && z >= oz0 && z <= oz1;

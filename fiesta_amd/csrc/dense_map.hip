@@ -45,6 +45,16 @@ __device__ inline bool occ_test(const uint32_t *occbits, const Geom &g, int x, i
   return (occbits[g.bitword(x, y, z)] >> (z & 31)) & 1u;
 }
 
+// Is the obstacle at GLOBAL voxel (cx,cy,cz) still occupied?  Unsharded: the map's own bitmap.  Sharded: the
+// replicated global bitmap (kept in sync by export_transitions / apply_transitions), because a closest
+// obstacle may live on any shard.
+__device__ inline bool obstacle_alive(const Geom &g, const uint32_t *occbits, const uint32_t *gocc, int cx, int cy,
+                                      int cz) {
+  if (g.sharded) return (gocc[g.gbitword(cx, cy, cz)] >> (cz & 31)) & 1u;
+  const int x = cx - g.gx0, y = cy - g.gy0, z = cz - g.gz0;
+  return g.in_grid(x, y, z) && occ_test(occbits, g, x, y, z);
+}
+
 // ---- SetOccupancy(Vector3i,int), PROBABILISTIC branch (src/ESDFMap.cpp:417-437) ----
 // vox are map (global) voxel coordinates. No validation of occ here: the reference's Vector3i overload
 // does none either.
@@ -100,8 +110,8 @@ __global__ void k_observe_pos(Geom g, const double *pos, const int32_t *occ, int
 
 // ---- UpdateOccupancy (src/ESDFMap.cpp:235-271): one lane per touched voxel ----
 __global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *touched, int64_t n,
-                       unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *ins,
-                       uint32_t *del, unsigned long long *counters) {
+                       unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *gocc,
+                       uint32_t *ins, uint32_t *del, unsigned long long *counters) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t idx = touched[i];
@@ -124,9 +134,11 @@ __global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *to
   const uint32_t bit = 1u << (z & 31);
   if (now && !was) {  // free -> occupied: insert_queue_ (:263-264)
     atomicOr(&occbits[g.bitword(x, y, z)], bit);
+    if (g.sharded) atomicOr(&gocc[g.gbitword(x + g.gx0, y + g.gy0, z + g.gz0)], 1u << ((z + g.gz0) & 31));
     ins[atomicAdd(&counters[C_INSERT], 1ull)] = idx;
   } else if (!now && was) {  // occupied -> free: delete_queue_ (:265-266)
     atomicAnd(&occbits[g.bitword(x, y, z)], ~bit);
+    if (g.sharded) atomicAnd(&gocc[g.gbitword(x + g.gx0, y + g.gy0, z + g.gz0)], ~(1u << ((z + g.gz0) & 31)));
     del[atomicAdd(&counters[C_DELETE], 1ull)] = idx;
   }
 }
@@ -163,8 +175,8 @@ __global__ void k_seed_insert(Geom g, TileGrid tg, const uint32_t *ins, int64_t 
 // at the same obstacle). Such a voxel is reset to "no obstacle" and tagged as frontier seed; its re-seed
 // from the neighbourhood (:308-321) is simply its first pull in k_relax.
 __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits,
-                                                    uint32_t *flag, uint32_t *list, unsigned long long *count,
-                                                    unsigned long long *counters) {
+                                                    const uint32_t *gocc, uint32_t *flag, uint32_t *list,
+                                                    unsigned long long *count, unsigned long long *counters) {
   // one wave per 64-voxel run of a z-row: row and tile arithmetic is wave-uniform, loads are 256 B coalesced
   const int zchunks = (g.nz + 63) >> 6;
   const int64_t nitems = (int64_t)g.nx * g.ny * zchunks;
@@ -182,11 +194,7 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
       if (!(w & kNoCoc)) {
         int cx, cy, cz;
         unpack_coc(w, cx, cy, cz);
-        cx -= g.gx0;
-        cy -= g.gy0;
-        cz -= g.gz0;
-        // an obstacle that lives on another shard is invalidated by the halo protocol, not here
-        if (g.in_grid(cx, cy, cz) && !occ_test(occbits, g, cx, cy, cz) && g.owned(x, y, z)) {
+        if (g.owned(x, y, z) && !obstacle_alive(g, occbits, gocc, cx, cy, cz)) {
           coc[i] = kReset;
           reset = true;
         }
@@ -666,7 +674,8 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
         // push: |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2
         const vox_t c = lo & ~kAct;
         const int rcx = vx - (int)((c >> 20) & 1023), rcy = vy - (int)((c >> 10) & 1023), rcz = vz - (int)(c & 1023);
-        const int32_t dv = interior ? (int32_t)hi : rcx * rcx + rcy * rcy + rcz * rcz;
+        // source-only voxels (halo, ghost cells of a shard) keep d^2 = 0 in LDS: recompute theirs
+        const int32_t dv = hi ? (int32_t)hi : rcx * rcx + rcy * rcy + rcz * rcz;
         const int ax = 2 * rcx, ay = 2 * rcy, az = 2 * rcz;
         const unsigned long long keylo = (unsigned long long)(c | kAct);
         uint32_t dnv[24];
@@ -881,7 +890,7 @@ __global__ void k_export(Geom g, const vox_t *coc, const uint32_t *occbits, int3
 
 // "updated voxel" as SURVEY.md 8d defines it: d^2 differs, or the old closest obstacle vanished.
 __global__ void k_count_updated(Geom g, const vox_t *before, const vox_t *now, const uint32_t *occbits,
-                                unsigned long long *out) {
+                                const uint32_t *gocc, unsigned long long *out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned long long local = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += stride) {
@@ -895,10 +904,9 @@ __global__ void k_count_updated(Geom g, const vox_t *before, const vox_t *now, c
     if (!upd && !(a & kNoCoc)) {
       int cx, cy, cz;
       unpack_coc(a, cx, cy, cz);
-      cx -= g.gx0, cy -= g.gy0, cz -= g.gz0;
-      upd = g.in_grid(cx, cy, cz) && !occ_test(occbits, g, cx, cy, cz);
+      upd = !obstacle_alive(g, occbits, gocc, cx, cy, cz);
     }
-    local += upd;
+    local += upd && g.owned(x, y, z);
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
@@ -943,19 +951,33 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
     if (gg[i] > kMaxDim)
       throw Error(FIESTA_HIP_ERR_INVALID,
                   "grid extent exceeds 1024 voxels per axis (32-bit closest-obstacle words, see DESIGN.md)");
-  g.nx = gs[0];
-  g.ny = gs[1];
-  g.nz = gs[2];
-  g.gx0 = sharded ? cfg.shard_lo[0] : 0;
-  g.gy0 = sharded ? cfg.shard_lo[1] : 0;
-  g.gz0 = sharded ? cfg.shard_lo[2] : 0;
+  // Sharded: map_size is the OWNED box, shard_lo its global voxel origin; a 2-voxel ghost layer (the stencil
+  // radius) is added on every side that has a neighbour shard. origin stays the GLOBAL map origin.
+  int glo[3] = {0, 0, 0}, ghi[3] = {0, 0, 0};
+  if (sharded) {
+    for (int i = 0; i < 3; ++i) {
+      if (cfg.shard_lo[i] < 0 || cfg.shard_lo[i] + gs[i] > gg[i]) throw Error(FIESTA_HIP_ERR_INVALID, "shard box outside the global grid");
+      glo[i] = cfg.shard_lo[i] > 0 ? 2 : 0;
+      ghi[i] = cfg.shard_lo[i] + gs[i] < gg[i] ? 2 : 0;
+      g.hi[i] = cfg.origin[i] + gg[i] * cfg.resolution;
+    }
+  }
+  g.sharded = sharded ? 1 : 0;
+  g.GX = gg[0], g.GY = gg[1], g.GZ = gg[2];
+  g.GZW = (gg[2] + 31) / 32;
+  g.nx = gs[0] + glo[0] + ghi[0];
+  g.ny = gs[1] + glo[1] + ghi[1];
+  g.nz = gs[2] + glo[2] + ghi[2];
+  g.gx0 = sharded ? cfg.shard_lo[0] - glo[0] : 0;
+  g.gy0 = sharded ? cfg.shard_lo[1] - glo[1] : 0;
+  g.gz0 = sharded ? cfg.shard_lo[2] - glo[2] : 0;
   g.n = (int64_t)g.nx * g.ny * g.nz;
   if (g.n >= (1ll << 32)) throw Error(FIESTA_HIP_ERR_INVALID, "grid too large for 32-bit voxel indices");
   g.nzw = (g.nz + 31) / 32;
-  g.ox0 = g.oy0 = g.oz0 = 0;
-  g.ox1 = g.nx - 1;
-  g.oy1 = g.ny - 1;
-  g.oz1 = g.nz - 1;
+  g.ox0 = glo[0], g.oy0 = glo[1], g.oz0 = glo[2];
+  g.ox1 = glo[0] + gs[0] - 1;
+  g.oy1 = glo[1] + gs[1] - 1;
+  g.oz1 = glo[2] + gs[2] - 1;
   nbitwords_ = (int64_t)g.nx * g.ny * g.nzw;
 
   // tile_shape: 0 = default engine. 1..4 = v1 Jacobi-sweep engine (k_relax) with 8x8 / 16x8 / 16x16 / 4x8
@@ -971,6 +993,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
     case 12: tx_ = 16, ty_ = 8, engine_ = 1; break;
     default: throw Error(FIESTA_HIP_ERR_INVALID, "unknown tile_shape");
   }
+  if (sharded && engine_ != 1) throw Error(FIESTA_HIP_ERR_INVALID, "sharded maps need the work-queue engine");
   ntx_ = (g.nx + tx_ - 1) / tx_;
   nty_ = (g.ny + ty_ - 1) / ty_;
   ntz_ = (g.nz + 31) / 32;
@@ -984,6 +1007,11 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   FIESTA_HIP_CHECK(hipMalloc((void **)&cnt_, g.n * sizeof(unsigned long long)));
   FIESTA_HIP_CHECK(hipMalloc((void **)&occbits_, nbitwords_ * sizeof(uint32_t)));
   FIESTA_HIP_CHECK(hipMalloc((void **)&rbits_, nbitwords_ * sizeof(uint32_t)));
+  if (sharded) {
+    ngoccwords_ = (int64_t)g.GX * g.GY * g.GZW;
+    FIESTA_HIP_CHECK(hipMalloc((void **)&gocc_, ngoccwords_ * sizeof(uint32_t)));
+    FIESTA_HIP_CHECK(hipMemsetAsync(gocc_, 0, ngoccwords_ * sizeof(uint32_t), stream_));
+  }
   FIESTA_HIP_CHECK(hipMalloc((void **)&tile_epoch_, ntiles_ * sizeof(uint32_t)));
   for (int k = 0; k < 2; ++k) {
     FIESTA_HIP_CHECK(hipMalloc((void **)&cbits_[k], nbitwords_ * sizeof(uint32_t)));
@@ -1017,7 +1045,7 @@ DenseMap::~DenseMap() {
   free_raycast_state();
   void *ptrs[] = {coc_,          logodds_,      cnt_,          occbits_,      rbits_,     tile_epoch_,
                   tile_flag_[0], tile_flag_[1], tile_list_[0], tile_list_[1], counters_,  cbits_[0],
-                  cbits_[1],     cstamp_[0],    cstamp_[1]};
+                  cbits_[1],     cstamp_[0],    cstamp_[1],    gocc_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
@@ -1170,8 +1198,8 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
     ins_.ensure(ni + nt, stream_, ni);
     del_.ensure(nd + nt, stream_, nd);
     hipLaunchKernelGGL(k_fuse, dim3(grid_for((int64_t)nt)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
-                       (const uint32_t *)touched_.p, (int64_t)nt, cnt_, logodds_, coc_, occbits_, ins_.p, del_.p,
-                       counters_);
+                       (const uint32_t *)touched_.p, (int64_t)nt, cnt_, logodds_, coc_, occbits_, gocc_, ins_.p,
+                       del_.p, counters_);
     FIESTA_HIP_CHECK(hipGetLastError());
     zero_counter(C_TOUCHED);
     touched_upper_ = 0;
@@ -1308,19 +1336,20 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
   }
 }
 
-void DenseMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
+void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const auto h0 = std::chrono::steady_clock::now();
   FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   const unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
+  const bool remote_del = g_.sharded && read_counter(C_REMOTE_DEL) != 0;
   if (st) {
     memset(st, 0, sizeof(*st));
     st->inserted = (int64_t)ni;
     st->deleted = (int64_t)nd;
   }
-  if (ni == 0 && nd == 0) {
+  if (ni == 0 && nd == 0 && !seed_only) {
     if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     return;
   }
@@ -1335,13 +1364,20 @@ void DenseMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.c
                        tile_list_[0], &counters_[C_LIST0]);
     FIESTA_HIP_CHECK(hipGetLastError());
   }
-  if (nd) {
+  if (nd || remote_del) {
     hipLaunchKernelGGL(k_invalidate, dim3(grid_for(g_.n / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, tg, coc_,
-                       (const uint32_t *)occbits_, tile_flag_[0], tile_list_[0], &counters_[C_LIST0], counters_);
+                       (const uint32_t *)occbits_, (const uint32_t *)gocc_, tile_flag_[0], tile_list_[0],
+                       &counters_[C_LIST0], counters_);
     FIESTA_HIP_CHECK(hipGetLastError());
   }
   zero_counter(C_INSERT);
   zero_counter(C_DELETE);
+  if (g_.sharded) zero_counter(C_REMOTE_DEL);
+  if (seed_only) {  // sharded driver: ghost exchange comes next, then relax_pending()
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+    return;
+  }
   const uint32_t n0 = (uint32_t)read_counter(C_LIST0);
   run_rounds(st, n0, 0);
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
@@ -1553,16 +1589,126 @@ int64_t DenseMap::snapshot_count_updated(int slot) {
   zero_counter(C_SCRATCH);
   hipLaunchKernelGGL(k_count_updated, dim3(grid_for(g_.n, 256, 8192)), dim3(256), 0, stream_, g_,
                      (const vox_t *)snaps_[slot].coc.p, (const vox_t *)coc_, (const uint32_t *)occbits_,
+                     (const uint32_t *)gocc_, &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  return (int64_t)read_counter(C_SCRATCH);
+}
+
+// ---- multi-GPU: ghost-layer exchange and the replicated occupancy bitmap ----
+// Boxes are in LOCAL array coordinates, inclusive. pack copies the words of a box into a dense buffer
+// (x-major, z fastest); apply compares a received buffer with the local words of a box of the same shape
+// (ghost cells): a word that differs is replaced, tagged as a frontier source if it carries an obstacle, and
+// its tile is activated (list 0).
+__global__ void k_halo_pack(Geom g, int x0, int y0, int z0, int ex, int ey, int ez, const vox_t *coc, uint32_t *out) {
+  const int64_t n = (int64_t)ex * ey * ez;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int z = z0 + (int)(i % ez), y = y0 + (int)((i / ez) % ey), x = x0 + (int)(i / ((int64_t)ez * ey));
+    out[i] = coc[g.idx(x, y, z)];
+  }
+}
+__device__ inline vox_t strip_tag(vox_t w) { return w == kUnobserved ? w : (w & ~kAct); }
+__global__ void k_halo_apply(Geom g, TileGrid tg, int x0, int y0, int z0, int ex, int ey, int ez, vox_t *coc,
+                             const uint32_t *in, uint32_t *flag, uint32_t *list, unsigned long long *count,
+                             unsigned long long *changed) {
+  const int64_t n = (int64_t)ex * ey * ez;
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int z = z0 + (int)(i % ez), y = y0 + (int)((i / ez) % ey), x = x0 + (int)(i / ((int64_t)ez * ey));
+    const int64_t idx = g.idx(x, y, z);
+    const vox_t mine = strip_tag(coc[idx]), theirs = strip_tag(in[i]);
+    if (mine == theirs) continue;
+    ++local;
+    if (theirs & kNoCoc) {
+      coc[idx] = theirs;  // unobserved / no obstacle: not a source
+    } else {
+      coc[idx] = theirs | kAct;
+      const uint32_t t = tg.tile_of(x, y, z);
+      if (flag[t] == 0u) activate_tile(t, flag, list, count);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(changed, local);
+}
+// Occupancy transitions of this shard since the queues were last drained, as packed GLOBAL coordinates with
+// bit 31 = "occupied now" -- idempotent, order-free updates for the other shards' global bitmaps.
+__global__ void k_export_transitions(Geom g, const uint32_t *ins, int64_t ni, const uint32_t *del, int64_t nd,
+                                     const uint32_t *occbits, uint32_t *out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= ni + nd) return;
+  const uint32_t idx = i < ni ? ins[i] : del[i - ni];
+  const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
+  out[i] = pack_coc(x + g.gx0, y + g.gy0, z + g.gz0) | (occ_test(occbits, g, x, y, z) ? 0x80000000u : 0u);
+}
+__global__ void k_apply_transitions(Geom g, const uint32_t *ent, int64_t n, uint32_t *gocc,
+                                    unsigned long long *remote_del) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t e = ent[i];
+  int x, y, z;
+  unpack_coc(e & 0x3FFFFFFFu, x, y, z);
+  if (x >= g.GX || y >= g.GY || z >= g.GZ) return;
+  if (e & 0x80000000u)
+    atomicOr(&gocc[g.gbitword(x, y, z)], 1u << (z & 31));
+  else {
+    atomicAnd(&gocc[g.gbitword(x, y, z)], ~(1u << (z & 31)));
+    *remote_del = 1ull;  // voxels of THIS shard may point at it: the next UpdateESDF must run the invalidation scan
+  }
+}
+
+static void check_box(const Geom &g, const int32_t *lo, const int32_t *hi) {
+  if (lo[0] < 0 || lo[1] < 0 || lo[2] < 0 || hi[0] >= g.nx || hi[1] >= g.ny || hi[2] >= g.nz || hi[0] < lo[0] ||
+      hi[1] < lo[1] || hi[2] < lo[2])
+    throw Error(FIESTA_HIP_ERR_INVALID, "halo box outside the local array");
+}
+
+void DenseMap::halo_pack(const int32_t *lo, const int32_t *hi, uint32_t *out_dev) {
+  use_device();
+  check_box(g_, lo, hi);
+  const int ex = hi[0] - lo[0] + 1, ey = hi[1] - lo[1] + 1, ez = hi[2] - lo[2] + 1;
+  hipLaunchKernelGGL(k_halo_pack, dim3(grid_for((int64_t)ex * ey * ez, 256, 8192)), dim3(256), 0, stream_, g_, lo[0],
+                     lo[1], lo[2], ex, ey, ez, (const vox_t *)coc_, out_dev);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));  // the buffer is handed to another stream / RCCL next
+}
+
+int64_t DenseMap::halo_apply(const int32_t *lo, const int32_t *hi, const uint32_t *in_dev) {
+  use_device();
+  check_box(g_, lo, hi);
+  const int ex = hi[0] - lo[0] + 1, ey = hi[1] - lo[1] + 1, ez = hi[2] - lo[2] + 1;
+  TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
+  zero_counter(C_SCRATCH);
+  hipLaunchKernelGGL(k_halo_apply, dim3(grid_for((int64_t)ex * ey * ez, 256, 8192)), dim3(256), 0, stream_, g_, tg, lo[0],
+                     lo[1], lo[2], ex, ey, ez, coc_, in_dev, tile_flag_[0], tile_list_[0], &counters_[C_LIST0],
                      &counters_[C_SCRATCH]);
   FIESTA_HIP_CHECK(hipGetLastError());
   return (int64_t)read_counter(C_SCRATCH);
 }
 
-int64_t DenseMap::halo_pack(const int32_t *, const int32_t *, bool, uint32_t *, int64_t) {
-  throw Error(FIESTA_HIP_ERR_INVALID, "halo exchange is not available in this build");
+int64_t DenseMap::export_transitions(uint32_t *out_dev, int64_t cap) {
+  use_device();
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  const int64_t ni = (int64_t)h_counters_[C_INSERT], nd = (int64_t)h_counters_[C_DELETE];
+  if (out_dev == nullptr) return ni + nd;
+  if (ni + nd > cap) throw Error(FIESTA_HIP_ERR_INVALID, "transition buffer too small");
+  if (ni + nd) {
+    hipLaunchKernelGGL(k_export_transitions, dim3(grid_for(ni + nd)), dim3(256), 0, stream_, g_, (const uint32_t *)ins_.p,
+                       ni, (const uint32_t *)del_.p, nd, (const uint32_t *)occbits_, out_dev);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+  return ni + nd;
 }
-int64_t DenseMap::halo_apply(const int32_t *, const int32_t *, const uint32_t *, int64_t) {
-  throw Error(FIESTA_HIP_ERR_INVALID, "halo exchange is not available in this build");
+
+void DenseMap::apply_transitions(const uint32_t *ent_dev, int64_t n) {
+  use_device();
+  if (!g_.sharded) throw Error(FIESTA_HIP_ERR_STATE, "apply_transitions: not a sharded map");
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_apply_transitions, dim3(grid_for(n)), dim3(256), 0, stream_, g_, ent_dev, n, gocc_,
+                     &counters_[C_REMOTE_DEL]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
 void DenseMap::synchronize() {

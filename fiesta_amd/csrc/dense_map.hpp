@@ -47,6 +47,7 @@ enum Counter {
   C_WRITES,
   C_VISITS,
   C_SCRATCH,
+  C_REMOTE_DEL,  // sharded maps: some shard reported an occupied->free transition since the last UpdateESDF
   C_PROF0,  // 8 profiling slots (FIESTA_HIP_PROF=1): cycles in stage / propagate / write-back, queue items, ...
   C_COUNT = C_PROF0 + 8
 };
@@ -80,7 +81,7 @@ class DenseMap {
 
   bool check_update();
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
-  void update_esdf(fiesta_hip_stats *st);
+  void update_esdf(fiesta_hip_stats *st, bool seed_only = false);
   // continue relaxing tiles that are already flagged (after ghost entries were applied)
   void relax_pending(fiesta_hip_stats *st, int64_t *pending);
 
@@ -96,10 +97,28 @@ class DenseMap {
   void snapshot_restore(int slot);
   int64_t snapshot_count_updated(int slot);
 
-  int64_t halo_pack(const int32_t *lo, const int32_t *hi, bool only_changed, uint32_t *entries, int64_t cap);
-  int64_t halo_apply(const int32_t *lo, const int32_t *hi, const uint32_t *entries, int64_t n);
+  void halo_pack(const int32_t *lo, const int32_t *hi, uint32_t *out_dev);
+  int64_t halo_apply(const int32_t *lo, const int32_t *hi, const uint32_t *in_dev);
+  int64_t export_transitions(uint32_t *out_dev, int64_t cap);
+  void apply_transitions(const uint32_t *ent_dev, int64_t n);
 
   void synchronize();
+  // staging helpers for the host-buffer forms of the shard calls
+  uint32_t *scratch_u32(int64_t n) {
+    use_device();
+    stage_c_.ensure((size_t)n * sizeof(uint32_t), stream_);
+    return (uint32_t *)stage_c_.p;
+  }
+  void copy_to_host(void *dst, const void *src_dev, size_t bytes) {
+    use_device();
+    FIESTA_HIP_CHECK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+  void copy_to_device(void *dst_dev, const void *src, size_t bytes) {
+    use_device();
+    FIESTA_HIP_CHECK(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
 
   // raycast front end (raycast.hip)
   void raycast_frame(const float *points, int64_t n, const double *T, const double *origin,
@@ -133,6 +152,8 @@ class DenseMap {
   unsigned long long *cnt_ = nullptr;  // 8 B/voxel, cold: hits<<32 | observations (num_hit_/num_miss_)
   uint32_t *occbits_ = nullptr;        // 1 bit/voxel: Exist(idx)
   uint32_t *rbits_ = nullptr;          // 1 bit/voxel: voxel joined the frontier during the current update
+  uint32_t *gocc_ = nullptr;           // sharded maps: 1 bit/voxel of the GLOBAL grid, replicated on every shard
+  int64_t ngoccwords_ = 0;
   int64_t nbitwords_ = 0;
 
   // tiles

@@ -236,3 +236,69 @@ class ESDFMap:
 
     def synchronize(self):
         check(self._lib.fiesta_hip_synchronize(self._h))
+
+    # -- shard interface (driven by fiesta_amd.sharded.ShardedESDFMap) ---------------------------
+    def shard_info(self) -> dict:
+        info = _lib.ShardInfo()
+        check(self._lib.fiesta_hip_shard_info_get(self._h, C.byref(info)))
+        return {k: tuple(getattr(info, k)) for k, _ in _lib.ShardInfo._fields_}
+
+    def halo_pack(self, lo, hi) -> np.ndarray:
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        out = np.empty(tuple(int(b - a + 1) for a, b in zip(lo, hi)), np.uint32)
+        check(self._lib.fiesta_hip_halo_pack(self._h, _p(lo), _p(hi), _p(out)))
+        return out
+
+    def halo_apply(self, lo, hi, words) -> int:
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        assert w.size == int(np.prod(hi - lo + 1)), "halo buffer does not match the box"
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_halo_apply(self._h, _p(lo), _p(hi), _p(w), C.byref(n)))
+        return n.value
+
+    def halo_pack_dev(self, lo, hi, out_ptr: int):
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        check(self._lib.fiesta_hip_halo_pack_dev(self._h, _p(lo), _p(hi), C.c_void_p(out_ptr)))
+
+    def halo_apply_dev(self, lo, hi, in_ptr: int) -> int:
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_halo_apply_dev(self._h, _p(lo), _p(hi), C.c_void_p(in_ptr), C.byref(n)))
+        return n.value
+
+    def export_transitions(self) -> np.ndarray:
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_export_transitions(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        if n.value:
+            check(self._lib.fiesta_hip_export_transitions(self._h, _p(out), n.value, C.byref(n)))
+        return out
+
+    def apply_transitions(self, entries):
+        e = np.ascontiguousarray(entries, dtype=np.uint32)
+        check(self._lib.fiesta_hip_apply_transitions(self._h, _p(e), len(e)))
+
+    def export_transitions_dev(self, out_ptr: int, capacity: int) -> int:
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_export_transitions_dev(self._h, C.c_void_p(out_ptr) if out_ptr else None, capacity,
+                                                          C.byref(n)))
+        return n.value
+
+    def apply_transitions_dev(self, ptr: int, n: int):
+        check(self._lib.fiesta_hip_apply_transitions_dev(self._h, C.c_void_p(ptr), n))
+
+    def esdf_seed(self) -> dict:
+        st = Stats()
+        check(self._lib.fiesta_hip_esdf_seed(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def relax_pending(self):
+        st = Stats()
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_relax_pending(self._h, C.byref(st), C.byref(n)))
+        return n.value, st.as_dict()

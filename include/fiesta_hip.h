@@ -183,16 +183,44 @@ int fiesta_hip_snapshot_restore(fiesta_hip_map *m, int32_t slot);
  * occupied. */
 int fiesta_hip_snapshot_count_updated(fiesta_hip_map *m, int32_t slot, int64_t *updated);
 
-/* ---- multi-GPU halo exchange; used by the sharded driver ----
- * A shard owns its box plus a 2-voxel ghost layer. After a local UpdateESDF the driver packs the owned
- * boundary voxels that changed, sends them to the neighbouring ranks (RCCL via torch.distributed), and
- * applies received entries into the ghost layer, which re-activates the adjacent tiles. Entries are
- * 2 x uint32: {global linear-in-box index of the voxel, packed closest obstacle}. */
-int fiesta_hip_halo_pack_dev(fiesta_hip_map *m, const int32_t box_lo[3], const int32_t box_hi[3],
-                             int32_t only_changed, uint32_t *entries_dev, int64_t capacity, int64_t *n_out);
+/* ---- multi-GPU: one map = one SHARD of a larger grid; used by the sharded driver ----
+ * Create the shard with cfg.global_grid = the global extents, cfg.shard_lo = the global voxel origin of the box it
+ * OWNS, cfg.map_size = the owned extents in metres and cfg.origin = the GLOBAL map origin. The shard allocates a
+ * 2-voxel ghost layer (the stencil radius) on every side that has a neighbour; closest-obstacle ids are global.
+ * One UpdateESDF of the whole grid is, on every shard (all _dev pointers are on the shard's GPU):
+ *     update_occupancy -> export_transitions -> [all-gather] -> apply_transitions          (occupancy in sync)
+ *     esdf_seed -> { pack ghosts-to-be / [send,recv] / apply -> relax_pending } until no shard changed anything
+ * The [..] steps are RCCL collectives issued by the host driver (fiesta_amd/sharded.py over torch.distributed). */
+typedef struct fiesta_hip_shard_info {
+  int32_t local_dims[3];    /* extents of the local array (owned box + ghost layers) */
+  int32_t local_origin[3];  /* global voxel coordinates of local voxel (0,0,0) */
+  int32_t owned_lo[3];      /* owned box in LOCAL coordinates, inclusive */
+  int32_t owned_hi[3];
+  int32_t global_grid[3];
+} fiesta_hip_shard_info;
+int fiesta_hip_shard_info_get(fiesta_hip_map *m, fiesta_hip_shard_info *out);
+/* Copies the words of the inclusive LOCAL box [lo,hi] into out_dev (dense, z fastest); blocks until done. */
+int fiesta_hip_halo_pack_dev(fiesta_hip_map *m, const int32_t box_lo[3], const int32_t box_hi[3], uint32_t *out_dev);
+/* Overwrites the ghost cells of the inclusive LOCAL box with a neighbour's words; a cell that changed and carries
+ * an obstacle becomes a frontier source and wakes its tile. *n_changed (nullable) = cells that differed. */
 int fiesta_hip_halo_apply_dev(fiesta_hip_map *m, const int32_t box_lo[3], const int32_t box_hi[3],
-                              const uint32_t *entries_dev, int64_t n, int64_t *n_improved);
-/* Continue relaxation after ghost entries were applied (no queues consumed). */
+                              const uint32_t *in_dev, int64_t *n_changed);
+/* Occupancy transitions queued on this shard, as packed global coordinates (x<<20|y<<10|z) with bit 31 = occupied
+ * now. out_dev NULL: only the count. Does not consume the queues. */
+int fiesta_hip_export_transitions_dev(fiesta_hip_map *m, uint32_t *out_dev, int64_t capacity, int64_t *n_out);
+/* Applies transitions (of any shard, own ones included) to this shard's replica of the global occupancy bitmap. */
+int fiesta_hip_apply_transitions_dev(fiesta_hip_map *m, const uint32_t *entries_dev, int64_t n);
+/* Host-buffer forms of the four calls above (for transports that are not GPU-aware, and for tests). */
+int fiesta_hip_halo_pack(fiesta_hip_map *m, const int32_t box_lo[3], const int32_t box_hi[3], uint32_t *out);
+int fiesta_hip_halo_apply(fiesta_hip_map *m, const int32_t box_lo[3], const int32_t box_hi[3], const uint32_t *in,
+                          int64_t *n_changed);
+int fiesta_hip_export_transitions(fiesta_hip_map *m, uint32_t *out, int64_t capacity, int64_t *n_out);
+int fiesta_hip_apply_transitions(fiesta_hip_map *m, const uint32_t *entries, int64_t n);
+/* The seeding half of UpdateESDF (insert drain + delete invalidation, src/ESDFMap.cpp:278-337): consumes the
+ * queues and leaves the seeded tiles pending. */
+int fiesta_hip_esdf_seed(fiesta_hip_map *m, fiesta_hip_stats *stats);
+/* The relaxation half (src/ESDFMap.cpp:339-392): relaxes every pending tile to quiescence (no queues consumed).
+ * *pending_tiles (nullable) = tiles that were pending at entry. */
 int fiesta_hip_relax_pending(fiesta_hip_map *m, fiesta_hip_stats *stats, int64_t *pending_tiles);
 
 /* Blocks until all device work of the map has finished. */

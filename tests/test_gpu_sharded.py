@@ -1,0 +1,84 @@
+"""One grid cut into 1/2/4/8 shards (multiplexed on the one visible GPU through LocalTransport -- the same shard
+engine, halo kernels and driver loop the RCCL transport uses) against the single-grid CPU oracle
+(SURVEY.md 4 (iv), 8e).  Contract as everywhere: d^2 / occupancy bit-exact, closest obstacle tie-equivalent.
+"""
+import numpy as np
+import pytest
+
+from scenarios import D2_INF, P_DEFAULT, oracle_d2
+
+pytestmark = pytest.mark.gpu
+
+
+def drive(sharded, cpu, vox_occ_cycles):
+    for occ_vox, free_vox, cycles in vox_occ_cycles:
+        for _ in range(cycles):
+            for v, o in ((occ_vox, 1), (free_vox, 0)):
+                if len(v):
+                    sharded.SetOccupancy(v, o)
+                    cpu.SetOccupancyVox(v, o)
+            a, b = sharded.UpdateOccupancy(True), cpu.UpdateOccupancy(True)
+            assert a == b and (sharded.last_insert, sharded.last_delete) == (cpu.last_insert, cpu.last_delete)
+        sg, sc = sharded.UpdateESDF(), cpu.UpdateESDF()
+        assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+
+
+def compare(sharded, cpu, gs):
+    f = sharded.assemble()
+    o = cpu.dump_dense()
+    od2, vox = oracle_d2(o, gs)
+    assert np.array_equal(f["occ"], o["occ"])
+    gd2 = f["d2"].astype(np.int64)
+    assert np.array_equal(gd2 < 0, od2 < 0)
+    assert int((gd2 != od2).sum()) == 0, np.flatnonzero(gd2 != od2)[:10]
+    have = (gd2 >= 0) & (gd2 != D2_INF)
+    gc = f["coc"].astype(np.int64)
+    gi = (gc[have, 0] * gs[1] + gc[have, 1]) * gs[2] + gc[have, 2]
+    assert np.all(f["occ"][gi] == 1)
+    assert np.array_equal(((vox[have] - gc[have]) ** 2).sum(-1), gd2[have])
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 4, 8])
+def test_sharded_matches_single_grid_oracle(hip_lib, oracle_libs, best_oracle_kind, n_shards):
+    from fiesta_amd.sharded import ShardedESDFMap
+    gs, res = (72, 64, 80), 0.1
+    sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards)
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res), kind=best_oracle_kind)
+    assert cpu.grid_size == gs
+    for m in (sm, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    allv = np.stack(np.meshgrid(*[np.arange(n) for n in gs], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    rng = np.random.RandomState(3)
+    S = (rng.rand(500, 3) * gs).astype(np.int32)
+    # obstacles hugging the cuts: shard faces are at 36 / 32 / 40
+    S[:60, 0] = rng.randint(34, 38, 60)
+    S[60:120, 1] = rng.randint(30, 34, 60)
+    S[120:180, 2] = rng.randint(38, 42, 60)
+    drive(sm, cpu, [([], allv, 1), (S, [], 3)])
+    compare(sm, cpu, gs)
+    drive(sm, cpu, [((rng.rand(150, 3) * gs).astype(np.int32), S[:250], 6)])
+    compare(sm, cpu, gs)
+    occ = np.argwhere(cpu.dump_dense(("occ",))["occ"].reshape(gs) == 1).astype(np.int32)
+    drive(sm, cpu, [([], occ, 6)])
+    compare(sm, cpu, gs)
+    assert sm.last_sweeps >= 2
+    sm.close()
+
+
+def test_single_obstacle_wave_crosses_every_shard(hip_lib, oracle_libs, best_oracle_kind):
+    """The adversarial case of SURVEY.md 8e: one obstacle in a corner, its wave must cross all 8 shards."""
+    from fiesta_amd.sharded import ShardedESDFMap
+    gs, res = (64, 64, 64), 0.1
+    sm = ShardedESDFMap((0, 0, 0), res, gs, 8)
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res), kind=best_oracle_kind)
+    for m in (sm, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    allv = np.stack(np.meshgrid(*[np.arange(n) for n in gs], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    drive(sm, cpu, [([], allv, 1), (np.array([[1, 2, 3]], np.int32), [], 3)])
+    compare(sm, cpu, gs)
+    assert sm.last_sweeps >= 3
+    drive(sm, cpu, [(np.array([[60, 61, 59]], np.int32), np.array([[1, 2, 3]], np.int32), 6)])
+    compare(sm, cpu, gs)
+    sm.close()
