@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--tile-shape", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=192)
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded driver even with one rank (smoke test)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="with --gpus N: N independent maps instead of one spatially sharded map")
     return ap.parse_args()
 
 
@@ -150,17 +153,37 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if world == 1:  # single-rank smoke test of the sharded driver (no launcher): rendezvous on loopback
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     G, res = args.grid, 0.1
-    m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, device=local_rank, tile_shape=args.tile_shape)
-    assert m.grid_total_size_ == G ** 3, "grid rounding (SURVEY.md 7.3-G)"
-    m.SetParameters(*P_DEFAULT)
-    m.SetOriginalRange()
+    sharded_map = None
+    if (world > 1 and not args.replicas) or args.force_sharded:
+        # ONE map, spatially sharded: every rank owns a G^3 box of a (layout * G)^3 grid -> weak scaling
+        from fiesta_amd.sharded import DistTransport, ShardedESDFMap, rank_coords, shard_layout
+        layout = shard_layout(world)
+        gg = tuple(G * l for l in layout)
+        sharded_map = ShardedESDFMap((0, 0, 0), res, gg, world, transport=DistTransport(dev), devices=(local_rank,),
+                                     tile_shape=args.tile_shape)
+        m = sharded_map.shards[rank]
+        box_lo = np.array(rank_coords(rank, layout)) * G
+        sharded_map.SetParameters(*P_DEFAULT)
+        sharded_map.SetOriginalRange()
+    else:
+        m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, device=local_rank, tile_shape=args.tile_shape)
+        assert m.grid_total_size_ == G ** 3, "grid rounding (SURVEY.md 7.3-G)"
+        box_lo = np.zeros(3, int)
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    top = sharded_map if sharded_map is not None else m   # UpdateOccupancy / UpdateESDF go through the driver
 
     def dev_batch(vox, occ):
         v = torch.from_numpy(np.ascontiguousarray(vox, dtype=np.int32)).to(dev)
@@ -172,28 +195,21 @@ def main():
         m.SetOccupancyDevice(v.data_ptr(), o.data_ptr(), v.shape[0])
 
     # ---- prologue: observe every voxel free once (nothing propagates through unobserved voxels)
-    chunk = 64
-    for x0 in range(0, G, chunk):
-        xs = torch.arange(x0, min(G, x0 + chunk), device=dev, dtype=torch.int32)
-        ys = torch.arange(G, device=dev, dtype=torch.int32)
-        zs = torch.arange(G, device=dev, dtype=torch.int32)
-        v = torch.stack(torch.meshgrid(xs, ys, zs, indexing="ij"), -1).reshape(-1, 3).contiguous()
-        o = torch.zeros(v.shape[0], dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        m.SetOccupancyDevice(v.data_ptr(), o.data_ptr(), v.shape[0])
-        m.synchronize()
-        del v, o
-    m.UpdateOccupancy(True)
-    m.UpdateESDF()
+    m.SetOccupancyBox(tuple(int(v) for v in box_lo), tuple(int(v) for v in box_lo + G - 1), 0)
+    top.UpdateOccupancy(True)
+    top.UpdateESDF()
 
     # ---- scene A: scatter insert of all obstacles into the empty observed grid (reported, not the step)
     w = Workload(G, args.obstacles, seed=12345 + 1000 * rank)
-    init = dev_batch(w.initial(), np.ones(args.obstacles, np.int32))
+    init = dev_batch(w.initial() + box_lo.astype(np.int32), np.ones(args.obstacles, np.int32))
     for _ in range(3):
         observe(init)
-        m.UpdateOccupancy(True)
+        top.UpdateOccupancy(True)
     m.snapshot_save(0)
-    st_scatter = m.UpdateESDF()
+    t_sc = time.perf_counter()
+    st_scatter = top.UpdateESDF()
+    st_scatter.setdefault("host_ms", (time.perf_counter() - t_sc) * 1e3)
+    st_scatter.setdefault("device_ms", st_scatter["host_ms"])
     scatter_updated = m.snapshot_count_updated(0)
 
     # ---- pre-stage every step's input in HBM
@@ -201,6 +217,7 @@ def main():
     staged = []
     for _ in range(nsteps):
         new, old = w.next_step()
+        new, old = new + box_lo.astype(np.int32), old + box_lo.astype(np.int32)
         hits = dev_batch(new, np.ones(len(new), np.int32))
         both = dev_batch(np.concatenate([new, old]), np.concatenate([np.ones(len(new), np.int32), np.zeros(len(old), np.int32)]))
         staged.append((hits, both))
@@ -209,14 +226,18 @@ def main():
     def step(k, account=False):
         hits, both = staged[k]
         observe(hits)
-        m.UpdateOccupancy(True)
+        top.UpdateOccupancy(True)
         observe(hits)
-        m.UpdateOccupancy(True)
+        top.UpdateOccupancy(True)
         observe(both)
-        m.UpdateOccupancy(True)
+        top.UpdateOccupancy(True)
         if account:
             m.snapshot_save(2)
-        st = m.UpdateESDF()
+        t_up = time.perf_counter()
+        st = top.UpdateESDF()
+        st.setdefault("host_ms", (time.perf_counter() - t_up) * 1e3)
+        st.setdefault("device_ms", st["host_ms"])
+        st.setdefault("relax_launches", st.get("rounds", 0))
         if account:
             st["updated"] = m.snapshot_count_updated(2)
         return st
@@ -275,7 +296,11 @@ def main():
                             f"per step a {args.obstacles}-voxel delta = {args.obstacles // 2} inserts + {args.obstacles // 2} deletes "
                             "landing in one UpdateESDF (ingest: 3 SetOccupancy+UpdateOccupancy cycles, inputs resident in HBM)",
                 "grid": [G, G, G], "delta_voxels": args.obstacles,
-                "parallelism": "single GPU" if world == 1 else f"{world} independent map replicas (one per GPU)",
+                "parallelism": "single GPU" if world == 1 else (
+                    f"{world} independent map replicas (one per GPU)" if sharded_map is None else
+                    f"one map of {'x'.join(str(G * l) for l in layout)} voxels sharded {'x'.join(map(str, layout))} over {world} GPUs "
+                    f"({G}^3 owned per GPU + 2-voxel ghost layer; RCCL ghost exchange + transition all-gather, "
+                    f"{statistics.mean(s_['sweeps'] for s_ in timed):.1f} ghost sweeps per update)"),
                 "tile_shape": args.tile_shape,
             },
             "update_esdf_p50_ms": statistics.median(s["host_ms"] for s in timed),
@@ -289,7 +314,7 @@ def main():
                                     "voxels_per_sec": scatter_updated / (st_scatter["host_ms"] * 1e-3),
                                     "roofline_frac": scatter_updated * 16 / (st_scatter["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "roofline": {
-                "bound": "hbm", "kernel": "k_relax", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_relax_q", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "launches": launches, "avg_launch_us": relax_ms * 1e3 / max(1, launches),
                 "algorithmic_bytes_per_launch": my_updated * ALGO_BYTES_PER_UPDATED_VOXEL / max(1, launches),

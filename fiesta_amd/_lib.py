@@ -58,6 +58,27 @@ def declared_symbols(header_path: str = HEADER_PATH):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (+ HSA runtime); libfiesta_hip.so needs the same
+    SONAME from /opt/rocm.  Two HIP runtimes cannot share a process ("No HIP GPUs are available" in whichever
+    initialises second), and which one wins would otherwise depend on import order.  If torch is installed, bind
+    to its copy -- torch is only plumbing here (device buffers for the RCCL transport, bench.py), but it must be
+    able to coexist.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch's runtime is already mapped; the dynamic loader will reuse it by SONAME
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libfiesta_hip.so (raises FiestaHipError if it has not been built)."""
     global _lib
@@ -66,6 +87,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise FiestaHipError(-1, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     sig = {

@@ -1533,6 +1533,10 @@ void DenseMap::snapshot_save(int slot) {
   FIESTA_HIP_CHECK(hipMemcpyAsync(s.logodds.p, logodds_, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
   FIESTA_HIP_CHECK(hipMemcpyAsync(s.cnt.p, cnt_, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
   FIESTA_HIP_CHECK(hipMemcpyAsync(s.occbits.p, occbits_, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  if (gocc_) {
+    s.gocc.ensure(ngoccwords_, stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(s.gocc.p, gocc_, ngoccwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  }
   const size_t nt = s.counters[C_TOUCHED], ni = s.counters[C_INSERT], nd = s.counters[C_DELETE];
   if (nt) {
     s.touched.ensure(nt, stream_);
@@ -1560,6 +1564,7 @@ void DenseMap::snapshot_restore(int slot) {
   FIESTA_HIP_CHECK(hipMemcpyAsync(logodds_, s.logodds.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
   FIESTA_HIP_CHECK(hipMemcpyAsync(cnt_, s.cnt.p, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
   FIESTA_HIP_CHECK(hipMemcpyAsync(occbits_, s.occbits.p, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  if (gocc_) FIESTA_HIP_CHECK(hipMemcpyAsync(gocc_, s.gocc.p, ngoccwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
   const size_t nt = s.counters[C_TOUCHED], ni = s.counters[C_INSERT], nd = s.counters[C_DELETE];
   if (nt) {
     touched_.ensure(nt, stream_);

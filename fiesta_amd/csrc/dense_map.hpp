@@ -56,7 +56,7 @@ struct Snapshot {
   DevBuf<vox_t> coc;
   DevBuf<double> logodds;
   DevBuf<unsigned long long> cnt;
-  DevBuf<uint32_t> occbits;
+  DevBuf<uint32_t> occbits, gocc;
   DevBuf<uint32_t> touched, ins, del;
   unsigned long long counters[C_COUNT];
   Geom g;

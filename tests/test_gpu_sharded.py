@@ -82,3 +82,42 @@ def test_single_obstacle_wave_crosses_every_shard(hip_lib, oracle_libs, best_ora
     drive(sm, cpu, [(np.array([[60, 61, 59]], np.int32), np.array([[1, 2, 3]], np.int32), 6)])
     compare(sm, cpu, gs)
     sm.close()
+
+
+def test_device_pointer_halo_path_equals_host_path(hip_lib):
+    """The RCCL transport hands device buffers to halo_pack_dev / halo_apply_dev; same result as the host forms."""
+    import torch  # noqa: F401  (device buffers)
+    from fiesta_amd.sharded import ShardedESDFMap
+    gs, res = (40, 24, 36), 0.1
+    maps = [ShardedESDFMap((0, 0, 0), res, gs, 2) for _ in range(2)]
+    rng = np.random.RandomState(1)
+    S = (rng.rand(80, 3) * gs).astype(np.int32)
+    for sm in maps:
+        sm.SetParameters(*P_DEFAULT)
+        sm.SetOriginalRange()
+        sm.SetOccupancyBox((0, 0, 0), tuple(np.array(gs) - 1), 0)
+        sm.UpdateOccupancy(True)
+        for _ in range(3):
+            sm.SetOccupancy(S, 1)
+            sm.UpdateOccupancy(True)
+        for sh in sm.shards.values():
+            sh.esdf_seed()
+    a, b = maps
+    dev = torch.device("cuda", 0)
+    changed = [0, 0]
+    for r in (0, 1):
+        for peer, slo, shi, rlo, rhi in a.plans[r][0]:
+            # host path on map a
+            changed[0] += a.shards[peer].halo_apply(a.plans[peer][0][0][3], a.plans[peer][0][0][4], a.shards[r].halo_pack(slo, shi))
+            # device path on map b
+            n = int(np.prod(shi - slo + 1))
+            buf = torch.empty(n, dtype=torch.int32, device=dev)
+            b.shards[r].halo_pack_dev(slo, shi, buf.data_ptr())
+            torch.cuda.synchronize()
+            changed[1] += b.shards[peer].halo_apply_dev(b.plans[peer][0][0][3], b.plans[peer][0][0][4], buf.data_ptr())
+    assert changed[0] == changed[1] > 0
+    for r in (0, 1):
+        fa, fb = a.shards[r].download_field(("d2", "coc")), b.shards[r].download_field(("d2", "coc"))
+        assert np.array_equal(fa["d2"], fb["d2"]) and np.array_equal(fa["coc"], fb["coc"])
+    for sm in maps:
+        sm.close()
