@@ -1,0 +1,409 @@
+// fiesta_amd/csrc/relax_kernels.hpp -- device code shared by the dense-array map (dense_map.hip) and the paged
+// hash-block map (hash_map.hip): tile bookkeeping and the work-queue relaxation kernel k_relax_q.
+#pragma once
+#include "common.hpp"
+#include "dense_map.hpp"
+
+namespace fiesta {
+
+__device__ inline bool occ_test(const uint32_t *occbits, const Geom &g, int x, int y, int z) {
+  return (occbits[g.bitword(x, y, z)] >> (z & 31)) & 1u;
+}
+
+struct TileGrid {
+  int tx, ty;  // tile extent in x and y (z extent is 32)
+  int ntx, nty, ntz;
+  __device__ inline int tile_of(int x, int y, int z) const { return ((x / tx) * nty + (y / ty)) * ntz + (z >> 5); }
+};
+
+__device__ inline void activate_tile(uint32_t t, uint32_t *flag, uint32_t *list, unsigned long long *count) {
+  if (atomicExch(&flag[t], 1u) == 0u) list[atomicAdd(count, 1ull)] = t;
+}
+
+// =====================================================================================================
+// k_relax_q -- work-efficient tile relaxation: an LDS work queue instead of Jacobi sweeps.
+//
+// The reference pops one voxel at a time and runs 24 pulls + 24 pushes for it (src/ESDFMap.cpp:339-392),
+// ~1.04 expansions per updated voxel.  k_relax (above) keeps lanes on fixed voxels and re-reads all 24
+// neighbours of EVERY voxel in EVERY sweep, which costs ~20 sweeps x 24 LDS reads per voxel per visit.
+// Here a tile + 2-voxel halo is staged in LDS as 64-bit keys  (d^2 << 32 | closest obstacle | flag)  and
+// only voxels whose key CHANGED do work, exactly like the reference's queue:
+//   * push   a changed voxel v offers its obstacle c to its 24 neighbours n.  |n-c|^2 is not recomputed:
+//            |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2  (two integer adds per direction); a plain 32-bit read
+//            of d(n) filters, ds_min_u64 on the key decides, the winner is appended to the next level's
+//            queue (level-synchronous inside the tile, one barrier per level).
+//   * pull   a voxel that goes from "no obstacle" to a finite distance (first reached by a wave, or
+//            orphaned by a delete: the re-seed of :308-321) asks the neighbours whose value predates
+//            this UpdateESDF -- they are a fixed point among themselves and would never push.  Neighbours
+//            that changed during this update push by themselves, so they are skipped (flag bit 30 in LDS
+//            = "joined the frontier during this update" = the rbits bitmap in HBM).
+// Halo voxels are sources only (their d^2 field is 0, so no push can ever win against them); a halo voxel
+// offers its obstacle iff it changed in the PREVIOUS round (cbits bitmap, double-buffered by round
+// parity and validated by a per-tile round stamp) or still carries a seed tag in HBM.
+// =====================================================================================================
+struct RelaxQArgs {
+  Geom g;
+  TileGrid tg;
+  vox_t *coc;
+  uint32_t *rbits;
+  uint32_t *tile_epoch;
+  uint32_t epoch;
+  uint32_t *cbits_prev;   // written by the previous round (read here for halo voxels)
+  uint32_t *cbits_cur;    // written by this round
+  const uint32_t *cstamp_prev;
+  uint32_t *cstamp_cur;
+  uint32_t serial;        // serial number of this round; stamps equal to serial-1 validate cbits_prev
+  const uint32_t *list_cur;
+  uint32_t n_cur;
+  uint32_t *flag_cur;
+  uint32_t *flag_next;
+  uint32_t *list_next;
+  unsigned long long *count_next;
+  unsigned long long *counters;
+  int prof;  // 1: accumulate per-phase cycle counters into counters[C_PROF0..]
+  // paged (hash-block) maps: voxel data lives in a pool of pages, one page = one tile (TX x TY x 32 voxels, same
+  // z-fastest row layout), found through the dense page directory dir[tile] (-1: not allocated = all unobserved)
+  const int32_t *dir;
+};
+
+template <int TX, int TY, int NT, bool PAGED = false>
+__global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
+  constexpr int TZ = 32, H = 2;
+  constexpr int RX = TX + 2 * H, RY = TY + 2 * H, RZ = TZ + 2 * H;
+  constexpr int RSIZE = RX * RY * RZ;
+  constexpr int NW = (RSIZE + 63) / 64 * 2;  // bitmap words (32 voxels each), padded to whole waves
+  constexpr int RPAD = NW * 32;
+  constexpr int ITER = RPAD / NT + (RPAD % NT ? 1 : 0);
+  constexpr int SLOTS = NT / 32, RPT = TX * TY / SLOTS;
+  constexpr int NWAVE = NT / 64;
+  constexpr int NROWW = RX * RY * 3;  // staged bitmap words: 3 z-words per (x,y) row of the region
+  static_assert(NT % 64 == 0 && (TX * TY) % SLOTS == 0 && RPT <= 32 && RSIZE < 65536 && NW <= NT, "tile shape");
+  __shared__ unsigned long long K[RSIZE];
+  __shared__ uint16_t Q[RSIZE];
+  __shared__ uint32_t F[2][NW], E[NW], P[NW];
+  __shared__ uint32_t rb[NROWW], cb[NROWW];
+  __shared__ uint32_t wsum[NWAVE];
+  __shared__ uint32_t n_oldvalid;
+  __shared__ uint32_t nb_ok[27];
+  __shared__ int32_t nb_page[27];
+  __shared__ int nbr_dirty[27];
+  constexpr int PAGE_VOX = TX * TY * TZ, PAGE_ROWS = TX * TY;
+  volatile uint32_t *K32 = (volatile uint32_t *)K;
+
+  const Geom &g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  for (uint32_t li = blockIdx.x; li < a.n_cur; li += gridDim.x) {
+    const uint32_t t = a.list_cur[li];
+    const int tz = t % a.tg.ntz, ty = (t / a.tg.ntz) % a.tg.nty, tx = t / (a.tg.ntz * a.tg.nty);
+    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+    const int bx = g.gx0 + x0 - H, by = g.gy0 + y0 - H, bz = g.gz0 + z0 - H;  // global coords of r-index 0
+    const bool prof = a.prof != 0;
+    uint32_t n_items = 0;
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (prof) t0 = clock64();
+    if (tid == 0) {
+      a.flag_cur[t] = 0;
+      n_oldvalid = 0;
+    }
+    if (tid < 27) {
+      nbr_dirty[tid] = 0;
+      const int ox = tid / 9 - 1, oy = (tid / 3) % 3 - 1, oz = tid % 3 - 1;
+      const int ux = tx + ox, uy = ty + oy, uz = tz + oz;
+      uint32_t ok = 0;
+      int32_t pg = -1;
+      if ((unsigned)ux < (unsigned)a.tg.ntx && (unsigned)uy < (unsigned)a.tg.nty && (unsigned)uz < (unsigned)a.tg.ntz) {
+        const uint32_t ot = (ux * a.tg.nty + uy) * a.tg.ntz + uz;
+        if (PAGED) pg = a.dir[ot];
+        if (!PAGED || pg >= 0) {
+          if (a.tile_epoch[ot] == a.epoch) ok |= 1u;
+          if (tid != 13 && a.cstamp_prev[ot] == a.serial - 1u) ok |= 2u;
+        }
+      }
+      nb_ok[tid] = ok;
+      nb_page[tid] = pg;
+    }
+    __syncthreads();  // nb_ok
+    // ---- stage the frontier bitmaps of the region's rows (3 z-words per row) through LDS
+    for (int j = tid; j < NROWW; j += NT) {
+      const int k = j % 3, ry = (j / 3) % RY, rx = j / (3 * RY);
+      const int x = x0 - H + rx, y = y0 - H + ry, zt = tz - 1 + k;
+      const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1);
+      const uint32_t ok = nb_ok[ox * 9 + oy * 3 + k];
+      uint32_t r = 0, c = 0;
+      if (ok && (unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny) {
+        const int64_t wi = PAGED ? (int64_t)nb_page[ox * 9 + oy * 3 + k] * PAGE_ROWS + ((x % TX) * TY + (y % TY))
+                                 : ((int64_t)x * g.ny + y) * g.nzw + zt;
+        if (ok & 1u) r = a.rbits[wi];
+        if (ok & 2u) c = a.cbits_prev[wi];
+      }
+      rb[j] = r;
+      cb[j] = c;
+    }
+    // ---- raw voxel words -> low halves of the keys (independent loads, issued back to back)
+    {
+      constexpr int UB = 8;
+      for (int i0 = tid; i0 < RSIZE; i0 += UB * NT) {
+        vox_t wv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int i = min(i0 + u * NT, RSIZE - 1);
+          const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
+          const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
+          bool ok = g.in_grid(x, y, z) && g.in_window(x, y, z);
+          int64_t idx;
+          if (PAGED) {
+            const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1),
+                      oz = (rz < H) ? 0 : ((rz >= TZ + H) ? 2 : 1);
+            const int32_t pg = nb_page[ox * 9 + oy * 3 + oz];
+            ok = ok && pg >= 0;
+            idx = (int64_t)max(pg, 0) * PAGE_VOX + (((x & (TX - 1)) * TY + (y & (TY - 1))) * TZ + (z & (TZ - 1)));
+          } else {
+            idx = g.idx(min(max(x, 0), g.nx - 1), min(max(y, 0), g.ny - 1), min(max(z, 0), g.nz - 1));
+          }
+          const vox_t w = a.coc[idx];  // always a legal address: the load never sits behind a branch
+          wv[u] = ok ? w : kUnobserved;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (i0 + u * NT < RSIZE) K32[2 * (i0 + u * NT)] = wv[u];
+      }
+    }
+    __syncthreads();
+    const bool own_epoch = nb_ok[13] & 1u;
+
+    // ---- build the keys; collect the level-0 frontier
+    uint32_t oldvalid = 0;
+#pragma unroll 1
+    for (int k = 0; k < ITER; ++k) {
+      const int i = tid + k * NT;
+      bool ever = false, pull = false, front = false;
+      if (i < RSIZE) {
+        const vox_t w = K32[2 * i];
+        uint32_t lo = kUnobserved, hi = 0;
+        if (w != kUnobserved) {
+          const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
+          const bool act = (w & kAct) != 0;
+          const bool valid = !(w & kNoCoc);
+          const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
+                                (unsigned)(rz - H) < (unsigned)TZ;
+          const int zq = rz + (TZ - H);  // z - (z0 - TZ)
+          const int j = (rx * RY + ry) * 3 + (zq >> 5);
+          const uint32_t bit = 1u << (zq & 31);
+          const bool upd = interior && g.owned(x0 - H + rx, y0 - H + ry, z0 - H + rz);
+          const bool src = !upd && valid && (act || (cb[j] & bit));
+          // "joined the frontier during this update": own voxels from the tile's own bitmap; a halo voxel
+          // only if it offers its obstacle in this very visit (a neighbour tile that runs concurrently may
+          // already have published a newer bitmap than the value loaded above)
+          const bool inR = upd ? (act || (rb[j] & bit)) : src;
+          const vox_t c = w & ~kAct;
+          lo = (valid ? c : kInf) | (inR ? kAct : 0u);
+          if (upd) {
+            hi = valid ? (uint32_t)dist2(bx + rx, by + ry, bz + rz, c) : (uint32_t)kD2Inf;
+            if (act) {
+              ever = true;
+              front = true;
+              pull = !valid;  // orphaned by a delete: re-seed from the neighbourhood (:308-321)
+            }
+          } else {
+            front = src;  // a source only: its d^2 field stays 0
+          }
+          if (valid && !inR) ++oldvalid;
+        }
+        K[i] = ((unsigned long long)hi << 32) | lo;
+      }
+      const unsigned long long me = __ballot(ever), mp = __ballot(pull), mf = __ballot(front);
+      if ((tid & 31) == 0 && i < RPAD) {
+        const int wq = i >> 5;
+        const bool upper = tid & 32;
+        E[wq] = upper ? (uint32_t)(me >> 32) : (uint32_t)me;
+        P[wq] = upper ? (uint32_t)(mp >> 32) : (uint32_t)mp;
+        F[0][wq] = upper ? (uint32_t)(mf >> 32) : (uint32_t)mf;
+        F[1][wq] = 0;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) oldvalid += __shfl_down(oldvalid, off);
+    if (lane == 0 && oldvalid) atomicAdd(&n_oldvalid, oldvalid);
+    if (prof) t1 = clock64();
+
+    // ---- level-synchronous propagation inside the tile
+    uint32_t level = 0;
+    for (;; ++level) {
+      const int cur = level & 1;
+      __syncthreads();  // every push of the previous level has landed in F[cur]
+      const bool pulls_enabled = n_oldvalid != 0;
+      // compact the frontier bitmap into the work queue
+      uint32_t bits = 0;
+      if (tid < NW) {
+        bits = F[cur][tid];
+        F[cur][tid] = 0;
+        if (bits) E[tid] |= bits;
+      }
+      uint32_t incl = __popc(bits);
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      uint32_t base = incl - __popc(bits), total = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) {
+        const uint32_t s = wsum[w];
+        if (w < wave) base += s;
+        total += s;
+      }
+      while (bits) {
+        const int bpos = __ffs(bits) - 1;
+        bits &= bits - 1;
+        Q[base++] = (uint16_t)(tid * 32 + bpos);
+      }
+      __syncthreads();
+      if (total == 0) break;
+      uint32_t *Fn = F[cur ^ 1];
+      for (uint32_t j = tid; j < total; j += NT) {
+        const int v = Q[j];
+        const uint32_t vbit = 1u << (v & 31);
+        const int rz = v % RZ, ry = (v / RZ) % RY, rx = v / (RZ * RY);
+        const int vx = bx + rx, vy = by + ry, vz = bz + rz;
+        unsigned long long key = __hip_atomic_load(&K[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+        if (prof) ++n_items;
+        const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
+                              (unsigned)(rz - H) < (unsigned)TZ;
+        if (interior && (P[v >> 5] & vbit)) {
+          __hip_atomic_fetch_and(&P[v >> 5], ~vbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          vox_t best = lo;
+          uint32_t bestd = hi;
+          vox_t un[24];
+          {
+            int q = 0;
+#define FIESTA_PULLL(DX, DY, DZ) un[q++] = K32[2 * (v + ((DX)*RY + (DY)) * RZ + (DZ))];
+            FIESTA_STENCIL24(FIESTA_PULLL)
+#undef FIESTA_PULLL
+          }
+#pragma unroll
+          for (int q = 0; q < 24; ++q) {
+            const vox_t u = un[q];
+            if (!(u & (kNoCoc | kAct))) {
+              const uint32_t d = (uint32_t)dist2(vx, vy, vz, u);
+              if (d < bestd) {
+                bestd = d;
+                best = u;
+              }
+            }
+          }
+          if (bestd < hi) {
+            const unsigned long long mine = ((unsigned long long)bestd << 32) | best | kAct;
+            const unsigned long long old = atomicMin(&K[v], mine);
+            key = old < mine ? old : mine;
+            lo = (uint32_t)key;
+            hi = (uint32_t)(key >> 32);
+          }
+        }
+        if (lo & kNoCoc) continue;
+        // push: |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2
+        const vox_t c = lo & ~kAct;
+        const int rcx = vx - (int)((c >> 20) & 1023), rcy = vy - (int)((c >> 10) & 1023), rcz = vz - (int)(c & 1023);
+        // source-only voxels (halo, ghost cells of a shard) keep d^2 = 0 in LDS: recompute theirs
+        const int32_t dv = hi ? (int32_t)hi : rcx * rcx + rcy * rcy + rcz * rcz;
+        const int ax = 2 * rcx, ay = 2 * rcy, az = 2 * rcz;
+        const unsigned long long keylo = (unsigned long long)(c | kAct);
+        uint32_t dnv[24];
+        {
+          int q = 0;
+#define FIESTA_PUSHL(DX, DY, DZ) dnv[q++] = K32[2 * min(max(v + (((DX)*RY + (DY)) * RZ + (DZ)), 0), RSIZE - 1) + 1];
+          FIESTA_STENCIL24(FIESTA_PUSHL)
+#undef FIESTA_PUSHL
+        }
+        {
+          int q = 0;
+#define FIESTA_PUSH(DX, DY, DZ)                                                                              \
+  {                                                                                                          \
+    const uint32_t cand = (uint32_t)(dv + (DX)*ax + (DY)*ay + (DZ)*az + ((DX) * (DX) + (DY) * (DY) + (DZ) * (DZ))); \
+    const uint32_t dn = dnv[q++];                                                                            \
+    if (cand < dn) {                                                                                         \
+      const int n = min(max(v + (((DX)*RY + (DY)) * RZ + (DZ)), 0), RSIZE - 1);                              \
+      __hip_atomic_fetch_min(&K[n], ((unsigned long long)cand << 32) | keylo, __ATOMIC_RELAXED,              \
+                             __HIP_MEMORY_SCOPE_WORKGROUP);                                                  \
+      const uint32_t nbit = 1u << (n & 31);                                                                  \
+      __hip_atomic_fetch_or(&Fn[n >> 5], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);              \
+      if (dn == (uint32_t)kD2Inf && pulls_enabled)                                                           \
+        __hip_atomic_fetch_or(&P[n >> 5], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);             \
+    }                                                                                                        \
+  }
+          FIESTA_STENCIL24(FIESTA_PUSH)
+#undef FIESTA_PUSH
+        }
+      }
+    }
+    if (prof) t2 = clock64();
+
+    // ---- write back what changed, publish frontier membership, wake the neighbours
+    const int lz = tid & 31, slot = tid >> 5;
+    uint32_t nwrites = 0;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int row = slot + SLOTS * r, lx = row / TY, ly = row % TY;
+      const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+      const int ri = ((lx + H) * RY + (ly + H)) * RZ + (lz + H);
+      const bool e = (E[ri >> 5] >> (ri & 31)) & 1u;
+      if (e) {
+        const vox_t w = K32[2 * ri] & ~kAct;
+        a.coc[PAGED ? (int64_t)nb_page[13] * PAGE_VOX + (lx * TY + ly) * TZ + lz : g.idx(x, y, z)] = w;
+        ++nwrites;
+#define FIESTA_WAKE(DX, DY, DZ)                                                          \
+  {                                                                                      \
+    const int ox = (lx + (DX) < 0) ? -1 : ((lx + (DX) >= TX) ? 1 : 0);                   \
+    const int oy = (ly + (DY) < 0) ? -1 : ((ly + (DY) >= TY) ? 1 : 0);                   \
+    const int oz = (lz + (DZ) < 0) ? -1 : ((lz + (DZ) >= TZ) ? 1 : 0);                   \
+    if (ox | oy | oz) nbr_dirty[(ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)] = 1;             \
+  }
+        if (!(w & kNoCoc) && (lx < H || lx >= TX - H || ly < H || ly >= TY - H || lz < H || lz >= TZ - H)) {
+          FIESTA_STENCIL24(FIESTA_WAKE)
+        }
+#undef FIESTA_WAKE
+      }
+      const unsigned long long b = __ballot(e);
+      if (lz == 0 && x < g.nx && y < g.ny && z < g.nz) {
+        const uint32_t ebits = (tid & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+        const int64_t wi = PAGED ? (int64_t)nb_page[13] * PAGE_ROWS + lx * TY + ly : g.bitword(x, y, z);
+        a.rbits[wi] = own_epoch ? (rb[((lx + H) * RY + (ly + H)) * 3 + 1] | ebits) : ebits;
+        a.cbits_cur[wi] = ebits;
+      }
+    }
+    {
+      uint32_t v = nwrites;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (lane == 0 && v) atomicAdd(&a.counters[C_WRITES], (unsigned long long)v);
+    }
+    __syncthreads();
+    if (prof) {
+      t3 = clock64();
+      uint32_t v = n_items;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (lane == 0 && v) atomicAdd(&a.counters[C_PROF0 + 3], (unsigned long long)v);
+      if (tid == 0) {
+        atomicAdd(&a.counters[C_PROF0 + 0], (unsigned long long)(t1 - t0));
+        atomicAdd(&a.counters[C_PROF0 + 1], (unsigned long long)(t2 - t1));
+        atomicAdd(&a.counters[C_PROF0 + 2], (unsigned long long)(t3 - t2));
+      }
+    }
+    if (tid == 0) {
+      a.tile_epoch[t] = a.epoch;
+      a.cstamp_cur[t] = a.serial;
+      atomicAdd(&a.counters[C_SWEEPS], (unsigned long long)level);
+      atomicAdd(&a.counters[C_VISITS], 1ull);
+    }
+    if (tid < 27 && nbr_dirty[tid]) {
+      const int ox = tid / 9 - 1, oy = (tid / 3) % 3 - 1, oz = tid % 3 - 1;
+      const int ux = tx + ox, uy = ty + oy, uz = tz + oz;
+      if ((unsigned)ux < (unsigned)a.tg.ntx && (unsigned)uy < (unsigned)a.tg.nty && (unsigned)uz < (unsigned)a.tg.ntz)
+        activate_tile((ux * a.tg.nty + uy) * a.tg.ntz + uz, a.flag_next, a.list_next, a.count_next);
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace fiesta
