@@ -1,6 +1,8 @@
 // fiesta_amd/csrc/relax_kernels.hpp -- device code shared by the dense-array map (dense_map.hip) and the paged
 // hash-block map (hash_map.hip): tile bookkeeping and the work-queue relaxation kernel k_relax_q.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 #include "dense_map.hpp"
 
@@ -204,8 +206,10 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
             if (act) {
               ever = true;
               front = true;
-              pull = !valid;  // orphaned by a delete: re-seed from the neighbourhood (:308-321)
             }
+            // a voxel without an obstacle asks its old-valid neighbours once, when it first joins the frontier:
+            // now if it was orphaned by a delete (the re-seed of :308-321), else when a wave first reaches it
+            pull = !valid;
           } else {
             front = src;  // a source only: its d^2 field stays 0
           }
@@ -229,9 +233,12 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
 
     // ---- level-synchronous propagation inside the tile
     uint32_t level = 0;
+    long long tc = 0, tp = 0, tmark = 0;
+    uint32_t n_pulls = 0, n_succ = 0;
     for (;; ++level) {
       const int cur = level & 1;
       __syncthreads();  // every push of the previous level has landed in F[cur]
+      if (prof) tmark = clock64();
       const bool pulls_enabled = n_oldvalid != 0;
       // compact the frontier bitmap into the work queue
       uint32_t bits = 0;
@@ -260,83 +267,105 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
         Q[base++] = (uint16_t)(tid * 32 + bpos);
       }
       __syncthreads();
+      if (prof) {
+        const long long now = clock64();
+        tc += now - tmark;
+        tmark = now;
+      }
       if (total == 0) break;
       uint32_t *Fn = F[cur ^ 1];
-      for (uint32_t j = tid; j < total; j += NT) {
-        const int v = Q[j];
-        const uint32_t vbit = 1u << (v & 31);
-        const int rz = v % RZ, ry = (v / RZ) % RY, rx = v / (RZ * RY);
-        const int vx = bx + rx, vy = by + ry, vz = bz + rz;
-        unsigned long long key = __hip_atomic_load(&K[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-        if (prof) ++n_items;
-        const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
-                              (unsigned)(rz - H) < (unsigned)TZ;
-        if (interior && (P[v >> 5] & vbit)) {
-          __hip_atomic_fetch_and(&P[v >> 5], ~vbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          vox_t best = lo;
-          uint32_t bestd = hi;
-          vox_t un[24];
-          {
-            int q = 0;
+      // One frontier item = one voxel whose key changed (or a source-only voxel at level 0). CLAMP: the item may be
+      // a halo / ghost voxel, so neighbour indices can leave the array (clamped onto a halo corner, whose d^2 = 0
+      // rejects every push) and its own d^2 is recomputed. Levels >= 1 only hold updatable voxels: neighbour
+      // offsets are instruction immediates.
+      auto process = [&](auto clamp_tag) {
+        constexpr bool CLAMP = decltype(clamp_tag)::value;
+        for (uint32_t j = tid; j < total; j += NT) {
+          const int v = Q[j];
+          const uint32_t vbit = 1u << (v & 31);
+          const int rz = v % RZ, ry = (v / RZ) % RY, rx = v / (RZ * RY);
+          const int vx = bx + rx, vy = by + ry, vz = bz + rz;
+          unsigned long long key = __hip_atomic_load(&K[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+          if (prof) ++n_items;
+          bool want_pull = (P[v >> 5] & vbit) != 0;  // had no obstacle when the tile was staged, not asked yet
+          if (CLAMP)
+            want_pull = want_pull && (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
+                        (unsigned)(rz - H) < (unsigned)TZ;
+          if (want_pull) {
+            __hip_atomic_fetch_and(&P[v >> 5], ~vbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pulls_enabled) {
+              if (prof) ++n_pulls;
+              vox_t best = lo;
+              uint32_t bestd = hi;
+              vox_t un[24];
+              {
+                int q = 0;
 #define FIESTA_PULLL(DX, DY, DZ) un[q++] = K32[2 * (v + ((DX)*RY + (DY)) * RZ + (DZ))];
-            FIESTA_STENCIL24(FIESTA_PULLL)
+                FIESTA_STENCIL24(FIESTA_PULLL)
 #undef FIESTA_PULLL
-          }
+              }
 #pragma unroll
-          for (int q = 0; q < 24; ++q) {
-            const vox_t u = un[q];
-            if (!(u & (kNoCoc | kAct))) {
-              const uint32_t d = (uint32_t)dist2(vx, vy, vz, u);
-              if (d < bestd) {
-                bestd = d;
-                best = u;
+              for (int q = 0; q < 24; ++q) {
+                const vox_t u = un[q];
+                if (!(u & (kNoCoc | kAct))) {
+                  const uint32_t d = (uint32_t)dist2(vx, vy, vz, u);
+                  if (d < bestd) {
+                    bestd = d;
+                    best = u;
+                  }
+                }
+              }
+              if (bestd < hi) {
+                const unsigned long long mine = ((unsigned long long)bestd << 32) | best | kAct;
+                const unsigned long long old = atomicMin(&K[v], mine);
+                key = old < mine ? old : mine;
+                lo = (uint32_t)key;
+                hi = (uint32_t)(key >> 32);
               }
             }
           }
-          if (bestd < hi) {
-            const unsigned long long mine = ((unsigned long long)bestd << 32) | best | kAct;
-            const unsigned long long old = atomicMin(&K[v], mine);
-            key = old < mine ? old : mine;
-            lo = (uint32_t)key;
-            hi = (uint32_t)(key >> 32);
-          }
-        }
-        if (lo & kNoCoc) continue;
-        // push: |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2
-        const vox_t c = lo & ~kAct;
-        const int rcx = vx - (int)((c >> 20) & 1023), rcy = vy - (int)((c >> 10) & 1023), rcz = vz - (int)(c & 1023);
-        // source-only voxels (halo, ghost cells of a shard) keep d^2 = 0 in LDS: recompute theirs
-        const int32_t dv = hi ? (int32_t)hi : rcx * rcx + rcy * rcy + rcz * rcz;
-        const int ax = 2 * rcx, ay = 2 * rcy, az = 2 * rcz;
-        const unsigned long long keylo = (unsigned long long)(c | kAct);
-        uint32_t dnv[24];
-        {
-          int q = 0;
-#define FIESTA_PUSHL(DX, DY, DZ) dnv[q++] = K32[2 * min(max(v + (((DX)*RY + (DY)) * RZ + (DZ)), 0), RSIZE - 1) + 1];
-          FIESTA_STENCIL24(FIESTA_PUSHL)
+          if (lo & kNoCoc) continue;
+          // push: |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2
+          const vox_t c = lo & ~kAct;
+          const int rcx = vx - (int)((c >> 20) & 1023), rcy = vy - (int)((c >> 10) & 1023), rcz = vz - (int)(c & 1023);
+          // source-only voxels (halo, ghost cells of a shard) keep d^2 = 0 in LDS: recompute theirs
+          const int32_t dv = (!CLAMP || hi) ? (int32_t)hi : rcx * rcx + rcy * rcy + rcz * rcz;
+          const int ax = 2 * rcx, ay = 2 * rcy, az = 2 * rcz;
+          const unsigned long long keylo = (unsigned long long)(c | kAct);
+#define FIESTA_NIDX(DX, DY, DZ) \
+  (CLAMP ? min(max(v + (((DX)*RY + (DY)) * RZ + (DZ)), 0), RSIZE - 1) : v + (((DX)*RY + (DY)) * RZ + (DZ)))
+          uint32_t dnv[24];
+          {
+            int q = 0;
+#define FIESTA_PUSHL(DX, DY, DZ) dnv[q++] = K32[2 * FIESTA_NIDX(DX, DY, DZ) + 1];
+            FIESTA_STENCIL24(FIESTA_PUSHL)
 #undef FIESTA_PUSHL
-        }
-        {
-          int q = 0;
+          }
+          {
+            int q = 0;
 #define FIESTA_PUSH(DX, DY, DZ)                                                                              \
   {                                                                                                          \
     const uint32_t cand = (uint32_t)(dv + (DX)*ax + (DY)*ay + (DZ)*az + ((DX) * (DX) + (DY) * (DY) + (DZ) * (DZ))); \
-    const uint32_t dn = dnv[q++];                                                                            \
-    if (cand < dn) {                                                                                         \
-      const int n = min(max(v + (((DX)*RY + (DY)) * RZ + (DZ)), 0), RSIZE - 1);                              \
+    if (cand < dnv[q++]) {                                                                                   \
+      if (prof) ++n_succ;                                                                                    \
+      const int n = FIESTA_NIDX(DX, DY, DZ);                                                                 \
       __hip_atomic_fetch_min(&K[n], ((unsigned long long)cand << 32) | keylo, __ATOMIC_RELAXED,              \
                              __HIP_MEMORY_SCOPE_WORKGROUP);                                                  \
-      const uint32_t nbit = 1u << (n & 31);                                                                  \
-      __hip_atomic_fetch_or(&Fn[n >> 5], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);              \
-      if (dn == (uint32_t)kD2Inf && pulls_enabled)                                                           \
-        __hip_atomic_fetch_or(&P[n >> 5], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);             \
+      __hip_atomic_fetch_or(&Fn[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    \
     }                                                                                                        \
   }
-          FIESTA_STENCIL24(FIESTA_PUSH)
+            FIESTA_STENCIL24(FIESTA_PUSH)
 #undef FIESTA_PUSH
+          }
+#undef FIESTA_NIDX
         }
-      }
+      };
+      if (level == 0)
+        process(std::true_type{});
+      else
+        process(std::false_type{});
+      if (prof) tp += clock64() - tmark;
     }
     if (prof) t2 = clock64();
 
@@ -353,17 +382,23 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
         const vox_t w = K32[2 * ri] & ~kAct;
         a.coc[PAGED ? (int64_t)nb_page[13] * PAGE_VOX + (lx * TY + ly) * TZ + lz : g.idx(x, y, z)] = w;
         ++nwrites;
-#define FIESTA_WAKE(DX, DY, DZ)                                                          \
-  {                                                                                      \
-    const int ox = (lx + (DX) < 0) ? -1 : ((lx + (DX) >= TX) ? 1 : 0);                   \
-    const int oy = (ly + (DY) < 0) ? -1 : ((ly + (DY) >= TY) ? 1 : 0);                   \
-    const int oz = (lz + (DZ) < 0) ? -1 : ((lz + (DZ) >= TZ) ? 1 : 0);                   \
-    if (ox | oy | oz) nbr_dirty[(ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)] = 1;             \
-  }
-        if (!(w & kNoCoc) && (lx < H || lx >= TX - H || ly < H || ly >= TY - H || lz < H || lz >= TZ - H)) {
-          FIESTA_STENCIL24(FIESTA_WAKE)
+        // Which neighbour tiles can this voxel's change reach through the 24-direction stencil (radius 2)?
+        // Faces: within 2 of the face (the +-1 and +-2 axis steps). Edges: within 1 of both faces (the +-1,+-1
+        // diagonals). Corners: never (the stencil has no 3-axis diagonals, include/parameters.h:54-68).
+        if (!(w & kNoCoc)) {
+          const int fx = (lx < H) ? -1 : ((lx >= TX - H) ? 1 : 0), fy = (ly < H) ? -1 : ((ly >= TY - H) ? 1 : 0),
+                    fz = (lz < H) ? -1 : ((lz >= TZ - H) ? 1 : 0);
+          if (fx | fy | fz) {
+            const int ex = (lx == 0) ? -1 : ((lx == TX - 1) ? 1 : 0), ey = (ly == 0) ? -1 : ((ly == TY - 1) ? 1 : 0),
+                      ez = (lz == 0) ? -1 : ((lz == TZ - 1) ? 1 : 0);
+            if (fx) nbr_dirty[(fx + 1) * 9 + 4] = 1;
+            if (fy) nbr_dirty[9 + (fy + 1) * 3 + 1] = 1;
+            if (fz) nbr_dirty[9 + 3 + (fz + 1)] = 1;
+            if (ex && ey) nbr_dirty[(ex + 1) * 9 + (ey + 1) * 3 + 1] = 1;
+            if (ex && ez) nbr_dirty[(ex + 1) * 9 + 3 + (ez + 1)] = 1;
+            if (ey && ez) nbr_dirty[9 + (ey + 1) * 3 + (ez + 1)] = 1;
+          }
         }
-#undef FIESTA_WAKE
       }
       const unsigned long long b = __ballot(e);
       if (lz == 0 && x < g.nx && y < g.ny && z < g.nz) {
@@ -384,7 +419,15 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
       uint32_t v = n_items;
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
       if (lane == 0 && v) atomicAdd(&a.counters[C_PROF0 + 3], (unsigned long long)v);
+      v = n_pulls;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (lane == 0 && v) atomicAdd(&a.counters[C_PROF0 + 6], (unsigned long long)v);
+      v = n_succ;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (lane == 0 && v) atomicAdd(&a.counters[C_PROF0 + 7], (unsigned long long)v);
       if (tid == 0) {
+        atomicAdd(&a.counters[C_PROF0 + 4], (unsigned long long)tc);
+        atomicAdd(&a.counters[C_PROF0 + 5], (unsigned long long)tp);
         atomicAdd(&a.counters[C_PROF0 + 0], (unsigned long long)(t1 - t0));
         atomicAdd(&a.counters[C_PROF0 + 1], (unsigned long long)(t2 - t1));
         atomicAdd(&a.counters[C_PROF0 + 2], (unsigned long long)(t3 - t2));

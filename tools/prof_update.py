@@ -65,7 +65,7 @@ def show(tag, st):
     print(f"{tag:9s} dev {st['device_ms']:8.3f} ms relax {st['relax_ms']:8.3f} ms rounds {st['rounds']:3d} visits {st['tile_visits']:8d} "
           f"levels {st['sweeps']:9d} writes {st['voxel_writes']:10d} updated {st['updated']:10d} inval {st['invalidated']:9d} | "
           f"cycles stage {p[0] / tot:.2f} propagate {p[1] / tot:.2f} writeback {p[2] / tot:.2f} items {p[3]} "
-          f"cyc/visit {tot / max(1, st['tile_visits']):.0f}")
+          f"cyc/visit {tot / max(1, st['tile_visits']):.0f} | compact {p[4] / tot:.2f} process {p[5] / tot:.2f} pulls {p[6]} push-ok {p[7]}")
 
 
 def main():
