@@ -609,9 +609,10 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
     case 3: tx_ = 16, ty_ = 16, engine_ = 0; break;
     case 4: tx_ = 4, ty_ = 8, engine_ = 0; break;
     case 10: tx_ = 8, ty_ = 8, engine_ = 1; break;
-    case 0:
     case 11: tx_ = 16, ty_ = 16, engine_ = 1; break;
     case 12: tx_ = 16, ty_ = 8, engine_ = 1; break;
+    case 0:  // 512 threads: 256 VGPRs per lane, no spills (1024 threads cap at 128 and spill to scratch)
+    case 13: tx_ = 16, ty_ = 16, engine_ = 1, threads_ = 512; break;
     default: throw Error(FIESTA_HIP_ERR_INVALID, "unknown tile_shape");
   }
   if (sharded && engine_ != 1) throw Error(FIESTA_HIP_ERR_INVALID, "sharded maps need the work-queue engine");
@@ -902,6 +903,8 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
     if (tx_ == 8 && ty_ == 8)
       hipLaunchKernelGGL((k_relax_q<8, 8, 256>), dim3(blocks), dim3(256), 0, stream_, a);
+    else if (tx_ == 16 && ty_ == 16 && threads_ == 512)
+      hipLaunchKernelGGL((k_relax_q<16, 16, 512>), dim3(blocks), dim3(512), 0, stream_, a);
     else if (tx_ == 16 && ty_ == 16)
       hipLaunchKernelGGL((k_relax_q<16, 16, 1024>), dim3(blocks), dim3(1024), 0, stream_, a);
     else

@@ -160,6 +160,7 @@ class DenseMap {
   int tx_ = 8, ty_ = 8;  // tile extent in x,y (z extent is always 32)
   int ntx_ = 0, nty_ = 0, ntz_ = 0, ntiles_ = 0;
   uint32_t *tile_epoch_ = nullptr;
+  int threads_ = 1024;                          // work-group size of k_relax_q for 16x16 tiles
   int engine_ = 1;                              // 0: Jacobi sweeps (k_relax), 1: LDS work queue (k_relax_q)
   uint32_t *cbits_[2] = {nullptr, nullptr};     // 1 bit/voxel: changed in the round of that parity
   uint32_t *cstamp_[2] = {nullptr, nullptr};    // per tile: serial of the round that wrote cbits_[parity]

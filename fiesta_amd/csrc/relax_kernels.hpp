@@ -69,7 +69,7 @@ struct RelaxQArgs {
 };
 
 template <int TX, int TY, int NT, bool PAGED = false>
-__global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
+__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs a) {
   constexpr int TZ = 32, H = 2;
   constexpr int RX = TX + 2 * H, RY = TY + 2 * H, RZ = TZ + 2 * H;
   constexpr int RSIZE = RX * RY * RZ;
@@ -80,7 +80,12 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
   constexpr int NWAVE = NT / 64;
   constexpr int NROWW = RX * RY * 3;  // staged bitmap words: 3 z-words per (x,y) row of the region
   static_assert(NT % 64 == 0 && (TX * TY) % SLOTS == 0 && RPT <= 32 && RSIZE < 65536 && NW <= NT, "tile shape");
+  // keys: lo half = obstacle word | flag, hi half = d^2. The halves are read through KW(j) = the array itself
+  // reinterpreted in place (no pointer variable, no volatile): that keeps every access a DS instruction -- a
+  // `volatile uint32_t *` alias of K compiled to FLAT loads.
   __shared__ unsigned long long K[RSIZE];
+#define KW(j) (reinterpret_cast<uint32_t *>(K)[j])
+#define K64(i) (K[i])
   __shared__ uint16_t Q[RSIZE];
   __shared__ uint32_t F[2][NW], E[NW], P[NW];
   __shared__ uint32_t rb[NROWW], cb[NROWW];
@@ -90,7 +95,6 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
   __shared__ int32_t nb_page[27];
   __shared__ int nbr_dirty[27];
   constexpr int PAGE_VOX = TX * TY * TZ, PAGE_ROWS = TX * TY;
-  volatile uint32_t *K32 = (volatile uint32_t *)K;
 
   const Geom &g = a.g;
   const int tid = threadIdx.x;
@@ -143,9 +147,10 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
       rb[j] = r;
       cb[j] = c;
     }
-    // ---- raw voxel words -> low halves of the keys (independent loads, issued back to back)
+    // ---- raw voxel words -> low halves of the keys (independent loads, issued in batches; addresses are always
+    //      legal so no load sits behind a branch)
     {
-      constexpr int UB = 8;
+      constexpr int UB = NT >= 1024 ? 8 : 15;
       for (int i0 = tid; i0 < RSIZE; i0 += UB * NT) {
         vox_t wv[UB];
 #pragma unroll
@@ -164,12 +169,12 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
           } else {
             idx = g.idx(min(max(x, 0), g.nx - 1), min(max(y, 0), g.ny - 1), min(max(z, 0), g.nz - 1));
           }
-          const vox_t w = a.coc[idx];  // always a legal address: the load never sits behind a branch
+          const vox_t w = a.coc[idx];
           wv[u] = ok ? w : kUnobserved;
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u)
-          if (i0 + u * NT < RSIZE) K32[2 * (i0 + u * NT)] = wv[u];
+          if (i0 + u * NT < RSIZE) KW(2 * (i0 + u * NT)) = wv[u];
       }
     }
     __syncthreads();
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
       const int i = tid + k * NT;
       bool ever = false, pull = false, front = false;
       if (i < RSIZE) {
-        const vox_t w = K32[2 * i];
+        const vox_t w = KW(2 * i);
         uint32_t lo = kUnobserved, hi = 0;
         if (w != kUnobserved) {
           const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
           }
           if (valid && !inR) ++oldvalid;
         }
-        K[i] = ((unsigned long long)hi << 32) | lo;
+        K64(i) = ((unsigned long long)hi << 32) | lo;
       }
       const unsigned long long me = __ballot(ever), mp = __ballot(pull), mf = __ballot(front);
       if ((tid & 31) == 0 && i < RPAD) {
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
           const uint32_t vbit = 1u << (v & 31);
           const int rz = v % RZ, ry = (v / RZ) % RY, rx = v / (RZ * RY);
           const int vx = bx + rx, vy = by + ry, vz = bz + rz;
-          unsigned long long key = __hip_atomic_load(&K[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          unsigned long long key = __hip_atomic_load(&K64(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
           if (prof) ++n_items;
           bool want_pull = (P[v >> 5] & vbit) != 0;  // had no obstacle when the tile was staged, not asked yet
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
               vox_t un[24];
               {
                 int q = 0;
-#define FIESTA_PULLL(DX, DY, DZ) un[q++] = K32[2 * (v + ((DX)*RY + (DY)) * RZ + (DZ))];
+#define FIESTA_PULLL(DX, DY, DZ) un[q++] = KW(2 * (v + ((DX)*RY + (DY)) * RZ + (DZ)));
                 FIESTA_STENCIL24(FIESTA_PULLL)
 #undef FIESTA_PULLL
               }
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
               }
               if (bestd < hi) {
                 const unsigned long long mine = ((unsigned long long)bestd << 32) | best | kAct;
-                const unsigned long long old = atomicMin(&K[v], mine);
+                const unsigned long long old = atomicMin(&K64(v), mine);
                 key = old < mine ? old : mine;
                 lo = (uint32_t)key;
                 hi = (uint32_t)(key >> 32);
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
           uint32_t dnv[24];
           {
             int q = 0;
-#define FIESTA_PUSHL(DX, DY, DZ) dnv[q++] = K32[2 * FIESTA_NIDX(DX, DY, DZ) + 1];
+#define FIESTA_PUSHL(DX, DY, DZ) dnv[q++] = KW(2 * FIESTA_NIDX(DX, DY, DZ) + 1);
             FIESTA_STENCIL24(FIESTA_PUSHL)
 #undef FIESTA_PUSHL
           }
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
     if (cand < dnv[q++]) {                                                                                   \
       if (prof) ++n_succ;                                                                                    \
       const int n = FIESTA_NIDX(DX, DY, DZ);                                                                 \
-      __hip_atomic_fetch_min(&K[n], ((unsigned long long)cand << 32) | keylo, __ATOMIC_RELAXED,              \
+      __hip_atomic_fetch_min(&K64(n), ((unsigned long long)cand << 32) | keylo, __ATOMIC_RELAXED,              \
                              __HIP_MEMORY_SCOPE_WORKGROUP);                                                  \
       __hip_atomic_fetch_or(&Fn[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    \
     }                                                                                                        \
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
       const int ri = ((lx + H) * RY + (ly + H)) * RZ + (lz + H);
       const bool e = (E[ri >> 5] >> (ri & 31)) & 1u;
       if (e) {
-        const vox_t w = K32[2 * ri] & ~kAct;
+        const vox_t w = KW(2 * ri) & ~kAct;
         a.coc[PAGED ? (int64_t)nb_page[13] * PAGE_VOX + (lx * TY + ly) * TZ + lz : g.idx(x, y, z)] = w;
         ++nwrites;
         // Which neighbour tiles can this voxel's change reach through the 24-direction stencil (radius 2)?
@@ -448,5 +453,8 @@ __global__ __launch_bounds__(NT, 4) void k_relax_q(RelaxQArgs a) {
     __syncthreads();
   }
 }
+
+#undef K64
+#undef KW
 
 }  // namespace fiesta
