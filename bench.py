@@ -17,7 +17,7 @@ identical *untimed* replay of the same K steps from a device snapshot (the diff 
 inside the timed region).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel k_relax: algorithmic bytes (16 B per updated voxel) over the
+  roofline      dominant kernel k_relax_q: algorithmic bytes (16 B per updated voxel) over the
                 sum of its launch durations, measured live with HIP events on the map's own stream.
   cpu_baseline  the CPU oracle (verbatim-compiled reference when oracle/_ref is present, else the pinned
                 restatement) timed on one host core on a bounded sample of the same workload (same obstacle
@@ -274,6 +274,16 @@ def main():
         total_updated = float(t.item())
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
+        # read from inside the process); the newest committed summary of tools/pmc_traffic.py is quoted here.
+        traffic, traffic_src = None, None
+        try:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "pmc_traffic" in f and f.endswith(".json"))
+            if cands and world == 1:
+                tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{cands[-1]} ({tj['kernel']}, {tj['command']})"
+        except Exception:
+            pass
         relax_ms = sum(s["relax_ms"] for s in timed)
         launches = sum(s["relax_launches"] for s in timed)
         my_updated = float(sum(updated))
@@ -315,7 +325,7 @@ def main():
                                     "roofline_frac": scatter_updated * 16 / (st_scatter["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "roofline": {
                 "bound": "hbm", "kernel": "k_relax_q", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                 "launches": launches, "avg_launch_us": relax_ms * 1e3 / max(1, launches),
                 "algorithmic_bytes_per_launch": my_updated * ALGO_BYTES_PER_UPDATED_VOXEL / max(1, launches),
                 "frac_of_measured_copy_6.29TBs": achieved / 6290.0,

@@ -658,6 +658,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   set_original_range();
   pp_ = ProbParams{0, 0, 0, 0, 0};
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
+  if (const char *e = getenv("FIESTA_HIP_SPATIAL")) spatial_ = atoi(e);
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
@@ -899,7 +900,10 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     a.counters = counters_;
     a.prof = prof_;
     a.dir = nullptr;
-    const int blocks = (int)std::min<uint32_t>(ncur, 16384u);
+    a.spatial = spatial_;
+    // spatial walk: a multiple of 8 blocks (one stream per XCD), a few per CU for load balance
+    const int blocks = spatial_ ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), 2048u)
+                                : (int)std::min<uint32_t>(ncur, 16384u);
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
     if (tx_ == 8 && ty_ == 8)
       hipLaunchKernelGGL((k_relax_q<8, 8, 256>), dim3(blocks), dim3(256), 0, stream_, a);

@@ -62,6 +62,7 @@ struct RelaxQArgs {
   uint32_t *list_next;
   unsigned long long *count_next;
   unsigned long long *counters;
+  int spatial;  // dense maps: 1 = walk all tiles in XCD-chunked spatial order (flag_cur is the list)
   int prof;  // 1: accumulate per-phase cycle counters into counters[C_PROF0..]
   // paged (hash-block) maps: voxel data lives in a pool of pages, one page = one tile (TX x TY x 32 voxels, same
   // z-fastest row layout), found through the dense page directory dir[tile] (-1: not allocated = all unobserved)
@@ -100,8 +101,27 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
 
-  for (uint32_t li = blockIdx.x; li < a.n_cur; li += gridDim.x) {
-    const uint32_t t = a.list_cur[li];
+  // Two ways to walk the active tiles. PAGED maps (huge, mostly empty directory): the compact list of the round.
+  // Dense maps: every tile in SPATIAL order, skipping the inactive ones (flag_cur is the list) -- tiles are grouped
+  // in chunks of 64 consecutive ids (a 16-tile z-column x 4 y-neighbours), chunk c goes to XCD c % 8 and block b runs
+  // on XCD b % 8 (observed placement, used for speed only), so tiles that share halo lines meet in one XCD's L2
+  // at about the same time instead of each missing to HBM.
+  const uint32_t ntiles = (uint32_t)(a.tg.ntx * a.tg.nty * a.tg.ntz);
+  for (uint32_t it = 0;; ++it) {
+    uint32_t t;
+    if (PAGED || a.spatial == 0) {
+      const uint32_t li = blockIdx.x + it * gridDim.x;
+      if (li >= a.n_cur) break;
+      t = a.list_cur[li];
+    } else {
+      const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) + it * (gridDim.x >> 3);
+      const uint32_t chunk = (v >> 6) * 8u + xcd;
+      if (chunk * 64u >= ntiles) break;
+      t = chunk * 64u + (v & 63u);
+      const bool active = t < ntiles && a.flag_cur[t] != 0u;
+      __syncthreads();  // everybody has read the flag before thread 0 clears it below
+      if (!active) continue;
+    }
     const int tz = t % a.tg.ntz, ty = (t / a.tg.ntz) % a.tg.nty, tx = t / (a.tg.ntz * a.tg.nty);
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const int bx = g.gx0 + x0 - H, by = g.gy0 + y0 - H, bz = g.gz0 + z0 - H;  // global coords of r-index 0

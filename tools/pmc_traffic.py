@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""HBM traffic of the dominant kernel from rocprofv3 PMC passes (MI355X_MICROARCH.md, "HBM" + "rocprofv3 PMC slots").
+
+FETCH_SIZE and WRITE_SIZE do not fit one pass (TCC slots), so they are collected in two runs of the same command:
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_FETCH_SIZE -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_WRITE_SIZE -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+Units are KB. Calibration inside the very same runs, on kernels whose byte counts are known:
+    WRITE_SIZE  k_fill<uint>      writes the 512 MiB word array once            -> factor = bytes / reported
+    FETCH_SIZE  k_count_updated   reads two 512 MiB word arrays (+16 MiB bitmap) -> factor = bytes / reported
+(the guide: on gfx950 FETCH_SIZE reports 1/2 of a coalesced streaming read; confirmed here for 4 B/lane loads).
+Usage: python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE k_relax_q > profiles/rNN_pmc_traffic.json
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def per_kernel(d, counter):
+    acc = collections.defaultdict(list)
+    with open(os.path.join(d, "bench_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]) * 1024.0)
+    return acc
+
+
+def find(acc, key):
+    for k, v in acc.items():
+        if key in k:
+            return k, v
+    raise KeyError(key)
+
+
+def main():
+    fdir, wdir, kern = sys.argv[1], sys.argv[2], sys.argv[3]
+    grid = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+    F, W = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
+    words = grid ** 3 * 4
+    _, fill = find(W, "k_fill<unsigned int>")
+    _, cnt = find(F, "k_count_updated")
+    wfac = words / (sum(fill) / len(fill))
+    ffac = (2 * words + grid ** 3 // 8) / (sum(cnt) / len(cnt))
+    kname, fr = find(F, kern)
+    _, wr = find(W, kern)
+    out = {
+        "kernel": kname, "launches": len(fr),
+        "fetch_reported_bytes_per_launch": sum(fr) / len(fr), "write_reported_bytes_per_launch": sum(wr) / len(wr),
+        "fetch_calibration_factor": ffac, "write_calibration_factor": wfac,
+        "calibration": {"write": "k_fill<uint> writes grid^3 x 4 B", "fetch": "k_count_updated reads 2 x grid^3 x 4 B + grid^3/8 B"},
+        "fetch_bytes_per_launch": ffac * sum(fr) / len(fr), "write_bytes_per_launch": wfac * sum(wr) / len(wr),
+    }
+    out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+    out["command"] = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (two rocprofv3 --pmc passes)"
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
