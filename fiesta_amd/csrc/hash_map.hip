@@ -587,6 +587,7 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
       st->sweeps = (int64_t)h_counters_[C_SWEEPS];
       st->voxel_writes = (int64_t)h_counters_[C_WRITES];
       st->tile_visits = (int64_t)h_counters_[C_VISITS];
+      for (int k = 0; k < 8; ++k) st->prof[k] = (int64_t)h_counters_[C_PROF0 + k];
       st->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
     }
   }

@@ -151,6 +151,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       nb_page[tid] = pg;
     }
     __syncthreads();  // nb_ok
+    if (PAGED && nb_page[13] < 0) {  // a tile without a page holds no observed voxel: nothing to relax, nothing to write
+      __syncthreads();
+      continue;
+    }
     // ---- stage the frontier bitmaps of the region's rows (3 z-words per row) through LDS
     for (int j = tid; j < NROWW; j += NT) {
       const int k = j % 3, ry = (j / 3) % RY, rx = j / (3 * RY);
@@ -467,7 +471,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     if (tid < 27 && nbr_dirty[tid]) {
       const int ox = tid / 9 - 1, oy = (tid / 3) % 3 - 1, oz = tid % 3 - 1;
       const int ux = tx + ox, uy = ty + oy, uz = tz + oz;
-      if ((unsigned)ux < (unsigned)a.tg.ntx && (unsigned)uy < (unsigned)a.tg.nty && (unsigned)uz < (unsigned)a.tg.ntz)
+      if ((unsigned)ux < (unsigned)a.tg.ntx && (unsigned)uy < (unsigned)a.tg.nty && (unsigned)uz < (unsigned)a.tg.ntz &&
+          (!PAGED || nb_page[tid] >= 0))
         activate_tile((ux * a.tg.nty + uy) * a.tg.ntz + uz, a.flag_next, a.list_next, a.count_next);
     }
     __syncthreads();

@@ -141,3 +141,23 @@ def test_hash_mode_errors_are_loud(hip_lib):
     with pytest.raises(fiesta_amd.FiestaHipError):
         m.snapshot_save(0)
     assert m.GetDistance(np.array([[5, 5, 5]], np.int32))[0] == 10000.0
+
+
+def test_hash_wave_reaches_unallocated_space(hip_lib, oracle_libs, best_oracle_kind):
+    """The observed region is exactly ONE page (tile-aligned 16x16x32 box): every wave runs into unallocated
+    neighbour tiles, which must be neither woken nor visited (regression: bitmap writes at page index -1)."""
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.1, 0)
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(32), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    cycles(gpu, cpu, [], g, 1)
+    cycles(gpu, cpu, np.array([[8, 8, 16], [0, 0, 0], [15, 15, 31]], np.int32), [], 3)
+    rep = compare(gpu, cpu)
+    assert rep["d2_mismatch"] == 0 and rep["finite"] == 16 * 16 * 32 and rep["pages"] == 1, rep
+    cycles(gpu, cpu, [], np.array([[8, 8, 16]], np.int32), 6)
+    rep = compare(gpu, cpu)
+    assert rep["d2_mismatch"] == 0, rep
+    # grow sideways: the neighbours get pages now and join the propagation
+    g2 = g + np.array([16, 0, 0], np.int32)
+    cycles(gpu, cpu, [], g2, 1)
+    cycles(gpu, cpu, np.array([[20, 3, 5]], np.int32), [], 3)
+    rep = compare(gpu, cpu)
+    assert rep["d2_mismatch"] <= 2 and rep["pages"] == 2, rep  # freshly observed free space: order-dependent regime

@@ -17,9 +17,40 @@ import fiesta_amd  # noqa: E402
 from bench import P_DEFAULT, Workload  # noqa: E402
 
 
-def run(G, n_obs, ts):
+def run(G, n_obs, ts, hash_mode=False):
     dev = torch.device("cuda", 0)
     res = 0.1
+    if hash_mode:  # same workload on the paged ("bricked") map: grid placed at voxels [-G/2, G/2)
+        m = fiesta_amd.ESDFMap((0, 0, 0), res, reserve_size=G ** 3, mode="hash")
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+        off = -G // 2
+        for x0 in range(0, G, 32):
+            g = np.stack(np.meshgrid(np.arange(x0, x0 + 32), np.arange(G), np.arange(G), indexing="ij"), -1).reshape(-1, 3)
+            m.SetOccupancy((g + off).astype(np.int32), 0, want_ret=False)
+        m.UpdateOccupancy(True)
+        m.UpdateESDF()
+        w = Workload(G, n_obs)
+        out = {}
+        init = w.initial() + off
+        for _ in range(3):
+            m.SetOccupancy(init, 1, want_ret=False)
+            m.UpdateOccupancy(True)
+        st = m.UpdateESDF()
+        st["updated"] = 0
+        out["scatter"] = st
+        for k in range(2):
+            new, old = w.next_step()
+            for c in range(3):
+                m.SetOccupancy(new + off, 1, want_ret=False)
+                if c == 2:
+                    m.SetOccupancy(old + off, 0, want_ret=False)
+                m.UpdateOccupancy(True)
+            st = m.UpdateESDF()
+            st["updated"] = 0
+            out[f"steady{k}"] = st
+        m.close()
+        return out, None, None
     m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, tile_shape=ts)
     m.SetParameters(*P_DEFAULT)
     m.SetOriginalRange()
@@ -74,9 +105,10 @@ def main():
     ap.add_argument("--obstacles", type=int, default=None)
     ap.add_argument("--tile-shape", type=int, default=0)
     ap.add_argument("--compare", type=int, default=None)
+    ap.add_argument("--hash", action="store_true", help="run the workload on the paged hash-block map")
     a = ap.parse_args()
     n_obs = a.obstacles or int(round(50000 * (a.grid / 512) ** 3))
-    o1, d1, occ1 = run(a.grid, n_obs, a.tile_shape)
+    o1, d1, occ1 = run(a.grid, n_obs, a.tile_shape, a.hash)
     for k, st in o1.items():
         show(f"ts{a.tile_shape}:{k}", st)
     if a.compare is not None:
