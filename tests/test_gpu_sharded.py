@@ -121,3 +121,75 @@ def test_device_pointer_halo_path_equals_host_path(hip_lib):
         assert np.array_equal(fa["d2"], fb["d2"]) and np.array_equal(fa["coc"], fb["coc"])
     for sm in maps:
         sm.close()
+
+
+def _dist_worker(rank, world, port, gs, q):
+    try:
+        import torch  # noqa: F401  (before the HIP library: one HIP runtime per process)
+        import torch.distributed as dist
+        import os
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, here)
+        sys.path.insert(0, os.path.dirname(here))
+        from fiesta_amd.sharded import DistTransport, ShardedESDFMap
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sm = ShardedESDFMap((0, 0, 0), 0.1, gs, world, transport=DistTransport(), devices=(0,))
+        sm.SetParameters(*P_DEFAULT)
+        sm.SetOriginalRange()
+        sm.SetOccupancyBox((0, 0, 0), tuple(np.array(gs) - 1), 0)
+        sm.UpdateOccupancy(True)
+        sm.UpdateESDF()
+        rng = np.random.RandomState(11)
+        S = np.unique((rng.rand(120, 3) * gs).astype(np.int32), axis=0)
+        S[:20, 0] = gs[0] // 2 - 2 + rng.randint(0, 4, 20)
+        S = np.unique(S, axis=0)
+
+        def check(obstacles, tag):
+            ix = np.indices(gs).reshape(3, -1).T
+            want = ((ix[:, None, :] - obstacles[None, :, :]) ** 2).sum(-1).min(1).reshape(gs)
+            for lo, size, crop in sm.download_owned(("d2",)).values():
+                sl = tuple(slice(int(a), int(a + s)) for a, s in zip(lo, size))
+                assert np.array_equal(crop["d2"].astype(np.int64), want[sl]), (tag, rank)
+        for _ in range(3):
+            sm.SetOccupancy(S, 1)
+            sm.UpdateOccupancy(True)
+        assert sm.last_insert == len(S)
+        sm.UpdateESDF()
+        check(S, "insert")
+        gone, new = S[:40], np.array([[1, 1, 1], [gs[0] - 2, gs[1] - 2, gs[2] - 2]], np.int32)
+        for _ in range(6):
+            sm.SetOccupancy(gone, 0)
+            sm.SetOccupancy(new, 1)
+            sm.UpdateOccupancy(True)
+        assert sm.last_delete == len(gone)
+        sm.UpdateESDF()
+        check(np.concatenate([S[40:], new]), "mixed")
+        q.put((rank, "ok", sm.last_sweeps))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+
+
+def test_dist_transport_with_hip_shards_two_ranks_one_gpu(hip_lib):
+    """The torch.distributed driver path (what `bench.py --gpus N` runs over RCCL) with real HIP shards: two ranks
+    share the one visible GPU, gloo carries the host-buffer forms of the same messages. Checked against brute force."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    gs = (48, 40, 40)
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, gs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), [r for r in results if r[1] != "ok"]
