@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--tile-shape", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=192)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded driver even with one rank (smoke test)")
     ap.add_argument("--replicas", action="store_true",
                     help="with --gpus N: N independent maps instead of one spatially sharded map")
@@ -151,6 +152,8 @@ def main():
 
     if not torch.cuda.is_available() or fiesta_amd.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.backend != "nccl":
+        local_rank = 0  # gloo smoke test: every rank uses the one visible GPU
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_sharded:
@@ -161,8 +164,12 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:  # debugging only: several ranks on ONE GPU, messages through host buffers
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
 
     G, res = args.grid, 0.1
     sharded_map = None
@@ -171,7 +178,7 @@ def main():
         from fiesta_amd.sharded import DistTransport, ShardedESDFMap, rank_coords, shard_layout
         layout = shard_layout(world)
         gg = tuple(G * l for l in layout)
-        sharded_map = ShardedESDFMap((0, 0, 0), res, gg, world, transport=DistTransport(dev), devices=(local_rank,),
+        sharded_map = ShardedESDFMap((0, 0, 0), res, gg, world, transport=DistTransport(cdev), devices=(local_rank,),
                                      tile_shape=args.tile_shape)
         m = sharded_map.shards[rank]
         box_lo = np.array(rank_coords(rank, layout)) * G
@@ -259,7 +266,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -269,7 +276,7 @@ def main():
     updated = [r["updated"] for r in replay]
     total_updated = float(sum(updated))
     if dist:
-        t = torch.tensor([total_updated], device=dev, dtype=torch.float64)
+        t = torch.tensor([total_updated], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_updated = float(t.item())
 
