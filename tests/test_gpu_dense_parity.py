@@ -237,3 +237,48 @@ def test_pillars_workload_of_reference_test(hip_lib, oracle_libs, best_oracle_ki
             b.fuse()
         b.esdf()
     assert_exact(compare_dense(b.gpu, b.cpu))
+
+
+def test_local_sliding_window_mode(hip_lib, oracle_libs, best_oracle_kind):
+    """What launch/demo.launch ships for on-board use: UpdateOccupancy(global_map=false) with a
+    window that follows the sensor: SetUpdateRange clips ingest AND propagation (VoxInRange, src/ESDFMap.cpp:351,378)
+    and a touched voxel outside the PREVIOUS window is reset (:256-259). The reference's reset is inconsistent: it sets
+    distance = infinity but leaves closest_obstacle_ (and the list link) pointing at the old obstacle, so its own
+    state stops satisfying dist == |v - coc| * res there. This engine stores no separate distance, so the reset clears
+    the obstacle. Occupancy, log-odds, queues and observed sets must still agree exactly; distances are
+    compared where the reference is self-consistent, with a small budget for what the stale obstacles leak."""
+    from scenarios import D2_INF, oracle_d2
+    n = 48
+    b = make_pair(oracle_libs, best_oracle_kind, n)
+    observe_all(b, n)
+    rng = np.random.RandomState(21)
+    S = rng.randint(4, n - 4, (250, 3)).astype(np.int32)
+    b.make_occupied(S)
+    b.esdf()
+    assert_exact(compare_dense(b.gpu, b.cpu))
+
+    def compare_local():
+        f, o = b.gpu.download_field(), b.cpu.dump_dense()
+        assert np.array_equal(f["occ"], o["occ"]) and np.array_equal(f["logodds"], o["logodds"])
+        od2, _ = oracle_d2(o, b.gpu.grid_size)
+        gd2 = f["d2"].astype(np.int64)
+        assert np.array_equal(gd2 < 0, od2 < 0)
+        finite = (od2 >= 0) & (od2 != D2_INF)
+        consistent = np.ones(len(od2), bool)
+        consistent[finite] = np.sqrt(od2[finite].astype(np.float64)) * b.gpu.resolution == o["dist"][finite]
+        return int(((gd2 != od2) & consistent).sum()), int((~consistent).sum())
+    worst = 0
+    for step in range(4):
+        c = np.array([1.2 + 0.5 * step, 2.0, 2.4])
+        for m in (b.gpu, b.cpu):
+            m.SetUpdateRange(c - [1.5, 1.5, 1.0], c + [1.5, 1.5, 1.0])
+        new = (c / 0.1 + rng.randint(-12, 12, (60, 3))).astype(np.int32)
+        gone = S[rng.choice(len(S), 40, replace=False)]
+        for _ in range(6):
+            b.observe(new, 1)
+            b.observe(gone, 0)
+            b.fuse(global_map=False)
+        b.esdf()
+        mism, inconsistent = compare_local()
+        worst = max(worst, mism)
+    assert worst <= 0.02 * n ** 3, worst
