@@ -164,37 +164,37 @@ __global__ void k_seed_insert(Geom g, TileGrid tg, const uint32_t *ins, int64_t 
 __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits,
                                                     const uint32_t *gocc, uint32_t *flag, uint32_t *list,
                                                     unsigned long long *count, unsigned long long *counters) {
-  // one wave per 64-voxel run of a z-row: row and tile arithmetic is wave-uniform, loads are 256 B coalesced
+  // one wave per z-row (64 voxels = 256 B per step): row and tile arithmetic is wave-uniform 32-bit math
   const int zchunks = (g.nz + 63) >> 6;
-  const int64_t nitems = (int64_t)g.nx * g.ny * zchunks;
+  const uint32_t nrows = (uint32_t)g.nx * (uint32_t)g.ny;
   const int lane = threadIdx.x & 63;
   unsigned long long local = 0;
-  for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < nitems; item += (int64_t)gridDim.x * 4) {
-    const int64_t row = item / zchunks;
-    const int zc = (int)(item - row * zchunks);
-    const int x = (int)(row / g.ny), y = (int)(row - (int64_t)x * g.ny);
-    const int z = zc * 64 + lane;
-    bool reset = false;
-    if (z < g.nz) {
-      const int64_t i = row * g.nz + z;
-      const vox_t w = coc[i];
-      if (!(w & kNoCoc)) {
-        int cx, cy, cz;
-        unpack_coc(w, cx, cy, cz);
-        if (g.owned(x, y, z) && !obstacle_alive(g, occbits, gocc, cx, cy, cz)) {
-          coc[i] = kReset;
-          reset = true;
+  for (uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4u) {
+    const int x = (int)(row / (uint32_t)g.ny), y = (int)(row - (uint32_t)x * (uint32_t)g.ny);
+    const int64_t base = (int64_t)row * g.nz;
+    for (int zc = 0; zc < zchunks; ++zc) {
+      const int z = zc * 64 + lane;
+      bool reset = false;
+      if (z < g.nz) {
+        const vox_t w = coc[base + z];
+        if (!(w & kNoCoc)) {
+          int cx, cy, cz;
+          unpack_coc(w, cx, cy, cz);
+          if (g.owned(x, y, z) && !obstacle_alive(g, occbits, gocc, cx, cy, cz)) {
+            coc[base + z] = kReset;
+            reset = true;
+          }
         }
       }
-    }
-    const unsigned long long m = __ballot(reset);
-    if (m) {
-      if (lane == 0) local += __popcll(m);
-      if ((lane & 31) == 0 && z < g.nz) {
-        const uint32_t half = (lane & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
-        if (half) {
-          const uint32_t t = tg.tile_of(x, y, z);
-          if (flag[t] == 0u) activate_tile(t, flag, list, count);
+      const unsigned long long m = __ballot(reset);
+      if (m) {
+        if (lane == 0) local += __popcll(m);
+        if ((lane & 31) == 0 && z < g.nz) {
+          const uint32_t half = (lane & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
+          if (half) {
+            const uint32_t t = tg.tile_of(x, y, z);
+            if (flag[t] == 0u) activate_tile(t, flag, list, count);
+          }
         }
       }
     }
@@ -660,6 +660,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_SPATIAL")) spatial_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_HYBRID")) hybrid_ = atoi(e);
+  if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
@@ -904,7 +905,7 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     a.spatial = spatial_;
     a.hybrid = (spatial_ && hybrid_ && tx_ == 16 && ty_ == 16) ? 1 : 0;
     // spatial walk: a multiple of 8 blocks (one stream per XCD), a few per CU for load balance
-    const int blocks = spatial_ ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), 2048u)
+    const int blocks = spatial_ ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), (uint32_t)spatial_blocks_)
                                 : (int)std::min<uint32_t>(ncur, 16384u);
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
     if (tx_ == 8 && ty_ == 8)
