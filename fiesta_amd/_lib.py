@@ -120,6 +120,8 @@ def load():
         "fiesta_hip_get_occupancy_pos": (C.c_int, [vp, vp, i64, vp]),
         "fiesta_hip_download_field": (C.c_int, [vp, vp, vp, vp, vp]),
         "fiesta_hip_download_counts": (C.c_int, [vp, vp, vp]),
+        "fiesta_hip_get_occupied_voxels": (C.c_int, [vp, vp, i64, vp]),
+        "fiesta_hip_get_slice": (C.c_int, [vp, i32, vp]),
         "fiesta_hip_download_hash": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "fiesta_hip_snapshot_save": (C.c_int, [vp, i32]),
         "fiesta_hip_snapshot_restore": (C.c_int, [vp, i32]),

@@ -293,6 +293,18 @@ int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint
 int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num_miss) {
   return guarded([&] { dense(m, "download_counts").download_counts(num_hit, num_miss); });
 }
+int fiesta_hip_get_occupied_voxels(fiesta_hip_map *m, int32_t *vox, int64_t capacity, int64_t *n_out) {
+  return guarded([&] {
+    need(n_out != nullptr && capacity >= 0, "bad argument");
+    *n_out = dense(m, "get_occupied_voxels").occupied_voxels(vox, capacity);
+  });
+}
+int fiesta_hip_get_slice(fiesta_hip_map *m, int32_t z_vox, double *out) {
+  return guarded([&] {
+    need(out != nullptr, "null argument");
+    dense(m, "get_slice").slice_distances(z_vox, out);
+  });
+}
 int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
                              uint8_t *occ) {
   return guarded([&] {

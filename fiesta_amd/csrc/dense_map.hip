@@ -509,6 +509,38 @@ __global__ void k_export(Geom g, const vox_t *coc, const uint32_t *occbits, int3
   }
 }
 
+// ---- visualisation exports (reference: GetPointCloud / GetSliceMarker, src/ESDFMap.cpp:544-699) ----
+// Occupied voxels, compacted on the device (wave-aggregated append); coordinates are map voxel coordinates.
+__global__ void k_occupied_list(Geom g, const uint32_t *occbits, int32_t *out, unsigned long long cap,
+                                unsigned long long *count) {
+  const int64_t nwords = (int64_t)g.nx * g.ny * g.nzw;
+  for (int64_t wi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; wi < nwords; wi += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t bits = occbits[wi];
+    if (!bits) continue;
+    const int zw = (int)(wi % g.nzw), y = (int)((wi / g.nzw) % g.ny), x = (int)(wi / ((int64_t)g.nzw * g.ny));
+    const unsigned long long base = atomicAdd(count, (unsigned long long)__popc(bits));
+    unsigned long long k = base;
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      if (k < cap) {
+        out[3 * k] = x + g.gx0;
+        out[3 * k + 1] = y + g.gy0;
+        out[3 * k + 2] = zw * 32 + b + g.gz0;
+      }
+      ++k;
+    }
+  }
+}
+// One z-slice of the distance field (GetDistance(Vector3i) per cell: unobserved / no obstacle read +10000).
+__global__ void k_slice(Geom g, const vox_t *coc, int z, double *out) {
+  const int64_t n = (int64_t)g.nx * g.ny;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i % g.ny), x = (int)(i / g.ny);
+    out[i] = vox_distance(g, coc, x, y, z);
+  }
+}
+
 // "updated voxel" as SURVEY.md 8d defines it: d^2 differs, or the old closest obstacle vanished.
 __global__ void k_count_updated(Geom g, const vox_t *before, const vox_t *now, const uint32_t *occbits,
                                 const uint32_t *gocc, unsigned long long *out) {
@@ -1135,6 +1167,36 @@ void DenseMap::download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *l
   if (coc) FIESTA_HIP_CHECK(hipMemcpyAsync(coc, dc, n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
   if (occ) FIESTA_HIP_CHECK(hipMemcpyAsync(occ, docc, n, hipMemcpyDeviceToHost, stream_));
   if (logodds) FIESTA_HIP_CHECK(hipMemcpyAsync(logodds, logodds_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+int64_t DenseMap::occupied_voxels(int32_t *vox, int64_t cap) {
+  use_device();
+  zero_counter(C_SCRATCH);
+  const int64_t nwords = nbitwords_;
+  int32_t *dout = nullptr;
+  if (vox && cap > 0) {
+    stage_a_.ensure((size_t)cap * 3 * sizeof(int32_t), stream_);
+    dout = (int32_t *)stage_a_.p;
+  }
+  hipLaunchKernelGGL(k_occupied_list, dim3(grid_for(nwords, 256, 8192)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
+                     dout, (unsigned long long)(dout ? cap : 0), &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  const int64_t n = (int64_t)read_counter(C_SCRATCH);
+  if (dout && n) FIESTA_HIP_CHECK(hipMemcpyAsync(vox, dout, (size_t)std::min(n, cap) * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  return n;
+}
+
+void DenseMap::slice_distances(int z_vox, double *out) {
+  use_device();
+  const int z = z_vox - g_.gz0;
+  if (z < 0 || z >= g_.nz) throw Error(FIESTA_HIP_ERR_INVALID, "slice outside the grid");
+  const int64_t n = (int64_t)g_.nx * g_.ny;
+  stage_c_.ensure((size_t)n * sizeof(double), stream_);
+  hipLaunchKernelGGL(k_slice, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, z, (double *)stage_c_.p);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 

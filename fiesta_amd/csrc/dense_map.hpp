@@ -93,6 +93,8 @@ class DenseMap {
 
   void download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds);
   void download_counts(int32_t *num_hit, int32_t *num_miss);
+  int64_t occupied_voxels(int32_t *vox, int64_t cap);  // returns the total count (may exceed cap)
+  void slice_distances(int z_vox, double *out);        // nx * ny doubles, x-major
   void snapshot_save(int slot);
   void snapshot_restore(int slot);
   int64_t snapshot_count_updated(int slot);

@@ -197,6 +197,21 @@ class ESDFMap:
         check(self._lib.fiesta_hip_download_field(self._h, _p(d2), _p(coc), _p(occ), _p(lo)))
         return {"d2": d2, "coc": coc, "occ": occ, "logodds": lo}
 
+    def GetOccupiedVoxels(self) -> np.ndarray:
+        """Voxel coordinates of all occupied voxels (the content of ESDFMap::GetPointCloud, src/ESDFMap.cpp:544-582)."""
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_get_occupied_voxels(self._h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 3), np.int32)
+        if n.value:
+            check(self._lib.fiesta_hip_get_occupied_voxels(self._h, _p(out), n.value, C.byref(n)))
+        return out
+
+    def GetSlice(self, z_vox: int) -> np.ndarray:
+        """Distances of the plane z = z_vox as an (nx, ny) array (ESDFMap::GetSliceMarker, src/ESDFMap.cpp:639-699)."""
+        out = np.empty(self.grid_size[:2], np.float64)
+        check(self._lib.fiesta_hip_get_slice(self._h, int(z_vox), _p(out)))
+        return out
+
     def download_counts(self):
         """Pending (num_hit_, num_miss_) per voxel; num_miss_ counts all observations (src/ESDFMap.cpp:424)."""
         n = self.grid_total_size_

@@ -147,14 +147,18 @@ class ESDFMap {
   void GetOccupiedVoxels(std::vector<Eigen::Vector3d> *centres) {
     Flush();
     centres->clear();
-    std::vector<uint8_t> occ((size_t)grid_total_size_);
-    ck(fiesta_hip_download_field(h_, nullptr, nullptr, occ.data(), nullptr));
-    for (int64_t i = 0; i < (int64_t)occ.size(); ++i)
-      if (occ[i]) {
-        const int z = i % gs_[2], y = (i / gs_[2]) % gs_[1], x = i / ((int64_t)gs_[2] * gs_[1]);
-        centres->push_back(Eigen::Vector3d((x + 0.5) * res_ + origin_[0], (y + 0.5) * res_ + origin_[1],
-                                           (z + 0.5) * res_ + origin_[2]));
-      }
+    int64_t n = 0;
+    ck(fiesta_hip_get_occupied_voxels(h_, nullptr, 0, &n));
+    std::vector<int32_t> vox((size_t)3 * n);
+    if (n) ck(fiesta_hip_get_occupied_voxels(h_, vox.data(), n, &n));
+    for (int64_t i = 0; i < n; ++i)  // voxel centres, as GetPointCloud emits them (src/ESDFMap.cpp:560-575)
+      centres->push_back(Eigen::Vector3d((vox[3 * i] + 0.5) * res_ + origin_[0], (vox[3 * i + 1] + 0.5) * res_ + origin_[1],
+                                         (vox[3 * i + 2] + 0.5) * res_ + origin_[2]));
+  }
+  // distances of the plane z = z_vox, nx * ny values, x-major (the data behind GetSliceMarker)
+  void GetSlice(int z_vox, std::vector<double> *dist) {
+    dist->resize((size_t)gs_[0] * gs_[1]);
+    ck(fiesta_hip_get_slice(h_, z_vox, dist->data()));
   }
 
   // DEBUG checkers (src/ESDFMap.cpp:856-1054). The doubly-linked lists they walk do not exist here; the

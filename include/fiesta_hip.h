@@ -171,6 +171,13 @@ int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint
 /* Pending observation counters num_hit_ / num_miss_ (include/ESDFMap.h:89; num_miss_ counts ALL observations
  * since the last UpdateOccupancy), dense order; each output nullable. */
 int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num_miss);
+/* Visualisation exports, compacted / sliced on the device (reference: ESDFMap::GetPointCloud and GetSliceMarker,
+ * src/ESDFMap.cpp:544-699, which fill ROS messages -- a ROS adapter wraps these two calls).
+ * get_occupied_voxels: map voxel coordinates of every occupied voxel, at most `capacity` triples are written,
+ * *n_out is the total (call with vox NULL / capacity 0 to size the buffer). Order is unspecified.
+ * get_slice: GetDistance(Vector3i) for every (x, y) of the plane z = z_vox, nx * ny doubles, x-major. */
+int fiesta_hip_get_occupied_voxels(fiesta_hip_map *m, int32_t *vox, int64_t capacity, int64_t *n_out);
+int fiesta_hip_get_slice(fiesta_hip_map *m, int32_t z_vox, double *out);
 /* Hash mode: allocated voxels in allocation order (vox n x 3); with all outputs NULL only *n_out is set. */
 int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
                              uint8_t *occ);

@@ -282,3 +282,25 @@ def test_local_sliding_window_mode(hip_lib, oracle_libs, best_oracle_kind):
         mism, inconsistent = compare_local()
         worst = max(worst, mism)
     assert worst <= 0.02 * n ** 3, worst
+
+
+def test_visualisation_exports(hip_lib, oracle_libs, best_oracle_kind):
+    """Device-side occupied-voxel compaction and z-slice extraction (the data behind GetPointCloud / GetSliceMarker,
+    src/ESDFMap.cpp:544-699) against the oracle's dense dump."""
+    n = 40
+    b = make_pair(oracle_libs, best_oracle_kind, (n, 33, 37))
+    observe_all(b)
+    rng = np.random.RandomState(4)
+    gs = b.gpu.grid_size
+    b.make_occupied((rng.rand(300, 3) * gs).astype(np.int32))
+    b.esdf()
+    o = b.cpu.dump_dense(("occ", "dist"))
+    want = np.argwhere(o["occ"].reshape(gs) == 1)
+    got = b.gpu.GetOccupiedVoxels()
+    assert len(got) == len(want) > 0
+    assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])].astype(np.int32))
+    for z in (0, 17, gs[2] - 1):
+        d = np.where(o["dist"] < 0, 10000.0, o["dist"]).reshape(gs)[:, :, z]
+        assert np.array_equal(b.gpu.GetSlice(z), d)
+    with pytest.raises(Exception):
+        b.gpu.GetSlice(gs[2])
