@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--tile-shape", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=192)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"], help="c2 = the headline metric; c3 = depth-frame pipeline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded driver even with one rank (smoke test)")
     ap.add_argument("--replicas", action="store_true",
@@ -141,8 +142,94 @@ def run_cpu_baseline(args):
     }
 
 
+def run_c3(args):
+    """BASELINE config 3 (`--workload c3`): 512^3 @0.1 m fed by 640x480 synthetic depth frames through the HIP ray cast
+    (fiesta_hip_raycast_depth) -> UpdateOccupancy -> UpdateESDF on one MI355X.  Scene: 6x6x3 m box
+    room with 5 spheres, sensor at the grid centre, yaw sweep 2 deg/frame, ray window 0.5-5.0 m, the reference's
+    de-duplication semantics.  One JSON line: rays/s, per-stage p50 ms, frame p50; cpu_baseline = the oracle on the
+    first frames (whose hit/miss counters must be bit-identical to the GPU's)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenarios import depth_to_points, render_depth, yaw_pose
+    import fiesta_amd
+    intr = dict(fx=384.4, fy=384.4, cx=323.1, cy=235.5)
+    G, res = args.grid, 0.1
+    half = G * res / 2
+    origin, size = (-half, -half, -half), (G * res,) * 3
+    m = fiesta_amd.ESDFMap(origin, res, size, tile_shape=args.tile_shape)
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    cpu, cpu_frames = None, 0 if args.no_cpu_baseline else 2
+    if cpu_frames:
+        from oracle import pyoracle
+        pyoracle.build("port")
+        kind = "ref" if pyoracle.available("ref", "array") else "port"
+        cpu = pyoracle.OracleMap(origin, res, size, kind=kind)
+        cpu.SetParameters(*P_DEFAULT)
+        cpu.SetOriginalRange()
+    spheres = [((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7), ((0.5, -2.0, -0.5), 0.4), ((-2.0, -1.0, 0.5), 0.6),
+               ((2.2, -1.8, 0.2), 0.3)]
+    nframes = args.warmup + args.steps
+    frames = []
+    for f in range(nframes):
+        T = yaw_pose(2.0 * f, (0.0, 0.0, 0.0))
+        frames.append((T, render_depth(T, rows=480, cols=640, spheres=spheres, intr=intr)))
+    lc, rc = origin, tuple(np.add(origin, size))
+    t_ray, t_fuse, t_esdf, t_all, cpu_t = [], [], [], [], []
+    for f, (T, depth) in enumerate(frames):
+        checked = cpu is not None and f < cpu_frames
+        t0 = time.perf_counter()
+        m.RaycastDepth(depth, intr["fx"], intr["fy"], intr["cx"], intr["cy"], T, T[:3, 3], 0.5, 5.0, lc, rc, dedup=1)
+        m.synchronize()
+        t1 = time.perf_counter()
+        if checked:
+            pts = depth_to_points(depth, intr)
+            c0 = time.perf_counter()
+            cpu.raycast_frame(pts, T, T[:3, 3], 0.5, 5.0, lc, rc)
+            c1 = time.perf_counter()
+            gh, gm = m.download_counts()
+            ch, cm = cpu.dump_counts()
+            assert np.array_equal(gm, cm) and np.array_equal(gh, ch), "hit/miss counters differ from the oracle"
+        t1b = time.perf_counter()
+        m.UpdateOccupancy(True)
+        m.synchronize()
+        t2 = time.perf_counter()
+        st = m.UpdateESDF()
+        t3 = time.perf_counter()
+        if checked:
+            c2 = time.perf_counter()
+            cpu.UpdateOccupancy(True)
+            c3 = time.perf_counter()
+            sc = cpu.UpdateESDF()
+            c4 = time.perf_counter()
+            assert (st["inserted"], st["deleted"]) == (sc["inserted"], sc["deleted"])
+            cpu_t.append({"raycast_ms": (c1 - c0) * 1e3, "fuse_ms": (c3 - c2) * 1e3, "esdf_ms": (c4 - c3) * 1e3})
+        if f >= args.warmup and not checked:
+            t_ray.append((t1 - t0) * 1e3)
+            t_fuse.append((t2 - t1b) * 1e3)
+            t_esdf.append((t3 - t2) * 1e3)
+            t_all.append((t1 - t0 + t3 - t1b) * 1e3)
+    p50 = statistics.median
+    out = {
+        "metric": "c3_depth_frames_per_sec", "value": 1e3 / p50(t_all), "unit": "frames/s", "n_gpus": 1, "steps": len(t_all),
+        "warmup": args.warmup, "ms_per_step": p50(t_all), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 ray arithmetic, u32 voxel words", "data": "synthetic",
+        "config": {"workload": f"C3: {G}^3 @0.1 m, 640x480 depth frames (307200 rays), yaw 2 deg/frame, dedup=1; host "
+                               "uint16 image uploaded inside the timed ray cast (PCIe-inclusive)"},
+        "raycast_p50_ms": p50(t_ray), "rays_per_sec": 307200 / (p50(t_ray) * 1e-3),
+        "update_occupancy_p50_ms": p50(t_fuse), "update_esdf_p50_ms": p50(t_esdf),
+        "cpu_baseline": {"kind": "reference" if cpu is not None and cpu.describe.startswith("reference") else "port",
+                         "cores": 1, "unit": "ms per stage", "sample": "the first frames of the same sequence",
+                         "frames": cpu_t, "counters_bit_identical": bool(cpu_t)} if cpu_t else None,
+    }
+    print(json.dumps(out), flush=True)
+    m.close()
+
+
 def main():
     args = parse()
+    if args.workload == "c3":
+        import torch  # noqa: F401  (one HIP runtime per process: torch first)
+        return run_c3(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
