@@ -50,6 +50,18 @@ __host__ __device__ inline int32_t dist2(int x, int y, int z, vox_t c) {
 
 // The 24-direction stencil (include/parameters.h:54-68): 6 faces, 12 edges, 6 two-step faces.
 // Order is the reference's; it is irrelevant for the fixed point.
+// the same stencil as two halves of 12 (for kernels that batch the neighbour reads but are short of registers)
+#define FIESTA_STENCIL12A(X)                                                                            \
+  X(-1, 0, 0) X(1, 0, 0) X(0, -1, 0) X(0, 1, 0) X(0, 0, -1) X(0, 0, 1) X(-1, -1, 0) X(1, 1, 0)          \
+  X(0, -1, -1) X(0, 1, 1) X(-1, 0, -1) X(1, 0, 1)
+#define FIESTA_STENCIL12B(X)                                                                            \
+  X(-1, 1, 0) X(1, -1, 0) X(0, -1, 1) X(0, 1, -1) X(1, 0, -1) X(-1, 0, 1) X(-2, 0, 0) X(2, 0, 0)        \
+  X(0, -2, 0) X(0, 2, 0) X(0, 0, -2) X(0, 0, 2)
+// ... and as four groups of 6
+#define FIESTA_STENCIL6A(X) X(-1, 0, 0) X(1, 0, 0) X(0, -1, 0) X(0, 1, 0) X(0, 0, -1) X(0, 0, 1)
+#define FIESTA_STENCIL6B(X) X(-1, -1, 0) X(1, 1, 0) X(0, -1, -1) X(0, 1, 1) X(-1, 0, -1) X(1, 0, 1)
+#define FIESTA_STENCIL6C(X) X(-1, 1, 0) X(1, -1, 0) X(0, -1, 1) X(0, 1, -1) X(1, 0, -1) X(-1, 0, 1)
+#define FIESTA_STENCIL6D(X) X(-2, 0, 0) X(2, 0, 0) X(0, -2, 0) X(0, 2, 0) X(0, 0, -2) X(0, 0, 2)
 #define FIESTA_STENCIL24(X)                                                                             \
   X(-1, 0, 0) X(1, 0, 0) X(0, -1, 0) X(0, 1, 0) X(0, 0, -1) X(0, 0, 1) X(-1, -1, 0) X(1, 1, 0)          \
   X(0, -1, -1) X(0, 1, 1) X(-1, 0, -1) X(1, 0, 1) X(-1, 1, 0) X(1, -1, 0) X(0, -1, 1) X(0, 1, -1)       \

@@ -641,10 +641,10 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
     case 3: tx_ = 16, ty_ = 16, engine_ = 0; break;
     case 4: tx_ = 4, ty_ = 8, engine_ = 0; break;
     case 10: tx_ = 8, ty_ = 8, engine_ = 1; break;
+    case 0:  // 1024 threads = 4 waves/SIMD under a 128-VGPR cap; the push runs in four batches of 6 directions to fit
     case 11: tx_ = 16, ty_ = 16, engine_ = 1; break;
     case 12: tx_ = 16, ty_ = 8, engine_ = 1; break;
-    case 0:  // 512 threads: 256 VGPRs per lane, no spills (1024 threads cap at 128 and spill to scratch)
-    case 13: tx_ = 16, ty_ = 16, engine_ = 1, threads_ = 512; break;
+    case 13: tx_ = 16, ty_ = 16, engine_ = 1, threads_ = 512; break;  // 2 waves/SIMD, 213 VGPRs, single 24-batch
     default: throw Error(FIESTA_HIP_ERR_INVALID, "unknown tile_shape");
   }
   if (sharded && engine_ != 1) throw Error(FIESTA_HIP_ERR_INVALID, "sharded maps need the work-queue engine");

@@ -329,24 +329,40 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
               if (prof) ++n_pulls;
               vox_t best = lo;
               uint32_t bestd = hi;
-              vox_t un[24];
-              {
-                int q = 0;
-#define FIESTA_PULLL(DX, DY, DZ) un[q++] = KW(2 * (v + ((DX)*RY + (DY)) * RZ + (DZ)));
-                FIESTA_STENCIL24(FIESTA_PULLL)
-#undef FIESTA_PULLL
-              }
-#pragma unroll
-              for (int q = 0; q < 24; ++q) {
-                const vox_t u = un[q];
-                if (!(u & (kNoCoc | kAct))) {
-                  const uint32_t d = (uint32_t)dist2(vx, vy, vz, u);
-                  if (d < bestd) {
-                    bestd = d;
-                    best = u;
-                  }
+#define FIESTA_PULLL(DX, DY, DZ) un[q++] = KW(2 * (v + (((DX)*RY + (DY)) * RZ + (DZ))));
+#define FIESTA_PULLEVAL(NQ)                                 \
+  _Pragma("unroll") for (int q = 0; q < (NQ); ++q) {        \
+    const vox_t u = un[q];                                  \
+    if (!(u & (kNoCoc | kAct))) {                           \
+      const uint32_t d = (uint32_t)dist2(vx, vy, vz, u);    \
+      if (d < bestd) {                                      \
+        bestd = d;                                          \
+        best = u;                                           \
+      }                                                     \
+    }                                                       \
+  }
+              if (NT >= 1024) {
+                vox_t un[12];
+                {
+                  int q = 0;
+                  FIESTA_STENCIL12A(FIESTA_PULLL)
                 }
+                FIESTA_PULLEVAL(12)
+                {
+                  int q = 0;
+                  FIESTA_STENCIL12B(FIESTA_PULLL)
+                }
+                FIESTA_PULLEVAL(12)
+              } else {
+                vox_t un[24];
+                {
+                  int q = 0;
+                  FIESTA_STENCIL24(FIESTA_PULLL)
+                }
+                FIESTA_PULLEVAL(24)
               }
+#undef FIESTA_PULLL
+#undef FIESTA_PULLEVAL
               if (bestd < hi) {
                 const unsigned long long mine = ((unsigned long long)bestd << 32) | best | kAct;
                 const unsigned long long old = atomicMin(&K64(v), mine);
@@ -366,15 +382,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
           const unsigned long long keylo = (unsigned long long)(c | kAct);
 #define FIESTA_NIDX(DX, DY, DZ) \
   (CLAMP ? min(max(v + (((DX)*RY + (DY)) * RZ + (DZ)), 0), RSIZE - 1) : v + (((DX)*RY + (DY)) * RZ + (DZ)))
-          uint32_t dnv[24];
-          {
-            int q = 0;
 #define FIESTA_PUSHL(DX, DY, DZ) dnv[q++] = KW(2 * FIESTA_NIDX(DX, DY, DZ) + 1);
-            FIESTA_STENCIL24(FIESTA_PUSHL)
-#undef FIESTA_PUSHL
-          }
-          {
-            int q = 0;
 #define FIESTA_PUSH(DX, DY, DZ)                                                                              \
   {                                                                                                          \
     const uint32_t cand = (uint32_t)(dv + (DX)*ax + (DY)*ay + (DZ)*az + ((DX) * (DX) + (DY) * (DY) + (DZ) * (DZ))); \
@@ -386,9 +394,35 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       __hip_atomic_fetch_or(&Fn[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    \
     }                                                                                                        \
   }
-            FIESTA_STENCIL24(FIESTA_PUSH)
-#undef FIESTA_PUSH
+          if (NT >= 1024) {  // 128-VGPR budget: four batches of 6 filter reads
+            uint32_t dnv[6];
+#define FIESTA_BATCH(ST)  \
+  {                       \
+    int q = 0;            \
+    ST(FIESTA_PUSHL)      \
+  }                       \
+  {                       \
+    int q = 0;            \
+    ST(FIESTA_PUSH)       \
+  }
+            FIESTA_BATCH(FIESTA_STENCIL6A)
+            FIESTA_BATCH(FIESTA_STENCIL6B)
+            FIESTA_BATCH(FIESTA_STENCIL6C)
+            FIESTA_BATCH(FIESTA_STENCIL6D)
+#undef FIESTA_BATCH
+          } else {
+            uint32_t dnv[24];
+            {
+              int q = 0;
+              FIESTA_STENCIL24(FIESTA_PUSHL)
+            }
+            {
+              int q = 0;
+              FIESTA_STENCIL24(FIESTA_PUSH)
+            }
           }
+#undef FIESTA_PUSHL
+#undef FIESTA_PUSH
 #undef FIESTA_NIDX
         }
       };
