@@ -846,10 +846,11 @@ bool DenseMap::check_update() {  // CheckUpdate (src/ESDFMap.cpp:227-233)
 
 bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
   use_device();
-  unsigned long long nt = touched_upper_ ? read_counter(C_TOUCHED) : 0;
-  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long),
+  // C_TOUCHED, C_INSERT, C_DELETE are adjacent: one copy, one synchronisation
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_TOUCHED], &counters_[C_TOUCHED], 3 * sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  unsigned long long nt = touched_upper_ ? h_counters_[C_TOUCHED] : 0;
   unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
   if (nt) {
     ins_.ensure(ni + nt, stream_, ni);
