@@ -106,12 +106,10 @@ __global__ void k_observe_pos(Geom g, const double *pos, const int32_t *occ, int
 }
 
 // ---- UpdateOccupancy (src/ESDFMap.cpp:235-271): one lane per touched voxel ----
-__global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *touched, int64_t n,
-                       unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *gocc,
-                       uint32_t *ins, uint32_t *del, unsigned long long *counters) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t idx = touched[i];
+// UpdateOccupancy for one touched voxel (src/ESDFMap.cpp:239-267); reports a transition, does not queue it.
+__device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_map, uint32_t idx,
+                                     unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits,
+                                     uint32_t *gocc, bool &to_ins, bool &to_del) {
   const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
   const unsigned long long c = cnt[idx];
   cnt[idx] = 0;  // num_hit_ = num_miss_ = 0 (:245)
@@ -132,11 +130,40 @@ __global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *to
   if (now && !was) {  // free -> occupied: insert_queue_ (:263-264)
     atomicOr(&occbits[g.bitword(x, y, z)], bit);
     if (g.sharded) atomicOr(&gocc[g.gbitword(x + g.gx0, y + g.gy0, z + g.gz0)], 1u << ((z + g.gz0) & 31));
-    ins[atomicAdd(&counters[C_INSERT], 1ull)] = idx;
+    to_ins = true;
   } else if (!now && was) {  // occupied -> free: delete_queue_ (:265-266)
     atomicAnd(&occbits[g.bitword(x, y, z)], ~bit);
     if (g.sharded) atomicAnd(&gocc[g.gbitword(x + g.gx0, y + g.gy0, z + g.gz0)], ~(1u << ((z + g.gz0) & 31)));
-    del[atomicAdd(&counters[C_DELETE], 1ull)] = idx;
+    to_del = true;
+  }
+}
+
+// ---- UpdateOccupancy (src/ESDFMap.cpp:235-271): one lane per touched voxel ----
+__global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *touched, int64_t n,
+                       unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *gocc,
+                       uint32_t *ins, uint32_t *del, unsigned long long *counters) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool to_ins = false, to_del = false;
+  uint32_t idx = 0;
+  if (i < n) {
+    idx = touched[i];
+    fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, to_ins, to_del);
+  }
+  // queue appends: ONE atomic per wave and queue (tens of thousands of transitions would otherwise serialise on
+  // the two counters)
+  const int lane = threadIdx.x & 63;
+  const unsigned long long mi = __ballot(to_ins), md = __ballot(to_del);
+  if (mi) {
+    uint32_t base = 0;  // (queues hold < 2^32 entries: voxel indices are 32-bit)
+    if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_INSERT], (unsigned long long)__popcll(mi));
+    base = __shfl(base, 0);
+    if (to_ins) ins[base + __popcll(mi & ((1ull << lane) - 1ull))] = idx;
+  }
+  if (md) {
+    uint32_t base = 0;
+    if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_DELETE], (unsigned long long)__popcll(md));
+    base = __shfl(base, 0);
+    if (to_del) del[base + __popcll(md & ((1ull << lane) - 1ull))] = idx;
   }
 }
 
@@ -164,41 +191,54 @@ __global__ void k_seed_insert(Geom g, TileGrid tg, const uint32_t *ins, int64_t 
 __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits,
                                                     const uint32_t *gocc, uint32_t *flag, uint32_t *list,
                                                     unsigned long long *count, unsigned long long *counters) {
-  // one wave per z-row (64 voxels = 256 B per step): row and tile arithmetic is wave-uniform 32-bit math
-  const int zchunks = (g.nz + 63) >> 6;
+  // one wave per z-row, 16-byte loads: a lane owns 4 consecutive voxels (256 voxels = 1 KiB per wave step), so the
+  // four obstacle-occupancy gathers of a lane are independent instead of one dependent load -> gather -> store chain
+  // per voxel. Row and tile arithmetic is wave-uniform 32-bit math. (nz % 4 != 0: the same loop with scalar loads.)
   const uint32_t nrows = (uint32_t)g.nx * (uint32_t)g.ny;
   const int lane = threadIdx.x & 63;
+  const bool vec = (g.nz & 3) == 0;
   unsigned long long local = 0;
   for (uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4u) {
     const int x = (int)(row / (uint32_t)g.ny), y = (int)(row - (uint32_t)x * (uint32_t)g.ny);
     const int64_t base = (int64_t)row * g.nz;
-    for (int zc = 0; zc < zchunks; ++zc) {
-      const int z = zc * 64 + lane;
-      bool reset = false;
-      if (z < g.nz) {
-        const vox_t w = coc[base + z];
-        if (!(w & kNoCoc)) {
+    for (int zb = 0; zb < g.nz; zb += 256) {
+      const int z4 = zb + 4 * lane;
+      vox_t w[4] = {kUnobserved, kUnobserved, kUnobserved, kUnobserved};
+      if (vec) {
+        if (z4 < g.nz) {
+          const uint4 q = *reinterpret_cast<const uint4 *>(coc + base + z4);
+          w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (z4 + k < g.nz) w[k] = coc[base + z4 + k];
+      }
+      uint32_t rmask = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!(w[k] & kNoCoc)) {
           int cx, cy, cz;
-          unpack_coc(w, cx, cy, cz);
-          if (g.owned(x, y, z) && !obstacle_alive(g, occbits, gocc, cx, cy, cz)) {
-            coc[base + z] = kReset;
-            reset = true;
-          }
+          unpack_coc(w[k], cx, cy, cz);
+          if (g.owned(x, y, z4 + k) && !obstacle_alive(g, occbits, gocc, cx, cy, cz)) rmask |= 1u << k;
         }
       }
-      const unsigned long long m = __ballot(reset);
-      if (m) {
-        if (lane == 0) local += __popcll(m);
-        if ((lane & 31) == 0 && z < g.nz) {
-          const uint32_t half = (lane & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
-          if (half) {
-            const uint32_t t = tg.tile_of(x, y, z);
-            if (flag[t] == 0u) activate_tile(t, flag, list, count);
-          }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((rmask >> k) & 1u) coc[base + z4 + k] = kReset;
+      if (__ballot(rmask != 0)) {
+        local += __popc(rmask);
+        // lanes 8j .. 8j+7 cover the 32 voxels of one tile along z
+        const unsigned long long m = __ballot(rmask != 0);
+        const int grp = lane >> 3;
+        if ((lane & 7) == 0 && ((m >> (grp * 8)) & 0xFFull) && z4 < g.nz) {
+          const uint32_t t = tg.tile_of(x, y, z4);
+          if (flag[t] == 0u) activate_tile(t, flag, list, count);
         }
       }
     }
   }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
   if (lane == 0 && local) atomicAdd(&counters[C_INVALIDATED], local);
 }
 
