@@ -67,6 +67,19 @@ __host__ __device__ inline int32_t dist2(int x, int y, int z, vox_t c) {
   X(0, -1, -1) X(0, 1, 1) X(-1, 0, -1) X(1, 0, 1) X(-1, 1, 0) X(1, -1, 0) X(0, -1, 1) X(0, 1, -1)       \
   X(1, 0, -1) X(-1, 0, 1) X(-2, 0, 0) X(2, 0, 0) X(0, -2, 0) X(0, 2, 0) X(0, 0, -2) X(0, 0, 2)
 
+// Appends `value` to list[] for every ACTIVE lane whose `pred` holds, with ONE atomicAdd per wave (hundreds of
+// thousands of appends per batch would otherwise serialise on the counter). Safe in divergent code: the ballot only
+// sees the lanes that execute the call. Work-groups are 1-D with a multiple of 64 threads everywhere in this engine.
+__device__ inline void wave_append(bool pred, uint32_t value, uint32_t *list, unsigned long long *counter) {
+  const unsigned long long m = __ballot(pred);
+  if (!m) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = (uint32_t)atomicAdd(counter, (unsigned long long)__popcll(m));
+  base = __shfl(base, leader);
+  if (pred) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
 // ---- geometry of one (shard of a) dense grid -------------------------------------------------------
 struct Geom {
   int nx, ny, nz;     // local array extent (owned box + ghost layers when sharded)

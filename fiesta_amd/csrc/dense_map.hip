@@ -64,10 +64,8 @@ __global__ void k_observe_vox(Geom g, const int32_t *vox, const int32_t *occ, in
   const int64_t idx = g.idx(x, y, z);
   const unsigned long long add = ((unsigned long long)(uint32_t)occ[i] << 32) | 1ull;
   const unsigned long long old = atomicAdd(&cnt[idx], add);
-  if ((uint32_t)old == 0) {  // num_miss_ became 1: first touch since the last fusion (:426)
-    const unsigned long long slot = atomicAdd(&counters[C_TOUCHED], 1ull);
-    touched[slot] = (uint32_t)idx;
-  }
+  // num_miss_ became 1: first touch since the last fusion -> occupancy_queue_ (:426)
+  wave_append((uint32_t)old == 0, (uint32_t)idx, touched, &counters[C_TOUCHED]);
 }
 
 // SetOccupancy(Vector3i, occ) for EVERY voxel of a box (map coordinates, inclusive), e.g. "observe the whole
@@ -80,7 +78,7 @@ __global__ void k_observe_box(Geom g, int bx0, int by0, int bz0, int ex, int ey,
     if (!g.in_grid(x, y, z) || !g.in_window(x, y, z) || !g.owned(x, y, z)) continue;
     const int64_t idx = g.idx(x, y, z);
     const unsigned long long old = atomicAdd(&cnt[idx], ((unsigned long long)(uint32_t)occ << 32) | 1ull);
-    if ((uint32_t)old == 0) touched[atomicAdd(&counters[C_TOUCHED], 1ull)] = (uint32_t)idx;
+    wave_append((uint32_t)old == 0, (uint32_t)idx, touched, &counters[C_TOUCHED]);
   }
 }
 
@@ -99,10 +97,7 @@ __global__ void k_observe_pos(Geom g, const double *pos, const int32_t *occ, int
   if (!g.in_grid(x, y, z) || !g.in_window(x, y, z) || !g.owned(x, y, z)) return;
   const int64_t idx = g.idx(x, y, z);
   const unsigned long long old = atomicAdd(&cnt[idx], ((unsigned long long)(uint32_t)o << 32) | 1ull);
-  if ((uint32_t)old == 0) {
-    const unsigned long long slot = atomicAdd(&counters[C_TOUCHED], 1ull);
-    touched[slot] = (uint32_t)idx;
-  }
+  wave_append((uint32_t)old == 0, (uint32_t)idx, touched, &counters[C_TOUCHED]);
 }
 
 // ---- UpdateOccupancy (src/ESDFMap.cpp:235-271): one lane per touched voxel ----

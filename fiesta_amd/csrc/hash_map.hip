@@ -89,7 +89,7 @@ __global__ void k_h_assign(const uint32_t *fresh, int64_t k, int32_t first_page,
 // ---- SetOccupancy (src/ESDFMap.cpp:401-437) ----
 __device__ inline void h_count(int64_t addr, int occ, unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
   const unsigned long long old = atomicAdd(&cnt[addr], ((unsigned long long)(uint32_t)occ << 32) | 1ull);
-  if ((uint32_t)old == 0) touched[atomicAdd(&counters[C_TOUCHED], 1ull)] = (uint32_t)addr;
+  wave_append((uint32_t)old == 0, (uint32_t)addr, touched, &counters[C_TOUCHED]);
 }
 __global__ void k_h_observe_vox(Geom g, const int32_t *dir, const int32_t *vox, const int32_t *occ, int64_t n,
                                 unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {

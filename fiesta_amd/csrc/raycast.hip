@@ -99,7 +99,7 @@ __device__ inline bool ray_pos_in_map(const Geom &g, const double *p) {
 __device__ inline void count_observation(int64_t idx, int occ, unsigned long long *cnt, uint32_t *touched,
                                          unsigned long long *counters) {
   const unsigned long long old = atomicAdd(&cnt[idx], ((unsigned long long)(uint32_t)occ << 32) | 1ull);
-  if ((uint32_t)old == 0) touched[atomicAdd(&counters[C_TOUCHED], 1ull)] = (uint32_t)idx;
+  wave_append((uint32_t)old == 0, (uint32_t)idx, touched, &counters[C_TOUCHED]);
 }
 
 // flags: bit0 valid ray, bit1 casts (winner of its end-point voxel), bit2 traversal overflow
