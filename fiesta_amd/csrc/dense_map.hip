@@ -726,7 +726,6 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   pp_ = ProbParams{0, 0, 0, 0, 0};
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_SPATIAL")) spatial_ = atoi(e);
-  if (const char *e = getenv("FIESTA_HIP_HYBRID")) hybrid_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -971,7 +970,6 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     a.prof = prof_;
     a.dir = nullptr;
     a.spatial = spatial_;
-    a.hybrid = (spatial_ && hybrid_ && tx_ == 16 && ty_ == 16) ? 1 : 0;
     // spatial walk: a multiple of 8 blocks (one stream per XCD), a few per CU for load balance
     const int blocks = spatial_ ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), (uint32_t)spatial_blocks_)
                                 : (int)std::min<uint32_t>(ncur, 16384u);
@@ -984,8 +982,6 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
       hipLaunchKernelGGL((k_relax_q<16, 16, 1024>), dim3(blocks), dim3(1024), 0, stream_, a);
     else
       hipLaunchKernelGGL((k_relax_q<16, 8, 512>), dim3(blocks), dim3(512), 0, stream_, a);
-    if (a.hybrid)  // revisits: light kernel on the words in HBM (runs after the staging kernel of the same round)
-      hipLaunchKernelGGL((k_relax_light<16, 16, 256>), dim3(blocks), dim3(256), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds + 1), stream_));
     ++rounds;

@@ -167,7 +167,6 @@ class DenseMap {
   uint32_t *cbits_[2] = {nullptr, nullptr};     // 1 bit/voxel: changed in the round of that parity
   uint32_t *cstamp_[2] = {nullptr, nullptr};    // per tile: serial of the round that wrote cbits_[parity]
   int prof_ = 0;
-  int hybrid_ = 0;   // EXPERIMENT (FIESTA_HIP_HYBRID=1): revisits via k_relax_light on the words in HBM -- measured slower
   int spatial_blocks_ = 1024;  // work-groups of the spatial walk (multiple of 8: one stream of tiles per XCD)
   int spatial_ = 1;  // walk the tiles in XCD-chunked spatial order (FIESTA_HIP_SPATIAL=0: compact list order)
   uint32_t serial_ = 0;                         // relaxation rounds launched so far (all updates)

@@ -530,7 +530,6 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
     a.prof = prof_;
     a.dir = dir_;
     a.spatial = 0;
-    a.hybrid = 0;
     FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
     hipLaunchKernelGGL((k_relax_q<kTX, kTY, 1024, true>), dim3(std::min<uint32_t>(ncur, 16384u)), dim3(1024), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());

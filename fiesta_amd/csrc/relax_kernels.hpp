@@ -63,7 +63,6 @@ struct RelaxQArgs {
   unsigned long long *count_next;
   unsigned long long *counters;
   int spatial;  // dense maps: 1 = walk all tiles in XCD-chunked spatial order (flag_cur is the list)
-  int hybrid;   // dense maps: 1 = revisits of a tile within one update are handled by k_relax_light
   int prof;  // 1: accumulate per-phase cycle counters into counters[C_PROF0..]
   // paged (hash-block) maps: voxel data lives in a pool of pages, one page = one tile (TX x TY x 32 voxels, same
   // z-fastest row layout), found through the dense page directory dir[tile] (-1: not allocated = all unobserved)
@@ -119,8 +118,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       const uint32_t chunk = (v >> 6) * 8u + xcd;
       if (chunk * 64u >= ntiles) break;
       t = chunk * 64u + (v & 63u);
-      // hybrid mode: this (staging) kernel only takes a tile's FIRST visit of the update; revisits go to k_relax_light
-      const bool active = t < ntiles && a.flag_cur[t] != 0u && (!a.hybrid || a.tile_epoch[t] != a.epoch);
+      const bool active = t < ntiles && a.flag_cur[t] != 0u;
       __syncthreads();  // everybody has read the flag before thread 0 clears it below
       if (!active) continue;
     }
@@ -518,269 +516,5 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
 #undef K64
 #undef KW
 
-
-// =====================================================================================================
-// k_relax_light -- the REVISIT of a tile that was already relaxed in this update (dense maps).
-//
-// After its first visit a tile is a local fixed point; later rounds only have to absorb what changed in the
-// neighbouring tiles' boundary shells, which typically moves a few hundred of the tile's 8192 voxels. Staging 14 400
-// voxels into 155 KB of LDS for that (k_relax_q) costs more than the work itself, so a revisit works directly on the
-// 4-byte words in HBM / L2: halo voxels that changed in the previous round offer their obstacle to the tile's voxels,
-// improved voxels are queued (frontier bitmaps + compaction, as in k_relax_q) and run the reference's pull + push
-// on global memory, updates are compare-and-swap on the 32-bit word (d^2 is recomputed from the word, never stored).
-// 24 KB of LDS and 256 threads: six work-groups share a CU. Same round protocol as k_relax_q (cbits / stamps / flags).
-// =====================================================================================================
-__device__ inline uint32_t word_d2(vox_t w, int gx, int gy, int gz) {  // kUnobserved -> 0: never improvable
-  return w == kUnobserved ? 0u : ((w & kNoCoc) ? (uint32_t)kD2Inf : (uint32_t)dist2(gx, gy, gz, w & ~kAct));
-}
-// try to give voxel *p (global coords gx,gy,gz) the obstacle `c` at squared distance cand
-__device__ inline bool improve_word(vox_t *p, vox_t seen, uint32_t cand, vox_t c, int gx, int gy, int gz) {
-  for (;;) {
-    if (cand >= word_d2(seen, gx, gy, gz)) return false;
-    const vox_t prev = atomicCAS(p, seen, c);
-    if (prev == seen) return true;
-    seen = prev;
-  }
-}
-
-template <int TX, int TY, int NT>
-__global__ __launch_bounds__(NT) void k_relax_light(RelaxQArgs a) {
-  constexpr int TZ = 32, H = 2;
-  constexpr int RX = TX + 2 * H, RY = TY + 2 * H, RZ = TZ + 2 * H, RSIZE = RX * RY * RZ;
-  constexpr int TILE = TX * TY * TZ, NWT = TILE / 32, NROWW = RX * RY * 3, NWAVE = NT / 64;
-  static_assert(NWT <= NT && TILE <= 65536, "tile shape");
-  __shared__ uint16_t Q[TILE];
-  __shared__ uint32_t F[2][NWT], E[NWT];
-  __shared__ uint32_t cb[NROWW];
-  __shared__ uint32_t wsum[NWAVE];
-  __shared__ uint32_t nb_ok[27];
-  __shared__ int nbr_dirty[27];
-  const Geom &g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t ntiles = (uint32_t)(a.tg.ntx * a.tg.nty * a.tg.ntz);
-
-  for (uint32_t it = 0;; ++it) {
-    const uint32_t xcd = blockIdx.x & 7u, vv = (blockIdx.x >> 3) + it * (gridDim.x >> 3);
-    const uint32_t chunk = (vv >> 6) * 8u + xcd;
-    if (chunk * 64u >= ntiles) break;
-    const uint32_t t = chunk * 64u + (vv & 63u);
-    const bool active = t < ntiles && a.flag_cur[t] != 0u && a.tile_epoch[t] == a.epoch;
-    __syncthreads();
-    if (!active) continue;
-    const int tz = t % a.tg.ntz, ty = (t / a.tg.ntz) % a.tg.nty, tx = t / (a.tg.ntz * a.tg.nty);
-    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
-    if (tid == 0) a.flag_cur[t] = 0;
-    if (tid < 27) {
-      nbr_dirty[tid] = 0;
-      const int ux = tx + tid / 9 - 1, uy = ty + (tid / 3) % 3 - 1, uz = tz + tid % 3 - 1;
-      uint32_t ok = 0;
-      if (tid != 13 && (unsigned)ux < (unsigned)a.tg.ntx && (unsigned)uy < (unsigned)a.tg.nty && (unsigned)uz < (unsigned)a.tg.ntz) {
-        const uint32_t ot = (ux * a.tg.nty + uy) * a.tg.ntz + uz;
-        if (a.cstamp_prev[ot] == a.serial - 1u) ok = 1u;
-      }
-      nb_ok[tid] = ok;
-    }
-    for (int w = tid; w < NWT; w += NT) F[0][w] = F[1][w] = E[w] = 0u;
-    __syncthreads();
-    for (int j = tid; j < NROWW; j += NT) {  // "changed in the previous round" bitmaps of the halo rows
-      const int k = j % 3, ry = (j / 3) % RY, rx = j / (3 * RY);
-      const int x = x0 - H + rx, y = y0 - H + ry, zt = tz - 1 + k;
-      const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1);
-      uint32_t c = 0;
-      if (nb_ok[ox * 9 + oy * 3 + k] && (unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny)
-        c = a.cbits_prev[((int64_t)x * g.ny + y) * g.nzw + zt];
-      cb[j] = c;
-    }
-    __syncthreads();
-
-    // is (x,y,z) a voxel of this tile that may be written?
-    auto target_ok = [&](int x, int y, int z) {
-      return (unsigned)(x - x0) < (unsigned)TX && (unsigned)(y - y0) < (unsigned)TY && (unsigned)(z - z0) < (unsigned)TZ &&
-             g.in_grid(x, y, z) && g.in_window(x, y, z) && g.owned(x, y, z);
-    };
-    auto mark = [&](uint32_t *bits, int x, int y, int z) {
-      const int ii = ((x - x0) * TY + (y - y0)) * TZ + (z - z0);
-      __hip_atomic_fetch_or(&bits[ii >> 5], 1u << (ii & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    // a source voxel (x,y,z) holding obstacle word c offers it to its stencil neighbours inside the tile. tw[] are
-    // the neighbours' words, loaded by the caller in ONE batch (kUnobserved where the neighbour is not a writable
-    // voxel of this tile): 24 dependent L2 round trips per source would otherwise dominate the kernel.
-    auto offer = [&](int x, int y, int z, vox_t c, uint32_t *Fn, const vox_t *tw) {
-      const int gx = g.gx0 + x, gy = g.gy0 + y, gz = g.gz0 + z;
-      const int rcx = gx - (int)((c >> 20) & 1023), rcy = gy - (int)((c >> 10) & 1023), rcz = gz - (int)(c & 1023);
-      const int32_t dv = rcx * rcx + rcy * rcy + rcz * rcz;
-      int q = 0;
-#define FIESTA_OFFER(DX, DY, DZ)                                                                              \
-  {                                                                                                           \
-    const vox_t seen = tw[q++];                                                                               \
-    const uint32_t cand = (uint32_t)(dv + 2 * ((DX)*rcx + (DY)*rcy + (DZ)*rcz) + ((DX) * (DX) + (DY) * (DY) + (DZ) * (DZ))); \
-    if (cand < word_d2(seen, gx + (DX), gy + (DY), gz + (DZ)) &&                                              \
-        improve_word(&a.coc[g.idx(x + (DX), y + (DY), z + (DZ))], seen, cand, c, gx + (DX), gy + (DY), gz + (DZ))) { \
-      mark(Fn, x + (DX), y + (DY), z + (DZ));                                                                 \
-      mark(E, x + (DX), y + (DY), z + (DZ));                                                                  \
-    }                                                                                                         \
-  }
-      FIESTA_STENCIL24(FIESTA_OFFER)
-#undef FIESTA_OFFER
-    };
-    // the 24 stencil neighbours' words of (x,y,z); only_targets: kUnobserved unless a writable voxel of this tile
-    auto load_nbrs = [&](int x, int y, int z, vox_t *tw, const bool only_targets) {
-      int q = 0;
-#define FIESTA_LNB(DX, DY, DZ)                                                                                \
-  {                                                                                                           \
-    const int nx = x + (DX), ny = y + (DY), nz = z + (DZ);                                                    \
-    const bool ok = only_targets ? target_ok(nx, ny, nz) : (g.in_grid(nx, ny, nz) && g.in_window(nx, ny, nz)); \
-    vox_t u = kUnobserved;                                                                                    \
-    if (ok) u = a.coc[g.idx(nx, ny, nz)];                                                                     \
-    tw[q++] = u;                                                                                              \
-  }
-      FIESTA_STENCIL24(FIESTA_LNB)
-#undef FIESTA_LNB
-    };
-
-    // ---- level 0: halo voxels that changed in the previous round (and tagged ghost cells of a shard)
-    for (int i = tid; i < RSIZE; i += NT) {
-      const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
-      const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
-      const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY && (unsigned)(rz - H) < (unsigned)TZ;
-      if (!g.in_grid(x, y, z) || !g.in_window(x, y, z)) continue;
-      if (interior) {
-        if (!g.sharded || g.owned(x, y, z)) continue;
-        vox_t *p = &a.coc[g.idx(x, y, z)];  // ghost cell of a shard: a source iff the halo exchange tagged it
-        const vox_t w = *p;
-        if (w == kUnobserved || !(w & kAct)) continue;
-        *p = w & ~kAct;
-        mark(E, x, y, z);
-        if (!(w & kNoCoc)) {
-          vox_t tw[24];
-          load_nbrs(x, y, z, tw, true);
-          offer(x, y, z, w & ~kAct, F[0], tw);
-        }
-        continue;
-      }
-      const int zq = rz + (TZ - H);
-      if (!(cb[(rx * RY + ry) * 3 + (zq >> 5)] & (1u << (zq & 31)))) continue;
-      const vox_t w = a.coc[g.idx(x, y, z)];
-      if (w == kUnobserved || (w & kNoCoc)) continue;
-      vox_t tw[24];
-      load_nbrs(x, y, z, tw, true);
-      offer(x, y, z, w & ~kAct, F[0], tw);
-    }
-
-    // ---- levels: queued voxels of the tile run the reference's pull + push on global memory
-    uint32_t level = 0;
-    for (;; ++level) {
-      const int cur = level & 1;
-      __syncthreads();
-      uint32_t bits = 0;
-      if (tid < NWT) {
-        bits = F[cur][tid];
-        F[cur][tid] = 0;
-      }
-      uint32_t incl = __popc(bits);
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-      }
-      if (lane == 63) wsum[wave] = incl;
-      __syncthreads();
-      uint32_t base = incl - __popc(bits), total = 0;
-#pragma unroll
-      for (int w = 0; w < NWAVE; ++w) {
-        const uint32_t sw = wsum[w];
-        if (w < wave) base += sw;
-        total += sw;
-      }
-      while (bits) {
-        const int bpos = __ffs(bits) - 1;
-        bits &= bits - 1;
-        Q[base++] = (uint16_t)(tid * 32 + bpos);
-      }
-      __syncthreads();
-      if (total == 0) break;
-      uint32_t *Fn = F[cur ^ 1];
-      for (uint32_t j = tid; j < total; j += NT) {
-        const int ii = Q[j];
-        const int x = x0 + ii / (TY * TZ), y = y0 + (ii / TZ) % TY, z = z0 + ii % TZ;
-        const int gx = g.gx0 + x, gy = g.gy0 + y, gz = g.gz0 + z;
-        vox_t *pv = &a.coc[g.idx(x, y, z)];
-        vox_t w = *pv;
-        // pull: the obstacles of all 24 stencil neighbours (src/ESDFMap.cpp:349-367)
-        vox_t tw[24];
-        load_nbrs(x, y, z, tw, false);
-        vox_t best = w;
-        uint32_t bestd = word_d2(w, gx, gy, gz);
-#pragma unroll
-        for (int q = 0; q < 24; ++q) {
-          const vox_t u = tw[q];
-          if (!(u & kNoCoc)) {
-            const uint32_t d = (uint32_t)dist2(gx, gy, gz, u & ~kAct);
-            if (d < bestd) {
-              bestd = d;
-              best = u & ~kAct;
-            }
-          }
-        }
-        if (best != w && improve_word(pv, w, bestd, best, gx, gy, gz)) w = best;
-        else w = *pv;
-        if (w == kUnobserved || (w & kNoCoc)) continue;
-        {  // the same words serve as the push filter, restricted to the writable voxels of this tile
-          int q = 0;
-#define FIESTA_TGT(DX, DY, DZ)                                         \
-  {                                                                    \
-    if (!target_ok(x + (DX), y + (DY), z + (DZ))) tw[q] = kUnobserved; \
-    ++q;                                                               \
-  }
-          FIESTA_STENCIL24(FIESTA_TGT)
-#undef FIESTA_TGT
-        }
-        offer(x, y, z, w & ~kAct, Fn, tw);  // push (:375-391)
-      }
-    }
-
-    // ---- publish: which voxels changed in this round, wake the neighbours whose halo saw a change
-    uint32_t nwr = 0;
-    for (int row = tid; row < NWT; row += NT) {
-      const uint32_t eb = E[row];
-      const int lx = row / TY, ly = row % TY;
-      const int x = x0 + lx, y = y0 + ly;
-      if (x < g.nx && y < g.ny && z0 < g.nz) {
-        const int64_t wi = g.bitword(x, y, z0);
-        a.cbits_cur[wi] = eb;
-        if (eb) a.rbits[wi] |= eb;
-      }
-      if (eb) {
-        nwr += __popc(eb);
-        const int fx = (lx < H) ? -1 : ((lx >= TX - H) ? 1 : 0), fy = (ly < H) ? -1 : ((ly >= TY - H) ? 1 : 0);
-        const int ex = (lx == 0) ? -1 : ((lx == TX - 1) ? 1 : 0), ey = (ly == 0) ? -1 : ((ly == TY - 1) ? 1 : 0);
-        const uint32_t zlo2 = eb & 0x3u, zhi2 = eb & 0xC0000000u, zlo1 = eb & 0x1u, zhi1 = eb & 0x80000000u;
-        // (inf voxels never get an E bit here: every marked voxel carries an obstacle)
-        if (fx) nbr_dirty[(fx + 1) * 9 + 4] = 1;
-        if (fy) nbr_dirty[9 + (fy + 1) * 3 + 1] = 1;
-        if (zlo2) nbr_dirty[9 + 3 + 0] = 1;
-        if (zhi2) nbr_dirty[9 + 3 + 2] = 1;
-        if (ex && ey) nbr_dirty[(ex + 1) * 9 + (ey + 1) * 3 + 1] = 1;
-        if (ex && zlo1) nbr_dirty[(ex + 1) * 9 + 3 + 0] = 1;
-        if (ex && zhi1) nbr_dirty[(ex + 1) * 9 + 3 + 2] = 1;
-        if (ey && zlo1) nbr_dirty[9 + (ey + 1) * 3 + 0] = 1;
-        if (ey && zhi1) nbr_dirty[9 + (ey + 1) * 3 + 2] = 1;
-      }
-    }
-    for (int off = 32; off > 0; off >>= 1) nwr += __shfl_down(nwr, off);
-    if (lane == 0 && nwr) atomicAdd(&a.counters[C_WRITES], (unsigned long long)nwr);
-    __syncthreads();
-    if (tid == 0) {
-      a.cstamp_cur[t] = a.serial;
-      atomicAdd(&a.counters[C_SWEEPS], (unsigned long long)level);
-      atomicAdd(&a.counters[C_VISITS], 1ull);
-    }
-    if (tid < 27 && nbr_dirty[tid]) {
-      const int ux = tx + tid / 9 - 1, uy = ty + (tid / 3) % 3 - 1, uz = tz + tid % 3 - 1;
-      if ((unsigned)ux < (unsigned)a.tg.ntx && (unsigned)uy < (unsigned)a.tg.nty && (unsigned)uz < (unsigned)a.tg.ntz)
-        activate_tile((ux * a.tg.nty + uy) * a.tg.ntz + uz, a.flag_next, a.list_next, a.count_next);
-    }
-    __syncthreads();
-  }
-}
 
 }  // namespace fiesta
