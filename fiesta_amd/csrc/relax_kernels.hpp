@@ -89,6 +89,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
 #define K64(i) (K[i])
   __shared__ uint16_t Q[RSIZE];
   __shared__ uint32_t F[2][NW], E[NW], P[NW];
+  __shared__ uint32_t FH[NW];  // level-0 sources that are not voxels of the tile: halo voxels, ghost cells of a shard
   __shared__ uint32_t rb[NROWW], cb[NROWW];
   __shared__ uint32_t wsum[NWAVE];
   __shared__ uint32_t n_oldvalid;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
 #pragma unroll 1
     for (int k = 0; k < ITER; ++k) {
       const int i = tid + k * NT;
-      bool ever = false, pull = false, front = false;
+      bool ever = false, pull = false, front = false, hsrc = false;
       if (i < RSIZE) {
         const vox_t w = KW(2 * i);
         uint32_t lo = kUnobserved, hi = 0;
@@ -239,14 +240,20 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
             // a voxel without an obstacle asks its old-valid neighbours once, when it first joins the frontier:
             // now if it was orphaned by a delete (the re-seed of :308-321), else when a wave first reaches it
             pull = !valid;
-          } else {
-            front = src;  // a source only: its d^2 field stays 0
+          } else if (src) {  // a source only: its d^2 field stays 0
+            // a halo voxel can reach the tile through the stencil only from a face slab (one axis outside) or
+            // from an edge at distance 1 on both outside axes (the +-1,+-1 diagonals); ghost cells sit inside
+            const int ox_ = (rx < H) ? H - rx : ((rx >= TX + H) ? rx - (TX + H) + 1 : 0);
+            const int oy_ = (ry < H) ? H - ry : ((ry >= TY + H) ? ry - (TY + H) + 1 : 0);
+            const int oz_ = (rz < H) ? H - rz : ((rz >= TZ + H) ? rz - (TZ + H) + 1 : 0);
+            const int nout = (ox_ != 0) + (oy_ != 0) + (oz_ != 0);
+            hsrc = nout <= 1 || (nout == 2 && ox_ <= 1 && oy_ <= 1 && oz_ <= 1);
           }
           if (valid && !inR) ++oldvalid;
         }
         K64(i) = ((unsigned long long)hi << 32) | lo;
       }
-      const unsigned long long me = __ballot(ever), mp = __ballot(pull), mf = __ballot(front);
+      const unsigned long long me = __ballot(ever), mp = __ballot(pull), mf = __ballot(front), mh = __ballot(hsrc);
       if ((tid & 31) == 0 && i < RPAD) {
         const int wq = i >> 5;
         const bool upper = tid & 32;
@@ -254,6 +261,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
         P[wq] = upper ? (uint32_t)(mp >> 32) : (uint32_t)mp;
         F[0][wq] = upper ? (uint32_t)(mf >> 32) : (uint32_t)mf;
         F[1][wq] = 0;
+        FH[wq] = upper ? (uint32_t)(mh >> 32) : (uint32_t)mh;
       }
     }
     for (int off = 32; off > 0; off >>= 1) oldvalid += __shfl_down(oldvalid, off);
@@ -261,20 +269,17 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     if (prof) t1 = clock64();
 
     // ---- level-synchronous propagation inside the tile
-    uint32_t level = 0;
     long long tc = 0, tp = 0, tmark = 0;
     uint32_t n_pulls = 0, n_succ = 0;
-    for (;; ++level) {
-      const int cur = level & 1;
-      __syncthreads();  // every push of the previous level has landed in F[cur]
-      if (prof) tmark = clock64();
-      const bool pulls_enabled = n_oldvalid != 0;
-      // compact the frontier bitmap into the work queue
+    __syncthreads();  // keys, frontier bitmaps and n_oldvalid are complete
+    const bool pulls_enabled = n_oldvalid != 0;
+    // compact a frontier bitmap into the work queue Q (block scan); returns the number of items
+    auto compact = [&](uint32_t *Fsrc, const bool into_E) -> uint32_t {
       uint32_t bits = 0;
       if (tid < NW) {
-        bits = F[cur][tid];
-        F[cur][tid] = 0;
-        if (bits) E[tid] |= bits;
+        bits = Fsrc[tid];
+        Fsrc[tid] = 0;
+        if (bits && into_E) E[tid] |= bits;
       }
       uint32_t incl = __popc(bits);
       for (int off = 1; off < 64; off <<= 1) {
@@ -286,9 +291,9 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       uint32_t base = incl - __popc(bits), total = 0;
 #pragma unroll
       for (int w = 0; w < NWAVE; ++w) {
-        const uint32_t s = wsum[w];
-        if (w < wave) base += s;
-        total += s;
+        const uint32_t sw = wsum[w];
+        if (w < wave) base += sw;
+        total += sw;
       }
       while (bits) {
         const int bpos = __ffs(bits) - 1;
@@ -296,37 +301,27 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
         Q[base++] = (uint16_t)(tid * 32 + bpos);
       }
       __syncthreads();
-      if (prof) {
-        const long long now = clock64();
-        tc += now - tmark;
-        tmark = now;
-      }
-      if (total == 0) break;
-      uint32_t *Fn = F[cur ^ 1];
-      // One frontier item = one voxel whose key changed (or a source-only voxel at level 0). CLAMP: the item may be
-      // a halo / ghost voxel, so neighbour indices can leave the array (clamped onto a halo corner, whose d^2 = 0
-      // rejects every push) and its own d^2 is recomputed. Levels >= 1 only hold updatable voxels: neighbour
-      // offsets are instruction immediates.
-      auto process = [&](auto clamp_tag) {
-        constexpr bool CLAMP = decltype(clamp_tag)::value;
-        for (uint32_t j = tid; j < total; j += NT) {
-          const int v = Q[j];
-          const uint32_t vbit = 1u << (v & 31);
-          const int rz = v % RZ, ry = (v / RZ) % RY, rx = v / (RZ * RY);
-          const int vx = bx + rx, vy = by + ry, vz = bz + rz;
-          unsigned long long key = __hip_atomic_load(&K64(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-          if (prof) ++n_items;
-          bool want_pull = (P[v >> 5] & vbit) != 0;  // had no obstacle when the tile was staged, not asked yet
-          if (CLAMP)
-            want_pull = want_pull && (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
-                        (unsigned)(rz - H) < (unsigned)TZ;
-          if (want_pull) {
-            __hip_atomic_fetch_and(&P[v >> 5], ~vbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (pulls_enabled) {
-              if (prof) ++n_pulls;
-              vox_t best = lo;
-              uint32_t bestd = hi;
+      return total;
+    };
+    // One frontier item = one voxel whose key changed. SRC: the item is a source-only voxel (halo voxel or ghost cell
+    // of a shard; they only occur in the pass before level 0): no pull, its d^2 is recomputed, and a halo voxel only
+    // probes the <= 6 directions that land inside the tile instead of 24.
+    auto process = [&](auto src_tag, const uint32_t total, uint32_t *Fn) {
+      constexpr bool SRC = decltype(src_tag)::value;
+      for (uint32_t j = tid; j < total; j += NT) {
+        const int v = Q[j];
+        const uint32_t vbit = 1u << (v & 31);
+        const int rz = v % RZ, ry = (v / RZ) % RY, rx = v / (RZ * RY);
+        const int vx = bx + rx, vy = by + ry, vz = bz + rz;
+        unsigned long long key = __hip_atomic_load(&K64(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+        if (prof) ++n_items;
+        if (!SRC && (P[v >> 5] & vbit)) {  // had no obstacle when the tile was staged, not asked yet
+          __hip_atomic_fetch_and(&P[v >> 5], ~vbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (pulls_enabled) {
+            if (prof) ++n_pulls;
+            vox_t best = lo;
+            uint32_t bestd = hi;
 #define FIESTA_PULLL(DX, DY, DZ) un[q++] = KW(2 * (v + (((DX)*RY + (DY)) * RZ + (DZ))));
 #define FIESTA_PULLEVAL(NQ)                                 \
   _Pragma("unroll") for (int q = 0; q < (NQ); ++q) {        \
@@ -339,47 +334,79 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       }                                                     \
     }                                                       \
   }
-              if (NT >= 1024) {
-                vox_t un[12];
-                {
-                  int q = 0;
-                  FIESTA_STENCIL12A(FIESTA_PULLL)
-                }
-                FIESTA_PULLEVAL(12)
-                {
-                  int q = 0;
-                  FIESTA_STENCIL12B(FIESTA_PULLL)
-                }
-                FIESTA_PULLEVAL(12)
-              } else {
-                vox_t un[24];
-                {
-                  int q = 0;
-                  FIESTA_STENCIL24(FIESTA_PULLL)
-                }
-                FIESTA_PULLEVAL(24)
+            if (NT >= 1024) {
+              vox_t un[12];
+              {
+                int q = 0;
+                FIESTA_STENCIL12A(FIESTA_PULLL)
               }
+              FIESTA_PULLEVAL(12)
+              {
+                int q = 0;
+                FIESTA_STENCIL12B(FIESTA_PULLL)
+              }
+              FIESTA_PULLEVAL(12)
+            } else {
+              vox_t un[24];
+              {
+                int q = 0;
+                FIESTA_STENCIL24(FIESTA_PULLL)
+              }
+              FIESTA_PULLEVAL(24)
+            }
 #undef FIESTA_PULLL
 #undef FIESTA_PULLEVAL
-              if (bestd < hi) {
-                const unsigned long long mine = ((unsigned long long)bestd << 32) | best | kAct;
-                const unsigned long long old = atomicMin(&K64(v), mine);
-                key = old < mine ? old : mine;
-                lo = (uint32_t)key;
-                hi = (uint32_t)(key >> 32);
-              }
+            if (bestd < hi) {
+              const unsigned long long mine = ((unsigned long long)bestd << 32) | best | kAct;
+              const unsigned long long old = atomicMin(&K64(v), mine);
+              key = old < mine ? old : mine;
+              lo = (uint32_t)key;
+              hi = (uint32_t)(key >> 32);
             }
           }
-          if (lo & kNoCoc) continue;
-          // push: |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2
-          const vox_t c = lo & ~kAct;
-          const int rcx = vx - (int)((c >> 20) & 1023), rcy = vy - (int)((c >> 10) & 1023), rcz = vz - (int)(c & 1023);
-          // source-only voxels (halo, ghost cells of a shard) keep d^2 = 0 in LDS: recompute theirs
-          const int32_t dv = (!CLAMP || hi) ? (int32_t)hi : rcx * rcx + rcy * rcy + rcz * rcz;
-          const int ax = 2 * rcx, ay = 2 * rcy, az = 2 * rcz;
-          const unsigned long long keylo = (unsigned long long)(c | kAct);
-#define FIESTA_NIDX(DX, DY, DZ) \
-  (CLAMP ? min(max(v + (((DX)*RY + (DY)) * RZ + (DZ)), 0), RSIZE - 1) : v + (((DX)*RY + (DY)) * RZ + (DZ)))
+        }
+        if (lo & kNoCoc) continue;
+        // push: |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2
+        const vox_t c = lo & ~kAct;
+        const int rcx = vx - (int)((c >> 20) & 1023), rcy = vy - (int)((c >> 10) & 1023), rcz = vz - (int)(c & 1023);
+        const int32_t dv = SRC ? rcx * rcx + rcy * rcy + rcz * rcz : (int32_t)hi;  // (source-only voxels keep d^2 = 0 in LDS)
+        const unsigned long long keylo = (unsigned long long)(c | kAct);
+        if (SRC) {
+          const int ux = (rx < H) ? 1 : ((rx >= TX + H) ? -1 : 0), uy = (ry < H) ? 1 : ((ry >= TY + H) ? -1 : 0),
+                    uz = (rz < H) ? 1 : ((rz >= TZ + H) ? -1 : 0);  // direction towards the tile per axis (0: inside)
+          const int nout = (ux != 0) + (uy != 0) + (uz != 0);
+          if (nout) {  // a halo voxel
+            const int depth = max(max((rx < H) ? H - rx : rx - (TX + H) + 1, (ry < H) ? H - ry : ry - (TY + H) + 1),
+                                  (rz < H) ? H - rz : rz - (TZ + H) + 1);
+            auto probe = [&](const int ex, const int ey, const int ez) {
+              const int n = v + (ex * RY + ey) * RZ + ez;
+              const uint32_t cand = (uint32_t)(dv + 2 * (ex * rcx + ey * rcy + ez * rcz) + ex * ex + ey * ey + ez * ez);
+              if (cand < KW(2 * n + 1)) {
+                if (prof) ++n_succ;
+                __hip_atomic_fetch_min(&K64(n), ((unsigned long long)cand << 32) | keylo, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(&Fn[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            };
+            if (nout == 1) {  // face slab: the step towards the tile, its four diagonals, and the double step
+              if (depth == 1) {
+                const int bx_ = (ux == 0) ? 1 : 0, by_ = (ux != 0) ? 1 : 0;  // first in-range axis
+                const int cz_ = (uz == 0) ? 1 : 0, cy_ = (uz != 0) ? 1 : 0;  // second in-range axis
+                probe(ux, uy, uz);
+                probe(ux + bx_, uy + by_, uz);
+                probe(ux - bx_, uy - by_, uz);
+                probe(ux, uy + cy_, uz + cz_);
+                probe(ux, uy - cy_, uz - cz_);
+              }
+              probe(2 * ux, 2 * uy, 2 * uz);
+            } else if (nout == 2 && depth == 1) {
+              probe(ux, uy, uz);  // edge: the one diagonal that lands inside
+            }
+            continue;
+          }
+        }
+        const int ax = 2 * rcx, ay = 2 * rcy, az = 2 * rcz;
+#define FIESTA_NIDX(DX, DY, DZ) (v + (((DX)*RY + (DY)) * RZ + (DZ)))
 #define FIESTA_PUSHL(DX, DY, DZ) dnv[q++] = KW(2 * FIESTA_NIDX(DX, DY, DZ) + 1);
 #define FIESTA_PUSH(DX, DY, DZ)                                                                              \
   {                                                                                                          \
@@ -392,8 +419,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       __hip_atomic_fetch_or(&Fn[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    \
     }                                                                                                        \
   }
-          if (NT >= 1024) {  // 128-VGPR budget: four batches of 6 filter reads
-            uint32_t dnv[6];
+        if (NT >= 1024) {  // 128-VGPR budget: four batches of 6 filter reads
+          uint32_t dnv[6];
 #define FIESTA_BATCH(ST)  \
   {                       \
     int q = 0;            \
@@ -403,31 +430,54 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     int q = 0;            \
     ST(FIESTA_PUSH)       \
   }
-            FIESTA_BATCH(FIESTA_STENCIL6A)
-            FIESTA_BATCH(FIESTA_STENCIL6B)
-            FIESTA_BATCH(FIESTA_STENCIL6C)
-            FIESTA_BATCH(FIESTA_STENCIL6D)
+          FIESTA_BATCH(FIESTA_STENCIL6A)
+          FIESTA_BATCH(FIESTA_STENCIL6B)
+          FIESTA_BATCH(FIESTA_STENCIL6C)
+          FIESTA_BATCH(FIESTA_STENCIL6D)
 #undef FIESTA_BATCH
-          } else {
-            uint32_t dnv[24];
-            {
-              int q = 0;
-              FIESTA_STENCIL24(FIESTA_PUSHL)
-            }
-            {
-              int q = 0;
-              FIESTA_STENCIL24(FIESTA_PUSH)
-            }
+        } else {
+          uint32_t dnv[24];
+          {
+            int q = 0;
+            FIESTA_STENCIL24(FIESTA_PUSHL)
           }
+          {
+            int q = 0;
+            FIESTA_STENCIL24(FIESTA_PUSH)
+          }
+        }
 #undef FIESTA_PUSHL
 #undef FIESTA_PUSH
 #undef FIESTA_NIDX
-        }
-      };
-      if (level == 0)
-        process(std::true_type{});
-      else
-        process(std::false_type{});
+      }
+    };
+
+    // pass before level 0: the source-only voxels offer their obstacles; what they improve joins level 0
+    if (prof) tmark = clock64();
+    {
+      const uint32_t nsrc = compact(FH, true);  // (ghost cells of a shard sit inside the tile: their tag is cleared and
+                                                //  their change published by the write-back, like any tile voxel)
+      if (prof) {
+        const long long now = clock64();
+        tc += now - tmark;
+        tmark = now;
+      }
+      if (nsrc) process(std::true_type{}, nsrc, F[0]);
+      if (prof) tp += clock64() - tmark;
+    }
+    uint32_t level = 0;
+    for (;; ++level) {
+      const int cur = level & 1;
+      __syncthreads();  // every push of the previous level has landed in F[cur]
+      if (prof) tmark = clock64();
+      const uint32_t total = compact(F[cur], true);
+      if (prof) {
+        const long long now = clock64();
+        tc += now - tmark;
+        tmark = now;
+      }
+      if (total == 0) break;
+      process(std::false_type{}, total, F[cur ^ 1]);
       if (prof) tp += clock64() - tmark;
     }
     if (prof) t2 = clock64();
