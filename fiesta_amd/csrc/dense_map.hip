@@ -70,15 +70,45 @@ __global__ void k_observe_vox(Geom g, const int32_t *vox, const int32_t *occ, in
 
 // SetOccupancy(Vector3i, occ) for EVERY voxel of a box (map coordinates, inclusive), e.g. "observe the whole
 // grid free once": same effect as one call per voxel, without materialising the coordinate list.
-__global__ void k_observe_box(Geom g, int bx0, int by0, int bz0, int ex, int ey, int ez, int occ,
-                              unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
-  const int64_t n = (int64_t)ex * ey * ez;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int z = bz0 + (int)(i % ez) - g.gz0, y = by0 + (int)((i / ez) % ey) - g.gy0, x = bx0 + (int)(i / ((int64_t)ez * ey)) - g.gx0;
-    if (!g.in_grid(x, y, z) || !g.in_window(x, y, z) || !g.owned(x, y, z)) continue;
-    const int64_t idx = g.idx(x, y, z);
-    const unsigned long long old = atomicAdd(&cnt[idx], ((unsigned long long)(uint32_t)occ << 32) | 1ull);
-    wave_append((uint32_t)old == 0, (uint32_t)idx, touched, &counters[C_TOUCHED]);
+__global__ __launch_bounds__(1024) void k_observe_box(Geom g, int bx0, int by0, int bz0, int ex, int ey, int ez, int occ,
+                                                      unsigned long long *cnt, uint32_t *touched,
+                                                      unsigned long long *counters) {
+  // 16 waves per work-group, one z-run of 64 voxels of a box row per wave and step. Every voxel is visited exactly
+  // once, so the counter update needs no atomic (kernels of one map are stream-ordered). The first-touch appends of a
+  // step are aggregated per WORK-GROUP (LDS) into one global atomicAdd: a whole-grid box makes 134 M of them, and even
+  // one atomic per wave on the single list counter took 20 ms.
+  __shared__ uint32_t blk_count, blk_base;
+  const int zchunks = (ez + 63) >> 6;
+  const int64_t nitems = (int64_t)ex * ey * zchunks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int64_t steps = (nitems + (int64_t)gridDim.x * nwave - 1) / ((int64_t)gridDim.x * nwave);
+  for (int64_t st = 0; st < steps; ++st) {
+    const int64_t item = (st * gridDim.x + blockIdx.x) * nwave + wave;
+    if (threadIdx.x == 0) blk_count = 0;
+    __syncthreads();
+    bool first = false;
+    int64_t idx = 0;
+    if (item < nitems) {
+      const int zc = (int)(item % zchunks);
+      const int64_t row = item / zchunks;
+      const int y = by0 + (int)(row % ey) - g.gy0, x = bx0 + (int)(row / ey) - g.gx0;
+      const int zi = zc * 64 + lane;
+      const int z = bz0 + zi - g.gz0;
+      if (zi < ez && g.in_grid(x, y, z) && g.in_window(x, y, z) && g.owned(x, y, z)) {
+        idx = g.idx(x, y, z);
+        const unsigned long long old = cnt[idx];
+        cnt[idx] = old + (((unsigned long long)(uint32_t)occ << 32) | 1ull);
+        first = (uint32_t)old == 0;
+      }
+    }
+    const unsigned long long m = __ballot(first);
+    uint32_t woff = 0;
+    if (lane == 0 && m) woff = atomicAdd(&blk_count, (uint32_t)__popcll(m));
+    woff = __shfl(woff, 0);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_count) blk_base = (uint32_t)atomicAdd(&counters[C_TOUCHED], (unsigned long long)blk_count);
+    __syncthreads();
+    if (first) touched[blk_base + woff + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
   }
 }
 
@@ -838,7 +868,7 @@ void DenseMap::observe_box(const int32_t *lo, const int32_t *hi, int occ) {
   if (ex <= 0 || ey <= 0 || ez <= 0) return;
   if (ex > 4096 || ey > 4096 || ez > 4096) throw Error(FIESTA_HIP_ERR_INVALID, "box too large");
   ensure_touched_capacity(ex * ey * ez);
-  hipLaunchKernelGGL(k_observe_box, dim3(grid_for(ex * ey * ez, 256, 65536)), dim3(256), 0, stream_, g_, lo[0], lo[1],
+  hipLaunchKernelGGL(k_observe_box, dim3(grid_for(ex * ey * ((ez + 63) / 64), 16, 4096)), dim3(1024), 0, stream_, g_, lo[0], lo[1],
                      lo[2], (int)ex, (int)ey, (int)ez, occ, cnt_, touched_.p, counters_);
   FIESTA_HIP_CHECK(hipGetLastError());
 }
