@@ -78,7 +78,6 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
   constexpr int RPAD = NW * 32;
   constexpr int ITER = RPAD / NT + (RPAD % NT ? 1 : 0);
   constexpr int SLOTS = NT / 32, RPT = TX * TY / SLOTS;
-  constexpr int NWAVE = NT / 64;
   constexpr int NROWW = RX * RY * 3;  // staged bitmap words: 3 z-words per (x,y) row of the region
   static_assert(NT % 64 == 0 && (TX * TY) % SLOTS == 0 && RPT <= 32 && RSIZE < 65536 && NW <= NT, "tile shape");
   // keys: lo half = obstacle word | flag, hi half = d^2. The halves are read through KW(j) = the array itself
@@ -91,7 +90,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
   __shared__ uint32_t F[2][NW], E[NW], P[NW];
   __shared__ uint32_t FH[NW];  // level-0 sources that are not voxels of the tile: halo voxels, ghost cells of a shard
   __shared__ uint32_t rb[NROWW], cb[NROWW];
-  __shared__ uint32_t wsum[NWAVE];
+  __shared__ uint32_t qcount[2];
   __shared__ uint32_t n_oldvalid;
   __shared__ uint32_t nb_ok[27];
   __shared__ int32_t nb_page[27];
@@ -133,6 +132,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     if (tid == 0) {
       a.flag_cur[t] = 0;
       n_oldvalid = 0;
+      qcount[0] = 0;
     }
     if (tid < 27) {
       nbr_dirty[tid] = 0;
@@ -273,35 +273,34 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     uint32_t n_pulls = 0, n_succ = 0;
     __syncthreads();  // keys, frontier bitmaps and n_oldvalid are complete
     const bool pulls_enabled = n_oldvalid != 0;
-    // compact a frontier bitmap into the work queue Q (block scan); returns the number of items
-    auto compact = [&](uint32_t *Fsrc, const bool into_E) -> uint32_t {
-      uint32_t bits = 0;
-      if (tid < NW) {
-        bits = Fsrc[tid];
-        Fsrc[tid] = 0;
-        if (bits && into_E) E[tid] |= bits;
+    // compact a frontier bitmap into the work queue Q; returns the number of items. Wave scan + one LDS atomicAdd per
+    // wave for the wave's base (the order of Q does not matter: ds_min on whole keys is commutative), one barrier.
+    // qcount[slot] is zero on entry; the other slot is cleared for the next call.
+    auto compact = [&](uint32_t *Fsrc, const bool into_E, const int slot) -> uint32_t {
+      if (wave * 64 < NW) {
+        uint32_t bits = 0;
+        if (tid < NW) {
+          bits = Fsrc[tid];
+          Fsrc[tid] = 0;
+          if (bits && into_E) E[tid] |= bits;
+        }
+        uint32_t incl = __popc(bits);
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_up(incl, off);
+          if (lane >= off) incl += o;
+        }
+        uint32_t base = 0;
+        if (lane == 63 && incl) base = atomicAdd(&qcount[slot], incl);
+        base = __shfl(base, 63) + incl - __popc(bits);
+        while (bits) {
+          const int bpos = __ffs(bits) - 1;
+          bits &= bits - 1;
+          Q[base++] = (uint16_t)(tid * 32 + bpos);
+        }
       }
-      uint32_t incl = __popc(bits);
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-      }
-      if (lane == 63) wsum[wave] = incl;
+      if (tid == NT - 1) qcount[slot ^ 1] = 0;
       __syncthreads();
-      uint32_t base = incl - __popc(bits), total = 0;
-#pragma unroll
-      for (int w = 0; w < NWAVE; ++w) {
-        const uint32_t sw = wsum[w];
-        if (w < wave) base += sw;
-        total += sw;
-      }
-      while (bits) {
-        const int bpos = __ffs(bits) - 1;
-        bits &= bits - 1;
-        Q[base++] = (uint16_t)(tid * 32 + bpos);
-      }
-      __syncthreads();
-      return total;
+      return qcount[slot];
     };
     // One frontier item = one voxel whose key changed. SRC: the item is a source-only voxel (halo voxel or ghost cell
     // of a shard; they only occur in the pass before level 0): no pull, its d^2 is recomputed, and a halo voxel only
@@ -455,7 +454,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     // pass before level 0: the source-only voxels offer their obstacles; what they improve joins level 0
     if (prof) tmark = clock64();
     {
-      const uint32_t nsrc = compact(FH, true);  // (ghost cells of a shard sit inside the tile: their tag is cleared and
+      const uint32_t nsrc = compact(FH, true, 0);  // (ghost cells of a shard sit inside the tile: their tag is cleared and
                                                 //  their change published by the write-back, like any tile voxel)
       if (prof) {
         const long long now = clock64();
@@ -470,7 +469,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       const int cur = level & 1;
       __syncthreads();  // every push of the previous level has landed in F[cur]
       if (prof) tmark = clock64();
-      const uint32_t total = compact(F[cur], true);
+      const uint32_t total = compact(F[cur], true, cur ^ 1);
       if (prof) {
         const long long now = clock64();
         tc += now - tmark;
