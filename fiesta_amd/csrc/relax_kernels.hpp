@@ -172,96 +172,139 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       rb[j] = r;
       cb[j] = c;
     }
-    // ---- raw voxel words -> low halves of the keys (independent loads, issued in batches; addresses are always
-    //      legal so no load sits behind a branch)
+    for (int j = tid; j < NW; j += NT) {
+      E[j] = 0;
+      P[j] = 0;
+      F[0][j] = 0;
+      F[1][j] = 0;
+      FH[j] = 0;
+    }
+    __syncthreads();  // rb, cb staged; frontier bitmaps cleared
+    const bool own_epoch = nb_ok[13] & 1u;
+
+    // ---- stage the region: raw voxel word -> 64-bit key, and collect the level-0 frontier.
+    // Main pass: a half-wave per (x,y) row, lane = one of the row's 32 tile-interior z (aligned 128-byte loads, the
+    // row arithmetic is shared by the half-wave's lanes); the 4 z-halo voxels of every row go through a second, small
+    // pass. Loads are issued in batches with always-legal addresses, so none sits behind a branch.
+    uint32_t oldvalid = 0;
+    // flags: 1 = already in the frontier (E), 2 = has no obstacle yet (P), 4 = level-0 frontier (F0), 8 = source only (FH)
+    auto build = [&](auto zin_tag, const vox_t w, const int rx, const int ry, const int rz, uint32_t &flags) -> unsigned long long {
+      constexpr bool ZIN = decltype(zin_tag)::value;  // rz is a tile-interior z
+      flags = 0;
+      uint32_t lo = kUnobserved, hi = 0;
+      if (w != kUnobserved) {
+        const bool act = (w & kAct) != 0;
+        const bool valid = !(w & kNoCoc);
+        const bool interior = ZIN && (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY;
+        const int zq = rz + (TZ - H);  // z - (z0 - TZ)
+        const int j = (rx * RY + ry) * 3 + (zq >> 5);
+        const uint32_t bit = 1u << (zq & 31);
+        const bool upd = interior && g.owned(x0 - H + rx, y0 - H + ry, z0 - H + rz);
+        const bool src = !upd && valid && (act || (cb[j] & bit));
+        // "joined the frontier during this update": own voxels from the tile's own bitmap; a halo voxel
+        // only if it offers its obstacle in this very visit (a neighbour tile that runs concurrently may
+        // already have published a newer bitmap than the value loaded above)
+        const bool inR = upd ? (act || (rb[j] & bit)) : src;
+        const vox_t c = w & ~kAct;
+        lo = (valid ? c : kInf) | (inR ? kAct : 0u);
+        if (upd) {
+          hi = valid ? (uint32_t)dist2(bx + rx, by + ry, bz + rz, c) : (uint32_t)kD2Inf;
+          if (act) flags |= 1u | 4u;
+          // a voxel without an obstacle asks its old-valid neighbours once, when it first joins the frontier:
+          // now if it was orphaned by a delete (the re-seed of :308-321), else when a wave first reaches it
+          if (!valid) flags |= 2u;
+        } else if (src) {  // a source only: its d^2 field stays 0
+          // a halo voxel can reach the tile through the stencil only from a face slab (one axis outside) or
+          // from an edge at distance 1 on both outside axes (the +-1,+-1 diagonals); ghost cells sit inside
+          const int ox_ = (rx < H) ? H - rx : ((rx >= TX + H) ? rx - (TX + H) + 1 : 0);
+          const int oy_ = (ry < H) ? H - ry : ((ry >= TY + H) ? ry - (TY + H) + 1 : 0);
+          const int oz_ = ZIN ? 0 : ((rz < H) ? H - rz : rz - (TZ + H) + 1);
+          const int nout = (ox_ != 0) + (oy_ != 0) + (oz_ != 0);
+          if (nout <= 1 || (nout == 2 && ox_ <= 1 && oy_ <= 1 && oz_ <= 1)) flags |= 8u;
+        }
+        if (valid && !inR) ++oldvalid;
+      }
+      return ((unsigned long long)hi << 32) | lo;
+    };
+    auto address = [&](const int rx, const int ry, const int rz, bool &ok) -> int64_t {
+      const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
+      ok = g.in_grid(x, y, z) && g.in_window(x, y, z);
+      if (PAGED) {
+        const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1),
+                  oz = (rz < H) ? 0 : ((rz >= TZ + H) ? 2 : 1);
+        const int32_t pg = nb_page[ox * 9 + oy * 3 + oz];
+        ok = ok && pg >= 0;
+        return (int64_t)max(pg, 0) * PAGE_VOX + (((x & (TX - 1)) * TY + (y & (TY - 1))) * TZ + (z & (TZ - 1)));
+      }
+      return g.idx(min(max(x, 0), g.nx - 1), min(max(y, 0), g.ny - 1), min(max(z, 0), g.nz - 1));
+    };
     {
-      constexpr int UB = NT >= 1024 ? 8 : 15;
-      for (int i0 = tid; i0 < RSIZE; i0 += UB * NT) {
-        vox_t wv[UB];
+      constexpr int NROWS = RX * RY, RSLOTS = NT / 32;
+      constexpr int MIT = (NROWS + RSLOTS - 1) / RSLOTS;  // main-pass steps (32 lanes per row)
+      constexpr int HIT = (NROWS * 2 * H + NT - 1) / NT;   // z-halo steps (4 voxels per row)
+      constexpr int MB = (MIT + 1) / 2;
+      const int hl = tid & 31, rslot = tid >> 5;
+      // z-halo loads first, consumed last
+      vox_t wh[HIT];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int i = min(i0 + u * NT, RSIZE - 1);
-          const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
-          const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
-          bool ok = g.in_grid(x, y, z) && g.in_window(x, y, z);
-          int64_t idx;
-          if (PAGED) {
-            const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1),
-                      oz = (rz < H) ? 0 : ((rz >= TZ + H) ? 2 : 1);
-            const int32_t pg = nb_page[ox * 9 + oy * 3 + oz];
-            ok = ok && pg >= 0;
-            idx = (int64_t)max(pg, 0) * PAGE_VOX + (((x & (TX - 1)) * TY + (y & (TY - 1))) * TZ + (z & (TZ - 1)));
-          } else {
-            idx = g.idx(min(max(x, 0), g.nx - 1), min(max(y, 0), g.ny - 1), min(max(z, 0), g.nz - 1));
-          }
+      for (int u = 0; u < HIT; ++u) {
+        const int id = min(tid + u * NT, NROWS * 2 * H - 1);
+        const int row = id >> 2, q = id & 3;
+        bool ok;
+        const int64_t idx = address(row / RY, row % RY, q < H ? q : TZ + q, ok);
+        const vox_t w = a.coc[idx];
+        wh[u] = ok ? w : kUnobserved;
+      }
+#pragma unroll 1
+      for (int k0 = 0; k0 < MIT; k0 += MB) {
+        vox_t wv[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+          const int row = min(rslot + RSLOTS * (k0 + u), NROWS - 1);
+          bool ok;
+          const int64_t idx = address(row / RY, row % RY, H + hl, ok);
           const vox_t w = a.coc[idx];
           wv[u] = ok ? w : kUnobserved;
         }
 #pragma unroll
-        for (int u = 0; u < UB; ++u)
-          if (i0 + u * NT < RSIZE) KW(2 * (i0 + u * NT)) = wv[u];
-      }
-    }
-    __syncthreads();
-    const bool own_epoch = nb_ok[13] & 1u;
-
-    // ---- build the keys; collect the level-0 frontier
-    uint32_t oldvalid = 0;
-#pragma unroll 1
-    for (int k = 0; k < ITER; ++k) {
-      const int i = tid + k * NT;
-      bool ever = false, pull = false, front = false, hsrc = false;
-      if (i < RSIZE) {
-        const vox_t w = KW(2 * i);
-        uint32_t lo = kUnobserved, hi = 0;
-        if (w != kUnobserved) {
-          const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
-          const bool act = (w & kAct) != 0;
-          const bool valid = !(w & kNoCoc);
-          const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
-                                (unsigned)(rz - H) < (unsigned)TZ;
-          const int zq = rz + (TZ - H);  // z - (z0 - TZ)
-          const int j = (rx * RY + ry) * 3 + (zq >> 5);
-          const uint32_t bit = 1u << (zq & 31);
-          const bool upd = interior && g.owned(x0 - H + rx, y0 - H + ry, z0 - H + rz);
-          const bool src = !upd && valid && (act || (cb[j] & bit));
-          // "joined the frontier during this update": own voxels from the tile's own bitmap; a halo voxel
-          // only if it offers its obstacle in this very visit (a neighbour tile that runs concurrently may
-          // already have published a newer bitmap than the value loaded above)
-          const bool inR = upd ? (act || (rb[j] & bit)) : src;
-          const vox_t c = w & ~kAct;
-          lo = (valid ? c : kInf) | (inR ? kAct : 0u);
-          if (upd) {
-            hi = valid ? (uint32_t)dist2(bx + rx, by + ry, bz + rz, c) : (uint32_t)kD2Inf;
-            if (act) {
-              ever = true;
-              front = true;
-            }
-            // a voxel without an obstacle asks its old-valid neighbours once, when it first joins the frontier:
-            // now if it was orphaned by a delete (the re-seed of :308-321), else when a wave first reaches it
-            pull = !valid;
-          } else if (src) {  // a source only: its d^2 field stays 0
-            // a halo voxel can reach the tile through the stencil only from a face slab (one axis outside) or
-            // from an edge at distance 1 on both outside axes (the +-1,+-1 diagonals); ghost cells sit inside
-            const int ox_ = (rx < H) ? H - rx : ((rx >= TX + H) ? rx - (TX + H) + 1 : 0);
-            const int oy_ = (ry < H) ? H - ry : ((ry >= TY + H) ? ry - (TY + H) + 1 : 0);
-            const int oz_ = (rz < H) ? H - rz : ((rz >= TZ + H) ? rz - (TZ + H) + 1 : 0);
-            const int nout = (ox_ != 0) + (oy_ != 0) + (oz_ != 0);
-            hsrc = nout <= 1 || (nout == 2 && ox_ <= 1 && oy_ <= 1 && oz_ <= 1);
+        for (int u = 0; u < MB; ++u) {
+          const int row = rslot + RSLOTS * (k0 + u);
+          const bool live = (k0 + u) < MIT && row < NROWS;
+          uint32_t flags = 0;
+          if (live) {
+            const int rx = row / RY, ry = row % RY;
+            K64(row * RZ + H + hl) = build(std::true_type{}, wv[u], rx, ry, H + hl, flags);
           }
-          if (valid && !inR) ++oldvalid;
+          const unsigned long long me = __ballot(flags & 1u), mp = __ballot(flags & 2u), mf = __ballot(flags & 4u),
+                                   mh = __ballot(flags & 8u);
+          if (hl == 0 && live) {
+            const bool upper = tid & 32;
+            const int ib = row * RZ + H, w0 = ib >> 5, sh = ib & 31;
+            auto put = [&](uint32_t *B, const unsigned long long mm) {
+              const uint32_t m = upper ? (uint32_t)(mm >> 32) : (uint32_t)mm;
+              if (m) {
+                __hip_atomic_fetch_or(&B[w0], m << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t m2 = sh ? (m >> (32 - sh)) : 0u;
+                if (m2) __hip_atomic_fetch_or(&B[w0 + 1], m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            };
+            put(E, me);
+            put(P, mp);
+            put(F[0], mf);
+            put(FH, mh);
+          }
         }
-        K64(i) = ((unsigned long long)hi << 32) | lo;
       }
-      const unsigned long long me = __ballot(ever), mp = __ballot(pull), mf = __ballot(front), mh = __ballot(hsrc);
-      if ((tid & 31) == 0 && i < RPAD) {
-        const int wq = i >> 5;
-        const bool upper = tid & 32;
-        E[wq] = upper ? (uint32_t)(me >> 32) : (uint32_t)me;
-        P[wq] = upper ? (uint32_t)(mp >> 32) : (uint32_t)mp;
-        F[0][wq] = upper ? (uint32_t)(mf >> 32) : (uint32_t)mf;
-        F[1][wq] = 0;
-        FH[wq] = upper ? (uint32_t)(mh >> 32) : (uint32_t)mh;
+#pragma unroll
+      for (int u = 0; u < HIT; ++u) {
+        const int id = tid + u * NT;
+        if (id < NROWS * 2 * H) {
+          const int row = id >> 2, q = id & 3, rz = q < H ? q : TZ + q;
+          const int i = row * RZ + rz;
+          uint32_t flags;
+          K64(i) = build(std::false_type{}, wh[u], row / RY, row % RY, rz, flags);
+          if (flags & 8u) __hip_atomic_fetch_or(&FH[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
     for (int off = 32; off > 0; off >>= 1) oldvalid += __shfl_down(oldvalid, off);
