@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
         const int zq = rz + (TZ - H);  // z - (z0 - TZ)
         const int j = (rx * RY + ry) * 3 + (zq >> 5);
         const uint32_t bit = 1u << (zq & 31);
-        const bool upd = interior && g.owned(x0 - H + rx, y0 - H + ry, z0 - H + rz);
+        const bool upd = interior && (!g.sharded || g.owned(x0 - H + rx, y0 - H + ry, z0 - H + rz));
         const bool src = !upd && valid && (act || (cb[j] & bit));
         // "joined the frontier during this update": own voxels from the tile's own bitmap; a halo voxel
         // only if it offers its obstacle in this very visit (a neighbour tile that runs concurrently may
@@ -226,9 +226,13 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       }
       return ((unsigned long long)hi << 32) | lo;
     };
+    // the whole region (tile + halo) lies inside the grid and the update window: no per-voxel range tests
+    const bool region_inside = x0 - H >= max(0, g.wx0) && x0 + TX + H - 1 <= min(g.nx - 1, g.wx1) &&
+                               y0 - H >= max(0, g.wy0) && y0 + TY + H - 1 <= min(g.ny - 1, g.wy1) &&
+                               z0 - H >= max(0, g.wz0) && z0 + TZ + H - 1 <= min(g.nz - 1, g.wz1);
     auto address = [&](const int rx, const int ry, const int rz, bool &ok) -> int64_t {
       const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
-      ok = g.in_grid(x, y, z) && g.in_window(x, y, z);
+      ok = region_inside || (g.in_grid(x, y, z) && g.in_window(x, y, z));
       if (PAGED) {
         const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1),
                   oz = (rz < H) ? 0 : ((rz >= TZ + H) ? 2 : 1);
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
         ok = ok && pg >= 0;
         return (int64_t)max(pg, 0) * PAGE_VOX + (((x & (TX - 1)) * TY + (y & (TY - 1))) * TZ + (z & (TZ - 1)));
       }
-      return g.idx(min(max(x, 0), g.nx - 1), min(max(y, 0), g.ny - 1), min(max(z, 0), g.nz - 1));
+      return ok ? g.idx(x, y, z) : 0;
     };
     {
       constexpr int NROWS = RX * RY, RSLOTS = NT / 32;
@@ -255,9 +259,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
         const vox_t w = a.coc[idx];
         wh[u] = ok ? w : kUnobserved;
       }
-#pragma unroll 1
-      for (int k0 = 0; k0 < MIT; k0 += MB) {
-        vox_t wv[MB];
+      vox_t wv[MB];
+      auto load_batch = [&](const int k0) {
 #pragma unroll
         for (int u = 0; u < MB; ++u) {
           const int row = min(rslot + RSLOTS * (k0 + u), NROWS - 1);
@@ -266,6 +269,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
           const vox_t w = a.coc[idx];
           wv[u] = ok ? w : kUnobserved;
         }
+      };
+      auto build_batch = [&](const int k0) {
 #pragma unroll
         for (int u = 0; u < MB; ++u) {
           const int row = rslot + RSLOTS * (k0 + u);
@@ -294,6 +299,11 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
             put(FH, mh);
           }
         }
+      };
+#pragma unroll 1
+      for (int k0 = 0; k0 < MIT; k0 += MB) {
+        load_batch(k0);
+        build_batch(k0);
       }
 #pragma unroll
       for (int u = 0; u < HIT; ++u) {
