@@ -362,6 +362,12 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       constexpr bool SRC = decltype(src_tag)::value;
       for (uint32_t j = tid; j < total; j += NT) {
         const int v = Q[j];
+        // all 24 neighbours as NON-NEGATIVE constant offsets from one base: they fold into the DS instructions'
+        // unsigned immediate offset (a negative offset costs an address register and two VALU instructions each)
+        constexpr int NB0 = 2 * RY * RZ;
+        int vb = v - NB0;
+        asm volatile("" : "+v"(vb));  // keep the compiler from folding vb + NB0 back into v
+        __builtin_assume(vb >= 0 && vb < RSIZE);
         const uint32_t vbit = 1u << (v & 31);
         const int rz = v % RZ, ry = (v / RZ) % RY, rx = v / (RZ * RY);
         const int vx = bx + rx, vy = by + ry, vz = bz + rz;
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
             if (prof) ++n_pulls;
             vox_t best = lo;
             uint32_t bestd = hi;
-#define FIESTA_PULLL(DX, DY, DZ) un[q++] = KW(2 * (v + (((DX)*RY + (DY)) * RZ + (DZ))));
+#define FIESTA_PULLL(DX, DY, DZ) un[q++] = KW(2 * (vb + (NB0 + ((DX)*RY + (DY)) * RZ + (DZ))));
 #define FIESTA_PULLEVAL(NQ)                                 \
   _Pragma("unroll") for (int q = 0; q < (NQ); ++q) {        \
     const vox_t u = un[q];                                  \
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
           }
         }
         const int ax = 2 * rcx, ay = 2 * rcy, az = 2 * rcz;
-#define FIESTA_NIDX(DX, DY, DZ) (v + (((DX)*RY + (DY)) * RZ + (DZ)))
+#define FIESTA_NIDX(DX, DY, DZ) (vb + (NB0 + ((DX)*RY + (DY)) * RZ + (DZ)))
 #define FIESTA_PUSHL(DX, DY, DZ) dnv[q++] = KW(2 * FIESTA_NIDX(DX, DY, DZ) + 1);
 #define FIESTA_PUSH(DX, DY, DZ)                                                                              \
   {                                                                                                          \
