@@ -107,6 +107,9 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
   // on XCD b % 8 (observed placement, used for speed only), so tiles that share halo lines meet in one XCD's L2
   // at about the same time instead of each missing to HBM.
   const uint32_t ntiles = (uint32_t)(a.tg.ntx * a.tg.nty * a.tg.ntz);
+  // statistics are summed per work-group and flushed once after the walk (tens of thousands of visits would
+  // otherwise queue their atomics on three hot addresses)
+  uint32_t acc_writes = 0, acc_levels = 0, acc_visits = 0;
   for (uint32_t it = 0;; ++it) {
     uint32_t t;
     if (PAGED || a.spatial == 0) {
@@ -579,11 +582,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
         a.cbits_cur[wi] = ebits;
       }
     }
-    {
-      uint32_t v = nwrites;
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-      if (lane == 0 && v) atomicAdd(&a.counters[C_WRITES], (unsigned long long)v);
-    }
+    acc_writes += nwrites;
     __syncthreads();
     if (prof) {
       t3 = clock64();
@@ -607,8 +606,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     if (tid == 0) {
       a.tile_epoch[t] = a.epoch;
       a.cstamp_cur[t] = a.serial;
-      atomicAdd(&a.counters[C_SWEEPS], (unsigned long long)level);
-      atomicAdd(&a.counters[C_VISITS], 1ull);
+      acc_levels += level;
+      ++acc_visits;
     }
     if (tid < 27 && nbr_dirty[tid]) {
       const int ox = tid / 9 - 1, oy = (tid / 3) % 3 - 1, oz = tid % 3 - 1;
@@ -618,6 +617,12 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
         activate_tile((ux * a.tg.nty + uy) * a.tg.ntz + uz, a.flag_next, a.list_next, a.count_next);
     }
     __syncthreads();
+  }
+  for (int off = 32; off > 0; off >>= 1) acc_writes += __shfl_down(acc_writes, off);
+  if (lane == 0 && acc_writes) atomicAdd(&a.counters[C_WRITES], (unsigned long long)acc_writes);
+  if (tid == 0 && acc_visits) {
+    atomicAdd(&a.counters[C_SWEEPS], (unsigned long long)acc_levels);
+    atomicAdd(&a.counters[C_VISITS], (unsigned long long)acc_visits);
   }
 }
 
