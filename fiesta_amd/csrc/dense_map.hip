@@ -223,48 +223,72 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
   const int lane = threadIdx.x & 63;
   const bool vec = (g.nz & 3) == 0;
   unsigned long long local = 0;
+  constexpr int U = 2;  // 16-byte loads in flight per lane (the scan is latency-bound with one)
   for (uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4u) {
     const int x = (int)(row / (uint32_t)g.ny), y = (int)(row - (uint32_t)x * (uint32_t)g.ny);
     const int64_t base = (int64_t)row * g.nz;
-    for (int zb = 0; zb < g.nz; zb += 256) {
-      const int z4 = zb + 4 * lane;
-      vox_t w[4] = {kUnobserved, kUnobserved, kUnobserved, kUnobserved};
-      if (vec) {
-        if (z4 < g.nz) {
-          const uint4 q = *reinterpret_cast<const uint4 *>(coc + base + z4);
-          w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
-        }
-      } else {
+    for (int zb = 0; zb < g.nz; zb += 256 * U) {
+      vox_t w[U][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (z4 + k < g.nz) w[k] = coc[base + z4 + k];
-      }
-      uint32_t rmask = 0;
+      for (int u = 0; u < U; ++u) {
+        const int z4 = zb + 256 * u + 4 * lane;
+        w[u][0] = w[u][1] = w[u][2] = w[u][3] = kUnobserved;
+        if (vec) {
+          if (z4 < g.nz) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(coc + base + z4);
+            w[u][0] = q.x, w[u][1] = q.y, w[u][2] = q.z, w[u][3] = q.w;
+          }
+        } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (!(w[k] & kNoCoc)) {
-          int cx, cy, cz;
-          unpack_coc(w[k], cx, cy, cz);
-          if (g.owned(x, y, z4 + k) && !obstacle_alive(g, occbits, gocc, cx, cy, cz)) rmask |= 1u << k;
+          for (int k = 0; k < 4; ++k)
+            if (z4 + k < g.nz) w[u][k] = coc[base + z4 + k];
         }
       }
+      uint32_t rmask[U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if ((rmask >> k) & 1u) coc[base + z4 + k] = kReset;
-      if (__ballot(rmask != 0)) {
-        local += __popc(rmask);
-        // lanes 8j .. 8j+7 cover the 32 voxels of one tile along z
-        const unsigned long long m = __ballot(rmask != 0);
-        const int grp = lane >> 3;
-        if ((lane & 7) == 0 && ((m >> (grp * 8)) & 0xFFull) && z4 < g.nz) {
-          const uint32_t t = tg.tile_of(x, y, z4);
-          if (flag[t] == 0u) activate_tile(t, flag, list, count);
+      for (int u = 0; u < U; ++u) {
+        const int z4 = zb + 256 * u + 4 * lane;
+        rmask[u] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!(w[u][k] & kNoCoc)) {
+            int cx, cy, cz;
+            unpack_coc(w[u][k], cx, cy, cz);
+            if ((!g.sharded || g.owned(x, y, z4 + k)) && !obstacle_alive(g, occbits, gocc, cx, cy, cz)) rmask[u] |= 1u << k;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int z4 = zb + 256 * u + 4 * lane;
+        if (vec && rmask[u] == 15u) {
+          *reinterpret_cast<uint4 *>(coc + base + z4) = make_uint4(kReset, kReset, kReset, kReset);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((rmask[u] >> k) & 1u) coc[base + z4 + k] = kReset;
+        }
+        const unsigned long long m = __ballot(rmask[u] != 0);
+        if (m) {
+          local += __popc(rmask[u]);
+          // lanes 8j .. 8j+7 cover the 32 voxels of one tile along z
+          const int grp = lane >> 3;
+          if ((lane & 7) == 0 && ((m >> (grp * 8)) & 0xFFull) && z4 < g.nz) {
+            const uint32_t t = tg.tile_of(x, y, z4);
+            if (flag[t] == 0u) activate_tile(t, flag, list, count);
+          }
         }
       }
     }
   }
+  // one atomic per work-group: ~10 ns each on a single hot address, one per wave was most of this kernel's run time
+  __shared__ unsigned long long blk_local;
+  if (threadIdx.x == 0) blk_local = 0;
+  __syncthreads();
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-  if (lane == 0 && local) atomicAdd(&counters[C_INVALIDATED], local);
+  if (lane == 0 && local) atomicAdd(&blk_local, local);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_local) atomicAdd(&counters[C_INVALIDATED], blk_local);
 }
 
 struct RelaxArgs {
@@ -1093,7 +1117,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     FIESTA_HIP_CHECK(hipGetLastError());
   }
   if (nd || remote_del) {
-    hipLaunchKernelGGL(k_invalidate, dim3(grid_for(g_.n / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, tg, coc_,
+    hipLaunchKernelGGL(k_invalidate, dim3(grid_for(g_.n / 16 + 1, 256, 4096)), dim3(256), 0, stream_, g_, tg, coc_,
                        (const uint32_t *)occbits_, (const uint32_t *)gocc_, tile_flag_[0], tile_list_[0],
                        &counters_[C_LIST0], counters_);
     FIESTA_HIP_CHECK(hipGetLastError());
