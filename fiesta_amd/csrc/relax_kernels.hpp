@@ -129,6 +129,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const int bx = g.gx0 + x0 - H, by = g.gy0 + y0 - H, bz = g.gz0 + z0 - H;  // global coords of r-index 0
     const bool prof = a.prof != 0;
+    // the thread id, opaque per visit: index arithmetic derived from it is recomputed per tile (a few VALU
+    // instructions) instead of being hoisted out of the tile loop as dozens of invariants that spill to scratch
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
     uint32_t n_items = 0;
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (prof) t0 = clock64();
@@ -159,8 +163,71 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       __syncthreads();
       continue;
     }
+    // ---- stage the region: raw voxel word -> 64-bit key, and collect the level-0 frontier.
+    // EVERY voxel load of the region is issued up front, before the bitmaps are staged: a lane owns 4 consecutive
+    // tile-interior z of one (x,y) row (one 16-byte load, 8 lanes per row; the row arithmetic is shared by the four
+    // voxels), the 2+2 z-halo voxels of a row are two 8-byte loads. One memory latency per visit instead of three.
+    // Addresses are always legal, so no load sits behind a branch. (nz % 4 != 0: the same code with 4-byte loads.)
+    // the whole region (tile + halo) lies inside the grid and the update window: no per-voxel range tests
+    const bool region_inside = x0 - H >= max(0, g.wx0) && x0 + TX + H - 1 <= min(g.nx - 1, g.wx1) &&
+                               y0 - H >= max(0, g.wy0) && y0 + TY + H - 1 <= min(g.ny - 1, g.wy1) &&
+                               z0 - H >= max(0, g.wz0) && z0 + TZ + H - 1 <= min(g.nz - 1, g.wz1);
+    const bool vec = PAGED || (g.nz & 3) == 0;
+    constexpr int NROWS = RX * RY;
+    constexpr int NQ = NROWS * (TZ / 4), UM = (NQ + NT - 1) / NT;  // interior quads
+    constexpr int NHP = NROWS * 2, UH = (NHP + NT - 1) / NT;       // z-halo pairs
+    auto loadn = [&](auto n_tag, const int rx, const int ry, const int rz, vox_t *out) {
+      constexpr int N = decltype(n_tag)::value;
+      const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
+      bool okxy = region_inside || ((unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny && x >= g.wx0 &&
+                                    x <= g.wx1 && y >= g.wy0 && y <= g.wy1);
+      int64_t idx;
+      if (PAGED) {
+        const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1),
+                  oz = (rz < H) ? 0 : ((rz >= TZ + H) ? 2 : 1);
+        const int32_t pg = nb_page[ox * 9 + oy * 3 + oz];
+        okxy = okxy && pg >= 0;
+        idx = (int64_t)max(pg, 0) * PAGE_VOX + (((x & (TX - 1)) * TY + (y & (TY - 1))) * TZ + (z & (TZ - 1)));
+      } else {
+        idx = g.idx(x, y, z);
+      }
+      bool okz[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) okz[k] = region_inside || ((unsigned)(z + k) < (unsigned)g.nz && z + k >= g.wz0 && z + k <= g.wz1);
+      if (vec) {  // z and nz are multiples of N: the run is inside the array or outside as a whole
+        const bool in = okxy && (region_inside || (unsigned)z < (unsigned)g.nz);
+        vox_t q[N];
+        if (N == 4) {
+          const uint4 t = *reinterpret_cast<const uint4 *>(a.coc + (in ? idx : 0));
+          q[0] = t.x, q[1] = t.y, q[2] = t.z, q[3] = t.w;
+        } else {
+          const uint2 t = *reinterpret_cast<const uint2 *>(a.coc + (in ? idx : 0));
+          q[0] = t.x, q[1] = t.y;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = (in && okz[k]) ? q[k] : kUnobserved;
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const bool ok = okxy && okz[k];
+          const vox_t w = a.coc[ok ? idx + k : 0];
+          out[k] = ok ? w : kUnobserved;
+        }
+      }
+    };
+    vox_t wq[UM][4], wh[UH][2];
+#pragma unroll
+    for (int u = 0; u < UM; ++u) {
+      const int id = min(tl + u * NT, NQ - 1), row = id >> 3, quad = id & 7;
+      loadn(std::integral_constant<int, 4>{}, row / RY, row % RY, H + 4 * quad, wq[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UH; ++u) {
+      const int id = min(tl + u * NT, NHP - 1), row = id >> 1;
+      loadn(std::integral_constant<int, 2>{}, row / RY, row % RY, (id & 1) ? TZ + H : 0, wh[u]);
+    }
     // ---- stage the frontier bitmaps of the region's rows (3 z-words per row) through LDS
-    for (int j = tid; j < NROWW; j += NT) {
+    for (int j = tl; j < NROWW; j += NT) {
       const int k = j % 3, ry = (j / 3) % RY, rx = j / (3 * RY);
       const int x = x0 - H + rx, y = y0 - H + ry, zt = tz - 1 + k;
       const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1);
@@ -185,10 +252,6 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     __syncthreads();  // rb, cb staged; frontier bitmaps cleared
     const bool own_epoch = nb_ok[13] & 1u;
 
-    // ---- stage the region: raw voxel word -> 64-bit key, and collect the level-0 frontier.
-    // Main pass: a half-wave per (x,y) row, lane = one of the row's 32 tile-interior z (aligned 128-byte loads, the
-    // row arithmetic is shared by the half-wave's lanes); the 4 z-halo voxels of every row go through a second, small
-    // pass. Loads are issued in batches with always-legal addresses, so none sits behind a branch.
     uint32_t oldvalid = 0;
     // flags: 1 = already in the frontier (E), 2 = has no obstacle yet (P), 4 = level-0 frontier (F0), 8 = source only (FH)
     auto build = [&](auto zin_tag, const vox_t w, const int rx, const int ry, const int rz, uint32_t &flags) -> unsigned long long {
@@ -229,94 +292,46 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       }
       return ((unsigned long long)hi << 32) | lo;
     };
-    // the whole region (tile + halo) lies inside the grid and the update window: no per-voxel range tests
-    const bool region_inside = x0 - H >= max(0, g.wx0) && x0 + TX + H - 1 <= min(g.nx - 1, g.wx1) &&
-                               y0 - H >= max(0, g.wy0) && y0 + TY + H - 1 <= min(g.ny - 1, g.wy1) &&
-                               z0 - H >= max(0, g.wz0) && z0 + TZ + H - 1 <= min(g.nz - 1, g.wz1);
-    auto address = [&](const int rx, const int ry, const int rz, bool &ok) -> int64_t {
-      const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
-      ok = region_inside || (g.in_grid(x, y, z) && g.in_window(x, y, z));
-      if (PAGED) {
-        const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1),
-                  oz = (rz < H) ? 0 : ((rz >= TZ + H) ? 2 : 1);
-        const int32_t pg = nb_page[ox * 9 + oy * 3 + oz];
-        ok = ok && pg >= 0;
-        return (int64_t)max(pg, 0) * PAGE_VOX + (((x & (TX - 1)) * TY + (y & (TY - 1))) * TZ + (z & (TZ - 1)));
-      }
-      return ok ? g.idx(x, y, z) : 0;
-    };
-    {
-      constexpr int NROWS = RX * RY, RSLOTS = NT / 32;
-      constexpr int MIT = (NROWS + RSLOTS - 1) / RSLOTS;  // main-pass steps (32 lanes per row)
-      constexpr int HIT = (NROWS * 2 * H + NT - 1) / NT;   // z-halo steps (4 voxels per row)
-      constexpr int MB = (MIT + 1) / 2;
-      const int hl = tid & 31, rslot = tid >> 5;
-      // z-halo loads first, consumed last
-      vox_t wh[HIT];
 #pragma unroll
-      for (int u = 0; u < HIT; ++u) {
-        const int id = min(tid + u * NT, NROWS * 2 * H - 1);
-        const int row = id >> 2, q = id & 3;
-        bool ok;
-        const int64_t idx = address(row / RY, row % RY, q < H ? q : TZ + q, ok);
-        const vox_t w = a.coc[idx];
-        wh[u] = ok ? w : kUnobserved;
-      }
-      vox_t wv[MB];
-      auto load_batch = [&](const int k0) {
+    for (int u = 0; u < UM; ++u) {
+      const int id = tl + u * NT;
+      if (id < NQ) {
+        const int row = id >> 3, quad = id & 7, rx = row / RY, ry = row % RY, rz0 = H + 4 * quad;
+        const int i0 = row * RZ + rz0, w0 = i0 >> 5, sh = i0 & 31;
+        uint32_t ne = 0, np = 0, nf = 0, nh = 0;
 #pragma unroll
-        for (int u = 0; u < MB; ++u) {
-          const int row = min(rslot + RSLOTS * (k0 + u), NROWS - 1);
-          bool ok;
-          const int64_t idx = address(row / RY, row % RY, H + hl, ok);
-          const vox_t w = a.coc[idx];
-          wv[u] = ok ? w : kUnobserved;
-        }
-      };
-      auto build_batch = [&](const int k0) {
-#pragma unroll
-        for (int u = 0; u < MB; ++u) {
-          const int row = rslot + RSLOTS * (k0 + u);
-          const bool live = (k0 + u) < MIT && row < NROWS;
-          uint32_t flags = 0;
-          if (live) {
-            const int rx = row / RY, ry = row % RY;
-            K64(row * RZ + H + hl) = build(std::true_type{}, wv[u], rx, ry, H + hl, flags);
-          }
-          const unsigned long long me = __ballot(flags & 1u), mp = __ballot(flags & 2u), mf = __ballot(flags & 4u),
-                                   mh = __ballot(flags & 8u);
-          if (hl == 0 && live) {
-            const bool upper = tid & 32;
-            const int ib = row * RZ + H, w0 = ib >> 5, sh = ib & 31;
-            auto put = [&](uint32_t *B, const unsigned long long mm) {
-              const uint32_t m = upper ? (uint32_t)(mm >> 32) : (uint32_t)mm;
-              if (m) {
-                __hip_atomic_fetch_or(&B[w0], m << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t m2 = sh ? (m >> (32 - sh)) : 0u;
-                if (m2) __hip_atomic_fetch_or(&B[w0 + 1], m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              }
-            };
-            put(E, me);
-            put(P, mp);
-            put(F[0], mf);
-            put(FH, mh);
-          }
-        }
-      };
-#pragma unroll 1
-      for (int k0 = 0; k0 < MIT; k0 += MB) {
-        load_batch(k0);
-        build_batch(k0);
-      }
-#pragma unroll
-      for (int u = 0; u < HIT; ++u) {
-        const int id = tid + u * NT;
-        if (id < NROWS * 2 * H) {
-          const int row = id >> 2, q = id & 3, rz = q < H ? q : TZ + q;
-          const int i = row * RZ + rz;
+        for (int k = 0; k < 4; ++k) {
           uint32_t flags;
-          K64(i) = build(std::false_type{}, wh[u], row / RY, row % RY, rz, flags);
-          if (flags & 8u) __hip_atomic_fetch_or(&FH[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          K64(i0 + k) = build(std::true_type{}, wq[u][k], rx, ry, rz0 + k, flags);
+          ne |= (flags & 1u) << k;
+          np |= ((flags >> 1) & 1u) << k;
+          nf |= ((flags >> 2) & 1u) << k;
+          nh |= ((flags >> 3) & 1u) << k;
+        }
+        auto put = [&](uint32_t *B, const uint32_t nib) {  // 4 frontier bits of this quad (a quad may straddle two words)
+          if (nib) {
+            __hip_atomic_fetch_or(&B[w0], nib << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t m2 = sh > 28 ? (nib >> (32 - sh)) : 0u;
+            if (m2) __hip_atomic_fetch_or(&B[w0 + 1], m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        };
+        put(E, ne);
+        put(P, np);
+        put(F[0], nf);
+        put(FH, nh);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UH; ++u) {
+      const int id = tl + u * NT;
+      if (id < NHP) {
+        const int row = id >> 1, rz0 = (id & 1) ? TZ + H : 0, i0 = row * RZ + rz0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          uint32_t flags;
+          K64(i0 + k) = build(std::false_type{}, wh[u][k], row / RY, row % RY, rz0 + k, flags);
+          if (flags & 8u)
+            __hip_atomic_fetch_or(&FH[(i0 + k) >> 5], 1u << ((i0 + k) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
     }
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     if (prof) t2 = clock64();
 
     // ---- write back what changed, publish frontier membership, wake the neighbours
-    const int lz = tid & 31, slot = tid >> 5;
+    const int lz = tl & 31, slot = tl >> 5;
     uint32_t nwrites = 0;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
