@@ -134,7 +134,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
     int tl = tid;
     asm volatile("" : "+v"(tl));
     uint32_t n_items = 0;
-    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ts_a = 0, ts_b = 0;  // (prof == 2: staging sub-phases)
     if (prof) t0 = clock64();
     if (tid == 0) {
       a.flag_cur[t] = 0;
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       nb_page[tid] = pg;
     }
     __syncthreads();  // nb_ok
+    if (prof) ts_a = clock64();
     if (PAGED && nb_page[13] < 0) {  // a tile without a page holds no observed voxel: nothing to relax, nothing to write
       __syncthreads();
       continue;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       FH[j] = 0;
     }
     __syncthreads();  // rb, cb staged; frontier bitmaps cleared
+    if (prof) ts_b = clock64();
     const bool own_epoch = nb_ok[13] & 1u;
 
     uint32_t oldvalid = 0;
@@ -391,11 +393,11 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
         const int vx = bx + rx, vy = by + ry, vz = bz + rz;
         unsigned long long key = __hip_atomic_load(&K64(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-        if (prof) ++n_items;
+        if (a.prof == 1) ++n_items;
         if (!SRC && (P[v >> 5] & vbit)) {  // had no obstacle when the tile was staged, not asked yet
           __hip_atomic_fetch_and(&P[v >> 5], ~vbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (pulls_enabled) {
-            if (prof) ++n_pulls;
+            if (a.prof == 1) ++n_pulls;
             vox_t best = lo;
             uint32_t bestd = hi;
 #define FIESTA_PULLL(DX, DY, DZ) un[q++] = KW(2 * (vb + (NB0 + ((DX)*RY + (DY)) * RZ + (DZ))));
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
               const int n = v + (ex * RY + ey) * RZ + ez;
               const uint32_t cand = (uint32_t)(dv + 2 * (ex * rcx + ey * rcy + ez * rcz) + ex * ex + ey * ey + ez * ez);
               if (cand < KW(2 * n + 1)) {
-                if (prof) ++n_succ;
+                if (a.prof == 1) ++n_succ;
                 __hip_atomic_fetch_min(&K64(n), ((unsigned long long)cand << 32) | keylo, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_or(&Fn[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
   {                                                                                                          \
     const uint32_t cand = (uint32_t)(dv + (DX)*ax + (DY)*ay + (DZ)*az + ((DX) * (DX) + (DY) * (DY) + (DZ) * (DZ))); \
     if (cand < dnv[q++]) {                                                                                   \
-      if (prof) ++n_succ;                                                                                    \
+      if (a.prof == 1) ++n_succ;                                                                             \
       const int n = FIESTA_NIDX(DX, DY, DZ);                                                                 \
       __hip_atomic_fetch_min(&K64(n), ((unsigned long long)cand << 32) | keylo, __ATOMIC_RELAXED,              \
                              __HIP_MEMORY_SCOPE_WORKGROUP);                                                  \
@@ -610,6 +612,11 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       v = n_succ;
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
       if (lane == 0 && v) atomicAdd(&a.counters[C_PROF0 + 7], (unsigned long long)v);
+      if (tid == 0 && a.prof == 2) {  // replaces the three event counts above by: flags+neighbour table / loads+bitmaps / keys
+        atomicAdd(&a.counters[C_PROF0 + 3], (unsigned long long)(ts_a - t0));
+        atomicAdd(&a.counters[C_PROF0 + 6], (unsigned long long)(ts_b - ts_a));
+        atomicAdd(&a.counters[C_PROF0 + 7], (unsigned long long)(t1 - ts_b));
+      }
       if (tid == 0) {
         atomicAdd(&a.counters[C_PROF0 + 4], (unsigned long long)tc);
         atomicAdd(&a.counters[C_PROF0 + 5], (unsigned long long)tp);
