@@ -186,12 +186,15 @@ __global__ void k_ray_winner(int64_t n, int dedup, const int32_t *end_idx, const
 }
 
 // One fixed-point round: truncate every casting ray with the previous round's first-stamper array and rebuild
-// the array for the next round.
+// the array for the next round. Rounds are launched in batches without a host round trip: round `it` (1-based)
+// reports into changed[it]; a round that finds its predecessor unchanged (the fixed point) does nothing, and so
+// do all later rounds of the batch (their changed[] entries stay 0).
 __global__ void k_ray_resolve(int64_t n, const uint32_t *entries, const int32_t *m_count, const uint8_t *flags,
                               int32_t *last_k, int have_prev, int stamp, const uint32_t *fprev, uint32_t tag_prev,
-                              uint32_t *fnext, uint32_t tag_next, int ibits, int *changed) {
+                              uint32_t *fnext, uint32_t tag_next, int ibits, int *changed, int it) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (it >= 3 && changed[it - 1] == 0) return;  // round 1 always "changes" (from nothing visited to the full walk)
   if (!(flags[i] & 2)) return;
   const int m = m_count[i];
   const uint32_t imask = (1u << ibits) - 1u;
@@ -210,7 +213,7 @@ __global__ void k_ray_resolve(int64_t n, const uint32_t *entries, const int32_t 
   }
   if (lk != last_k[i]) {
     last_k[i] = lk;
-    *changed = 1;
+    changed[it] = 1;
   }
 }
 
@@ -261,7 +264,8 @@ struct DenseMap::RaycastState {
   uint32_t *stamp_occ = nullptr, *fa = nullptr, *fb = nullptr;
   int ibits = 0;
   uint32_t tag = 0;
-  int *d_flags = nullptr;  // [0] changed, [1] error
+  static constexpr int kMaxRounds = 240, kFlagInts = kMaxRounds + 8;
+  int *d_flags = nullptr;  // [0] unused, [1] error, [2 + it] "round it changed something"
   int *h_flags = nullptr;
   int64_t last_iterations = 0;
 };
@@ -288,8 +292,8 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
     throw Error(FIESTA_HIP_ERR_INVALID, "bad ray length window");
   if (!rc_) {
     rc_ = new RaycastState;
-    FIESTA_HIP_CHECK(hipMalloc((void **)&rc_->d_flags, 2 * sizeof(int)));
-    FIESTA_HIP_CHECK(hipHostMalloc((void **)&rc_->h_flags, 2 * sizeof(int)));
+    FIESTA_HIP_CHECK(hipMalloc((void **)&rc_->d_flags, RaycastState::kFlagInts * sizeof(int)));
+    FIESTA_HIP_CHECK(hipHostMalloc((void **)&rc_->h_flags, RaycastState::kFlagInts * sizeof(int)));
   }
   RaycastState &rc = *rc_;
   const Geom &g = g_;
@@ -318,7 +322,9 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
       FIESTA_HIP_CHECK(hipMalloc((void **)&rc.fa, g.n * sizeof(uint32_t)));
       FIESTA_HIP_CHECK(hipMalloc((void **)&rc.fb, g.n * sizeof(uint32_t)));
     }
-    if (fresh || ibits != rc.ibits || rc.tag < 4096) {
+    // a frame uses one tag for the end points and one per fixed-point round; clear the stamp arrays (3 whole-grid
+    // memsets) only when the tag space is about to run out, i.e. every few hundred frames
+    if (fresh || ibits != rc.ibits || rc.tag < (uint32_t)RaycastState::kMaxRounds + 16u) {
       FIESTA_HIP_CHECK(hipMemsetAsync(rc.stamp_occ, 0xFF, g.n * sizeof(uint32_t), stream_));
       FIESTA_HIP_CHECK(hipMemsetAsync(rc.fa, 0xFF, g.n * sizeof(uint32_t), stream_));
       FIESTA_HIP_CHECK(hipMemsetAsync(rc.fb, 0xFF, g.n * sizeof(uint32_t), stream_));
@@ -338,7 +344,7 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
   ra.dedup = dedup;
   // worst case every ray touches `stride` new voxels
   ensure_touched_capacity(std::min<int64_t>(g.n, n * (int64_t)(stride + 1)));
-  FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, 2 * sizeof(int), stream_));
+  FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, RaycastState::kFlagInts * sizeof(int), stream_));
   const uint32_t tag_occ = dedup ? rc.tag-- : 0;
   hipLaunchKernelGGL(k_ray_prepare, dim3(rgrid(n)), dim3(256), 0, stream_, g, ra, dpts, n, stride, rc.entries.p,
                      rc.end_idx.p, rc.m_count.p, rc.flags.p, rc.stamp_occ, dedup ? (tag_occ << ibits) : 0u, cnt_,
@@ -352,27 +358,36 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
   if (!dedup) {
     hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
                        (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, 0, 0,
-                       (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u, ibits, rc.d_flags);
+                       (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u, ibits, rc.d_flags + 2, 1);
     FIESTA_HIP_CHECK(hipGetLastError());
   } else {
     uint32_t *fprev = rc.fa, *fnext = rc.fb;
     uint32_t tag_prev = 0;
-    for (;;) {
-      const uint32_t tag_next = rc.tag--;
-      FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, sizeof(int), stream_));
-      hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
-                         (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, iters > 0 ? 1 : 0, 1,
-                         (const uint32_t *)fprev, tag_prev, fnext, tag_next, ibits, rc.d_flags);
-      FIESTA_HIP_CHECK(hipGetLastError());
-      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    constexpr int kBatch = 8;  // rounds per host round trip
+    bool done = false;
+    while (!done) {
+      const int64_t first = iters + 1;
+      for (int b = 0; b < kBatch; ++b) {
+        const uint32_t tag_next = rc.tag--;
+        ++iters;
+        hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
+                           (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, iters > 1 ? 1 : 0, 1,
+                           (const uint32_t *)fprev, tag_prev, fnext, tag_next, ibits, rc.d_flags + 2, (int)iters);
+        FIESTA_HIP_CHECK(hipGetLastError());
+        std::swap(fprev, fnext);
+        tag_prev = tag_next;
+      }
+      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, (2 + iters + 1) * sizeof(int), hipMemcpyDeviceToHost, stream_));
       FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-      ++iters;
       if (rc.h_flags[1]) break;
-      // round 1 always "changes" (from nothing visited to the full walk); stop when a round changes nothing
-      if (iters > 1 && !rc.h_flags[0]) break;
-      std::swap(fprev, fnext);
-      tag_prev = tag_next;
-      if (rc.tag < 16) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup did not converge");
+      // stop at the first round (after round 1) that changed nothing
+      for (int64_t it = std::max<int64_t>(first, 2); it <= iters; ++it)
+        if (!rc.h_flags[2 + it]) {
+          iters = it;
+          done = true;
+          break;
+        }
+      if (!done && iters + kBatch > RaycastState::kMaxRounds) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup did not converge");
     }
   }
   rc.last_iterations = iters;
@@ -391,8 +406,8 @@ void DenseMap::raycast_depth(const uint16_t *depth, int rows, int cols, double f
   use_device();
   if (!rc_) {
     rc_ = new RaycastState;
-    FIESTA_HIP_CHECK(hipMalloc((void **)&rc_->d_flags, 2 * sizeof(int)));
-    FIESTA_HIP_CHECK(hipHostMalloc((void **)&rc_->h_flags, 2 * sizeof(int)));
+    FIESTA_HIP_CHECK(hipMalloc((void **)&rc_->d_flags, RaycastState::kFlagInts * sizeof(int)));
+    FIESTA_HIP_CHECK(hipHostMalloc((void **)&rc_->h_flags, RaycastState::kFlagInts * sizeof(int)));
   }
   const int64_t n = (int64_t)rows * cols;
   rc_->depth.ensure(n, stream_);
