@@ -133,10 +133,10 @@ __global__ void k_h_fuse(Geom g, ProbParams pp, int global_map, const int32_t *p
   const uint32_t bit = 1u << (a & 31);
   if (now && !was) {
     atomicOr(&occbits[a >> 5], bit);
-    ins[atomicAdd(&counters[C_INSERT], 1ull)] = a;
+    wave_append(true, a, ins, &counters[C_INSERT]);  // one atomic per wave on the hot counter
   } else if (!now && was) {
     atomicAnd(&occbits[a >> 5], ~bit);
-    del[atomicAdd(&counters[C_DELETE], 1ull)] = a;
+    wave_append(true, a, del, &counters[C_DELETE]);
   }
 }
 
@@ -177,7 +177,12 @@ __global__ __launch_bounds__(256) void k_h_invalidate(const int32_t *dir, const 
       if (flag[t] == 0u) activate_tile(t, flag, list, count);
     }
   }
-  if (lane == 0 && local) atomicAdd(&counters[C_INVALIDATED], local);
+  __shared__ unsigned long long blk_local;  // one atomic per work-group on the hot counter
+  if (threadIdx.x == 0) blk_local = 0;
+  __syncthreads();
+  if (lane == 0 && local) atomicAdd(&blk_local, local);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_local) atomicAdd(&counters[C_INVALIDATED], blk_local);
 }
 
 // ---- queries (src/ESDFMap.cpp:452-540); an unallocated voxel reads like a freshly allocated one ----
