@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--obstacles", type=int, default=50000)
     ap.add_argument("--tile-shape", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-grid", type=int, default=192)
+    ap.add_argument("--cpu-grid", type=int, default=224)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"], help="c2 = the headline metric; c3 = depth-frame pipeline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded driver even with one rank (smoke test)")
