@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--tile-shape", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=224)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"], help="c2 = the headline metric; c3 = depth-frame pipeline")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
+                    help="c2 = the headline metric; c3 = depth-frame pipeline; c4 = hash-block map, streaming window")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded driver even with one rank (smoke test)")
     ap.add_argument("--replicas", action="store_true",
@@ -225,11 +226,112 @@ def run_c3(args):
     m.close()
 
 
+def run_c4(args):
+    """BASELINE config 4 (`--workload c4`): hash-block map @0.05 m, streaming insert/delete: a
+    6 x 6 x 3 m observation window (864 000 voxels) moving through a 40 m volume, per frame: observe the window free
+    (fiesta_hip_set_occupancy_box), observe ~16 k surface voxels occupied (device batch), UpdateOccupancy, UpdateESDF
+    (tests/scenarios.py: c4_frame).  Inputs are generated before the clock starts and are resident in HBM.  value =
+    updated voxels (SURVEY.md 8d unit, counted on the device outside the timed segments) / time of the timed frames.
+    cpu_baseline = the reference built with -DHASH_TABLE on the first frames of the same stream."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenarios import box_voxels, c4_frame
+    import fiesta_amd
+    res = 0.05
+    m = fiesta_amd.ESDFMap((0.0, 0.0, 0.0), res, reserve_size=1000000, mode="hash")
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    nframes = args.warmup + args.steps
+    dev = torch.device("cuda", 0)
+    frames = []
+    for k in range(nframes):
+        lo, hi, occ = c4_frame(k)
+        v = torch.from_numpy(occ).to(dev)
+        frames.append((lo, hi, occ, v, torch.ones(len(occ), dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    t_obs, t_fuse, t_esdf, upd, relax_ms, launches = [], [], [], [], [], []
+    for k, (lo, hi, occ, v, o) in enumerate(frames):
+        t0 = time.perf_counter()
+        m.SetOccupancyBox(lo, hi, 0)
+        m.SetOccupancyDevice(v.data_ptr(), o.data_ptr(), len(occ))
+        m.synchronize()
+        t1 = time.perf_counter()
+        m.UpdateOccupancy(True)
+        m.synchronize()
+        t2 = time.perf_counter()
+        m.snapshot_save(0)
+        t3 = time.perf_counter()
+        st = m.UpdateESDF()
+        t4 = time.perf_counter()
+        n_upd = m.snapshot_count_updated(0)
+        if k >= args.warmup:
+            t_obs.append(t1 - t0), t_fuse.append(t2 - t1), t_esdf.append(t4 - t3), upd.append(n_upd)
+            relax_ms.append(st["relax_ms"]), launches.append(st["relax_launches"])
+    total_s = sum(t_obs) + sum(t_fuse) + sum(t_esdf)
+    pages = m.grid_total_size_ // 8192
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        pyoracle.build("port")
+        kind = "ref" if pyoracle.available("ref", "hash") else "port"
+        c = pyoracle.OracleMap((0.0, 0.0, 0.0), res, reserve_size=1000000, mode="hash", kind=kind)
+        c.SetParameters(*P_DEFAULT)
+        c.SetOriginalRange()
+        cu, ct, ce = 0, 0.0, 0.0
+        ncpu = 0
+        for k in range(nframes):
+            lo, hi, occ = c4_frame(k)
+            bv = box_voxels(lo, hi)
+            c0 = time.perf_counter()
+            c.SetOccupancyVox(bv, 0)
+            c.SetOccupancyVox(occ, 1)
+            c.UpdateOccupancy(True)
+            c1 = time.perf_counter()
+            before = c.dump_hash()
+            c2 = time.perf_counter()
+            sc = c.UpdateESDF()
+            c3 = time.perf_counter()
+            after = c.dump_hash()
+            nb = len(before["dist"])
+            ch = (after["dist"][:nb] != before["dist"]) | np.any(after["coc"][:nb] != before["coc"], axis=1)
+            cu += int(ch.sum()) + int((after["dist"][nb:] != -10000).sum())
+            ct += (c1 - c0) + (c3 - c2)
+            ce += c3 - c2
+            ncpu += 1
+            if ct > 20.0:
+                break
+        cpu = {"value": cu / ct, "unit": "voxels/s", "cores": 1, "kind": "reference" if c.describe.startswith("reference") else "port",
+               "sample": f"the first {ncpu} frames of the same stream (ingest + UpdateOccupancy + UpdateESDF, {ct:.1f} s; changed "
+                         f"(distance, obstacle) entries {cu}); UpdateESDF alone {ce:.1f} s", "update_esdf_voxels_per_sec": cu / max(ce, 1e-9)}
+    sum_relax_s = sum(relax_ms) * 1e-3
+    n_launch = max(1, int(sum(launches)))
+    out = {
+        "metric": "c4_hash_updated_voxels_per_sec", "value": sum(upd) / total_s, "unit": "voxels/s", "n_gpus": 1,
+        "steps": len(upd), "warmup": args.warmup, "ms_per_step": 1e3 * total_s / len(upd), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "C4: hash-block map (16x16x32-voxel pages behind a dense directory) @0.05 m, reserve 1e6, a "
+                               "120x120x60-voxel observation window streaming 3 voxels/frame through a 40 m volume: per frame "
+                               "864000 free + ~16400 occupied observations, UpdateOccupancy, UpdateESDF; inputs resident in HBM"},
+        "observe_p50_ms": 1e3 * statistics.median(t_obs), "update_occupancy_p50_ms": 1e3 * statistics.median(t_fuse),
+        "update_esdf_p50_ms": 1e3 * statistics.median(t_esdf), "updated_voxels_per_frame": sum(upd) / len(upd),
+        "update_esdf_voxels_per_sec": sum(upd) / sum(t_esdf), "allocated_pages": int(pages),
+        "allocated_voxels": int(m.grid_total_size_),
+        "roofline": {"bound": "hbm", "kernel": "k_relax_q<16,16,1024,PAGED>", "achieved": 16.0 * sum(upd) / max(sum_relax_s, 1e-12) / 1e9,
+                     "peak": 8000.0, "unit": "GB/s", "frac": 16.0 * sum(upd) / max(sum_relax_s, 1e-12) / 8e12, "traffic": None,
+                     "launches": n_launch, "avg_launch_us": 1e6 * sum_relax_s / n_launch},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    m.close()
+
+
 def main():
     args = parse()
     if args.workload == "c3":
         import torch  # noqa: F401  (one HIP runtime per process: torch first)
         return run_c3(args)
+    if args.workload == "c4":
+        return run_c4(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

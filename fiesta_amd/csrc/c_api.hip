@@ -165,14 +165,20 @@ int fiesta_hip_set_occupancy_pos(fiesta_hip_map *m, const double *pos, const int
 int fiesta_hip_set_occupancy_vox_dev(fiesta_hip_map *m, const int32_t *vox_dev, const int32_t *occ_dev, int64_t n) {
   return guarded([&] {
     need(m && (n == 0 || (vox_dev && occ_dev)) && n >= 0, "bad argument");
-    dense(m, "set_occupancy_vox_dev").observe_vox(vox_dev, occ_dev, n, nullptr, true);
+    if (m->dense)
+      m->dense->observe_vox(vox_dev, occ_dev, n, nullptr, true);
+    else
+      m->hash->observe_vox(vox_dev, occ_dev, n, nullptr, true);
   });
 }
 
 int fiesta_hip_set_occupancy_box(fiesta_hip_map *m, const int32_t lo[3], const int32_t hi[3], int32_t occ) {
   return guarded([&] {
     need(m && lo && hi && (occ == 0 || occ == 1), "bad argument");
-    dense(m, "set_occupancy_box").observe_box(lo, hi, occ);
+    if (m->dense)
+      m->dense->observe_box(lo, hi, occ);
+    else
+      m->hash->observe_box(lo, hi, occ);
   });
 }
 
@@ -315,7 +321,15 @@ int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, in
 }
 
 int fiesta_hip_snapshot_save(fiesta_hip_map *m, int32_t slot) {
-  return guarded([&] { dense(m, "snapshot_save").snapshot_save(slot); });
+  return guarded([&] {
+    need(m != nullptr, "null map");
+    if (m->dense) {
+      m->dense->snapshot_save(slot);
+    } else {  // hash-block maps keep ONE copy of the state words, enough for the "updated voxels" unit (no restore)
+      need(slot == 0, "hash-mode maps have snapshot slot 0 only");
+      m->hash->snapshot_save();
+    }
+  });
 }
 int fiesta_hip_snapshot_restore(fiesta_hip_map *m, int32_t slot) {
   return guarded([&] { dense(m, "snapshot_restore").snapshot_restore(slot); });
@@ -323,7 +337,13 @@ int fiesta_hip_snapshot_restore(fiesta_hip_map *m, int32_t slot) {
 int fiesta_hip_snapshot_count_updated(fiesta_hip_map *m, int32_t slot, int64_t *updated) {
   return guarded([&] {
     need(updated != nullptr, "null argument");
-    *updated = dense(m, "snapshot_count_updated").snapshot_count_updated(slot);
+    need(m != nullptr, "null map");
+    if (m->dense) {
+      *updated = m->dense->snapshot_count_updated(slot);
+    } else {
+      need(slot == 0, "hash-mode maps have snapshot slot 0 only");
+      *updated = m->hash->snapshot_count_updated();
+    }
   });
 }
 

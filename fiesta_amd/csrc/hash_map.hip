@@ -104,6 +104,81 @@ __global__ void k_h_observe_pos(Geom g, const int32_t *dir, const double *pos, c
   if (i < n && obs_pos(g, pos, occ, i, x, y, z)) h_count(vaddr(dir, x, y, z), occ[i], cnt, touched, counters);
 }
 
+// SetOccupancy(Vector3i, occ) for every voxel of a box given in WINDOW coordinates (inclusive): tiles first ...
+__global__ void k_h_mark_box(Geom g, int x0, int y0, int z0, int x1, int y1, int z1, uint32_t *need) {
+  const int tx0 = x0 >> 4, ty0 = y0 >> 4, tz0 = z0 >> 5;
+  const int ntx = (x1 >> 4) - tx0 + 1, nty = (y1 >> 4) - ty0 + 1, ntz = (z1 >> 5) - tz0 + 1;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)ntx * nty * ntz) return;
+  const int tz = (int)(i % ntz), ty = (int)((i / ntz) % nty), tx = (int)(i / ((int64_t)ntz * nty));
+  need[((tx0 + tx) * kNTY + (ty0 + ty)) * kNTZ + (tz0 + tz)] = 1u;
+}
+// ... then the voxels: 16 waves per work-group, one z-run of 64 voxels of a box row per wave and step; every voxel is
+// visited once (no atomic on the counter word), first-touch appends aggregated per work-group (dense_map.hip,
+// k_observe_box).
+__global__ __launch_bounds__(1024) void k_h_observe_box(Geom g, const int32_t *dir, int x0, int y0, int z0, int ex, int ey,
+                                                        int ez, int occ, unsigned long long *cnt, uint32_t *touched,
+                                                        unsigned long long *counters) {
+  __shared__ uint32_t blk_count, blk_base;
+  const int zchunks = (ez + 63) >> 6;
+  const int64_t nitems = (int64_t)ex * ey * zchunks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int64_t steps = (nitems + (int64_t)gridDim.x * nwave - 1) / ((int64_t)gridDim.x * nwave);
+  for (int64_t st = 0; st < steps; ++st) {
+    const int64_t item = (st * gridDim.x + blockIdx.x) * nwave + wave;
+    if (threadIdx.x == 0) blk_count = 0;
+    __syncthreads();
+    bool first = false;
+    int64_t addr = 0;
+    if (item < nitems) {
+      const int zc = (int)(item % zchunks);
+      const int64_t row = item / zchunks;
+      const int y = y0 + (int)(row % ey), x = x0 + (int)(row / ey);
+      const int zi = zc * 64 + lane, z = z0 + zi;
+      if (zi < ez && in_win(x, y, z) && g.in_window(x, y, z)) {
+        addr = vaddr(dir, x, y, z);
+        const unsigned long long old = cnt[addr];
+        cnt[addr] = old + (((unsigned long long)(uint32_t)occ << 32) | 1ull);
+        first = (uint32_t)old == 0;
+      }
+    }
+    const unsigned long long m = __ballot(first);
+    uint32_t woff = 0;
+    if (lane == 0 && m) woff = atomicAdd(&blk_count, (uint32_t)__popcll(m));
+    woff = __shfl(woff, 0);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_count) blk_base = (uint32_t)atomicAdd(&counters[C_TOUCHED], (unsigned long long)blk_count);
+    __syncthreads();
+    if (first) touched[blk_base + woff + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)addr;
+  }
+}
+
+// "updated voxel" as SURVEY.md 8d defines it (d^2 differs, or the old closest obstacle vanished), between a saved copy
+// of the pool's state words and now; pages allocated after the copy read as unobserved before.
+__global__ void k_h_count_updated(const int32_t *dir, const int32_t *page_tile, const vox_t *before, int64_t n_before,
+                                  const vox_t *now, int64_t n_now, const uint32_t *occbits, unsigned long long *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_now; i += stride) {
+    const vox_t a = (i < n_before ? before[i] : kUnobserved) & ~kAct, b = now[i] & ~kAct;
+    if (a == b) continue;
+    int x, y, z;
+    vcoords(page_tile, (uint32_t)i, x, y, z);
+    const int32_t da = (a == kUnobserved) ? -1 : ((a & kNoCoc) ? kD2Inf : dist2(x, y, z, a));
+    const int32_t db = (b == kUnobserved) ? -1 : ((b & kNoCoc) ? kD2Inf : dist2(x, y, z, b));
+    bool upd = da != db;
+    if (!upd && !(a & kNoCoc)) {
+      int cx, cy, cz;
+      unpack_coc(a, cx, cy, cz);
+      const int64_t ca = vaddr(dir, cx, cy, cz);
+      upd = ca < 0 || !hbit(occbits, ca);
+    }
+    local += upd;
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+
 // ---- UpdateOccupancy (src/ESDFMap.cpp:235-271) ----
 __global__ void k_h_fuse(Geom g, ProbParams pp, int global_map, const int32_t *page_tile, const uint32_t *touched,
                          int64_t n, unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *ins,
@@ -419,21 +494,26 @@ void HashMap::allocate_marked() {
   npages_ += k;
 }
 
-void HashMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret) {
+void HashMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret, bool dev) {
   use_device();
   if (n <= 0) return;
-  stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
-  stage_b_.ensure(n * sizeof(int32_t), stream_);
-  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-  FIESTA_HIP_CHECK(hipMemcpyAsync(stage_b_.p, occ, n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-  hipLaunchKernelGGL(k_h_mark_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)stage_a_.p, n, need_);
+  const int32_t *dvox = vox, *docc = occ;
+  if (!dev) {
+    stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
+    stage_b_.ensure(n * sizeof(int32_t), stream_);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(stage_b_.p, occ, n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    dvox = (const int32_t *)stage_a_.p;
+    docc = (const int32_t *)stage_b_.p;
+  }
+  hipLaunchKernelGGL(k_h_mark_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, dvox, n, need_);
   allocate_marked();
   touched_upper_ = std::min<int64_t>(npages_ * kPageVox, touched_upper_ + n);
   touched_.ensure((size_t)touched_upper_, stream_, touched_.cap);
-  hipLaunchKernelGGL(k_h_observe_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, (const int32_t *)stage_a_.p,
-                     (const int32_t *)stage_b_.p, n, cnt_.p, touched_.p, counters_);
+  hipLaunchKernelGGL(k_h_observe_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, dvox, docc, n, cnt_.p,
+                     touched_.p, counters_);
   FIESTA_HIP_CHECK(hipGetLastError());
-  if (ret) {  // the reference returns its internal index (allocation-order dependent); what callers rely on is
+  if (ret && !dev) {  // the reference returns its internal index (allocation-order dependent); what callers rely on is
               // "-10000 = rejected, otherwise a key that identifies the voxel" (include/Fiesta.h:221,253)
     for (int64_t i = 0; i < n; ++i) {
       const int x = vox[3 * i] + kHalf, y = vox[3 * i + 1] + kHalf, z = vox[3 * i + 2] + kHalf;
@@ -442,6 +522,48 @@ void HashMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int
     }
   }
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void HashMap::observe_box(const int32_t *lo, const int32_t *hi, int occ) {
+  use_device();
+  // clip to the virtual window (SetOccupancy outside the map is rejected, src/ESDFMap.cpp:406-410), window coordinates
+  int a[3], b[3];
+  for (int k = 0; k < 3; ++k) {
+    a[k] = std::max(lo[k] + kHalf, 0);
+    b[k] = std::min(hi[k] + kHalf, kWin - 1);
+    if (a[k] > b[k]) return;
+  }
+  const int64_t ex = b[0] - a[0] + 1, ey = b[1] - a[1] + 1, ez = b[2] - a[2] + 1;
+  const int64_t ntiles = (int64_t)((b[0] >> 4) - (a[0] >> 4) + 1) * ((b[1] >> 4) - (a[1] >> 4) + 1) * ((b[2] >> 5) - (a[2] >> 5) + 1);
+  hipLaunchKernelGGL(k_h_mark_box, dim3(grid_for(ntiles)), dim3(256), 0, stream_, g_, a[0], a[1], a[2], b[0], b[1], b[2], need_);
+  allocate_marked();
+  touched_upper_ = std::min<int64_t>(npages_ * kPageVox, touched_upper_ + ex * ey * ez);
+  touched_.ensure((size_t)touched_upper_, stream_, touched_.cap);
+  hipLaunchKernelGGL(k_h_observe_box, dim3(grid_for(ex * ey * ((ez + 63) / 64), 16, 4096)), dim3(1024), 0, stream_, g_,
+                     (const int32_t *)dir_, a[0], a[1], a[2], (int)ex, (int)ey, (int)ez, occ, cnt_.p, touched_.p, counters_);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void HashMap::snapshot_save() {
+  use_device();
+  shadow_.ensure((size_t)npages_ * kPageVox, stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(shadow_.p, coc_.p, (size_t)npages_ * kPageVox * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
+  shadow_vox_ = npages_ * kPageVox;
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+int64_t HashMap::snapshot_count_updated() {
+  use_device();
+  if (shadow_vox_ < 0) throw Error(FIESTA_HIP_ERR_STATE, "snapshot_count_updated: no snapshot saved");
+  zero_counter(C_SCRATCH);
+  const int64_t n_now = npages_ * kPageVox;
+  if (n_now)
+    hipLaunchKernelGGL(k_h_count_updated, dim3(grid_for(n_now, 256, 8192)), dim3(256), 0, stream_, (const int32_t *)dir_,
+                       (const int32_t *)page_tile_.p, (const vox_t *)shadow_.p, shadow_vox_, (const vox_t *)coc_.p, n_now,
+                       (const uint32_t *)occbits_.p, &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  return (int64_t)read_counter(C_SCRATCH);
 }
 
 void HashMap::observe_pos(const double *pos, const int32_t *occ, int64_t n, int32_t *ret) {

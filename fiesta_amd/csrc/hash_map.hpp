@@ -33,7 +33,10 @@ class HashMap {
   void set_prob_params(double p_hit, double p_miss, double p_min, double p_max, double p_occ);
   void set_update_range(const double *mn, const double *mx, bool new_vec);
   void set_original_range();
-  void observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret);
+  void observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret, bool dev = false);
+  void observe_box(const int32_t *lo, const int32_t *hi, int occ);  // inclusive voxel box, map voxel coordinates
+  void snapshot_save();                                             // copy of the state words (benchmark unit only)
+  int64_t snapshot_count_updated();
   void observe_pos(const double *pos, const int32_t *occ, int64_t n, int32_t *ret);
   void raycast_frame(const float *, int64_t, const double *, const double *, const fiesta_hip_raycast_params *) {
     throw Error(FIESTA_HIP_ERR_INVALID, "raycast_frame: array-mode maps only in this build");
@@ -71,6 +74,8 @@ class HashMap {
   DevBuf<unsigned long long> cnt_;
   DevBuf<uint32_t> occbits_, rbits_, cbits_[2];
   DevBuf<int32_t> page_tile_;
+  DevBuf<vox_t> shadow_;
+  int64_t shadow_vox_ = -1;
   int64_t npages_ = 0, cap_pages_ = 0;
 
   // directory space (fixed size kNTiles)

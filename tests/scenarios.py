@@ -229,3 +229,40 @@ def compare_gpu_to_golden(gpu_map, gold, cp):
             return {"dist": gold[f"{cp}/dist"], "coc": gold[f"{cp}/coc"].astype(np.int32), "occ": gold[f"{cp}/occ"],
                     "logodds": gold[f"{cp}/logodds"]}
     return compare_dense(gpu_map, _Gold())
+
+
+# ---- BASELINE config 4: hash-block map, streaming insert/delete -------------------------------------
+def c4_frame(k, res=0.05):
+    """Frame k of the streaming scenario, in voxel coordinates of a 0.05 m map whose origin is the world centre
+    (the 40 m bounding volume is [-400, 399]^3): a 6 x 6 x 3 m observation window (120 x 120 x 60 voxels) moving 3
+    voxels per frame along x on a slow sine in y.  Returns (box_lo, box_hi, occ_vox): every voxel of the inclusive box
+    is observed FREE once and the voxels of occ_vox additionally OCCUPIED once in that frame (a voxel seen both ways
+    counts as a hit, src/ESDFMap.cpp:240).  Content: a floor plane, 2x2 pillars on a 40-voxel lattice, a sphere shell
+    that moves with the sensor (its old surface is deleted, its new one inserted), and a rotating 10 % of the static
+    surface switched off for 8 frames at a time (deleted after 6 misses, re-inserted after 3 hits)."""
+    import math
+    cx, cy, cz = -300 + 3 * k, int(round(100.0 * math.sin(2.0 * math.pi * k / 200.0))), 0
+    lo = np.array([cx - 60, cy - 60, cz - 30], np.int32)
+    hi = np.array([cx + 59, cy + 59, cz + 29], np.int32)
+    xs, ys, zs = (np.arange(lo[i], hi[i] + 1, dtype=np.int64) for i in range(3))
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    floor = np.stack([X.ravel(), Y.ravel(), np.full(X.size, -28, np.int64)], -1)
+    px, py = xs[(xs % 40) < 2], ys[(ys % 40) < 2]
+    P = np.stack(np.meshgrid(px, py, zs, indexing="ij"), -1).reshape(-1, 3)
+    static = np.concatenate([floor, P])
+    h = (static[:, 0] * 73856093) ^ (static[:, 1] * 19349663) ^ (static[:, 2] * 83492791)
+    static = static[((h & 0x7FFFFFFF) + k // 8) % 10 != 0]
+    sc = np.array([cx + int(round(20 * math.cos(k / 5.0))), cy + int(round(20 * math.sin(k / 5.0))), 0], np.int64)
+    r = np.arange(-11, 12, dtype=np.int64)
+    B = np.stack(np.meshgrid(r, r, r, indexing="ij"), -1).reshape(-1, 3)
+    d = np.sqrt((B ** 2).sum(-1))
+    shell = B[np.abs(d - 9.0) < 0.7] + sc
+    occ = np.concatenate([static, shell])
+    inside = np.all((occ >= lo) & (occ <= hi), axis=1)
+    occ = np.unique(occ[inside], axis=0).astype(np.int32)
+    return lo, hi, occ
+
+
+def box_voxels(lo, hi):
+    g = np.stack(np.meshgrid(*(np.arange(lo[i], hi[i] + 1, dtype=np.int32) for i in range(3)), indexing="ij"), -1)
+    return np.ascontiguousarray(g.reshape(-1, 3))

@@ -139,7 +139,9 @@ def test_hash_mode_errors_are_loud(hip_lib):
     assert m.SetOccupancy(np.array([[600, 0, 0]], np.int32), 1)[0] == -10000
     assert m.SetOccupancy(np.array([[5, 5, 5]], np.int32), 1)[0] != -10000
     with pytest.raises(fiesta_amd.FiestaHipError):
-        m.snapshot_save(0)
+        m.snapshot_restore(0)   # hash-mode maps keep one copy of the state words for the benchmark unit: no restore
+    with pytest.raises(fiesta_amd.FiestaHipError):
+        m.snapshot_save(1)
     assert m.GetDistance(np.array([[5, 5, 5]], np.int32))[0] == 10000.0
 
 
@@ -161,3 +163,34 @@ def test_hash_wave_reaches_unallocated_space(hip_lib, oracle_libs, best_oracle_k
     cycles(gpu, cpu, np.array([[20, 3, 5]], np.int32), [], 3)
     rep = compare(gpu, cpu)
     assert rep["d2_mismatch"] <= 2 and rep["pages"] == 2, rep  # freshly observed free space: order-dependent regime
+
+
+def test_hash_c4_stream_box_observe(hip_lib, oracle_libs, best_oracle_kind):
+    """The bench's C4 stream (tests/scenarios.py: c4_frame) through the device-side box observe of the paged map, first
+    frames, against the hash-table reference fed voxel by voxel; and the device-side "updated voxels" unit against a
+    count made from two downloads."""
+    from scenarios import box_voxels, c4_frame
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.05, 1000000)
+    for k in range(4):
+        lo, hi, occ = c4_frame(k)
+        gpu.SetOccupancyBox(lo, hi, 0)
+        gpu.SetOccupancy(occ, 1)
+        cpu.SetOccupancyVox(box_voxels(lo, hi), 0)
+        cpu.SetOccupancyVox(occ, 1)
+        a, b = gpu.UpdateOccupancy(True), cpu.UpdateOccupancy(True)
+        assert a == b and (gpu.last_insert, gpu.last_delete) == (cpu.last_insert, cpu.last_delete), k
+        before = gpu.download_hash() if k == 3 else None
+        gpu.snapshot_save(0)
+        sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
+        assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+        n_upd = gpu.snapshot_count_updated(0)
+        if before is not None:
+            after = gpu.download_hash()
+            nb = len(before["d2"])
+            assert np.array_equal(after["vox"][:nb], before["vox"])          # pages are only appended
+            d2_changed = int((after["d2"][:nb] != before["d2"]).sum()) + int((after["d2"][nb:] != -1).sum())
+            any_changed = d2_changed + int(((after["d2"][:nb] == before["d2"]) & np.any(after["coc"][:nb] != before["coc"], axis=1)).sum())
+            assert d2_changed <= n_upd <= any_changed, (d2_changed, n_upd, any_changed)
+    rep = compare(gpu, cpu)
+    # frames 0..2 only observe (3 hits make an obstacle): frame 3 inserts the whole visible surface at once
+    assert rep["finite"] > 500000 and rep["d2_mismatch"] <= 0.02 * rep["finite"], rep
