@@ -739,6 +739,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
     case 11: tx_ = 16, ty_ = 16, engine_ = 1; break;
     case 12: tx_ = 16, ty_ = 8, engine_ = 1; break;
     case 13: tx_ = 16, ty_ = 16, engine_ = 1, threads_ = 512; break;  // 2 waves/SIMD, 213 VGPRs, single 24-batch
+    case 14: tx_ = 8, ty_ = 8, engine_ = 1, threads_ = 512; break;    // 58 KB of LDS: TWO work-groups per CU
     default: throw Error(FIESTA_HIP_ERR_INVALID, "unknown tile_shape");
   }
   if (sharded && engine_ != 1) throw Error(FIESTA_HIP_ERR_INVALID, "sharded maps need the work-queue engine");
@@ -1033,7 +1034,9 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     const int blocks = spatial_ ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), (uint32_t)spatial_blocks_)
                                 : (int)std::min<uint32_t>(ncur, 16384u);
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
-    if (tx_ == 8 && ty_ == 8)
+    if (tx_ == 8 && ty_ == 8 && threads_ == 512)
+      hipLaunchKernelGGL((k_relax_q<8, 8, 512>), dim3(blocks), dim3(512), 0, stream_, a);
+    else if (tx_ == 8 && ty_ == 8)
       hipLaunchKernelGGL((k_relax_q<8, 8, 256>), dim3(blocks), dim3(256), 0, stream_, a);
     else if (tx_ == 16 && ty_ == 16 && threads_ == 512)
       hipLaunchKernelGGL((k_relax_q<16, 16, 512>), dim3(blocks), dim3(512), 0, stream_, a);

@@ -70,7 +70,9 @@ struct RelaxQArgs {
 };
 
 template <int TX, int TY, int NT, bool PAGED = false>
-__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs a) {
+__global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2)) void k_relax_q(RelaxQArgs a) {
+  // 4 waves per SIMD (128 VGPRs): one 1024-thread work-group per CU, or two 512-thread work-groups on 8x8x32 tiles
+  constexpr bool LOWREG = NT >= 1024 || NT * 4 >= TX * TY * 32;
   constexpr int TZ = 32, H = 2;
   constexpr int RX = TX + 2 * H, RY = TY + 2 * H, RZ = TZ + 2 * H;
   constexpr int RSIZE = RX * RY * RZ;
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       }                                                     \
     }                                                       \
   }
-            if (NT >= 1024) {
+            if (LOWREG) {
               vox_t un[12];
               {
                 int q = 0;
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void k_relax_q(RelaxQArgs
       __hip_atomic_fetch_or(&Fn[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    \
     }                                                                                                        \
   }
-        if (NT >= 1024) {  // 128-VGPR budget: four batches of 6 filter reads
+        if (LOWREG) {  // 128-VGPR budget: four batches of 6 filter reads
           uint32_t dnv[6];
 #define FIESTA_BATCH(ST)  \
   {                       \
