@@ -213,13 +213,74 @@ __global__ void k_seed_insert(Geom g, TileGrid tg, const uint32_t *ins, int64_t 
 // of the 4-byte state (the obstacle's occupancy bit is an L2-resident gather: neighbouring voxels point
 // at the same obstacle). Such a voxel is reset to "no obstacle" and tagged as frontier seed; its re-seed
 // from the neighbourhood (:308-321) is simply its first pull in k_relax.
+// Largest finite d^2 currently stored (one pass over the grid when distance tracking is switched on).
+__global__ void k_maxd2_scan(Geom g, const vox_t *coc, unsigned long long *counters) {
+  __shared__ uint32_t blk;
+  if (threadIdx.x == 0) blk = 0;
+  __syncthreads();
+  uint32_t mx = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const vox_t w = coc[i];
+    if (w & kNoCoc) continue;
+    const int z = (int)(i % g.nz), y = (int)((i / g.nz) % g.ny), x = (int)(i / ((int64_t)g.nz * g.ny));
+    mx = max(mx, (uint32_t)dist2(x + g.gx0, y + g.gy0, z + g.gz0, w & ~kAct));
+  }
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(&blk, mx);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk) atomicMax(&counters[C_MAXD2], (unsigned long long)blk);
+}
+
+// Bounding box of the delete queue (ONE work-group: a few thousand entries at most per update in practice).
+__global__ __launch_bounds__(1024) void k_del_bbox(Geom g, const uint32_t *del, int64_t n, unsigned long long *counters) {
+  __shared__ int lo[3], hi[3];
+  if (threadIdx.x < 3) lo[threadIdx.x] = 0x7FFFFFFF, hi[threadIdx.x] = -1;
+  __syncthreads();
+  int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, mx[3] = {-1, -1, -1};
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t idx = del[i];
+    const int c[3] = {(int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny)), (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny),
+                      (int)(idx % (uint32_t)g.nz)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mn[k] = min(mn[k], c[k]), mx[k] = max(mx[k], c[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[k] = min(mn[k], __shfl_xor(mn[k], off));
+      mx[k] = max(mx[k], __shfl_xor(mx[k], off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&lo[k], mn[k]);
+      atomicMax(&hi[k], mx[k]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    counters[C_DBOX0 + threadIdx.x] = (unsigned long long)(long long)lo[threadIdx.x];
+    counters[C_DBOX0 + 3 + threadIdx.x] = (unsigned long long)(long long)hi[threadIdx.x];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits,
                                                     const uint32_t *gocc, uint32_t *flag, uint32_t *list,
-                                                    unsigned long long *count, unsigned long long *counters) {
+                                                    unsigned long long *count, unsigned long long *counters, int bounded) {
   // one wave per z-row, 16-byte loads: a lane owns 4 consecutive voxels (256 voxels = 1 KiB per wave step), so the
   // four obstacle-occupancy gathers of a lane are independent instead of one dependent load -> gather -> store chain
   // per voxel. Row and tile arithmetic is wave-uniform 32-bit math. (nz % 4 != 0: the same loop with scalar loads.)
-  const uint32_t nrows = (uint32_t)g.nx * (uint32_t)g.ny;
+  // bounded: a voxel whose closest obstacle was deleted lies within max-stored-distance of that obstacle, so only the
+  // delete queue's bounding box grown by that radius is scanned (a handful of deletes per depth frame no longer cost a
+  // pass over the whole grid). Both bounds are read from device memory: no host round trip.
+  int bx0 = 0, by0 = 0, bz0 = 0, bx1 = g.nx - 1, by1 = g.ny - 1, bz1 = g.nz - 1;
+  if (bounded) {
+    const int r = (int)ceil(sqrt((double)counters[C_MAXD2])) + 1;
+    bx0 = max(bx0, (int)(long long)counters[C_DBOX0 + 0] - r), bx1 = min(bx1, (int)(long long)counters[C_DBOX0 + 3] + r);
+    by0 = max(by0, (int)(long long)counters[C_DBOX0 + 1] - r), by1 = min(by1, (int)(long long)counters[C_DBOX0 + 4] + r);
+    bz0 = max(bz0, (int)(long long)counters[C_DBOX0 + 2] - r), bz1 = min(bz1, (int)(long long)counters[C_DBOX0 + 5] + r);
+    if (bx0 > bx1 || by0 > by1 || bz0 > bz1) return;
+    bz0 &= ~31;  // whole tiles along z (the lane groups below map to tiles)
+  }
+  const uint32_t nry = (uint32_t)(by1 - by0 + 1), nrows = (uint32_t)(bx1 - bx0 + 1) * nry;
   const int lane = threadIdx.x & 63;
   const bool vec = (g.nz & 3) == 0;
   unsigned long long local = 0;
@@ -230,9 +291,9 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
   const uint32_t per_xcd = (nrows + 7u) / 8u, xcd = blockIdx.x & 7u;
   const uint32_t row_end = min(nrows, (xcd + 1u) * per_xcd);
   for (uint32_t row = xcd * per_xcd + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); row < row_end; row += (gridDim.x >> 3) * 4u) {
-    const int x = (int)(row / (uint32_t)g.ny), y = (int)(row - (uint32_t)x * (uint32_t)g.ny);
-    const int64_t base = (int64_t)row * g.nz;
-    for (int zb = 0; zb < g.nz; zb += 256 * U) {
+    const int x = bx0 + (int)(row / nry), y = by0 + (int)(row % nry);
+    const int64_t base = ((int64_t)x * g.ny + y) * g.nz;
+    for (int zb = bz0; zb <= bz1; zb += 256 * U) {
       vox_t w[U][4];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -786,6 +847,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   pp_ = ProbParams{0, 0, 0, 0, 0};
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_SPATIAL")) spatial_ = atoi(e);
+  if (const char *e = getenv("FIESTA_HIP_BOUND_SCAN")) bound_scan_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -966,6 +1028,16 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
   return ni != 0 || nd != 0;  // (:270)
 }
 
+// Maps that take many small updates (the ray-cast front end switches this on): keep an upper bound of the stored
+// distances so that the delete drain scans (box of the deleted obstacles) + (that radius) instead of the whole grid.
+// Default work-queue engine on an unsharded map only (ghost cells / remote deletes of a shard are not covered).
+void DenseMap::enable_distance_tracking() {
+  if (track_ || !bound_scan_ || engine_ != 1 || g_.sharded || tx_ != 16 || ty_ != 16 || threads_ == 512) return;
+  hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  track_ = true;
+}
+
 void DenseMap::reset_stats_counters() {
   FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INVALIDATED], 0, (C_COUNT - C_INVALIDATED) * sizeof(unsigned long long),
                                   stream_));
@@ -1040,6 +1112,8 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
       hipLaunchKernelGGL((k_relax_q<8, 8, 256>), dim3(blocks), dim3(256), 0, stream_, a);
     else if (tx_ == 16 && ty_ == 16 && threads_ == 512)
       hipLaunchKernelGGL((k_relax_q<16, 16, 512>), dim3(blocks), dim3(512), 0, stream_, a);
+    else if (tx_ == 16 && ty_ == 16 && track_)
+      hipLaunchKernelGGL((k_relax_q<16, 16, 1024, false, true>), dim3(blocks), dim3(1024), 0, stream_, a);
     else if (tx_ == 16 && ty_ == 16)
       hipLaunchKernelGGL((k_relax_q<16, 16, 1024>), dim3(blocks), dim3(1024), 0, stream_, a);
     else
@@ -1125,9 +1199,16 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     FIESTA_HIP_CHECK(hipGetLastError());
   }
   if (nd || remote_del) {
+    // the scan is bounded by (delete queue's box) + (largest stored distance) where that bound is tracked
+    // (enable_distance_tracking)
+    const int bounded = (track_ && nd) ? 1 : 0;
+    if (bounded) {
+      hipLaunchKernelGGL(k_del_bbox, dim3(1), dim3(1024), 0, stream_, g_, (const uint32_t *)del_.p, (int64_t)nd, counters_);
+      FIESTA_HIP_CHECK(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_invalidate, dim3((grid_for(g_.n / 16 + 1, 256, 4096) + 7) / 8 * 8), dim3(256), 0, stream_, g_, tg, coc_,
                        (const uint32_t *)occbits_, (const uint32_t *)gocc_, tile_flag_[0], tile_list_[0],
-                       &counters_[C_LIST0], counters_);
+                       &counters_[C_LIST0], counters_, bounded);
     FIESTA_HIP_CHECK(hipGetLastError());
   }
   zero_counter(C_INSERT);
@@ -1375,6 +1456,11 @@ void DenseMap::snapshot_restore(int slot) {
   FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
   touched_upper_ = (int64_t)nt;
   g_ = s.g;
+  if (track_) {  // the snapshot may predate the tracking: recompute the distance bound for the restored field
+    zero_counter(C_MAXD2);
+    hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 

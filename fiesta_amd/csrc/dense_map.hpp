@@ -40,6 +40,9 @@ enum Counter {
   C_TOUCHED = 0,   // length of the touched-voxel list (the reference's occupancy_queue_)
   C_INSERT,        // insert_queue_
   C_DELETE,        // delete_queue_
+  C_MAXD2,         // upper bound of every finite d^2 the work-queue engine ever stored (bounds the delete scan)
+  C_DBOX0,         // bounding box of the pending delete queue, local voxel coordinates: min x,y,z then max x,y,z
+  C_DBOX5 = C_DBOX0 + 5,
   C_LIST0,         // active-tile list, even rounds
   C_LIST1,         // active-tile list, odd rounds
   C_INVALIDATED,   // stats
@@ -138,6 +141,7 @@ class DenseMap {
   void ensure_touched_capacity(int64_t extra);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list);
   void reset_stats_counters();
+  void enable_distance_tracking();
   void collect_stats(fiesta_hip_stats *st);
 
   Geom g_;
@@ -168,6 +172,8 @@ class DenseMap {
   uint32_t *cstamp_[2] = {nullptr, nullptr};    // per tile: serial of the round that wrote cbits_[parity]
   int prof_ = 0;
   int spatial_blocks_ = 1024;  // work-groups of the spatial walk (multiple of 8: one stream of tiles per XCD)
+  bool track_ = false;  // C_MAXD2 is maintained (enable_distance_tracking)
+  int bound_scan_ = 1;  // bound the delete scan by the delete queue's box + the largest stored distance (FIESTA_HIP_BOUND_SCAN=0: whole grid)
   int spatial_ = 1;  // walk the tiles in XCD-chunked spatial order (FIESTA_HIP_SPATIAL=0: compact list order)
   uint32_t serial_ = 0;                         // relaxation rounds launched so far (all updates)
   uint32_t *tile_flag_[2] = {nullptr, nullptr};

@@ -297,6 +297,7 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
   }
   RaycastState &rc = *rc_;
   const Geom &g = g_;
+  enable_distance_tracking();  // depth frames = many small deltas: bound the delete scans from now on
   // a ray of length <= max_ray_length crosses at most |dx|+|dy|+|dz|+1 voxels
   const int per_axis = (int)std::ceil(p->max_ray_length / g.res) + 2;
   const int stride = std::min(kMaxRayVoxels + 1, 3 * per_axis + 2);

@@ -69,7 +69,9 @@ struct RelaxQArgs {
   const int32_t *dir;
 };
 
-template <int TX, int TY, int NT, bool PAGED = false>
+// TRACK: also maintain counters[C_MAXD2], an upper bound of every finite d^2 stored (bounds the delete scan of maps that
+// take many small updates, see k_invalidate; a separate instance so that the default code stays as it is).
+template <int TX, int TY, int NT, bool PAGED = false, bool TRACK = false>
 __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2)) void k_relax_q(RelaxQArgs a) {
   // 4 waves per SIMD (128 VGPRs): one 1024-thread work-group per CU, or two 512-thread work-groups on 8x8x32 tiles
   constexpr bool LOWREG = NT >= 1024 || NT * 4 >= TX * TY * 32;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
   const uint32_t ntiles = (uint32_t)(a.tg.ntx * a.tg.nty * a.tg.ntz);
   // statistics are summed per work-group and flushed once after the walk (tens of thousands of visits would
   // otherwise queue their atomics on three hot addresses)
-  uint32_t acc_writes = 0, acc_levels = 0, acc_visits = 0;
+  uint32_t acc_writes = 0, acc_levels = 0, acc_visits = 0, acc_maxd2 = 0;
   for (uint32_t it = 0;; ++it) {
     uint32_t t;
     if (PAGED || a.spatial == 0) {
@@ -572,9 +574,11 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
       const int ri = ((lx + H) * RY + (ly + H)) * RZ + (lz + H);
       const bool e = (E[ri >> 5] >> (ri & 31)) & 1u;
       if (e) {
-        const vox_t w = KW(2 * ri) & ~kAct;
+        const unsigned long long kfin = K64(ri);  // (one 8-byte read: the d^2 half feeds the distance bound below)
+        const vox_t w = (vox_t)kfin & ~kAct;
         a.coc[PAGED ? (int64_t)nb_page[13] * PAGE_VOX + (lx * TY + ly) * TZ + lz : g.idx(x, y, z)] = w;
         ++nwrites;
+        if (TRACK && !(w & kNoCoc)) acc_maxd2 = max(acc_maxd2, (uint32_t)(kfin >> 32));
         // Which neighbour tiles can this voxel's change reach through the 24-direction stencil (radius 2)?
         // Faces: within 2 of the face (the +-1 and +-2 axis steps). Edges: within 1 of both faces (the +-1,+-1
         // diagonals). Corners: never (the stencil has no 3-axis diagonals, include/parameters.h:54-68).
@@ -644,6 +648,10 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
   }
   for (int off = 32; off > 0; off >>= 1) acc_writes += __shfl_down(acc_writes, off);
   if (lane == 0 && acc_writes) atomicAdd(&a.counters[C_WRITES], (unsigned long long)acc_writes);
+  if (TRACK) {  // largest d^2 ever stored: bounds the delete scan (k_invalidate); rises rarely, so test before the atomic
+    for (int off = 32; off > 0; off >>= 1) acc_maxd2 = max(acc_maxd2, (uint32_t)__shfl_xor((int)acc_maxd2, off));
+    if (lane == 0 && (unsigned long long)acc_maxd2 > a.counters[C_MAXD2]) atomicMax(&a.counters[C_MAXD2], (unsigned long long)acc_maxd2);
+  }
   if (tid == 0 && acc_visits) {
     atomicAdd(&a.counters[C_SWEEPS], (unsigned long long)acc_levels);
     atomicAdd(&a.counters[C_VISITS], (unsigned long long)acc_visits);
