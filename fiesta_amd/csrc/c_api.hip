@@ -189,14 +189,17 @@ int fiesta_hip_raycast_frame(fiesta_hip_map *m, const float *points, int64_t n, 
     if (m->dense)
       m->dense->raycast_frame(points, n, T, origin, p, false);
     else
-      m->hash->raycast_frame(points, n, T, origin, p);
+      m->hash->raycast_frame(points, n, T, origin, p, false);
   });
 }
 int fiesta_hip_raycast_frame_dev(fiesta_hip_map *m, const float *points_dev, int64_t n, const double T[16],
                                  const double origin[3], const fiesta_hip_raycast_params *p) {
   return guarded([&] {
     need(m && (n == 0 || points_dev) && T && origin && p && n >= 0, "bad argument");
-    dense(m, "raycast_frame_dev").raycast_frame(points_dev, n, T, origin, p, true);
+    if (m->dense)
+      m->dense->raycast_frame(points_dev, n, T, origin, p, true);
+    else
+      m->hash->raycast_frame(points_dev, n, T, origin, p, true);
   });
 }
 int fiesta_hip_raycast_depth(fiesta_hip_map *m, const uint16_t *depth, int32_t rows, int32_t cols, double fx,
@@ -204,7 +207,10 @@ int fiesta_hip_raycast_depth(fiesta_hip_map *m, const uint16_t *depth, int32_t r
                              const fiesta_hip_raycast_params *p) {
   return guarded([&] {
     need(m && depth && rows > 0 && cols > 0 && T && origin && p, "bad argument");
-    dense(m, "raycast_depth").raycast_depth(depth, rows, cols, fx, fy, cx, cy, T, origin, p);
+    if (m->dense)
+      m->dense->raycast_depth(depth, rows, cols, fx, fy, cx, cy, T, origin, p);
+    else
+      m->hash->raycast_depth(depth, rows, cols, fx, fy, cx, cy, T, origin, p);
   });
 }
 int fiesta_hip_raycast_single(const double start[3], const double end[3], const double minv[3],
@@ -297,7 +303,13 @@ int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint
   return guarded([&] { dense(m, "download_field").download_field(d2, coc, occ, logodds); });
 }
 int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num_miss) {
-  return guarded([&] { dense(m, "download_counts").download_counts(num_hit, num_miss); });
+  return guarded([&] {
+    need(m != nullptr, "null map");
+    if (m->dense)
+      m->dense->download_counts(num_hit, num_miss);
+    else
+      m->hash->download_counts(num_hit, num_miss);
+  });
 }
 int fiesta_hip_get_occupied_voxels(fiesta_hip_map *m, int32_t *vox, int64_t capacity, int64_t *n_out) {
   return guarded([&] {

@@ -8,6 +8,8 @@
 //   GetDistance / GetDistWithGradTrilinear / GetOccupancy :452-540           -> k_h_query_*
 #include "hash_map.hpp"
 
+#include <vector>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -401,6 +403,7 @@ HashMap::HashMap(const fiesta_hip_config &cfg) {
 HashMap::~HashMap() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  free_raycast_state();
   void *ptrs[] = {dir_, need_, tile_epoch_, cstamp_[0], cstamp_[1], tile_flag_[0], tile_flag_[1], tile_list_[0], tile_list_[1], counters_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -799,6 +802,20 @@ int64_t HashMap::download(int32_t *vox, int32_t *d2, int32_t *coc, uint8_t *occ)
   if (occ) FIESTA_HIP_CHECK(hipMemcpyAsync(occ, doc, n, hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   return n;
+}
+
+// pending (num_hit_, num_miss_) of every voxel of every allocated page, in the order of download()
+void HashMap::download_counts(int32_t *num_hit, int32_t *num_miss) {
+  use_device();
+  const int64_t n = npages_ * kPageVox;
+  if (n == 0) return;
+  std::vector<unsigned long long> h((size_t)n);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(h.data(), cnt_.p, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (int64_t i = 0; i < n; ++i) {
+    if (num_hit) num_hit[i] = (int32_t)(h[i] >> 32);
+    if (num_miss) num_miss[i] = (int32_t)(uint32_t)h[i];
+  }
 }
 
 void HashMap::synchronize() {

@@ -38,9 +38,11 @@ class HashMap {
   void snapshot_save();                                             // copy of the state words (benchmark unit only)
   int64_t snapshot_count_updated();
   void observe_pos(const double *pos, const int32_t *occ, int64_t n, int32_t *ret);
-  void raycast_frame(const float *, int64_t, const double *, const double *, const fiesta_hip_raycast_params *) {
-    throw Error(FIESTA_HIP_ERR_INVALID, "raycast_frame: array-mode maps only in this build");
-  }
+  // ray-cast front end (raycast.hip): points are host or device (dev) n x 3 floats / a host uint16 depth image
+  void raycast_frame(const float *points, int64_t n, const double *T, const double *origin, const fiesta_hip_raycast_params *p,
+                     bool dev);
+  void raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy, const double *T,
+                     const double *origin, const fiesta_hip_raycast_params *p);
   bool check_update();
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
   void update_esdf(fiesta_hip_stats *st);
@@ -51,6 +53,7 @@ class HashMap {
   void get_occupancy_pos(const double *pos, int64_t n, int32_t *out);
   // every voxel of every allocated page, page order: vox (map voxel coordinates), d2, coc, occ; returns the count
   int64_t download(int32_t *vox, int32_t *d2, int32_t *coc, uint8_t *occ);
+  void download_counts(int32_t *num_hit, int32_t *num_miss);  // same order as download()
   void synchronize();
 
  private:
@@ -60,6 +63,9 @@ class HashMap {
   unsigned long long read_counter(int which);
   void zero_counter(int which);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count);
+  void free_raycast_state();
+  struct RaycastState;
+  RaycastState *rc_ = nullptr;
 
   Geom g_;  // the virtual window as a "grid": nx = ny = nz = 1024, coordinates offset by kHalf
   ProbParams pp_{0, 0, 0, 0, 0};

@@ -102,11 +102,29 @@ __device__ inline void count_observation(int64_t idx, int occ, unsigned long lon
   wave_append((uint32_t)old == 0, (uint32_t)idx, touched, &counters[C_TOUCHED]);
 }
 
+// ---- paged (hash-block) maps: window coordinates (map voxel + 512 per axis), pool address through the directory ----
+namespace paged {
+constexpr int kWin = HashMap::kWin, kHalf = HashMap::kHalf, kNTY = HashMap::kNTY, kNTZ = HashMap::kNTZ, kPageVox = HashMap::kPageVox;
+__device__ inline int tile_id(int x, int y, int z) { return ((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5); }
+__device__ inline bool in_win(int x, int y, int z) {
+  return (unsigned)x < (unsigned)kWin && (unsigned)y < (unsigned)kWin && (unsigned)z < (unsigned)kWin;
+}
+__device__ inline int64_t vaddr(const int32_t *dir, int x, int y, int z) {
+  const int32_t p = dir[tile_id(x, y, z)];
+  return p < 0 ? -1 : (int64_t)p * kPageVox + (((x & 15) * 16 + (y & 15)) * 32 + (z & 31));
+}
+}  // namespace paged
+
 // flags: bit0 valid ray, bit1 casts (winner of its end-point voxel), bit2 traversal overflow
+// PAGED: a voxel's slot in the page pool is only known once its page exists, so this pass stores packed WINDOW
+// coordinates instead of slots (end_idx: coords | occ << 30), marks the tiles it touches (the reference's Vox2Idx
+// allocates on every SetOccupancy, in or out of the update window, src/ESDFMap.cpp:418-421,732-765) and leaves the
+// counting and stamping of the end points to k_ray_translate, after the pages have been allocated.
+template <bool PAGED>
 __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, int stride, uint32_t *entries,
                               int32_t *end_idx, int32_t *m_count, uint8_t *flags, uint32_t *stamp_occ,
                               uint32_t tagged, unsigned long long *cnt, uint32_t *touched,
-                              unsigned long long *counters, int *err) {
+                              unsigned long long *counters, int *err, uint32_t *need) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   flags[i] = 0;
@@ -127,7 +145,14 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
   }
   // SetOccupancy(point, occ) (src/ESDFMap.cpp:401-437); every valid point counts its end point
   int eidx = -1;
-  if (ray_pos_in_map(g, q)) {
+  if (PAGED) {  // PosInMap is always true for the hash build (:46-48); the virtual window is the map
+    const int x = (int)floor((q[0] - g.org[0]) / g.res) + paged::kHalf, y = (int)floor((q[1] - g.org[1]) / g.res) + paged::kHalf,
+              z = (int)floor((q[2] - g.org[2]) / g.res) + paged::kHalf;
+    if (paged::in_win(x, y, z)) {
+      eidx = (int)(pack_coc(x, y, z) | ((uint32_t)occ << 30));
+      need[paged::tile_id(x, y, z)] = 1u;
+    }
+  } else if (ray_pos_in_map(g, q)) {
     const int x = (int)floor((q[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((q[1] - g.org[1]) / g.res) - g.gy0,
               z = (int)floor((q[2] - g.org[2]) / g.res) - g.gz0;
     if (g.in_grid(x, y, z)) {
@@ -136,7 +161,7 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
     }
   }
   end_idx[i] = eidx;
-  if (ra.dedup && eidx >= 0) atomicMin(&stamp_occ[eidx], tagged | (uint32_t)i);  // set_occ_ (:221-232)
+  if (!PAGED && ra.dedup && eidx >= 0) atomicMin(&stamp_occ[eidx], tagged | (uint32_t)i);  // set_occ_ (:221-232)
   // Raycast(origin/res, point/res, l_cornor/res, r_cornor/res) (:233-237)
   double a[3], b[3], lo[3], hi[3];
   for (int k = 0; k < 3; ++k) {
@@ -156,13 +181,22 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
     const double e0 = c[0] - ra.o[0], e1 = c[1] - ra.o[1], e2 = c[2] - ra.o[2];
     const double l2 = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
     uint32_t code = kCodeSkip;
-    if (l2 < ra.minr)
+    if (l2 < ra.minr) {
       code = kCodeMinBreak;
-    else if (!(l2 > ra.maxr) && ray_pos_in_map(g, c)) {
-      const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
-                z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
-      if (g.in_grid(x, y, z))
-        code = (uint32_t)g.idx(x, y, z) | ((g.in_window(x, y, z) && g.owned(x, y, z)) ? 0u : kCodeNoCount);
+    } else if (!(l2 > ra.maxr)) {
+      if (PAGED) {
+        const int x = (int)floor((c[0] - g.org[0]) / g.res) + paged::kHalf, y = (int)floor((c[1] - g.org[1]) / g.res) + paged::kHalf,
+                  z = (int)floor((c[2] - g.org[2]) / g.res) + paged::kHalf;
+        if (paged::in_win(x, y, z)) {
+          code = pack_coc(x, y, z) | (g.in_window(x, y, z) ? 0u : kCodeNoCount);
+          need[paged::tile_id(x, y, z)] = 1u;
+        }
+      } else if (ray_pos_in_map(g, c)) {
+        const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
+                  z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
+        if (g.in_grid(x, y, z))
+          code = (uint32_t)g.idx(x, y, z) | ((g.in_window(x, y, z) && g.owned(x, y, z)) ? 0u : kCodeNoCount);
+      }
     }
     entries[(int64_t)k * n + i] = code;
   });
@@ -173,6 +207,33 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
   }
   m_count[i] = m;
   flags[i] = 1;
+}
+
+// PAGED, after the pages exist: window coordinates -> pool slots (end points and walk entries), and the end-point part
+// of k_ray_prepare (count the observation, stamp set_occ_).
+__global__ void k_ray_translate(Geom g, const int32_t *dir, int64_t n, int dedup, uint32_t *entries, int32_t *end_idx,
+                                const int32_t *m_count, const uint8_t *flags, uint32_t *stamp_occ, uint32_t tagged,
+                                unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t e = end_idx[i];
+  if (e >= 0) {
+    int x, y, z;
+    unpack_coc((vox_t)e & kCodeIdxMask, x, y, z);
+    const int64_t addr = paged::vaddr(dir, x, y, z);
+    end_idx[i] = (int32_t)addr;
+    if (g.in_window(x, y, z)) count_observation(addr, (e >> 30) & 1, cnt, touched, counters);
+    if (dedup) atomicMin(&stamp_occ[addr], tagged | (uint32_t)i);
+  }
+  if (!(flags[i] & 1)) return;
+  const int m = m_count[i];
+  for (int k = 0; k < m; ++k) {
+    const uint32_t code = entries[(int64_t)k * n + i];
+    if (code == kCodeSkip || code == kCodeMinBreak) continue;
+    int x, y, z;
+    unpack_coc(code & kCodeIdxMask, x, y, z);
+    entries[(int64_t)k * n + i] = (uint32_t)paged::vaddr(dir, x, y, z) | (code & kCodeNoCount);
+  }
 }
 
 __global__ void k_ray_winner(int64_t n, int dedup, const int32_t *end_idx, const int32_t *m_count, uint8_t *flags,
@@ -255,84 +316,89 @@ __global__ void k_raycast_one(const double *io, double *out, int cap, int *n_out
 }
 
 // =====================================================================================================
-struct DenseMap::RaycastState {
+// host side, shared by the dense-array and the paged map
+struct RayState {
   DevBuf<uint32_t> entries;
   DevBuf<int32_t> end_idx, m_count, last_k;
   DevBuf<uint8_t> flags;
   DevBuf<float> points;
   DevBuf<uint16_t> depth;
   uint32_t *stamp_occ = nullptr, *fa = nullptr, *fb = nullptr;
+  size_t stamp_words = 0;
   int ibits = 0;
   uint32_t tag = 0;
   static constexpr int kMaxRounds = 240, kFlagInts = kMaxRounds + 8;
   int *d_flags = nullptr;  // [0] unused, [1] error, [2 + it] "round it changed something"
   int *h_flags = nullptr;
   int64_t last_iterations = 0;
+  RayState() {
+    FIESTA_HIP_CHECK(hipMalloc((void **)&d_flags, kFlagInts * sizeof(int)));
+    FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_flags, kFlagInts * sizeof(int)));
+  }
+  ~RayState() {
+    if (stamp_occ) (void)hipFree(stamp_occ);
+    if (fa) (void)hipFree(fa);
+    if (fb) (void)hipFree(fb);
+    if (d_flags) (void)hipFree(d_flags);
+    if (h_flags) (void)hipHostFree(h_flags);
+  }
 };
+struct DenseMap::RaycastState : RayState {};
+struct HashMap::RaycastState : RayState {};
 
 void DenseMap::free_raycast_state() {
-  if (!rc_) return;
-  if (rc_->stamp_occ) (void)hipFree(rc_->stamp_occ);
-  if (rc_->fa) (void)hipFree(rc_->fa);
-  if (rc_->fb) (void)hipFree(rc_->fb);
-  if (rc_->d_flags) (void)hipFree(rc_->d_flags);
-  if (rc_->h_flags) (void)hipHostFree(rc_->h_flags);
+  delete rc_;
+  rc_ = nullptr;
+}
+void HashMap::free_raycast_state() {
   delete rc_;
   rc_ = nullptr;
 }
 
 static inline int rgrid(int64_t n) { return (int)std::max<int64_t>(1, (n + 255) / 256); }
 
-void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, const double *origin,
-                             const fiesta_hip_raycast_params *p, bool dev) {
-  use_device();
-  if (n <= 0) return;
+// per-ray buffers of one frame; returns the row stride of `entries`
+static int ray_frame_buffers(RayState &rc, double res, int64_t n, const fiesta_hip_raycast_params *p, hipStream_t stream) {
   if (n >= (1ll << 26)) throw Error(FIESTA_HIP_ERR_INVALID, "more than 2^26 points in one frame");
-  if (!(p->max_ray_length > 0) || !(p->min_ray_length >= 0))
-    throw Error(FIESTA_HIP_ERR_INVALID, "bad ray length window");
-  if (!rc_) {
-    rc_ = new RaycastState;
-    FIESTA_HIP_CHECK(hipMalloc((void **)&rc_->d_flags, RaycastState::kFlagInts * sizeof(int)));
-    FIESTA_HIP_CHECK(hipHostMalloc((void **)&rc_->h_flags, RaycastState::kFlagInts * sizeof(int)));
-  }
-  RaycastState &rc = *rc_;
-  const Geom &g = g_;
-  enable_distance_tracking();  // depth frames = many small deltas: bound the delete scans from now on
+  if (!(p->max_ray_length > 0) || !(p->min_ray_length >= 0)) throw Error(FIESTA_HIP_ERR_INVALID, "bad ray length window");
   // a ray of length <= max_ray_length crosses at most |dx|+|dy|+|dz|+1 voxels
-  const int per_axis = (int)std::ceil(p->max_ray_length / g.res) + 2;
+  const int per_axis = (int)std::ceil(p->max_ray_length / res) + 2;
   const int stride = std::min(kMaxRayVoxels + 1, 3 * per_axis + 2);
-  rc.entries.ensure((size_t)stride * n, stream_);
-  rc.end_idx.ensure(n, stream_);
-  rc.m_count.ensure(n, stream_);
-  rc.last_k.ensure(n, stream_);
-  rc.flags.ensure(n, stream_);
-  const float *dpts = points;
-  if (!dev) {
-    rc.points.ensure(3 * n, stream_);
-    FIESTA_HIP_CHECK(hipMemcpyAsync(rc.points.p, points, 3 * n * sizeof(float), hipMemcpyHostToDevice, stream_));
-    dpts = rc.points.p;
-  }
-  const int dedup = p->dedup ? 1 : 0;
-  // tagged per-frame stamps (set_occ_/set_free_): value = tag << ibits | ray index, newer tags are smaller
+  rc.entries.ensure((size_t)stride * n, stream);
+  rc.end_idx.ensure(n, stream);
+  rc.m_count.ensure(n, stream);
+  rc.last_k.ensure(n, stream);
+  rc.flags.ensure(n, stream);
+  return stride;
+}
+
+// tagged per-frame stamps (set_occ_/set_free_): value = tag << ibits | ray index, newer tags are smaller. `words` = the
+// number of voxel slots (grid size, or the capacity of the page pool). A frame uses one tag for the end points and
+// one per fixed-point round; the three arrays are cleared only when the tag space is about to run out (every few
+// hundred frames), when the ray-index width changes, or when they had to grow.
+static int ray_stamps(RayState &rc, size_t words, int64_t n, hipStream_t stream) {
   int ibits = 20;
   while ((1ll << ibits) < n) ++ibits;
-  if (dedup) {
-    const bool fresh = rc.stamp_occ == nullptr;
-    if (fresh) {
-      FIESTA_HIP_CHECK(hipMalloc((void **)&rc.stamp_occ, g.n * sizeof(uint32_t)));
-      FIESTA_HIP_CHECK(hipMalloc((void **)&rc.fa, g.n * sizeof(uint32_t)));
-      FIESTA_HIP_CHECK(hipMalloc((void **)&rc.fb, g.n * sizeof(uint32_t)));
+  bool fresh = false;
+  if (rc.stamp_words < words) {
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
+    for (uint32_t **q : {&rc.stamp_occ, &rc.fa, &rc.fb}) {
+      if (*q) (void)hipFree(*q);
+      *q = nullptr;
+      FIESTA_HIP_CHECK(hipMalloc((void **)q, words * sizeof(uint32_t)));
     }
-    // a frame uses one tag for the end points and one per fixed-point round; clear the stamp arrays (3 whole-grid
-    // memsets) only when the tag space is about to run out, i.e. every few hundred frames
-    if (fresh || ibits != rc.ibits || rc.tag < (uint32_t)RaycastState::kMaxRounds + 16u) {
-      FIESTA_HIP_CHECK(hipMemsetAsync(rc.stamp_occ, 0xFF, g.n * sizeof(uint32_t), stream_));
-      FIESTA_HIP_CHECK(hipMemsetAsync(rc.fa, 0xFF, g.n * sizeof(uint32_t), stream_));
-      FIESTA_HIP_CHECK(hipMemsetAsync(rc.fb, 0xFF, g.n * sizeof(uint32_t), stream_));
-      rc.ibits = ibits;
-      rc.tag = (0xFFFFFFFFu >> ibits) - 1u;
-    }
+    rc.stamp_words = words;
+    fresh = true;
   }
+  if (fresh || ibits != rc.ibits || rc.tag < (uint32_t)RayState::kMaxRounds + 16u) {
+    for (uint32_t *q : {rc.stamp_occ, rc.fa, rc.fb}) FIESTA_HIP_CHECK(hipMemsetAsync(q, 0xFF, rc.stamp_words * sizeof(uint32_t), stream));
+    rc.ibits = ibits;
+    rc.tag = (0xFFFFFFFFu >> ibits) - 1u;
+  }
+  return ibits;
+}
+
+static RayArgs ray_args(const double *T, const double *origin, const fiesta_hip_raycast_params *p) {
   RayArgs ra;
   memcpy(ra.T, T, sizeof(ra.T));
   for (int k = 0; k < 3; ++k) {
@@ -342,22 +408,21 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
   }
   ra.minr = p->min_ray_length;
   ra.maxr = p->max_ray_length;
-  ra.dedup = dedup;
-  // worst case every ray touches `stride` new voxels
-  ensure_touched_capacity(std::min<int64_t>(g.n, n * (int64_t)(stride + 1)));
-  FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, RaycastState::kFlagInts * sizeof(int), stream_));
-  const uint32_t tag_occ = dedup ? rc.tag-- : 0;
-  hipLaunchKernelGGL(k_ray_prepare, dim3(rgrid(n)), dim3(256), 0, stream_, g, ra, dpts, n, stride, rc.entries.p,
-                     rc.end_idx.p, rc.m_count.p, rc.flags.p, rc.stamp_occ, dedup ? (tag_occ << ibits) : 0u, cnt_,
-                     touched_.p, counters_, rc.d_flags + 1);
-  FIESTA_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_ray_winner, dim3(rgrid(n)), dim3(256), 0, stream_, n, dedup, (const int32_t *)rc.end_idx.p,
+  ra.dedup = p->dedup ? 1 : 0;
+  return ra;
+}
+
+// winners of the end-point voxels, the free-space fixed point, the counters; slots in `entries` / `end_idx` index
+// cnt[], the stamp arrays and the touched list
+static void ray_rounds(RayState &rc, int64_t n, int dedup, int ibits, uint32_t tag_occ, unsigned long long *cnt,
+                       uint32_t *touched, unsigned long long *counters, hipStream_t stream) {
+  hipLaunchKernelGGL(k_ray_winner, dim3(rgrid(n)), dim3(256), 0, stream, n, dedup, (const int32_t *)rc.end_idx.p,
                      (const int32_t *)rc.m_count.p, rc.flags.p, (const uint32_t *)rc.stamp_occ,
                      dedup ? (tag_occ << ibits) : 0u, rc.last_k.p);
   FIESTA_HIP_CHECK(hipGetLastError());
   int64_t iters = 0;
   if (!dedup) {
-    hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
+    hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream, n, (const uint32_t *)rc.entries.p,
                        (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, 0, 0,
                        (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u, ibits, rc.d_flags + 2, 1);
     FIESTA_HIP_CHECK(hipGetLastError());
@@ -371,15 +436,15 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
       for (int b = 0; b < kBatch; ++b) {
         const uint32_t tag_next = rc.tag--;
         ++iters;
-        hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
+        hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream, n, (const uint32_t *)rc.entries.p,
                            (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, iters > 1 ? 1 : 0, 1,
                            (const uint32_t *)fprev, tag_prev, fnext, tag_next, ibits, rc.d_flags + 2, (int)iters);
         FIESTA_HIP_CHECK(hipGetLastError());
         std::swap(fprev, fnext);
         tag_prev = tag_next;
       }
-      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, (2 + iters + 1) * sizeof(int), hipMemcpyDeviceToHost, stream_));
-      FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, (2 + iters + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
       if (rc.h_flags[1]) break;
       // stop at the first round (after round 1) that changed nothing
       for (int64_t it = std::max<int64_t>(first, 2); it <= iters; ++it)
@@ -388,36 +453,107 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
           done = true;
           break;
         }
-      if (!done && iters + kBatch > RaycastState::kMaxRounds) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup did not converge");
+      if (!done && iters + kBatch > RayState::kMaxRounds) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup did not converge");
     }
   }
   rc.last_iterations = iters;
-  hipLaunchKernelGGL(k_ray_apply, dim3(rgrid(n)), dim3(256), 0, stream_, n, (const uint32_t *)rc.entries.p,
-                     (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, (const int32_t *)rc.last_k.p, cnt_,
-                     touched_.p, counters_);
+  hipLaunchKernelGGL(k_ray_apply, dim3(rgrid(n)), dim3(256), 0, stream, n, (const uint32_t *)rc.entries.p,
+                     (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, (const int32_t *)rc.last_k.p, cnt,
+                     touched, counters);
   FIESTA_HIP_CHECK(hipGetLastError());
-  FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
   if (rc.h_flags[1])  // the reference throws std::out_of_range("Too many RaycasMultithread voxels")
     throw Error(FIESTA_HIP_ERR_INVALID, "Too many raycast voxels (a ray crosses more than 1500 voxels)");
+}
+
+static const float *ray_points(RayState &rc, const float *points, int64_t n, bool dev, hipStream_t stream) {
+  if (dev) return points;
+  rc.points.ensure(3 * n, stream);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(rc.points.p, points, 3 * n * sizeof(float), hipMemcpyHostToDevice, stream));
+  return rc.points.p;
+}
+
+static const float *ray_depth_points(RayState &rc, const uint16_t *depth, int rows, int cols, double fx, double fy, double cx,
+                                     double cy, hipStream_t stream) {
+  const int64_t n = (int64_t)rows * cols;
+  rc.depth.ensure(n, stream);
+  rc.points.ensure(3 * n, stream);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(rc.depth.p, depth, n * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_depth_points, dim3(rgrid(n)), dim3(256), 0, stream, (const uint16_t *)rc.depth.p, rows, cols, fx, fy, cx,
+                     cy, rc.points.p);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  return rc.points.p;
+}
+
+void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, const double *origin,
+                             const fiesta_hip_raycast_params *p, bool dev) {
+  use_device();
+  if (n <= 0) return;
+  if (!rc_) rc_ = new RaycastState;
+  RaycastState &rc = *rc_;
+  const Geom &g = g_;
+  enable_distance_tracking();  // depth frames = many small deltas: bound the delete scans from now on
+  const int stride = ray_frame_buffers(rc, g.res, n, p, stream_);
+  const float *dpts = ray_points(rc, points, n, dev, stream_);
+  const RayArgs ra = ray_args(T, origin, p);
+  const int ibits = ra.dedup ? ray_stamps(rc, (size_t)g.n, n, stream_) : 20;
+  // worst case every ray touches `stride` new voxels
+  ensure_touched_capacity(std::min<int64_t>(g.n, n * (int64_t)(stride + 1)));
+  FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, RayState::kFlagInts * sizeof(int), stream_));
+  const uint32_t tag_occ = ra.dedup ? rc.tag-- : 0;
+  hipLaunchKernelGGL(k_ray_prepare<false>, dim3(rgrid(n)), dim3(256), 0, stream_, g, ra, dpts, n, stride, rc.entries.p,
+                     rc.end_idx.p, rc.m_count.p, rc.flags.p, rc.stamp_occ, ra.dedup ? (tag_occ << ibits) : 0u, cnt_,
+                     touched_.p, counters_, rc.d_flags + 1, (uint32_t *)nullptr);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  ray_rounds(rc, n, ra.dedup, ibits, tag_occ, cnt_, touched_.p, counters_, stream_);
 }
 
 void DenseMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
                              const double *T, const double *origin, const fiesta_hip_raycast_params *p) {
   use_device();
-  if (!rc_) {
-    rc_ = new RaycastState;
-    FIESTA_HIP_CHECK(hipMalloc((void **)&rc_->d_flags, RaycastState::kFlagInts * sizeof(int)));
-    FIESTA_HIP_CHECK(hipHostMalloc((void **)&rc_->h_flags, RaycastState::kFlagInts * sizeof(int)));
-  }
-  const int64_t n = (int64_t)rows * cols;
-  rc_->depth.ensure(n, stream_);
-  rc_->points.ensure(3 * n, stream_);
-  FIESTA_HIP_CHECK(hipMemcpyAsync(rc_->depth.p, depth, n * sizeof(uint16_t), hipMemcpyHostToDevice, stream_));
-  hipLaunchKernelGGL(k_depth_points, dim3(rgrid(n)), dim3(256), 0, stream_, (const uint16_t *)rc_->depth.p, rows, cols,
-                     fx, fy, cx, cy, rc_->points.p);
+  if (!rc_) rc_ = new RaycastState;
+  const float *pts = ray_depth_points(*rc_, depth, rows, cols, fx, fy, cx, cy, stream_);
+  raycast_frame(pts, (int64_t)rows * cols, T, origin, p, true);
+}
+
+// Paged map: the same frame in three steps -- walk the rays in window coordinates and mark the tiles they touch,
+// allocate the missing pages, translate coordinates to pool slots (+ count / stamp the end points) -- then the common
+// rounds. The stamp arrays cover the pool's capacity and are re-created when the pool grows.
+void HashMap::raycast_frame(const float *points, int64_t n, const double *T, const double *origin,
+                            const fiesta_hip_raycast_params *p, bool dev) {
+  use_device();
+  if (n <= 0) return;
+  if (!rc_) rc_ = new RaycastState;
+  RaycastState &rc = *rc_;
+  const int stride = ray_frame_buffers(rc, g_.res, n, p, stream_);
+  const float *dpts = ray_points(rc, points, n, dev, stream_);
+  const RayArgs ra = ray_args(T, origin, p);
+  FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, RayState::kFlagInts * sizeof(int), stream_));
+  hipLaunchKernelGGL(k_ray_prepare<true>, dim3(rgrid(n)), dim3(256), 0, stream_, g_, ra, dpts, n, stride, rc.entries.p,
+                     rc.end_idx.p, rc.m_count.p, rc.flags.p, (uint32_t *)nullptr, 0u, (unsigned long long *)nullptr,
+                     (uint32_t *)nullptr, (unsigned long long *)nullptr, rc.d_flags + 1, need_);
   FIESTA_HIP_CHECK(hipGetLastError());
-  raycast_frame(rc_->points.p, n, T, origin, p, true);
+  allocate_marked();
+  if ((int64_t)cap_pages_ * kPageVox > (1ll << 30))
+    throw Error(FIESTA_HIP_ERR_INVALID, "ray cast: page pool larger than 2^30 voxels (walk entries hold 30-bit slots)");
+  const int ibits = ra.dedup ? ray_stamps(rc, (size_t)cap_pages_ * kPageVox, n, stream_) : 20;
+  touched_upper_ = std::min<int64_t>(npages_ * kPageVox, touched_upper_ + n * (int64_t)(stride + 1));
+  touched_.ensure((size_t)touched_upper_, stream_, touched_.cap);
+  const uint32_t tag_occ = ra.dedup ? rc.tag-- : 0;
+  hipLaunchKernelGGL(k_ray_translate, dim3(rgrid(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, n, ra.dedup, rc.entries.p,
+                     rc.end_idx.p, (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.stamp_occ,
+                     ra.dedup ? (tag_occ << ibits) : 0u, cnt_.p, touched_.p, counters_);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  ray_rounds(rc, n, ra.dedup, ibits, tag_occ, cnt_.p, touched_.p, counters_, stream_);
+}
+
+void HashMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
+                            const double *T, const double *origin, const fiesta_hip_raycast_params *p) {
+  use_device();
+  if (!rc_) rc_ = new RaycastState;
+  const float *pts = ray_depth_points(*rc_, depth, rows, cols, fx, fy, cx, cy, stream_);
+  raycast_frame(pts, (int64_t)rows * cols, T, origin, p, true);
 }
 
 void raycast_single(const double *start, const double *end, const double *minv, const double *maxv, double *out,

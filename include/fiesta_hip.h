@@ -169,7 +169,8 @@ int fiesta_hip_get_dist_grad_dev(fiesta_hip_map *m, const double *pos_dev, int64
  *   logodds double occupancy_buffer_ */
 int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds);
 /* Pending observation counters num_hit_ / num_miss_ (include/ESDFMap.h:89; num_miss_ counts ALL observations
- * since the last UpdateOccupancy), dense order; each output nullable. */
+ * since the last UpdateOccupancy), dense order (hash-block maps: the order of fiesta_hip_download_hash); each output
+ * nullable. */
 int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num_miss);
 /* Visualisation exports, compacted / sliced on the device (reference: ESDFMap::GetPointCloud and GetSliceMarker,
  * src/ESDFMap.cpp:544-699, which fill ROS messages -- a ROS adapter wraps these two calls).
@@ -182,7 +183,8 @@ int fiesta_hip_get_slice(fiesta_hip_map *m, int32_t z_vox, double *out);
 int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
                              uint8_t *occ);
 
-/* Device-side snapshots of the complete map state (benchmark repetitions, tests). slot in [0,3]. */
+/* Device-side snapshots of the complete map state (benchmark repetitions, tests). slot in [0,3].
+ * Hash-block maps: slot 0 only, save + count_updated only (one copy of the state words; restore is an error). */
 int fiesta_hip_snapshot_save(fiesta_hip_map *m, int32_t slot);
 int fiesta_hip_snapshot_restore(fiesta_hip_map *m, int32_t slot);
 /* Number of voxels whose (d2, closest obstacle) differs between snapshot `slot` and the current state,

@@ -545,7 +545,13 @@ void oracle_dump_dense(oracle_map *m, double *dist, int32_t *coc, uint8_t *occ, 
 }
 void oracle_dump_counts(oracle_map *m, int32_t *num_hit, int32_t *num_miss) {
   Port &p = m->p;
-  if (p.mode != 0) return;
+  if (p.mode != 0) {  // hash mode: the order of oracle_dump_hash
+    for (int64_t k = 0; k < p.count - 1; ++k) {
+      if (num_hit) num_hit[k] = p.hits[k + 1];
+      if (num_miss) num_miss[k] = p.seen[k + 1];
+    }
+    return;
+  }
   for (int64_t i = 0; i < p.total; ++i) {
     if (num_hit) num_hit[i] = p.hits[i];
     if (num_miss) num_miss[i] = p.seen[i];

@@ -222,7 +222,8 @@ class OracleMap:
         return {"dist": dist, "coc": coc, "occ": occ, "logodds": lo}
 
     def dump_counts(self):
-        n = self.grid_total_size
+        """Pending (num_hit_, num_miss_); hash mode: one entry per allocated slot, in the order of dump_hash()."""
+        n = self.grid_total_size if self.mode != "hash" else int(self.lib.oracle_dump_hash(self.h, None, None, None, None))
         hit = np.empty(n, np.int32)
         miss = np.empty(n, np.int32)
         self.lib.oracle_dump_counts(self.h, _p(hit), _p(miss))

@@ -219,8 +219,12 @@ void oracle_dump_counts(oracle_map *m, int32_t *num_hit, int32_t *num_miss) {
     if (num_hit) num_hit[i] = m->map->num_hit_[i];
     if (num_miss) num_miss[i] = m->map->num_miss_[i];
   }
-#else
-  (void)m; (void)num_hit; (void)num_miss;
+#else  // hash build: the order of oracle_dump_hash (slot k+1 of the reference's vectors)
+  fiesta::ESDFMap &e = *m->map;
+  for (int64_t k = 0; k < e.count - 1; ++k) {
+    if (num_hit) num_hit[k] = e.num_hit_[k + 1];
+    if (num_miss) num_miss[k] = e.num_miss_[k + 1];
+  }
 #endif
 }
 

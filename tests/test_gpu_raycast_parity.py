@@ -130,3 +130,55 @@ def test_no_dedup_mode_counts_every_crossing(hip_lib, oracle_libs, best_oracle_k
     assert np.all(m0 >= m1) and np.all(h0 >= h1)
     assert m0.sum() > m1.sum()
     assert np.all((m1 > 0) <= (m0 > 0))
+
+
+def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind):
+    """The same front end on the paged (hash-block) map against the reference built with -DHASH_TABLE: pages are
+    allocated by the rays themselves; per-voxel hit/miss counters of every frame, queues and the ESDF must match voxel
+    by voxel (internal slots differ by design, so everything is keyed by voxel coordinates)."""
+    import fiesta_amd
+    from test_gpu_hash_parity import compare as compare_hash
+    kind = best_oracle_kind if oracle_libs.available(best_oracle_kind, "hash") else "port"
+    origin, res = (0.3, -0.2, 0.1), 0.1
+    gpu = fiesta_amd.ESDFMap(origin, res, reserve_size=1000, mode="hash")
+    cpu = oracle_libs.OracleMap(origin, res, reserve_size=1000, mode="hash", kind=kind)
+    for m in (gpu, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    lc, rc = (-20.0, -20.0, -20.0), (20.0, 20.0, 20.0)      # the hash build's l_cornor/r_cornor only clip the walk
+    spheres = [((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7), ((0.5, -2.0, -0.5), 0.4)]
+    intr = dict(fx=96.1, fy=96.1, cx=80.7, cy=58.9)
+    pos = np.array([0.13, -0.21, 0.05])
+    key = lambda v: (v[:, 0].astype(np.int64) + 100000) * (1 << 40) + (v[:, 1].astype(np.int64) + 100000) * (1 << 20) + v[:, 2] + 100000  # noqa: E731
+    touched_total = 0
+    for f in range(5):
+        T = yaw_pose(25.0 * f, pos + 0.07 * f)
+        depth = render_depth(T, rows=120, cols=160, spheres=spheres, intr=intr)
+        pts = depth_to_points(depth, intr=intr)
+        pts[::397] = np.nan
+        o = T[:3, 3]
+        if f == 3:   # the depth-image entry point on the paged map
+            gpu.RaycastDepth(depth, intr["fx"], intr["fy"], intr["cx"], intr["cy"], T, o, 0.5, 5.0, lc, rc, dedup=1)
+            cpu.raycast_frame(depth_to_points(depth, intr=intr), T, o, 0.5, 5.0, lc, rc)
+        else:
+            gpu.RaycastFrame(pts, T, o, 0.5, 5.0, lc, rc, dedup=1)
+            cpu.raycast_frame(pts, T, o, 0.5, 5.0, lc, rc)
+        # counters, voxel by voxel
+        gh, gm = gpu.download_counts()
+        gv = gpu.download_hash()["vox"]
+        ch, cm = cpu.dump_counts()
+        cv = cpu.dump_hash()["vox"]
+        gk, ck = key(gv), key(cv)
+        gsel, csel = gm > 0, cm > 0
+        og, oc = np.argsort(gk[gsel]), np.argsort(ck[csel])
+        assert np.array_equal(gk[gsel][og], ck[csel][oc]), "different sets of observed voxels"
+        assert np.array_equal(gm[gsel][og], cm[csel][oc]) and np.array_equal(gh[gsel][og], ch[csel][oc])
+        touched_total += int(gsel.sum())
+        assert gpu.CheckUpdate() == cpu.CheckUpdate()
+        a, b = gpu.UpdateOccupancy(True), cpu.UpdateOccupancy(True)
+        assert a == b and (gpu.last_insert, gpu.last_delete) == (cpu.last_insert, cpu.last_delete)
+        sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
+        assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+        rep = compare_hash(gpu, cpu)
+        assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]), rep
+    assert touched_total > 30000 and rep["pages"] >= 8
