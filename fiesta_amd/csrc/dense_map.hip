@@ -847,6 +847,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   pp_ = ProbParams{0, 0, 0, 0, 0};
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_SPATIAL")) spatial_ = atoi(e);
+  if (const char *e = getenv("FIESTA_HIP_LIST_THRESHOLD")) list_threshold_ = std::max(0, atoi(e));
   if (const char *e = getenv("FIESTA_HIP_BOUND_SCAN")) bound_scan_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1076,8 +1077,9 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
   int64_t rounds = 0;
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   serial_ += 2;  // no stamp of an earlier update may validate this update's first round
-  while (ncur && engine_ == 1) {
-    const int nxt = cur ^ 1;
+  // one round of the work-queue engine: active tiles of list/flags `cur_list` -> `cur_list ^ 1`
+  auto launch_q = [&](const int cur_list, const uint32_t n_host, const unsigned long long *n_dev, const int spatial) {
+    const int nxt = cur_list ^ 1;
     zero_counter(C_LIST0 + nxt);
     ++serial_;
     RelaxQArgs a;
@@ -1092,19 +1094,21 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     a.cstamp_prev = cstamp_[(serial_ - 1) & 1];
     a.cstamp_cur = cstamp_[serial_ & 1];
     a.serial = serial_;
-    a.list_cur = tile_list_[cur];
-    a.n_cur = ncur;
-    a.flag_cur = tile_flag_[cur];
+    a.list_cur = tile_list_[cur_list];
+    a.n_cur = n_host;
+    a.n_cur_dev = n_dev;
+    a.flag_cur = tile_flag_[cur_list];
     a.flag_next = tile_flag_[nxt];
     a.list_next = tile_list_[nxt];
     a.count_next = &counters_[C_LIST0 + nxt];
     a.counters = counters_;
     a.prof = prof_;
     a.dir = nullptr;
-    a.spatial = spatial_;
+    a.spatial = spatial;
     // spatial walk: a multiple of 8 blocks (one stream per XCD), a few per CU for load balance
-    const int blocks = spatial_ ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), (uint32_t)spatial_blocks_)
-                                : (int)std::min<uint32_t>(ncur, 16384u);
+    const int blocks = spatial ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), (uint32_t)spatial_blocks_)
+                       : n_dev ? (int)std::min<uint32_t>(16384u, std::max<uint32_t>(256u, 4u * ncur))
+                               : (int)std::min<uint32_t>(n_host, 16384u);
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
     if (tx_ == 8 && ty_ == 8 && threads_ == 512)
       hipLaunchKernelGGL((k_relax_q<8, 8, 512>), dim3(blocks), dim3(512), 0, stream_, a);
@@ -1121,8 +1125,26 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds + 1), stream_));
     ++rounds;
-    ncur = (uint32_t)read_counter(C_LIST0 + nxt);
-    cur = nxt;
+  };
+  while (ncur && engine_ == 1) {
+    const int nxt = cur ^ 1;
+    // Large updates walk all tiles in XCD-chunked spatial order, one round per host round trip. Small ones (few active
+    // tiles: depth frames) use the compact list, and rounds go out in pairs: the second reads the length of its list
+    // on the device and does nothing if the first activated no tile -- half the host round trips.
+    if (spatial_ && ncur >= (uint32_t)list_threshold_) {
+      launch_q(cur, ncur, nullptr, 1);
+      ncur = (uint32_t)read_counter(C_LIST0 + nxt);
+      cur = nxt;
+    } else {
+      launch_q(cur, ncur, nullptr, 0);
+      launch_q(nxt, 0, &counters_[C_LIST0 + nxt], 0);
+      FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_LIST0], &counters_[C_LIST0], 2 * sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, stream_));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+      const uint32_t n1 = (uint32_t)h_counters_[C_LIST0 + nxt], n2 = (uint32_t)h_counters_[C_LIST0 + cur];
+      if (!n1) --rounds;  // the speculative round had nothing to do: not a round (its events are overwritten or ignored)
+      ncur = n1 ? n2 : 0;
+    }
   }
   while (ncur) {
     const int nxt = cur ^ 1;

@@ -174,6 +174,7 @@ class DenseMap {
   int spatial_blocks_ = 1024;  // work-groups of the spatial walk (multiple of 8: one stream of tiles per XCD)
   bool track_ = false;  // C_MAXD2 is maintained (enable_distance_tracking)
   int bound_scan_ = 1;  // bound the delete scan by the delete queue's box + the largest stored distance (FIESTA_HIP_BOUND_SCAN=0: whole grid)
+  int list_threshold_ = 1024;  // updates that start with fewer active tiles use the compact list + paired rounds
   int spatial_ = 1;  // walk the tiles in XCD-chunked spatial order (FIESTA_HIP_SPATIAL=0: compact list order)
   uint32_t serial_ = 0;                         // relaxation rounds launched so far (all updates)
   uint32_t *tile_flag_[2] = {nullptr, nullptr};

@@ -634,8 +634,9 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
   double relax_ms = 0;
   TileGrid tg{kTX, kTY, kNTX, kNTY, kNTZ};
   serial_ += 2;
-  while (ncur) {
-    const int nxt = cur ^ 1;
+  // one round: the active-tile list `cur` (length known to the host, or read on the device) -> list `cur ^ 1`
+  auto launch = [&](const int cur_list, const uint32_t n_host, const unsigned long long *n_dev) {
+    const int nxt = cur_list ^ 1;
     zero_counter(C_LIST0 + nxt);
     ++serial_;
     RelaxQArgs a;
@@ -650,9 +651,10 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
     a.cstamp_prev = cstamp_[(serial_ - 1) & 1];
     a.cstamp_cur = cstamp_[serial_ & 1];
     a.serial = serial_;
-    a.list_cur = tile_list_[cur];
-    a.n_cur = ncur;
-    a.flag_cur = tile_flag_[cur];
+    a.list_cur = tile_list_[cur_list];
+    a.n_cur = n_host;
+    a.n_cur_dev = n_dev;
+    a.flag_cur = tile_flag_[cur_list];
     a.flag_next = tile_flag_[nxt];
     a.list_next = tile_list_[nxt];
     a.count_next = &counters_[C_LIST0 + nxt];
@@ -660,16 +662,28 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
     a.prof = prof_;
     a.dir = dir_;
     a.spatial = 0;
-    FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
-    hipLaunchKernelGGL((k_relax_q<kTX, kTY, 1024, true>), dim3(std::min<uint32_t>(ncur, 16384u)), dim3(1024), 0, stream_, a);
+    const uint32_t blocks = n_dev ? std::min<uint32_t>(16384u, std::max<uint32_t>(256u, 4u * ncur)) : std::min<uint32_t>(n_host, 16384u);
+    hipLaunchKernelGGL((k_relax_q<kTX, kTY, 1024, true>), dim3(blocks), dim3(1024), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
+  };
+  // Rounds go out in pairs: the second is launched before the host knows how many tiles the first activated (it reads
+  // the count on the device and does nothing if it is zero) -- half the host round trips of an update that is a chain
+  // of small rounds.
+  while (ncur) {
+    const int nxt = cur ^ 1;
+    FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+    launch(cur, ncur, nullptr);
+    launch(nxt, 0, &counters_[C_LIST0 + nxt]);
     FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
-    ++rounds;
-    ncur = (uint32_t)read_counter(C_LIST0 + nxt);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_LIST0], &counters_[C_LIST0], 2 * sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    const uint32_t n1 = (uint32_t)h_counters_[C_LIST0 + nxt], n2 = (uint32_t)h_counters_[C_LIST0 + cur];
+    rounds += n1 ? 2 : 1;
+    ncur = n1 ? n2 : 0;  // (after two rounds the lists are back in place)
     float ms = 0;
     FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
     relax_ms += ms;
-    cur = nxt;
   }
   if (st) {
     st->rounds = rounds;

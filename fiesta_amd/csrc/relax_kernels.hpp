@@ -57,6 +57,8 @@ struct RelaxQArgs {
   uint32_t serial;        // serial number of this round; stamps equal to serial-1 validate cbits_prev
   const uint32_t *list_cur;
   uint32_t n_cur;
+  const unsigned long long *n_cur_dev;  // list mode: if set, the length of list_cur is read from here (a round launched
+                                        // before the host knows how many tiles its predecessor activated)
   uint32_t *flag_cur;
   uint32_t *flag_next;
   uint32_t *list_next;
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
   // on XCD b % 8 (observed placement, used for speed only), so tiles that share halo lines meet in one XCD's L2
   // at about the same time instead of each missing to HBM.
   const uint32_t ntiles = (uint32_t)(a.tg.ntx * a.tg.nty * a.tg.ntz);
+  const uint32_t n_list = a.n_cur_dev ? (uint32_t)*a.n_cur_dev : a.n_cur;
   // statistics are summed per work-group and flushed once after the walk (tens of thousands of visits would
   // otherwise queue their atomics on three hot addresses)
   uint32_t acc_writes = 0, acc_levels = 0, acc_visits = 0, acc_maxd2 = 0;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
     uint32_t t;
     if (PAGED || a.spatial == 0) {
       const uint32_t li = blockIdx.x + it * gridDim.x;
-      if (li >= a.n_cur) break;
+      if (li >= n_list) break;
       t = a.list_cur[li];
     } else {
       const uint32_t xcd = blockIdx.x & 7u, v = (blockIdx.x >> 3) + it * (gridDim.x >> 3);
