@@ -265,9 +265,9 @@ __global__ __launch_bounds__(1024) void k_del_bbox(Geom g, const uint32_t *del, 
 __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits,
                                                     const uint32_t *gocc, uint32_t *flag, uint32_t *list,
                                                     unsigned long long *count, unsigned long long *counters, int bounded) {
-  // one wave per z-row, 16-byte loads: a lane owns 4 consecutive voxels (256 voxels = 1 KiB per wave step), so the
-  // four obstacle-occupancy gathers of a lane are independent instead of one dependent load -> gather -> store chain
-  // per voxel. Row and tile arithmetic is wave-uniform 32-bit math. (nz % 4 != 0: the same loop with scalar loads.)
+  // one wave per z-row, 16-byte loads: a lane owns 8 consecutive voxels (512 voxels = 2 KiB per wave step); its
+  // obstacle-occupancy gathers are independent of each other instead of one dependent load -> gather -> store chain per
+  // voxel. Row and tile arithmetic is wave-uniform 32-bit math. (nz % 4 != 0: the same loop with scalar loads.)
   // bounded: a voxel whose closest obstacle was deleted lies within max-stored-distance of that obstacle, so only the
   // delete queue's bounding box grown by that radius is scanned (a handful of deletes per depth frame no longer cost a
   // pass over the whole grid). Both bounds are read from device memory: no host round trip.
@@ -284,63 +284,89 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
   const int lane = threadIdx.x & 63;
   const bool vec = (g.nz & 3) == 0;
   unsigned long long local = 0;
-  constexpr int U = 2;  // 16-byte loads in flight per lane (the scan is latency-bound with one)
+  constexpr int V = 8;  // consecutive voxels per lane: two 16-byte loads in flight, and longer same-obstacle runs per lane
   // XCD-aware row order (work-group b runs on XCD b % 8; used for speed only): every XCD scans one contiguous eighth
   // of the rows, so the slice of the occupancy bitmap its gathers hit (the obstacles NEAR its voxels, ~2 MB of the
   // 16 MB at 512^3) stays in that XCD's 4 MB L2 instead of missing to the fabric.
   const uint32_t per_xcd = (nrows + 7u) / 8u, xcd = blockIdx.x & 7u;
   const uint32_t row_end = min(nrows, (xcd + 1u) * per_xcd);
-  for (uint32_t row = xcd * per_xcd + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); row < row_end; row += (gridDim.x >> 3) * 4u) {
-    const int x = bx0 + (int)(row / nry), y = by0 + (int)(row % nry);
-    const int64_t base = ((int64_t)x * g.ny + y) * g.nz;
-    for (int zb = bz0; zb <= bz1; zb += 256 * U) {
-      vox_t w[U][4];
+  // R rows per wave and step: R * 2 KiB of loads in flight per wave (the scan needs ~16 MB in flight device-wide to
+  // cover the HBM latency at full bandwidth)
+  constexpr int R = 2;
+  const uint32_t rstride = (gridDim.x >> 3) * 4u;
+  for (uint32_t row0 = xcd * per_xcd + (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); row0 < row_end; row0 += R * rstride) {
+    for (int zb = bz0; zb <= bz1; zb += 64 * V) {
+      const int z8 = zb + V * lane;
+      vox_t w[R][V];
+      int xs[R], ys[R];
+      int64_t bases[R];
+      bool live[R];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int z4 = zb + 256 * u + 4 * lane;
-        w[u][0] = w[u][1] = w[u][2] = w[u][3] = kUnobserved;
+      for (int r = 0; r < R; ++r) {
+        const uint32_t row = row0 + r * rstride;
+        live[r] = row < row_end;
+        const uint32_t rr = live[r] ? row : row0;
+        xs[r] = bx0 + (int)(rr / nry), ys[r] = by0 + (int)(rr % nry);
+        bases[r] = ((int64_t)xs[r] * g.ny + ys[r]) * g.nz;
+#pragma unroll
+        for (int k = 0; k < V; ++k) w[r][k] = kUnobserved;
+        if (!live[r]) continue;
         if (vec) {
-          if (z4 < g.nz) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(coc + base + z4);
-            w[u][0] = q.x, w[u][1] = q.y, w[u][2] = q.z, w[u][3] = q.w;
-          }
+#pragma unroll
+          for (int u = 0; u < V / 4; ++u)
+            if (z8 + 4 * u < g.nz) {
+              const uint4 q = *reinterpret_cast<const uint4 *>(coc + bases[r] + z8 + 4 * u);
+              w[r][4 * u] = q.x, w[r][4 * u + 1] = q.y, w[r][4 * u + 2] = q.z, w[r][4 * u + 3] = q.w;
+            }
         } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (z4 + k < g.nz) w[u][k] = coc[base + z4 + k];
-        }
-      }
-      uint32_t rmask[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int z4 = zb + 256 * u + 4 * lane;
-        rmask[u] = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (!(w[u][k] & kNoCoc)) {
-            int cx, cy, cz;
-            unpack_coc(w[u][k], cx, cy, cz);
-            if ((!g.sharded || g.owned(x, y, z4 + k)) && !obstacle_alive(g, occbits, gocc, cx, cy, cz)) rmask[u] |= 1u << k;
-          }
+          for (int k = 0; k < V; ++k)
+            if (z8 + k < g.nz) w[r][k] = coc[bases[r] + z8 + k];
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int z4 = zb + 256 * u + 4 * lane;
-        if (vec && rmask[u] == 15u) {
-          *reinterpret_cast<uint4 *>(coc + base + z4) = make_uint4(kReset, kReset, kReset, kReset);
-        } else {
+      for (int r = 0; r < R; ++r) {
+        if (!live[r]) continue;  // (wave-uniform)
+        const int x = xs[r], y = ys[r];
+        const int64_t base = bases[r];
+        // neighbours along z mostly share their obstacle: one occupancy gather per RUN inside the lane's voxels
+        uint32_t rmask = 0;
+        bool dead_prev = false;
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if ((rmask[u] >> k) & 1u) coc[base + z4 + k] = kReset;
+        for (int k = 0; k < V; ++k) {
+          if (!(w[r][k] & kNoCoc)) {
+            const vox_t c = w[r][k] & ~kAct;
+            bool dead;
+            if (k > 0 && c == (w[r][k - 1] & ~kAct)) {
+              dead = dead_prev;
+            } else {
+              int cx, cy, cz;
+              unpack_coc(c, cx, cy, cz);
+              dead = !obstacle_alive(g, occbits, gocc, cx, cy, cz);
+            }
+            dead_prev = dead;
+            if (dead && (!g.sharded || g.owned(x, y, z8 + k))) rmask |= 1u << k;
+          }
         }
-        const unsigned long long m = __ballot(rmask[u] != 0);
+#pragma unroll
+        for (int u = 0; u < V / 4; ++u) {
+          const uint32_t nib = (rmask >> (4 * u)) & 15u;
+          if (vec && nib == 15u) {
+            *reinterpret_cast<uint4 *>(coc + base + z8 + 4 * u) = make_uint4(kReset, kReset, kReset, kReset);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if ((nib >> k) & 1u) coc[base + z8 + 4 * u + k] = kReset;
+          }
+        }
+        const unsigned long long m = __ballot(rmask != 0);
         if (m) {
-          local += __popc(rmask[u]);
-          // lanes 8j .. 8j+7 cover the 32 voxels of one tile along z
-          const int grp = lane >> 3;
-          if ((lane & 7) == 0 && ((m >> (grp * 8)) & 0xFFull) && z4 < g.nz) {
-            const uint32_t t = tg.tile_of(x, y, z4);
+          local += __popc(rmask);
+          // lanes 4j .. 4j+3 cover the 32 voxels of one tile along z
+          constexpr int LPT = 32 / V;
+          const int grp = lane / LPT;
+          if ((lane % LPT) == 0 && ((m >> (grp * LPT)) & ((1ull << LPT) - 1ull)) && z8 < g.nz) {
+            const uint32_t t = tg.tile_of(x, y, z8);
             if (flag[t] == 0u) activate_tile(t, flag, list, count);
           }
         }
