@@ -26,14 +26,15 @@ __device__ inline void activate_tile(uint32_t t, uint32_t *flag, uint32_t *list,
 // k_relax_q -- work-efficient tile relaxation: an LDS work queue instead of Jacobi sweeps.
 //
 // The reference pops one voxel at a time and runs 24 pulls + 24 pushes for it (src/ESDFMap.cpp:339-392),
-// ~1.04 expansions per updated voxel.  k_relax (above) keeps lanes on fixed voxels and re-reads all 24
+// ~1.04 expansions per updated voxel.  k_relax (v1, dense_map.hip) keeps lanes on fixed voxels and re-reads all 24
 // neighbours of EVERY voxel in EVERY sweep, which costs ~20 sweeps x 24 LDS reads per voxel per visit.
 // Here a tile + 2-voxel halo is staged in LDS as 64-bit keys  (d^2 << 32 | closest obstacle | flag)  and
 // only voxels whose key CHANGED do work, exactly like the reference's queue:
 //   * push   a changed voxel v offers its obstacle c to its 24 neighbours n.  |n-c|^2 is not recomputed:
 //            |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2  (two integer adds per direction); a plain 32-bit read
-//            of d(n) filters, ds_min_u64 on the key decides, the winner is appended to the next level's
-//            queue (level-synchronous inside the tile, one barrier per level).
+//            of d(n) filters, ds_min_u64 on the key decides, the winner's bit is set in the next level's
+//            frontier bitmap (level-synchronous inside the tile: bitmap -> compact queue -> items, two
+//            barriers per level).
 //   * pull   a voxel that goes from "no obstacle" to a finite distance (first reached by a wave, or
 //            orphaned by a delete: the re-seed of :308-321) asks the neighbours whose value predates
 //            this UpdateESDF -- they are a fixed point among themselves and would never push.  Neighbours
@@ -81,8 +82,6 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
   constexpr int RX = TX + 2 * H, RY = TY + 2 * H, RZ = TZ + 2 * H;
   constexpr int RSIZE = RX * RY * RZ;
   constexpr int NW = (RSIZE + 63) / 64 * 2;  // bitmap words (32 voxels each), padded to whole waves
-  constexpr int RPAD = NW * 32;
-  constexpr int ITER = RPAD / NT + (RPAD % NT ? 1 : 0);
   constexpr int SLOTS = NT / 32, RPT = TX * TY / SLOTS;
   constexpr int NROWW = RX * RY * 3;  // staged bitmap words: 3 z-words per (x,y) row of the region
   static_assert(NT % 64 == 0 && (TX * TY) % SLOTS == 0 && RPT <= 32 && RSIZE < 65536 && NW <= NT, "tile shape");
