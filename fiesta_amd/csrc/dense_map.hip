@@ -264,8 +264,7 @@ __global__ __launch_bounds__(1024) void k_del_bbox(Geom g, const uint32_t *del, 
 
 __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits,
                                                     const uint32_t *gocc, uint32_t *flag, uint32_t *list,
-                                                    unsigned long long *count, unsigned long long *counters, int bounded,
-                                                    uint32_t *obits) {
+                                                    unsigned long long *count, unsigned long long *counters, int bounded) {
   // one wave per z-row, 16-byte loads: a lane owns 8 consecutive voxels (512 voxels = 2 KiB per wave step); its
   // obstacle-occupancy gathers are independent of each other instead of one dependent load -> gather -> store chain per
   // voxel. Row and tile arithmetic is wave-uniform 32-bit math. (nz % 4 != 0: the same loop with scalar loads.)
@@ -362,13 +361,6 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
         }
         const unsigned long long m = __ballot(rmask != 0);
         if (m) {
-          // orphan bitmap (cleared by the host before this kernel): the 4 lanes of a 32-voxel word combine their masks
-          if (obits) {
-            uint32_t word = rmask << (V * (lane & (32 / V - 1)));
-            word |= __shfl_xor(word, 1);
-            word |= __shfl_xor(word, 2);
-            if ((lane & (32 / V - 1)) == 0 && word && z8 < g.nz) obits[g.bitword(x, y, z8)] = word;
-          }
           local += __popc(rmask);
           // lanes 4j .. 4j+3 cover the 32 voxels of one tile along z
           constexpr int LPT = 32 / V;
@@ -389,122 +381,6 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
   if (lane == 0 && local) atomicAdd(&blk_local, local);
   __syncthreads();
   if (threadIdx.x == 0 && blk_local) atomicAdd(&counters[C_INVALIDATED], blk_local);
-}
-
-// =====================================================================================================
-// Bulk updates: directional sweeps before the tile rounds.
-//
-// A delta that orphans or improves a large part of the grid (C2: 25 k deletes + 25 k inserts touch 2/3 of 512^3)
-// makes the tile engine visit every tile 3-4 times. Most of that propagation can be done by regular, barrier-light
-// streaming instead: four sweeps along +x, -x, +y, -y, z on the lanes. A sweep step takes plane a of a (B, z) tile
-// and lets every voxel pull from its stencil neighbours in the planes behind it: (a-1: same, B+-1, z+-1), (a-2: same).
-// Pulls follow the reference's rule for who may change (src/ESDFMap.cpp:339-392): the source changed during this
-// update (tag) or the target is itself in the work set (tag: orphans of the delete drain are, :292-337); an observed
-// voxel without obstacle and without tag is left to the tile rounds (it pulls when a wave first reaches it). Every
-// adoption is an ordinary relaxation step and tags its voxel, so the tile rounds that follow treat all of them as
-// frontier voxels and establish the exact fixed point; the sweeps only make them cheap (such sweeps alone reproduce
-// the exact nearest obstacle for > 99.9 % of the voxels of the scatter scenes). The one thing the tile rounds would
-// not redo by themselves is an orphan's own pull once a sweep has given it an obstacle: k_invalidate records the
-// orphans in a bitmap and the first tile round makes every one of them ask its 24 neighbours as before.
-//
-// Work-group = 8 waves = 8 B-rows (1 halo + 6 + 1 halo) x 64 lanes of z (1 halo + 62 + 1 halo); halo threads
-// compute but never store. Loads run 4 planes ahead; B+-1 neighbours go through a double-buffered LDS row buffer
-// (one barrier per plane), z neighbours through lane shuffles.
-// =====================================================================================================
-constexpr int kSweepWaves = 8, kSweepRows = kSweepWaves - 2, kSweepZ = 62;
-// lane l reads lane l-1 / l+1 of the wave (one DPP instruction each; the out-of-wave ends read `fill`)
-__device__ inline vox_t lane_below(vox_t v, vox_t fill) {
-  return (vox_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-}
-__device__ inline vox_t lane_above(vox_t v, vox_t fill) {
-  return (vox_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-}
-template <int AXIS>
-__global__ __launch_bounds__(kSweepWaves * 64) void k_sweep(Geom g, vox_t *coc, int sign) {
-  __shared__ vox_t rowbuf[2][kSweepWaves][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nA = AXIS == 0 ? g.nx : g.ny, nB = AXIS == 0 ? g.ny : g.nx;
-  const int b = (int)blockIdx.x * kSweepRows - 1 + w, z = (int)blockIdx.y * kSweepZ - 1 + lane;
-  const bool inside = (unsigned)b < (unsigned)nB && (unsigned)z < (unsigned)g.nz;
-  const bool writer = inside && w >= 1 && w <= kSweepRows && lane >= 1 && lane <= kSweepZ;
-  const int64_t strideA = AXIS == 0 ? (int64_t)g.ny * g.nz : (int64_t)g.nz;
-  const int64_t base = inside ? (AXIS == 0 ? (int64_t)b * g.nz + z : (int64_t)b * g.ny * g.nz + z) : 0;
-  const int vb = b + (AXIS == 0 ? g.gy0 : g.gx0), vz = z + g.gz0, a_off = AXIS == 0 ? g.gx0 : g.gy0;
-  constexpr int PF = 4;
-  vox_t q[PF];
-#pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    const int a = sign > 0 ? u : nA - 1 - u;
-    q[u] = (inside && u < nA) ? coc[base + a * strideA] : kUnobserved;
-  }
-  vox_t p1 = kUnobserved, p2 = kUnobserved;
-  for (int s0 = 0; s0 < nA; s0 += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int s = s0 + u;
-      if (s >= nA) break;  // (uniform)
-      const int a = sign > 0 ? s : nA - 1 - s;
-      const vox_t cur = q[u];
-      if (s + PF < nA) {
-        const int an = sign > 0 ? s + PF : nA - 1 - (s + PF);
-        q[u] = inside ? coc[base + an * strideA] : kUnobserved;
-      }
-      // the planes behind: (a-1: same, z-1, z+1, B-1, B+1) after their update, (a-2: same)
-      vox_t nb[6];
-      nb[0] = p1;
-      nb[1] = p2;
-      nb[2] = lane_below(p1, kUnobserved);
-      nb[3] = lane_above(p1, kUnobserved);
-      nb[4] = (s > 0 && w > 0) ? rowbuf[(s - 1) & 1][w - 1][lane] : kUnobserved;
-      nb[5] = (s > 0 && w < kSweepWaves - 1) ? rowbuf[(s - 1) & 1][w + 1][lane] : kUnobserved;
-      vox_t now = cur;
-      // who may change: an observed voxel that has an obstacle already or is in the work set (tagged); a source must have
-      // an obstacle, and (it changed during this update or the target is in the work set)
-      const bool may = cur != kUnobserved && (!(cur & kNoCoc) || (cur & kAct));
-      vox_t tags = cur, news = 0;
-      const vox_t curc = cur & ~kAct;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const vox_t o = (nb[k] & kNoCoc) ? 0u : nb[k];  // (words without obstacle offer nothing)
-        tags |= o;
-        news |= o ? ((o & ~kAct) ^ curc) : 0u;          // some neighbour holds a different obstacle
-      }
-      const bool any = may && (tags & kAct) && news;
-      // cheap screen first: most voxels of most planes are settled, whole waves skip the arithmetic
-      if (__ballot(any)) {
-        const int va = a + a_off;
-        const int vx = AXIS == 0 ? va : vb, vy = AXIS == 0 ? vb : va;
-        int32_t dcur = (cur & kNoCoc) ? kD2Inf : dist2(vx, vy, vz, cur & ~kAct);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const vox_t cn = nb[k], c = cn & ~kAct;
-          const bool elig = any && !(cn & kNoCoc) && ((cn | now) & kAct) && c != (now & ~kAct);
-          if (__ballot(elig)) {
-            const int32_t d = dist2(vx, vy, vz, c);
-            if (elig && d < dcur) {
-              dcur = d;
-              now = c | kAct;
-            }
-          }
-        }
-        if (now != cur && writer) coc[base + a * strideA] = now;
-      }
-      p2 = p1;
-      p1 = now;
-      rowbuf[s & 1][w][lane] = now;
-      __syncthreads();
-    }
-  }
-}
-
-// every tile joins the first round (after the sweeps)
-__global__ void k_all_tiles(uint32_t n, uint32_t *flag, uint32_t *list, unsigned long long *count) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) {
-    flag[t] = 1u;
-    list[t] = t;
-  }
-  if (t == 0) *count = n;
 }
 
 struct RelaxArgs {
@@ -997,7 +873,6 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   pp_ = ProbParams{0, 0, 0, 0, 0};
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_SPATIAL")) spatial_ = atoi(e);
-  if (const char *e = getenv("FIESTA_HIP_BULK_SWEEPS")) bulk_sweeps_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_LIST_THRESHOLD")) list_threshold_ = std::max(0, atoi(e));
   if (const char *e = getenv("FIESTA_HIP_BOUND_SCAN")) bound_scan_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
@@ -1010,7 +885,7 @@ DenseMap::~DenseMap() {
   free_raycast_state();
   void *ptrs[] = {coc_,          logodds_,      cnt_,          occbits_,      rbits_,     tile_epoch_,
                   tile_flag_[0], tile_flag_[1], tile_list_[0], tile_list_[1], counters_,  cbits_[0],
-                  cbits_[1],     cstamp_[0],    cstamp_[1],    gocc_,         obits_};
+                  cbits_[1],     cstamp_[0],    cstamp_[1],    gocc_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
@@ -1255,7 +1130,6 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     a.counters = counters_;
     a.prof = prof_;
     a.dir = nullptr;
-    a.obits = (swept_ && obits_valid_ && rounds == 0) ? obits_ : nullptr;  // first round after the sweeps only
     a.spatial = spatial;
     // spatial walk: a multiple of 8 blocks (one stream per XCD), a few per CU for load balance
     const int blocks = spatial ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), (uint32_t)spatial_blocks_)
@@ -1380,15 +1254,9 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
       hipLaunchKernelGGL(k_del_bbox, dim3(1), dim3(1024), 0, stream_, g_, (const uint32_t *)del_.p, (int64_t)nd, counters_);
       FIESTA_HIP_CHECK(hipGetLastError());
     }
-    const bool want_obits = bulk_sweeps_ && engine_ == 1 && !g_.sharded;
-    if (want_obits) {
-      if (!obits_) FIESTA_HIP_CHECK(hipMalloc((void **)&obits_, nbitwords_ * sizeof(uint32_t)));
-      FIESTA_HIP_CHECK(hipMemsetAsync(obits_, 0, nbitwords_ * sizeof(uint32_t), stream_));
-      obits_valid_ = true;
-    }
     hipLaunchKernelGGL(k_invalidate, dim3((grid_for(g_.n / 16 + 1, 256, 4096) + 7) / 8 * 8), dim3(256), 0, stream_, g_, tg, coc_,
                        (const uint32_t *)occbits_, (const uint32_t *)gocc_, tile_flag_[0], tile_list_[0],
-                       &counters_[C_LIST0], counters_, bounded, want_obits ? obits_ : (uint32_t *)nullptr);
+                       &counters_[C_LIST0], counters_, bounded);
     FIESTA_HIP_CHECK(hipGetLastError());
   }
   zero_counter(C_INSERT);
@@ -1399,27 +1267,8 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     return;
   }
-  uint32_t n0 = (uint32_t)read_counter(C_LIST0);
-  // bulk update (a large part of the grid orphaned or about to change): directional sweeps first, see k_sweep
-  const bool full_window = g_.wx0 <= 0 && g_.wy0 <= 0 && g_.wz0 <= 0 && g_.wx1 >= g_.nx - 1 && g_.wy1 >= g_.ny - 1 && g_.wz1 >= g_.nz - 1;
-  if (bulk_sweeps_ && engine_ == 1 && !g_.sharded && full_window && n0 &&
-      (int64_t)n0 * bulk_tile_fraction_ >= (int64_t)ntiles_) {
-    const dim3 gx((g_.ny + kSweepRows - 1) / kSweepRows, (g_.nz + kSweepZ - 1) / kSweepZ);
-    const dim3 gy((g_.nx + kSweepRows - 1) / kSweepRows, (g_.nz + kSweepZ - 1) / kSweepZ);
-    hipLaunchKernelGGL(k_sweep<0>, gx, dim3(kSweepWaves * 64), 0, stream_, g_, coc_, +1);
-    hipLaunchKernelGGL(k_sweep<0>, gx, dim3(kSweepWaves * 64), 0, stream_, g_, coc_, -1);
-    hipLaunchKernelGGL(k_sweep<1>, gy, dim3(kSweepWaves * 64), 0, stream_, g_, coc_, +1);
-    hipLaunchKernelGGL(k_sweep<1>, gy, dim3(kSweepWaves * 64), 0, stream_, g_, coc_, -1);
-    FIESTA_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_all_tiles, dim3((ntiles_ + 255) / 256), dim3(256), 0, stream_, (uint32_t)ntiles_, tile_flag_[0],
-                       tile_list_[0], &counters_[C_LIST0]);
-    FIESTA_HIP_CHECK(hipGetLastError());
-    n0 = (uint32_t)ntiles_;
-    swept_ = true;
-  }
+  const uint32_t n0 = (uint32_t)read_counter(C_LIST0);
   run_rounds(st, n0, 0);
-  swept_ = false;
-  obits_valid_ = false;
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
   collect_stats(st);
   FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));

@@ -158,8 +158,6 @@ class DenseMap {
   unsigned long long *cnt_ = nullptr;  // 8 B/voxel, cold: hits<<32 | observations (num_hit_/num_miss_)
   uint32_t *occbits_ = nullptr;        // 1 bit/voxel: Exist(idx)
   uint32_t *rbits_ = nullptr;          // 1 bit/voxel: voxel joined the frontier during the current update
-  uint32_t *obits_ = nullptr;          // 1 bit/voxel: orphaned by the delete drain of the current update (bulk updates)
-  bool obits_valid_ = false, swept_ = false;
   uint32_t *gocc_ = nullptr;           // sharded maps: 1 bit/voxel of the GLOBAL grid, replicated on every shard
   int64_t ngoccwords_ = 0;
   int64_t nbitwords_ = 0;
@@ -177,8 +175,6 @@ class DenseMap {
   bool track_ = false;  // C_MAXD2 is maintained (enable_distance_tracking)
   int bound_scan_ = 1;  // bound the delete scan by the delete queue's box + the largest stored distance (FIESTA_HIP_BOUND_SCAN=0: whole grid)
   int list_threshold_ = 1024;  // updates that start with fewer active tiles use the compact list + paired rounds
-  int bulk_sweeps_ = 1;          // directional sweeps before the tile rounds of an update that starts with ...
-  int bulk_tile_fraction_ = 2;   // ... at least 1/2 of all tiles active (FIESTA_HIP_BULK_SWEEPS=0: never)
   int spatial_ = 1;  // walk the tiles in XCD-chunked spatial order (FIESTA_HIP_SPATIAL=0: compact list order)
   uint32_t serial_ = 0;                         // relaxation rounds launched so far (all updates)
   uint32_t *tile_flag_[2] = {nullptr, nullptr};

@@ -661,7 +661,6 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
     a.counters = counters_;
     a.prof = prof_;
     a.dir = dir_;
-    a.obits = nullptr;
     a.spatial = 0;
     const uint32_t blocks = n_dev ? std::min<uint32_t>(16384u, std::max<uint32_t>(256u, 4u * ncur)) : std::min<uint32_t>(n_host, 16384u);
     hipLaunchKernelGGL((k_relax_q<kTX, kTY, 1024, true>), dim3(blocks), dim3(1024), 0, stream_, a);

@@ -70,9 +70,6 @@ struct RelaxQArgs {
   // paged (hash-block) maps: voxel data lives in a pool of pages, one page = one tile (TX x TY x 32 voxels, same
   // z-fastest row layout), found through the dense page directory dir[tile] (-1: not allocated = all unobserved)
   const int32_t *dir;
-  // first round after the directional sweeps of a bulk update (dense maps): voxels the delete drain orphaned; a sweep
-  // may have given them an obstacle already, they still ask their 24 neighbours once like every orphan
-  const uint32_t *obits;
 };
 
 // TRACK: also maintain counters[C_MAXD2], an upper bound of every finite d^2 stored (bounds the delete scan of maps that
@@ -243,13 +240,11 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
       const int ox = (rx < H) ? 0 : ((rx >= TX + H) ? 2 : 1), oy = (ry < H) ? 0 : ((ry >= TY + H) ? 2 : 1);
       const uint32_t ok = nb_ok[ox * 9 + oy * 3 + k];
       uint32_t r = 0, c = 0;
-      const bool own_o = !PAGED && a.obits && ox == 1 && oy == 1 && k == 1;  // (own tile: cb is otherwise unused there)
-      if ((ok || own_o) && (unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny) {
+      if (ok && (unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny) {
         const int64_t wi = PAGED ? (int64_t)nb_page[ox * 9 + oy * 3 + k] * PAGE_ROWS + ((x % TX) * TY + (y % TY))
                                  : ((int64_t)x * g.ny + y) * g.nzw + zt;
         if (ok & 1u) r = a.rbits[wi];
         if (ok & 2u) c = a.cbits_prev[wi];
-        if (own_o) c = a.obits[wi];
       }
       rb[j] = r;
       cb[j] = c;
@@ -291,7 +286,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
           if (act) flags |= 1u | 4u;
           // a voxel without an obstacle asks its old-valid neighbours once, when it first joins the frontier:
           // now if it was orphaned by a delete (the re-seed of :308-321), else when a wave first reaches it
-          if (!valid || (cb[j] & bit)) flags |= 2u;
+          if (!valid) flags |= 2u;
         } else if (src) {  // a source only: its d^2 field stays 0
           // a halo voxel can reach the tile through the stencil only from a face slab (one axis outside) or
           // from an edge at distance 1 on both outside axes (the +-1,+-1 diagonals); ghost cells sit inside
