@@ -26,7 +26,7 @@ def _make(oracle_libs, kind, size_vox, res, origin):
     return b
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("seed", list(range(11, 27)))
 def test_random_sequences_fully_observed(hip_lib, oracle_libs, best_oracle_kind, seed):
     rng = np.random.RandomState(seed)
     dims = tuple(int(v) for v in rng.randint(9, 44, 3))
@@ -76,7 +76,7 @@ def test_random_sequences_fully_observed(hip_lib, oracle_libs, best_oracle_kind,
         assert np.array_equal(b.gpu.GetOccupancy(q), b.cpu.GetOccupancyPos(q))
 
 
-@pytest.mark.parametrize("seed", [21, 22, 23])
+@pytest.mark.parametrize("seed", list(range(41, 49)))
 def test_random_sequences_partially_observed(hip_lib, oracle_libs, best_oracle_kind, seed):
     """Only random boxes are ever observed: the reference's result depends on its queue order there,
     so distances carry the stated budget; occupancy, log-odds, queue sizes and the observed set stay exact."""
@@ -97,3 +97,44 @@ def test_random_sequences_partially_observed(hip_lib, oracle_libs, best_oracle_k
         b.esdf()
         rep = compare_dense(b.gpu, b.cpu)
         assert rep["d2_mismatch"] <= max(10, 0.02 * rep["finite"]), rep
+
+
+@pytest.mark.parametrize("seed", [61, 62, 63, 64])
+def test_random_sequences_hash_map(hip_lib, oracle_libs, best_oracle_kind, seed):
+    """The same on the paged (hash-block) map against the -DHASH_TABLE reference: random boxes around a wandering centre
+    (negative coordinates, page growth from a tiny reserve), obstacles that come and go."""
+    import fiesta_amd
+    from test_gpu_hash_parity import compare as compare_hash
+    kind = best_oracle_kind if oracle_libs.available(best_oracle_kind, "hash") else "port"
+    rng = np.random.RandomState(seed)
+    origin, res = tuple(float(v) for v in rng.uniform(-1, 1, 3)), float(rng.choice([0.05, 0.1]))
+    gpu = fiesta_amd.ESDFMap(origin, res, reserve_size=int(rng.choice([0, 1000, 50000])), mode="hash")
+    cpu = oracle_libs.OracleMap(origin, res, reserve_size=1000, mode="hash", kind=kind)
+    for m in (gpu, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    centre = rng.randint(-30, 30, 3)
+    live = np.zeros((0, 3), np.int32)
+    for step in range(5):
+        centre = centre + rng.randint(-6, 7, 3)
+        ext = rng.randint(8, 22, 3)
+        box = (all_voxels(tuple(int(v) for v in ext)) + (centre - ext // 2)).astype(np.int32)
+        new = box[rng.rand(len(box)) < 0.01]
+        gone = live[rng.rand(len(live)) < 0.4]
+        for k in range(3):
+            if k == 0:
+                gpu.SetOccupancy(box, 0)
+                cpu.SetOccupancyVox(box, 0)
+            for vv, o in ((new, 1), (gone, 0)):
+                if len(vv):
+                    gpu.SetOccupancy(vv, o)
+                    cpu.SetOccupancyVox(vv, o)
+            a, c = gpu.UpdateOccupancy(True), cpu.UpdateOccupancy(True)
+            assert a == c and (gpu.last_insert, gpu.last_delete) == (cpu.last_insert, cpu.last_delete)
+        sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
+        assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+        rep = compare_hash(gpu, cpu)
+        assert rep["d2_mismatch"] <= max(30, 0.03 * rep["finite"]), rep
+        live = np.concatenate([live, new])
+        q = (rng.uniform(-25, 25, (150, 3)) + centre) * res + np.array(origin)
+        assert np.array_equal(gpu.GetOccupancy(q), cpu.GetOccupancyPos(q))
