@@ -46,11 +46,13 @@ ALGO_BYTES_PER_UPDATED_VOXEL = 16           # read 8 B + write 8 B
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--obstacles", type=int, default=50000)
     ap.add_argument("--tile-shape", type=int, default=0)
+    ap.add_argument("--scene", default="scatter", choices=["scatter", "surfaces"],
+                    help="C2 obstacle distribution: uniform scatter (headline) or depth-sensor-like shells (scene C)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=224)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
@@ -63,19 +65,43 @@ def parse():
 
 
 class Workload:
-    """Deterministic stationary scatter workload: `n_obs` live obstacle voxels, half replaced per step."""
+    """Deterministic stationary workload: `n_obs` live obstacle voxels, half replaced per step.  scene "scatter":
+    uniform voxels (SURVEY.md 8d, C2 scenes A/B); "surfaces": voxels sampled on 3 axis-aligned planes and 20 spheres
+    of radius 8-40 voxels, the shells a depth sensor produces (C2 scene C)."""
 
-    def __init__(self, grid, n_obs, seed=12345):
-        self.grid, self.n_obs, self.half = grid, n_obs, n_obs // 2
+    def __init__(self, grid, n_obs, seed=12345, scene="scatter"):
+        self.grid, self.n_obs, self.half, self.scene = grid, n_obs, n_obs // 2, scene
         self.rng = np.random.RandomState(seed)
+        g = grid
+        srng = np.random.RandomState(4242)  # the surfaces themselves are the same for every rank / step
+        self.planes = [(int(a), int(srng.randint(g // 8, g - g // 8))) for a in range(3)]
+        self.spheres = [(srng.randint(g // 8, g - g // 8, 3), float(srng.uniform(8, 40))) for _ in range(20)]
         self.live = self._fresh(n_obs, set())
         self.step_id = 0
+
+    def _sample(self, k):
+        if self.scene == "scatter":
+            return self.rng.randint(0, self.grid, (k, 3))
+        g, out = self.grid, np.empty((k, 3), np.int64)
+        which = self.rng.randint(0, 23, k)  # 3 planes + 20 spheres, equally likely
+        for i in range(k):
+            w = which[i]
+            if w < 3:
+                ax, pos = self.planes[w]
+                v = self.rng.randint(0, g, 3)
+                v[ax] = pos
+            else:
+                c, r = self.spheres[w - 3]
+                d = self.rng.normal(size=3)
+                v = np.rint(c + r * d / np.linalg.norm(d)).astype(np.int64)
+            out[i] = np.clip(v, 0, g - 1)
+        return out
 
     def _fresh(self, k, taken):
         out = []
         seen = set(taken)
         while len(out) < k:
-            c = self.rng.randint(0, self.grid, (k - len(out), 3))
+            c = self._sample(k - len(out))
             for v in map(tuple, c):
                 if v not in seen:
                     seen.add(v)
@@ -112,7 +138,7 @@ def run_cpu_baseline(args):
     m.SetOccupancyVox(allv, 0)
     m.UpdateOccupancy(True)
     m.UpdateESDF()
-    w = Workload(g, n_obs)
+    w = Workload(g, n_obs, scene=args.scene)
     for _ in range(3):
         m.SetOccupancyVox(w.initial(), 1)
         m.UpdateOccupancy(True)
@@ -396,7 +422,7 @@ def main():
     top.UpdateESDF()
 
     # ---- scene A: scatter insert of all obstacles into the empty observed grid (reported, not the step)
-    w = Workload(G, args.obstacles, seed=12345 + 1000 * rank)
+    w = Workload(G, args.obstacles, seed=12345 + 1000 * rank, scene=args.scene)
     init = dev_batch(w.initial() + box_lo.astype(np.int32), np.ones(args.obstacles, np.int32))
     for _ in range(3):
         observe(init)
@@ -498,7 +524,8 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {G}^3 dense-array grid @0.1 m fully observed, {args.obstacles} scattered obstacle voxels, "
+                "workload": f"C2: {G}^3 dense-array grid @0.1 m fully observed, {args.obstacles} "
+                            f"{'scattered' if args.scene == 'scatter' else 'surface (3 planes + 20 spheres)'} obstacle voxels, "
                             f"per step a {args.obstacles}-voxel delta = {args.obstacles // 2} inserts + {args.obstacles // 2} deletes "
                             "landing in one UpdateESDF (ingest: 3 SetOccupancy+UpdateOccupancy cycles, inputs resident in HBM)",
                 "grid": [G, G, G], "delta_voxels": args.obstacles,
