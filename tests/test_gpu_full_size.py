@@ -120,3 +120,50 @@ def test_engines_agree_256cube(hip_lib):
     # (the reference has the same property); the default engine must be the exact one wherever they differ
     assert len(diff) <= 4, len(diff)
     assert _brute_force_sample(fields[0]["d2"], fields[0]["occ"], G, np.random.RandomState(1), k=4000) == 0
+
+
+def test_config2_density_192cube_exact_vs_reference(hip_lib, oracle_libs, best_oracle_kind):
+    """Config 2 at the largest size the CPU reference finishes in seconds (192^3, 7 M voxels, the same obstacle density:
+    2637 obstacles; scatter insert, then the steady-state step = half inserted + half deleted in one UpdateESDF): the whole
+    field against the reference, voxel by voxel, tolerance 0."""
+    import fiesta_amd
+    from scenarios import assert_exact, compare_dense
+    G, res = 192, 0.1
+    size = ((G - 0.5) * res,) * 3
+    gpu = fiesta_amd.ESDFMap((0, 0, 0), res, size)
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, size, kind=best_oracle_kind)
+    assert gpu.grid_size == (G, G, G) == cpu.grid_size
+    for m in (gpu, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    _observe_all(gpu, G)
+    g = np.stack(np.meshgrid(np.arange(G), np.arange(G), np.arange(G), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    cpu.SetOccupancyVox(g, 0)
+    cpu.UpdateOccupancy(True)
+    cpu.UpdateESDF()
+    rng = np.random.RandomState(12345)
+    n_obs = 2637
+    A = np.unique(rng.randint(0, G, (n_obs, 3)), axis=0).astype(np.int32)
+    for _ in range(3):
+        gpu.SetOccupancy(A, 1, want_ret=False)
+        cpu.SetOccupancyVox(A, 1)
+        assert gpu.UpdateOccupancy(True) == cpu.UpdateOccupancy(True)
+    sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
+    assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"]) == (len(A), 0)
+    assert_exact(compare_dense(gpu, cpu))
+    B = rng.randint(0, G, (n_obs // 2, 3)).astype(np.int32)
+    old = A[: len(A) // 2]
+    for k in range(6):
+        if k < 3:
+            gpu.SetOccupancy(B, 1, want_ret=False)
+            cpu.SetOccupancyVox(B, 1)
+        gpu.SetOccupancy(old, 0, want_ret=False)
+        cpu.SetOccupancyVox(old, 0)
+        assert gpu.UpdateOccupancy(True) == cpu.UpdateOccupancy(True)
+        assert (gpu.last_insert, gpu.last_delete) == (cpu.last_insert, cpu.last_delete)
+    sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
+    assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+    assert sg["deleted"] > 1000 and sg["inserted"] > 1000
+    rep = compare_dense(gpu, cpu)
+    assert_exact(rep)
+    assert rep["finite"] == G ** 3
