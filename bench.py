@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--obstacles", type=int, default=50000)
-    ap.add_argument("--tile-shape", type=int, default=0)
+    ap.add_argument("--engine", default="auto", choices=["auto", "rounds", "bulk"],
+                    help="UpdateESDF engine: chosen per update (default), frontier rounds only, or the bulk feature "
+                         "transform whenever the map state allows it")
     ap.add_argument("--scene", default="scatter", choices=["scatter", "surfaces"],
                     help="C2 obstacle distribution: uniform scatter (headline) or depth-sensor-like shells (scene C)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,7 +184,7 @@ def run_c3(args):
     G, res = args.grid, 0.1
     half = G * res / 2
     origin, size = (-half, -half, -half), (G * res,) * 3
-    m = fiesta_amd.ESDFMap(origin, res, size, tile_shape=args.tile_shape)
+    m = fiesta_amd.ESDFMap(origin, res, size, update_engine=args.engine)
     m.SetParameters(*P_DEFAULT)
     m.SetOriginalRange()
     cpu, cpu_frames = None, 0 if args.no_cpu_baseline else 2
@@ -394,13 +396,13 @@ def main():
         layout = shard_layout(world)
         gg = tuple(G * l for l in layout)
         sharded_map = ShardedESDFMap((0, 0, 0), res, gg, world, transport=DistTransport(cdev), devices=(local_rank,),
-                                     tile_shape=args.tile_shape)
+                                     update_engine=args.engine)
         m = sharded_map.shards[rank]
         box_lo = np.array(rank_coords(rank, layout)) * G
         sharded_map.SetParameters(*P_DEFAULT)
         sharded_map.SetOriginalRange()
     else:
-        m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, device=local_rank, tile_shape=args.tile_shape)
+        m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, device=local_rank, update_engine=args.engine)
         assert m.grid_total_size_ == G ** 3, "grid rounding (SURVEY.md 7.3-G)"
         box_lo = np.zeros(3, int)
         m.SetParameters(*P_DEFAULT)
@@ -499,9 +501,11 @@ def main():
         # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
         # read from inside the process); the newest committed summary of tools/pmc_traffic.py is quoted here.
         traffic, traffic_src = None, None
+        all_bulk = all(int(s.get("bulk", 0)) for s in timed)
         try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "pmc_traffic" in f and f.endswith(".json"))
-            if cands and world == 1:
+            tag = "pmc_traffic_ft" if all_bulk else "pmc_traffic_k_relax_q"
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if tag in f and f.endswith(".json"))
+            if cands and world == 1 and args.scene == "scatter" and G == 512:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
                 traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{cands[-1]} ({tj['kernel']}, {tj['command']})"
         except Exception:
@@ -510,6 +514,15 @@ def main():
         launches = sum(s["relax_launches"] for s in timed)
         my_updated = float(sum(updated))
         achieved = my_updated * ALGO_BYTES_PER_UPDATED_VOXEL / (relax_ms * 1e-3) / 1e9 if relax_ms > 0 else 0.0
+        n_bulk = sum(int(s.get("bulk", 0)) for s in timed)
+        if n_bulk == len(timed):
+            kernel = "k_ft_rows + k_ft_plane + k_ft_x (bulk feature transform: every kernel of UpdateESDF)"
+            phases = {k: statistics.median(s[k] for s in timed) for k in ("ft_rows_ms", "ft_plane_ms", "ft_x_ms")}
+            dominant = {"kernel": "k_ft_x", "ms": phases["ft_x_ms"],
+                        "frac": my_updated / args.steps * ALGO_BYTES_PER_UPDATED_VOXEL / (phases["ft_x_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            overflow = [int(sum(s["ft_overflow"][k] for s in timed)) for k in range(6)]
+        else:
+            kernel, phases, dominant, overflow = "k_relax_q (frontier rounds)", None, None, None
         out = {
             "metric": "esdf_updated_voxels_per_sec",
             "value": total_updated / elapsed,
@@ -534,7 +547,7 @@ def main():
                     f"one map of {'x'.join(str(G * l) for l in layout)} voxels sharded {'x'.join(map(str, layout))} over {world} GPUs "
                     f"({G}^3 owned per GPU + 2-voxel ghost layer; RCCL ghost exchange + transition all-gather, "
                     f"{statistics.mean(s_['sweeps'] for s_ in timed):.1f} ghost sweeps per update)"),
-                "tile_shape": args.tile_shape,
+                "update_engine": args.engine,
             },
             "update_esdf_p50_ms": statistics.median(s["host_ms"] for s in timed),
             "update_esdf_device_p50_ms": statistics.median(s["device_ms"] for s in timed),
@@ -547,11 +560,12 @@ def main():
                                     "voxels_per_sec": scatter_updated / (st_scatter["host_ms"] * 1e-3),
                                     "roofline_frac": scatter_updated * 16 / (st_scatter["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "roofline": {
-                "bound": "hbm", "kernel": "k_relax_q", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                 "launches": launches, "avg_launch_us": relax_ms * 1e3 / max(1, launches),
                 "algorithmic_bytes_per_launch": my_updated * ALGO_BYTES_PER_UPDATED_VOXEL / max(1, launches),
                 "frac_of_measured_copy_6.29TBs": achieved / 6290.0,
+                "phases_p50_ms": phases, "dominant_kernel": dominant, "ring_overflows": overflow,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -23,18 +23,21 @@ class FiestaHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("mode", C.c_int32), ("device", C.c_int32), ("origin", C.c_double * 3),
                 ("resolution", C.c_double), ("map_size", C.c_double * 3), ("reserve_size", C.c_int32),
-                ("tile_shape", C.c_int32), ("shard_lo", C.c_int32 * 3), ("global_grid", C.c_int32 * 3)]
+                ("update_engine", C.c_int32), ("shard_lo", C.c_int32 * 3), ("global_grid", C.c_int32 * 3)]
 
 
 class Stats(C.Structure):
     _fields_ = [("inserted", C.c_int64), ("deleted", C.c_int64), ("invalidated", C.c_int64),
                 ("rounds", C.c_int64), ("tile_visits", C.c_int64), ("sweeps", C.c_int64),
                 ("voxel_writes", C.c_int64), ("device_ms", C.c_double), ("host_ms", C.c_double),
-                ("relax_ms", C.c_double), ("relax_launches", C.c_int64), ("prof", C.c_int64 * 8)]
+                ("relax_ms", C.c_double), ("relax_launches", C.c_int64), ("prof", C.c_int64 * 8),
+                ("bulk", C.c_int64), ("ft_rows_ms", C.c_double), ("ft_plane_ms", C.c_double), ("ft_x_ms", C.c_double),
+                ("ft_overflow", C.c_int64 * 6), ("observed_voxels", C.c_int64), ("occupied_voxels", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["prof"] = list(self.prof)
+        d["ft_overflow"] = list(self.ft_overflow)
         return d
 
 

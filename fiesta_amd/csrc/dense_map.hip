@@ -23,6 +23,7 @@
 // tile's members of R are recorded in a bitmap, and neighbouring tiles whose halo saw a frontier voxel
 // are appended to the next round's tile list (level-synchronous rounds, one launch per round).
 #include "dense_map.hpp"
+#include "ft_kernels.hpp"
 #include "relax_kernels.hpp"
 
 #include <algorithm>
@@ -134,7 +135,7 @@ __global__ void k_observe_pos(Geom g, const double *pos, const int32_t *occ, int
 // UpdateOccupancy for one touched voxel (src/ESDFMap.cpp:239-267); reports a transition, does not queue it.
 __device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_map, uint32_t idx,
                                      unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits,
-                                     uint32_t *gocc, bool &to_ins, bool &to_del) {
+                                     uint32_t *gocc, bool &to_ins, bool &to_del, bool &first_obs) {
   const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
   const unsigned long long c = cnt[idx];
   cnt[idx] = 0;  // num_hit_ = num_miss_ = 0 (:245)
@@ -142,7 +143,10 @@ __device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_
   const double step = (hits >= seen - hits) ? pp.l_hit : pp.l_miss;  // majority vote (:243)
   double L = logodds[idx];
   const bool was = L > pp.l_occ;  // Exist (:16-22)
-  if (coc[idx] == kUnobserved) coc[idx] = kInf;  // first observation: -10000 -> +10000 (:246-249)
+  if (coc[idx] == kUnobserved) {  // first observation: -10000 -> +10000 (:246-249)
+    coc[idx] = kInf;
+    first_obs = true;
+  }
   if ((step >= 0 && L >= pp.l_max) || (step <= 0 && L <= pp.l_min)) return;  // already clamped (:250-255)
   if (!global_map && !g.in_prev_window(x, y, z)) {  // local-map reset (:256-259); see DESIGN.md
     L = 0;
@@ -168,16 +172,20 @@ __global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *to
                        unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *gocc,
                        uint32_t *ins, uint32_t *del, unsigned long long *counters) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  bool to_ins = false, to_del = false;
+  bool to_ins = false, to_del = false, first_obs = false;
   uint32_t idx = 0;
   if (i < n) {
     idx = touched[i];
-    fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, to_ins, to_del);
+    fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, to_ins, to_del, first_obs);
   }
   // queue appends: ONE atomic per wave and queue (tens of thousands of transitions would otherwise serialise on
   // the two counters)
   const int lane = threadIdx.x & 63;
-  const unsigned long long mi = __ballot(to_ins), md = __ballot(to_del);
+  const unsigned long long mi = __ballot(to_ins), md = __ballot(to_del), mo = __ballot(first_obs);
+  // bookkeeping for the choice of the UpdateESDF engine: observed voxels and occupied voxels of the map
+  if (lane == 0 && mo) atomicAdd(&counters[C_OBSERVED], (unsigned long long)__popcll(mo));
+  if (lane == 0 && (mi | md))
+    atomicAdd(&counters[C_NOCC], (unsigned long long)((long long)__popcll(mi) - (long long)__popcll(md)));
   if (mi) {
     uint32_t base = 0;  // (queues hold < 2^32 entries: voxel indices are 32-bit)
     if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_INSERT], (unsigned long long)__popcll(mi));
@@ -383,199 +391,6 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
   if (threadIdx.x == 0 && blk_local) atomicAdd(&counters[C_INVALIDATED], blk_local);
 }
 
-struct RelaxArgs {
-  Geom g;
-  TileGrid tg;
-  vox_t *coc;
-  uint32_t *rbits;
-  uint32_t *tile_epoch;
-  uint32_t epoch;
-  const uint32_t *list_cur;
-  uint32_t n_cur;
-  uint32_t *flag_cur;
-  uint32_t *flag_next;
-  uint32_t *list_next;
-  unsigned long long *count_next;
-  unsigned long long *counters;
-};
-
-// One work-group relaxes one tile to local quiescence. 256 threads = 8 half-waves; a half-wave owns a
-// 32-voxel z-row (128 B in HBM, 32 consecutive LDS banks), so every stencil read is conflict-free.
-template <int TX, int TY>
-__global__ __launch_bounds__(256) void k_relax(RelaxArgs a) {
-  constexpr int TZ = 32, H = 2;
-  constexpr int RX = TX + 2 * H, RY = TY + 2 * H, RZ = TZ + 2 * H;
-  constexpr int RSIZE = RX * RY * RZ;
-  constexpr int ROWS = TX * TY;
-  constexpr int RPT = ROWS / 8;  // rows (= voxels) per thread
-  static_assert(ROWS % 8 == 0 && RPT <= 32, "tile shape");
-  __shared__ vox_t L[RSIZE];
-  __shared__ int nbr_dirty[27];
-
-  const Geom &g = a.g;
-  const int tid = threadIdx.x;
-  const int lz = tid & 31, slot = tid >> 5;
-
-  for (uint32_t li = blockIdx.x; li < a.n_cur; li += gridDim.x) {
-    const uint32_t t = a.list_cur[li];
-    const int tz = t % a.tg.ntz, ty = (t / a.tg.ntz) % a.tg.nty, tx = t / (a.tg.ntz * a.tg.nty);
-    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
-    if (tid == 0) a.flag_cur[t] = 0;
-    if (tid < 27) nbr_dirty[tid] = 0;
-
-    // ---- stage tile + halo. Out-of-grid / out-of-window voxels become "unobserved": neither a source
-    //      nor a target (VoxInRange gates both the pull and the push, src/ESDFMap.cpp:351,378).
-    for (int i = tid; i < RSIZE; i += 256) {
-      const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
-      const int x = x0 - H + rx, y = y0 - H + ry, z = z0 - H + rz;
-      vox_t w = kUnobserved;
-      if (g.in_grid(x, y, z) && g.in_window(x, y, z)) {
-        w = a.coc[g.idx(x, y, z)];
-        const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
-                              (unsigned)(rz - H) < (unsigned)TZ;
-        if (!interior && w != kUnobserved) {
-          // a halo voxel is a frontier source iff it joined the frontier earlier in THIS update
-          const uint32_t ot = a.tg.tile_of(x, y, z);
-          if (a.tile_epoch[ot] == a.epoch && ((a.rbits[g.bitword(x, y, z)] >> (z & 31)) & 1u)) w |= kAct;
-        }
-      }
-      L[i] = w;
-    }
-    __syncthreads();
-
-    // ---- per-thread bookkeeping for the voxels this thread owns
-    uint32_t updmask = 0, ever = 0;
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const int row = slot + 8 * r, lx = row / TY, ly = row % TY;
-      const vox_t w = L[((lx + H) * RY + (ly + H)) * RZ + (lz + H)];
-      if (w != kUnobserved && g.owned(x0 + lx, y0 + ly, z0 + lz)) {
-        updmask |= 1u << r;
-        if (w & kAct) ever |= 1u << r;
-      }
-    }
-
-    // ---- Jacobi sweeps with a frontier bit per voxel
-    vox_t res[RPT];
-    uint32_t nsweeps = 0;
-    bool first = true;
-    for (;;) {
-      bool any = false;
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        const int row = slot + 8 * r, lx = row / TY, ly = row % TY;
-        const int c0 = ((lx + H) * RY + (ly + H)) * RZ + (lz + H);
-        const vox_t w = L[c0];
-        vox_t out = w;
-        if ((updmask >> r) & 1u) {
-          const bool selfact = (w & kAct) != 0;
-          const vox_t cur = w & ~kAct;
-          vox_t best = cur;
-          const int gx = g.gx0 + x0 + lx, gy = g.gy0 + y0 + ly, gz = g.gz0 + z0 + lz;
-          int32_t bestd = (cur & kNoCoc) ? kD2Inf : dist2(gx, gy, gz, cur);
-#define FIESTA_PULL(DX, DY, DZ)                                             \
-  {                                                                         \
-    const vox_t u = L[c0 + ((DX)*RY + (DY)) * RZ + (DZ)];                   \
-    if (!(u & kNoCoc) && (selfact || (u & kAct))) {                         \
-      const vox_t c = u & ~kAct;                                            \
-      if (c != best) {                                                      \
-        const int32_t d = dist2(gx, gy, gz, c);                             \
-        if (d < bestd) {                                                    \
-          bestd = d;                                                        \
-          best = c;                                                         \
-        }                                                                   \
-      }                                                                     \
-    }                                                                       \
-  }
-          FIESTA_STENCIL24(FIESTA_PULL)
-#undef FIESTA_PULL
-          const bool improved = best != cur;
-          out = improved ? (best | kAct) : cur;
-          if (improved) {
-            ever |= 1u << r;
-            any = true;
-          }
-        }
-        res[r] = out;
-      }
-      __syncthreads();  // every read of this sweep is done
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        if ((updmask >> r) & 1u) {
-          const int row = slot + 8 * r, lx = row / TY, ly = row % TY;
-          L[((lx + H) * RY + (ly + H)) * RZ + (lz + H)] = res[r];
-        }
-      }
-      if (first) {  // halo frontier bits have now been seen by everyone: retire them
-        for (int i = tid; i < RSIZE; i += 256) {
-          const int rz = i % RZ, ry = (i / RZ) % RY, rx = i / (RZ * RY);
-          const bool interior = (unsigned)(rx - H) < (unsigned)TX && (unsigned)(ry - H) < (unsigned)TY &&
-                                (unsigned)(rz - H) < (unsigned)TZ;
-          if (!interior) {
-            const vox_t w = L[i];
-            if (w != kUnobserved && (w & kAct)) L[i] = w & ~kAct;
-          }
-        }
-        first = false;
-      }
-      ++nsweeps;
-      if (!__syncthreads_or(any)) break;
-    }
-
-    // ---- write back what changed, publish the tile's frontier members, wake the neighbours
-    const bool had_epoch = a.tile_epoch[t] == a.epoch;
-    uint32_t nwrites = 0;
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const int row = slot + 8 * r, lx = row / TY, ly = row % TY;
-      const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
-      const bool e = (ever >> r) & 1u;
-      if (e) {  // (e implies updatable, hence in grid)
-        a.coc[g.idx(x, y, z)] = L[((lx + H) * RY + (ly + H)) * RZ + (lz + H)] & ~kAct;
-        ++nwrites;
-#define FIESTA_WAKE(DX, DY, DZ)                                                          \
-  {                                                                                      \
-    const int ox = (lx + (DX) < 0) ? -1 : ((lx + (DX) >= TX) ? 1 : 0);                   \
-    const int oy = (ly + (DY) < 0) ? -1 : ((ly + (DY) >= TY) ? 1 : 0);                   \
-    const int oz = (lz + (DZ) < 0) ? -1 : ((lz + (DZ) >= TZ) ? 1 : 0);                   \
-    if (ox | oy | oz) nbr_dirty[(ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)] = 1;             \
-  }
-        if (lx < H || lx >= TX - H || ly < H || ly >= TY - H || lz < H || lz >= TZ - H) {
-          FIESTA_STENCIL24(FIESTA_WAKE)
-        }
-#undef FIESTA_WAKE
-      }
-      const unsigned long long b = __ballot(e);
-      if (lz == 0 && x < g.nx && y < g.ny && z < g.nz) {
-        const uint32_t bits = (tid & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
-        const int64_t wi = g.bitword(x, y, z);
-        a.rbits[wi] = had_epoch ? (a.rbits[wi] | bits) : bits;
-      }
-    }
-    // stats (one atomic per wave)
-    {
-      uint32_t v = nwrites;
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-      if ((tid & 63) == 0 && v) atomicAdd(&a.counters[C_WRITES], (unsigned long long)v);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      a.tile_epoch[t] = a.epoch;
-      atomicAdd(&a.counters[C_SWEEPS], (unsigned long long)nsweeps);
-      atomicAdd(&a.counters[C_VISITS], 1ull);
-    }
-    if (tid < 27 && nbr_dirty[tid]) {
-      const int ox = tid / 9 - 1, oy = (tid / 3) % 3 - 1, oz = tid % 3 - 1;
-      const int ntx_ = tx + ox, nty_ = ty + oy, ntz_ = tz + oz;
-      if ((unsigned)ntx_ < (unsigned)a.tg.ntx && (unsigned)nty_ < (unsigned)a.tg.nty &&
-          (unsigned)ntz_ < (unsigned)a.tg.ntz)
-        activate_tile((ntx_ * a.tg.nty + nty_) * a.tg.ntz + ntz_, a.flag_next, a.list_next, a.count_next);
-    }
-    __syncthreads();  // L and nbr_dirty are reused by the next tile of this work-group
-  }
-}
-
-
 // =====================================================================================================
 // queries
 // =====================================================================================================
@@ -728,7 +543,8 @@ __global__ void k_count_updated(Geom g, const vox_t *before, const vox_t *now, c
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned long long local = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += stride) {
-    const vox_t a = before[i] & ~kAct, b = now[i] & ~kAct;
+    const vox_t a = before[i] == kUnobserved ? kUnobserved : (before[i] & ~kAct);
+    const vox_t b = now[i] == kUnobserved ? kUnobserved : (now[i] & ~kAct);
     if (a == b) continue;
     const int z = i % g.nz, y = (i / g.nz) % g.ny, x = i / ((int64_t)g.nz * g.ny);
     const int gx = x + g.gx0, gy = y + g.gy0, gz = z + g.gz0;
@@ -741,6 +557,17 @@ __global__ void k_count_updated(Geom g, const vox_t *before, const vox_t *now, c
       upd = !obstacle_alive(g, occbits, gocc, cx, cy, cz);
     }
     local += upd && g.owned(x, y, z);
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+
+// Observed voxels that carry no obstacle (bulk-path precondition, see DenseMap::stale_inf_).
+__global__ void k_count_stale(Geom g, const vox_t *coc, unsigned long long *out) {
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const vox_t w = coc[i];
+    local += (w != kUnobserved) && (w & kNoCoc);
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
@@ -814,22 +641,10 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   g.oz1 = glo[2] + gs[2] - 1;
   nbitwords_ = (int64_t)g.nx * g.ny * g.nzw;
 
-  // tile_shape: 0 = default engine. 1..4 = v1 Jacobi-sweep engine (k_relax) with 8x8 / 16x8 / 16x16 / 4x8
-  // tiles, kept for A/B measurements; 10.. = work-queue engine (k_relax_q).
-  switch (cfg.tile_shape) {
-    case 1: tx_ = 8, ty_ = 8, engine_ = 0; break;
-    case 2: tx_ = 16, ty_ = 8, engine_ = 0; break;
-    case 3: tx_ = 16, ty_ = 16, engine_ = 0; break;
-    case 4: tx_ = 4, ty_ = 8, engine_ = 0; break;
-    case 10: tx_ = 8, ty_ = 8, engine_ = 1; break;
-    case 0:  // 1024 threads = 4 waves/SIMD under a 128-VGPR cap; the push runs in four batches of 6 directions to fit
-    case 11: tx_ = 16, ty_ = 16, engine_ = 1; break;
-    case 12: tx_ = 16, ty_ = 8, engine_ = 1; break;
-    case 13: tx_ = 16, ty_ = 16, engine_ = 1, threads_ = 512; break;  // 2 waves/SIMD, 213 VGPRs, single 24-batch
-    case 14: tx_ = 8, ty_ = 8, engine_ = 1, threads_ = 512; break;    // 58 KB of LDS: TWO work-groups per CU
-    default: throw Error(FIESTA_HIP_ERR_INVALID, "unknown tile_shape");
-  }
-  if (sharded && engine_ != 1) throw Error(FIESTA_HIP_ERR_INVALID, "sharded maps need the work-queue engine");
+  if (cfg.update_engine < 0 || cfg.update_engine > 2) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
+  update_engine_ = cfg.update_engine;
+  if (update_engine_ == 0)  // (test suites run every scenario on both engines through this)
+    if (const char *e = getenv("FIESTA_HIP_UPDATE_ENGINE")) update_engine_ = std::min(2, std::max(0, atoi(e)));
   ntx_ = (g.nx + tx_ - 1) / tx_;
   nty_ = (g.ny + ty_ - 1) / ty_;
   ntz_ = (g.nz + 31) / 32;
@@ -876,6 +691,10 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   if (const char *e = getenv("FIESTA_HIP_LIST_THRESHOLD")) list_threshold_ = std::max(0, atoi(e));
   if (const char *e = getenv("FIESTA_HIP_BOUND_SCAN")) bound_scan_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
+  if (const char *e = getenv("FIESTA_HIP_BULK_RATIO")) bulk_ratio_ = atof(e);
+  if (const char *e = getenv("FIESTA_HIP_FT_S0")) ft_s0_ = atoi(e), ft_s0_fixed_ = true;
+  if (ft_s0_ != 16 && ft_s0_ != 32) throw Error(FIESTA_HIP_ERR_INVALID, "FIESTA_HIP_FT_S0 must be 16 or 32");
+  for (auto &e : ft_ev_) FIESTA_HIP_CHECK(hipEventCreate(&e));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
@@ -890,6 +709,8 @@ DenseMap::~DenseMap() {
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
   for (hipEvent_t e : evpool_) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ft_ev_)
+    if (e) (void)hipEventDestroy(e);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -1030,11 +851,13 @@ bool DenseMap::check_update() {  // CheckUpdate (src/ESDFMap.cpp:227-233)
 bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
   use_device();
   // C_TOUCHED, C_INSERT, C_DELETE are adjacent: one copy, one synchronisation
-  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_TOUCHED], &counters_[C_TOUCHED], 3 * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_TOUCHED], &counters_[C_TOUCHED], 5 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));  // ... + C_OBSERVED, C_NOCC
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   unsigned long long nt = touched_upper_ ? h_counters_[C_TOUCHED] : 0;
   unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
+  const unsigned long long obs_before = h_counters_[C_OBSERVED];
+  const long long nocc_before = (long long)h_counters_[C_NOCC];
   if (nt) {
     ins_.ensure(ni + nt, stream_, ni);
     del_.ensure(nd + nt, stream_, nd);
@@ -1044,11 +867,13 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
     FIESTA_HIP_CHECK(hipGetLastError());
     zero_counter(C_TOUCHED);
     touched_upper_ = 0;
-    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long),
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
                                     hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
     ni = h_counters_[C_INSERT];
     nd = h_counters_[C_DELETE];
+    // voxels observed for the first time while obstacles (or pending deletes of obstacles) exist: see stale_inf_
+    if (h_counters_[C_OBSERVED] != obs_before && (nocc_before > 0 || nd > 0)) stale_inf_ = true;
   }
   if (n_ins) *n_ins = (int64_t)ni;
   if (n_del) *n_del = (int64_t)nd;
@@ -1059,7 +884,7 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
 // distances so that the delete drain scans (box of the deleted obstacles) + (that radius) instead of the whole grid.
 // Default work-queue engine on an unsharded map only (ghost cells / remote deletes of a shard are not covered).
 void DenseMap::enable_distance_tracking() {
-  if (track_ || !bound_scan_ || engine_ != 1 || g_.sharded || tx_ != 16 || ty_ != 16 || threads_ == 512) return;
+  if (track_ || !bound_scan_ || g_.sharded) return;
   hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);
   FIESTA_HIP_CHECK(hipGetLastError());
   track_ = true;
@@ -1081,11 +906,6 @@ void DenseMap::collect_stats(fiesta_hip_stats *st) {
     st->tile_visits = (int64_t)h_counters_[C_VISITS];
     for (int k = 0; k < 8; ++k) st->prof[k] = (int64_t)h_counters_[C_PROF0 + k];
   }
-}
-
-template <int TX, int TY>
-static void launch_relax(const RelaxArgs &a, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL((k_relax<TX, TY>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 hipEvent_t DenseMap::pool_event(size_t i) {
@@ -1136,23 +956,15 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
                        : n_dev ? (int)std::min<uint32_t>(16384u, std::max<uint32_t>(256u, 4u * ncur))
                                : (int)std::min<uint32_t>(n_host, 16384u);
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
-    if (tx_ == 8 && ty_ == 8 && threads_ == 512)
-      hipLaunchKernelGGL((k_relax_q<8, 8, 512>), dim3(blocks), dim3(512), 0, stream_, a);
-    else if (tx_ == 8 && ty_ == 8)
-      hipLaunchKernelGGL((k_relax_q<8, 8, 256>), dim3(blocks), dim3(256), 0, stream_, a);
-    else if (tx_ == 16 && ty_ == 16 && threads_ == 512)
-      hipLaunchKernelGGL((k_relax_q<16, 16, 512>), dim3(blocks), dim3(512), 0, stream_, a);
-    else if (tx_ == 16 && ty_ == 16 && track_)
+    if (track_)
       hipLaunchKernelGGL((k_relax_q<16, 16, 1024, false, true>), dim3(blocks), dim3(1024), 0, stream_, a);
-    else if (tx_ == 16 && ty_ == 16)
-      hipLaunchKernelGGL((k_relax_q<16, 16, 1024>), dim3(blocks), dim3(1024), 0, stream_, a);
     else
-      hipLaunchKernelGGL((k_relax_q<16, 8, 512>), dim3(blocks), dim3(512), 0, stream_, a);
+      hipLaunchKernelGGL((k_relax_q<16, 16, 1024>), dim3(blocks), dim3(1024), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds + 1), stream_));
     ++rounds;
   };
-  while (ncur && engine_ == 1) {
+  while (ncur) {
     const int nxt = cur ^ 1;
     // Large updates walk all tiles in XCD-chunked spatial order, one round per host round trip. Small ones (few active
     // tiles: depth frames) use the compact list, and rounds go out in pairs: the second reads the length of its list
@@ -1172,39 +984,6 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
       ncur = n1 ? n2 : 0;
     }
   }
-  while (ncur) {
-    const int nxt = cur ^ 1;
-    zero_counter(C_LIST0 + nxt);
-    RelaxArgs a;
-    a.g = g_;
-    a.tg = tg;
-    a.coc = coc_;
-    a.rbits = rbits_;
-    a.tile_epoch = tile_epoch_;
-    a.epoch = epoch_;
-    a.list_cur = tile_list_[cur];
-    a.n_cur = ncur;
-    a.flag_cur = tile_flag_[cur];
-    a.flag_next = tile_flag_[nxt];
-    a.list_next = tile_list_[nxt];
-    a.count_next = &counters_[C_LIST0 + nxt];
-    a.counters = counters_;
-    const int blocks = (int)std::min<uint32_t>(ncur, 8192u);
-    FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
-    if (tx_ == 8 && ty_ == 8)
-      launch_relax<8, 8>(a, blocks, stream_);
-    else if (tx_ == 16 && ty_ == 8)
-      launch_relax<16, 8>(a, blocks, stream_);
-    else if (tx_ == 16 && ty_ == 16)
-      launch_relax<16, 16>(a, blocks, stream_);
-    else
-      launch_relax<4, 8>(a, blocks, stream_);
-    FIESTA_HIP_CHECK(hipGetLastError());
-    FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds + 1), stream_));
-    ++rounds;
-    ncur = (uint32_t)read_counter(C_LIST0 + nxt);
-    cur = nxt;
-  }
   if (st) {
     st->rounds = rounds;
     double sum = 0;
@@ -1218,11 +997,98 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
   }
 }
 
+// ---- the bulk path: whole-grid exact feature transform (ft_core.hpp / ft_kernels.hpp) -------------------------------
+// Valid when the reference's propagation has nothing to be gated by: every voxel of the array observed, the update
+// window = the whole array, one unsharded map.  Then the fixed point of src/ESDFMap.cpp:339-392 IS the Euclidean
+// feature transform of the occupied set, whatever the previous state was.
+bool DenseMap::bulk_applicable() const {
+  const Geom &g = g_;
+  return !g.sharded && g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1;
+}
+
+template <int S, int LANES, int WAVES>
+static void launch_ft_plane(const FtArgs &a, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((k_ft_plane<S, LANES, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, s, a);
+}
+template <int S, int LANES, int WAVES>
+static void launch_ft_x(const FtArgs &a, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((k_ft_x<S, LANES, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, s, a);
+}
+
+void DenseMap::run_bulk(fiesta_hip_stats *st) {
+  const Geom &g = g_;
+  FtArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nx = g.nx, a.ny = g.ny, a.nz = g.nz, a.nzw = g.nzw, a.nzc = (g.nz + 63) / 64;
+  a.gx0 = g.gx0, a.gy0 = g.gy0, a.gz0 = g.gz0;
+  const uint32_t items_a = (uint32_t)(g.nx * a.nzc), items_b = (uint32_t)(g.ny * a.nzc);
+  const uint32_t cap = std::max(items_a, items_b);
+  ft_inter_.ensure((size_t)g.n, stream_);
+  ft_rowlist_.ensure((size_t)g.nx * g.ny, stream_);
+  ft_rowcnt_.ensure((size_t)g.nx + 32, stream_);  // + the 1024-bit plane mask
+  ft_ovf_.ensure((size_t)cap * 6, stream_);
+  a.occbits = occbits_;
+  a.rowlist = ft_rowlist_.p;
+  a.rowcnt = ft_rowcnt_.p;
+  a.planemask = reinterpret_cast<uint32_t *>(ft_rowcnt_.p + g.nx);
+  FIESTA_HIP_CHECK(hipMemsetAsync(a.planemask, 0, 32 * sizeof(uint32_t), stream_));
+  a.inter = ft_inter_.p;
+  a.coc = coc_;
+  a.maxd2 = track_ ? &counters_[C_MAXD2] : nullptr;
+  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 6 * sizeof(unsigned long long), stream_));
+  if (track_) zero_counter(C_MAXD2);
+  FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[0], stream_));
+  hipLaunchKernelGGL(k_ft_rows, dim3(g.nx), dim3(256), 0, stream_, a);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[1], stream_));
+  // four tiers per pass: rings of S0 (16 or 32) entries for everybody, then 64, 256 and finally 1024 entries x 16
+  // lanes for the column groups whose deque outgrew the tier before (lists and their lengths stay on the device)
+  auto tiers = [&](const bool pass_a, const uint32_t n0, const int ovf0) {
+    FtArgs t = a;
+    t.items = nullptr, t.n_items_dev = nullptr, t.n_items = n0;
+    t.ovf_list = ft_ovf_.p + (size_t)(pass_a ? 0 : 3) * cap, t.ovf_count = &counters_[ovf0];
+    const int blocks0 = (int)((n0 + 3) / 4);
+    if (pass_a) {
+      if (ft_s0_ == 16) launch_ft_plane<16, 64, 4>(t, blocks0, stream_);
+      else launch_ft_plane<32, 64, 4>(t, blocks0, stream_);
+    } else {
+      if (ft_s0_ == 16) launch_ft_x<16, 64, 4>(t, blocks0, stream_);
+      else launch_ft_x<32, 64, 4>(t, blocks0, stream_);
+    }
+    FIESTA_HIP_CHECK(hipGetLastError());
+    auto next = [&]() {
+      t.items = t.ovf_list, t.n_items_dev = t.ovf_count, t.n_items = 0;
+      t.ovf_list += cap, t.ovf_count = t.ovf_count + 1;
+    };
+    next();
+    if (pass_a) launch_ft_plane<64, 64, 2>(t, 2048, stream_);
+    else launch_ft_x<64, 64, 2>(t, 2048, stream_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    next();
+    if (pass_a) launch_ft_plane<256, 64, 1>(t, 1024, stream_);
+    else launch_ft_x<256, 64, 1>(t, 1024, stream_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    next();
+    t.ovf_list = nullptr, t.ovf_count = nullptr;
+    if (pass_a) launch_ft_plane<1024, 16, 1>(t, 1024, stream_);
+    else launch_ft_x<1024, 16, 1>(t, 1024, stream_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  };
+  tiers(true, items_a, C_FT_OVF0);
+  FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[2], stream_));
+  tiers(false, items_b, C_FT_OVF0 + 3);
+  FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[3], stream_));
+  if (st) {
+    st->bulk = 1;
+    st->relax_launches = 9;
+  }
+}
+
 void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const auto h0 = std::chrono::steady_clock::now();
-  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));  // C_INSERT, C_DELETE, C_OBSERVED, C_NOCC
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   const unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
   const bool remote_del = g_.sharded && read_counter(C_REMOTE_DEL) != 0;
@@ -1230,6 +1096,8 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     memset(st, 0, sizeof(*st));
     st->inserted = (int64_t)ni;
     st->deleted = (int64_t)nd;
+    st->observed_voxels = (int64_t)h_counters_[C_OBSERVED];
+    st->occupied_voxels = (int64_t)h_counters_[C_NOCC];
   }
   if (ni == 0 && nd == 0 && !seed_only) {
     if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
@@ -1240,6 +1108,45 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
   reset_stats_counters();
   zero_counter(C_LIST0);
+  // Engine choice.  The bulk transform costs one fixed sweep over the grid; the frontier rounds cost in proportion to
+  // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).
+  if (!seed_only && update_engine_ != 1 && (long long)h_counters_[C_OBSERVED] == (long long)g_.n && bulk_applicable()) {
+    const double nocc = (double)(long long)h_counters_[C_NOCC];
+    bool want = update_engine_ == 2 || (double)(ni + nd) >= bulk_ratio_ * std::max(nocc, 1.0);
+    if (want && stale_inf_) {  // re-validate: does any observed voxel still wait for its first wave?
+      zero_counter(C_SCRATCH);
+      hipLaunchKernelGGL(k_count_stale, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
+                         &counters_[C_SCRATCH]);
+      FIESTA_HIP_CHECK(hipGetLastError());
+      // (with no obstacle before this update every voxel legitimately reads "no obstacle")
+      if (read_counter(C_SCRATCH) == 0 || (long long)(nocc - (double)ni + (double)nd) <= 0) stale_inf_ = false;
+      want = !stale_inf_;
+    }
+    if (want) {
+      run_bulk(st);
+      zero_counter(C_INSERT);
+      zero_counter(C_DELETE);
+      FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
+      collect_stats(st);
+      FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+      if (st) {
+        float ms = 0, m1 = 0, m2 = 0, m3 = 0;
+        FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+        FIESTA_HIP_CHECK(hipEventElapsedTime(&m1, ft_ev_[0], ft_ev_[1]));
+        FIESTA_HIP_CHECK(hipEventElapsedTime(&m2, ft_ev_[1], ft_ev_[2]));
+        FIESTA_HIP_CHECK(hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]));
+        st->device_ms = ms;
+        st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
+        st->relax_ms = (double)m1 + m2 + m3;
+        for (int k = 0; k < 6; ++k) st->ft_overflow[k] = (int64_t)h_counters_[C_FT_OVF0 + k];
+        // adapt the first tier to the scene: deep deques (far from obstacles) -> start with the 32-entry rings next time
+        const int64_t spill = st->ft_overflow[0] + st->ft_overflow[3];
+        if (!ft_s0_fixed_ && ft_s0_ == 16 && spill * 50 > (int64_t)(g_.nx + g_.ny) * ((g_.nz + 63) / 64)) ft_s0_ = 32;
+        st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+      }
+      return;
+    }
+  }
   if (ni) {
     hipLaunchKernelGGL(k_seed_insert, dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, g_, tg,
                        (const uint32_t *)ins_.p, (int64_t)ni, coc_, (const uint32_t *)occbits_, tile_flag_[0],
@@ -1470,6 +1377,7 @@ void DenseMap::snapshot_save(int slot) {
     FIESTA_HIP_CHECK(hipMemcpyAsync(s.del.p, del_.p, nd * 4, hipMemcpyDeviceToDevice, stream_));
   }
   s.g = g_;
+  s.stale_inf = stale_inf_;
   s.valid = true;
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -1504,6 +1412,7 @@ void DenseMap::snapshot_restore(int slot) {
   FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
   touched_upper_ = (int64_t)nt;
   g_ = s.g;
+  stale_inf_ = s.stale_inf;
   if (track_) {  // the snapshot may predate the tracking: recompute the distance bound for the restored field
     zero_counter(C_MAXD2);
     hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);

@@ -40,6 +40,8 @@ enum Counter {
   C_TOUCHED = 0,   // length of the touched-voxel list (the reference's occupancy_queue_)
   C_INSERT,        // insert_queue_
   C_DELETE,        // delete_queue_
+  C_OBSERVED,      // voxels observed at least once (first-observation transitions counted by k_fuse)
+  C_NOCC,          // occupied voxels (Exist() count), kept by k_fuse
   C_MAXD2,         // upper bound of every finite d^2 the work-queue engine ever stored (bounds the delete scan)
   C_DBOX0,         // bounding box of the pending delete queue, local voxel coordinates: min x,y,z then max x,y,z
   C_DBOX5 = C_DBOX0 + 5,
@@ -51,6 +53,8 @@ enum Counter {
   C_VISITS,
   C_SCRATCH,
   C_REMOTE_DEL,  // sharded maps: some shard reported an occupied->free transition since the last UpdateESDF
+  C_FT_OVF0,     // bulk path: lengths of the ring-overflow lists (pass A tiers 0-2, pass B tiers 0-2)
+  C_FT_OVF5 = C_FT_OVF0 + 5,
   C_PROF0,  // 8 profiling slots (FIESTA_HIP_PROF=1): cycles in stage / propagate / write-back, queue items, ...
   C_COUNT = C_PROF0 + 8
 };
@@ -63,6 +67,7 @@ struct Snapshot {
   DevBuf<uint32_t> touched, ins, del;
   unsigned long long counters[C_COUNT];
   Geom g;
+  bool stale_inf = false;
   bool valid = false;
 };
 
@@ -140,6 +145,8 @@ class DenseMap {
   void zero_counter(int which);
   void ensure_touched_capacity(int64_t extra);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list);
+  bool bulk_applicable() const;
+  void run_bulk(fiesta_hip_stats *st);
   void reset_stats_counters();
   void enable_distance_tracking();
   void collect_stats(fiesta_hip_stats *st);
@@ -163,11 +170,23 @@ class DenseMap {
   int64_t nbitwords_ = 0;
 
   // tiles
-  int tx_ = 8, ty_ = 8;  // tile extent in x,y (z extent is always 32)
+  static constexpr int tx_ = 16, ty_ = 16;  // tile extent in x,y (z extent is always 32)
   int ntx_ = 0, nty_ = 0, ntz_ = 0, ntiles_ = 0;
   uint32_t *tile_epoch_ = nullptr;
-  int threads_ = 1024;                          // work-group size of k_relax_q for 16x16 tiles
-  int engine_ = 1;                              // 0: Jacobi sweeps (k_relax), 1: LDS work queue (k_relax_q)
+  // UpdateESDF engine (fiesta_hip_config.update_engine): 0 = choose per update, 1 = frontier rounds only,
+  // 2 = bulk feature transform whenever the map state allows it
+  int update_engine_ = 0;
+  double bulk_ratio_ = 0.04;  // auto: bulk when (inserts + deletes) exceed this fraction of the occupied voxels
+  // Late observations: a voxel first observed while obstacles exist stays at "no obstacle" until a wave reaches it
+  // (the reference never queues it), so the field is no longer the transform of the occupied set and the bulk path is
+  // off until a scan finds no such voxel left (k_count_stale) or the map holds no obstacle.
+  bool stale_inf_ = false;
+  int ft_s0_ = 16;            // ring size of the bulk path's first tier: 16, or 32 once a scene needed deeper deques
+  bool ft_s0_fixed_ = false;  // (FIESTA_HIP_FT_S0 pins it)
+  DevBuf<uint32_t> ft_inter_, ft_ovf_;
+  DevBuf<uint16_t> ft_rowlist_;
+  DevBuf<int32_t> ft_rowcnt_;
+  hipEvent_t ft_ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t *cbits_[2] = {nullptr, nullptr};     // 1 bit/voxel: changed in the round of that parity
   uint32_t *cstamp_[2] = {nullptr, nullptr};    // per tile: serial of the round that wrote cbits_[parity]
   int prof_ = 0;

@@ -1,0 +1,324 @@
+// fiesta_amd/csrc/ft_kernels.hpp -- gfx950 kernels of the BULK UpdateESDF path: the exact feature transform of the
+// whole occupied set in three separable passes (see ft_core.hpp for why this equals the reference's fixed point on
+// fully observed maps, and dense_map.hip: update_esdf for when it is used).
+//
+//   k_ft_rows    per x-plane: which z-rows hold an occupied voxel (ordered list + count)        reads 1 bit / voxel
+//   k_ft_plane   pass A, per plane x: nearest occupied voxel of the SAME plane for every (y, z)  writes 4 B / voxel
+//                (z: nearest set bit of a row, straight from the occupancy bitmap; y: lower envelope over the plane's
+//                non-empty rows only -- a scalar loop that skips the ~85 % of rows that are empty in a scatter scene)
+//   k_ft_x       pass B, per (y, z) column: lower envelope along x over the planes' candidates    reads 4 B, writes 4 B
+//
+// Work decomposition: one WAVE owns one column group -- 64 consecutive z (the lane axis, contiguous in HBM: every
+// load and store of a step is one 256-byte row segment) -- and walks the scan axis serially; each lane runs its own
+// LaneEnvelope with its deque in LDS (ring[slot][lane]: a lane always hits its own bank, no conflicts).  The deque is
+// bounded because positions are emitted as soon as they are final; emission is lock-step across the wave (a position
+// is written when it is final in all 64 lanes) so that stores stay coalesced.  If a ring of S entries overflows, the
+// wave appends its item to a list and the next tier (bigger rings, fewer resident waves) redoes those items.
+#pragma once
+#include "common.hpp"
+#include "ft_core.hpp"
+
+namespace fiesta {
+
+struct FtArgs {
+  int nx, ny, nz, nzw, nzc;  // nzc = 64-voxel column groups per z-row
+  int gx0, gy0, gz0;         // global coordinates of local voxel (0,0,0): sites are stored in global coordinates
+  const uint32_t *occbits;   // [nx][ny][nzw]
+  uint16_t *rowlist;         // [nx][ny]: non-empty rows of plane x, ascending
+  int32_t *rowcnt;           // [nx]
+  uint32_t *planemask;       // [32]: bit x = plane x holds a site (zeroed before k_ft_rows)
+  uint32_t *inter;           // [nx][ny][nz]: pass A result, y' << 10 | z' (local coordinates)
+  vox_t *coc;                // the map's voxel words (pass B output)
+  // work items: implicit 0..n_items-1 (items == nullptr) or an explicit list whose length lives on the device
+  const uint32_t *items;
+  const unsigned long long *n_items_dev;
+  uint32_t n_items;
+  uint32_t *ovf_list;  // items whose ring overflowed, for the next tier
+  unsigned long long *ovf_count;
+  unsigned long long *maxd2;  // optional: atomicMax of every d^2 written (maps that track it)
+};
+
+// LDS rings of one wave: site[slot][lane] (4 B) + start[slot][lane] (2 B).  LANES < 64: only the first LANES lanes of
+// the wave carry a column (the deepest tier trades lanes for depth).
+template <int S, int LANES>
+struct LdsRing {
+  uint32_t *s;
+  uint16_t *st;
+  __device__ __forceinline__ uint32_t site(int i) const { return s[i * LANES]; }
+  __device__ __forceinline__ int start(int i) const { return st[i * LANES]; }
+  __device__ __forceinline__ void set(int i, uint32_t v, int b) {
+    s[i * LANES] = v;
+    st[i * LANES] = (uint16_t)b;
+  }
+};
+struct FtMetricA {  // column along y at lane z; site = y' << 10 | z'
+  int z;
+  __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> 10); }
+  __device__ __forceinline__ int f(uint32_t s) const {
+    const int d = z - (int)(s & 1023u);
+    return ft::mul24(d, d);
+  }
+};
+struct FtMetricB {  // column along x at (y, z); site = x' << 20 | y' << 10 | z'
+  int y, z;
+  __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> 20); }
+  __device__ __forceinline__ int f(uint32_t s) const {
+    const int dy = y - (int)((s >> 10) & 1023u), dz = z - (int)(s & 1023u);
+    return ft::mul24(dy, dy) + ft::mul24(dz, dz);
+  }
+};
+
+// ---- per plane: ordered list of the rows that hold at least one occupied voxel -------------------------------------
+__global__ __launch_bounds__(256) void k_ft_rows(FtArgs a) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int x = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int y0 = 0; y0 < a.ny; y0 += 256) {
+    const int y = y0 + tid;
+    bool any = false;
+    if (y < a.ny) {
+      const uint32_t *row = a.occbits + ((int64_t)x * a.ny + y) * a.nzw;
+      uint32_t acc = 0;
+      if ((a.nzw & 3) == 0) {
+        for (int w = 0; w < a.nzw; w += 4) {
+          const uint4 q = *reinterpret_cast<const uint4 *>(row + w);
+          acc |= q.x | q.y | q.z | q.w;
+        }
+      } else {
+        for (int w = 0; w < a.nzw; ++w) acc |= row[w];
+      }
+      any = acc != 0;
+    }
+    const unsigned long long m = __ballot(any);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (any) a.rowlist[(int64_t)x * a.ny + off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)y;
+    __syncthreads();
+    if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.rowcnt[x] = base;
+    if (base) atomicOr(&a.planemask[x >> 5], 1u << (x & 31));
+  }
+}
+
+__device__ __forceinline__ void ft_overflow(const FtArgs &a, uint32_t id, int lane) {
+  if (lane == 0 && a.ovf_list) a.ovf_list[atomicAdd(a.ovf_count, 1ull)] = id;
+}
+
+// ---- pass A: in-plane nearest site.  item = x * nzc + c: plane x, lanes z = 64 c + lane ------------------------------
+template <int S, int LANES, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
+  constexpr int RB = 16;  // bitmap rows staged per batch
+  __shared__ uint32_t ring_site[WAVES][S * LANES];
+  __shared__ uint16_t ring_start[WAVES][S * LANES];
+  __shared__ uint32_t rowstage[WAVES][RB][32];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int SUB = 64 / LANES;  // sub-items per column group when a wave only carries LANES columns
+  const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
+  for (uint32_t it = blockIdx.x * WAVES + wave; it < n; it += gridDim.x * WAVES) {
+    const uint32_t id = a.items ? a.items[it / SUB] : it / SUB;
+    const int sub = (int)(it % SUB);
+    const int x = (int)(id / (uint32_t)a.nzc), c = (int)(id % (uint32_t)a.nzc);
+    const int cnt = __builtin_amdgcn_readfirstlane(a.rowcnt[x]);
+    if (cnt == 0) continue;  // pass B never reads an empty plane
+    const int k = sub * LANES + lane;  // position inside the 64-voxel group
+    const int z = 64 * c + k;
+    const bool act = lane < LANES && z < a.nz;
+    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricA> env;
+    env.r = LdsRing<S, LANES>{&ring_site[wave][lane % LANES], &ring_start[wave][lane % LANES]};
+    env.m = FtMetricA{z};
+    env.init();
+    int p_out = 0;
+    bool failed = false;
+    uint32_t *out = a.inter + (int64_t)x * a.ny * a.nz + (act ? z : 0);
+    const uint16_t *rows = a.rowlist + (int64_t)x * a.ny;
+    for (int i0 = 0; i0 < cnt && !failed; i0 += RB) {
+      // stage the bitmap words of the next RB non-empty rows: two dependent loads per batch instead of per row
+      const int nb = min(RB, cnt - i0);
+      const int ylist = rows[min(i0 + lane, cnt - 1)];  // lanes 0..nb-1: the rows of this batch; lane RB: the one after
+      const int ynext_batch = (i0 + RB < cnt) ? __builtin_amdgcn_readlane(ylist, RB) : ft::kFarAhead;
+      __builtin_amdgcn_wave_barrier();
+      for (int j = lane; j < nb * 32; j += 64) {
+        const int r = j >> 5, w = j & 31;
+        const int yr = __shfl(ylist, r);
+        rowstage[wave][r][w] = w < a.nzw ? a.occbits[((int64_t)x * a.ny + yr) * a.nzw + w] : 0u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int r = 0; r < nb; ++r) {
+        const int yr = __builtin_amdgcn_readlane(ylist, r);
+        const int ynext = (r + 1 < nb) ? __builtin_amdgcn_readlane(ylist, r + 1) : ynext_batch;
+        // nearest occupied voxel of this row for every lane: own 64-bit chunk + nearest set bit outside it
+        const uint32_t wv = lane < 32 ? rowstage[wave][r][lane] : 0u;
+        const unsigned long long nonempty = __ballot(wv != 0u);
+        unsigned long long chunk = rowstage[wave][r][2 * c];
+        if (2 * c + 1 < a.nzw) chunk |= (unsigned long long)rowstage[wave][r][2 * c + 1] << 32;
+        int left_out = -1, right_out = -1;
+        const unsigned long long below = nonempty & ((1ull << (2 * c)) - 1ull);
+        const unsigned long long above = (2 * c + 2 < 64) ? (nonempty >> (2 * c + 2)) << (2 * c + 2) : 0ull;
+        if (below) {
+          const int iw = 63 - __clzll((long long)below);
+          left_out = 32 * iw + 31 - __clz((int)__builtin_amdgcn_readlane(wv, iw));
+        }
+        if (above) {
+          const int iw = __ffsll((long long)above) - 1;
+          right_out = 32 * iw + __ffs((int)__builtin_amdgcn_readlane(wv, iw)) - 1;
+        }
+        int d;
+        const int zp = ft::nearest_in_row(chunk, 64 * c, k, left_out, right_out, d);
+        const uint32_t site = ((uint32_t)yr << 10) | (uint32_t)(zp & 1023);
+        const int key = yr * yr + ft::mul24(d, d);
+        for (;;) {  // pop while any lane wants to
+          const bool want = act && env.wants_pop(yr, key);
+          if (!__ballot(want)) break;
+          env.pop(want);
+        }
+        env.place(act, site, yr, key, a.ny, p_out);
+        if (__ballot(env.overflow)) {
+          failed = true;
+          break;
+        }
+        while (p_out < a.ny && p_out < ynext) {
+          const bool fin = !act || env.final_at(p_out, ynext);
+          if (__ballot(fin) != ~0ull) break;
+          const bool adv = __ballot(act && env.advances_at(p_out)) != 0ull;
+          const uint32_t s = env.emit(p_out, act, adv);
+          if (act) *out = s;
+          out += a.nz;
+          ++p_out;
+        }
+      }
+    }
+    if (failed) ft_overflow(a, id, lane);
+  }
+}
+
+// ---- pass B: lower envelope along x.  item = y * nzc + c: row y, lanes z = 64 c + lane ------------------------------
+// Memory choreography of one wave: the planes' candidates are prefetched a whole batch (P planes, one 256-byte row
+// segment each) ahead into registers, and emitted words are parked in an LDS staging buffer and stored at the batch
+// boundary BEFORE the next prefetch is issued.  gfx9's vmcnt is one in-order counter for loads and stores: with stores
+// issued between a prefetch and its use, the wait for the prefetch would also wait for those stores to reach HBM.
+template <int S, int LANES, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
+  constexpr int P = 8, OB = 16;
+  static_assert(P == 8, "the hand-written wait below names eight registers");
+  __shared__ uint32_t ring_site[WAVES][S * LANES];
+  __shared__ uint16_t ring_start[WAVES][S * LANES];
+  __shared__ uint32_t stage[WAVES][OB * LANES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int SUB = 64 / LANES;
+  const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
+  uint32_t acc_maxd2 = 0;
+  // which planes hold any site: bit x of the 1024-bit mask, word w in lane w
+  const uint32_t pm = lane < 32 ? a.planemask[lane] : 0u;
+  auto plane_has = [&](const int x) -> bool { return (__builtin_amdgcn_readlane(pm, (x >> 5) & 31) >> (x & 31)) & 1u; };
+  for (uint32_t it = blockIdx.x * WAVES + wave; it < n; it += gridDim.x * WAVES) {
+    const uint32_t id = a.items ? a.items[it / SUB] : it / SUB;
+    const int sub = (int)(it % SUB);
+    const int y = (int)(id / (uint32_t)a.nzc), c = (int)(id % (uint32_t)a.nzc);
+    const int z = 64 * c + sub * LANES + lane;
+    const bool act = lane < LANES && z < a.nz;
+    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricB> env;
+    env.r = LdsRing<S, LANES>{&ring_site[wave][lane % LANES], &ring_start[wave][lane % LANES]};
+    env.m = FtMetricB{y, z};
+    env.init();
+    int p_out = 0, p_stored = 0;  // positions [p_stored, p_out) sit in the staging buffer
+    bool failed = false;
+    const int64_t plane = (int64_t)a.ny * a.nz, col = (int64_t)y * a.nz + (act ? z : 0);
+    const uint32_t *in = a.inter + col;
+    vox_t *out = a.coc + col;
+    uint32_t *stg = &stage[wave][lane % LANES];
+    const uint32_t goff = ((uint32_t)a.gx0 << 20) | ((uint32_t)a.gy0 << 10) | (uint32_t)a.gz0;
+    vox_t *optr = out;  // -> position p_stored of this column
+    auto flush = [&]() {
+      for (int p = p_stored; p < p_out; ++p) {
+        if (act) *optr = stg[(p & (OB - 1)) * LANES];
+        optr += plane;
+      }
+      p_stored = p_out;
+    };
+    // emits what is final; returns true if it had to stop because the staging buffer is full (the caller flushes and
+    // calls again: stores stay out of this loop, see the note on vmcnt above)
+    auto drain = [&](const int x_next) -> bool {
+      while (p_out < a.nx && p_out < x_next) {
+        const bool fin = !act || env.final_at(p_out, x_next);
+        if (__ballot(fin) != ~0ull) break;
+        if (p_out - p_stored == OB) return true;
+        const bool adv = __ballot(act && env.advances_at(p_out)) != 0ull;
+        const uint32_t s = env.emit(p_out, act, adv);
+        if (act) stg[(p_out & (OB - 1)) * LANES] = s + goff;  // (no carries: every global coordinate is below 1024)
+        if (a.maxd2) acc_maxd2 = max(acc_maxd2, (uint32_t)(ft::mul24(p_out, p_out - 2 * env.c_q) + env.c_key));
+        ++p_out;
+      }
+      return false;
+    };
+    // The prefetch is issued and waited for BY HAND (inline asm): hipcc's wait-count pass otherwise drains vmcnt to 0
+    // in front of every inner loop that might store (one full HBM round trip per step).  Loads are unconditional: a
+    // plane without sites is simply never looked at.
+    uint32_t w[P], wn[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const uint32_t *ptr = in + (int64_t)min(u, a.nx - 1) * plane;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(wn[u]) : "v"(ptr) : "memory");
+    }
+    for (int x0 = 0; x0 < a.nx && !failed; x0 += P) {
+      flush();
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(wn[4]), "+v"(wn[5]), "+v"(wn[6]), "+v"(wn[7])
+                   :
+                   : "memory");
+#pragma unroll
+      for (int u = 0; u < P; ++u) w[u] = wn[u];
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const uint32_t *ptr = in + (int64_t)min(x0 + P + u, a.nx - 1) * plane;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(wn[u]) : "v"(ptr) : "memory");
+      }
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int x = x0 + u;
+        if (x >= a.nx || failed) break;
+        if (plane_has(x)) {
+          const uint32_t site = ((uint32_t)x << 20) | (w[u] & 0xFFFFFu);
+          const int key = env.key_of(site);
+          for (;;) {  // pop while any lane wants to
+            const bool want = act && env.wants_pop(x, key);
+            if (!__ballot(want)) break;
+            env.pop(want);
+          }
+          env.place(act, site, x, key, a.nx, p_out);
+          if (__ballot(env.overflow)) {
+            failed = true;
+            break;
+          }
+        }
+        while (drain(x + 1)) flush();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, unused prefetch)
+    if (failed) {
+      ft_overflow(a, id, lane);
+      continue;
+    }
+    if (__ballot(act && !env.empty())) {
+      while (drain(ft::kFarAhead)) flush();
+      flush();
+    } else {  // no occupied voxel anywhere: "observed, no obstacle"
+      for (int p = 0; p < a.nx; ++p)
+        if (act) out[(int64_t)p * plane] = kInf;
+    }
+  }
+  if (a.maxd2) {
+    for (int off = 32; off > 0; off >>= 1) acc_maxd2 = max(acc_maxd2, (uint32_t)__shfl_xor((int)acc_maxd2, off));
+    if (lane == 0 && (unsigned long long)acc_maxd2 > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)acc_maxd2);
+  }
+}
+
+}  // namespace fiesta

@@ -34,7 +34,7 @@ class ESDFMap:
     """Drop-in for ``fiesta::ESDFMap``; array mode by default, hash-block mode with ``mode="hash"``."""
 
     def __init__(self, origin, resolution, map_size=None, reserve_size=0, mode="array", device=0,
-                 tile_shape=0, shard_lo=None, global_grid=None):
+                 update_engine=0, shard_lo=None, global_grid=None):
         self._lib = _lib.load()
         cfg = Config()
         cfg.mode = 0 if mode == "array" else 1
@@ -43,7 +43,7 @@ class ESDFMap:
         cfg.resolution = float(resolution)
         cfg.map_size[:] = list(_d3(map_size if map_size is not None else (0, 0, 0)))
         cfg.reserve_size = int(reserve_size)
-        cfg.tile_shape = int(tile_shape)
+        cfg.update_engine = {"auto": 0, "rounds": 1, "bulk": 2}.get(update_engine, update_engine)
         if shard_lo is not None:
             cfg.shard_lo[:] = [int(v) for v in shard_lo]
             cfg.global_grid[:] = [int(v) for v in global_grid]

@@ -194,7 +194,7 @@ class ShardedESDFMap:
     builds one shard engine; the default builds fiesta_amd.ESDFMap on `devices[rank % len(devices)]`."""
 
     def __init__(self, origin, resolution, global_grid, n_shards, transport=None, devices=(0,), make_shard=None,
-                 tile_shape=0):
+                 update_engine=0):
         self.origin = np.asarray(origin, np.float64).reshape(3)
         self.resolution = float(resolution)
         self.global_grid = tuple(int(v) for v in global_grid)
@@ -205,7 +205,7 @@ class ShardedESDFMap:
             from .esdf_map import ESDFMap
 
             def make_shard(rank, origin, res, size_m, lo, gg):
-                return ESDFMap(origin, res, size_m, device=devices[rank % len(devices)], tile_shape=tile_shape,
+                return ESDFMap(origin, res, size_m, device=devices[rank % len(devices)], update_engine=update_engine,
                                shard_lo=lo, global_grid=gg)
         self.shards, self.plans, self.infos = {}, {}, {}
         for r in self.transport.local_ranks:

@@ -48,7 +48,9 @@ typedef struct fiesta_hip_config {
   double resolution;    /* metres per voxel */
   double map_size[3];   /* array mode: grid = ceil(map_size/resolution) (src/ESDFMap.cpp:175-176) */
   int32_t reserve_size; /* hash mode: initial voxel reserve (src/ESDFMap.cpp:141-145) */
-  int32_t tile_shape;   /* 0 = default; engine tuning knob, results do not depend on it */
+  int32_t update_engine; /* UpdateESDF engine: 0 = chosen per update (default), 1 = frontier rounds only, 2 = bulk
+                            feature transform whenever the map is fully observed; on maps where both
+                            apply the distances do not depend on it */
   /* Spatial sharding. A map may be one shard of a larger global grid: it owns the global
    * voxel box [shard_lo, shard_lo + grid) and stores closest-obstacle ids in GLOBAL coordinates. For an
    * unsharded map leave these zero. */
@@ -70,6 +72,10 @@ typedef struct fiesta_hip_stats {
   double relax_ms;       /* sum of the HIP-event durations of the relaxation launches (k_relax) */
   int64_t relax_launches;
   int64_t prof[8];       /* engine profiling counters (only with FIESTA_HIP_PROF=1 in the environment) */
+  int64_t bulk;          /* 1: this update ran the bulk feature transform (rounds == 0), relax_ms = its kernels */
+  double ft_rows_ms, ft_plane_ms, ft_x_ms; /* bulk path: HIP-event time of k_ft_rows / pass A / pass B */
+  int64_t ft_overflow[6];/* bulk path: column groups that outgrew the ring of pass A tiers 0-2, pass B tiers 0-2 */
+  int64_t observed_voxels, occupied_voxels; /* map totals at entry (array mode): observed at least once / Exist() */
 } fiesta_hip_stats;
 
 const char *fiesta_hip_last_error(void);

@@ -34,3 +34,12 @@ def hip_lib():
     if fiesta_amd.device_count() < 1:
         pytest.fail("libfiesta_hip.so loaded but no gfx950 device is usable: GPU tests cannot fall back")
     return lib
+
+
+@pytest.fixture(params=["rounds", "bulk"])
+def engine(request, monkeypatch):
+    """Runs a GPU test once per UpdateESDF engine: frontier rounds only / bulk feature transform wherever the map state
+    allows it (maps created without an explicit update_engine read FIESTA_HIP_UPDATE_ENGINE).  On fully observed maps
+    both must reproduce the reference exactly; elsewhere "bulk" falls back to the rounds by itself."""
+    monkeypatch.setenv("FIESTA_HIP_UPDATE_ENGINE", {"rounds": "1", "bulk": "2"}[request.param])
+    return request.param

@@ -1,0 +1,253 @@
+// tests/cpp/ft_model.cpp -- TEST INFRASTRUCTURE: host model of the bulk feature-transform kernels.
+//
+// Compiles fiesta_amd/csrc/ft_core.hpp (the per-lane envelope machine the HIP kernels instantiate with LDS rings) with
+// g++ and drives it exactly the way ft_kernels.hpp does -- 64-lane "waves", lock-step emission, ring overflow ->
+// retry on the next tier -- so that the integer logic is checked against brute force on a machine without a GPU
+// (tests/test_ft_model.py).  Not part of the product: libfiesta_hip.so never links this file.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../fiesta_amd/csrc/ft_core.hpp"
+
+using namespace fiesta::ft;
+
+namespace {
+constexpr uint32_t kNone = 0x80000000u;
+constexpr int W = 64;  // lanes per wave
+
+struct VecRing {
+  uint32_t *s;
+  uint16_t *st;
+  uint32_t site(int i) const { return s[i]; }
+  int start(int i) const { return st[i]; }
+  void set(int i, uint32_t v, int b) {
+    s[i] = v;
+    st[i] = (uint16_t)b;
+  }
+};
+struct MetricA {  // pass A: site = y' << 10 | z', column along y at lane z
+  int z;
+  int q(uint32_t s) const { return (int)(s >> 10); }
+  int f(uint32_t s) const {
+    const int d = z - (int)(s & 1023u);
+    return d * d;
+  }
+};
+struct MetricB {  // pass B: site = x' << 20 | y' << 10 | z', column along x at (y, z)
+  int y, z;
+  int q(uint32_t s) const { return (int)(s >> 20); }
+  int f(uint32_t s) const {
+    const int dy = y - (int)((s >> 10) & 1023u), dz = z - (int)(s & 1023u);
+    return dy * dy + dz * dz;
+  }
+};
+
+struct Model {
+  int nx, ny, nz, nzw;
+  const uint32_t *bits;  // [nx][ny][nzw]
+  std::vector<uint16_t> rowlist;  // [nx][ny]: the non-empty rows of plane x, ascending
+  std::vector<int> rowcnt;        // [nx]
+  std::vector<uint32_t> inter;    // [nx][ny][nz]: y' << 10 | z' of the in-plane nearest site (planes with sites only)
+  int max_depth = 0;
+
+  template <int S>
+  bool plane_item(int x, int c) {  // pass A for plane x, lanes z = 64 c + k; false: ring overflow
+    std::vector<uint32_t> rs(S * W);
+    std::vector<uint16_t> rst(S * W);
+    LaneEnvelope<S, VecRing, MetricA> env[W];
+    bool act[W];
+    for (int k = 0; k < W; ++k) {
+      env[k].r = VecRing{&rs[k * S], &rst[k * S]};
+      env[k].m = MetricA{64 * c + k};
+      env[k].init();
+      act[k] = 64 * c + k < nz;
+    }
+    const int cnt = rowcnt[x];
+    int p_out = 0;
+    auto drain = [&](int x_next) {
+      while (p_out < ny && p_out < x_next) {
+        bool all = true, adv = false;
+        for (int k = 0; k < W; ++k) all = all && (!act[k] || env[k].final_at(p_out, x_next));
+        if (!all) break;
+        for (int k = 0; k < W; ++k) adv = adv || (act[k] && env[k].advances_at(p_out));
+        for (int k = 0; k < W; ++k) {
+          const uint32_t s = env[k].emit(p_out, act[k], adv);
+          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = s & 0xFFFFFu;
+        }
+        ++p_out;
+      }
+    };
+    for (int i = 0; i < cnt; ++i) {
+      const int yr = rowlist[(size_t)x * ny + i];
+      const uint32_t *row = bits + ((size_t)x * ny + yr) * nzw;
+      unsigned long long chunk = row[2 * c];
+      if (2 * c + 1 < nzw) chunk |= (unsigned long long)row[2 * c + 1] << 32;
+      int left_out = -1, right_out = -1;
+      for (int w = 0; w < 2 * c && w < nzw; ++w)
+        if (row[w]) left_out = 32 * w + 31 - __builtin_clz(row[w]);
+      for (int w = nzw - 1; w >= 2 * c + 2; --w)
+        if (row[w]) right_out = 32 * w + __builtin_ctz(row[w]);
+      uint32_t site[W];
+      int key[W];
+      for (int k = 0; k < W; ++k) {
+        int d;
+        const int zp = nearest_in_row(chunk, 64 * c, k, left_out, right_out, d);
+        site[k] = ((uint32_t)yr << 10) | (uint32_t)zp;
+        key[k] = yr * yr + d * d;
+      }
+      for (;;) {  // pop while any lane wants to (wave vote), then place
+        bool any = false;
+        bool want[W];
+        for (int k = 0; k < W; ++k) any = (want[k] = act[k] && env[k].wants_pop(yr, key[k])) || any;
+        if (!any) break;
+        for (int k = 0; k < W; ++k) env[k].pop(want[k]);
+      }
+      for (int k = 0; k < W; ++k) {
+        env[k].place(act[k], site[k], yr, key[k], ny, p_out);
+        if (env[k].overflow) return false;
+        if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
+      }
+      drain(i + 1 < cnt ? (int)rowlist[(size_t)x * ny + i + 1] : kFarAhead);
+    }
+    return p_out == ny;
+  }
+
+  template <int S>
+  bool column_item(int y, int c, uint32_t *out) {  // pass B for row y, lanes z = 64 c + k
+    std::vector<uint32_t> rs(S * W);
+    std::vector<uint16_t> rst(S * W);
+    LaneEnvelope<S, VecRing, MetricB> env[W];
+    bool act[W];
+    for (int k = 0; k < W; ++k) {
+      env[k].r = VecRing{&rs[k * S], &rst[k * S]};
+      env[k].m = MetricB{y, 64 * c + k};
+      env[k].init();
+      act[k] = 64 * c + k < nz;
+    }
+    int p_out = 0;
+    auto drain = [&](int x_next) {
+      while (p_out < nx && p_out < x_next) {
+        bool all = true, adv = false;
+        for (int k = 0; k < W; ++k) all = all && (!act[k] || env[k].final_at(p_out, x_next));
+        if (!all) break;
+        for (int k = 0; k < W; ++k) adv = adv || (act[k] && env[k].advances_at(p_out));
+        for (int k = 0; k < W; ++k) {
+          const uint32_t s = env[k].emit(p_out, act[k], adv);
+          if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = s;
+        }
+        ++p_out;
+      }
+    };
+    int last = -1;
+    for (int x = 0; x < nx; ++x)
+      if (rowcnt[x]) last = x;
+    for (int x = 0; x <= last; ++x) {
+      if (rowcnt[x]) {
+        uint32_t site[W];
+        int key[W];
+        for (int k = 0; k < W; ++k) {
+          const uint32_t w = act[k] ? inter[((size_t)x * ny + y) * nz + 64 * c + k] : 0u;
+          site[k] = ((uint32_t)x << 20) | w;
+          key[k] = env[k].key_of(site[k]);
+        }
+        for (;;) {
+          bool any = false;
+          bool want[W];
+          for (int k = 0; k < W; ++k) any = (want[k] = act[k] && env[k].wants_pop(x, key[k])) || any;
+          if (!any) break;
+          for (int k = 0; k < W; ++k) env[k].pop(want[k]);
+        }
+        for (int k = 0; k < W; ++k) {
+          env[k].place(act[k], site[k], x, key[k], nx, p_out);
+          if (env[k].overflow) return false;
+          if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
+        }
+      }
+      drain(x == last ? kFarAhead : x + 1);
+    }
+    if (last < 0) {
+      for (int p = 0; p < nx; ++p)
+        for (int k = 0; k < W; ++k)
+          if (act[k]) out[((size_t)p * ny + y) * nz + 64 * c + k] = kNone;
+      return true;
+    }
+    return p_out == nx;
+  }
+};
+
+template <int S>
+int run_tier(Model &m, uint32_t *out, std::vector<int> &items_a, std::vector<int> &items_b) {
+  const int nzc = (m.nz + 63) / 64;
+  std::vector<int> oa, ob;
+  for (int it : items_a)
+    if (!m.plane_item<S>(it / nzc, it % nzc)) oa.push_back(it);
+  items_a.swap(oa);
+  if (!items_a.empty()) return 1;  // pass B needs every plane
+  for (int it : items_b)
+    if (!m.column_item<S>(it / nzc, it % nzc, out)) ob.push_back(it);
+  items_b.swap(ob);
+  return items_b.empty() ? 0 : 1;
+}
+}  // namespace
+
+// occ: nx*ny*nz bytes (x-major, z fastest).  out: packed closest site x<<20|y<<10|z, or 0x80000000 when there is no
+// site at all.  S0: ring size of the first tier (4, 8, 32 or 64); overflowing items go to 256, then 1024.
+// stats[0] = deepest ring seen, stats[1] = items that overflowed tier 0 (pass A + pass B), stats[2] = tier 1.
+extern "C" int ft_model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, uint32_t *out, int *stats) {
+  if (nx > 1024 || ny > 1024 || nz > 1024) return -1;
+  Model m;
+  m.nx = nx, m.ny = ny, m.nz = nz, m.nzw = (nz + 31) / 32;
+  std::vector<uint32_t> bits((size_t)nx * ny * m.nzw, 0u);
+  for (size_t i = 0; i < (size_t)nx * ny * nz; ++i)
+    if (occ[i]) {
+      const size_t row = i / nz;
+      const int z = (int)(i % nz);
+      bits[row * m.nzw + (z >> 5)] |= 1u << (z & 31);
+    }
+  m.bits = bits.data();
+  m.rowlist.assign((size_t)nx * ny, 0);
+  m.rowcnt.assign(nx, 0);
+  for (int x = 0; x < nx; ++x)
+    for (int y = 0; y < ny; ++y) {
+      bool any = false;
+      for (int w = 0; w < m.nzw; ++w) any = any || bits[((size_t)x * ny + y) * m.nzw + w];
+      if (any) m.rowlist[(size_t)x * ny + m.rowcnt[x]++] = (uint16_t)y;
+    }
+  m.inter.assign((size_t)nx * ny * nz, 0xFFFFFFFFu);
+  const int nzc = (nz + 63) / 64;
+  std::vector<int> ia, ib;
+  for (int x = 0; x < nx; ++x)
+    if (m.rowcnt[x])
+      for (int c = 0; c < nzc; ++c) ia.push_back(x * nzc + c);
+  for (int y = 0; y < ny; ++y)
+    for (int c = 0; c < nzc; ++c) ib.push_back(y * nzc + c);
+  // pass A on every tier first (pass B reads all planes), then pass B
+  std::vector<int> none;
+  int r;
+  switch (S0) {
+    case 4: r = run_tier<4>(m, out, ia, none); break;
+    case 8: r = run_tier<8>(m, out, ia, none); break;
+    case 32: r = run_tier<32>(m, out, ia, none); break;
+    default: r = run_tier<64>(m, out, ia, none); break;
+  }
+  stats[1] = (int)ia.size();
+  if (!ia.empty()) run_tier<256>(m, out, ia, none);
+  stats[2] = (int)ia.size();
+  if (!ia.empty()) run_tier<1024>(m, out, ia, none);
+  if (!ia.empty()) return -2;
+  switch (S0) {
+    case 4: r = run_tier<4>(m, out, none, ib); break;
+    case 8: r = run_tier<8>(m, out, none, ib); break;
+    case 32: r = run_tier<32>(m, out, none, ib); break;
+    default: r = run_tier<64>(m, out, none, ib); break;
+  }
+  stats[1] += (int)ib.size();
+  if (!ib.empty()) run_tier<256>(m, out, none, ib);
+  stats[2] += (int)ib.size();
+  if (!ib.empty()) run_tier<1024>(m, out, none, ib);
+  (void)r;
+  stats[0] = m.max_depth;
+  return ib.empty() ? 0 : -3;
+}

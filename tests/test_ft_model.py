@@ -1,0 +1,106 @@
+"""The bulk path's integer machinery (fiesta_amd/csrc/ft_core.hpp: streaming lower envelope, nearest set bit of a row)
+checked on the CPU: tests/cpp/ft_model.cpp drives the very header the HIP kernels instantiate -- 64-lane waves,
+lock-step emission, ring overflow and the retry tiers -- and the result must be the exact Euclidean feature transform
+(squared distances equal to scipy's EDT; every closest site occupied).  No GPU, no oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "cpp", "ft_model.cpp")
+LIB = os.path.join(HERE, "cpp", "libft_model.so")
+CORE = os.path.join(os.path.dirname(HERE), "fiesta_amd", "csrc", "ft_core.hpp")
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(CORE)):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", LIB, SRC], check=True)
+    lib = C.CDLL(LIB)
+    lib.ft_model_run.restype = C.c_int
+    lib.ft_model_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def run(lib, occ, S0):
+    nx, ny, nz = occ.shape
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    out = np.empty(occ.shape, np.uint32)
+    stats = np.zeros(3, np.int32)
+    rc = lib.ft_model_run(occ.ctypes.data, nx, ny, nz, S0, out.ctypes.data, stats.ctypes.data)
+    assert rc == 0, rc
+    return out, stats
+
+
+def check_exact(occ, out):
+    nx, ny, nz = occ.shape
+    if not occ.any():
+        assert np.all(out == 0x80000000)
+        return
+    idx = ndimage.distance_transform_edt(occ == 0, return_distances=False, return_indices=True)
+    gx, gy, gz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    want = (idx[0] - gx) ** 2 + (idx[1] - gy) ** 2 + (idx[2] - gz) ** 2
+    cx, cy, cz = (out >> 20).astype(np.int64), ((out >> 10) & 1023).astype(np.int64), (out & 1023).astype(np.int64)
+    assert np.all(out < 0x40000000)
+    assert cx.max() < nx and cy.max() < ny and cz.max() < nz
+    assert np.all(occ[cx, cy, cz] == 1), "closest site is not occupied"
+    got = (cx - gx) ** 2 + (cy - gy) ** 2 + (cz - gz) ** 2
+    bad = np.flatnonzero(got != want)
+    assert len(bad) == 0, f"{len(bad)} voxels differ from the exact transform, first {np.unravel_index(bad[:3], occ.shape)}"
+
+
+CASES = [
+    ((20, 24, 70), 0.002, 11), ((33, 17, 130), 0.0005, 12), ((40, 40, 64), 0.01, 13), ((7, 50, 65), 0.05, 14),
+    ((48, 48, 96), 0.0001, 15), ((16, 16, 200), 0.3, 16), ((5, 5, 5), 0.1, 17), ((64, 3, 129), 0.003, 18),
+]
+
+
+@pytest.mark.parametrize("shape,density,seed", CASES)
+@pytest.mark.parametrize("S0", [64, 4])
+def test_random_scatter_is_exact(model, shape, density, seed, S0):
+    rng = np.random.RandomState(seed)
+    occ = (rng.rand(*shape) < density).astype(np.uint8)
+    if not occ.any():
+        occ[tuple(rng.randint(0, s) for s in shape)] = 1
+    out, stats = run(model, occ, S0)
+    check_exact(occ, out)
+    if S0 == 4 and density <= 0.01 and min(shape) > 8:
+        assert stats[1] > 0, "a 4-entry ring must overflow somewhere on sparse fields (the retry tiers were not exercised)"
+
+
+def test_no_site_and_single_site(model):
+    occ = np.zeros((9, 10, 70), np.uint8)
+    out, _ = run(model, occ, 64)
+    check_exact(occ, out)
+    occ[8, 0, 69] = 1
+    out, stats = run(model, occ, 64)
+    check_exact(occ, out)
+
+
+def test_walls_and_shells_need_deep_rings(model):
+    """A wall parallel to a column makes every position a different winner: the deque is as deep as twice the
+    distance; a 32-entry ring overflows and the 256/1024 tiers take over."""
+    occ = np.zeros((70, 40, 66), np.uint8)
+    occ[:, 2, :] = 1          # wall y = 2
+    occ[35, 30:40, 10:60] = 1  # plate
+    g = np.stack(np.meshgrid(np.arange(70), np.arange(40), np.arange(66), indexing="ij"), -1)
+    r = np.sqrt(((g - np.array([30, 20, 30])) ** 2).sum(-1))
+    occ[np.abs(r - 14) < 0.6] = 1
+    out, stats = run(model, occ, 32)
+    check_exact(occ, out)
+    out2, stats2 = run(model, occ, 8)
+    check_exact(occ, out2)
+    assert stats2[1] > 0
+
+
+def test_far_field_of_a_wall(model):
+    occ = np.zeros((150, 12, 64), np.uint8)
+    occ[:, 0, :] = 1  # wall; the far rows are 11 voxels away, columns along x see one new winner per position
+    occ[:, 11, 5] = 0
+    out, stats = run(model, occ, 8)
+    check_exact(occ, out)
+    assert stats[0] >= 8 and stats[1] > 0

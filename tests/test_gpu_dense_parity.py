@@ -11,13 +11,13 @@ import pytest
 
 from scenarios import Both, all_voxels, assert_exact, compare_dense
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("engine")]
 
 
-def make_pair(oracle_libs, kind, n, res=0.1, origin=(0, 0, 0), tile_shape=0):
+def make_pair(oracle_libs, kind, n, res=0.1, origin=(0, 0, 0)):
     import fiesta_amd
     size = tuple(np.asarray(n if not np.isscalar(n) else (n, n, n)) * res)
-    gpu = fiesta_amd.ESDFMap(origin, res, size, tile_shape=tile_shape)
+    gpu = fiesta_amd.ESDFMap(origin, res, size)
     cpu = oracle_libs.OracleMap(origin, res, size, kind=kind)
     assert gpu.grid_size == cpu.grid_size
     assert gpu.grid_total_size_ == cpu.grid_total_size
@@ -36,13 +36,13 @@ def observe_all(b, n=None):
     assert sg["inserted"] == 0 and sg["deleted"] == 0
 
 
-@pytest.mark.parametrize("tile_shape", [0, 1, 2, 3, 4, 10, 12])
-def test_insert_then_delete_fully_observed(hip_lib, oracle_libs, best_oracle_kind, tile_shape):
-    n = 48
-    b = make_pair(oracle_libs, best_oracle_kind, n, tile_shape=tile_shape)
+@pytest.mark.parametrize("n", [48, (37, 50, 70), (20, 24, 130)])
+def test_insert_then_delete_fully_observed(hip_lib, oracle_libs, best_oracle_kind, n):
+    b = make_pair(oracle_libs, best_oracle_kind, n)
     observe_all(b, n)
     rng = np.random.RandomState(7)
-    S = rng.randint(0, n, (300, 3)).astype(np.int32)
+    dims = np.array(b.gpu.grid_size)
+    S = (rng.randint(0, 1 << 20, (300, 3)) % dims).astype(np.int32)
     b.make_occupied(S)
     sg, sc = b.esdf()
     assert sg["inserted"] == sc["inserted"] > 0
@@ -50,7 +50,7 @@ def test_insert_then_delete_fully_observed(hip_lib, oracle_libs, best_oracle_kin
     assert_exact(rep)
     assert rep["finite"] == b.gpu.grid_total_size_
     # delete half, insert some new ones in the same UpdateESDF
-    b.mixed(rng.randint(0, n, (100, 3)).astype(np.int32), S[:150])
+    b.mixed((rng.randint(0, 1 << 20, (100, 3)) % dims).astype(np.int32), S[:150])
     sg, sc = b.esdf()
     assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
     assert sg["deleted"] > 0

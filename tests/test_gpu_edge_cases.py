@@ -8,7 +8,7 @@ import pytest
 
 from scenarios import P_DEFAULT
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("engine")]
 
 
 def test_empty_batches_and_noop_updates(hip_lib):
@@ -63,7 +63,7 @@ def test_largest_axis_and_rejected_configs(hip_lib):
     with pytest.raises(fiesta_amd.FiestaHipError):
         fiesta_amd.ESDFMap((0, 0, 0), -0.1, (1.0, 1.0, 1.0))
     with pytest.raises(fiesta_amd.FiestaHipError):
-        fiesta_amd.ESDFMap((0, 0, 0), 0.1, (1.0, 1.0, 1.0), tile_shape=99)
+        fiesta_amd.ESDFMap((0, 0, 0), 0.1, (1.0, 1.0, 1.0), update_engine=99)
     with pytest.raises(fiesta_amd.FiestaHipError):
         fiesta_amd.ESDFMap((0, 0, 0), 0.1, (1.0, 1.0, 1.0), device=63)
 

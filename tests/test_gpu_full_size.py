@@ -8,10 +8,13 @@ oracle comparison itself is done at <=128^3 (tests/test_gpu_dense_parity.py) and
                 and at exactly the stored distance;
   * idempotence a second UpdateESDF with empty queues changes nothing;
   * round trip  insert a batch, delete the same batch: the field returns to the previous d^2 field;
-  * engines     the Jacobi engine (k_relax) and the work-queue engine (k_relax_q) are independent
-                implementations: they must agree on (almost) every voxel -- where they do not, the sampled
-                brute force above arbitrates.
+  * engines     the frontier rounds (k_relax_q) and the bulk feature transform (k_ft_*) are independent
+                implementations: they must agree on every voxel;
+  * digest      the reference itself, run once at 512^3 on the benchmark's inputs (tests/golden/make_golden_c2.py):
+                a CRC32 per x-slab of its squared distances pins all 134 M voxels of both checkpoints.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -98,28 +101,133 @@ def test_config2_512cube_50k_delta_properties(hip_lib):
 
 
 def test_engines_agree_256cube(hip_lib):
+    """The two UpdateESDF engines -- frontier rounds (k_relax_q) and the bulk feature transform (k_ft_*) -- share no code:
+    on a fully observed grid they must produce the same squared distance in EVERY voxel (ids may differ among ties)."""
     import fiesta_amd
     G, res = 256, 0.1
     fields = []
-    for ts in (0, 1):
+    for eng in ("rounds", "bulk"):
         rng = np.random.RandomState(7)
-        m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, tile_shape=ts)
+        m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, update_engine=eng)
         m.SetParameters(*P_DEFAULT)
         m.SetOriginalRange()
         _observe_all(m, G)
         A = rng.randint(0, G, (6250, 3)).astype(np.int32)
         _cycles(m, A, [], 3)
-        m.UpdateESDF()
+        st = m.UpdateESDF()
+        assert st["bulk"] == (eng == "bulk")
         _cycles(m, rng.randint(0, G, (3000, 3)).astype(np.int32), A[:3000], 6)
-        m.UpdateESDF()
+        st = m.UpdateESDF()
+        assert st["bulk"] == (eng == "bulk") and st["deleted"] > 0
         fields.append(m.download_field(("d2", "occ")))
         m.close()
     assert np.array_equal(fields[0]["occ"], fields[1]["occ"])
-    diff = np.flatnonzero(fields[0]["d2"] != fields[1]["d2"])
-    # vector propagation is not an exact EDT: isolated voxels may keep a distance that is off by one obstacle
-    # (the reference has the same property); the default engine must be the exact one wherever they differ
-    assert len(diff) <= 4, len(diff)
-    assert _brute_force_sample(fields[0]["d2"], fields[0]["occ"], G, np.random.RandomState(1), k=4000) == 0
+    rounds, bulk = fields[0]["d2"], fields[1]["d2"]
+    assert _brute_force_sample(bulk, fields[1]["occ"], G, np.random.RandomState(1), k=4000) == 0
+    # Vector propagation is not an exact transform on every voxel, and where it is not the result depends on the order
+    # in which the frontier reaches the voxel (the reference has the same property: tests/test_oracle_order_sensitivity.py).
+    # So the round engine may be FARTHER than the exact transform on a handful of voxels, never closer, and the bulk
+    # engine must be the exact one there (brute force over the occupied set).
+    diff = np.flatnonzero(rounds != bulk)
+    assert len(diff) <= 8, len(diff)
+    assert np.all(rounds[diff] > bulk[diff])
+    obs = np.flatnonzero(fields[1]["occ"]).astype(np.int64)
+    O = np.stack([obs // (G * G), (obs // G) % G, obs % G], -1)
+    V = np.stack([diff // (G * G), (diff // G) % G, diff % G], -1)
+    exact = ((V[:, None, :] - O[None, :, :]) ** 2).sum(-1).min(1) if len(diff) else np.zeros(0, np.int64)
+    assert np.array_equal(exact, bulk[diff])
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run_c2(scene, eng, gold):
+    """bench.py's C2 sequence on a 512^3 map; returns the int32 d^2 fields after the scatter insert and after the step."""
+    import fiesta_amd
+    from bench import Workload
+    G, res = int(gold["grid"][0]), 0.1
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, update_engine=eng)
+    assert m.grid_total_size_ == G ** 3
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    _observe_all(m, G)
+    w = Workload(G, int(gold["obstacles"]), seed=12345, scene=scene)
+    out = {}
+
+    def grab(cp, st):
+        assert (st["inserted"], st["deleted"]) == tuple(int(v) for v in gold[f"{cp}/stats"][:2])
+        assert st["bulk"] == (0 if eng == "rounds" else 1)   # auto: a delta this large takes the bulk path
+        f = m.download_field(("d2", "occ"))
+        assert int(f["occ"].sum()) == int(gold[f"{cp}/n_occ"])
+        out[cp] = f["d2"].astype(np.int32)
+
+    _cycles(m, w.initial(), [], 3)
+    grab("scatter", m.UpdateESDF())
+    new, old = w.next_step()
+    for c in range(3):
+        m.SetOccupancy(new, 1, want_ret=False)
+        if c == 2:
+            m.SetOccupancy(old, 0, want_ret=False)
+        m.UpdateOccupancy(True)
+    m.snapshot_save(0)
+    grab("step", m.UpdateESDF())
+    out["updated"] = m.snapshot_count_updated(0)
+    m.close()
+    return out
+
+
+def _slab_crc(d2, G):
+    import zlib
+    slab = G * G
+    return np.array([zlib.crc32(d2[x * slab:(x + 1) * slab].tobytes()) for x in range(G)], np.uint32)
+
+
+@pytest.mark.parametrize("scene", ["scatter", "surfaces"])
+def test_config2_512cube_matches_reference_digest(hip_lib, scene):
+    """BASELINE config 2 at FULL size against the reference itself.  tests/golden/make_golden_c2.py ran the verbatim
+    reference once on exactly bench.py's inputs (observe-all, 50 000-obstacle insert, then the 25 000 + 25 000 step) and
+    stored, per checkpoint, a CRC32 per x-slab of its squared distances, the same CRCs of the exact Euclidean transform
+    (scipy), and the list of voxels where the two differ: the reference's vector propagation is not exact on a handful
+    of voxels (scatter: 0 and 4 of 134 M; surfaces: thousands), it can only be FARTHER there, and which voxels those are
+    depends on the order of the inserts inside the batch (tests/test_oracle_order_sensitivity.py).  Contract, checked on
+    every one of the 2 x 134 M voxels:
+      * the default engine reproduces the exact transform slab for slab (CRC), i.e. the reference's value wherever the
+        reference is order-independent, and the exact value on the listed voxels (patching the listed voxels with the
+        reference's values reproduces the reference's CRCs too);
+      * the frontier-round engine equals the default engine except on a few order-sensitive voxels of its own, where it
+        is farther, never closer."""
+    gold = np.load(os.path.join(GOLD, f"c2_512_{scene}_digest.npz"))
+    G = int(gold["grid"][0])
+    bulk = _run_c2(scene, "auto", gold)
+    n_exc = 0
+    for cp in ("scatter", "step"):
+        d2 = bulk[cp]
+        crc = _slab_crc(d2, G)
+        bad = np.flatnonzero(crc != gold[f"{cp}/crc_exact"])
+        assert len(bad) == 0, f"{cp}: {len(bad)} of {G} x-slabs differ from the exact transform, first x = {bad[:5]}"
+        exc, ref = gold[f"{cp}/exc_idx"], gold[f"{cp}/exc_ref_d2"]
+        n_exc += len(exc)
+        assert np.all(d2[exc] < ref)
+        patched = d2.copy()
+        patched[exc] = ref
+        bad = np.flatnonzero(_slab_crc(patched, G) != gold[f"{cp}/crc"])
+        assert len(bad) == 0, f"{cp}: {len(bad)} x-slabs differ from the reference outside its listed inexact voxels"
+        fin = (patched >= 0) & (patched != 0x7FFFFFFF)
+        assert int(patched[fin].astype(np.int64).sum()) == int(gold[f"{cp}/sum_d2"])
+        del patched
+    # The benchmark's unit of work (SURVEY.md 8d: d^2 changed, or the old closest obstacle vanished).  Its second clause
+    # looks at WHICH of several equidistant obstacles a voxel pointed at before the step, and that choice is the
+    # reference's FIFO order (SURVEY.md 7.3-A), so the two counts agree to a fraction of a percent, not to the voxel.
+    ref_upd = int(gold["step/updated"])
+    print(f"{scene}: updated voxels of the step: gpu {bulk['updated']}, reference {ref_upd}")
+    assert abs(bulk["updated"] - ref_upd) <= 0.01 * ref_upd
+    rounds = _run_c2(scene, "rounds", gold)
+    for cp in ("scatter", "step"):
+        diff = np.flatnonzero(rounds[cp] != bulk[cp])
+        budget = max(16, 4 * len(gold[f"{cp}/exc_idx"]))
+        assert len(diff) <= budget, f"{cp}: frontier rounds differ from the exact transform on {len(diff)} voxels"
+        assert np.all(rounds[cp][diff] > bulk[cp][diff])
+        print(f"{scene}/{cp}: reference inexact on {len(gold[f'{cp}/exc_idx'])} voxels, frontier rounds on {len(diff)}")
 
 
 def test_config2_density_192cube_exact_vs_reference(hip_lib, oracle_libs, best_oracle_kind):

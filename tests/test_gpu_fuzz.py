@@ -10,7 +10,7 @@ import pytest
 
 from scenarios import P_DEFAULT, Both, all_voxels, assert_exact, compare_dense
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("engine")]
 
 
 def _make(oracle_libs, kind, size_vox, res, origin):

@@ -11,7 +11,7 @@ import pytest
 from golden_programs import PROGRAMS, golden_rays
 from scenarios import GpuAsOracle, assert_exact, compare_gpu_to_golden
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("engine")]
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
