@@ -17,11 +17,14 @@ identical *untimed* replay of the same K steps from a device snapshot (the diff 
 inside the timed region).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel k_relax_q: algorithmic bytes (16 B per updated voxel) over the
-                sum of its launch durations, measured live with HIP events on the map's own stream.
+  roofline      algorithmic bytes (16 B per updated voxel) over the SUM of the durations of every kernel
+                of UpdateESDF (bulk path: k_ft_rows + k_ft_plane + k_ft_x; frontier rounds: the k_relax_q launches),
+                measured live with HIP events on the map's own stream; `dominant_kernel` quotes k_ft_x alone.
   cpu_baseline  the CPU oracle (verbatim-compiled reference when oracle/_ref is present, else the pinned
                 restatement) timed on one host core on a bounded sample of the same workload (same obstacle
-                density on a 192^3 grid); rank 0, N=1 only.  A reported baseline, not the target.
+                density on a 224^3 grid, --cpu-grid); rank 0, N=1 only.  The one-off measurement of the reference
+                at the full 512^3 size (profiles/r02_cpu_512.json, ~2 min per UpdateESDF) is quoted beside it.
+                A reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -180,7 +183,7 @@ def run_c3(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from scenarios import depth_to_points, render_depth, yaw_pose
     import fiesta_amd
-    intr = dict(fx=384.4, fy=384.4, cx=323.1, cy=235.5)
+    from scenarios import INTRINSICS as intr  # the reference's defaults, src/parameters.cpp:21-24
     G, res = args.grid, 0.1
     half = G * res / 2
     origin, size = (-half, -half, -half), (G * res,) * 3
@@ -570,6 +573,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(args)
+            try:  # the one-off full-size run of the reference (build container, tests/golden/make_golden_c2.py)
+                full = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_512.json")))[args.scene]["steady_state_step"]
+                out["cpu_baseline"]["full_size_512"] = {"voxels_per_sec": full["voxels_per_sec"], "seconds": full["seconds"],
+                                                        "updated_voxels": full["updated_voxels"], "source": "profiles/r02_cpu_512.json"}
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     m.close()
     if dist:

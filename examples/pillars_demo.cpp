@@ -4,19 +4,32 @@
 //   g++ -std=c++17 -O2 -Iinclude examples/pillars_demo.cpp -Lfiesta_amd -lfiesta_hip -Wl,-rpath,$PWD/fiesta_amd -o pillars_demo
 #include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <set>
 
 #include "fiesta/ESDFMap.h"
 
-int main() {
+template <class Map>
+static int run(Map &map, bool hash) {
   using Eigen::Vector3d;
   using Eigen::Vector3i;
-  fiesta::ESDFMap map(Vector3d(-5, -5, 0), 0.2, Vector3d(10, 10, 5));
   map.SetParameters(0.70, 0.35, 0.12, 0.97, 0.80);
   map.SetOriginalRange();
-  std::printf("grid_total_size_ %d\n", map.grid_total_size_);
+  if (!hash) std::printf("grid_total_size_ %d\n", map.grid_total_size_);
+  // the per-frame de-duplication of the reference's caller keys on SetOccupancy's return value
+  // (include/Fiesta.h:221-232,253-273): it must differ from -10000 and identify the voxel
+  std::set<int> keys;
   for (int x = 0; x < 50; ++x)
     for (int y = 0; y < 50; ++y)
-      for (int z = 0; z < 25; ++z) map.SetOccupancy(Vector3i(x, y, z), 0);
+      for (int z = 0; z < 25; ++z) {
+        const int k = map.SetOccupancy(Vector3i(x, y, z), 0);
+        if (k == -10000) {
+          std::printf("rejected voxel %d %d %d\n", x, y, z);
+          return 1;
+        }
+        keys.insert(k);
+      }
+  std::printf("distinct keys %zu\n", keys.size());
   map.UpdateOccupancy(true);
   map.UpdateESDF();
   const int order[25] = {5, 2, 19, 16, 11, 22, 17, 24, 23, 14, 1, 10, 13, 8, 6, 18, 4, 9, 7, 20, 3, 0, 21, 15, 12};
@@ -43,7 +56,20 @@ int main() {
   Vector3d grad;
   const double d = map.GetDistWithGradTrilinear(Vector3d(0.33, -1.27, 2.2), grad);
   std::printf("checksum %.12f trilinear %.12f grad %.12f %.12f %.12f\n", sum, d, grad(0), grad(1), grad(2));
-  std::printf("outside %.1f %d\n", map.GetDistance(Vector3d(100, 0, 0)), map.SetOccupancy(Vector3d(100, 0, 0), 1));
+  if (!hash)
+    std::printf("outside %.1f %d\n", map.GetDistance(Vector3d(100, 0, 0)), map.SetOccupancy(Vector3d(100, 0, 0), 1));
   std::printf("38 UpdateESDF calls: %.3f ms total\n", total_ms);
   return 0;
+}
+
+// no argument: the array flavour, ESDFMap(origin, resolution, map_size); "hash": the hash-block flavour,
+// ESDFMap(origin, resolution, reserve_size) (the reference selects it with -DHASH_TABLE at compile time)
+int main(int argc, char **argv) {
+  using Eigen::Vector3d;
+  if (argc > 1 && std::strcmp(argv[1], "hash") == 0) {
+    fiesta::ESDFMap map(Vector3d(-5, -5, 0), 0.2, 100000);
+    return run(map, true);
+  }
+  fiesta::ESDFMap map(Vector3d(-5, -5, 0), 0.2, Vector3d(10, 10, 5));
+  return run(map, false);
 }

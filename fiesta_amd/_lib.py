@@ -101,6 +101,7 @@ def load():
         "fiesta_hip_destroy": (C.c_int, [vp]),
         "fiesta_hip_grid_size": (C.c_int, [vp, vp]),
         "fiesta_hip_grid_total_size": (C.c_int, [vp, vp]),
+        "fiesta_hip_voxel_key": (C.c_int, [vp, vp, C.c_int64, vp]),
         "fiesta_hip_set_prob_params": (C.c_int, [vp, dbl, dbl, dbl, dbl, dbl]),
         "fiesta_hip_set_update_range": (C.c_int, [vp, vp, vp, C.c_int]),
         "fiesta_hip_set_original_range": (C.c_int, [vp]),

@@ -115,6 +115,21 @@ int fiesta_hip_grid_total_size(fiesta_hip_map *m, int64_t *out) {
   });
 }
 
+int fiesta_hip_voxel_key(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32_t *out) {
+  return guarded([&] {
+    need(m && (n == 0 || (vox && out)), "null argument");
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t *v = vox + 3 * i;
+      if (m->dense) {
+        const fiesta::Geom &g = m->dense->geom();
+        out[i] = (v[0] - g.gx0) * g.ny * g.nz + (v[1] - g.gy0) * g.nz + (v[2] - g.gz0);
+      } else {
+        out[i] = HashMap::voxel_key(v[0], v[1], v[2]);
+      }
+    }
+  });
+}
+
 int fiesta_hip_set_prob_params(fiesta_hip_map *m, double p_hit, double p_miss, double p_min, double p_max,
                                double p_occ) {
   return guarded([&] {

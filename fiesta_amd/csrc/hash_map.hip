@@ -518,11 +518,7 @@ void HashMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int
   FIESTA_HIP_CHECK(hipGetLastError());
   if (ret && !dev) {  // the reference returns its internal index (allocation-order dependent); what callers rely on is
               // "-10000 = rejected, otherwise a key that identifies the voxel" (include/Fiesta.h:221,253)
-    for (int64_t i = 0; i < n; ++i) {
-      const int x = vox[3 * i] + kHalf, y = vox[3 * i + 1] + kHalf, z = vox[3 * i + 2] + kHalf;
-      const bool ok = (unsigned)x < (unsigned)kWin && (unsigned)y < (unsigned)kWin && (unsigned)z < (unsigned)kWin;
-      ret[i] = ok ? (int32_t)pack_coc(x, y, z) : FIESTA_HIP_UNDEFINED;
-    }
+    for (int64_t i = 0; i < n; ++i) ret[i] = voxel_key(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]);
   }
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }

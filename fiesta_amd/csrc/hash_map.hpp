@@ -25,6 +25,12 @@ class HashMap {
   static constexpr int kNTiles = kNTX * kNTY * kNTZ;
   static constexpr int kPageVox = kTX * kTY * kTZ, kPageRows = kTX * kTY;
 
+  // what SetOccupancy returns for a voxel: a key unique per voxel of the window, -10000 outside (see fiesta_hip_voxel_key)
+  static int32_t voxel_key(int vx, int vy, int vz) {
+    const int x = vx + kHalf, y = vy + kHalf, z = vz + kHalf;
+    const bool ok = (unsigned)x < (unsigned)kWin && (unsigned)y < (unsigned)kWin && (unsigned)z < (unsigned)kWin;
+    return ok ? (int32_t)pack_coc(x, y, z) : FIESTA_HIP_UNDEFINED;
+  }
   explicit HashMap(const fiesta_hip_config &cfg);
   ~HashMap();
 

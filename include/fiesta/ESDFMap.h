@@ -16,6 +16,7 @@
 //   * single-point queries cost one device round trip each -- use the *Batch forms in planners.
 //   * closest-obstacle ids are tie-equivalent, not FIFO-order-identical (parity contract).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <stdexcept>
@@ -89,7 +90,7 @@ class ESDFMap {
     pend_vox_.push_back(vox(2));
     pend_occ_.push_back(occ);
     if (pend_occ_.size() >= kFlushAt) Flush();
-    return Vox2Idx(vox);
+    return Vox2Idx(vox);  // the caller's de-duplication key (include/Fiesta.h:221-232,253-273); unique per voxel
   }
   int GetOccupancy(Eigen::Vector3d pos) {
     Flush();
@@ -106,7 +107,10 @@ class ESDFMap {
     return out;
   }
 
-  // Distance Field Management (src/ESDFMap.cpp:467-540)
+  // Distance Field Management (src/ESDFMap.cpp:467-540).  Rule for the buffered SetOccupancy calls: whatever can
+  // observe them flushes them first (CheckUpdate, UpdateOccupancy, GetOccupancy, the range setters, the exports);
+  // distance queries do NOT flush -- distances only change inside UpdateESDF, which only sees what UpdateOccupancy
+  // (a flush) fused before it, so pending observations cannot change any answer below.
   double GetDistance(Eigen::Vector3d pos) {
     double out = 0;
     const double p[3] = {pos(0), pos(1), pos(2)};
@@ -165,6 +169,7 @@ class ESDFMap {
   // equivalent invariant is: every finite voxel's closest obstacle is occupied and sits at the stored distance.
   bool CheckConsistency() {
     Flush();
+    if (hash_) return CheckConsistencyHash();
     const size_t n = (size_t)grid_total_size_;
     std::vector<int32_t> d2(n), coc(3 * n);
     std::vector<uint8_t> occ(n);
@@ -233,8 +238,31 @@ class ESDFMap {
   void Pos2Vox(const Eigen::Vector3d &p, Eigen::Vector3i &v) const {  // :74-77
     for (int i = 0; i < 3; ++i) v(i) = (int)std::floor((p(i) - origin_[i]) / res_);
   }
-  int Vox2Idx(const Eigen::Vector3i &v) const {  // :84-93 (array flavour)
-    return v(0) * gs_[1] * gs_[2] + v(1) * gs_[2] + v(2);
+  int Vox2Idx(const Eigen::Vector3i &v) const {  // :84-93; hash flavour: see fiesta_hip_voxel_key
+    if (!hash_) return v(0) * gs_[1] * gs_[2] + v(1) * gs_[2] + v(2);
+    const int32_t vox[3] = {v(0), v(1), v(2)};
+    int32_t key = FIESTA_HIP_UNDEFINED;
+    ck(fiesta_hip_voxel_key(h_, vox, 1, &key));
+    return key;
+  }
+  bool CheckConsistencyHash() {  // the same invariant over the allocated voxels of a hash-block map
+    int64_t n = 0;
+    ck(fiesta_hip_download_hash(h_, &n, nullptr, nullptr, nullptr, nullptr));
+    std::vector<int32_t> vox(3 * (size_t)n), d2((size_t)n), coc(3 * (size_t)n);
+    std::vector<uint8_t> occ((size_t)n);
+    if (n) ck(fiesta_hip_download_hash(h_, &n, vox.data(), d2.data(), coc.data(), occ.data()));
+    auto key = [](int64_t x, int64_t y, int64_t z) { return ((x + (1 << 20)) << 42) | ((y + (1 << 20)) << 21) | (z + (1 << 20)); };
+    std::vector<int64_t> occupied;
+    for (int64_t i = 0; i < n; ++i)
+      if (occ[i]) occupied.push_back(key(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]));
+    std::sort(occupied.begin(), occupied.end());
+    for (int64_t i = 0; i < n; ++i) {
+      if (d2[i] < 0 || d2[i] == INT32_MAX) continue;
+      const int64_t dx = vox[3 * i] - coc[3 * i], dy = vox[3 * i + 1] - coc[3 * i + 1], dz = vox[3 * i + 2] - coc[3 * i + 2];
+      if (dx * dx + dy * dy + dz * dz != d2[i]) return false;
+      if (!std::binary_search(occupied.begin(), occupied.end(), key(coc[3 * i], coc[3 * i + 1], coc[3 * i + 2]))) return false;
+    }
+    return true;
   }
 };
 

@@ -89,6 +89,12 @@ int fiesta_hip_destroy(fiesta_hip_map *m);
 /* array mode: grid_size_ and grid_total_size_ (include/ESDFMap.h:78,115); hash mode: allocated voxels. */
 int fiesta_hip_grid_size(fiesta_hip_map *m, int32_t out[3]);
 int fiesta_hip_grid_total_size(fiesta_hip_map *m, int64_t *out);
+/* What SetOccupancy(Vector3i) returns for each voxel WITHOUT observing it (host arithmetic only): the reference's
+ * callers test the value against -10000 and use it as the per-frame de-duplication key (include/Fiesta.h:221-232,
+ * 253-273), so it must identify the voxel.  Array mode: Vox2Idx = x*Ny*Nz + y*Nz + z (src/ESDFMap.cpp:84-93; no range
+ * check, like the reference).  Hash mode: the reference returns an allocation-order slot number; here a packed key of
+ * the voxel's window coordinates, unique per voxel, or FIESTA_HIP_UNDEFINED outside the addressable window. */
+int fiesta_hip_voxel_key(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32_t *out);
 
 /* ---- parameters and window ---- */
 /* ESDFMap::SetParameters (src/ESDFMap.cpp:218-224). */

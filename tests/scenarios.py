@@ -118,7 +118,48 @@ def compare_dense(gpu_map, cpu_map, check_logodds=True):
     both = finite_o & finite_g
     report["id_match"] = float((gc[both] == o["coc"][both]).all(-1).mean()) if both.any() else 1.0
     report["mismatch_idx"] = mism[:10]
+    # Where the two engines disagree (partially observed maps only: the reference's own result depends on its FIFO
+    # order there), the GPU value must still be a fixed point of the reference's operator, not just "some obstacle":
+    # signed counts, and the pair inequalities of src/ESDFMap.cpp:339-392 against the 24 observed stencil neighbours.
+    report["gpu_closer"] = int((gd2[mism] < od2[mism]).sum())
+    report["gpu_farther"] = int((gd2[mism] > od2[mism]).sum())
+    report["pair_violations"] = fixed_point_violations(gd2, gc, gs, mism)
     return report
+
+
+DIRS24 = np.array([(-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1), (-1, -1, 0), (1, 1, 0), (0, -1, -1),
+                   (0, 1, 1), (-1, 0, -1), (1, 0, 1), (-1, 1, 0), (1, -1, 0), (0, -1, 1), (0, 1, -1), (1, 0, -1), (-1, 0, 1),
+                   (-2, 0, 0), (2, 0, 0), (0, -2, 0), (0, 2, 0), (0, 0, -2), (0, 0, 2)], np.int64)  # include/parameters.h:54-68
+
+
+def fixed_point_violations(d2, coc, gs, idx, window=None):
+    """For the voxels `idx` (linear indices) of a field (d2: -1 unobserved / D2_INF / finite, coc n x 3): how many
+    (voxel, neighbour) pairs break the fixed point of the reference's 24-neighbour operator -- a finite voxel v and an
+    FINITE neighbour n must satisfy d(n) <= |n - coc(v)|^2 (v's push would have improved n) and d(v) <= |v - coc(n)|^2
+    (v's pull would have improved v).  A voxel without an obstacle next to a finite one is NOT a violation (a freshly
+    observed voxel waits for a wave, src/ESDFMap.cpp:246-249), so only finite-finite pairs are judged."""
+    idx = np.asarray(idx, np.int64)
+    if len(idx) == 0:
+        return 0
+    nx, ny, nz = gs
+    V = np.stack([idx // (ny * nz), (idx // nz) % ny, idx % nz], -1)
+    dv, cv = d2[idx].astype(np.int64), coc[idx].astype(np.int64)
+    fin_v = (dv >= 0) & (dv != D2_INF)
+    bad = 0
+    for e in DIRS24:
+        N = V + e
+        ok = np.all((N >= 0) & (N < np.array(gs)), axis=1)
+        if window is not None:
+            ok &= np.all((N >= window[0]) & (N <= window[1]), axis=1)
+        ni = (N[:, 0] * ny + N[:, 1]) * nz + N[:, 2]
+        ni = np.where(ok, ni, 0)
+        dn, cn = d2[ni].astype(np.int64), coc[ni].astype(np.int64)
+        obs_n = ok & (dn >= 0)
+        fin_n = obs_n & (dn != D2_INF)
+        push = fin_v & fin_n & (((N - cv) ** 2).sum(-1) < dn)          # v could still improve n
+        pull = fin_v & fin_n & (((V - cn) ** 2).sum(-1) < dv)          # n could still improve v
+        bad += int(push.sum()) + int(pull.sum())
+    return bad
 
 
 def assert_exact(report):
@@ -126,7 +167,7 @@ def assert_exact(report):
 
 
 # ---- synthetic depth frames -------------------------------------------------
-INTRINSICS = dict(fx=384.4, fy=384.4, cx=323.1, cy=235.5)  # shape of src/parameters.cpp:21-24 (values arbitrary)
+INTRINSICS = dict(fx=384.458089392, fy=383.982755697, cx=322.477357419, cy=237.076346481)  # src/parameters.cpp:21-24
 
 
 def yaw_pose(yaw_deg, position):

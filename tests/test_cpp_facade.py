@@ -46,6 +46,7 @@ def test_pillars_demo_matches_oracle(tmp_path, oracle_libs, best_oracle_kind):
     exe = build_demo(str(tmp_path))
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     assert "grid_total_size_ 62500" in out and out.count("consistent 1") == 2, out
+    assert "distinct keys 62500" in out, out
     got = [float(x) for x in re.search(r"checksum (\S+) trilinear (\S+) grad (\S+) (\S+) (\S+)", out).groups()]
     assert "outside -10000.0 -10000" in out
     # the same workload on the oracle
@@ -75,3 +76,42 @@ def test_pillars_demo_matches_oracle(tmp_path, oracle_libs, best_oracle_kind):
     dist, grad = m.GetDistWithGradTrilinear(np.array([[0.33, -1.27, 2.2]]))
     want = [want_sum, dist[0], grad[0, 0], grad[0, 1], grad[0, 2]]
     assert np.allclose(got, want, rtol=0, atol=1e-9), (got, want)  # printed with 12 decimals
+
+
+@pytest.mark.gpu
+def test_pillars_demo_hash_flavour_matches_hash_oracle(tmp_path, oracle_libs):
+    """The hash-block overload ESDFMap(origin, resolution, reserve_size) through the C++ class (the facade
+    returned vox.z as the key and divided by zero in CheckConsistency): SetOccupancy's return value must identify the
+    voxel -- it is the reference caller's per-frame de-dup key (include/Fiesta.h:221-232,253-273) -- and the field must
+    match the reference built with -DHASH_TABLE."""
+    exe = build_demo(str(tmp_path))
+    out = subprocess.run([exe, "hash"], capture_output=True, text=True, check=True).stdout
+    assert "distinct keys 62500" in out and out.count("consistent 1") == 2, out
+    got = [float(x) for x in re.search(r"checksum (\S+) trilinear (\S+) grad (\S+) (\S+) (\S+)", out).groups()]
+    kind = "ref" if oracle_libs.available("ref", "hash") else "port"
+    m = oracle_libs.OracleMap((-5.0, -5.0, 0.0), 0.2, reserve_size=100000, mode="hash", kind=kind)
+    m.SetParameters(0.70, 0.35, 0.12, 0.97, 0.80)
+    m.SetOriginalRange()
+    g = np.stack(np.meshgrid(np.arange(50), np.arange(50), np.arange(25), indexing="ij"), -1).reshape(-1, 3)
+    m.SetOccupancyVox(g.astype(np.int32), 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+
+    def pillar(k, occ, cycles):
+        px, py = -4 + 2 * (k // 5) + 0.01, -4 + 2 * (k % 5) + 0.01
+        pos = np.array([[px, py, 0.1 * i + 0.01] for i in range(50)])
+        for _ in range(cycles):
+            m.SetOccupancyPos(pos, occ)
+            m.UpdateOccupancy(True)
+        m.UpdateESDF()
+    for k in ORDER:
+        pillar(k, 1, 3)
+    for k in ORDER[:13]:
+        pillar(k, 0, 6)
+    lat = np.stack(np.meshgrid(np.arange(0, 50, 3), np.arange(0, 50, 3), np.arange(0, 25, 3), indexing="ij"), -1)
+    want_sum = 0.0
+    for d in m.GetDistanceVox(lat.reshape(-1, 3).astype(np.int32)):
+        want_sum += d
+    dist, grad = m.GetDistWithGradTrilinear(np.array([[0.33, -1.27, 2.2]]))
+    want = [want_sum, dist[0], grad[0, 0], grad[0, 1], grad[0, 2]]
+    assert np.allclose(got, want, rtol=0, atol=1e-9), (got, want)

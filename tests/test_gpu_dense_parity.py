@@ -126,17 +126,20 @@ def test_partial_observation_frontier_semantics(hip_lib, oracle_libs, best_oracl
     b.esdf()
     rep = compare_dense(b.gpu, b.cpu)
     assert rep["d2_mismatch"] <= 20, rep
+    assert rep["pair_violations"] == 0, rep
     # now observe the rest: freshly observed free voxels must stay at "infinity" until a wave passes
     b.observe(g[~keep], 0)
     b.fuse()
     b.esdf()
     rep2 = compare_dense(b.gpu, b.cpu)
     assert rep2["d2_mismatch"] <= 20, rep2
+    assert rep2["pair_violations"] == 0, rep2
     # a new insert sends a wave through
     b.make_occupied(rng.randint(0, n, (50, 3)).astype(np.int32))
     b.esdf()
     rep3 = compare_dense(b.gpu, b.cpu)
     assert rep3["d2_mismatch"] <= 0.002 * n ** 3, rep3
+    assert rep3["pair_violations"] == 0, rep3
 
 
 def test_queries_bit_exact(hip_lib, oracle_libs, best_oracle_kind):
@@ -188,6 +191,7 @@ def test_occupancy_fusion_logodds_and_positions(hip_lib, oracle_libs, best_oracl
         # the reference with the same observations shuffled changes up to 15 of ~5000 finite distances
         # ("parity contract"); budget 1 % of the finite voxels.
         assert rep["d2_mismatch"] <= max(30, 0.01 * rep["finite"]), rep
+        assert rep["pair_violations"] == 0, rep
 
 
 def test_update_window_clips_ingest(hip_lib, oracle_libs, best_oracle_kind):

@@ -97,6 +97,7 @@ def test_random_sequences_partially_observed(hip_lib, oracle_libs, best_oracle_k
         b.esdf()
         rep = compare_dense(b.gpu, b.cpu)
         assert rep["d2_mismatch"] <= max(10, 0.02 * rep["finite"]), rep
+        assert rep["pair_violations"] == 0, rep
 
 
 @pytest.mark.parametrize("seed", [61, 62, 63, 64])

@@ -27,6 +27,7 @@ def test_hip_matches_reference_fixture(hip_lib, name):
             # observations in another first-touch order changes 116-214 of 13766 finite distances
             # (0.8-1.6 %), see tests/test_oracle_order_sensitivity.py.  Budget 2 %.
             assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]), rep
+            assert rep["pair_violations"] == 0, rep
         else:
             assert_exact(rep)
         for k, v in extra.items():

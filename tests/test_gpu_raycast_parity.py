@@ -94,6 +94,7 @@ def test_frames_counts_exact_with_reference_dedup(hip_lib, oracle_libs, best_ora
         rep = compare_dense(gpu, cpu)
         # partially observed map: the reference itself is order-dependent here
         assert rep["d2_mismatch"] <= max(30, 0.01 * rep["finite"]), rep
+        assert rep["pair_violations"] == 0, rep
     assert touched_total > 30000
     assert gpu.download_field(("occ",))["occ"].sum() > 500
 
@@ -182,3 +183,36 @@ def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind):
         rep = compare_hash(gpu, cpu)
         assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]), rep
     assert touched_total > 30000 and rep["pages"] >= 8
+
+
+def test_config3_640x480_frames_reference_intrinsics(hip_lib, oracle_libs, best_oracle_kind):
+    """BASELINE config 3 at FULL size: the 512^3 @0.1 m map fed by 640 x 480 depth frames (307 200 rays) through the
+    device-side depth front end, with the reference's default intrinsics (src/parameters.cpp:21-24), ray window
+    0.5-5.0 m and the reference's per-frame de-duplication -- the very frames `bench.py --workload c3` times.  Per-voxel
+    hit/miss counters of every frame, UpdateOccupancy's queue sizes and UpdateESDF's counters must equal the oracle's
+    (verbatim Raycast + restated RaycastProcess, single thread, cloud order)."""
+    G, res = 512, 0.1
+    half = G * res / 2
+    origin, size = (-half, -half, -half), (G * res,) * 3
+    gpu, cpu = make(oracle_libs, best_oracle_kind, origin, size, res)
+    assert gpu.grid_size == (G, G, G)
+    lc, rc = origin, tuple(np.add(origin, size))
+    spheres = [((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7), ((0.5, -2.0, -0.5), 0.4), ((-2.0, -1.0, 0.5), 0.6),
+               ((2.2, -1.8, 0.2), 0.3)]
+    assert abs(INTRINSICS["fx"] - 384.458089392) < 1e-12 and abs(INTRINSICS["cy"] - 237.076346481) < 1e-12
+    touched = 0
+    for f in range(3):
+        T = yaw_pose(2.0 * f, (0.0, 0.0, 0.0))
+        depth = render_depth(T, rows=480, cols=640, spheres=spheres, intr=INTRINSICS)
+        gpu.RaycastDepth(depth, INTRINSICS["fx"], INTRINSICS["fy"], INTRINSICS["cx"], INTRINSICS["cy"], T, T[:3, 3],
+                         RAY["min_ray_length"], RAY["max_ray_length"], lc, rc, dedup=1)
+        cpu.raycast_frame(depth_to_points(depth, INTRINSICS), T, T[:3, 3], RAY["min_ray_length"], RAY["max_ray_length"], lc, rc)
+        touched += check_counts(gpu, cpu)
+        a, b = gpu.UpdateOccupancy(True), cpu.UpdateOccupancy(True)
+        assert a == b and (gpu.last_insert, gpu.last_delete) == (cpu.last_insert, cpu.last_delete)
+        sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
+        assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+    assert touched > 25000   # (~10 k distinct voxels per frame after the per-frame de-duplication)
+    # occupancy after three frames, voxel for voxel (the distance field of this partially observed map is covered, with
+    # its stated budget, by the smaller frame tests above)
+    assert np.array_equal(gpu.download_field(("occ",))["occ"], cpu.dump_dense(("occ",))["occ"])
