@@ -131,4 +131,13 @@ struct Error : std::runtime_error {
                                                                    hipGetErrorString(_e));              \
   } while (0)
 
+// The library carries gfx950 code objects only: on any other HIP device a launch would fail without a code object and
+// leave the map uninitialised, so creation refuses it up front.
+inline void require_gfx950(int device) {
+  hipDeviceProp_t p;
+  FIESTA_HIP_CHECK(hipGetDeviceProperties(&p, device));
+  if (std::string(p.gcnArchName).compare(0, 6, "gfx950") != 0)
+    throw Error(2, std::string("device is ") + p.gcnArchName + ", this engine is built for gfx950 (MI355X) only");
+}
+
 }  // namespace fiesta

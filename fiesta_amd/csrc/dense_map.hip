@@ -270,6 +270,31 @@ __global__ __launch_bounds__(1024) void k_del_bbox(Geom g, const uint32_t *del, 
   }
 }
 
+// A voxel OUTSIDE the update window whose obstacle vanished (local / sliding-window maps only).  The reference re-seeds
+// every orphan, wherever it lies, from the first stencil neighbour IN the window that still has a live obstacle
+// (src/ESDFMap.cpp:308-321: dirs_ order, VoxInRange gates the neighbour, not the orphan) and never pushes into it again
+// while it stays outside (the BFS gates its targets with VoxInRange, :367).  The frontier rounds only stage voxels of the
+// window, so that re-seed is done here, once, and the word is left WITHOUT a frontier tag: when the window later covers
+// the voxel it holds what the reference holds, not a stale seed.
+__device__ inline vox_t reseed_outside_window(const Geom &g, const vox_t *coc, const uint32_t *occbits, const uint32_t *gocc,
+                                              int x, int y, int z) {
+#define FIESTA_RESEED(DX, DY, DZ)                                                                   \
+  {                                                                                                 \
+    const int ux = x + (DX), uy = y + (DY), uz = z + (DZ);                                          \
+    if (g.in_grid(ux, uy, uz) && g.in_window(ux, uy, uz)) {                                         \
+      const vox_t w = coc[g.idx(ux, uy, uz)];                                                       \
+      if (!(w & kNoCoc)) {                                                                          \
+        int cx, cy, cz;                                                                             \
+        unpack_coc(w & ~kAct, cx, cy, cz);                                                          \
+        if (obstacle_alive(g, occbits, gocc, cx, cy, cz)) return w & ~kAct;                         \
+      }                                                                                             \
+    }                                                                                               \
+  }
+  FIESTA_STENCIL24(FIESTA_RESEED)
+#undef FIESTA_RESEED
+  return kInf;
+}
+
 __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits,
                                                     const uint32_t *gocc, uint32_t *flag, uint32_t *list,
                                                     unsigned long long *count, unsigned long long *counters, int bounded) {
@@ -291,6 +316,7 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
   const uint32_t nry = (uint32_t)(by1 - by0 + 1), nrows = (uint32_t)(bx1 - bx0 + 1) * nry;
   const int lane = threadIdx.x & 63;
   const bool vec = (g.nz & 3) == 0;
+  const bool win_all = g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1;
   unsigned long long local = 0;
   constexpr int V = 8;  // consecutive voxels per lane: two 16-byte loads in flight, and longer same-obstacle runs per lane
   // XCD-aware row order (work-group b runs on XCD b % 8; used for speed only): every XCD scans one contiguous eighth
@@ -355,6 +381,15 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
             dead_prev = dead;
             if (dead && (!g.sharded || g.owned(x, y, z8 + k))) rmask |= 1u << k;
           }
+        }
+        if (rmask && !win_all) {  // orphans outside the update window: re-seeded here, not by the rounds
+#pragma unroll
+          for (int k = 0; k < V; ++k)
+            if (((rmask >> k) & 1u) && !g.in_window(x, y, z8 + k)) {
+              coc[base + z8 + k] = reseed_outside_window(g, coc, occbits, gocc, x, y, z8 + k);
+              rmask &= ~(1u << k);
+              ++local;
+            }
         }
 #pragma unroll
         for (int u = 0; u < V / 4; ++u) {
@@ -591,6 +626,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     throw Error(FIESTA_HIP_ERR_DEVICE, "no HIP device available (this engine has no CPU fallback)");
   if (device_ < 0 || device_ >= ndev) throw Error(FIESTA_HIP_ERR_INVALID, "device ordinal out of range");
+  require_gfx950(device_);
   use_device();
   if (!(cfg.resolution > 0)) throw Error(FIESTA_HIP_ERR_INVALID, "resolution must be positive");
   Geom &g = g_;
@@ -679,6 +715,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_counters_, C_COUNT * sizeof(unsigned long long)));
   FIESTA_HIP_CHECK(hipMemsetAsync(counters_, 0, C_COUNT * sizeof(unsigned long long), stream_));
   hipLaunchKernelGGL(k_fill<vox_t>, dim3(grid_for(g.n, 256, 4096)), dim3(256), 0, stream_, coc_, kUnobserved, g.n);
+  FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipMemsetAsync(logodds_, 0, g.n * sizeof(double), stream_));
   FIESTA_HIP_CHECK(hipMemsetAsync(cnt_, 0, g.n * sizeof(unsigned long long), stream_));
   FIESTA_HIP_CHECK(hipMemsetAsync(occbits_, 0, nbitwords_ * sizeof(uint32_t), stream_));

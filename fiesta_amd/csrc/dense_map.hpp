@@ -42,6 +42,7 @@ enum Counter {
   C_DELETE,        // delete_queue_
   C_OBSERVED,      // voxels observed at least once (first-observation transitions counted by k_fuse)
   C_NOCC,          // occupied voxels (Exist() count), kept by k_fuse
+  C_DROPPED,       // hash-block maps: observations that fell outside the addressable window and were ignored (cumulative)
   C_MAXD2,         // upper bound of every finite d^2 the work-queue engine ever stored (bounds the delete scan)
   C_DBOX0,         // bounding box of the pending delete queue, local voxel coordinates: min x,y,z then max x,y,z
   C_DBOX5 = C_DBOX0 + 5,

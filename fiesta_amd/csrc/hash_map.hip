@@ -96,14 +96,21 @@ __device__ inline void h_count(int64_t addr, int occ, unsigned long long *cnt, u
 __global__ void k_h_observe_vox(Geom g, const int32_t *dir, const int32_t *vox, const int32_t *occ, int64_t n,
                                 unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int x, y, z;
-  if (i < n && obs_vox(g, vox, i, x, y, z)) h_count(vaddr(dir, x, y, z), occ[i], cnt, touched, counters);
+  int x = 0, y = 0, z = 0;
+  const bool ok = i < n && obs_vox(g, vox, i, x, y, z);
+  if (ok) h_count(vaddr(dir, x, y, z), occ[i], cnt, touched, counters);
+  // the reference's hash build accepts any voxel; an observation outside the addressable window is lost here: count it
+  const unsigned long long lost = __ballot(i < n && !in_win(x, y, z));
+  if (lost && (threadIdx.x & 63) == 0) atomicAdd(&counters[C_DROPPED], (unsigned long long)__popcll(lost));
 }
 __global__ void k_h_observe_pos(Geom g, const int32_t *dir, const double *pos, const int32_t *occ, int64_t n,
                                 unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int x, y, z;
-  if (i < n && obs_pos(g, pos, occ, i, x, y, z)) h_count(vaddr(dir, x, y, z), occ[i], cnt, touched, counters);
+  int x = 0, y = 0, z = 0;
+  const bool valid = i < n && (occ[i] == 0 || occ[i] == 1);
+  if (valid && obs_pos(g, pos, occ, i, x, y, z)) h_count(vaddr(dir, x, y, z), occ[i], cnt, touched, counters);
+  const unsigned long long lost = __ballot(valid && !in_win(x, y, z));
+  if (lost && (threadIdx.x & 63) == 0) atomicAdd(&counters[C_DROPPED], (unsigned long long)__popcll(lost));
 }
 
 // SetOccupancy(Vector3i, occ) for every voxel of a box given in WINDOW coordinates (inclusive): tiles first ...
@@ -366,6 +373,7 @@ HashMap::HashMap(const fiesta_hip_config &cfg) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     throw Error(FIESTA_HIP_ERR_DEVICE, "no HIP device available (this engine has no CPU fallback)");
   if (device_ < 0 || device_ >= ndev) throw Error(FIESTA_HIP_ERR_INVALID, "device ordinal out of range");
+  require_gfx950(device_);
   use_device();
   if (!(cfg.resolution > 0)) throw Error(FIESTA_HIP_ERR_INVALID, "resolution must be positive");
   Geom &g = g_;
@@ -442,6 +450,7 @@ void HashMap::ensure_pages(int64_t need_total) {
   grow_exact(page_tile_, (size_t)cap, keep_p);
   const int64_t nv = (cap - cap_pages_) * kPageVox, nr = (cap - cap_pages_) * kPageRows;
   hipLaunchKernelGGL(k_h_fill<vox_t>, dim3(grid_for(nv, 256, 4096)), dim3(256), 0, stream_, coc_.p + keep_v, kUnobserved, nv);
+  FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipMemsetAsync(logodds_.p + keep_v, 0, nv * sizeof(double), stream_));
   FIESTA_HIP_CHECK(hipMemsetAsync(cnt_.p + keep_v, 0, nv * sizeof(unsigned long long), stream_));
   for (uint32_t *b : {occbits_.p, rbits_.p, cbits_[0].p, cbits_[1].p})
@@ -527,11 +536,17 @@ void HashMap::observe_box(const int32_t *lo, const int32_t *hi, int occ) {
   use_device();
   // clip to the virtual window (SetOccupancy outside the map is rejected, src/ESDFMap.cpp:406-410), window coordinates
   int a[3], b[3];
+  int64_t asked = 1, kept = 1;
   for (int k = 0; k < 3; ++k) {
     a[k] = std::max(lo[k] + kHalf, 0);
     b[k] = std::min(hi[k] + kHalf, kWin - 1);
-    if (a[k] > b[k]) return;
+    asked *= std::max<int64_t>(0, (int64_t)hi[k] - lo[k] + 1);
+    kept *= std::max<int64_t>(0, (int64_t)b[k] - a[k] + 1);
   }
+  if (asked > kept) {  // the part of the box outside the addressable window is lost: count it (see C_DROPPED)
+    dropped_host_ += asked - kept;
+  }
+  if (kept == 0) return;
   const int64_t ex = b[0] - a[0] + 1, ey = b[1] - a[1] + 1, ez = b[2] - a[2] + 1;
   const int64_t ntiles = (int64_t)((b[0] >> 4) - (a[0] >> 4) + 1) * ((b[1] >> 4) - (a[1] >> 4) + 1) * ((b[2] >> 5) - (a[2] >> 5) + 1);
   hipLaunchKernelGGL(k_h_mark_box, dim3(grid_for(ntiles)), dim3(256), 0, stream_, g_, a[0], a[1], a[2], b[0], b[1], b[2], need_);
@@ -698,6 +713,7 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
     memset(st, 0, sizeof(*st));
     st->inserted = (int64_t)ni;
     st->deleted = (int64_t)nd;
+    st->dropped_observations = (int64_t)read_counter(C_DROPPED) + dropped_host_;
   }
   if (ni || nd) {
     ++epoch_;

@@ -99,6 +99,7 @@ class HashMap {
 
   DevBuf<uint32_t> touched_, ins_, del_;
   int64_t touched_upper_ = 0;
+  int64_t dropped_host_ = 0;  // voxels of observe_box() requests clipped away by the window (added to C_DROPPED in stats)
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   DevBuf<unsigned char> stage_a_, stage_b_, stage_c_, stage_d_;
 };

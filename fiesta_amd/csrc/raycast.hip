@@ -431,6 +431,8 @@ static void ray_rounds(RayState &rc, int64_t n, int dedup, int ibits, uint32_t t
     uint32_t tag_prev = 0;
     constexpr int kBatch = 8;  // rounds per host round trip
     bool done = false;
+    int64_t base = 0;  // rounds whose flag slots were recycled (the fixed point needs at most n rounds: ray i depends
+                       // only on rays before it; a valid frame never fails here, however long its dependency chains)
     while (!done) {
       const int64_t first = iters + 1;
       for (int b = 0; b < kBatch; ++b) {
@@ -438,22 +440,26 @@ static void ray_rounds(RayState &rc, int64_t n, int dedup, int ibits, uint32_t t
         ++iters;
         hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream, n, (const uint32_t *)rc.entries.p,
                            (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, iters > 1 ? 1 : 0, 1,
-                           (const uint32_t *)fprev, tag_prev, fnext, tag_next, ibits, rc.d_flags + 2, (int)iters);
+                           (const uint32_t *)fprev, tag_prev, fnext, tag_next, ibits, rc.d_flags + 2, (int)(iters - base));
         FIESTA_HIP_CHECK(hipGetLastError());
         std::swap(fprev, fnext);
         tag_prev = tag_next;
       }
-      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, (2 + iters + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, (2 + (iters - base) + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
       FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
       if (rc.h_flags[1]) break;
       // stop at the first round (after round 1) that changed nothing
       for (int64_t it = std::max<int64_t>(first, 2); it <= iters; ++it)
-        if (!rc.h_flags[2 + it]) {
+        if (!rc.h_flags[2 + (it - base)]) {
           iters = it;
           done = true;
           break;
         }
-      if (!done && iters + kBatch > RayState::kMaxRounds) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup did not converge");
+      if (!done && (iters - base) + kBatch > RayState::kMaxRounds) {  // recycle the per-round flag slots
+        FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags + 2, 0, (RayState::kFlagInts - 2) * sizeof(int), stream));
+        base = iters;
+      }
+      if (!done && iters > n + kBatch) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup: more rounds than rays (internal error)");
     }
   }
   rc.last_iterations = iters;

@@ -288,6 +288,42 @@ def test_local_sliding_window_mode(hip_lib, oracle_libs, best_oracle_kind):
     assert worst <= 0.02 * n ** 3, worst
 
 
+def test_window_then_delete_with_dependents_outside_the_window(hip_lib, oracle_libs, best_oracle_kind):
+    """a delete whose orphans lie OUTSIDE the update window.  The reference re-seeds every orphan from its
+    first in-window neighbour with a live obstacle, wherever the orphan lies (src/ESDFMap.cpp:308-321: VoxInRange gates the
+    neighbour), and never propagates into it while it stays outside.  Then the window moves over those voxels and a second
+    delete runs: no stale frontier tag may turn them into fresh seeds.  (global_map = true: no local reset involved, the
+    reference's state stays self-consistent and is compared voxel by voxel, with the budget of an order-dependent regime.)"""
+    n = 40
+    b = make_pair(oracle_libs, best_oracle_kind, n)
+    observe_all(b, n)
+    rng = np.random.RandomState(5)
+    S = rng.randint(2, n - 2, (120, 3)).astype(np.int32)
+    b.make_occupied(S)
+    b.esdf()
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    res = b.gpu.resolution
+    # window = the low-x half; delete obstacles that sit in it but whose Voronoi cells reach far beyond it
+    for m in (b.gpu, b.cpu):
+        m.SetUpdateRange((0.0, 0.0, 0.0), (1.8, n * res, n * res))
+    inside = S[S[:, 0] < 17]
+    b.make_free(inside[:25])
+    sg, sc = b.esdf()
+    assert sg["deleted"] == sc["deleted"] > 0
+    rep = compare_dense(b.gpu, b.cpu)
+    assert rep["cpu_finite_gpu_inf"] + rep["gpu_finite_cpu_inf"] <= 0.01 * n ** 3, rep
+    assert rep["d2_mismatch"] <= 0.03 * n ** 3, rep
+    # the window moves over the former outside; a second delete and an insert there
+    for m in (b.gpu, b.cpu):
+        m.SetUpdateRange((1.0, 0.0, 0.0), (n * res, n * res, n * res))
+    outside = S[S[:, 0] >= 20]
+    b.mixed(rng.randint(22, n - 2, (10, 3)).astype(np.int32), outside[:20])
+    sg, sc = b.esdf()
+    assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+    rep = compare_dense(b.gpu, b.cpu)
+    assert rep["gpu_finite_cpu_inf"] <= 0.01 * n ** 3 and rep["d2_mismatch"] <= 0.03 * n ** 3, rep
+
+
 def test_visualisation_exports(hip_lib, oracle_libs, best_oracle_kind):
     """Device-side occupied-voxel compaction and z-slice extraction (the data behind GetPointCloud / GetSliceMarker,
     src/ESDFMap.cpp:544-699) against the oracle's dense dump."""
