@@ -443,9 +443,9 @@ int fiesta_hip_export_transitions(fiesta_hip_map *m, uint32_t *out, int64_t capa
     *n_out = n;
     if (!out || n == 0) return;
     need(n <= capacity, "transition buffer too small");
-    uint32_t *buf = d.scratch_u32(n);
+    uint32_t *buf = d.scratch_u32(2 * n);
     d.export_transitions(buf, n);
-    d.copy_to_host(out, buf, n * sizeof(uint32_t));
+    d.copy_to_host(out, buf, 2 * n * sizeof(uint32_t));
   });
 }
 int fiesta_hip_apply_transitions(fiesta_hip_map *m, const uint32_t *entries, int64_t n) {
@@ -453,8 +453,8 @@ int fiesta_hip_apply_transitions(fiesta_hip_map *m, const uint32_t *entries, int
     need(n == 0 || entries, "null argument");
     if (n == 0) return;
     DenseMap &d = dense(m, "apply_transitions");
-    uint32_t *buf = d.scratch_u32(n);
-    d.copy_to_device(buf, entries, n * sizeof(uint32_t));
+    uint32_t *buf = d.scratch_u32(2 * n);
+    d.copy_to_device(buf, entries, 2 * n * sizeof(uint32_t));
     d.apply_transitions(buf, n);
   });
 }

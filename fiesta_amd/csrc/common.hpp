@@ -34,19 +34,40 @@ constexpr int32_t kD2Inf = 0x7FFFFFFF;
 constexpr int kCoordBits = 10;
 constexpr int kMaxDim = 1 << kCoordBits;
 
+// Ids are GLOBAL voxel coordinates modulo 1024 per axis.  A grid of at most 1024 voxels per axis stores the plain
+// coordinate.  A larger (sharded) grid -- BASELINE config 5: 2048^3 -- decodes an id RELATIVE TO THE VOXEL THAT HOLDS IT
+// ("wrap"): the obstacle is the one point congruent to the id within (-512, 512) voxels of the voxel on every axis.
+// That needs no wider word and no second encoding; its price is a reach of 512 voxels: on such grids a candidate with
+// d^2 >= 2^18 is never adopted (kD2Cap), i.e. a voxel farther than 51.2 m (at 0.1 m) from every obstacle reads "no
+// obstacle".  The reference cannot hold such a grid at all (int indices, 48 B/voxel: 412 GB at 2048^3).
 __host__ __device__ inline vox_t pack_coc(int x, int y, int z) {
-  return ((vox_t)x << 20) | ((vox_t)y << 10) | (vox_t)z;
+  return ((vox_t)(x & 1023) << 20) | ((vox_t)(y & 1023) << 10) | (vox_t)(z & 1023);
 }
+constexpr int32_t kD2Cap = 1 << 18;  // wrap maps: squared reach of an id
+// offset of voxel (x,y,z) from the obstacle its word c names: voxel minus obstacle, per axis
+__host__ __device__ inline void coc_offset(int wrap, int x, int y, int z, vox_t c, int &dx, int &dy, int &dz) {
+  dx = x - (int)((c >> 20) & 1023), dy = y - (int)((c >> 10) & 1023), dz = z - (int)(c & 1023);
+  if (wrap) dx = ((dx + 512) & 1023) - 512, dy = ((dy + 512) & 1023) - 512, dz = ((dz + 512) & 1023) - 512;
+}
+// the obstacle itself, in global coordinates
+__host__ __device__ inline void unpack_coc(int wrap, int x, int y, int z, vox_t c, int &cx, int &cy, int &cz) {
+  int dx, dy, dz;
+  coc_offset(wrap, x, y, z, c, dx, dy, dz);
+  cx = x - dx, cy = y - dy, cz = z - dz;
+}
+// squared voxel distance; exact in int32
+__host__ __device__ inline int32_t dist2(int wrap, int x, int y, int z, vox_t c) {
+  int dx, dy, dz;
+  coc_offset(wrap, x, y, z, c, dx, dy, dz);
+  return dx * dx + dy * dy + dz * dz;
+}
+// plain forms for coordinate systems that never exceed 1024 per axis (the hash-block map's window, the ray codes)
 __host__ __device__ inline void unpack_coc(vox_t c, int &x, int &y, int &z) {
   x = (c >> 20) & 1023;
   y = (c >> 10) & 1023;
   z = c & 1023;
 }
-// squared voxel distance; exact in int32 (<= 3 * 1023^2)
-__host__ __device__ inline int32_t dist2(int x, int y, int z, vox_t c) {
-  const int dx = x - (int)((c >> 20) & 1023), dy = y - (int)((c >> 10) & 1023), dz = z - (int)(c & 1023);
-  return dx * dx + dy * dy + dz * dz;
-}
+__host__ __device__ inline int32_t dist2(int x, int y, int z, vox_t c) { return dist2(0, x, y, z, c); }
 
 // The 24-direction stencil (include/parameters.h:54-68): 6 faces, 12 edges, 6 two-step faces.
 // Order is the reference's; it is irrelevant for the fixed point.
@@ -89,6 +110,7 @@ struct Geom {
   int ox0, oy0, oz0, ox1, oy1, oz1;  // owned box, local coords, inclusive (== whole array if unsharded)
   int wx0, wy0, wz0, wx1, wy1, wz1;  // update window (VoxInRange), local coords, inclusive
   int px0, py0, pz0, px1, py1, pz1;  // previous window (last_min_vec_/last_max_vec_)
+  int wrap;              // 1: some GLOBAL extent exceeds 1024: ids are decoded relative to their voxel (see pack_coc)
   int sharded;           // 1: this array is one shard (owned box + 2-voxel ghost layers) of a GX x GY x GZ grid
   int GX, GY, GZ, GZW;   // global grid and words per z-row of the replicated global occupancy bitmap
   double org[3], res, res_inv;

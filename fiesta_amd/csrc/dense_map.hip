@@ -231,7 +231,7 @@ __global__ void k_maxd2_scan(Geom g, const vox_t *coc, unsigned long long *count
     const vox_t w = coc[i];
     if (w & kNoCoc) continue;
     const int z = (int)(i % g.nz), y = (int)((i / g.nz) % g.ny), x = (int)(i / ((int64_t)g.nz * g.ny));
-    mx = max(mx, (uint32_t)dist2(x + g.gx0, y + g.gy0, z + g.gz0, w & ~kAct));
+    mx = max(mx, (uint32_t)dist2(g.wrap, x + g.gx0, y + g.gy0, z + g.gz0, w & ~kAct));
   }
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
   if ((threadIdx.x & 63) == 0) atomicMax(&blk, mx);
@@ -285,7 +285,7 @@ __device__ inline vox_t reseed_outside_window(const Geom &g, const vox_t *coc, c
       const vox_t w = coc[g.idx(ux, uy, uz)];                                                       \
       if (!(w & kNoCoc)) {                                                                          \
         int cx, cy, cz;                                                                             \
-        unpack_coc(w & ~kAct, cx, cy, cz);                                                          \
+        unpack_coc(g.wrap, ux + g.gx0, uy + g.gy0, uz + g.gz0, w & ~kAct, cx, cy, cz);                \
         if (obstacle_alive(g, occbits, gocc, cx, cy, cz)) return w & ~kAct;                         \
       }                                                                                             \
     }                                                                                               \
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
               dead = dead_prev;
             } else {
               int cx, cy, cz;
-              unpack_coc(c, cx, cy, cz);
+              unpack_coc(g.wrap, x + g.gx0, y + g.gy0, z8 + k + g.gz0, c, cx, cy, cz);
               dead = !obstacle_alive(g, occbits, gocc, cx, cy, cz);
             }
             dead_prev = dead;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
 __device__ inline double word_distance(const Geom &g, vox_t w, int x, int y, int z) {
   // GetDistance(Vector3i) (src/ESDFMap.cpp:477-479): unobserved (-10000) reads as +10000
   if (w & kNoCoc) return (double)FIESTA_HIP_INFINITY;
-  const int32_t d2 = dist2(x + g.gx0, y + g.gy0, z + g.gz0, w);
+  const int32_t d2 = dist2(g.wrap, x + g.gx0, y + g.gy0, z + g.gz0, w);
   return sqrt((double)d2) * g.res;  // Dist (:122-124)
 }
 __device__ inline double vox_distance(const Geom &g, const vox_t *coc, int x, int y, int z) {
@@ -528,10 +528,10 @@ __global__ void k_export(Geom g, const vox_t *coc, const uint32_t *occbits, int3
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += stride) {
     const int z = i % g.nz, y = (i / g.nz) % g.ny, x = i / ((int64_t)g.nz * g.ny);
     const vox_t w = coc[i];
-    if (d2) d2[i] = (w == kUnobserved) ? -1 : ((w & kNoCoc) ? kD2Inf : dist2(x + g.gx0, y + g.gy0, z + g.gz0, w));
+    if (d2) d2[i] = (w == kUnobserved) ? -1 : ((w & kNoCoc) ? kD2Inf : dist2(g.wrap, x + g.gx0, y + g.gy0, z + g.gz0, w));
     if (cxyz) {
       int cx = FIESTA_HIP_UNDEFINED, cy = FIESTA_HIP_UNDEFINED, cz = FIESTA_HIP_UNDEFINED;
-      if (!(w & kNoCoc)) unpack_coc(w, cx, cy, cz);
+      if (!(w & kNoCoc)) unpack_coc(g.wrap, x + g.gx0, y + g.gy0, z + g.gz0, w, cx, cy, cz);
       cxyz[3 * i] = cx;
       cxyz[3 * i + 1] = cy;
       cxyz[3 * i + 2] = cz;
@@ -583,12 +583,12 @@ __global__ void k_count_updated(Geom g, const vox_t *before, const vox_t *now, c
     if (a == b) continue;
     const int z = i % g.nz, y = (i / g.nz) % g.ny, x = i / ((int64_t)g.nz * g.ny);
     const int gx = x + g.gx0, gy = y + g.gy0, gz = z + g.gz0;
-    const int32_t da = (a == kUnobserved) ? -1 : ((a & kNoCoc) ? kD2Inf : dist2(gx, gy, gz, a));
-    const int32_t db = (b == kUnobserved) ? -1 : ((b & kNoCoc) ? kD2Inf : dist2(gx, gy, gz, b));
+    const int32_t da = (a == kUnobserved) ? -1 : ((a & kNoCoc) ? kD2Inf : dist2(g.wrap, gx, gy, gz, a));
+    const int32_t db = (b == kUnobserved) ? -1 : ((b & kNoCoc) ? kD2Inf : dist2(g.wrap, gx, gy, gz, b));
     bool upd = da != db;
     if (!upd && !(a & kNoCoc)) {
       int cx, cy, cz;
-      unpack_coc(a, cx, cy, cz);
+      unpack_coc(g.wrap, gx, gy, gz, a, cx, cy, cz);
       upd = !obstacle_alive(g, occbits, gocc, cx, cy, cz);
     }
     local += upd && g.owned(x, y, z);
@@ -644,10 +644,13 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   const bool sharded = cfg.global_grid[0] > 0;
   int gg[3];
   for (int i = 0; i < 3; ++i) gg[i] = sharded ? cfg.global_grid[i] : gs[i];
-  for (int i = 0; i < 3; ++i)
-    if (gg[i] > kMaxDim)
-      throw Error(FIESTA_HIP_ERR_INVALID,
-                  "grid extent exceeds 1024 voxels per axis (32-bit closest-obstacle words, see DESIGN.md)");
+  // closest-obstacle ids are coordinates modulo 1024 (common.hpp: pack_coc): plain up to 1024 voxels per axis, decoded
+  // relative to the voxel ("wrap", reach 512 voxels) beyond that -- up to the 16-bit coordinates of the shard protocol
+  g.wrap = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (gg[i] > 32768) throw Error(FIESTA_HIP_ERR_INVALID, "grid extent exceeds 32768 voxels per axis");
+    if (gg[i] > kMaxDim) g.wrap = 1;
+  }
   // Sharded: map_size is the OWNED box, shard_lo its global voxel origin; a 2-voxel ghost layer (the stencil
   // radius) is added on every side that has a neighbour shard. origin stays the GLOBAL map origin.
   int glo[3] = {0, 0, 0}, ghi[3] = {0, 0, 0};
@@ -1040,7 +1043,7 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
 // feature transform of the occupied set, whatever the previous state was.
 bool DenseMap::bulk_applicable() const {
   const Geom &g = g_;
-  return !g.sharded && g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1;
+  return !g.sharded && !g.wrap && g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1;
 }
 
 template <int S, int LANES, int WAVES>
@@ -1504,23 +1507,24 @@ __global__ void k_halo_apply(Geom g, TileGrid tg, int x0, int y0, int z0, int ex
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(changed, local);
 }
-// Occupancy transitions of this shard since the queues were last drained, as packed GLOBAL coordinates with
-// bit 31 = "occupied now" -- idempotent, order-free updates for the other shards' global bitmaps.
+// Occupancy transitions of this shard since the queues were last drained: TWO words per entry, x | y << 16 and
+// z | "occupied now" << 31 (global coordinates, up to 65535 / 2^31 per axis) -- idempotent, order-free updates for the
+// other shards' replicas of the global bitmap.
 __global__ void k_export_transitions(Geom g, const uint32_t *ins, int64_t ni, const uint32_t *del, int64_t nd,
                                      const uint32_t *occbits, uint32_t *out) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= ni + nd) return;
   const uint32_t idx = i < ni ? ins[i] : del[i - ni];
   const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
-  out[i] = pack_coc(x + g.gx0, y + g.gy0, z + g.gz0) | (occ_test(occbits, g, x, y, z) ? 0x80000000u : 0u);
+  out[2 * i] = (uint32_t)(x + g.gx0) | ((uint32_t)(y + g.gy0) << 16);
+  out[2 * i + 1] = (uint32_t)(z + g.gz0) | (occ_test(occbits, g, x, y, z) ? 0x80000000u : 0u);
 }
 __global__ void k_apply_transitions(Geom g, const uint32_t *ent, int64_t n, uint32_t *gocc,
                                     unsigned long long *remote_del) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t e = ent[i];
-  int x, y, z;
-  unpack_coc(e & 0x3FFFFFFFu, x, y, z);
+  const uint32_t e0 = ent[2 * i], e = ent[2 * i + 1];
+  const int x = (int)(e0 & 0xFFFFu), y = (int)(e0 >> 16), z = (int)(e & 0x7FFFFFFFu);
   if (x >= g.GX || y >= g.GY || z >= g.GZ) return;
   if (e & 0x80000000u)
     atomicOr(&gocc[g.gbitword(x, y, z)], 1u << (z & 31));

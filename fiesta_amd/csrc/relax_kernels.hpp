@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
         const vox_t c = w & ~kAct;
         lo = (valid ? c : kInf) | (inR ? kAct : 0u);
         if (upd) {
-          hi = valid ? (uint32_t)dist2(bx + rx, by + ry, bz + rz, c) : (uint32_t)kD2Inf;
+          hi = valid ? (uint32_t)dist2(g.wrap, bx + rx, by + ry, bz + rz, c) : (uint32_t)(g.wrap ? kD2Cap : kD2Inf);
           if (act) flags |= 1u | 4u;
           // a voxel without an obstacle asks its old-valid neighbours once, when it first joins the frontier:
           // now if it was orphaned by a delete (the re-seed of :308-321), else when a wave first reaches it
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
   _Pragma("unroll") for (int q = 0; q < (NQ); ++q) {        \
     const vox_t u = un[q];                                  \
     if (!(u & (kNoCoc | kAct))) {                           \
-      const uint32_t d = (uint32_t)dist2(vx, vy, vz, u);    \
+      const uint32_t d = (uint32_t)dist2(g.wrap, vx, vy, vz, u); \
       if (d < bestd) {                                      \
         bestd = d;                                          \
         best = u;                                           \
@@ -452,7 +452,8 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
         if (lo & kNoCoc) continue;
         // push: |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2
         const vox_t c = lo & ~kAct;
-        const int rcx = vx - (int)((c >> 20) & 1023), rcy = vy - (int)((c >> 10) & 1023), rcz = vz - (int)(c & 1023);
+        int rcx, rcy, rcz;
+        coc_offset(g.wrap, vx, vy, vz, c, rcx, rcy, rcz);
         const int32_t dv = SRC ? rcx * rcx + rcy * rcy + rcz * rcz : (int32_t)hi;  // (source-only voxels keep d^2 = 0 in LDS)
         const unsigned long long keylo = (unsigned long long)(c | kAct);
         if (SRC) {

@@ -289,14 +289,14 @@ class ESDFMap:
     def export_transitions(self) -> np.ndarray:
         n = C.c_int64(0)
         check(self._lib.fiesta_hip_export_transitions(self._h, None, 0, C.byref(n)))
-        out = np.empty(n.value, np.uint32)
+        out = np.empty(2 * n.value, np.uint32)   # two words per entry: x | y << 16, z | occupied << 31
         if n.value:
             check(self._lib.fiesta_hip_export_transitions(self._h, _p(out), n.value, C.byref(n)))
         return out
 
     def apply_transitions(self, entries):
-        e = np.ascontiguousarray(entries, dtype=np.uint32)
-        check(self._lib.fiesta_hip_apply_transitions(self._h, _p(e), len(e)))
+        e = np.ascontiguousarray(entries, dtype=np.uint32).reshape(-1)
+        check(self._lib.fiesta_hip_apply_transitions(self._h, _p(e), len(e) // 2))
 
     def export_transitions_dev(self, out_ptr: int, capacity: int) -> int:
         n = C.c_int64(0)

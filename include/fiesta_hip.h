@@ -229,8 +229,9 @@ int fiesta_hip_halo_pack_dev(fiesta_hip_map *m, const int32_t box_lo[3], const i
  * an obstacle becomes a frontier source and wakes its tile. *n_changed (nullable) = cells that differed. */
 int fiesta_hip_halo_apply_dev(fiesta_hip_map *m, const int32_t box_lo[3], const int32_t box_hi[3],
                               const uint32_t *in_dev, int64_t *n_changed);
-/* Occupancy transitions queued on this shard, as packed global coordinates (x<<20|y<<10|z) with bit 31 = occupied
- * now. out_dev NULL: only the count. Does not consume the queues. */
+/* Occupancy transitions queued on this shard: TWO uint32 words per entry, x | y << 16 and z | occupied-now << 31
+ * (global voxel coordinates); capacity and *n_out count ENTRIES. out_dev NULL: only the count. Does not consume the
+ * queues. */
 int fiesta_hip_export_transitions_dev(fiesta_hip_map *m, uint32_t *out_dev, int64_t capacity, int64_t *n_out);
 /* Applies transitions (of any shard, own ones included) to this shard's replica of the global occupancy bitmap. */
 int fiesta_hip_apply_transitions_dev(fiesta_hip_map *m, const uint32_t *entries_dev, int64_t n);

@@ -81,13 +81,13 @@ class NumpyShard:
         out = []
         for idx in self.ins + self.dels:
             g = np.array(idx) + self.g0
-            out.append(int(pack(*g)) | (0x80000000 if self.occ[idx] else 0))
+            out += [int(g[0]) | (int(g[1]) << 16), int(g[2]) | (0x80000000 if self.occ[idx] else 0)]
         return np.array(out, np.uint32)
 
     def apply_transitions(self, ent):
-        for e in np.asarray(ent, np.uint32):
-            c = int(e) & 0x3FFFFFFF
-            x, y, z = (c >> 20) & 1023, (c >> 10) & 1023, c & 1023
+        ent = np.asarray(ent, np.uint32).reshape(-1, 2)
+        for e0, e in ent:
+            x, y, z = int(e0) & 0xFFFF, int(e0) >> 16, int(e) & 0x7FFFFFFF
             alive = bool(int(e) & 0x80000000)
             self.gocc[x, y, z] = alive
             if not alive:

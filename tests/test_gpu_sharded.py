@@ -193,3 +193,85 @@ def test_dist_transport_with_hip_shards_two_ranks_one_gpu(hip_lib):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in results), [r for r in results if r[1] != "ok"]
+
+
+def _brute_d2(vox, obs):
+    out = np.empty(len(vox), np.int64)
+    for s in range(0, len(vox), 4096):
+        out[s:s + 4096] = ((vox[s:s + 4096, None, :].astype(np.int64) - obs[None, :, :]) ** 2).sum(-1).min(1)
+    return out
+
+
+@pytest.mark.parametrize("n_shards", [1, 2])
+def test_global_extent_2048_ids_beyond_30_bits(hip_lib, n_shards):
+    """BASELINE config 5 needs a 2048-voxel axis: closest-obstacle ids are coordinates modulo 1024, decoded relative to
+    the voxel that holds them on grids larger than 1024 (fiesta_amd/csrc/common.hpp: pack_coc).  A 2048 x 64 x 64 grid,
+    unsharded and cut into 2 shards of 1024 x 64 x 64 (the reference cannot even index such a map along one axis of
+    C5's size with its 48 B/voxel): fully observed, obstacles scattered along the whole length incl. around x = 1024
+    (the cut, and the wrap of the id) -- every squared distance and every closest obstacle against brute force."""
+    from fiesta_amd.sharded import ShardedESDFMap
+    gs, res = (2048, 64, 64), 0.1
+    sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards)
+    sm.SetParameters(*P_DEFAULT)
+    sm.SetOriginalRange()
+    sm.SetOccupancyBox((0, 0, 0), tuple(np.array(gs) - 1), 0)
+    sm.UpdateOccupancy(True)
+    sm.UpdateESDF()
+    rng = np.random.RandomState(9)
+    S = (rng.rand(900, 3) * gs).astype(np.int32)
+    S[:80, 0] = rng.randint(1015, 1034, 80)
+    S[80:100, 0] = rng.randint(0, 6, 20)
+    S[100:120, 0] = rng.randint(2042, 2048, 20)
+    S = np.unique(S, axis=0)
+    for _ in range(3):
+        sm.SetOccupancy(S, 1)
+        sm.UpdateOccupancy(True)
+    st = sm.UpdateESDF()
+    assert st["inserted"] == len(S)
+
+    def check(obs):
+        f = sm.assemble()
+        assert int(f["occ"].sum()) == len(obs)
+        idx = np.random.RandomState(2).randint(0, gs[0] * gs[1] * gs[2], 60000).astype(np.int64)
+        idx = np.concatenate([idx, (np.arange(1000, 1048)[:, None] * gs[1] * gs[2] + np.arange(0, gs[1] * gs[2], 37)[None, :]).reshape(-1)])
+        V = np.stack([idx // (gs[1] * gs[2]), (idx // gs[2]) % gs[1], idx % gs[2]], -1)
+        want = _brute_d2(V, obs.astype(np.int64))
+        got = f["d2"][idx].astype(np.int64)
+        assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+        c = f["coc"][idx].astype(np.int64)
+        assert np.array_equal(((V - c) ** 2).sum(-1), want)           # the decoded obstacle sits at that distance ...
+        lin = (c[:, 0] * gs[1] + c[:, 1]) * gs[2] + c[:, 2]
+        assert np.all(f["occ"][lin] == 1)                             # ... and is occupied
+    check(S)
+    gone = S[::2]
+    new = (rng.rand(200, 3) * gs).astype(np.int32)
+    for _ in range(6):
+        sm.SetOccupancy(new, 1)
+        sm.SetOccupancy(gone, 0)
+        sm.UpdateOccupancy(True)
+    sm.UpdateESDF()
+    live = np.unique(np.concatenate([S[1::2], new]), axis=0)
+    check(live)
+    sm.close()
+
+
+def test_wrap_ids_reach_512_voxels(hip_lib):
+    """On a grid larger than 1024 the reach of an id is 512 voxels (d^2 < 2^18): a voxel farther than that from every
+    obstacle reads "no obstacle" (documented limit; the reference cannot hold such a grid)."""
+    import fiesta_amd
+    gs, res = (1400, 16, 32), 0.1
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res))
+    assert m.grid_size == gs
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    m.SetOccupancyBox((0, 0, 0), tuple(np.array(gs) - 1), 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    for _ in range(3):
+        m.SetOccupancy(np.array([[10, 8, 16]], np.int32), 1)
+        m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    f = m.download_field(("d2",))["d2"].reshape(gs)
+    assert f[10 + 400, 8, 16] == 400 ** 2 and f[10 + 511, 8, 16] == 511 ** 2
+    assert f[10 + 512, 8, 16] == D2_INF and f[1399, 0, 0] == D2_INF
+    m.close()
