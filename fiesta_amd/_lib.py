@@ -103,6 +103,12 @@ def load():
         "fiesta_hip_grid_size": (C.c_int, [vp, vp]),
         "fiesta_hip_grid_total_size": (C.c_int, [vp, vp]),
         "fiesta_hip_voxel_key": (C.c_int, [vp, vp, C.c_int64, vp]),
+        "fiesta_hip_rccl_unique_id": (C.c_int, [vp]),
+        "fiesta_hip_shard_box": (C.c_int, [vp, C.c_int32, C.c_int32, vp, vp]),
+        "fiesta_hip_shard_group_create": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),
+        "fiesta_hip_shard_group_destroy": (C.c_int, [vp]),
+        "fiesta_hip_shard_group_update_occupancy": (C.c_int, [vp, C.c_int32, vp, vp, vp]),
+        "fiesta_hip_shard_group_update_esdf": (C.c_int, [vp, vp, vp, vp]),
         "fiesta_hip_set_prob_params": (C.c_int, [vp, dbl, dbl, dbl, dbl, dbl]),
         "fiesta_hip_set_update_range": (C.c_int, [vp, vp, vp, C.c_int]),
         "fiesta_hip_set_original_range": (C.c_int, [vp]),

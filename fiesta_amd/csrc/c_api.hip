@@ -7,10 +7,15 @@
 #include "../../include/fiesta_hip.h"
 #include "dense_map.hpp"
 #include "hash_map.hpp"
+#include "shard_group.hpp"
 
 using fiesta::DenseMap;
 using fiesta::Error;
 using fiesta::HashMap;
+
+struct fiesta_hip_shard_group {
+  fiesta::ShardGroup *g = nullptr;
+};
 
 struct fiesta_hip_map {
   int mode = 0;
@@ -463,6 +468,65 @@ int fiesta_hip_esdf_seed(fiesta_hip_map *m, fiesta_hip_stats *stats) {
 }
 int fiesta_hip_relax_pending(fiesta_hip_map *m, fiesta_hip_stats *stats, int64_t *pending) {
   return guarded([&] { dense(m, "relax_pending").relax_pending(stats, pending); });
+}
+
+int fiesta_hip_rccl_unique_id(uint8_t id[128]) {
+  return guarded([&] {
+    need(id != nullptr, "null argument");
+    fiesta::rccl_unique_id(id);
+  });
+}
+int fiesta_hip_shard_box(const int32_t gg[3], int32_t world, int32_t rank, int32_t lo[3], int32_t size[3]) {
+  return guarded([&] {
+    need(gg && lo && size, "null argument");
+    need(rank >= 0 && rank < world, "rank out of range");
+    const int g3[3] = {gg[0], gg[1], gg[2]};
+    int l3[3], s3[3];
+    fiesta::shard_box(g3, world, rank, l3, s3);
+    for (int i = 0; i < 3; ++i) lo[i] = l3[i], size[i] = s3[i];
+  });
+}
+int fiesta_hip_shard_group_create(fiesta_hip_map *const *shards, const int32_t *ranks, int32_t n_local, int32_t world,
+                                  const uint8_t *rccl_id, fiesta_hip_shard_group **out) {
+  return guarded([&] {
+    need(shards && ranks && out && n_local > 0, "null argument");
+    *out = nullptr;
+    std::vector<DenseMap *> maps;
+    std::vector<int> rk;
+    for (int i = 0; i < n_local; ++i) {
+      maps.push_back(&dense(shards[i], "shard_group_create"));
+      rk.push_back(ranks[i]);
+    }
+    auto *h = new fiesta_hip_shard_group;
+    try {
+      h->g = new fiesta::ShardGroup(maps, rk, world, rccl_id);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+  });
+}
+int fiesta_hip_shard_group_destroy(fiesta_hip_shard_group *g) {
+  return guarded([&] {
+    if (!g) return;
+    delete g->g;
+    delete g;
+  });
+}
+int fiesta_hip_shard_group_update_occupancy(fiesta_hip_shard_group *g, int32_t global_map, int64_t *n_insert, int64_t *n_delete,
+                                            int32_t *any) {
+  return guarded([&] {
+    need(g && g->g, "null shard group");
+    const bool a = g->g->update_occupancy(global_map != 0, n_insert, n_delete);
+    if (any) *any = a ? 1 : 0;
+  });
+}
+int fiesta_hip_shard_group_update_esdf(fiesta_hip_shard_group *g, fiesta_hip_stats *stats, int32_t *sweeps, int64_t *entries_sent) {
+  return guarded([&] {
+    need(g && g->g, "null shard group");
+    g->g->update_esdf(stats, sweeps, entries_sent);
+  });
 }
 
 int fiesta_hip_synchronize(fiesta_hip_map *m) {

@@ -1534,6 +1534,59 @@ __global__ void k_apply_transitions(Geom g, const uint32_t *ent, int64_t n, uint
   }
 }
 
+// ---- sparse ghost exchange (shard_group.hip) --------------------------------------------------------------------------
+// diff: the owned cells of the inclusive LOCAL box that a neighbour shard keeps as ghost cells; a cell whose word (tag
+// stripped) differs from what was last sent (`shadow`, same shape as the box) becomes one entry
+// {linear index of the ghost cell in the RECEIVER's array, word} and the shadow is updated.  apply: the receiver
+// replaces each named ghost cell that differs, tags it as a frontier source if it carries an obstacle and wakes its tile.
+__global__ void k_halo_diff(Geom g, int x0, int y0, int z0, int ex, int ey, int ez, const vox_t *coc, uint32_t *shadow,
+                            int rx0, int ry0, int rz0, int rny, int rnz, uint32_t *entries, unsigned long long *count) {
+  const int64_t n = (int64_t)ex * ey * ez;
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i0 + threadIdx.x;
+    bool send = false;
+    vox_t w = 0;
+    int dx = 0, dy = 0, dz = 0;
+    if (i < n) {
+      dz = (int)(i % ez), dy = (int)((i / ez) % ey), dx = (int)(i / ((int64_t)ez * ey));
+      w = strip_tag(coc[g.idx(x0 + dx, y0 + dy, z0 + dz)]);
+      send = w != shadow[i];
+      if (send) shadow[i] = w;
+    }
+    const unsigned long long m = __ballot(send);
+    if (!m) continue;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    if (send) {
+      const unsigned long long k = base + __popcll(m & ((1ull << lane) - 1ull));
+      entries[2 * k] = (uint32_t)(((int64_t)(rx0 + dx) * rny + (ry0 + dy)) * rnz + (rz0 + dz));
+      entries[2 * k + 1] = w;
+    }
+  }
+}
+__global__ void k_halo_apply_sparse(Geom g, TileGrid tg, const uint32_t *entries, int64_t n, vox_t *coc, uint32_t *flag,
+                                    uint32_t *list, unsigned long long *count, unsigned long long *changed) {
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t idx = entries[2 * i];
+    const vox_t theirs = entries[2 * i + 1], mine = strip_tag(coc[idx]);
+    if (mine == theirs) continue;
+    ++local;
+    if (theirs & kNoCoc) {
+      coc[idx] = theirs;
+    } else {
+      coc[idx] = theirs | kAct;
+      const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
+      const uint32_t t = tg.tile_of(x, y, z);
+      if (flag[t] == 0u) activate_tile(t, flag, list, count);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(changed, local);
+}
+
 static void check_box(const Geom &g, const int32_t *lo, const int32_t *hi) {
   if (lo[0] < 0 || lo[1] < 0 || lo[2] < 0 || hi[0] >= g.nx || hi[1] >= g.ny || hi[2] >= g.nz || hi[0] < lo[0] ||
       hi[1] < lo[1] || hi[2] < lo[2])
@@ -1588,6 +1641,31 @@ void DenseMap::apply_transitions(const uint32_t *ent_dev, int64_t n) {
                      &counters_[C_REMOTE_DEL]);
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void DenseMap::halo_diff(const int32_t *lo, const int32_t *hi, uint32_t *shadow_dev, const int32_t *recv_lo,
+                         const int32_t *recv_dims, uint32_t *entries_dev, unsigned long long *count_dev) {
+  use_device();
+  check_box(g_, lo, hi);
+  const int ex = hi[0] - lo[0] + 1, ey = hi[1] - lo[1] + 1, ez = hi[2] - lo[2] + 1;
+  hipLaunchKernelGGL(k_halo_diff, dim3(grid_for((int64_t)ex * ey * ez, 256, 4096)), dim3(256), 0, stream_, g_, lo[0], lo[1],
+                     lo[2], ex, ey, ez, (const vox_t *)coc_, shadow_dev, recv_lo[0], recv_lo[1], recv_lo[2], recv_dims[1],
+                     recv_dims[2], entries_dev, count_dev);
+  FIESTA_HIP_CHECK(hipGetLastError());
+}
+
+void DenseMap::halo_apply_sparse(const uint32_t *entries_dev, int64_t n, unsigned long long *changed_dev) {
+  use_device();
+  if (n <= 0) return;
+  TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
+  hipLaunchKernelGGL(k_halo_apply_sparse, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream_, g_, tg, entries_dev, n, coc_,
+                     tile_flag_[0], tile_list_[0], &counters_[C_LIST0], changed_dev);
+  FIESTA_HIP_CHECK(hipGetLastError());
+}
+
+int64_t DenseMap::pending_tiles() {
+  use_device();
+  return (int64_t)read_counter(C_LIST0);
 }
 
 void DenseMap::synchronize() {

@@ -110,6 +110,11 @@ class DenseMap {
 
   void halo_pack(const int32_t *lo, const int32_t *hi, uint32_t *out_dev);
   int64_t halo_apply(const int32_t *lo, const int32_t *hi, const uint32_t *in_dev);
+  // sparse ghost exchange (shard_group.hip): entries {receiver's linear cell index, word}, 2 words each
+  void halo_diff(const int32_t *lo, const int32_t *hi, uint32_t *shadow_dev, const int32_t *recv_lo, const int32_t *recv_dims,
+                 uint32_t *entries_dev, unsigned long long *count_dev);
+  void halo_apply_sparse(const uint32_t *entries_dev, int64_t n, unsigned long long *changed_dev);
+  int64_t pending_tiles();
   int64_t export_transitions(uint32_t *out_dev, int64_t cap);
   void apply_transitions(const uint32_t *ent_dev, int64_t n);
 

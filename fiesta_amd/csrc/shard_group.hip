@@ -1,0 +1,398 @@
+// fiesta_amd/csrc/shard_group.hip -- ONE map cut into spatial shards: the host protocol, in C++ over RCCL.
+//
+// The reference is single-process; this is what replaces its ESDFMap when a grid is spread over the GPUs of a node
+// (BASELINE config 5: 2048^3 as 2 x 2 x 2 shards of 1024^3).  Layouts: 1 -> 1x1x1, 2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2
+// (with 8 GPUs every pair of shards is adjacent = the fully connected xGMI mesh: every message is one hop on its own
+// link).  A shard is an ordinary array-mode DenseMap created with global_grid / shard_lo: owned box + 2-voxel ghost
+// layer (the stencil radius of the reference's 24 directions, include/parameters.h:54-68), ids in global coordinates.
+//
+//   UpdateOccupancy   local k_fuse -> export the occupancy transitions -> all-gather (counts, then the entries padded to
+//                     the longest list) -> every shard applies all of them to its replica of the GLOBAL occupancy
+//                     bitmap (a closest obstacle may live on any shard; a remote delete arms the invalidation scan).
+//   UpdateESDF        seed (insert drain + delete invalidation) on every shard, then sweeps of
+//                       diff     every shard compares the owned cells its <= 26 neighbours keep as ghosts (faces, edges AND
+//                                corners: one phase, no forwarding) with what it last sent and compacts the CHANGED ones into
+//                                {ghost cell index at the receiver, word} entries -- wave ballot + prefix, per neighbour
+//                       counts   one all-gather of (entries per neighbour, pending tiles): the receivers' message sizes
+//                                and the convergence test in ONE host read per sweep
+//                       send     ncclGroupStart; ncclSend/ncclRecv of exactly the changed entries per peer; ncclGroupEnd
+//                       apply    ghost cells that differ are replaced, tagged as sources, their tiles woken
+//                       relax    the frontier rounds on the woken tiles (dense_map.hip: relax_pending)
+//                     until a sweep in which nobody sent anything and no tile is pending anywhere.
+//
+// Two transports behind the same code: RCCL (one shard per process, one rank per GPU; librccl is dlopen()ed so that a
+// single-GPU user never loads it) and "local" (all shards in this process: messages are device-to-device copies) -- the
+// GPU tests run 2/4/8 shards multiplexed on one MI355X through the very same diff/apply kernels and sweep loop.
+#include "shard_group.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+
+namespace fiesta {
+
+// ---- librccl, resolved at run time -------------------------------------------------------------------------------
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  static Rccl &get() {
+    static Rccl r;
+    if (!r.lib) {
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+      }
+      if (!r.lib) throw Error(FIESTA_HIP_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
+      auto sym = [&](const char *n) {
+        void *p = dlsym(r.lib, n);
+        if (!p) throw Error(FIESTA_HIP_ERR_DEVICE, std::string("librccl lacks ") + n);
+        return p;
+      };
+      r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+      r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+      r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+      r.Send = (decltype(r.Send))sym("ncclSend");
+      r.Recv = (decltype(r.Recv))sym("ncclRecv");
+      r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+      r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+      r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    }
+    return r;
+  }
+};
+#define FIESTA_RCCL_CHECK(expr)                                                                                   \
+  do {                                                                                                            \
+    ncclResult_t _r = (expr);                                                                                     \
+    if (_r != ncclSuccess) throw Error(FIESTA_HIP_ERR_DEVICE, std::string(#expr) + ": " + Rccl::get().GetErrorString(_r)); \
+  } while (0)
+
+void rccl_unique_id(uint8_t out[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  FIESTA_RCCL_CHECK(Rccl::get().GetUniqueId(&id));
+  memcpy(out, &id, 128);
+}
+
+// ---- geometry of the cut -------------------------------------------------------------------------------------------
+static void layout_of(int world, int l[3]) {
+  switch (world) {
+    case 1: l[0] = 1, l[1] = 1, l[2] = 1; break;
+    case 2: l[0] = 2, l[1] = 1, l[2] = 1; break;
+    case 4: l[0] = 2, l[1] = 2, l[2] = 1; break;
+    case 8: l[0] = 2, l[1] = 2, l[2] = 2; break;
+    default: throw Error(FIESTA_HIP_ERR_INVALID, "unsupported shard count (1, 2, 4 or 8)");
+  }
+}
+void shard_box(const int gg[3], int world, int rank, int lo[3], int size[3]) {
+  int l[3];
+  layout_of(world, l);
+  const int c[3] = {rank / (l[1] * l[2]), (rank / l[2]) % l[1], rank % l[2]};
+  for (int a = 0; a < 3; ++a) {
+    const int base = gg[a] / l[a];
+    if (base < 2 * kGhost) throw Error(FIESTA_HIP_ERR_INVALID, "shards thinner than two ghost layers are not supported");
+    lo[a] = c[a] * base;
+    size[a] = c[a] < l[a] - 1 ? base : gg[a] - base * (l[a] - 1);  // remainders go to the last shard of an axis
+  }
+}
+
+struct ShardGroup::Link {  // one directed neighbour relation of a local shard
+  int peer = -1;                        // global rank of the neighbour
+  int32_t send_lo[3], send_hi[3];       // my owned cells the peer keeps as ghosts, MY local coordinates (inclusive)
+  int32_t recv_lo[3], recv_dims[3];     // the same cells in the PEER's local array: origin of the box, array extents
+  int64_t cells = 0;
+  DevBuf<uint32_t> shadow, send, recv;  // last sent words; outgoing / incoming entries (2 words each)
+  int64_t recv_cap = 0;                 // cells of the box the peer sends to me (capacity of `recv`)
+  int slot = 0;                         // index of this link in the peer's link table (where the peer finds my count)
+};
+struct ShardGroup::Local {
+  DenseMap *map = nullptr;
+  int rank = 0;
+  std::vector<Link> links;
+  DevBuf<unsigned long long> counts;  // per link: entries to send this sweep; [nlinks]: changed ghost cells
+  DevBuf<uint32_t> trans;             // exported occupancy transitions
+};
+
+// local array of `rank`: global origin and extents (owned box grown by the ghost layers that exist)
+static void local_array(const int gg[3], int world, int rank, int org[3], int dims[3], int olo[3], int osz[3]) {
+  shard_box(gg, world, rank, olo, osz);
+  for (int a = 0; a < 3; ++a) {
+    const int glo = olo[a] > 0 ? kGhost : 0, ghi = olo[a] + osz[a] < gg[a] ? kGhost : 0;
+    org[a] = olo[a] - glo;
+    dims[a] = osz[a] + glo + ghi;
+  }
+}
+
+ShardGroup::ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id)
+    : world_(world) {
+  if (maps.empty() || maps.size() != ranks.size()) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: bad shard list");
+  const Geom &g0 = maps[0]->geom();
+  if (!g0.sharded) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: maps must be created as shards (global_grid / shard_lo)");
+  gg_[0] = g0.GX, gg_[1] = g0.GY, gg_[2] = g0.GZ;
+  int l[3];
+  layout_of(world, l);
+  if (rccl_id && maps.size() != 1) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: one shard per process under RCCL");
+  if (!rccl_id && (int)maps.size() != world) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: without RCCL every shard must be local");
+  for (size_t i = 0; i < maps.size(); ++i) {
+    auto L = std::make_unique<Local>();
+    L->map = maps[i];
+    L->rank = ranks[i];
+    const Geom &g = maps[i]->geom();
+    int org[3], dims[3], olo[3], osz[3];
+    local_array(gg_, world, ranks[i], org, dims, olo, osz);
+    if (org[0] != g.gx0 || org[1] != g.gy0 || org[2] != g.gz0 || dims[0] != g.nx || dims[1] != g.ny || dims[2] != g.nz)
+      throw Error(FIESTA_HIP_ERR_INVALID, "shard group: a shard's box does not match the regular cut of the global grid");
+    const int c[3] = {ranks[i] / (l[1] * l[2]), (ranks[i] / l[2]) % l[1], ranks[i] % l[2]};
+    // neighbours in a fixed order (dx, dy, dz lexicographic): both sides enumerate their links the same way
+    for (int dx = -1; dx <= 1; ++dx)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dz = -1; dz <= 1; ++dz) {
+          if (!dx && !dy && !dz) continue;
+          const int n[3] = {c[0] + dx, c[1] + dy, c[2] + dz};
+          if (n[0] < 0 || n[0] >= l[0] || n[1] < 0 || n[1] >= l[1] || n[2] < 0 || n[2] >= l[2]) continue;
+          Link k;
+          k.peer = (n[0] * l[1] + n[1]) * l[2] + n[2];
+          int porg[3], pdims[3], polo[3], posz[3];
+          local_array(gg_, world, k.peer, porg, pdims, polo, posz);
+          // my owned box  intersected with  the peer's local array (its ghost layer towards me), global coordinates
+          int64_t cells = 1, rcells = 1;
+          for (int a = 0; a < 3; ++a) {
+            const int lo = std::max(olo[a], porg[a]), hi = std::min(olo[a] + osz[a], porg[a] + pdims[a]) - 1;
+            k.send_lo[a] = lo - org[a], k.send_hi[a] = hi - org[a];
+            k.recv_lo[a] = lo - porg[a];
+            k.recv_dims[a] = pdims[a];
+            cells *= std::max(0, hi - lo + 1);
+            // what the peer sends me: its owned box intersected with MY local array
+            const int rlo = std::max(polo[a], org[a]), rhi = std::min(polo[a] + posz[a], org[a] + dims[a]) - 1;
+            rcells *= std::max(0, rhi - rlo + 1);
+          }
+          k.cells = cells;
+          k.recv_cap = rcells;
+          L->links.push_back(std::move(k));
+        }
+    // where does the peer list ME?  (same enumeration order on its side)
+    for (Link &k : L->links) {
+      const int pc[3] = {k.peer / (l[1] * l[2]), (k.peer / l[2]) % l[1], k.peer % l[2]};
+      int slot = 0;
+      bool found = false;
+      for (int dx = -1; dx <= 1 && !found; ++dx)
+        for (int dy = -1; dy <= 1 && !found; ++dy)
+          for (int dz = -1; dz <= 1 && !found; ++dz) {
+            if (!dx && !dy && !dz) continue;
+            const int n[3] = {pc[0] + dx, pc[1] + dy, pc[2] + dz};
+            if (n[0] < 0 || n[0] >= l[0] || n[1] < 0 || n[1] >= l[1] || n[2] < 0 || n[2] >= l[2]) continue;
+            if ((n[0] * l[1] + n[1]) * l[2] + n[2] == L->rank) {
+              found = true;
+              break;
+            }
+            ++slot;
+          }
+      k.slot = slot;
+    }
+    hipStream_t s = L->map->stream();
+    FIESTA_HIP_CHECK(hipSetDevice(L->map->device()));
+    for (Link &k : L->links) {
+      k.shadow.ensure((size_t)k.cells, s);
+      k.send.ensure((size_t)k.cells * 2, s);
+      k.recv.ensure((size_t)k.recv_cap * 2, s);
+      // ghost cells start out "never observed", and so does what was "last sent"
+      FIESTA_HIP_CHECK(hipMemsetAsync(k.shadow.p, 0xFF, (size_t)k.cells * sizeof(uint32_t), s));
+    }
+    L->counts.ensure(kMaxLinks + 2, s);
+    FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+    locals_.push_back(std::move(L));
+  }
+  FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_table_, (size_t)world_ * kRow * sizeof(long long)));
+  if (rccl_id) {
+    Local &L = *locals_[0];
+    FIESTA_HIP_CHECK(hipSetDevice(L.map->device()));
+    ncclUniqueId id;
+    memcpy(&id, rccl_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    FIESTA_RCCL_CHECK(Rccl::get().CommInitRank(&comm, world_, id, L.rank));
+    comm_ = comm;
+    FIESTA_HIP_CHECK(hipMalloc((void **)&d_row_, kRow * sizeof(long long)));
+    FIESTA_HIP_CHECK(hipMalloc((void **)&d_table_, (size_t)world_ * kRow * sizeof(long long)));
+  }
+}
+
+ShardGroup::~ShardGroup() {
+  if (comm_) (void)Rccl::get().CommDestroy((ncclComm_t)comm_);
+  if (d_row_) (void)hipFree(d_row_);
+  if (d_table_) (void)hipFree(d_table_);
+  if (h_table_) (void)hipHostFree(h_table_);
+}
+
+// Every shard contributes one row of kRow numbers; afterwards h_table_[rank * kRow + j] holds them all on the host.
+// (RCCL: ONE small all-gather + one stream synchronisation; local: the rows are simply written in place.)
+void ShardGroup::gather_rows(const std::vector<std::vector<long long>> &rows) {
+  if (comm_) {
+    Local &L = *locals_[0];
+    hipStream_t s = L.map->stream();
+    memcpy(&h_table_[(size_t)L.rank * kRow], rows[0].data(), kRow * sizeof(long long));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(d_row_, &h_table_[(size_t)L.rank * kRow], kRow * sizeof(long long), hipMemcpyHostToDevice, s));
+    FIESTA_RCCL_CHECK(Rccl::get().AllGather(d_row_, d_table_, kRow, ncclInt64, (ncclComm_t)comm_, s));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(h_table_, d_table_, (size_t)world_ * kRow * sizeof(long long), hipMemcpyDeviceToHost, s));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+  } else {
+    for (size_t i = 0; i < locals_.size(); ++i)
+      memcpy(&h_table_[(size_t)locals_[i]->rank * kRow], rows[i].data(), kRow * sizeof(long long));
+  }
+}
+
+ShardGroup::Local *ShardGroup::find_local(int rank) {
+  for (auto &L : locals_)
+    if (L->rank == rank) return L.get();
+  return nullptr;
+}
+
+bool ShardGroup::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
+  // 1. local fusion; 2. every shard's transitions to every shard
+  std::vector<std::vector<long long>> rows(locals_.size(), std::vector<long long>(kRow, 0));
+  for (size_t i = 0; i < locals_.size(); ++i) {
+    Local &L = *locals_[i];
+    int64_t ni = 0, nd = 0;
+    L.map->update_occupancy(global_map, &ni, &nd);
+    const int64_t n = L.map->export_transitions(nullptr, 0);
+    L.trans.ensure((size_t)std::max<int64_t>(1, 2 * n), L.map->stream());
+    if (n) L.map->export_transitions(L.trans.p, n);
+    rows[i][0] = n, rows[i][1] = ni, rows[i][2] = nd;
+  }
+  gather_rows(rows);
+  long long tot_i = 0, tot_d = 0, max_n = 0;
+  for (int r = 0; r < world_; ++r) {
+    max_n = std::max(max_n, h_table_[(size_t)r * kRow]);
+    tot_i += h_table_[(size_t)r * kRow + 1];
+    tot_d += h_table_[(size_t)r * kRow + 2];
+  }
+  if (max_n > 0) {
+    if (comm_) {
+      Local &L = *locals_[0];
+      hipStream_t s = L.map->stream();
+      L.trans.ensure((size_t)2 * max_n, s, (size_t)2 * h_table_[(size_t)L.rank * kRow]);
+      gathered_.ensure((size_t)2 * max_n * world_, s);
+      FIESTA_RCCL_CHECK(Rccl::get().AllGather(L.trans.p, gathered_.p, (size_t)2 * max_n, ncclUint32, (ncclComm_t)comm_, s));
+      for (int r = 0; r < world_; ++r)
+        L.map->apply_transitions(gathered_.p + (size_t)2 * max_n * r, h_table_[(size_t)r * kRow]);
+    } else {
+      for (auto &src : locals_) src->map->synchronize();
+      for (auto &dst : locals_)
+        for (auto &src : locals_) dst->map->apply_transitions(src->trans.p, h_table_[(size_t)src->rank * kRow]);
+    }
+  }
+  if (n_ins) *n_ins = tot_i;
+  if (n_del) *n_del = tot_d;
+  return tot_i != 0 || tot_d != 0;
+}
+
+void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t *entries_out) {
+  fiesta_hip_stats total;
+  memset(&total, 0, sizeof(total));
+  auto add = [&](const fiesta_hip_stats &s, bool first) {
+    if (first) total.inserted += s.inserted, total.deleted += s.deleted;
+    total.invalidated += s.invalidated;
+    total.tile_visits += s.tile_visits, total.sweeps += s.sweeps, total.voxel_writes += s.voxel_writes;
+    total.relax_ms += s.relax_ms, total.relax_launches += s.relax_launches;
+  };
+  const auto h0 = std::chrono::steady_clock::now();
+  int64_t rounds = 0;
+  for (auto &L : locals_) {
+    fiesta_hip_stats s;
+    L->map->update_esdf(&s, /*seed_only=*/true);
+    add(s, true);
+  }
+  int32_t sweeps = 0;
+  int64_t sent_total = 0;
+  for (;;) {
+    // ---- diff: changed boundary cells -> entries, per neighbour
+    for (auto &Lp : locals_) {
+      Local &L = *Lp;
+      hipStream_t s = L.map->stream();
+      FIESTA_HIP_CHECK(hipSetDevice(L.map->device()));
+      FIESTA_HIP_CHECK(hipMemsetAsync(L.counts.p, 0, (kMaxLinks + 2) * sizeof(unsigned long long), s));
+      for (size_t k = 0; k < L.links.size(); ++k) {
+        Link &ln = L.links[k];
+        L.map->halo_diff(ln.send_lo, ln.send_hi, ln.shadow.p, ln.recv_lo, ln.recv_dims, ln.send.p, &L.counts.p[k]);
+      }
+    }
+    // ---- counts (the receivers' message sizes) + pending tiles: one gather, one host read
+    std::vector<std::vector<long long>> rows(locals_.size(), std::vector<long long>(kRow, 0));
+    for (size_t i = 0; i < locals_.size(); ++i) {
+      Local &L = *locals_[i];
+      unsigned long long h[kMaxLinks];
+      FIESTA_HIP_CHECK(hipMemcpyAsync(h, L.counts.p, kMaxLinks * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.map->stream()));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(L.map->stream()));
+      for (size_t k = 0; k < L.links.size(); ++k) rows[i][k] = (long long)h[k];
+      rows[i][kMaxLinks] = L.map->pending_tiles();
+    }
+    gather_rows(rows);
+    long long any = 0;
+    for (int r = 0; r < world_; ++r)
+      for (int j = 0; j <= kMaxLinks; ++j) any += h_table_[(size_t)r * kRow + j];
+    if (!any) break;
+    ++sweeps;
+    // ---- send / receive exactly the changed entries
+    if (comm_) {
+      Local &L = *locals_[0];
+      hipStream_t s = L.map->stream();
+      FIESTA_RCCL_CHECK(Rccl::get().GroupStart());
+      for (size_t k = 0; k < L.links.size(); ++k) {
+        Link &ln = L.links[k];
+        const long long ns = h_table_[(size_t)L.rank * kRow + k], nr = h_table_[(size_t)ln.peer * kRow + ln.slot];
+        if (ns) FIESTA_RCCL_CHECK(Rccl::get().Send(ln.send.p, (size_t)2 * ns, ncclUint32, ln.peer, (ncclComm_t)comm_, s));
+        if (nr) FIESTA_RCCL_CHECK(Rccl::get().Recv(ln.recv.p, (size_t)2 * nr, ncclUint32, ln.peer, (ncclComm_t)comm_, s));
+        sent_total += ns;
+      }
+      FIESTA_RCCL_CHECK(Rccl::get().GroupEnd());
+      for (size_t k = 0; k < L.links.size(); ++k) {
+        Link &ln = L.links[k];
+        L.map->halo_apply_sparse(ln.recv.p, h_table_[(size_t)ln.peer * kRow + ln.slot], &L.counts.p[kMaxLinks]);
+      }
+    } else {
+      for (auto &Lp : locals_) Lp->map->synchronize();  // (every send buffer is complete before anybody copies from it)
+      for (auto &Lp : locals_) {
+        Local &L = *Lp;
+        FIESTA_HIP_CHECK(hipSetDevice(L.map->device()));
+        for (size_t k = 0; k < L.links.size(); ++k) {
+          Link &ln = L.links[k];
+          Local *P = find_local(ln.peer);
+          const long long nr = h_table_[(size_t)ln.peer * kRow + ln.slot];
+          sent_total += h_table_[(size_t)L.rank * kRow + k];
+          if (!nr) continue;
+          FIESTA_HIP_CHECK(hipMemcpyAsync(ln.recv.p, P->links[ln.slot].send.p, (size_t)2 * nr * sizeof(uint32_t),
+                                          hipMemcpyDeviceToDevice, L.map->stream()));
+          L.map->halo_apply_sparse(ln.recv.p, nr, &L.counts.p[kMaxLinks]);
+        }
+      }
+    }
+    // ---- relax what the new ghost values woke up
+    int64_t r_max = 0;
+    for (auto &L : locals_) {
+      fiesta_hip_stats s;
+      int64_t pending = 0;
+      L->map->relax_pending(&s, &pending);
+      add(s, false);
+      r_max = std::max<int64_t>(r_max, s.rounds);
+    }
+    rounds += r_max;
+    if (sweeps > 100000) throw Error(FIESTA_HIP_ERR_STATE, "shard group: ghost exchange does not converge");
+  }
+  total.rounds = rounds;
+  total.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+  total.device_ms = total.host_ms;
+  if (st) *st = total;
+  if (sweeps_out) *sweeps_out = sweeps;
+  if (entries_out) *entries_out = sent_total;
+}
+
+}  // namespace fiesta

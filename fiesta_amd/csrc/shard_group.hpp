@@ -1,0 +1,40 @@
+// fiesta_amd/csrc/shard_group.hpp -- one map cut into spatial shards: host protocol over RCCL (see shard_group.hip).
+#pragma once
+#include <chrono>
+#include <memory>
+#include <vector>
+
+#include "dense_map.hpp"
+
+namespace fiesta {
+
+constexpr int kGhost = 2;  // stencil radius of the reference's 24 directions
+
+void rccl_unique_id(uint8_t out[128]);
+// owned box of shard `rank` in the regular cut of a global grid into `world` shards
+void shard_box(const int global_grid[3], int world, int rank, int lo[3], int size[3]);
+
+class ShardGroup {
+ public:
+  // maps[i] is the shard of global rank ranks[i].  rccl_id != nullptr: one shard per process, `world` ranks over RCCL.
+  // rccl_id == nullptr: all `world` shards live in this process (tests, N shards multiplexed on one GPU).
+  ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id);
+  ~ShardGroup();
+  bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
+  void update_esdf(fiesta_hip_stats *st, int32_t *sweeps, int64_t *entries_sent);
+
+ private:
+  static constexpr int kMaxLinks = 26, kRow = 28;
+  struct Link;
+  struct Local;
+  void gather_rows(const std::vector<std::vector<long long>> &rows);
+  Local *find_local(int rank);
+  int world_ = 1;
+  int gg_[3] = {0, 0, 0};
+  std::vector<std::unique_ptr<Local>> locals_;
+  void *comm_ = nullptr;  // ncclComm_t
+  long long *h_table_ = nullptr, *d_row_ = nullptr, *d_table_ = nullptr;
+  DevBuf<uint32_t> gathered_;
+};
+
+}  // namespace fiesta

@@ -130,6 +130,12 @@ class DistTransport:
         self.device = device if device is not None else torch.device("cpu")
         self.on_gpu = self.device.type == "cuda"
 
+    def broadcast_bytes(self, buf):
+        """rank 0's bytes to every rank (the RCCL unique id of the native shard group)."""
+        t = self.torch.from_numpy(np.ascontiguousarray(buf, dtype=np.uint8).copy()).to(self.device)
+        self.dist.broadcast(t, src=0)
+        return t.cpu().numpy()
+
     def allreduce_sum(self, value):
         t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
@@ -194,13 +200,15 @@ class ShardedESDFMap:
     builds one shard engine; the default builds fiesta_amd.ESDFMap on `devices[rank % len(devices)]`."""
 
     def __init__(self, origin, resolution, global_grid, n_shards, transport=None, devices=(0,), make_shard=None,
-                 update_engine=0):
+                 update_engine=0, native=None):
         self.origin = np.asarray(origin, np.float64).reshape(3)
         self.resolution = float(resolution)
         self.global_grid = tuple(int(v) for v in global_grid)
         self.layout = shard_layout(n_shards)
         self.boxes = shard_boxes(self.global_grid, self.layout)
         self.transport = transport if transport is not None else LocalTransport(n_shards)
+        self.n_shards = n_shards
+        default_shards = make_shard is None
         if make_shard is None:
             from .esdf_map import ESDFMap
 
@@ -219,8 +227,40 @@ class ShardedESDFMap:
             self.plans[r] = exchange_plan(r, self.layout, info)
         self.last_insert = self.last_delete = 0
         self.last_sweeps = 0
+        self.last_entries_sent = 0
         # a wave crosses at most sum(layout) shard faces; anything far beyond that is a protocol bug
         self.max_sweeps = 16 + 4 * sum(self.layout)
+        # The protocol runs natively (C++ over RCCL / device copies, fiesta_amd/csrc/shard_group.hip) whenever the shards
+        # are real HIP maps reachable from one group: all of them in this process, or one per rank on the GPU transport.
+        # The Python loop below is the same protocol spelled out over torch.distributed -- what the CPU (gloo) tests drive
+        # with a numpy stand-in shard, and a cross-check for the native engine.
+        self._group = None
+        n_here = len(self.shards)
+        can = default_shards and (n_here == n_shards or (n_here == 1 and getattr(self.transport, "on_gpu", False)))
+        if native is None:
+            native = can
+        if native:
+            if not can:
+                raise ValueError("native shard group: needs HIP shards, all local or one per rank on the RCCL transport")
+            self._open_native_group()
+
+    def _open_native_group(self):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        ranks = sorted(self.shards)
+        rccl_id = None
+        if self.n_shards > 1 and len(ranks) == 1:
+            buf = np.zeros(128, np.uint8)
+            if self.transport.rank == 0:
+                _lib.check(lib.fiesta_hip_rccl_unique_id(buf.ctypes.data_as(C.c_void_p)))
+            rccl_id = self.transport.broadcast_bytes(buf)
+        handles = (C.c_void_p * len(ranks))(*[self.shards[r]._h for r in ranks])
+        rk = (C.c_int32 * len(ranks))(*ranks)
+        g = C.c_void_p()
+        idp = rccl_id.ctypes.data_as(C.c_void_p) if rccl_id is not None else None
+        _lib.check(lib.fiesta_hip_shard_group_create(handles, rk, len(ranks), self.n_shards, idp, C.byref(g)))
+        self._group, self._glib, self._check = g, lib, _lib.check
 
     # -- plumbing ---------------------------------------------------------------------------------------------
     def _owner_masks(self, vox):
@@ -229,6 +269,9 @@ class ShardedESDFMap:
             yield r, np.all((vox >= lo) & (vox < lo + size), axis=1)
 
     def close(self):
+        if self._group is not None:
+            self._glib.fiesta_hip_shard_group_destroy(self._group)
+            self._group = None
         for sh in self.shards.values():
             if hasattr(sh, "close"):
                 sh.close()
@@ -256,6 +299,13 @@ class ShardedESDFMap:
             sh.SetOccupancyBox(lo, hi, occ)  # the device kernel keeps only owned voxels
 
     def UpdateOccupancy(self, global_map=True):
+        if self._group is not None:
+            import ctypes as C
+            ni, nd, any_ = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+            self._check(self._glib.fiesta_hip_shard_group_update_occupancy(self._group, int(bool(global_map)), C.byref(ni),
+                                                                           C.byref(nd), C.byref(any_)))
+            self.last_insert, self.last_delete = ni.value, nd.value
+            return bool(any_.value)
         any_local, ni, nd = False, 0, 0
         for sh in self.shards.values():
             any_local |= bool(sh.UpdateOccupancy(global_map))
@@ -272,6 +322,15 @@ class ShardedESDFMap:
         return sum(self.transport.exchange_axis(self.shards, self.plans, a) for a in range(3))
 
     def UpdateESDF(self):
+        if self._group is not None:
+            import ctypes as C
+            from ._lib import Stats
+            st, sweeps, sent = Stats(), C.c_int32(0), C.c_int64(0)
+            self._check(self._glib.fiesta_hip_shard_group_update_esdf(self._group, C.byref(st), C.byref(sweeps), C.byref(sent)))
+            d = st.as_dict()
+            d["sweeps"] = self.last_sweeps = sweeps.value
+            d["halo_entries_sent"] = self.last_entries_sent = sent.value
+            return d
         stats = {"inserted": 0, "deleted": 0, "invalidated": 0, "rounds": 0, "tile_visits": 0, "relax_ms": 0.0,
                  "sweeps": 0}
         for sh in self.shards.values():

@@ -248,6 +248,29 @@ int fiesta_hip_esdf_seed(fiesta_hip_map *m, fiesta_hip_stats *stats);
  * *pending_tiles (nullable) = tiles that were pending at entry. */
 int fiesta_hip_relax_pending(fiesta_hip_map *m, fiesta_hip_stats *stats, int64_t *pending_tiles);
 
+/* ---- the shard protocol itself, native (fiesta_amd/csrc/shard_group.hip): C++ host code over RCCL ----
+ * A group drives UpdateOccupancy / UpdateESDF of ONE map cut into `world` shards (1, 2, 4 or 8: 1x1x1, 2x1x1, 2x2x1,
+ * 2x2x2; shard r owns box r of the regular cut, see fiesta_hip_shard_box).  Two set-ups:
+ *   - one rank per GPU: n_local = 1, local_ranks[0] = this process's rank, rccl_id = the 128 bytes rank 0 obtained from
+ *     fiesta_hip_rccl_unique_id and handed to every rank out of band (e.g. a torch.distributed / MPI broadcast);
+ *   - every shard in this process (tests; N shards multiplexed on one GPU): n_local = world, rccl_id = NULL.
+ * Per sweep of UpdateESDF each shard sends only the boundary cells that CHANGED since it last sent them
+ * ({receiver cell index, word} entries) to its <= 26 neighbours in one ncclGroup; one small all-gather per sweep carries
+ * the message sizes and the convergence test. */
+typedef struct fiesta_hip_shard_group fiesta_hip_shard_group;
+int fiesta_hip_rccl_unique_id(uint8_t id[128]);
+int fiesta_hip_shard_box(const int32_t global_grid[3], int32_t world, int32_t rank, int32_t lo[3], int32_t size[3]);
+int fiesta_hip_shard_group_create(fiesta_hip_map *const *local_shards, const int32_t *local_ranks, int32_t n_local,
+                                  int32_t world, const uint8_t *rccl_id, fiesta_hip_shard_group **out);
+int fiesta_hip_shard_group_destroy(fiesta_hip_shard_group *g);
+/* ESDFMap::UpdateOccupancy of the whole map: *n_insert / *n_delete are the queue sizes summed over all shards. */
+int fiesta_hip_shard_group_update_occupancy(fiesta_hip_shard_group *g, int32_t global_map, int64_t *n_insert,
+                                            int64_t *n_delete, int32_t *any);
+/* ESDFMap::UpdateESDF of the whole map. stats: summed over this process's shards; *sweeps: ghost exchanges;
+ * *entries_sent: boundary entries this process sent (8 bytes each). */
+int fiesta_hip_shard_group_update_esdf(fiesta_hip_shard_group *g, fiesta_hip_stats *stats, int32_t *sweeps,
+                                       int64_t *entries_sent);
+
 /* Blocks until all device work of the map has finished. */
 int fiesta_hip_synchronize(fiesta_hip_map *m);
 

@@ -38,11 +38,16 @@ def compare(sharded, cpu, gs):
     assert np.array_equal(((vox[have] - gc[have]) ** 2).sum(-1), gd2[have])
 
 
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
 @pytest.mark.parametrize("n_shards", [1, 2, 4, 8])
-def test_sharded_matches_single_grid_oracle(hip_lib, oracle_libs, best_oracle_kind, n_shards):
+def test_sharded_matches_single_grid_oracle(hip_lib, oracle_libs, best_oracle_kind, n_shards, native):
+    """native: the C++ protocol engine (shard_group.hip: sparse changed-entry halos, all 26 neighbours in one phase; the
+    RCCL transport differs from this one only in how a message moves).  python: the same protocol spelled out in
+    fiesta_amd/sharded.py (dense three-phase slabs), the form the CPU gloo tests drive."""
     from fiesta_amd.sharded import ShardedESDFMap
     gs, res = (72, 64, 80), 0.1
-    sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards)
+    sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards, native=native)
+    assert (sm._group is not None) == native
     cpu = oracle_libs.OracleMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res), kind=best_oracle_kind)
     assert cpu.grid_size == gs
     for m in (sm, cpu):
@@ -62,7 +67,7 @@ def test_sharded_matches_single_grid_oracle(hip_lib, oracle_libs, best_oracle_ki
     occ = np.argwhere(cpu.dump_dense(("occ",))["occ"].reshape(gs) == 1).astype(np.int32)
     drive(sm, cpu, [([], occ, 6)])
     compare(sm, cpu, gs)
-    assert sm.last_sweeps >= 2
+    assert sm.last_sweeps >= 1
     sm.close()
 
 
@@ -78,7 +83,8 @@ def test_single_obstacle_wave_crosses_every_shard(hip_lib, oracle_libs, best_ora
     allv = np.stack(np.meshgrid(*[np.arange(n) for n in gs], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
     drive(sm, cpu, [([], allv, 1), (np.array([[1, 2, 3]], np.int32), [], 3)])
     compare(sm, cpu, gs)
-    assert sm.last_sweeps >= 3
+    assert sm.last_sweeps >= 3   # the wave needs a ghost exchange per shard face it crosses
+    assert sm.last_entries_sent > 0
     drive(sm, cpu, [(np.array([[60, 61, 59]], np.int32), np.array([[1, 2, 3]], np.int32), 6)])
     compare(sm, cpu, gs)
     sm.close()
@@ -89,7 +95,7 @@ def test_device_pointer_halo_path_equals_host_path(hip_lib):
     import torch  # noqa: F401  (device buffers)
     from fiesta_amd.sharded import ShardedESDFMap
     gs, res = (40, 24, 36), 0.1
-    maps = [ShardedESDFMap((0, 0, 0), res, gs, 2) for _ in range(2)]
+    maps = [ShardedESDFMap((0, 0, 0), res, gs, 2, native=False) for _ in range(2)]
     rng = np.random.RandomState(1)
     S = (rng.rand(80, 3) * gs).astype(np.int32)
     for sm in maps:
