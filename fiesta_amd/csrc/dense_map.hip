@@ -1041,11 +1041,6 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
 // Valid when the reference's propagation has nothing to be gated by: every voxel of the array observed, the update
 // window = the whole array, one unsharded map.  Then the fixed point of src/ESDFMap.cpp:339-392 IS the Euclidean
 // feature transform of the occupied set, whatever the previous state was.
-bool DenseMap::bulk_applicable() const {
-  const Geom &g = g_;
-  return !g.sharded && !g.wrap && g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1;
-}
-
 template <int S, int LANES, int WAVES>
 static void launch_ft_plane(const FtArgs &a, int blocks, hipStream_t s) {
   hipLaunchKernelGGL((k_ft_plane<S, LANES, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, s, a);
@@ -1055,30 +1050,63 @@ static void launch_ft_x(const FtArgs &a, int blocks, hipStream_t s) {
   hipLaunchKernelGGL((k_ft_x<S, LANES, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, s, a);
 }
 
-void DenseMap::run_bulk(fiesta_hip_stats *st) {
+// The transform of this map's array.  Unsharded: the region is the array, the bitmap the map's own.  Sharded: the
+// region is the local array (owned box + ghost layers) grown by `margin` voxels towards every neighbour shard and read
+// from this shard's replica of the GLOBAL occupancy bitmap -- no communication at all.  The result is exact iff every
+// voxel written found its obstacle within the margin (an obstacle outside the region is farther than the margin from
+// every voxel of the array); *exact reports that, from the largest distance written.  Returns false (nothing done) if the
+// region exceeds the 1024 voxels per axis the transform's site packing allows.
+bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   const Geom &g = g_;
   FtArgs a;
   memset(&a, 0, sizeof(a));
-  a.nx = g.nx, a.ny = g.ny, a.nz = g.nz, a.nzw = g.nzw, a.nzc = (g.nz + 63) / 64;
-  a.gx0 = g.gx0, a.gy0 = g.gy0, a.gz0 = g.gz0;
-  const uint32_t items_a = (uint32_t)(g.nx * a.nzc), items_b = (uint32_t)(g.ny * a.nzc);
+  int rlo[3], rhi[3], mlo[3], mhi[3];  // region in GLOBAL coordinates (inclusive); margins actually obtained per side
+  const int l0[3] = {g.gx0, g.gy0, g.gz0}, ln[3] = {g.nx, g.ny, g.nz}, G[3] = {g.GX, g.GY, g.GZ};
+  bool open_side = false;  // some side of the region neither reaches the global boundary nor ... (needs the margin test)
+  for (int k = 0; k < 3; ++k) {
+    rlo[k] = g.sharded ? std::max(0, l0[k] - margin) : l0[k];
+    rhi[k] = g.sharded ? std::min(G[k] - 1, l0[k] + ln[k] - 1 + margin) : l0[k] + ln[k] - 1;
+  }
+  if (g.sharded) {  // whole bitmap words along z
+    rlo[2] &= ~31;
+    rhi[2] = std::min(G[2] - 1, rhi[2] | 31);
+  }
+  for (int k = 0; k < 3; ++k) {
+    mlo[k] = l0[k] - rlo[k], mhi[k] = rhi[k] - (l0[k] + ln[k] - 1);
+    if (g.sharded && ((rlo[k] > 0) || (rhi[k] < G[k] - 1))) open_side = true;
+    if (rhi[k] - rlo[k] + 1 > 1024) return false;
+  }
+  a.nx = rhi[0] - rlo[0] + 1, a.ny = rhi[1] - rlo[1] + 1, a.nz = rhi[2] - rlo[2] + 1;
+  a.nzw = (a.nz + 31) / 32, a.nzc = (a.nz + 63) / 64;
+  a.gx0 = rlo[0], a.gy0 = rlo[1], a.gz0 = rlo[2];
+  if (g.sharded) {
+    a.src = gocc_, a.sx0 = rlo[0], a.sy0 = rlo[1], a.sw0 = rlo[2] / 32, a.sny = g.GY, a.snzw = g.GZW;
+  } else {
+    a.src = occbits_, a.sx0 = 0, a.sy0 = 0, a.sw0 = 0, a.sny = g.ny, a.snzw = g.nzw;
+  }
+  a.ox0 = mlo[0], a.oy0 = mlo[1], a.oz0 = mlo[2];
+  a.onx = g.nx, a.ony = g.ny, a.onz = g.nz;
+  const int64_t rn = (int64_t)a.nx * a.ny * a.nz;
+  const uint32_t items_a = (uint32_t)(a.nx * a.nzc), items_b = (uint32_t)(a.ny * a.nzc);
   const uint32_t cap = std::max(items_a, items_b);
-  ft_inter_.ensure((size_t)g.n, stream_);
-  ft_rowlist_.ensure((size_t)g.nx * g.ny, stream_);
-  ft_rowcnt_.ensure((size_t)g.nx + 32, stream_);  // + the 1024-bit plane mask
+  ft_inter_.ensure((size_t)rn, stream_);
+  ft_rowlist_.ensure((size_t)a.nx * a.ny, stream_);
+  ft_rowcnt_.ensure((size_t)a.nx + 32, stream_);  // + the 1024-bit plane mask
   ft_ovf_.ensure((size_t)cap * 6, stream_);
-  a.occbits = occbits_;
   a.rowlist = ft_rowlist_.p;
   a.rowcnt = ft_rowcnt_.p;
-  a.planemask = reinterpret_cast<uint32_t *>(ft_rowcnt_.p + g.nx);
+  a.planemask = reinterpret_cast<uint32_t *>(ft_rowcnt_.p + a.nx);
   FIESTA_HIP_CHECK(hipMemsetAsync(a.planemask, 0, 32 * sizeof(uint32_t), stream_));
   a.inter = ft_inter_.p;
-  a.coc = coc_;
-  a.maxd2 = track_ ? &counters_[C_MAXD2] : nullptr;
-  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 6 * sizeof(unsigned long long), stream_));
-  if (track_) zero_counter(C_MAXD2);
+  // a shard's transform lands in a side buffer first: it only replaces the field once every shard has confirmed that
+  // its margin sufficed (bulk_commit); if not, the frontier rounds take over from the untouched field
+  if (g.sharded) ft_out_.ensure((size_t)g.n, stream_);
+  a.coc = g.sharded ? ft_out_.p : coc_;
+  const bool want_max = track_ || open_side;
+  a.maxd2 = want_max ? &counters_[C_FT_MAXD2] : nullptr;
+  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[0], stream_));
-  hipLaunchKernelGGL(k_ft_rows, dim3(g.nx), dim3(256), 0, stream_, a);
+  hipLaunchKernelGGL(k_ft_rows, dim3(a.nx), dim3(256), 0, stream_, a);
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[1], stream_));
   // four tiers per pass: rings of S0 (16 or 32) entries for everybody, then 64, 256 and finally 1024 entries x 16
@@ -1122,6 +1150,92 @@ void DenseMap::run_bulk(fiesta_hip_stats *st) {
     st->bulk = 1;
     st->relax_launches = 9;
   }
+  if (want_max) {
+    const unsigned long long dmax2 = read_counter(C_FT_MAXD2);
+    if (track_) {
+      h_counters_[C_MAXD2] = dmax2;
+      FIESTA_HIP_CHECK(hipMemcpyAsync(&counters_[C_MAXD2], &h_counters_[C_MAXD2], sizeof(unsigned long long), hipMemcpyHostToDevice, stream_));
+    }
+    bool ok = true;
+    for (int k = 0; k < 3; ++k) {
+      if (rlo[k] > 0 && (unsigned long long)mlo[k] * mlo[k] < dmax2) ok = false;
+      if (rhi[k] < G[k] - 1 && (unsigned long long)mhi[k] * mhi[k] < dmax2) ok = false;
+    }
+    if (exact) *exact = ok || !g.sharded;
+    if (st) st->ft_max_d2 = (int64_t)dmax2;
+  } else if (exact) {
+    *exact = true;
+  }
+  return true;
+}
+
+// The map-local half of the engine choice: may this update be served by the bulk transform at all?
+bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
+  const Geom &g = g_;
+  if (update_engine_ == 1 || g.wrap) return false;
+  if (!(g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1)) return false;
+  const long long owned = (long long)(g.ox1 - g.ox0 + 1) * (g.oy1 - g.oy0 + 1) * (g.oz1 - g.oz0 + 1);
+  if ((long long)h_counters_[C_OBSERVED] != owned) return false;
+  if (stale_inf_) {  // re-validate: does any observed voxel still wait for its first wave?
+    zero_counter(C_SCRATCH);
+    hipLaunchKernelGGL(k_count_stale, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
+                       &counters_[C_SCRATCH]);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    // (with no obstacle before this update every voxel legitimately reads "no obstacle"; a shard cannot tell from its own
+    //  counters whether another shard held one, so it only trusts the scan)
+    const long long before = (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd;
+    if (read_counter(C_SCRATCH) == 0 || (!g.sharded && before <= 0)) stale_inf_ = false;
+  }
+  return !stale_inf_;
+}
+
+// After a successful bulk transform: the queues are consumed, timings and counters reported.
+void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
+  zero_counter(C_INSERT);
+  zero_counter(C_DELETE);
+  if (g_.sharded) zero_counter(C_REMOTE_DEL);
+  FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
+  collect_stats(nullptr);
+  FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  if (st) {
+    float ms = 0, m1 = 0, m2 = 0, m3 = 0;
+    FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    FIESTA_HIP_CHECK(hipEventElapsedTime(&m1, ft_ev_[0], ft_ev_[1]));
+    FIESTA_HIP_CHECK(hipEventElapsedTime(&m2, ft_ev_[1], ft_ev_[2]));
+    FIESTA_HIP_CHECK(hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]));
+    st->device_ms = ms;
+    st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
+    st->relax_ms = (double)m1 + m2 + m3;
+    for (int k = 0; k < 6; ++k) st->ft_overflow[k] = (int64_t)h_counters_[C_FT_OVF0 + k];
+    st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+  }
+  // adapt the first tier to the scene: deep deques (far from obstacles) -> start with the 32-entry rings next time
+  const int64_t spill = (int64_t)h_counters_[C_FT_OVF0] + (int64_t)h_counters_[C_FT_OVF0 + 3];
+  if (!ft_s0_fixed_ && ft_s0_ == 16 && spill * 50 > (int64_t)(g_.nx + g_.ny) * ((g_.nz + 63) / 64)) ft_s0_ = 32;
+}
+
+// The sharded driver's bulk step (shard_group.hip): transform with `margin`, report exactness; commit consumes the queues.
+bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
+  use_device();
+  ++epoch_;
+  FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+  reset_stats_counters();
+  if (st) memset(st, 0, sizeof(*st));
+  return run_bulk(st, margin, exact);
+}
+void DenseMap::bulk_commit(fiesta_hip_stats *st) {
+  use_device();
+  if (g_.sharded) FIESTA_HIP_CHECK(hipMemcpyAsync(coc_, ft_out_.p, (size_t)g_.n * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
+  bulk_finish(st, std::chrono::steady_clock::now());
+}
+void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long long *nocc, bool *eligible) {
+  use_device();
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  *ni = h_counters_[C_INSERT], *nd = h_counters_[C_DELETE];
+  *nocc = (long long)h_counters_[C_NOCC];
+  *eligible = bulk_eligible(*ni, *nd);
 }
 
 void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
@@ -1150,41 +1264,14 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   zero_counter(C_LIST0);
   // Engine choice.  The bulk transform costs one fixed sweep over the grid; the frontier rounds cost in proportion to
   // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).
-  if (!seed_only && update_engine_ != 1 && (long long)h_counters_[C_OBSERVED] == (long long)g_.n && bulk_applicable()) {
+  if (!seed_only && !g_.sharded && bulk_eligible(ni, nd)) {
     const double nocc = (double)(long long)h_counters_[C_NOCC];
-    bool want = update_engine_ == 2 || (double)(ni + nd) >= bulk_ratio_ * std::max(nocc, 1.0);
-    if (want && stale_inf_) {  // re-validate: does any observed voxel still wait for its first wave?
-      zero_counter(C_SCRATCH);
-      hipLaunchKernelGGL(k_count_stale, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
-                         &counters_[C_SCRATCH]);
-      FIESTA_HIP_CHECK(hipGetLastError());
-      // (with no obstacle before this update every voxel legitimately reads "no obstacle")
-      if (read_counter(C_SCRATCH) == 0 || (long long)(nocc - (double)ni + (double)nd) <= 0) stale_inf_ = false;
-      want = !stale_inf_;
-    }
-    if (want) {
-      run_bulk(st);
-      zero_counter(C_INSERT);
-      zero_counter(C_DELETE);
-      FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
-      collect_stats(st);
-      FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
-      if (st) {
-        float ms = 0, m1 = 0, m2 = 0, m3 = 0;
-        FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
-        FIESTA_HIP_CHECK(hipEventElapsedTime(&m1, ft_ev_[0], ft_ev_[1]));
-        FIESTA_HIP_CHECK(hipEventElapsedTime(&m2, ft_ev_[1], ft_ev_[2]));
-        FIESTA_HIP_CHECK(hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]));
-        st->device_ms = ms;
-        st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
-        st->relax_ms = (double)m1 + m2 + m3;
-        for (int k = 0; k < 6; ++k) st->ft_overflow[k] = (int64_t)h_counters_[C_FT_OVF0 + k];
-        // adapt the first tier to the scene: deep deques (far from obstacles) -> start with the 32-entry rings next time
-        const int64_t spill = st->ft_overflow[0] + st->ft_overflow[3];
-        if (!ft_s0_fixed_ && ft_s0_ == 16 && spill * 50 > (int64_t)(g_.nx + g_.ny) * ((g_.nz + 63) / 64)) ft_s0_ = 32;
-        st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+    if (update_engine_ == 2 || (double)(ni + nd) >= bulk_ratio_ * std::max(nocc, 1.0)) {
+      bool exact = true;
+      if (run_bulk(st, 0, &exact)) {
+        bulk_finish(st, h0);
+        return;
       }
-      return;
     }
   }
   if (ni) {

@@ -1,6 +1,7 @@
 // fiesta_amd/csrc/dense_map.hpp -- dense-array ESDF map resident in HBM (host-side class).
 // Replaces the dense flavour of fiesta::ESDFMap (include/ESDFMap.h:37-166, src/ESDFMap.cpp).
 #pragma once
+#include <chrono>
 #include <vector>
 
 #include "../../include/fiesta_hip.h"
@@ -56,6 +57,7 @@ enum Counter {
   C_REMOTE_DEL,  // sharded maps: some shard reported an occupied->free transition since the last UpdateESDF
   C_FT_OVF0,     // bulk path: lengths of the ring-overflow lists (pass A tiers 0-2, pass B tiers 0-2)
   C_FT_OVF5 = C_FT_OVF0 + 5,
+  C_FT_MAXD2,    // bulk path: largest d^2 written (2^30: a voxel found no obstacle in its region)
   C_PROF0,  // 8 profiling slots (FIESTA_HIP_PROF=1): cycles in stage / propagate / write-back, queue items, ...
   C_COUNT = C_PROF0 + 8
 };
@@ -91,6 +93,13 @@ class DenseMap {
   bool check_update();
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
   void update_esdf(fiesta_hip_stats *st, bool seed_only = false);
+  // the bulk transform, step by step, for the sharded driver (shard_group.hip): probe = queue sizes + local eligibility,
+  // try = transform with a margin around the shard (false: region too large), commit = consume the queues
+  void bulk_probe(unsigned long long *ni, unsigned long long *nd, long long *nocc, bool *eligible);
+  bool bulk_try(fiesta_hip_stats *st, int margin, bool *exact);
+  void bulk_commit(fiesta_hip_stats *st);
+  int update_engine() const { return update_engine_; }
+  double bulk_ratio() const { return bulk_ratio_; }
   // continue relaxing tiles that are already flagged (after ghost entries were applied)
   void relax_pending(fiesta_hip_stats *st, int64_t *pending);
 
@@ -151,8 +160,9 @@ class DenseMap {
   void zero_counter(int which);
   void ensure_touched_capacity(int64_t extra);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list);
-  bool bulk_applicable() const;
-  void run_bulk(fiesta_hip_stats *st);
+  bool bulk_eligible(unsigned long long ni, unsigned long long nd);
+  bool run_bulk(fiesta_hip_stats *st, int margin, bool *exact);
+  void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0);
   void reset_stats_counters();
   void enable_distance_tracking();
   void collect_stats(fiesta_hip_stats *st);
@@ -189,7 +199,7 @@ class DenseMap {
   bool stale_inf_ = false;
   int ft_s0_ = 16;            // ring size of the bulk path's first tier: 16, or 32 once a scene needed deeper deques
   bool ft_s0_fixed_ = false;  // (FIESTA_HIP_FT_S0 pins it)
-  DevBuf<uint32_t> ft_inter_, ft_ovf_;
+  DevBuf<uint32_t> ft_inter_, ft_ovf_, ft_out_;
   DevBuf<uint16_t> ft_rowlist_;
   DevBuf<int32_t> ft_rowcnt_;
   hipEvent_t ft_ev_[4] = {nullptr, nullptr, nullptr, nullptr};

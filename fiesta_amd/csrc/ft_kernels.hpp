@@ -20,22 +20,32 @@
 
 namespace fiesta {
 
+// The transform runs over a REGION (nx x ny x nz voxels, at most 1024 per axis: sites are packed in 3 x 10 bits of
+// region coordinates) whose occupancy comes from any bitmap -- the map's own (unsharded: region = the whole array) or a
+// shard's replica of the GLOBAL bitmap (region = the shard's array grown by a margin, see DenseMap::run_bulk) -- and
+// writes the voxels of an OUTPUT box inside the region.
 struct FtArgs {
-  int nx, ny, nz, nzw, nzc;  // nzc = 64-voxel column groups per z-row
-  int gx0, gy0, gz0;         // global coordinates of local voxel (0,0,0): sites are stored in global coordinates
-  const uint32_t *occbits;   // [nx][ny][nzw]
+  int nx, ny, nz, nzw, nzc;  // region extents; nzw = 32-bit words, nzc = 64-voxel column groups per z-row
+  int gx0, gy0, gz0;         // global coordinates of region voxel (0,0,0): ids are stored in global coordinates
+  const uint32_t *src;       // occupancy bitmap; row (x, y) of the region starts at word ((x+sx0)*sny + y+sy0)*snzw + sw0
+  int sx0, sy0, sw0, sny, snzw;
   uint16_t *rowlist;         // [nx][ny]: non-empty rows of plane x, ascending
   int32_t *rowcnt;           // [nx]
   uint32_t *planemask;       // [32]: bit x = plane x holds a site (zeroed before k_ft_rows)
-  uint32_t *inter;           // [nx][ny][nz]: pass A result, y' << 10 | z' (local coordinates)
-  vox_t *coc;                // the map's voxel words (pass B output)
+  uint32_t *inter;           // [nx][ny][nz]: pass A result, y' << 10 | z' (region coordinates)
+  vox_t *coc;                // output array (the map's voxel words) with extents (., ony, onz); region voxel (x,y,z) is
+  int ox0, oy0, oz0;         // output voxel (x - ox0, y - oy0, z - oz0), written iff inside [0,onx) x [0,ony) x [0,onz)
+  int onx, ony, onz;
   // work items: implicit 0..n_items-1 (items == nullptr) or an explicit list whose length lives on the device
   const uint32_t *items;
   const unsigned long long *n_items_dev;
   uint32_t n_items;
   uint32_t *ovf_list;  // items whose ring overflowed, for the next tier
   unsigned long long *ovf_count;
-  unsigned long long *maxd2;  // optional: atomicMax of every d^2 written (maps that track it)
+  unsigned long long *maxd2;  // optional: atomicMax of every d^2 written; a voxel without any site counts as 2^30
+  __device__ __forceinline__ const uint32_t *row(int x, int y) const {
+    return src + ((int64_t)(x + sx0) * sny + (y + sy0)) * snzw + sw0;
+  }
 };
 
 // LDS rings of one wave: site[slot][lane] (4 B) + start[slot][lane] (2 B).  LANES < 64: only the first LANES lanes of
@@ -79,9 +89,9 @@ __global__ __launch_bounds__(256) void k_ft_rows(FtArgs a) {
     const int y = y0 + tid;
     bool any = false;
     if (y < a.ny) {
-      const uint32_t *row = a.occbits + ((int64_t)x * a.ny + y) * a.nzw;
+      const uint32_t *row = a.row(x, y);
       uint32_t acc = 0;
-      if ((a.nzw & 3) == 0) {
+      if ((a.nzw & 3) == 0 && (a.snzw & 3) == 0 && (a.sw0 & 3) == 0) {
         for (int w = 0; w < a.nzw; w += 4) {
           const uint4 q = *reinterpret_cast<const uint4 *>(row + w);
           acc |= q.x | q.y | q.z | q.w;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
     if (cnt == 0) continue;  // pass B never reads an empty plane
     const int k = sub * LANES + lane;  // position inside the 64-voxel group
     const int z = 64 * c + k;
-    const bool act = lane < LANES && z < a.nz;
+    const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;  // (pass B only reads these)
     ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricA> env;
     env.r = LdsRing<S, LANES>{&ring_site[wave][lane % LANES], &ring_start[wave][lane % LANES]};
     env.m = FtMetricA{z};
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
       for (int j = lane; j < nb * 32; j += 64) {
         const int r = j >> 5, w = j & 31;
         const int yr = __shfl(ylist, r);
-        rowstage[wave][r][w] = w < a.nzw ? a.occbits[((int64_t)x * a.ny + yr) * a.nzw + w] : 0u;
+        rowstage[wave][r][w] = w < a.nzw ? a.row(x, yr)[w] : 0u;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
           if (__ballot(fin) != ~0ull) break;
           const bool adv = __ballot(act && env.advances_at(p_out)) != 0ull;
           const uint32_t s = env.emit(p_out, act, adv);
-          if (act) *out = s;
+          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = s;
           out += a.nz;
           ++p_out;
         }
@@ -224,7 +234,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     const int sub = (int)(it % SUB);
     const int y = (int)(id / (uint32_t)a.nzc), c = (int)(id % (uint32_t)a.nzc);
     const int z = 64 * c + sub * LANES + lane;
-    const bool act = lane < LANES && z < a.nz;
+    const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;
+    if ((unsigned)(y - a.oy0) >= (unsigned)a.ony) continue;  // (the host only lists rows of the output box)
     ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricB> env;
     env.r = LdsRing<S, LANES>{&ring_site[wave][lane % LANES], &ring_start[wave][lane % LANES]};
     env.m = FtMetricB{y, z};
@@ -233,14 +244,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     bool failed = false;
     const int64_t plane = (int64_t)a.ny * a.nz, col = (int64_t)y * a.nz + (act ? z : 0);
     const uint32_t *in = a.inter + col;
-    vox_t *out = a.coc + col;
+    const int64_t oplane = (int64_t)a.ony * a.onz;
+    // -> output voxel of region position p_stored of this column (valid to dereference only inside the output box)
+    vox_t *optr = a.coc + ((int64_t)(0 - a.ox0) * a.ony + (y - a.oy0)) * a.onz + (act ? z - a.oz0 : 0);
     uint32_t *stg = &stage[wave][lane % LANES];
-    const uint32_t goff = ((uint32_t)a.gx0 << 20) | ((uint32_t)a.gy0 << 10) | (uint32_t)a.gz0;
-    vox_t *optr = out;  // -> position p_stored of this column
     auto flush = [&]() {
       for (int p = p_stored; p < p_out; ++p) {
-        if (act) *optr = stg[(p & (OB - 1)) * LANES];
-        optr += plane;
+        if (act && (unsigned)(p - a.ox0) < (unsigned)a.onx) *optr = stg[(p & (OB - 1)) * LANES];
+        optr += oplane;
       }
       p_stored = p_out;
     };
@@ -253,8 +264,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
         if (p_out - p_stored == OB) return true;
         const bool adv = __ballot(act && env.advances_at(p_out)) != 0ull;
         const uint32_t s = env.emit(p_out, act, adv);
-        if (act) stg[(p_out & (OB - 1)) * LANES] = s + goff;  // (no carries: every global coordinate is below 1024)
-        if (a.maxd2) acc_maxd2 = max(acc_maxd2, (uint32_t)(ft::mul24(p_out, p_out - 2 * env.c_q) + env.c_key));
+        // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc)
+        if (act) stg[(p_out & (OB - 1)) * LANES] = pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0);
+        if (a.maxd2 && act && (unsigned)(p_out - a.ox0) < (unsigned)a.onx)
+          acc_maxd2 = max(acc_maxd2, (uint32_t)(ft::mul24(p_out, p_out - 2 * env.c_q) + env.c_key));
         ++p_out;
       }
       return false;
@@ -310,9 +323,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     if (__ballot(act && !env.empty())) {
       while (drain(ft::kFarAhead)) flush();
       flush();
-    } else {  // no occupied voxel anywhere: "observed, no obstacle"
-      for (int p = 0; p < a.nx; ++p)
-        if (act) out[(int64_t)p * plane] = kInf;
+    } else {  // no occupied voxel anywhere in the region: "observed, no obstacle"
+      for (int p = 0; p < a.nx; ++p) {
+        if (act && (unsigned)(p - a.ox0) < (unsigned)a.onx) *optr = kInf;
+        optr += oplane;
+      }
+      if (a.maxd2 && act) acc_maxd2 = 1u << 30;
     }
   }
   if (a.maxd2) {

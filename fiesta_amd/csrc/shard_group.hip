@@ -29,6 +29,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace fiesta {
@@ -306,6 +307,72 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
   };
   const auto h0 = std::chrono::steady_clock::now();
   int64_t rounds = 0;
+  // ---- engine choice, identical on every rank.  On a fully observed map a large delta is served by the bulk feature
+  // transform (ft_kernels.hpp), shard by shard and WITHOUT any exchange: every shard transforms its own array grown by a
+  // margin, reading the replicated global occupancy bitmap; the result is exact once every voxel found its obstacle
+  // within the margin (checked from the largest distance written; otherwise the margin doubles).
+  {
+    std::vector<std::vector<long long>> rows(locals_.size(), std::vector<long long>(kRow, 0));
+    for (size_t i = 0; i < locals_.size(); ++i) {
+      unsigned long long ni = 0, nd = 0;
+      long long nocc = 0;
+      bool el = false;
+      locals_[i]->map->bulk_probe(&ni, &nd, &nocc, &el);
+      rows[i][0] = el ? 1 : 0, rows[i][1] = (long long)ni, rows[i][2] = (long long)nd, rows[i][3] = nocc;
+      rows[i][4] = locals_[i]->map->update_engine();
+    }
+    gather_rows(rows);
+    bool all = true, force = true;
+    long long ni = 0, nd = 0, nocc = 0;
+    for (int r = 0; r < world_; ++r) {
+      const long long *t = &h_table_[(size_t)r * kRow];
+      all = all && t[0] != 0;
+      force = force && t[4] == 2;
+      ni += t[1], nd += t[2], nocc += t[3];
+    }
+    const bool want = all && (ni + nd) > 0 && (force || (double)(ni + nd) >= locals_[0]->map->bulk_ratio() * std::max<double>(nocc, 1.0));
+    for (int m = margin_; want; m *= 2) {
+      std::vector<fiesta_hip_stats> ss(locals_.size());
+      for (size_t i = 0; i < locals_.size(); ++i) {
+        bool exact = false;
+        const bool ok = locals_[i]->map->bulk_try(&ss[i], m, &exact);
+        rows[i].assign(kRow, 0);
+        rows[i][0] = ok ? 1 : 0, rows[i][1] = exact ? 1 : 0, rows[i][2] = ok ? ss[i].ft_max_d2 : 0;
+      }
+      gather_rows(rows);
+      bool ok = true, exact = true;
+      long long dmax2 = 0;
+      for (int r = 0; r < world_; ++r) {
+        ok = ok && h_table_[(size_t)r * kRow] != 0;
+        exact = exact && h_table_[(size_t)r * kRow + 1] != 0;
+        dmax2 = std::max(dmax2, h_table_[(size_t)r * kRow + 2]);
+      }
+      if (!ok) break;  // a region outgrew the transform's 1024-voxel limit: the frontier rounds below take over
+      if (!exact) continue;
+      for (size_t i = 0; i < locals_.size(); ++i) {
+        locals_[i]->map->bulk_commit(&ss[i]);
+        total.inserted += ss[i].inserted, total.deleted += ss[i].deleted;
+        total.relax_ms = std::max(total.relax_ms, ss[i].relax_ms);
+        total.ft_rows_ms = std::max(total.ft_rows_ms, ss[i].ft_rows_ms);
+        total.ft_plane_ms = std::max(total.ft_plane_ms, ss[i].ft_plane_ms);
+        total.ft_x_ms = std::max(total.ft_x_ms, ss[i].ft_x_ms);
+        for (int k = 0; k < 6; ++k) total.ft_overflow[k] += ss[i].ft_overflow[k];
+        total.relax_launches += ss[i].relax_launches;
+      }
+      total.inserted = ni, total.deleted = nd;
+      total.bulk = 1;
+      total.ft_max_d2 = dmax2;
+      // next time start from what this scene needed (+ slack), in steps of 16 voxels
+      const int need = (int)std::ceil(std::sqrt((double)dmax2)) + 8;
+      margin_ = std::min(512, std::max(16, (need + 15) / 16 * 16));
+      total.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+      total.device_ms = total.host_ms;
+      if (st) *st = total;
+      if (sweeps_out) *sweeps_out = 0;
+      if (entries_out) *entries_out = 0;
+      return;
+    }
+  }
   for (auto &L : locals_) {
     fiesta_hip_stats s;
     L->map->update_esdf(&s, /*seed_only=*/true);

@@ -30,6 +30,7 @@ class ShardGroup {
   void gather_rows(const std::vector<std::vector<long long>> &rows);
   Local *find_local(int rank);
   int world_ = 1;
+  int margin_ = 32;  // bulk path: voxels added around a shard's array (adapts to the scene)
   int gg_[3] = {0, 0, 0};
   std::vector<std::unique_ptr<Local>> locals_;
   void *comm_ = nullptr;  // ncclComm_t

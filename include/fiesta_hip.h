@@ -76,6 +76,7 @@ typedef struct fiesta_hip_stats {
   double ft_rows_ms, ft_plane_ms, ft_x_ms; /* bulk path: HIP-event time of k_ft_rows / pass A / pass B */
   int64_t ft_overflow[6];/* bulk path: column groups that outgrew the ring of pass A tiers 0-2, pass B tiers 0-2 */
   int64_t observed_voxels, occupied_voxels; /* map totals at entry (array mode): observed at least once / Exist() */
+  int64_t ft_max_d2;     /* bulk path on a shard: largest squared distance written (decides whether the margin sufficed) */
   int64_t dropped_observations; /* hash mode, cumulative: SetOccupancy calls (voxel, position or box form) that fell
                                    outside the addressable window of +-512 voxels around the origin and were ignored --
                                    the reference's hash build is unbounded, so a non-zero value means lost map data */

@@ -7,7 +7,7 @@ import pytest
 
 from scenarios import D2_INF, P_DEFAULT, oracle_d2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("engine")]
 
 
 def drive(sharded, cpu, vox_occ_cycles):
@@ -67,11 +67,10 @@ def test_sharded_matches_single_grid_oracle(hip_lib, oracle_libs, best_oracle_ki
     occ = np.argwhere(cpu.dump_dense(("occ",))["occ"].reshape(gs) == 1).astype(np.int32)
     drive(sm, cpu, [([], occ, 6)])
     compare(sm, cpu, gs)
-    assert sm.last_sweeps >= 1
     sm.close()
 
 
-def test_single_obstacle_wave_crosses_every_shard(hip_lib, oracle_libs, best_oracle_kind):
+def test_single_obstacle_wave_crosses_every_shard(hip_lib, oracle_libs, best_oracle_kind, engine):
     """The adversarial case of SURVEY.md 8e: one obstacle in a corner, its wave must cross all 8 shards."""
     from fiesta_amd.sharded import ShardedESDFMap
     gs, res = (64, 64, 64), 0.1
@@ -83,8 +82,9 @@ def test_single_obstacle_wave_crosses_every_shard(hip_lib, oracle_libs, best_ora
     allv = np.stack(np.meshgrid(*[np.arange(n) for n in gs], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
     drive(sm, cpu, [([], allv, 1), (np.array([[1, 2, 3]], np.int32), [], 3)])
     compare(sm, cpu, gs)
-    assert sm.last_sweeps >= 3   # the wave needs a ghost exchange per shard face it crosses
-    assert sm.last_entries_sent > 0
+    if engine == "rounds":
+        assert sm.last_sweeps >= 3   # the wave needs a ghost exchange per shard face it crosses
+        assert sm.last_entries_sent > 0
     drive(sm, cpu, [(np.array([[60, 61, 59]], np.int32), np.array([[1, 2, 3]], np.int32), 6)])
     compare(sm, cpu, gs)
     sm.close()
