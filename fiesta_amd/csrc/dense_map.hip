@@ -729,6 +729,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_SPATIAL")) spatial_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_LIST_THRESHOLD")) list_threshold_ = std::max(0, atoi(e));
+  if (const char *e = getenv("FIESTA_HIP_SMALL_UPDATE")) small_update_ = std::max(0, atoi(e));
   if (const char *e = getenv("FIESTA_HIP_BOUND_SCAN")) bound_scan_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
   if (const char *e = getenv("FIESTA_HIP_BULK_RATIO")) bulk_ratio_ = atof(e);
@@ -960,7 +961,7 @@ hipEvent_t DenseMap::pool_event(size_t i) {
 void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list) {
   int cur = first_list;
   uint32_t ncur = first_count;
-  int64_t rounds = 0;
+  int64_t rounds = 0, device_rounds = -1, spatial_rounds = 0;  // launches; rounds that found work (counted on the device)
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   serial_ += 2;  // no stamp of an earlier update may validate this update's first round
   // one round of the work-queue engine: active tiles of list/flags `cur_list` -> `cur_list ^ 1`
@@ -1004,28 +1005,36 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds + 1), stream_));
     ++rounds;
   };
+  const bool unknown = first_count == kCountOnDevice;  // small update: nobody has read the length of the first list
   while (ncur) {
     const int nxt = cur ^ 1;
-    // Large updates walk all tiles in XCD-chunked spatial order, one round per host round trip. Small ones (few active
-    // tiles: depth frames) use the compact list, and rounds go out in pairs: the second reads the length of its list
-    // on the device and does nothing if the first activated no tile -- half the host round trips.
-    if (spatial_ && ncur >= (uint32_t)list_threshold_) {
+    // Large updates walk all tiles in XCD-chunked spatial order, one round per host round trip.  Small ones (few active
+    // tiles: depth frames) use the compact list and go out in chains of kChain rounds, each reading the length of its
+    // list on the device and doing nothing once a predecessor activated no tile: ONE host round trip per chain instead
+    // of one per round (a depth frame's update is a handful of ~10 us kernels; the round trips were most of its time).
+    if (!unknown && spatial_ && ncur >= (uint32_t)list_threshold_) {
       launch_q(cur, ncur, nullptr, 1);
+      ++spatial_rounds;
       ncur = (uint32_t)read_counter(C_LIST0 + nxt);
       cur = nxt;
     } else {
-      launch_q(cur, ncur, nullptr, 0);
-      launch_q(nxt, 0, &counters_[C_LIST0 + nxt], 0);
+      constexpr int kChain = 4;
+      if (unknown) ncur = 256;  // (sizes the grids of the chain: 1024 work-groups striding over the list)
+      const int64_t before = rounds;
+      for (int k = 0; k < kChain; ++k) launch_q((k & 1) ? nxt : cur, 0, &counters_[C_LIST0 + ((k & 1) ? nxt : cur)], 0);
       FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_LIST0], &counters_[C_LIST0], 2 * sizeof(unsigned long long),
                                       hipMemcpyDeviceToHost, stream_));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_ROUNDS], &counters_[C_ROUNDS], sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, stream_));
       FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-      const uint32_t n1 = (uint32_t)h_counters_[C_LIST0 + nxt], n2 = (uint32_t)h_counters_[C_LIST0 + cur];
-      if (!n1) --rounds;  // the speculative round had nothing to do: not a round (its events are overwritten or ignored)
-      ncur = n1 ? n2 : 0;
+      // kChain is even: the chain ends with list `cur` as the next input
+      ncur = (uint32_t)h_counters_[C_LIST0 + cur];
+      device_rounds = (int64_t)h_counters_[C_ROUNDS];
+      (void)before;
     }
   }
   if (st) {
-    st->rounds = rounds;
+    st->rounds = device_rounds >= 0 ? device_rounds + spatial_rounds : rounds;
     double sum = 0;
     for (int64_t r = 0; r < rounds; ++r) {
       float ms = 0;
@@ -1301,7 +1310,8 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     return;
   }
-  const uint32_t n0 = (uint32_t)read_counter(C_LIST0);
+  // a small delta (a depth frame): do not even read how many tiles were seeded, the chain of rounds finds out on the device
+  const uint32_t n0 = (ni + nd <= (unsigned long long)small_update_ && !remote_del) ? kCountOnDevice : (uint32_t)read_counter(C_LIST0);
   run_rounds(st, n0, 0);
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
   collect_stats(st);

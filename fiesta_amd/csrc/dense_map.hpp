@@ -53,6 +53,7 @@ enum Counter {
   C_SWEEPS,
   C_WRITES,
   C_VISITS,
+  C_ROUNDS,      // rounds of the compact-list mode that found a non-empty list (counted by the kernel)
   C_SCRATCH,
   C_REMOTE_DEL,  // sharded maps: some shard reported an occupied->free transition since the last UpdateESDF
   C_FT_OVF0,     // bulk path: lengths of the ring-overflow lists (pass A tiers 0-2, pass B tiers 0-2)
@@ -209,6 +210,8 @@ class DenseMap {
   int spatial_blocks_ = 1024;  // work-groups of the spatial walk (multiple of 8: one stream of tiles per XCD)
   bool track_ = false;  // C_MAXD2 is maintained (enable_distance_tracking)
   int bound_scan_ = 1;  // bound the delete scan by the delete queue's box + the largest stored distance (FIESTA_HIP_BOUND_SCAN=0: whole grid)
+  static constexpr uint32_t kCountOnDevice = 0xFFFFFFFFu;  // run_rounds: the first list's length was never read
+  int small_update_ = 4096;  // updates with at most this many inserts + deletes skip that read (FIESTA_HIP_SMALL_UPDATE)
   int list_threshold_ = 1024;  // updates that start with fewer active tiles use the compact list + paired rounds
   int spatial_ = 1;  // walk the tiles in XCD-chunked spatial order (FIESTA_HIP_SPATIAL=0: compact list order)
   uint32_t serial_ = 0;                         // relaxation rounds launched so far (all updates)

@@ -677,21 +677,23 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
     hipLaunchKernelGGL((k_relax_q<kTX, kTY, 1024, true>), dim3(blocks), dim3(1024), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
   };
-  // Rounds go out in pairs: the second is launched before the host knows how many tiles the first activated (it reads
-  // the count on the device and does nothing if it is zero) -- half the host round trips of an update that is a chain
-  // of small rounds.
+  // Rounds go out in chains of kChain: every round reads the length of its list on the device and does nothing once a
+  // predecessor activated no tile -- one host round trip per chain (a streaming frame's update is a handful of ~10 us
+  // kernels; the round trips were most of its time).  first_count == 0xFFFFFFFF: nobody read the first list's length.
+  if (ncur == 0xFFFFFFFFu) ncur = 256;
   while (ncur) {
+    constexpr int kChain = 4;
     const int nxt = cur ^ 1;
     FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
-    launch(cur, ncur, nullptr);
-    launch(nxt, 0, &counters_[C_LIST0 + nxt]);
+    for (int k = 0; k < kChain; ++k) launch((k & 1) ? nxt : cur, 0, &counters_[C_LIST0 + ((k & 1) ? nxt : cur)]);
     FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
     FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_LIST0], &counters_[C_LIST0], 2 * sizeof(unsigned long long),
                                     hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_ROUNDS], &counters_[C_ROUNDS], sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-    const uint32_t n1 = (uint32_t)h_counters_[C_LIST0 + nxt], n2 = (uint32_t)h_counters_[C_LIST0 + cur];
-    rounds += n1 ? 2 : 1;
-    ncur = n1 ? n2 : 0;  // (after two rounds the lists are back in place)
+    ncur = (uint32_t)h_counters_[C_LIST0 + cur];  // (kChain is even: the lists are back in place)
+    rounds = (int64_t)h_counters_[C_ROUNDS];
     float ms = 0;
     FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
     relax_ms += ms;
@@ -706,14 +708,15 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
 void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const auto h0 = std::chrono::steady_clock::now();
-  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+  // C_INSERT, C_DELETE, (C_OBSERVED, C_NOCC,) C_DROPPED are adjacent: one copy, one synchronisation
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   const unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
   if (st) {
     memset(st, 0, sizeof(*st));
     st->inserted = (int64_t)ni;
     st->deleted = (int64_t)nd;
-    st->dropped_observations = (int64_t)read_counter(C_DROPPED) + dropped_host_;
+    st->dropped_observations = (int64_t)h_counters_[C_DROPPED] + dropped_host_;
   }
   if (ni || nd) {
     ++epoch_;
@@ -735,7 +738,7 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
     zero_counter(C_INSERT);
     zero_counter(C_DELETE);
     const auto d0 = std::chrono::steady_clock::now();
-    run_rounds(st, (uint32_t)read_counter(C_LIST0));
+    run_rounds(st, 0xFFFFFFFFu);  // (the chain of rounds finds the seeded tiles' count on the device)
     FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
     if (st) {

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
   // at about the same time instead of each missing to HBM.
   const uint32_t ntiles = (uint32_t)(a.tg.ntx * a.tg.nty * a.tg.ntz);
   const uint32_t n_list = a.n_cur_dev ? (uint32_t)*a.n_cur_dev : a.n_cur;
+  if (a.n_cur_dev && n_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.counters[C_ROUNDS], 1ull);
   // statistics are summed per work-group and flushed once after the walk (tens of thousands of visits would
   // otherwise queue their atomics on three hot addresses)
   uint32_t acc_writes = 0, acc_levels = 0, acc_visits = 0, acc_maxd2 = 0;
