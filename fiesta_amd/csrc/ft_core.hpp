@@ -2,12 +2,13 @@
 // lower envelope of parabolas of one grid column, and the nearest set bit of a bitmap row.
 //
 // Why this exists.  On a fully observed map the fixed point of the reference's 24-neighbour propagation
-// (src/ESDFMap.cpp:339-392) is the exact Euclidean feature transform of the occupied set: every probe of the survey
-// and the full-size pins of tests/golden/c2_512_*_digest.npz (`edt_mismatch` = 0 on 134 M voxels) say so.  When an
-// update touches a large part of such a map, recomputing the whole transform with three separable passes costs a few
-// coalesced sweeps over the grid -- far less than pushing a wave front through every tile.  The frontier rounds
-// (relax_kernels.hpp) remain the engine for partially observed maps, windows, shards and small deltas; DenseMap
-// chooses per update (dense_map.hip: update_esdf).
+// (src/ESDFMap.cpp:339-392) is the exact Euclidean feature transform of the occupied set -- up to a handful of voxels
+// per 10^5 where the reference itself keeps a slightly larger distance that depends on the order of the inserts
+// (pinned on 2 x 134 M voxels by tests/golden/c2_512_*_digest.npz).  When an update touches a large
+// part of such a map, recomputing the whole transform with three separable passes costs a few coalesced sweeps over
+// the grid -- far less than pushing a wave front through every tile.  The frontier rounds (relax_kernels.hpp) remain
+// the engine for partially observed maps, windows and small deltas; DenseMap chooses per update (dense_map.hip:
+// update_esdf).
 //
 // The one-dimensional problem.  Sites arrive in increasing position q with a height f(q) >= 0 (the squared distance
 // already accumulated along the other axes); wanted is, for every integer position p of the column, a site minimising

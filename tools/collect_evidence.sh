@@ -10,21 +10,30 @@ export TMPDIR=/tmp
 # C2 headline under the kernel trace (the JSON line carries roofline + cpu_baseline)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -o bench -- python bench.py > "$R/bench_default.log" 2>&1
 grep metric "$R/bench_default.log" > "$R/bench_default.json"
-# HBM traffic of the dominant kernel: two PMC passes, calibrated inside the same runs (tools/pmc_traffic.py)
+# HBM traffic of UpdateESDF's kernels: two PMC passes, calibrated inside the same runs (tools/pmc_traffic.py)
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/pmc_$C" -o bench -- \
     python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$R/pmc_$C.log" 2>&1
 done
-python tools/pmc_traffic.py "$R/pmc_FETCH_SIZE" "$R/pmc_WRITE_SIZE" k_relax_q > "$R/pmc_traffic_k_relax_q.json"
-# the other configurations
+python tools/pmc_traffic.py "$R/pmc_FETCH_SIZE" "$R/pmc_WRITE_SIZE" k_ft_ > "$R/pmc_traffic_ft.json"
+# issue / wait / LDS counters of the same command
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+  --output-format csv -d "$R/pmc_SQ" -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$R/pmc_SQ.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+  --output-format csv -d "$R/pmc_LDS" -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$R/pmc_LDS.log" 2>&1
+# the other scene, the other engine, the other configurations
+python bench.py --scene surfaces --no-cpu-baseline 2>&1 | grep metric > "$R/bench_c2_surfaces.json"
+python bench.py --engine rounds --no-cpu-baseline 2>&1 | grep metric > "$R/bench_c2_rounds.json"
+python bench.py --engine rounds --scene surfaces --no-cpu-baseline 2>&1 | grep metric > "$R/bench_c2_surfaces_rounds.json"
 python bench.py --workload c3 --steps 20 --warmup 4 2>&1 | grep metric > "$R/bench_c3.json"
 python bench.py --workload c4 --steps 40 --warmup 5 2>&1 | grep metric > "$R/bench_c4.json"
+python bench.py --gpus 1 --force-sharded --no-cpu-baseline 2>&1 | grep metric > "$R/bench_sharded_1rank.json"
 # copy what is to be judged into profiles/ (gpurun_out/ is scratch)
 cp "$R/stats/bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats_default.csv"
-cp "$R/bench_default.json" "profiles/${TAG}_bench_default.json"
-cp "$R/bench_c3.json" "profiles/${TAG}_bench_c3.json"
-cp "$R/bench_c4.json" "profiles/${TAG}_bench_c4.json"
-cp "$R/pmc_FETCH_SIZE/bench_counter_collection.csv" "profiles/${TAG}_pmc_FETCH_SIZE_counter_collection.csv"
-cp "$R/pmc_WRITE_SIZE/bench_counter_collection.csv" "profiles/${TAG}_pmc_WRITE_SIZE_counter_collection.csv"
-cp "$R/pmc_traffic_k_relax_q.json" "profiles/${TAG}_pmc_traffic_k_relax_q.json"
+for f in bench_default bench_c2_surfaces bench_c2_rounds bench_c2_surfaces_rounds bench_c3 bench_c4 bench_sharded_1rank pmc_traffic_ft; do
+  cp "$R/$f.json" "profiles/${TAG}_$f.json"
+done
+for C in FETCH_SIZE WRITE_SIZE SQ LDS; do
+  cp "$R/pmc_$C/bench_counter_collection.csv" "profiles/${TAG}_pmc_${C}_counter_collection.csv"
+done
 echo "evidence for $TAG written; describe it in profiles/README.md"

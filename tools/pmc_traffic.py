@@ -42,14 +42,24 @@ def main():
     _, cnt = find(F, "k_count_updated")
     wfac = words / (sum(fill) / len(fill))
     ffac = (2 * words + grid ** 3 // 8) / (sum(cnt) / len(cnt))
-    kname, fr = find(F, kern)
-    _, wr = find(W, kern)
+    # every kernel whose name contains `kern` (the bulk path is several kernels per UpdateESDF: k_ft_rows, k_ft_plane<..>,
+    # k_ft_x<..> and their empty overflow tiers); bytes are summed per UpdateESDF = per launch of k_ft_rows
+    names = sorted(k for k in F if kern in k)
+    if not names:
+        raise KeyError(kern)
+    n_updates = max(1, len(F[[k for k in names if "k_ft_rows" in k][0]]) if any("k_ft_rows" in k for k in names) else len(F[names[0]]))
+    fr_sum = sum(sum(F[k]) for k in names)
+    wr_sum = sum(sum(W[k]) for k in names if k in W)
+    kname = " + ".join(names)
     out = {
-        "kernel": kname, "launches": len(fr),
-        "fetch_reported_bytes_per_launch": sum(fr) / len(fr), "write_reported_bytes_per_launch": sum(wr) / len(wr),
+        "kernel": kname, "launches": n_updates,
+        "fetch_reported_bytes_per_launch": fr_sum / n_updates, "write_reported_bytes_per_launch": wr_sum / n_updates,
         "fetch_calibration_factor": ffac, "write_calibration_factor": wfac,
         "calibration": {"write": "k_fill<uint> writes grid^3 x 4 B", "fetch": "k_count_updated reads 2 x grid^3 x 4 B + grid^3/8 B"},
-        "fetch_bytes_per_launch": ffac * sum(fr) / len(fr), "write_bytes_per_launch": wfac * sum(wr) / len(wr),
+        "fetch_bytes_per_launch": ffac * fr_sum / n_updates, "write_bytes_per_launch": wfac * wr_sum / n_updates,
+        "per_kernel": {k: {"launches": len(F[k]), "fetch_bytes": ffac * sum(F[k]) / len(F[k]),
+                           "write_bytes": wfac * sum(W[k]) / len(W[k]) if k in W else None} for k in names},
+        "unit": "bytes per UpdateESDF (all its kernels)",
     }
     out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
     out["command"] = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (two rocprofv3 --pmc passes)"
