@@ -47,6 +47,11 @@ class ShardInfo(C.Structure):
                 ("owned_hi", C.c_int32 * 3), ("global_grid", C.c_int32 * 3)]
 
 
+class DepthFilter(C.Structure):
+    _fields_ = [("tolerance", C.c_double), ("max_dist", C.c_double), ("min_dist", C.c_double), ("margin", C.c_int32),
+                ("reset", C.c_int32), ("rel_transform", C.c_double * 16)]
+
+
 class RaycastParams(C.Structure):
     _fields_ = [("min_ray_length", C.c_double), ("max_ray_length", C.c_double), ("l_cornor", C.c_double * 3),
                 ("r_cornor", C.c_double * 3), ("dedup", C.c_int32), ("reserved", C.c_int32)]
@@ -119,6 +124,8 @@ def load():
         "fiesta_hip_raycast_frame": (C.c_int, [vp, vp, i64, vp, vp, vp]),
         "fiesta_hip_raycast_frame_dev": (C.c_int, [vp, vp, i64, vp, vp, vp]),
         "fiesta_hip_raycast_depth": (C.c_int, [vp, vp, i32, i32, dbl, dbl, dbl, dbl, vp, vp, vp]),
+        "fiesta_hip_raycast_depth_filtered": (C.c_int, [vp, vp, i32, i32, dbl, dbl, dbl, dbl, vp, vp, vp, vp]),
+        "fiesta_hip_depth_conversion": (C.c_int, [vp, vp, i32, i32, dbl, dbl, dbl, dbl, vp, vp, vp]),
         "fiesta_hip_raycast_single": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i32]),
         "fiesta_hip_check_update": (C.c_int, [vp, vp]),
         "fiesta_hip_update_occupancy": (C.c_int, [vp, i32, vp, vp, vp]),

@@ -233,6 +233,25 @@ int fiesta_hip_raycast_depth(fiesta_hip_map *m, const uint16_t *depth, int32_t r
       m->hash->raycast_depth(depth, rows, cols, fx, fy, cx, cy, T, origin, p);
   });
 }
+int fiesta_hip_raycast_depth_filtered(fiesta_hip_map *m, const uint16_t *depth, int32_t rows, int32_t cols, double fx, double fy,
+                                      double cx, double cy, const double T[16], const double origin[3],
+                                      const fiesta_hip_raycast_params *p, const fiesta_hip_depth_filter *f) {
+  return guarded([&] {
+    need(m && depth && rows > 0 && cols > 0 && T && origin && p && f, "bad argument");
+    if (m->dense)
+      m->dense->raycast_depth(depth, rows, cols, fx, fy, cx, cy, T, origin, p, f);
+    else
+      m->hash->raycast_depth(depth, rows, cols, fx, fy, cx, cy, T, origin, p, f);
+  });
+}
+int fiesta_hip_depth_conversion(fiesta_hip_map *m, const uint16_t *depth, int32_t rows, int32_t cols, double fx, double fy,
+                                double cx, double cy, const fiesta_hip_depth_filter *f, float *points_out, int64_t *n_valid) {
+  return guarded([&] {
+    need(depth && rows > 0 && cols > 0 && points_out, "bad argument");
+    const int64_t n = dense(m, "depth_conversion").depth_conversion(depth, rows, cols, fx, fy, cx, cy, f, points_out);
+    if (n_valid) *n_valid = n;
+  });
+}
 int fiesta_hip_raycast_single(const double start[3], const double end[3], const double minv[3],
                               const double maxv[3], double *out, int32_t cap, int32_t *n_out, int32_t device) {
   return guarded([&] {

@@ -150,8 +150,12 @@ class DenseMap {
   void raycast_frame(const float *points, int64_t n, const double *T, const double *origin,
                      const fiesta_hip_raycast_params *p, bool dev);
   void raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
-                     const double *T, const double *origin, const fiesta_hip_raycast_params *p);
+                     const double *T, const double *origin, const fiesta_hip_raycast_params *p,
+                     const fiesta_hip_depth_filter *f = nullptr);
 
+  // Fiesta::DepthConversion alone (tests, inspection): the frame's points to the host, rejected pixels as NaN
+  int64_t depth_conversion(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
+                           const fiesta_hip_depth_filter *f, float *points_out);
   hipStream_t stream() const { return stream_; }
   int device() const { return device_; }
 

@@ -48,7 +48,8 @@ class HashMap {
   void raycast_frame(const float *points, int64_t n, const double *T, const double *origin, const fiesta_hip_raycast_params *p,
                      bool dev);
   void raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy, const double *T,
-                     const double *origin, const fiesta_hip_raycast_params *p);
+                     const double *origin, const fiesta_hip_raycast_params *p,
+                     const fiesta_hip_depth_filter *f = nullptr);
   bool check_update();
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
   void update_esdf(fiesta_hip_stats *st);

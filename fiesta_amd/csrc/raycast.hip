@@ -304,6 +304,43 @@ __global__ void k_depth_points(const uint16_t *depth, int rows, int cols, double
   pts[3 * i + 2] = (float)d;
 }
 
+// ... with the temporal consistency filter of DepthConversion (include/Fiesta.h:352-379): a pixel survives iff it lies
+// inside the margin, its depth within [min, max], and its re-projection into the PREVIOUS depth image (rel =
+// last_transform_^-1 * transform_) lands inside that image and agrees with the depth stored there within the tolerance.
+// The reference builds a shorter cloud; here a rejected pixel becomes a NaN point, which RaycastProcess skips
+// (include/Fiesta.h:202) -- the surviving points keep their cloud order, which is what the per-frame de-duplication
+// depends on.  f64 in the reference's operation order.
+struct DepthFilterArgs {
+  double tol, dmax, dmin;
+  int margin;
+  double rel[16];
+};
+__global__ void k_depth_points_filtered(const uint16_t *depth, const uint16_t *last, int rows, int cols, double fx, double fy,
+                                        double cx, double cy, DepthFilterArgs f, float *pts, unsigned long long *n_valid) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool keep = false;
+  if (i < (int64_t)rows * cols) {
+    const int v = i / cols, u = i % cols;
+    const double d = depth[i] / 1000.0;
+    const float px = (float)((u - cx) * d / fx), py = (float)((v - cy) * d / fy), pz = (float)d;
+    if (last && v >= f.margin && v < rows - f.margin && u >= f.margin && u < cols - f.margin && !(d > f.dmax || d < f.dmin)) {
+      double h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = f.rel[4 * r] * px + f.rel[4 * r + 1] * py + f.rel[4 * r + 2] * pz + f.rel[4 * r + 3] * 1.0;
+      const double qx = h[0] / h[3], qy = h[1] / h[3], qz = h[2] / h[3];
+      const double uu = qx * fx / qz + cx, vv = qy * fy / qz + cy;
+      if (uu >= 0 && uu < cols && vv >= 0 && vv < rows)
+        keep = fabs(last[(int64_t)(int)vv * cols + (int)uu] / 1000.0 - qz) < f.tol;
+    }
+    const float nanf_ = __int_as_float(0x7FC00000);
+    pts[3 * i] = keep ? px : nanf_;
+    pts[3 * i + 1] = keep ? py : nanf_;
+    pts[3 * i + 2] = keep ? pz : nanf_;
+  }
+  const unsigned long long m = __ballot(keep);
+  if (m && (threadIdx.x & 63) == 0 && n_valid) atomicAdd(n_valid, (unsigned long long)__popcll(m));
+}
+
 __global__ void k_raycast_one(const double *io, double *out, int cap, int *n_out) {
   int cnt = dda_walk(io, io + 3, io + 6, io + 9, [&](int x, int y, int z, int k) {
     if (k < cap) {
@@ -322,7 +359,9 @@ struct RayState {
   DevBuf<int32_t> end_idx, m_count, last_k;
   DevBuf<uint8_t> flags;
   DevBuf<float> points;
-  DevBuf<uint16_t> depth;
+  DevBuf<uint16_t> depth, last_depth;  // the image being converted; the previous one (temporal depth filter)
+  int last_rows = 0, last_cols = 0;    // 0: no previous image (start of a run: image_cnt_ == 1)
+  unsigned long long *d_valid = nullptr;
   uint32_t *stamp_occ = nullptr, *fa = nullptr, *fb = nullptr;
   size_t stamp_words = 0;
   int ibits = 0;
@@ -334,6 +373,7 @@ struct RayState {
   RayState() {
     FIESTA_HIP_CHECK(hipMalloc((void **)&d_flags, kFlagInts * sizeof(int)));
     FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_flags, kFlagInts * sizeof(int)));
+    FIESTA_HIP_CHECK(hipMalloc((void **)&d_valid, sizeof(unsigned long long)));
   }
   ~RayState() {
     if (stamp_occ) (void)hipFree(stamp_occ);
@@ -341,6 +381,7 @@ struct RayState {
     if (fb) (void)hipFree(fb);
     if (d_flags) (void)hipFree(d_flags);
     if (h_flags) (void)hipHostFree(h_flags);
+    if (d_valid) (void)hipFree(d_valid);
   }
 };
 struct DenseMap::RaycastState : RayState {};
@@ -481,14 +522,38 @@ static const float *ray_points(RayState &rc, const float *points, int64_t n, boo
 }
 
 static const float *ray_depth_points(RayState &rc, const uint16_t *depth, int rows, int cols, double fx, double fy, double cx,
-                                     double cy, hipStream_t stream) {
+                                     double cy, hipStream_t stream, const fiesta_hip_depth_filter *f = nullptr,
+                                     int64_t *n_valid = nullptr) {
   const int64_t n = (int64_t)rows * cols;
   rc.depth.ensure(n, stream);
   rc.points.ensure(3 * n, stream);
   FIESTA_HIP_CHECK(hipMemcpyAsync(rc.depth.p, depth, n * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
-  hipLaunchKernelGGL(k_depth_points, dim3(rgrid(n)), dim3(256), 0, stream, (const uint16_t *)rc.depth.p, rows, cols, fx, fy, cx,
-                     cy, rc.points.p);
+  if (!f) {
+    hipLaunchKernelGGL(k_depth_points, dim3(rgrid(n)), dim3(256), 0, stream, (const uint16_t *)rc.depth.p, rows, cols, fx, fy, cx,
+                       cy, rc.points.p);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    if (n_valid) *n_valid = n;
+    return rc.points.p;
+  }
+  // DepthConversion with use_depth_filter_ (include/Fiesta.h:352-379): the previous image stays on the device
+  if (f->reset || rc.last_rows != rows || rc.last_cols != cols) rc.last_rows = rc.last_cols = 0;
+  DepthFilterArgs a;
+  a.tol = f->tolerance, a.dmax = f->max_dist, a.dmin = f->min_dist, a.margin = f->margin;
+  memcpy(a.rel, f->rel_transform, sizeof(a.rel));
+  FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_valid, 0, sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(k_depth_points_filtered, dim3(rgrid(n)), dim3(256), 0, stream, (const uint16_t *)rc.depth.p,
+                     rc.last_rows ? (const uint16_t *)rc.last_depth.p : (const uint16_t *)nullptr, rows, cols, fx, fy, cx, cy, a,
+                     rc.points.p, rc.d_valid);
   FIESTA_HIP_CHECK(hipGetLastError());
+  if (n_valid) {
+    unsigned long long h = 0;
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h, rc.d_valid, sizeof(h), hipMemcpyDeviceToHost, stream));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
+    *n_valid = (int64_t)h;
+  }
+  std::swap(rc.depth.p, rc.last_depth.p);  // current_img becomes last_img (:322-323)
+  std::swap(rc.depth.cap, rc.last_depth.cap);
+  rc.last_rows = rows, rc.last_cols = cols;
   return rc.points.p;
 }
 
@@ -516,11 +581,22 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
 }
 
 void DenseMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
-                             const double *T, const double *origin, const fiesta_hip_raycast_params *p) {
+                             const double *T, const double *origin, const fiesta_hip_raycast_params *p,
+                             const fiesta_hip_depth_filter *f) {
   use_device();
   if (!rc_) rc_ = new RaycastState;
-  const float *pts = ray_depth_points(*rc_, depth, rows, cols, fx, fy, cx, cy, stream_);
+  const float *pts = ray_depth_points(*rc_, depth, rows, cols, fx, fy, cx, cy, stream_, f);
   raycast_frame(pts, (int64_t)rows * cols, T, origin, p, true);
+}
+int64_t DenseMap::depth_conversion(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
+                                   const fiesta_hip_depth_filter *f, float *points_out) {
+  use_device();
+  if (!rc_) rc_ = new RaycastState;
+  int64_t n_valid = 0;
+  const float *pts = ray_depth_points(*rc_, depth, rows, cols, fx, fy, cx, cy, stream_, f, &n_valid);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(points_out, pts, (size_t)rows * cols * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  return n_valid;
 }
 
 // Paged map: the same frame in three steps -- walk the rays in window coordinates and mark the tiles they touch,
@@ -555,10 +631,11 @@ void HashMap::raycast_frame(const float *points, int64_t n, const double *T, con
 }
 
 void HashMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
-                            const double *T, const double *origin, const fiesta_hip_raycast_params *p) {
+                            const double *T, const double *origin, const fiesta_hip_raycast_params *p,
+                            const fiesta_hip_depth_filter *f) {
   use_device();
   if (!rc_) rc_ = new RaycastState;
-  const float *pts = ray_depth_points(*rc_, depth, rows, cols, fx, fy, cx, cy, stream_);
+  const float *pts = ray_depth_points(*rc_, depth, rows, cols, fx, fy, cx, cy, stream_, f);
   raycast_frame(pts, (int64_t)rows * cols, T, origin, p, true);
 }
 

@@ -156,6 +156,37 @@ class ESDFMap:
         check(self._lib.fiesta_hip_raycast_depth(self._h, _p(d), d.shape[0], d.shape[1], fx, fy, cx, cy, _p(T),
                                                  _p(_d3(origin)), C.byref(prm)))
 
+    @staticmethod
+    def _depth_filter(rel_transform, tolerance, max_dist, min_dist, margin, reset):
+        from ._lib import DepthFilter
+        f = DepthFilter(tolerance, max_dist, min_dist, int(margin), int(bool(reset)))
+        f.rel_transform[:] = list(np.asarray(rel_transform, np.float64).reshape(16))
+        return f
+
+    def RaycastDepthFiltered(self, depth_mm, fx, fy, cx, cy, transform, origin, min_ray_length, max_ray_length, l_cornor,
+                             r_cornor, rel_transform, tolerance=0.1, max_dist=10.0, min_dist=0.1, margin=0, reset=False,
+                             dedup=1):
+        """RaycastDepth with DepthConversion's temporal consistency filter (include/Fiesta.h:352-379); rel_transform =
+        inv(last_transform) @ transform. The previous image lives on the device; the first image of a run casts nothing."""
+        d = np.ascontiguousarray(depth_mm, dtype=np.uint16)
+        T = np.ascontiguousarray(transform, dtype=np.float64).reshape(16)
+        prm = RaycastParams(min_ray_length, max_ray_length, (C.c_double * 3)(*l_cornor),
+                            (C.c_double * 3)(*r_cornor), int(dedup), 0)
+        f = self._depth_filter(rel_transform, tolerance, max_dist, min_dist, margin, reset)
+        check(self._lib.fiesta_hip_raycast_depth_filtered(self._h, _p(d), d.shape[0], d.shape[1], fx, fy, cx, cy, _p(T),
+                                                          _p(_d3(origin)), C.byref(prm), C.byref(f)))
+
+    def DepthConversion(self, depth_mm, fx, fy, cx, cy, rel_transform=None, tolerance=0.1, max_dist=10.0, min_dist=0.1,
+                        margin=0, reset=False):
+        """Fiesta::DepthConversion: (rows*cols x 3 float32 points with NaN where the filter rejected, surviving count)."""
+        d = np.ascontiguousarray(depth_mm, dtype=np.uint16)
+        out = np.empty((d.shape[0] * d.shape[1], 3), np.float32)
+        n = C.c_int64(0)
+        f = None if rel_transform is None else self._depth_filter(rel_transform, tolerance, max_dist, min_dist, margin, reset)
+        check(self._lib.fiesta_hip_depth_conversion(self._h, _p(d), d.shape[0], d.shape[1], fx, fy, cx, cy,
+                                                    C.byref(f) if f is not None else None, _p(out), C.byref(n)))
+        return out, n.value
+
     # -- queries ------------------------------------------------------------------------------------------
     def _query(self, where, fn_vox, fn_pos, out_dtype):
         a = np.asarray(where)

@@ -146,6 +146,28 @@ int fiesta_hip_raycast_frame_dev(fiesta_hip_map *m, const float *points_dev, int
 int fiesta_hip_raycast_depth(fiesta_hip_map *m, const uint16_t *depth, int32_t rows, int32_t cols,
                              double fx, double fy, double cx, double cy, const double transform[16],
                              const double origin[3], const fiesta_hip_raycast_params *p);
+/* The same front end with the temporal depth-consistency filter of Fiesta::DepthConversion (use_depth_filter_,
+ * include/Fiesta.h:352-379): a pixel casts a ray only if it lies inside the margin, its depth within [min_dist, max_dist],
+ * and its re-projection into the PREVIOUS depth image agrees with the depth stored there within `tolerance`. The map
+ * keeps the previous image on the device; the first image of a run (none stored yet, or reset != 0) casts nothing, as
+ * upstream (image_cnt_ == 1). rel_transform = last_transform_^-1 * transform_, row-major 4x4, supplied by the caller
+ * (the node has both poses). Defaults upstream: tolerance 0.1, max 10, min 0.1, margin 0 (src/parameters.cpp:38-42). */
+typedef struct fiesta_hip_depth_filter {
+  double tolerance, max_dist, min_dist;
+  int32_t margin;
+  int32_t reset;
+  double rel_transform[16];
+} fiesta_hip_depth_filter;
+int fiesta_hip_raycast_depth_filtered(fiesta_hip_map *m, const uint16_t *depth, int32_t rows, int32_t cols, double fx,
+                                      double fy, double cx, double cy, const double transform[16], const double origin[3],
+                                      const fiesta_hip_raycast_params *p, const fiesta_hip_depth_filter *filter);
+/* Fiesta::DepthConversion alone (array mode): the frame's point cloud to a host buffer of rows x cols x 3 floats in
+ * pixel order; a pixel the filter rejects (filter nullable: none) reads NaN, NaN -- such points are skipped by the ray
+ * cast like upstream's NaN points (include/Fiesta.h:202). *n_valid = points that survived. Advances the stored previous
+ * image like the call above. */
+int fiesta_hip_depth_conversion(fiesta_hip_map *m, const uint16_t *depth, int32_t rows, int32_t cols, double fx, double fy,
+                                double cx, double cy, const fiesta_hip_depth_filter *filter, float *points_out,
+                                int64_t *n_valid);
 /* The free function Raycast itself, for one ray (voxel units); returns the voxel count in *n_out
  * (FIESTA_HIP_ERR_INVALID if the reference would throw: more than 1500 voxels). out is cap x 3 doubles. */
 int fiesta_hip_raycast_single(const double start[3], const double end[3], const double minv[3],

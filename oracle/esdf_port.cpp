@@ -647,4 +647,6 @@ void oracle_raycast_frame(oracle_map *m, const float *pts, int64_t n, const doub
   }
 }
 
+#include "depth_filter.inc"
+
 }  // extern "C"

@@ -88,6 +88,11 @@ typedef struct oracle_raycast_params {
 void oracle_raycast_frame(oracle_map *m, const float *points, int64_t n, const double transform[16],
                           const double origin[3], const oracle_raycast_params *p);
 
+/* Fiesta::DepthConversion (include/Fiesta.h:319-382), restated: see depth_filter.inc. */
+int64_t oracle_depth_conversion(const uint16_t *cur, const uint16_t *last, int rows, int cols, double fx, double fy,
+                                double cx, double cy, int use_filter, const double rel[16], double tolerance,
+                                double max_dist, double min_dist, int margin, float *out);
+
 #ifdef __cplusplus
 }
 #endif

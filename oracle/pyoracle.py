@@ -91,6 +91,7 @@ def _load(kind: str, mode: str):
         "oracle_check_consistency": (i32, [vp]),
         "oracle_raycast": (i32, [vp, vp, vp, vp, vp, i32]),
         "oracle_raycast_frame": (None, [vp, vp, i64, vp, vp, vp]),
+        "oracle_depth_conversion": (i64, [vp, vp, i32, i32, dbl, dbl, dbl, dbl, i32, vp, dbl, dbl, dbl, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -254,4 +255,19 @@ def raycast(start, end, minv, maxv, kind="port", cap=4096):
     n = lib.oracle_raycast(_p(_d3(start)), _p(_d3(end)), _p(_d3(minv)), _p(_d3(maxv)), _p(out), cap)
     if n < 0:
         raise IndexError("Too many RaycasMultithread voxels")
+    return out[:n].copy()
+
+
+def depth_conversion(cur, last, fx, fy, cx, cy, rel=None, tolerance=0.1, max_dist=10.0, min_dist=0.1, margin=0, kind="port"):
+    """Fiesta::DepthConversion restated (oracle/depth_filter.inc): the frame's cloud (n x 3 float32) in pixel order.
+    rel None: no filter; else rel = inv(last_transform) @ transform and `last` the previous image (None: first image)."""
+    lib = _load(kind, "array")
+    cur = np.ascontiguousarray(cur, dtype=np.uint16)
+    rows, cols = cur.shape
+    out = np.empty((rows * cols, 3), np.float32)
+    use = rel is not None
+    relm = np.ascontiguousarray(rel if use else np.eye(4), dtype=np.float64).reshape(16)
+    lastp = None if last is None else np.ascontiguousarray(last, dtype=np.uint16)
+    n = lib.oracle_depth_conversion(_p(cur), _p(lastp), rows, cols, fx, fy, cx, cy, int(use), _p(relm), tolerance, max_dist,
+                                    min_dist, margin, _p(out))
     return out[:n].copy()

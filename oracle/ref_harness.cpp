@@ -357,4 +357,6 @@ void oracle_raycast_frame(oracle_map *m, const float *points, int64_t n, const d
   }
 }
 
+#include "depth_filter.inc"
+
 }  // extern "C"

@@ -216,3 +216,47 @@ def test_config3_640x480_frames_reference_intrinsics(hip_lib, oracle_libs, best_
     # occupancy after three frames, voxel for voxel (the distance field of this partially observed map is covered, with
     # its stated budget, by the smaller frame tests above)
     assert np.array_equal(gpu.download_field(("occ",))["occ"], cpu.dump_dense(("occ",))["occ"])
+
+
+def test_temporal_depth_filter_three_frames(hip_lib, oracle_libs, best_oracle_kind):
+    """Fiesta::DepthConversion with use_depth_filter_ (include/Fiesta.h:352-379; the reference's default): the previous
+    depth image and the relative pose decide which pixels may cast a ray.  A moving sensor over 4 frames (the first casts
+    nothing, like upstream's image_cnt_ == 1) with a sphere that APPEARS in frame 2 (its pixels disagree with the previous
+    image and are rejected once) and a non-zero margin: (1) the surviving points equal the oracle's cloud, point for point
+    and in order; (2) the ray cast of the filtered frame leaves bit-identical hit/miss counters."""
+    import fiesta_amd
+    origin, size, res = (-6.4, -6.4, -3.2), (12.75, 12.75, 6.35), 0.1
+    gpu, cpu = make(oracle_libs, best_oracle_kind, origin, size, res)
+    conv = fiesta_amd.ESDFMap(origin, res, size)      # a second map: the conversion-only entry point keeps its own image
+    lc, rc = origin, tuple(np.array(origin) + np.array(size))
+    intr = dict(fx=96.1, fy=95.9, cx=80.7, cy=58.9)
+    flt = dict(tolerance=0.1, max_dist=10.0, min_dist=0.1, margin=3)
+    last_img, last_T = None, None
+    total = 0
+    for f in range(4):
+        T = yaw_pose(4.0 * f, (0.05 * f, -0.03 * f, 0.01 * f))
+        spheres = [((1.5, 0.5, 0.0), 0.5)] + ([((1.2, -0.6, 0.1), 0.45)] if f >= 2 else [])
+        depth = render_depth(T, rows=120, cols=160, spheres=spheres, intr=intr)
+        rel = np.eye(4) if last_T is None else np.linalg.inv(last_T) @ T
+        want = oracle_libs.depth_conversion(depth, last_img, intr["fx"], intr["fy"], intr["cx"], intr["cy"], rel=rel,
+                                            kind=best_oracle_kind, **flt)
+        pts, n = conv.DepthConversion(depth, intr["fx"], intr["fy"], intr["cx"], intr["cy"], rel_transform=rel, **flt)
+        kept = pts[~np.isnan(pts[:, 0])]
+        assert n == len(want) == len(kept), (f, n, len(want))
+        assert np.array_equal(kept, want), f"frame {f}: filtered cloud differs from the reference's"
+        if f == 0:
+            assert n == 0
+        elif f == 2:
+            assert 0 < n < 0.98 * 114 * 154       # the new sphere's pixels were rejected (plus the margin)
+        gpu.RaycastDepthFiltered(depth, intr["fx"], intr["fy"], intr["cx"], intr["cy"], T, T[:3, 3], 0.5, 5.0, lc, rc, rel, **flt)
+        cpu.raycast_frame(want, T, T[:3, 3], 0.5, 5.0, lc, rc)
+        total += check_counts(gpu, cpu)
+        a, b = gpu.UpdateOccupancy(True), cpu.UpdateOccupancy(True)
+        assert a == b and (gpu.last_insert, gpu.last_delete) == (cpu.last_insert, cpu.last_delete)
+        gpu.UpdateESDF()
+        cpu.UpdateESDF()
+        last_img, last_T = depth, T
+    assert total > 10000
+    # a run can be restarted: reset forgets the previous image
+    pts, n = conv.DepthConversion(depth, intr["fx"], intr["fy"], intr["cx"], intr["cy"], rel_transform=np.eye(4), reset=True, **flt)
+    assert n == 0 and np.isnan(pts).all()
