@@ -174,6 +174,7 @@ __global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *to
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   bool to_ins = false, to_del = false, first_obs = false;
   uint32_t idx = 0;
+  if (n < 0) n = (int64_t)counters[C_TOUCHED];  // the host only knows an upper bound (it sized the grid with it)
   if (i < n) {
     idx = touched[i];
     fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, to_ins, to_del, first_obs);
@@ -891,19 +892,25 @@ bool DenseMap::check_update() {  // CheckUpdate (src/ESDFMap.cpp:227-233)
 
 bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
   use_device();
-  // C_TOUCHED, C_INSERT, C_DELETE are adjacent: one copy, one synchronisation
-  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_TOUCHED], &counters_[C_TOUCHED], 5 * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, stream_));  // ... + C_OBSERVED, C_NOCC
-  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-  unsigned long long nt = touched_upper_ ? h_counters_[C_TOUCHED] : 0;
-  unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
-  const unsigned long long obs_before = h_counters_[C_OBSERVED];
-  const long long nocc_before = (long long)h_counters_[C_NOCC];
+  // ONE host synchronisation per call (none when nothing was observed): the host keeps the queue sizes / map totals of
+  // its last read and an upper bound of the touched list, so the fusion kernel is launched without asking the device
+  // first (it reads the exact length itself); only the result is read back.
+  if (!host_counts_valid_) {
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, stream_));  // C_INSERT, C_DELETE, C_OBSERVED, C_NOCC
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int k = 0; k < 4; ++k) host_counts_[k] = h_counters_[C_INSERT + k];
+    host_counts_valid_ = true;
+  }
+  unsigned long long ni = host_counts_[0], nd = host_counts_[1];
+  const unsigned long long obs_before = host_counts_[2];
+  const long long nocc_before = (long long)host_counts_[3];
+  const unsigned long long nt = (unsigned long long)touched_upper_;
   if (nt) {
     ins_.ensure(ni + nt, stream_, ni);
     del_.ensure(nd + nt, stream_, nd);
     hipLaunchKernelGGL(k_fuse, dim3(grid_for((int64_t)nt)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
-                       (const uint32_t *)touched_.p, (int64_t)nt, cnt_, logodds_, coc_, occbits_, gocc_, ins_.p,
+                       (const uint32_t *)touched_.p, (int64_t)-1, cnt_, logodds_, coc_, occbits_, gocc_, ins_.p,
                        del_.p, counters_);
     FIESTA_HIP_CHECK(hipGetLastError());
     zero_counter(C_TOUCHED);
@@ -911,10 +918,11 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
     FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
                                     hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-    ni = h_counters_[C_INSERT];
-    nd = h_counters_[C_DELETE];
+    for (int k = 0; k < 4; ++k) host_counts_[k] = h_counters_[C_INSERT + k];
+    ni = host_counts_[0];
+    nd = host_counts_[1];
     // voxels observed for the first time while obstacles (or pending deletes of obstacles) exist: see stale_inf_
-    if (h_counters_[C_OBSERVED] != obs_before && (nocc_before > 0 || nd > 0)) stale_inf_ = true;
+    if (host_counts_[2] != obs_before && (nocc_before > 0 || nd > 0)) stale_inf_ = true;
   }
   if (n_ins) *n_ins = (int64_t)ni;
   if (n_del) *n_del = (int64_t)nd;
@@ -1202,6 +1210,7 @@ bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
 void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
   zero_counter(C_INSERT);
   zero_counter(C_DELETE);
+  host_counts_[0] = host_counts_[1] = 0;
   if (g_.sharded) zero_counter(C_REMOTE_DEL);
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
   collect_stats(nullptr);
@@ -1242,6 +1251,8 @@ void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long l
   FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (int k = 0; k < 4; ++k) host_counts_[k] = h_counters_[C_INSERT + k];
+  host_counts_valid_ = true;
   *ni = h_counters_[C_INSERT], *nd = h_counters_[C_DELETE];
   *nocc = (long long)h_counters_[C_NOCC];
   *eligible = bulk_eligible(*ni, *nd);
@@ -1250,9 +1261,13 @@ void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long l
 void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const auto h0 = std::chrono::steady_clock::now();
-  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, stream_));  // C_INSERT, C_DELETE, C_OBSERVED, C_NOCC
-  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (host_counts_valid_) {  // (what UpdateOccupancy read last: nothing else changes these four)
+    for (int k = 0; k < 4; ++k) h_counters_[C_INSERT + k] = host_counts_[k];
+  } else {
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, stream_));  // C_INSERT, C_DELETE, C_OBSERVED, C_NOCC
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
   const unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
   const bool remote_del = g_.sharded && read_counter(C_REMOTE_DEL) != 0;
   if (st) {
@@ -1304,6 +1319,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   }
   zero_counter(C_INSERT);
   zero_counter(C_DELETE);
+  host_counts_[0] = host_counts_[1] = 0;
   if (g_.sharded) zero_counter(C_REMOTE_DEL);
   if (seed_only) {  // sharded driver: ghost exchange comes next, then relax_pending()
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1550,6 +1566,7 @@ void DenseMap::snapshot_restore(int slot) {
   touched_upper_ = (int64_t)nt;
   g_ = s.g;
   stale_inf_ = s.stale_inf;
+  host_counts_valid_ = false;
   if (track_) {  // the snapshot may predate the tracking: recompute the distance bound for the restored field
     zero_counter(C_MAXD2);
     hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);

@@ -226,6 +226,8 @@ class DenseMap {
   // queues
   DevBuf<uint32_t> touched_, ins_, del_;
   int64_t touched_upper_ = 0;  // host-side upper bound of C_TOUCHED
+  unsigned long long host_counts_[4] = {0, 0, 0, 0};  // C_INSERT, C_DELETE, C_OBSERVED, C_NOCC as last read
+  bool host_counts_valid_ = false;
   unsigned long long *counters_ = nullptr;
   unsigned long long *h_counters_ = nullptr;  // pinned
 

@@ -75,15 +75,16 @@ struct LaneEnvelope {
   Metric m;
   int bot, top;  // live entries are bot..top (monotone counters, ring slot = counter & (S-1)); empty iff top < bot
   // cached entries: position q and key = q^2 + f(q), so that cost(p) = p (p - 2 q) + key
-  uint32_t t_site, c_site, n_site;  // top entry, entry `bot`, entry `bot + 1`
-  int t_q, t_key, t_s, c_q, c_key, n_q, n_key, n_s;
+  uint32_t t_site, c_site;  // top entry; entry `bot` = the winner at the emission point
+  int t_q, t_key, t_s, c_q, c_key;
+  int n_s;  // start of entry `bot + 1` (kNoStart: there is none)
   bool overflow;
 
   FT_HD void init() {
     bot = 0;
     top = -1;
-    t_site = c_site = n_site = 0;
-    t_q = t_key = t_s = c_q = c_key = n_q = n_key = 0;
+    t_site = c_site = 0;
+    t_q = t_key = t_s = c_q = c_key = 0;
     n_s = kNoStart;
     overflow = false;
   }
@@ -130,47 +131,37 @@ struct LaneEnvelope {
     t_q = keep ? q : t_q;
     t_key = keep ? key : t_key;
     t_s = keep ? s : t_s;
-    // the cached bottom entries follow pops and the push
-    const bool one = top == bot, two = top == bot + 1;
+    // the cached bottom follows pops and the push
+    const bool one = top == bot;
     c_site = one ? t_site : c_site;
     c_q = one ? t_q : c_q;
     c_key = one ? t_key : c_key;
-    n_site = two ? t_site : n_site;
-    n_q = two ? t_q : n_q;
-    n_key = two ? t_key : n_key;
-    n_s = two ? t_s : (top <= bot ? kNoStart : n_s);
+    n_s = top == bot + 1 ? t_s : (top <= bot ? kNoStart : n_s);
   }
 
+  // ---- emission.  Before position p is judged, the bottom moves on to the entry that wins there (advance): that is
+  // safe although p may not be final yet -- whatever later pops the new bottom beats it at its first position <= p, hence
+  // beats the released entry at p too, so the released entry never owns p again.
+  FT_HD bool wants_advance(int p) const { return n_s <= p; }
+  FT_HD void advance(bool doit) {
+    const int nb = bot + 1, i = nb & (S - 1), j = (nb + 1) & (S - 1);
+    const uint32_t rs = r.site(i);
+    const int rst = r.start(j);
+    const int nq = m.q(rs), nk = mul24(nq, nq) + m.f(rs);
+    bot = doit ? nb : bot;
+    c_site = doit ? rs : c_site;
+    c_q = doit ? nq : c_q;
+    c_key = doit ? nk : c_key;
+    n_s = doit ? (nb < top ? rst : kNoStart) : n_s;
+  }
   // Is the winner at position p settled, given that every site still to come lies at x_next or beyond (p < x_next)?
+  // (after advance: the winner is the bottom entry)
   FT_HD bool final_at(int p, int x_next) const {
-    const bool nx = n_s <= p;
-    const int oq = nx ? n_q : c_q, ok = nx ? n_key : c_key;
-    const int g = mul24(p, p - 2 * oq) + ok, dx = x_next - p;
+    const int g = mul24(p, p - 2 * c_q) + c_key, dx = x_next - p;
     return top >= bot && dx * dx >= g;
   }
-  FT_HD bool advances_at(int p) const { return n_s <= p; }
-
-  // The winner at p; p is emitted in increasing order, only after final_at(p, .) held.  any_advance: some lane of the
-  // wave moves on to its next entry at p (then every lane re-reads its ring; otherwise nobody touches LDS).
-  FT_HD uint32_t emit(int p, bool doit, bool any_advance) {
-    if (any_advance) {
-      const bool adv = doit && n_s <= p;
-      bot += adv ? 1 : 0;
-      c_site = adv ? n_site : c_site;
-      c_q = adv ? n_q : c_q;
-      c_key = adv ? n_key : c_key;
-      const int i = (bot + 1) & (S - 1);
-      const uint32_t rs = r.site(i);
-      const int rst = r.start(i);
-      const bool more = bot < top;
-      const int nq = m.q(rs), nk = mul24(nq, nq) + m.f(rs);
-      n_site = adv ? rs : n_site;
-      n_q = adv ? nq : n_q;
-      n_key = adv ? nk : n_key;
-      n_s = adv ? (more ? rst : kNoStart) : n_s;
-    }
-    return c_site;
-  }
+  FT_HD uint32_t winner() const { return c_site; }
+  FT_HD int winner_cost(int p) const { return mul24(p, p - 2 * c_q) + c_key; }
 };
 
 // Nearest set bit of a bitmap row to position z, for the 64 positions [cbase, cbase + 64) that share the 64-bit chunk

@@ -78,6 +78,9 @@ struct FtMetricB {  // column along x at (y, z); site = x' << 20 | y' << 10 | z'
   }
 };
 
+// wave vote on a bool: the comparison result itself (no 0/1 round trip through a VGPR as with __ballot(int))
+__device__ __forceinline__ unsigned long long ft_vote(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // ---- per plane: ordered list of the rows that hold at least one occupied voxel -------------------------------------
 __global__ __launch_bounds__(256) void k_ft_rows(FtArgs a) {
   __shared__ int wsum[4];
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void k_ft_rows(FtArgs a) {
       }
       any = acc != 0;
     }
-    const unsigned long long m = __ballot(any);
+    const unsigned long long m = ft_vote(any);
     if (lane == 0) wsum[wave] = __popcll(m);
     __syncthreads();
     int off = base;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         const int ynext = (r + 1 < nb) ? __builtin_amdgcn_readlane(ylist, r + 1) : ynext_batch;
         // nearest occupied voxel of this row for every lane: own 64-bit chunk + nearest set bit outside it
         const uint32_t wv = lane < 32 ? rowstage[wave][r][lane] : 0u;
-        const unsigned long long nonempty = __ballot(wv != 0u);
+        const unsigned long long nonempty = ft_vote(wv != 0u);
         unsigned long long chunk = rowstage[wave][r][2 * c];
         if (2 * c + 1 < a.nzw) chunk |= (unsigned long long)rowstage[wave][r][2 * c + 1] << 32;
         int left_out = -1, right_out = -1;
@@ -187,20 +190,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         const int key = yr * yr + ft::mul24(d, d);
         for (;;) {  // pop while any lane wants to
           const bool want = act && env.wants_pop(yr, key);
-          if (!__ballot(want)) break;
+          if (!ft_vote(want)) break;
           env.pop(want);
         }
         env.place(act, site, yr, key, a.ny, p_out);
-        if (__ballot(env.overflow)) {
+        if (ft_vote(env.overflow)) {
           failed = true;
           break;
         }
         while (p_out < a.ny && p_out < ynext) {
+          const bool adv = act && env.wants_advance(p_out);
+          if (ft_vote(adv)) env.advance(adv);
           const bool fin = !act || env.final_at(p_out, ynext);
-          if (__ballot(fin) != ~0ull) break;
-          const bool adv = __ballot(act && env.advances_at(p_out)) != 0ull;
-          const uint32_t s = env.emit(p_out, act, adv);
-          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = s;
+          if (ft_vote(fin) != ~0ull) break;
+          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = env.winner();
           out += a.nz;
           ++p_out;
         }
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     // -> output voxel of region position p_stored of this column (valid to dereference only inside the output box)
     vox_t *optr = a.coc + ((int64_t)(0 - a.ox0) * a.ony + (y - a.oy0)) * a.onz + (act ? z - a.oz0 : 0);
     uint32_t *stg = &stage[wave][lane % LANES];
+    const bool shifted = (a.gx0 | a.gy0 | a.gz0) != 0;
     auto flush = [&]() {
       for (int p = p_stored; p < p_out; ++p) {
         if (act && (unsigned)(p - a.ox0) < (unsigned)a.onx) *optr = stg[(p & (OB - 1)) * LANES];
@@ -255,22 +259,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       }
       p_stored = p_out;
     };
-    // emits what is final; returns true if it had to stop because the staging buffer is full (the caller flushes and
-    // calls again: stores stay out of this loop, see the note on vmcnt above)
-    auto drain = [&](const int x_next) -> bool {
+    // emits what is final (a burst longer than the staging buffer stores in between: rare)
+    auto drain = [&](const int x_next) {
       while (p_out < a.nx && p_out < x_next) {
+        const bool adv = act && env.wants_advance(p_out);
+        if (ft_vote(adv)) env.advance(adv);
         const bool fin = !act || env.final_at(p_out, x_next);
-        if (__ballot(fin) != ~0ull) break;
-        if (p_out - p_stored == OB) return true;
-        const bool adv = __ballot(act && env.advances_at(p_out)) != 0ull;
-        const uint32_t s = env.emit(p_out, act, adv);
-        // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc)
-        if (act) stg[(p_out & (OB - 1)) * LANES] = pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0);
-        if (a.maxd2 && act && (unsigned)(p_out - a.ox0) < (unsigned)a.onx)
-          acc_maxd2 = max(acc_maxd2, (uint32_t)(ft::mul24(p_out, p_out - 2 * env.c_q) + env.c_key));
+        if (ft_vote(fin) != ~0ull) break;
+        if (p_out - p_stored == OB) flush();
+        const uint32_t s = env.winner();
+        // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc); plain when the region
+        // starts at the global origin (every unsharded map)
+        if (act)
+          stg[(p_out & (OB - 1)) * LANES] =
+              shifted ? pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0) : s;
+        if (a.maxd2 && act && (unsigned)(p_out - a.ox0) < (unsigned)a.onx) acc_maxd2 = max(acc_maxd2, (uint32_t)env.winner_cost(p_out));
         ++p_out;
       }
-      return false;
     };
     // The prefetch is issued and waited for BY HAND (inline asm): hipcc's wait-count pass otherwise drains vmcnt to 0
     // in front of every inner loop that might store (one full HBM round trip per step).  Loads are unconditional: a
@@ -303,16 +308,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
           const int key = env.key_of(site);
           for (;;) {  // pop while any lane wants to
             const bool want = act && env.wants_pop(x, key);
-            if (!__ballot(want)) break;
+            if (!ft_vote(want)) break;
             env.pop(want);
           }
           env.place(act, site, x, key, a.nx, p_out);
-          if (__ballot(env.overflow)) {
+          if (ft_vote(env.overflow)) {
             failed = true;
             break;
           }
         }
-        while (drain(x + 1)) flush();
+        drain(x + 1);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, unused prefetch)
@@ -320,8 +325,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       ft_overflow(a, id, lane);
       continue;
     }
-    if (__ballot(act && !env.empty())) {
-      while (drain(ft::kFarAhead)) flush();
+    if (ft_vote(act && !env.empty())) {
+      drain(ft::kFarAhead);
       flush();
     } else {  // no occupied voxel anywhere in the region: "observed, no obstacle"
       for (int p = 0; p < a.nx; ++p) {

@@ -68,14 +68,15 @@ struct Model {
     int p_out = 0;
     auto drain = [&](int x_next) {
       while (p_out < ny && p_out < x_next) {
-        bool all = true, adv = false;
+        bool any = false, all = true;
+        bool adv[W];
+        for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
+        if (any)
+          for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
         for (int k = 0; k < W; ++k) all = all && (!act[k] || env[k].final_at(p_out, x_next));
         if (!all) break;
-        for (int k = 0; k < W; ++k) adv = adv || (act[k] && env[k].advances_at(p_out));
-        for (int k = 0; k < W; ++k) {
-          const uint32_t s = env[k].emit(p_out, act[k], adv);
-          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = s & 0xFFFFFu;
-        }
+        for (int k = 0; k < W; ++k)
+          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = env[k].winner() & 0xFFFFFu;
         ++p_out;
       }
     };
@@ -129,14 +130,15 @@ struct Model {
     int p_out = 0;
     auto drain = [&](int x_next) {
       while (p_out < nx && p_out < x_next) {
-        bool all = true, adv = false;
+        bool any = false, all = true;
+        bool adv[W];
+        for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
+        if (any)
+          for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
         for (int k = 0; k < W; ++k) all = all && (!act[k] || env[k].final_at(p_out, x_next));
         if (!all) break;
-        for (int k = 0; k < W; ++k) adv = adv || (act[k] && env[k].advances_at(p_out));
-        for (int k = 0; k < W; ++k) {
-          const uint32_t s = env[k].emit(p_out, act[k], adv);
-          if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = s;
-        }
+        for (int k = 0; k < W; ++k)
+          if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = env[k].winner();
         ++p_out;
       }
     };

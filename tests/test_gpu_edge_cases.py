@@ -40,7 +40,7 @@ def test_empty_batches_and_noop_updates(hip_lib):
 
 def test_largest_axis_and_rejected_configs(hip_lib):
     import fiesta_amd
-    m = fiesta_amd.ESDFMap((0, 0, 0), 0.1, (102.35, 0.75, 0.75))  # 1024 x 8 x 8: the 10-bit coordinate limit
+    m = fiesta_amd.ESDFMap((0, 0, 0), 0.1, (102.35, 0.75, 0.75))  # 1024 x 8 x 8: the largest axis with plain 10-bit ids
     assert m.grid_size == (1024, 8, 8)
     m.SetParameters(*P_DEFAULT)
     m.SetOccupancyBox((0, 0, 0), (1023, 7, 7), 0)
@@ -58,8 +58,12 @@ def test_largest_axis_and_rejected_configs(hip_lib):
     assert np.array_equal(d2[:, 3, 3], want)
     assert f["coc"].reshape(1024, 8, 8, 3)[1000, 4, 4].tolist() == [1023, 4, 4]
     m.close()
-    with pytest.raises(fiesta_amd.FiestaHipError):   # 1025 voxels on an axis do not fit the obstacle id
-        fiesta_amd.ESDFMap((0, 0, 0), 0.1, (102.45, 0.75, 0.75))
+    # 1025 voxels: beyond the plain 10-bit id; such maps decode ids relative to their voxel (tests/test_gpu_sharded.py)
+    big = fiesta_amd.ESDFMap((0, 0, 0), 0.1, (102.45, 0.75, 0.75))
+    assert big.grid_size == (1025, 8, 8)
+    big.close()
+    with pytest.raises(fiesta_amd.FiestaHipError):   # more than 32768 voxels on an axis: the shard protocol's coordinates
+        fiesta_amd.ESDFMap((0, 0, 0), 0.001, (33.0, 0.004, 0.004))
     with pytest.raises(fiesta_amd.FiestaHipError):
         fiesta_amd.ESDFMap((0, 0, 0), -0.1, (1.0, 1.0, 1.0))
     with pytest.raises(fiesta_amd.FiestaHipError):
