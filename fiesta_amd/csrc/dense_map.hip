@@ -1058,13 +1058,13 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
 // Valid when the reference's propagation has nothing to be gated by: every voxel of the array observed, the update
 // window = the whole array, one unsharded map.  Then the fixed point of src/ESDFMap.cpp:339-392 IS the Euclidean
 // feature transform of the occupied set, whatever the previous state was.
-template <int S, int LANES, int WAVES>
+template <int S, int LANES, int WAVES, bool WIDE>
 static void launch_ft_plane(const FtArgs &a, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL((k_ft_plane<S, LANES, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, s, a);
+  hipLaunchKernelGGL((k_ft_plane<S, LANES, WAVES, WIDE>), dim3(blocks), dim3(64 * WAVES), 0, s, a);
 }
-template <int S, int LANES, int WAVES>
+template <int S, int LANES, int WAVES, bool WIDE>
 static void launch_ft_x(const FtArgs &a, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL((k_ft_x<S, LANES, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, s, a);
+  hipLaunchKernelGGL((k_ft_x<S, LANES, WAVES, WIDE>), dim3(blocks), dim3(64 * WAVES), 0, s, a);
 }
 
 // The transform of this map's array.  Unsharded: the region is the array, the bitmap the map's own.  Sharded: the
@@ -1079,7 +1079,8 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   memset(&a, 0, sizeof(a));
   int rlo[3], rhi[3], mlo[3], mhi[3];  // region in GLOBAL coordinates (inclusive); margins actually obtained per side
   const int l0[3] = {g.gx0, g.gy0, g.gz0}, ln[3] = {g.nx, g.ny, g.nz}, G[3] = {g.GX, g.GY, g.GZ};
-  bool open_side = false;  // some side of the region neither reaches the global boundary nor ... (needs the margin test)
+  bool open_side = false;  // some side of the region does not reach the global boundary (needs the margin test)
+  bool wide = g.wrap != 0;  // site packing of the transform (ft_kernels.hpp: FtMetricB)
   for (int k = 0; k < 3; ++k) {
     rlo[k] = g.sharded ? std::max(0, l0[k] - margin) : l0[k];
     rhi[k] = g.sharded ? std::min(G[k] - 1, l0[k] + ln[k] - 1 + margin) : l0[k] + ln[k] - 1;
@@ -1091,7 +1092,8 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   for (int k = 0; k < 3; ++k) {
     mlo[k] = l0[k] - rlo[k], mhi[k] = rhi[k] - (l0[k] + ln[k] - 1);
     if (g.sharded && ((rlo[k] > 0) || (rhi[k] < G[k] - 1))) open_side = true;
-    if (rhi[k] - rlo[k] + 1 > 1024) return false;
+    if (rhi[k] - rlo[k] + 1 > 2048) return false;
+    if (rhi[k] - rlo[k] + 1 > 1024) wide = true;
   }
   a.nx = rhi[0] - rlo[0] + 1, a.ny = rhi[1] - rlo[1] + 1, a.nz = rhi[2] - rlo[2] + 1;
   a.nzw = (a.nz + 31) / 32, a.nzc = (a.nz + 63) / 64;
@@ -1108,12 +1110,12 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   const uint32_t cap = std::max(items_a, items_b);
   ft_inter_.ensure((size_t)rn, stream_);
   ft_rowlist_.ensure((size_t)a.nx * a.ny, stream_);
-  ft_rowcnt_.ensure((size_t)a.nx + 32, stream_);  // + the 1024-bit plane mask
+  ft_rowcnt_.ensure((size_t)a.nx + 64, stream_);  // + the 2048-bit plane mask
   ft_ovf_.ensure((size_t)cap * 6, stream_);
   a.rowlist = ft_rowlist_.p;
   a.rowcnt = ft_rowcnt_.p;
   a.planemask = reinterpret_cast<uint32_t *>(ft_rowcnt_.p + a.nx);
-  FIESTA_HIP_CHECK(hipMemsetAsync(a.planemask, 0, 32 * sizeof(uint32_t), stream_));
+  FIESTA_HIP_CHECK(hipMemsetAsync(a.planemask, 0, 64 * sizeof(uint32_t), stream_));
   a.inter = ft_inter_.p;
   // a shard's transform lands in a side buffer first: it only replaces the field once every shard has confirmed that
   // its margin sufficed (bulk_commit); if not, the frontier rounds take over from the untouched field
@@ -1133,30 +1135,39 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
     t.items = nullptr, t.n_items_dev = nullptr, t.n_items = n0;
     t.ovf_list = ft_ovf_.p + (size_t)(pass_a ? 0 : 3) * cap, t.ovf_count = &counters_[ovf0];
     const int blocks0 = (int)((n0 + 3) / 4);
-    if (pass_a) {
-      if (ft_s0_ == 16) launch_ft_plane<16, 64, 4>(t, blocks0, stream_);
-      else launch_ft_plane<32, 64, 4>(t, blocks0, stream_);
-    } else {
-      if (ft_s0_ == 16) launch_ft_x<16, 64, 4>(t, blocks0, stream_);
-      else launch_ft_x<32, 64, 4>(t, blocks0, stream_);
-    }
-    FIESTA_HIP_CHECK(hipGetLastError());
     auto next = [&]() {
       t.items = t.ovf_list, t.n_items_dev = t.ovf_count, t.n_items = 0;
       t.ovf_list += cap, t.ovf_count = t.ovf_count + 1;
     };
-    next();
-    if (pass_a) launch_ft_plane<64, 64, 2>(t, 2048, stream_);
-    else launch_ft_x<64, 64, 2>(t, 2048, stream_);
-    FIESTA_HIP_CHECK(hipGetLastError());
-    next();
-    if (pass_a) launch_ft_plane<256, 64, 1>(t, 1024, stream_);
-    else launch_ft_x<256, 64, 1>(t, 1024, stream_);
-    FIESTA_HIP_CHECK(hipGetLastError());
-    next();
-    t.ovf_list = nullptr, t.ovf_count = nullptr;
-    if (pass_a) launch_ft_plane<1024, 16, 1>(t, 1024, stream_);
-    else launch_ft_x<1024, 16, 1>(t, 1024, stream_);
+#define FIESTA_FT_TIERS(WIDE, LASTS, LASTL)                                                        \
+  if (pass_a) {                                                                                    \
+    if (ft_s0_ == 16) launch_ft_plane<16, 64, 4, WIDE>(t, blocks0, stream_);                       \
+    else launch_ft_plane<32, 64, 4, WIDE>(t, blocks0, stream_);                                    \
+    next();                                                                                        \
+    launch_ft_plane<64, 64, 2, WIDE>(t, 2048, stream_);                                            \
+    next();                                                                                        \
+    launch_ft_plane<256, 64, 1, WIDE>(t, 1024, stream_);                                           \
+    next();                                                                                        \
+    t.ovf_list = nullptr, t.ovf_count = nullptr;                                                   \
+    launch_ft_plane<LASTS, LASTL, 1, WIDE>(t, 1024, stream_);                                      \
+  } else {                                                                                         \
+    if (ft_s0_ == 16) launch_ft_x<16, 64, 4, WIDE>(t, blocks0, stream_);                           \
+    else launch_ft_x<32, 64, 4, WIDE>(t, blocks0, stream_);                                        \
+    next();                                                                                        \
+    launch_ft_x<64, 64, 2, WIDE>(t, 2048, stream_);                                                \
+    next();                                                                                        \
+    launch_ft_x<256, 64, 1, WIDE>(t, 1024, stream_);                                               \
+    next();                                                                                        \
+    t.ovf_list = nullptr, t.ovf_count = nullptr;                                                   \
+    launch_ft_x<LASTS, LASTL, 1, WIDE>(t, 1024, stream_);                                          \
+  }
+    // the last tier's ring holds a whole column: it cannot overflow (1024 entries x 16 lanes, wide: 2048 x 8)
+    if (wide) {
+      FIESTA_FT_TIERS(true, 2048, 8)
+    } else {
+      FIESTA_FT_TIERS(false, 1024, 16)
+    }
+#undef FIESTA_FT_TIERS
     FIESTA_HIP_CHECK(hipGetLastError());
   };
   tiers(true, items_a, C_FT_OVF0);
@@ -1173,10 +1184,13 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
       h_counters_[C_MAXD2] = dmax2;
       FIESTA_HIP_CHECK(hipMemcpyAsync(&counters_[C_MAXD2], &h_counters_[C_MAXD2], sizeof(unsigned long long), hipMemcpyHostToDevice, stream_));
     }
+    // (grids beyond 1024 per axis: nothing farther than an id's reach of 512 voxels is ever stored, so a margin of
+    //  512 always suffices there)
+    const unsigned long long need2 = g.wrap ? std::min<unsigned long long>(dmax2, (unsigned long long)kD2Cap) : dmax2;
     bool ok = true;
     for (int k = 0; k < 3; ++k) {
-      if (rlo[k] > 0 && (unsigned long long)mlo[k] * mlo[k] < dmax2) ok = false;
-      if (rhi[k] < G[k] - 1 && (unsigned long long)mhi[k] * mhi[k] < dmax2) ok = false;
+      if (rlo[k] > 0 && (unsigned long long)mlo[k] * mlo[k] < need2) ok = false;
+      if (rhi[k] < G[k] - 1 && (unsigned long long)mhi[k] * mhi[k] < need2) ok = false;
     }
     if (exact) *exact = ok || !g.sharded;
     if (st) st->ft_max_d2 = (int64_t)dmax2;
@@ -1189,7 +1203,7 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 // The map-local half of the engine choice: may this update be served by the bulk transform at all?
 bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
   const Geom &g = g_;
-  if (update_engine_ == 1 || g.wrap) return false;
+  if (update_engine_ == 1) return false;
   if (!(g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1)) return false;
   const long long owned = (long long)(g.ox1 - g.ox0 + 1) * (g.oy1 - g.oy0 + 1) * (g.oz1 - g.oz0 + 1);
   if ((long long)h_counters_[C_OBSERVED] != owned) return false;

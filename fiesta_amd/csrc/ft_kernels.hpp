@@ -20,8 +20,8 @@
 
 namespace fiesta {
 
-// The transform runs over a REGION (nx x ny x nz voxels, at most 1024 per axis: sites are packed in 3 x 10 bits of
-// region coordinates) whose occupancy comes from any bitmap -- the map's own (unsharded: region = the whole array) or a
+// The transform runs over a REGION (nx x ny x nz voxels; at most 1024 per axis with the plain site packing, 2048 with
+// the WIDE one, see FtMetricB) whose occupancy comes from any bitmap -- the map's own (unsharded: region = the whole array) or a
 // shard's replica of the GLOBAL bitmap (region = the shard's array grown by a margin, see DenseMap::run_bulk) -- and
 // writes the voxels of an OUTPUT box inside the region.
 struct FtArgs {
@@ -31,8 +31,8 @@ struct FtArgs {
   int sx0, sy0, sw0, sny, snzw;
   uint16_t *rowlist;         // [nx][ny]: non-empty rows of plane x, ascending
   int32_t *rowcnt;           // [nx]
-  uint32_t *planemask;       // [32]: bit x = plane x holds a site (zeroed before k_ft_rows)
-  uint32_t *inter;           // [nx][ny][nz]: pass A result, y' << 10 | z' (region coordinates)
+  uint32_t *planemask;       // [64]: bit x = plane x holds a site (zeroed before k_ft_rows)
+  uint32_t *inter;           // [nx][ny][nz]: pass A result, y' << 10 | z' (WIDE: << 11), region coordinates
   vox_t *coc;                // output array (the map's voxel words) with extents (., ony, onz); region voxel (x,y,z) is
   int ox0, oy0, oz0;         // output voxel (x - ox0, y - oy0, z - oz0), written iff inside [0,onx) x [0,ony) x [0,onz)
   int onx, ony, onz;
@@ -61,19 +61,38 @@ struct LdsRing {
     st[i * LANES] = (uint16_t)b;
   }
 };
-struct FtMetricA {  // column along y at lane z; site = y' << 10 | z'
+// Site packing.  Regions of at most 1024 voxels per axis (every unsharded map up to the plain-id limit): ABSOLUTE region
+// coordinates, 10 bits each.  WIDE (regions up to 2048: a 1024^3 shard of config 5 plus its margin; grids beyond 1024 per
+// axis, whose ids reach 512 voxels anyway, common.hpp): pass A keeps 11-bit absolute (y', z'); pass B packs the plane
+// (11 bits) and the site's OFFSET from the column, (y' - y, z' - z) as signed 10-bit fields -- a candidate farther than
+// 511 voxels in y or z could never be stored and is dropped on arrival.
+template <bool WIDE>
+struct FtMetricA {  // column along y at lane z; site = y' << SH | z'
+  static constexpr int SH = WIDE ? 11 : 10;
   int z;
-  __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> 10); }
+  __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> SH); }
   __device__ __forceinline__ int f(uint32_t s) const {
-    const int d = z - (int)(s & 1023u);
+    const int d = z - (int)(s & ((1u << SH) - 1u));
     return ft::mul24(d, d);
   }
 };
-struct FtMetricB {  // column along x at (y, z); site = x' << 20 | y' << 10 | z'
+template <bool WIDE>
+struct FtMetricB;
+template <>
+struct FtMetricB<false> {  // column along x at (y, z); site = x' << 20 | y' << 10 | z'
   int y, z;
   __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> 20); }
   __device__ __forceinline__ int f(uint32_t s) const {
     const int dy = y - (int)((s >> 10) & 1023u), dz = z - (int)(s & 1023u);
+    return ft::mul24(dy, dy) + ft::mul24(dz, dz);
+  }
+};
+template <>
+struct FtMetricB<true> {  // site = x' << 20 | (y' - y) << 10 | (z' - z), offsets as signed 10-bit fields
+  int y, z;
+  __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> 20); }
+  __device__ __forceinline__ int f(uint32_t s) const {
+    const int dy = ((int)(s << 12)) >> 22, dz = ((int)(s << 22)) >> 22;
     return ft::mul24(dy, dy) + ft::mul24(dz, dz);
   }
 };
@@ -125,12 +144,13 @@ __device__ __forceinline__ void ft_overflow(const FtArgs &a, uint32_t id, int la
 }
 
 // ---- pass A: in-plane nearest site.  item = x * nzc + c: plane x, lanes z = 64 c + lane ------------------------------
-template <int S, int LANES, int WAVES>
+template <int S, int LANES, int WAVES, bool WIDE>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
-  constexpr int RB = 16;  // bitmap rows staged per batch
+  constexpr int RB = 16;               // bitmap rows staged per batch
+  constexpr int RW = WIDE ? 64 : 32;   // 32-bit words of a staged row
   __shared__ uint32_t ring_site[WAVES][S * LANES];
   __shared__ uint16_t ring_start[WAVES][S * LANES];
-  __shared__ uint32_t rowstage[WAVES][RB][32];
+  __shared__ uint32_t rowstage[WAVES][RB][RW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int SUB = 64 / LANES;  // sub-items per column group when a wave only carries LANES columns
   const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
@@ -143,9 +163,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
     const int k = sub * LANES + lane;  // position inside the 64-voxel group
     const int z = 64 * c + k;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;  // (pass B only reads these)
-    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricA> env;
+    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricA<WIDE>> env;
     env.r = LdsRing<S, LANES>{&ring_site[wave][lane % LANES], &ring_start[wave][lane % LANES]};
-    env.m = FtMetricA{z};
+    env.m = FtMetricA<WIDE>{z};
     env.init();
     int p_out = 0;
     bool failed = false;
@@ -157,8 +177,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
       const int ylist = rows[min(i0 + lane, cnt - 1)];  // lanes 0..nb-1: the rows of this batch; lane RB: the one after
       const int ynext_batch = (i0 + RB < cnt) ? __builtin_amdgcn_readlane(ylist, RB) : ft::kFarAhead;
       __builtin_amdgcn_wave_barrier();
-      for (int j = lane; j < nb * 32; j += 64) {
-        const int r = j >> 5, w = j & 31;
+      for (int j = lane; j < nb * RW; j += 64) {
+        const int r = j / RW, w = j % RW;
         const int yr = __shfl(ylist, r);
         rowstage[wave][r][w] = w < a.nzw ? a.row(x, yr)[w] : 0u;
       }
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         const int yr = __builtin_amdgcn_readlane(ylist, r);
         const int ynext = (r + 1 < nb) ? __builtin_amdgcn_readlane(ylist, r + 1) : ynext_batch;
         // nearest occupied voxel of this row for every lane: own 64-bit chunk + nearest set bit outside it
-        const uint32_t wv = lane < 32 ? rowstage[wave][r][lane] : 0u;
+        const uint32_t wv = lane < RW ? rowstage[wave][r][lane] : 0u;
         const unsigned long long nonempty = ft_vote(wv != 0u);
         unsigned long long chunk = rowstage[wave][r][2 * c];
         if (2 * c + 1 < a.nzw) chunk |= (unsigned long long)rowstage[wave][r][2 * c + 1] << 32;
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         }
         int d;
         const int zp = ft::nearest_in_row(chunk, 64 * c, k, left_out, right_out, d);
-        const uint32_t site = ((uint32_t)yr << 10) | (uint32_t)(zp & 1023);
+        const uint32_t site = ((uint32_t)yr << FtMetricA<WIDE>::SH) | (uint32_t)(zp & ((1 << FtMetricA<WIDE>::SH) - 1));
         const int key = yr * yr + ft::mul24(d, d);
         for (;;) {  // pop while any lane wants to
           const bool want = act && env.wants_pop(yr, key);
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
 // segment each) ahead into registers, and emitted words are parked in an LDS staging buffer and stored at the batch
 // boundary BEFORE the next prefetch is issued.  gfx9's vmcnt is one in-order counter for loads and stores: with stores
 // issued between a prefetch and its use, the wait for the prefetch would also wait for those stores to reach HBM.
-template <int S, int LANES, int WAVES>
+template <int S, int LANES, int WAVES, bool WIDE>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
   constexpr int P = 8, OB = 16;
   static_assert(P == 8, "the hand-written wait below names eight registers");
@@ -229,9 +249,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
   constexpr int SUB = 64 / LANES;
   const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
   uint32_t acc_maxd2 = 0;
-  // which planes hold any site: bit x of the 1024-bit mask, word w in lane w
-  const uint32_t pm = lane < 32 ? a.planemask[lane] : 0u;
-  auto plane_has = [&](const int x) -> bool { return (__builtin_amdgcn_readlane(pm, (x >> 5) & 31) >> (x & 31)) & 1u; };
+  // which planes hold any site: bit x of the 2048-bit mask, word w in lane w
+  const uint32_t pm = a.planemask[lane];
+  auto plane_has = [&](const int x) -> bool { return (__builtin_amdgcn_readlane(pm, (x >> 5) & 63) >> (x & 31)) & 1u; };
   for (uint32_t it = blockIdx.x * WAVES + wave; it < n; it += gridDim.x * WAVES) {
     const uint32_t id = a.items ? a.items[it / SUB] : it / SUB;
     const int sub = (int)(it % SUB);
@@ -239,9 +259,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     const int z = 64 * c + sub * LANES + lane;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;
     if ((unsigned)(y - a.oy0) >= (unsigned)a.ony) continue;  // (the host only lists rows of the output box)
-    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricB> env;
+    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricB<WIDE>> env;
     env.r = LdsRing<S, LANES>{&ring_site[wave][lane % LANES], &ring_start[wave][lane % LANES]};
-    env.m = FtMetricB{y, z};
+    env.m = FtMetricB<WIDE>{y, z};
     env.init();
     int p_out = 0, p_stored = 0;  // positions [p_stored, p_out) sit in the staging buffer
     bool failed = false;
@@ -269,10 +289,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
         if (p_out - p_stored == OB) flush();
         const uint32_t s = env.winner();
         // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc); plain when the region
-        // starts at the global origin (every unsharded map)
-        if (act)
-          stg[(p_out & (OB - 1)) * LANES] =
-              shifted ? pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0) : s;
+        // starts at the global origin of a grid within the plain-id limit (every unsharded map up to 1024 per axis)
+        vox_t word;
+        if (WIDE) {
+          const int dy = ((int)(s << 12)) >> 22, dz = ((int)(s << 22)) >> 22;
+          word = pack_coc((int)(s >> 20) + a.gx0, y + dy + a.gy0, z + dz + a.gz0);
+          if (env.winner_cost(p_out) >= kD2Cap) word = kInf;  // beyond the reach of an id on such grids
+        } else {
+          word = shifted ? pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0) : s;
+        }
+        if (act) stg[(p_out & (OB - 1)) * LANES] = word;
         if (a.maxd2 && act && (unsigned)(p_out - a.ox0) < (unsigned)a.onx) acc_maxd2 = max(acc_maxd2, (uint32_t)env.winner_cost(p_out));
         ++p_out;
       }
@@ -304,14 +330,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
         const int x = x0 + u;
         if (x >= a.nx || failed) break;
         if (plane_has(x)) {
-          const uint32_t site = ((uint32_t)x << 20) | (w[u] & 0xFFFFFu);
+          uint32_t site;
+          bool use = act;
+          if (WIDE) {  // offsets from the column; a site out of an id's reach in y or z is no candidate
+            const int dy = (int)(w[u] >> 11) - y, dz = (int)(w[u] & 2047u) - z;
+            use = use && (unsigned)(dy + 511) < 1023u && (unsigned)(dz + 511) < 1023u;
+            site = ((uint32_t)x << 20) | (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u);
+          } else {
+            site = ((uint32_t)x << 20) | (w[u] & 0xFFFFFu);
+          }
           const int key = env.key_of(site);
           for (;;) {  // pop while any lane wants to
-            const bool want = act && env.wants_pop(x, key);
+            const bool want = use && env.wants_pop(x, key);
             if (!ft_vote(want)) break;
             env.pop(want);
           }
-          env.place(act, site, x, key, a.nx, p_out);
+          env.place(use, site, x, key, a.nx, p_out);
           if (ft_vote(env.overflow)) {
             failed = true;
             break;
