@@ -612,7 +612,10 @@ __global__ void k_count_stale(Geom g, const vox_t *coc, unsigned long long *out)
 // =====================================================================================================
 // host side
 // =====================================================================================================
-static inline int grid_for(int64_t n, int block = 256, int cap = 1 << 20) {
+// one thread per element unless the caller names a cap (= the kernel strides over the grid): the default must cover the
+// largest arrays (a 1024^3 shard touches 10^9 voxels at once -- a cap of 2^20 blocks silently dropped three quarters
+// of them, found by tools/c5_smoke.py)
+static inline int grid_for(int64_t n, int block = 256, int cap = 0x7FFFFFFF) {
   int64_t b = (n + block - 1) / block;
   if (b < 1) b = 1;
   if (b > cap) b = cap;

@@ -42,7 +42,10 @@ __device__ inline void vcoords(const int32_t *page_tile, uint32_t addr, int &x, 
 }
 __device__ inline bool hbit(const uint32_t *bits, int64_t addr) { return (bits[addr >> 5] >> (addr & 31)) & 1u; }
 
-static inline int grid_for(int64_t n, int block = 256, int cap = 1 << 20) {
+// one thread per element unless the caller names a cap (= the kernel strides over the grid): the default must cover the
+// largest arrays (a 1024^3 shard touches 10^9 voxels at once -- a cap of 2^20 blocks silently dropped three quarters
+// of them, found by tools/c5_smoke.py)
+static inline int grid_for(int64_t n, int block = 256, int cap = 0x7FFFFFFF) {
   int64_t b = (n + block - 1) / block;
   return (int)std::min<int64_t>(std::max<int64_t>(b, 1), cap);
 }
