@@ -51,8 +51,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--grid", type=int, default=512)
-    ap.add_argument("--obstacles", type=int, default=50000)
+    ap.add_argument("--grid", type=int, default=None,
+                    help="voxels per axis OWNED by each rank (default: 512 on one GPU = config 2; 1024 with --gpus N > 1, i.e. "
+                         "2048^3 as 2x2x2 shards at N = 8 = config 5)")
+    ap.add_argument("--obstacles", type=int, default=None,
+                    help="live obstacle voxels per rank (default: config 2's density, 50000 per 512^3)")
     ap.add_argument("--engine", default="auto", choices=["auto", "rounds", "bulk"],
                     help="UpdateESDF engine: chosen per update (default), frontier rounds only, or the bulk feature "
                          "transform whenever the map state allows it")
@@ -358,6 +361,10 @@ def run_c4(args):
 
 def main():
     args = parse()
+    if args.grid is None:
+        args.grid = 512 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 1024
+    if args.obstacles is None:
+        args.obstacles = int(round(50000 * (args.grid / 512.0) ** 3))
     if args.workload == "c3":
         import torch  # noqa: F401  (one HIP runtime per process: torch first)
         return run_c3(args)
@@ -540,7 +547,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {G}^3 dense-array grid @0.1 m fully observed, {args.obstacles} "
+                "workload": f"{'C2' if world == 1 else 'C5 shape (per rank)'}: {G}^3 dense-array grid @0.1 m fully observed, {args.obstacles} "
                             f"{'scattered' if args.scene == 'scatter' else 'surface (3 planes + 20 spheres)'} obstacle voxels, "
                             f"per step a {args.obstacles}-voxel delta = {args.obstacles // 2} inserts + {args.obstacles // 2} deletes "
                             "landing in one UpdateESDF (ingest: 3 SetOccupancy+UpdateOccupancy cycles, inputs resident in HBM)",

@@ -102,3 +102,30 @@ def test_repeated_insert_same_voxel_and_redundant_observations(hip_lib, oracle_l
         cpu.UpdateESDF()
         f, c = gpu.download_field(("occ", "logodds")), cpu.dump_dense(("occ", "logodds"))
         assert np.array_equal(f["occ"], c["occ"]) and np.array_equal(f["logodds"], c["logodds"])
+
+
+def test_updated_voxel_unit_counts_first_observations(hip_lib):
+    """snapshot_count_updated must see an unobserved -> observed transition (0xFFFFFFFF kept its tag bit after
+    masking and compared equal to nothing): a map observed for the first time between snapshot and count reports every
+    voxel, a second identical pass none, and an insert the whole grid (on both the tag-carrying and the clean words)."""
+    import fiesta_amd
+    n = 32
+    m = fiesta_amd.ESDFMap((0, 0, 0), 0.1, (n * 0.1,) * 3)
+    m.SetParameters(*P_DEFAULT)
+    m.snapshot_save(0)
+    m.SetOccupancyBox((0, 0, 0), (n - 1,) * 3, 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    assert m.snapshot_count_updated(0) == n ** 3        # -10000 -> +10000 on every voxel
+    m.snapshot_save(0)
+    m.SetOccupancyBox((0, 0, 0), (n - 1,) * 3, 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    assert m.snapshot_count_updated(0) == 0
+    for _ in range(5):   # (observed free twice: the log-odds need more than three hits now, SURVEY.md 7.3-H)
+        m.SetOccupancy(np.array([[5, 6, 7]], np.int32), 1)
+        m.UpdateOccupancy(True)
+    st = m.UpdateESDF()
+    assert st["inserted"] == 1
+    assert m.snapshot_count_updated(0) == n ** 3
+    m.close()

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Engine diagnostics: runs the C2 scatter insert and one steady-state step on a G^3 grid and prints the
 UpdateESDF counters (rounds, tile visits, levels, writes, per-phase cycles with FIESTA_HIP_PROF=1).
-With --compare TS the same workload runs on a second engine variant and the d^2 fields are compared.
-    FIESTA_HIP_PROF=1 python tools/prof_update.py --grid 512 --tile-shape 0 --compare 1
+With --compare E the same workload runs on a second engine (update_engine: 0 auto, 1 frontier rounds, 2 bulk transform) and the d^2 fields are compared.
+    FIESTA_HIP_PROF=1 python tools/prof_update.py --grid 512 --engine 1 --compare 2
 """
 import argparse
 import os
@@ -51,7 +51,7 @@ def run(G, n_obs, ts, hash_mode=False):
             out[f"steady{k}"] = st
         m.close()
         return out, None, None
-    m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, tile_shape=ts)
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, update_engine=ts)
     m.SetParameters(*P_DEFAULT)
     m.SetOriginalRange()
     for x0 in range(0, G, 64):
@@ -103,14 +103,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--obstacles", type=int, default=None)
-    ap.add_argument("--tile-shape", type=int, default=0)
+    ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--compare", type=int, default=None)
     ap.add_argument("--hash", action="store_true", help="run the workload on the paged hash-block map")
     a = ap.parse_args()
     n_obs = a.obstacles or int(round(50000 * (a.grid / 512) ** 3))
-    o1, d1, occ1 = run(a.grid, n_obs, a.tile_shape, a.hash)
+    o1, d1, occ1 = run(a.grid, n_obs, a.engine, a.hash)
     for k, st in o1.items():
-        show(f"ts{a.tile_shape}:{k}", st)
+        show(f"ts{a.engine}:{k}", st)
     if a.compare is not None:
         o2, d2, occ2 = run(a.grid, n_obs, a.compare)
         for k, st in o2.items():
@@ -126,7 +126,7 @@ def main():
             for i in idx[:20]:
                 v = np.array([i // (G * G), (i // G) % G, i % G])
                 exact = int(((O - v) ** 2).sum(-1).min())
-                print(f"  voxel {tuple(v)}: ts{a.tile_shape} d2={d1[i]} ts{a.compare} d2={d2[i]} exact EDT d2={exact}")
+                print(f"  voxel {tuple(v)}: ts{a.engine} d2={d1[i]} ts{a.compare} d2={d2[i]} exact EDT d2={exact}")
         sys.exit(1 if bad else 0)
 
 
