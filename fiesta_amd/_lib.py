@@ -108,6 +108,8 @@ def load():
         "fiesta_hip_grid_size": (C.c_int, [vp, vp]),
         "fiesta_hip_grid_total_size": (C.c_int, [vp, vp]),
         "fiesta_hip_voxel_key": (C.c_int, [vp, vp, C.c_int64, vp]),
+        "fiesta_hip_hash_window": (C.c_int, [vp, vp, vp]),
+        "fiesta_hip_hash_recentre": (C.c_int, [vp, vp]),
         "fiesta_hip_rccl_unique_id": (C.c_int, [vp]),
         "fiesta_hip_shard_box": (C.c_int, [vp, C.c_int32, C.c_int32, vp, vp]),
         "fiesta_hip_shard_group_create": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),

@@ -135,6 +135,22 @@ int fiesta_hip_voxel_key(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32
   });
 }
 
+int fiesta_hip_hash_window(fiesta_hip_map *m, int32_t origin[3], int64_t *moves) {
+  return guarded([&] {
+    need(m && origin, "null argument");
+    need(m->hash != nullptr, "fiesta_hip_hash_window: not a hash-block map");
+    m->hash->window_origin(origin);
+    if (moves) *moves = m->hash->window_moves();
+  });
+}
+int fiesta_hip_hash_recentre(fiesta_hip_map *m, const int32_t centre[3]) {
+  return guarded([&] {
+    need(m && centre, "null argument");
+    need(m->hash != nullptr, "fiesta_hip_hash_recentre: not a hash-block map");
+    m->hash->recentre(centre);
+  });
+}
+
 int fiesta_hip_set_prob_params(fiesta_hip_map *m, double p_hit, double p_miss, double p_min, double p_max,
                                double p_occ) {
   return guarded([&] {

@@ -41,6 +41,26 @@ __device__ inline void vcoords(const int32_t *page_tile, uint32_t addr, int &x, 
   z = (t % kNTZ) * 32 + (off & 31);
 }
 __device__ inline bool hbit(const uint32_t *bits, int64_t addr) { return (bits[addr >> 5] >> (addr & 31)) & 1u; }
+// The window MOVES (HashMap::ensure_window): window voxel (0,0,0) is map voxel (g.gx0, g.gy0, g.gz0), a multiple of the
+// tile size.  Closest-obstacle ids are therefore stored as MAP coordinates modulo 1024 and decoded relative to the voxel
+// that holds them (common.hpp: coc_offset with wrap; reach 512 voxels) -- they stay valid when the window moves.
+__device__ inline vox_t h_pack(const Geom &g, int x, int y, int z) { return pack_coc(x + g.gx0, y + g.gy0, z + g.gz0); }
+__device__ inline int32_t h_dist2(const Geom &g, int x, int y, int z, vox_t w) {
+  return dist2(1, x + g.gx0, y + g.gy0, z + g.gz0, w);
+}
+// window coordinates of the obstacle named by the id held at window voxel (x, y, z) (may lie outside the window)
+__device__ inline void h_obstacle(const Geom &g, int x, int y, int z, vox_t w, int &cx, int &cy, int &cz) {
+  int dx, dy, dz;
+  coc_offset(1, x + g.gx0, y + g.gy0, z + g.gz0, w, dx, dy, dz);
+  cx = x - dx, cy = y - dy, cz = z - dz;
+}
+__device__ inline bool h_alive(const Geom &g, const int32_t *dir, const uint32_t *occbits, int x, int y, int z, vox_t w) {
+  int cx, cy, cz;
+  h_obstacle(g, x, y, z, w, cx, cy, cz);
+  if (!in_win(cx, cy, cz)) return false;  // (its page left the window with it)
+  const int64_t ca = vaddr(dir, cx, cy, cz);
+  return ca >= 0 && hbit(occbits, ca);
+}
 
 // one thread per element unless the caller names a cap (= the kernel strides over the grid): the default must cover the
 // largest arrays (a 1024^3 shard touches 10^9 voxels at once -- a cap of 2^20 blocks silently dropped three quarters
@@ -57,15 +77,15 @@ __global__ void k_h_fill(T *p, T v, int64_t n) {
 
 // ---- page allocation: mark the tiles a batch touches, collect the unallocated ones, assign fresh pages ----
 __device__ inline bool obs_vox(const Geom &g, const int32_t *vox, int64_t i, int &x, int &y, int &z) {
-  x = vox[3 * i] + kHalf, y = vox[3 * i + 1] + kHalf, z = vox[3 * i + 2] + kHalf;
+  x = vox[3 * i] - g.gx0, y = vox[3 * i + 1] - g.gy0, z = vox[3 * i + 2] - g.gz0;
   return in_win(x, y, z) && g.in_window(x, y, z);  // VoxInRange (src/ESDFMap.cpp:420)
 }
 __device__ inline bool obs_pos(const Geom &g, const double *pos, const int32_t *occ, int64_t i, int &x, int &y, int &z) {
   const int o = occ[i];
   if (o != 0 && o != 1) return false;  // "occ value error!" (:402-405); PosInMap is always true here (:46-48)
-  x = (int)floor((pos[3 * i] - g.org[0]) / g.res) + kHalf;  // Pos2Vox (:74-77)
-  y = (int)floor((pos[3 * i + 1] - g.org[1]) / g.res) + kHalf;
-  z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) + kHalf;
+  x = (int)floor((pos[3 * i] - g.org[0]) / g.res) - g.gx0;  // Pos2Vox (:74-77)
+  y = (int)floor((pos[3 * i + 1] - g.org[1]) / g.res) - g.gy0;
+  z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) - g.gz0;
   return in_win(x, y, z) && g.in_window(x, y, z);
 }
 __global__ void k_h_mark_vox(Geom g, const int32_t *vox, int64_t n, uint32_t *need) {
@@ -84,11 +104,44 @@ __global__ void k_h_collect(uint32_t *need, const int32_t *dir, uint32_t *fresh,
   need[t] = 0u;
   if (dir[t] < 0) fresh[atomicAdd(count, 1ull)] = (uint32_t)t;
 }
-__global__ void k_h_assign(const uint32_t *fresh, int64_t k, int32_t first_page, int32_t *dir, int32_t *page_tile) {
+__global__ void k_h_assign(Geom g, const uint32_t *fresh, int64_t k, int32_t first_page, int32_t *dir, int32_t *page_tile,
+                           int32_t *page_gtile) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= k) return;
-  dir[fresh[i]] = first_page + (int32_t)i;
-  page_tile[first_page + i] = (int32_t)fresh[i];
+  const int t = (int)fresh[i], page = first_page + (int32_t)i;
+  dir[t] = page;
+  page_tile[page] = t;
+  page_gtile[3 * page] = (g.gx0 >> 4) + t / (kNTY * kNTZ);  // (the window origin is a whole number of tiles)
+  page_gtile[3 * page + 1] = (g.gy0 >> 4) + (t / kNTZ) % kNTY;
+  page_gtile[3 * page + 2] = (g.gz0 >> 5) + t % kNTZ;
+}
+// The window moved to g's origin: rebuild the directory (cleared by the caller) from the pages' map tiles.  A page
+// outside the new window is parked (page_tile -1); one that comes back is marked fresh for k_h_invalidate.
+__global__ void k_h_rebuild(Geom g, int64_t npages, const int32_t *page_gtile, int32_t *dir, int32_t *page_tile,
+                            uint32_t *page_fresh) {
+  const int64_t page = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (page >= npages) return;
+  const int tx = page_gtile[3 * page] - (g.gx0 >> 4), ty = page_gtile[3 * page + 1] - (g.gy0 >> 4),
+            tz = page_gtile[3 * page + 2] - (g.gz0 >> 5);
+  const bool in = (unsigned)tx < (unsigned)(kWin / 16) && (unsigned)ty < (unsigned)kNTY && (unsigned)tz < (unsigned)kNTZ;
+  if (in) {
+    const int t = (tx * kNTY + ty) * kNTZ + tz;
+    dir[t] = (int32_t)page;
+    if (page_tile[page] < 0) page_fresh[page] = 1u;
+    page_tile[page] = t;
+  } else {
+    page_tile[page] = -1;
+  }
+}
+// bounding box of a device-resident batch of voxels (min xyz, max xyz), for ensure_window
+__global__ void k_h_bbox(const int32_t *vox, int64_t n, int32_t *box) {
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    for (int k = 0; k < 3; ++k) lo[k] = min(lo[k], vox[3 * i + k]), hi[k] = max(hi[k], vox[3 * i + k]);
+  for (int k = 0; k < 3; ++k) {
+    for (int off = 32; off; off >>= 1) lo[k] = min(lo[k], __shfl_xor(lo[k], off)), hi[k] = max(hi[k], __shfl_xor(hi[k], off));
+    if ((threadIdx.x & 63) == 0 && lo[k] <= hi[k]) atomicMin(&box[k], lo[k]), atomicMax(&box[3 + k], hi[k]);
+  }
 }
 
 // ---- SetOccupancy (src/ESDFMap.cpp:401-437) ----
@@ -167,24 +220,21 @@ __global__ __launch_bounds__(1024) void k_h_observe_box(Geom g, const int32_t *d
 
 // "updated voxel" as SURVEY.md 8d defines it (d^2 differs, or the old closest obstacle vanished), between a saved copy
 // of the pool's state words and now; pages allocated after the copy read as unobserved before.
-__global__ void k_h_count_updated(const int32_t *dir, const int32_t *page_tile, const vox_t *before, int64_t n_before,
+__global__ void k_h_count_updated(Geom g, const int32_t *dir, const int32_t *page_tile, const vox_t *before, int64_t n_before,
                                   const vox_t *now, int64_t n_now, const uint32_t *occbits, unsigned long long *out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned long long local = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_now; i += stride) {
-    const vox_t a = (i < n_before ? before[i] : kUnobserved) & ~kAct, b = now[i] & ~kAct;
-    if (a == b) continue;
+    vox_t a = i < n_before ? before[i] : kUnobserved, b = now[i];
+    if (a != kUnobserved) a &= ~kAct;
+    if (b != kUnobserved) b &= ~kAct;
+    if (a == b || page_tile[i / kPageVox] < 0) continue;  // (a page that left the window is no longer part of the map)
     int x, y, z;
     vcoords(page_tile, (uint32_t)i, x, y, z);
-    const int32_t da = (a == kUnobserved) ? -1 : ((a & kNoCoc) ? kD2Inf : dist2(x, y, z, a));
-    const int32_t db = (b == kUnobserved) ? -1 : ((b & kNoCoc) ? kD2Inf : dist2(x, y, z, b));
+    const int32_t da = (a == kUnobserved) ? -1 : ((a & kNoCoc) ? kD2Inf : h_dist2(g, x, y, z, a));
+    const int32_t db = (b == kUnobserved) ? -1 : ((b & kNoCoc) ? kD2Inf : h_dist2(g, x, y, z, b));
     bool upd = da != db;
-    if (!upd && !(a & kNoCoc)) {
-      int cx, cy, cz;
-      unpack_coc(a, cx, cy, cz);
-      const int64_t ca = vaddr(dir, cx, cy, cz);
-      upd = ca < 0 || !hbit(occbits, ca);
-    }
+    if (!upd && !(a & kNoCoc)) upd = !h_alive(g, dir, occbits, x, y, z, a);
     local += upd;
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
@@ -206,7 +256,7 @@ __global__ void k_h_fuse(Geom g, ProbParams pp, int global_map, const int32_t *p
   const bool was = L > pp.l_occ;
   if (coc[a] == kUnobserved) coc[a] = kInf;
   if ((step >= 0 && L >= pp.l_max) || (step <= 0 && L <= pp.l_min)) return;
-  if (!global_map) {
+  if (!global_map && page_tile[a / kPageVox] >= 0) {  // (a page parked since the observation fuses like a global map's)
     int x, y, z;
     vcoords(page_tile, a, x, y, z);
     if (!g.in_prev_window(x, y, z)) {
@@ -228,18 +278,19 @@ __global__ void k_h_fuse(Geom g, ProbParams pp, int global_map, const int32_t *p
 }
 
 // ---- UpdateESDF seeding (src/ESDFMap.cpp:278-337) ----
-__global__ void k_h_seed_insert(const int32_t *page_tile, const uint32_t *ins, int64_t n, vox_t *coc,
+__global__ void k_h_seed_insert(Geom g, const int32_t *page_tile, const uint32_t *ins, int64_t n, vox_t *coc,
                                 const uint32_t *occbits, uint32_t *flag, uint32_t *list, unsigned long long *count) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t a = ins[i];
-  if (!hbit(occbits, a)) return;
+  if (!hbit(occbits, a) || page_tile[a / kPageVox] < 0) return;
   int x, y, z;
   vcoords(page_tile, a, x, y, z);
-  coc[a] = pack_coc(x, y, z) | kAct;
+  coc[a] = h_pack(g, x, y, z) | kAct;
   activate_tile((uint32_t)page_tile[a / kPageVox], flag, list, count);
 }
-__global__ __launch_bounds__(256) void k_h_invalidate(const int32_t *dir, const int32_t *page_tile, int64_t nvox, vox_t *coc,
+__global__ __launch_bounds__(256) void k_h_invalidate(Geom g, const int32_t *dir, const int32_t *page_tile,
+                                                      const uint32_t *page_fresh, int64_t nvox, vox_t *coc,
                                                       const uint32_t *occbits, uint32_t *flag, uint32_t *list,
                                                       unsigned long long *count, unsigned long long *counters) {
   const int lane = threadIdx.x & 63;
@@ -248,11 +299,24 @@ __global__ __launch_bounds__(256) void k_h_invalidate(const int32_t *dir, const 
     const int64_t a = base + lane;  // 64 consecutive pool words = two z-rows of one page
     bool reset = false;
     const vox_t w = coc[a];
-    if (!(w & kNoCoc)) {
-      int cx, cy, cz;
-      unpack_coc(w, cx, cy, cz);
-      const int64_t ca = vaddr(dir, cx, cy, cz);
-      if (ca < 0 || !hbit(occbits, ca)) {
+    const int32_t tile = page_tile[a / kPageVox];  // (wave-uniform; < 0: the page left the window)
+    if (tile >= 0 && page_fresh[a / kPageVox]) {
+      // a page that was parked missed every update meanwhile: rebuild it -- its obstacles are seeds again, every other
+      // observed voxel asks its neighbours
+      if (w != kUnobserved) {
+        vox_t nw = kReset;
+        if (hbit(occbits, a)) {
+          int x, y, z;
+          vcoords(page_tile, (uint32_t)a, x, y, z);
+          nw = h_pack(g, x, y, z) | kAct;
+        }
+        coc[a] = nw;
+        reset = true;
+      }
+    } else if (tile >= 0 && !(w & kNoCoc)) {
+      int x, y, z;
+      vcoords(page_tile, (uint32_t)a, x, y, z);
+      if (!h_alive(g, dir, occbits, x, y, z, w & ~kAct)) {
         coc[a] = kReset;
         reset = true;
       }
@@ -260,7 +324,7 @@ __global__ __launch_bounds__(256) void k_h_invalidate(const int32_t *dir, const 
     const unsigned long long m = __ballot(reset);
     if (m && lane == 0) {
       local += __popcll(m);
-      const uint32_t t = (uint32_t)page_tile[a / kPageVox];
+      const uint32_t t = (uint32_t)tile;
       if (flag[t] == 0u) activate_tile(t, flag, list, count);
     }
   }
@@ -279,7 +343,7 @@ __device__ inline double h_distance(const Geom &g, const int32_t *dir, const vox
   if (a < 0) return (double)FIESTA_HIP_INFINITY;
   const vox_t w = coc[a] & ~kAct;
   if (w & kNoCoc) return (double)FIESTA_HIP_INFINITY;
-  return sqrt((double)dist2(x, y, z, w)) * g.res;
+  return sqrt((double)h_dist2(g, x, y, z, w)) * g.res;
 }
 __global__ void k_h_query_dist(Geom g, const int32_t *dir, const vox_t *coc, const int32_t *vox, const double *pos,
                                int64_t n, double *out) {
@@ -287,11 +351,11 @@ __global__ void k_h_query_dist(Geom g, const int32_t *dir, const vox_t *coc, con
   if (i >= n) return;
   int x, y, z;
   if (vox) {
-    x = vox[3 * i] + kHalf, y = vox[3 * i + 1] + kHalf, z = vox[3 * i + 2] + kHalf;
+    x = vox[3 * i] - g.gx0, y = vox[3 * i + 1] - g.gy0, z = vox[3 * i + 2] - g.gz0;
   } else {
-    x = (int)floor((pos[3 * i] - g.org[0]) / g.res) + kHalf;
-    y = (int)floor((pos[3 * i + 1] - g.org[1]) / g.res) + kHalf;
-    z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) + kHalf;
+    x = (int)floor((pos[3 * i] - g.org[0]) / g.res) - g.gx0;
+    y = (int)floor((pos[3 * i + 1] - g.org[1]) / g.res) - g.gy0;
+    z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) - g.gz0;
   }
   out[i] = h_distance(g, dir, coc, x, y, z);
 }
@@ -301,11 +365,11 @@ __global__ void k_h_query_occ(Geom g, const int32_t *dir, const uint32_t *occbit
   if (i >= n) return;
   int x, y, z;
   if (vox) {
-    x = vox[3 * i] + kHalf, y = vox[3 * i + 1] + kHalf, z = vox[3 * i + 2] + kHalf;
+    x = vox[3 * i] - g.gx0, y = vox[3 * i + 1] - g.gy0, z = vox[3 * i + 2] - g.gz0;
   } else {
-    x = (int)floor((pos[3 * i] - g.org[0]) / g.res) + kHalf;
-    y = (int)floor((pos[3 * i + 1] - g.org[1]) / g.res) + kHalf;
-    z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) + kHalf;
+    x = (int)floor((pos[3 * i] - g.org[0]) / g.res) - g.gx0;
+    y = (int)floor((pos[3 * i + 1] - g.org[1]) / g.res) - g.gy0;
+    z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) - g.gz0;
   }
   const int64_t a = in_win(x, y, z) ? vaddr(dir, x, y, z) : -1;
   out[i] = a < 0 ? 0 : (int)hbit(occbits, a);
@@ -327,7 +391,7 @@ __global__ void k_h_query_trilinear(Geom g, const int32_t *dir, const vox_t *coc
   double v[2][2][2];
   for (int ix = 0; ix < 2; ++ix)
     for (int iy = 0; iy < 2; ++iy)
-      for (int iz = 0; iz < 2; ++iz) v[ix][iy][iz] = h_distance(g, dir, coc, b[0] + ix + kHalf, b[1] + iy + kHalf, b[2] + iz + kHalf);
+      for (int iz = 0; iz < 2; ++iz) v[ix][iy][iz] = h_distance(g, dir, coc, b[0] + ix - g.gx0, b[1] + iy - g.gy0, b[2] + iz - g.gz0);
   const double v00 = (1 - f[0]) * v[0][0][0] + f[0] * v[1][0][0];
   const double v01 = (1 - f[0]) * v[0][0][1] + f[0] * v[1][0][1];
   const double v10 = (1 - f[0]) * v[0][1][0] + f[0] * v[1][1][0];
@@ -346,20 +410,20 @@ __global__ void k_h_query_trilinear(Geom g, const int32_t *dir, const vox_t *coc
   }
 }
 
-__global__ void k_h_export(const int32_t *page_tile, int64_t nvox, const vox_t *coc, const uint32_t *occbits, int32_t *vox,
+__global__ void k_h_export(const int32_t *page_gtile, int64_t nvox, const vox_t *coc, const uint32_t *occbits, int32_t *vox,
                            int32_t *d2, int32_t *cxyz, uint8_t *occ) {
+  // every page, resident or parked, in MAP coordinates (ids decode relative to their voxel: no window involved)
   for (int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; a < nvox; a += (int64_t)gridDim.x * blockDim.x) {
-    int x, y, z;
-    vcoords(page_tile, (uint32_t)a, x, y, z);
+    const int64_t page = a / kPageVox;
+    const int off = (int)(a % kPageVox);
+    const int x = page_gtile[3 * page] * 16 + (off >> 9), y = page_gtile[3 * page + 1] * 16 + ((off >> 5) & 15),
+              z = page_gtile[3 * page + 2] * 32 + (off & 31);
     const vox_t w = coc[a] & ((coc[a] == kUnobserved) ? 0xFFFFFFFFu : ~kAct);
-    if (vox) vox[3 * a] = x - kHalf, vox[3 * a + 1] = y - kHalf, vox[3 * a + 2] = z - kHalf;
-    if (d2) d2[a] = (w == kUnobserved) ? -1 : ((w & kNoCoc) ? kD2Inf : dist2(x, y, z, w));
+    if (vox) vox[3 * a] = x, vox[3 * a + 1] = y, vox[3 * a + 2] = z;
+    if (d2) d2[a] = (w == kUnobserved) ? -1 : ((w & kNoCoc) ? kD2Inf : dist2(1, x, y, z, w));
     if (cxyz) {
       int cx = FIESTA_HIP_UNDEFINED, cy = FIESTA_HIP_UNDEFINED, cz = FIESTA_HIP_UNDEFINED;
-      if (!(w & kNoCoc)) {
-        unpack_coc(w, cx, cy, cz);
-        cx -= kHalf, cy -= kHalf, cz -= kHalf;
-      }
+      if (!(w & kNoCoc)) unpack_coc(1, x, y, z, w, cx, cy, cz);
       cxyz[3 * a] = cx, cxyz[3 * a + 1] = cy, cxyz[3 * a + 2] = cz;
     }
     if (occ) occ[a] = hbit(occbits, a);
@@ -390,6 +454,8 @@ HashMap::HashMap(const fiesta_hip_config &cfg) {
   g.ox1 = g.oy1 = g.oz1 = kWin - 1;
   g.GX = g.GY = g.GZ = kWin;
   g.GZW = kWin / 32;
+  g.gx0 = g.gy0 = g.gz0 = -kHalf;  // the window starts centred on map voxel 0 and follows the observations (ensure_window)
+  g.wrap = 1;                      // ids are map coordinates modulo 1024, decoded relative to their voxel
   set_original_range();
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
 
@@ -451,6 +517,9 @@ void HashMap::ensure_pages(int64_t need_total) {
   grow_exact(cbits_[0], (size_t)cap * kPageRows, keep_r);
   grow_exact(cbits_[1], (size_t)cap * kPageRows, keep_r);
   grow_exact(page_tile_, (size_t)cap, keep_p);
+  grow_exact(page_gtile_, (size_t)cap * 3, keep_p * 3);
+  grow_exact(page_fresh_, (size_t)cap, keep_p);
+  FIESTA_HIP_CHECK(hipMemsetAsync(page_fresh_.p + keep_p, 0, (size_t)(cap - cap_pages_) * sizeof(uint32_t), stream_));
   const int64_t nv = (cap - cap_pages_) * kPageVox, nr = (cap - cap_pages_) * kPageRows;
   hipLaunchKernelGGL(k_h_fill<vox_t>, dim3(grid_for(nv, 256, 4096)), dim3(256), 0, stream_, coc_.p + keep_v, kUnobserved, nv);
   FIESTA_HIP_CHECK(hipGetLastError());
@@ -475,22 +544,89 @@ void HashMap::set_prob_params(double p_hit, double p_miss, double p_min, double 
   pp_ = ProbParams{logit(p_hit), logit(p_miss), logit(p_min), logit(p_max), logit(p_occ)};
 }
 void HashMap::set_original_range() {  // src/ESDFMap.cpp:813-817: +-10000 voxels, i.e. everything
-  Geom &g = g_;
-  g.wx0 = g.wy0 = g.wz0 = 0;
-  g.wx1 = g.wy1 = g.wz1 = kWin - 1;
-  g.px0 = g.py0 = g.pz0 = 0;
-  g.px1 = g.py1 = g.pz1 = kWin - 1;
+  for (int k = 0; k < 3; ++k) ur_[k] = pr_[k] = -(1ll << 40), ur_[3 + k] = pr_[3 + k] = 1ll << 40;
+  refresh_range();
 }
 void HashMap::set_update_range(const double *mn, const double *mx, bool new_vec) {  // :792-810 (no clamping to a map box)
+  const Geom &g = g_;
+  if (new_vec) memcpy(pr_, ur_, sizeof(pr_));
+  auto p2v = [&](double p, int i) {
+    const double v = std::floor((p - g.org[i]) / g.res);
+    return (int64_t)std::min(std::max(v, -1e12), 1e12);
+  };
+  for (int k = 0; k < 3; ++k) ur_[k] = p2v(mn[k], k), ur_[3 + k] = p2v(mx[k] - g.res / 2, k);
+  refresh_range();
+}
+// the update boxes in window coordinates (clamped one voxel outside the window: "everything on that side")
+void HashMap::refresh_range() {
   Geom &g = g_;
-  if (new_vec) {
-    g.px0 = g.wx0, g.py0 = g.wy0, g.pz0 = g.wz0;
-    g.px1 = g.wx1, g.py1 = g.wy1, g.pz1 = g.wz1;
+  const int o[3] = {g.gx0, g.gy0, g.gz0};
+  auto w = [&](int64_t v, int k) { return (int)std::min<int64_t>(std::max<int64_t>(v - o[k], -1), kWin); };
+  g.wx0 = w(ur_[0], 0), g.wy0 = w(ur_[1], 1), g.wz0 = w(ur_[2], 2);
+  g.wx1 = w(ur_[3], 0), g.wy1 = w(ur_[4], 1), g.wz1 = w(ur_[5], 2);
+  g.px0 = w(pr_[0], 0), g.py0 = w(pr_[1], 1), g.pz0 = w(pr_[2], 2);
+  g.px1 = w(pr_[3], 0), g.py1 = w(pr_[4], 1), g.pz1 = w(pr_[5], 2);
+}
+
+// ---- the moving window ----
+// A batch whose bounding box (map voxels, inclusive) does not fit the window recentres the window on it, on the axes
+// where it does not fit; a box wider than the window is centred and loses its far ends (counted as dropped).
+void HashMap::ensure_window(const int64_t lo[3], const int64_t hi[3]) {
+  const int32_t o[3] = {g_.gx0, g_.gy0, g_.gz0}, tile[3] = {kTX, kTY, kTZ};
+  int32_t n[3];
+  bool move = false;
+  for (int k = 0; k < 3; ++k) {
+    n[k] = o[k];
+    if (lo[k] > hi[k] || (lo[k] >= o[k] && hi[k] < (int64_t)o[k] + kWin)) continue;
+    int64_t c = lo[k] + (hi[k] - lo[k]) / 2 - kHalf;                  // origin that centres the box ...
+    c = (c >= 0 ? (c + tile[k] / 2) / tile[k] : -((-c + tile[k] / 2) / tile[k])) * tile[k];  // ... in whole tiles
+    c = std::min<int64_t>(std::max<int64_t>(c, -(1ll << 30)), (1ll << 30) - kWin);
+    n[k] = (int32_t)c;
+    move |= n[k] != o[k];
   }
-  auto p2v = [&](double p, int i) { return (int)std::floor((p - g.org[i]) / g.res) + kHalf; };
-  auto clampw = [](int v) { return std::min(std::max(v, -1), kWin); };
-  g.wx0 = clampw(p2v(mn[0], 0)), g.wy0 = clampw(p2v(mn[1], 1)), g.wz0 = clampw(p2v(mn[2], 2));
-  g.wx1 = clampw(p2v(mx[0] - g.res / 2, 0)), g.wy1 = clampw(p2v(mx[1] - g.res / 2, 1)), g.wz1 = clampw(p2v(mx[2] - g.res / 2, 2));
+  if (move) move_window(n);
+}
+void HashMap::recentre(const int32_t centre[3]) {
+  use_device();
+  const int32_t tile[3] = {kTX, kTY, kTZ};
+  int32_t n[3];
+  for (int k = 0; k < 3; ++k) {
+    const int64_t c = (int64_t)centre[k] - kHalf;
+    n[k] = (int32_t)((c >= 0 ? (c + tile[k] / 2) / tile[k] : -((-c + tile[k] / 2) / tile[k])) * tile[k]);
+  }
+  if (n[0] != g_.gx0 || n[1] != g_.gy0 || n[2] != g_.gz0) move_window(n);
+}
+void HashMap::move_window(const int32_t origin[3]) {
+  g_.gx0 = origin[0], g_.gy0 = origin[1], g_.gz0 = origin[2];
+  refresh_range();
+  FIESTA_HIP_CHECK(hipMemsetAsync(dir_, 0xFF, kNTiles * sizeof(int32_t), stream_));
+  // everything indexed by window tile is between updates here: no list is live, stamps restart (epoch_/serial_ only grow)
+  for (uint32_t *p : {need_, tile_epoch_, cstamp_[0], cstamp_[1], tile_flag_[0], tile_flag_[1]})
+    FIESTA_HIP_CHECK(hipMemsetAsync(p, 0, kNTiles * sizeof(uint32_t), stream_));
+  if (npages_)
+    hipLaunchKernelGGL(k_h_rebuild, dim3(grid_for(npages_)), dim3(256), 0, stream_, g_, npages_, (const int32_t *)page_gtile_.p,
+                       dir_, page_tile_.p, page_fresh_.p);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  force_scan_ = true;
+  ++moves_;
+}
+void HashMap::ensure_window_vox(const int32_t *vox, int64_t n, bool dev) {
+  int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+  if (!dev) {
+    for (int64_t i = 0; i < n; ++i)
+      for (int k = 0; k < 3; ++k) lo[k] = std::min<int64_t>(lo[k], vox[3 * i + k]), hi[k] = std::max<int64_t>(hi[k], vox[3 * i + k]);
+  } else {
+    stage_c_.ensure(6 * sizeof(int32_t), stream_);
+    const int32_t init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+    int32_t box[6];
+    FIESTA_HIP_CHECK(hipMemcpyAsync(stage_c_.p, init, sizeof(init), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(k_h_bbox, dim3(grid_for(n, 256, 1024)), dim3(256), 0, stream_, vox, n, (int32_t *)stage_c_.p);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    FIESTA_HIP_CHECK(hipMemcpyAsync(box, stage_c_.p, sizeof(box), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int k = 0; k < 3; ++k) lo[k] = box[k], hi[k] = box[3 + k];
+  }
+  ensure_window(lo, hi);
 }
 
 // Assign pages to every marked tile that has none yet.
@@ -503,8 +639,8 @@ void HashMap::allocate_marked() {
   const int64_t k = (int64_t)read_counter(C_SCRATCH);
   if (k == 0) return;
   ensure_pages(npages_ + k);
-  hipLaunchKernelGGL(k_h_assign, dim3(grid_for(k)), dim3(256), 0, stream_, (const uint32_t *)stage_d_.p, k, (int32_t)npages_, dir_,
-                     page_tile_.p);
+  hipLaunchKernelGGL(k_h_assign, dim3(grid_for(k)), dim3(256), 0, stream_, g_, (const uint32_t *)stage_d_.p, k, (int32_t)npages_,
+                     dir_, page_tile_.p, page_gtile_.p);
   FIESTA_HIP_CHECK(hipGetLastError());
   npages_ += k;
 }
@@ -521,6 +657,7 @@ void HashMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int
     dvox = (const int32_t *)stage_a_.p;
     docc = (const int32_t *)stage_b_.p;
   }
+  ensure_window_vox(dev ? dvox : vox, n, dev);
   hipLaunchKernelGGL(k_h_mark_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, dvox, n, need_);
   allocate_marked();
   touched_upper_ = std::min<int64_t>(npages_ * kPageVox, touched_upper_ + n);
@@ -537,12 +674,17 @@ void HashMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int
 
 void HashMap::observe_box(const int32_t *lo, const int32_t *hi, int occ) {
   use_device();
-  // clip to the virtual window (SetOccupancy outside the map is rejected, src/ESDFMap.cpp:406-410), window coordinates
+  {
+    const int64_t l[3] = {lo[0], lo[1], lo[2]}, h[3] = {hi[0], hi[1], hi[2]};
+    ensure_window(l, h);
+  }
+  // clip to the window (window coordinates); a box wider than the window loses its ends
+  const int32_t o[3] = {g_.gx0, g_.gy0, g_.gz0};
   int a[3], b[3];
   int64_t asked = 1, kept = 1;
   for (int k = 0; k < 3; ++k) {
-    a[k] = std::max(lo[k] + kHalf, 0);
-    b[k] = std::min(hi[k] + kHalf, kWin - 1);
+    a[k] = (int)std::max<int64_t>((int64_t)lo[k] - o[k], 0);
+    b[k] = (int)std::min<int64_t>((int64_t)hi[k] - o[k], kWin - 1);
     asked *= std::max<int64_t>(0, (int64_t)hi[k] - lo[k] + 1);
     kept *= std::max<int64_t>(0, (int64_t)b[k] - a[k] + 1);
   }
@@ -576,7 +718,7 @@ int64_t HashMap::snapshot_count_updated() {
   zero_counter(C_SCRATCH);
   const int64_t n_now = npages_ * kPageVox;
   if (n_now)
-    hipLaunchKernelGGL(k_h_count_updated, dim3(grid_for(n_now, 256, 8192)), dim3(256), 0, stream_, (const int32_t *)dir_,
+    hipLaunchKernelGGL(k_h_count_updated, dim3(grid_for(n_now, 256, 8192)), dim3(256), 0, stream_, g_, (const int32_t *)dir_,
                        (const int32_t *)page_tile_.p, (const vox_t *)shadow_.p, shadow_vox_, (const vox_t *)coc_.p, n_now,
                        (const uint32_t *)occbits_.p, &counters_[C_SCRATCH]);
   FIESTA_HIP_CHECK(hipGetLastError());
@@ -586,6 +728,18 @@ int64_t HashMap::snapshot_count_updated() {
 void HashMap::observe_pos(const double *pos, const int32_t *occ, int64_t n, int32_t *ret) {
   use_device();
   if (n <= 0) return;
+  {
+    int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+    for (int64_t i = 0; i < n; ++i) {
+      if (occ[i] != 0 && occ[i] != 1) continue;
+      double v[3];
+      bool sane = true;
+      for (int k = 0; k < 3; ++k) v[k] = std::floor((pos[3 * i + k] - g_.org[k]) / g_.res), sane &= std::fabs(v[k]) < 1e9;
+      if (!sane) continue;  // (NaN / far-away garbage never moves the window; the kernel drops it)
+      for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], (int64_t)v[k]), hi[k] = std::max(hi[k], (int64_t)v[k]);
+    }
+    ensure_window(lo, hi);
+  }
   stage_a_.ensure(n * 3 * sizeof(double), stream_);
   stage_b_.ensure(n * sizeof(int32_t), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -601,10 +755,10 @@ void HashMap::observe_pos(const double *pos, const int32_t *occ, int64_t n, int3
   if (ret) {
     for (int64_t i = 0; i < n; ++i) {
       const double *p = pos + 3 * i;
-      const int x = (int)std::floor((p[0] - g_.org[0]) / g_.res) + kHalf, y = (int)std::floor((p[1] - g_.org[1]) / g_.res) + kHalf,
-                z = (int)std::floor((p[2] - g_.org[2]) / g_.res) + kHalf;
-      const bool ok = (occ[i] == 0 || occ[i] == 1) && (unsigned)x < (unsigned)kWin && (unsigned)y < (unsigned)kWin && (unsigned)z < (unsigned)kWin;
-      ret[i] = ok ? (int32_t)pack_coc(x, y, z) : FIESTA_HIP_UNDEFINED;
+      const bool ok = occ[i] == 0 || occ[i] == 1;
+      ret[i] = ok ? voxel_key((int)std::floor((p[0] - g_.org[0]) / g_.res), (int)std::floor((p[1] - g_.org[1]) / g_.res),
+                              (int)std::floor((p[2] - g_.org[2]) / g_.res))
+                  : FIESTA_HIP_UNDEFINED;
     }
   }
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -721,22 +875,24 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
     st->deleted = (int64_t)nd;
     st->dropped_observations = (int64_t)h_counters_[C_DROPPED] + dropped_host_;
   }
-  if (ni || nd) {
+  if (ni || nd || force_scan_) {
     ++epoch_;
     FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INVALIDATED], 0, (C_COUNT - C_INVALIDATED) * sizeof(unsigned long long), stream_));
     zero_counter(C_LIST0);
     if (ni) {
-      hipLaunchKernelGGL(k_h_seed_insert, dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, (const int32_t *)page_tile_.p,
+      hipLaunchKernelGGL(k_h_seed_insert, dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, g_, (const int32_t *)page_tile_.p,
                          (const uint32_t *)ins_.p, (int64_t)ni, coc_.p, (const uint32_t *)occbits_.p, tile_flag_[0], tile_list_[0],
                          &counters_[C_LIST0]);
       FIESTA_HIP_CHECK(hipGetLastError());
     }
-    if (nd) {
+    if (nd || force_scan_) {  // (a window move: obstacles left the window, parked pages came back)
       const int64_t nvox = npages_ * kPageVox;
-      hipLaunchKernelGGL(k_h_invalidate, dim3(grid_for(nvox / 16 + 1, 256, 16384)), dim3(256), 0, stream_, (const int32_t *)dir_,
-                         (const int32_t *)page_tile_.p, nvox, coc_.p, (const uint32_t *)occbits_.p, tile_flag_[0], tile_list_[0],
+      hipLaunchKernelGGL(k_h_invalidate, dim3(grid_for(nvox / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, (const int32_t *)dir_,
+                         (const int32_t *)page_tile_.p, (const uint32_t *)page_fresh_.p, nvox, coc_.p, (const uint32_t *)occbits_.p, tile_flag_[0], tile_list_[0],
                          &counters_[C_LIST0], counters_);
       FIESTA_HIP_CHECK(hipGetLastError());
+      if (force_scan_) FIESTA_HIP_CHECK(hipMemsetAsync(page_fresh_.p, 0, (size_t)npages_ * sizeof(uint32_t), stream_));
+      force_scan_ = false;
     }
     zero_counter(C_INSERT);
     zero_counter(C_DELETE);
@@ -825,7 +981,7 @@ int64_t HashMap::download(int32_t *vox, int32_t *d2, int32_t *coc, uint8_t *occ)
   if (coc) stage_b_.ensure(n * 3 * sizeof(int32_t), stream_), dc = (int32_t *)stage_b_.p;
   if (d2) stage_c_.ensure(n * sizeof(int32_t), stream_), dd = (int32_t *)stage_c_.p;
   if (occ) stage_d_.ensure(std::max<size_t>((size_t)n, (size_t)kNTiles * 4), stream_), doc = (uint8_t *)stage_d_.p;
-  hipLaunchKernelGGL(k_h_export, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream_, (const int32_t *)page_tile_.p, n,
+  hipLaunchKernelGGL(k_h_export, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream_, (const int32_t *)page_gtile_.p, n,
                      (const vox_t *)coc_.p, (const uint32_t *)occbits_.p, dv, dd, dc, doc);
   FIESTA_HIP_CHECK(hipGetLastError());
   if (vox) FIESTA_HIP_CHECK(hipMemcpyAsync(vox, dv, n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));

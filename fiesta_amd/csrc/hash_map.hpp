@@ -4,12 +4,20 @@
 // The reference keeps `unordered_map<blockId, base index>` over 8^3-voxel blocks appended to growing vectors
 // (FindAndInsert, :732-765; capacity doubles, :705-730). The GPU equivalent here is a PAGE POOL behind a dense
 // PAGE DIRECTORY: a page is one relaxation tile (16 x 16 x 32 voxels, z fastest -- 32 KiB of 4-byte words, 256
-// whole bitmap words), the directory is a flat array over the 64 x 64 x 32 tiles of a 1024^3-voxel virtual
-// window centred on the map origin (512 KiB), so a lookup is one load, never a probe chain, and the relaxation
-// kernel only swaps its address arithmetic (k_relax_q<.., PAGED>). Memory stays proportional to the observed
-// space; the pool doubles when it runs out (like IncreaseCapacity). Pages are allocated when a voxel in them is
-// OBSERVED; the reference additionally allocates the blocks its neighbour READS touch (they stay unobserved
-// forever and never influence a distance) -- see DESIGN.md.
+// whole bitmap words), the directory is a flat array over the 64 x 64 x 32 tiles of a 1024^3-voxel WINDOW (512 KiB),
+// so a lookup is one load, never a probe chain, and the relaxation kernel only swaps its address arithmetic
+// (k_relax_q<.., PAGED>). Memory stays proportional to the observed space; the pool doubles when it runs out (like
+// IncreaseCapacity). Pages are allocated when a voxel in them is OBSERVED; the reference additionally allocates the
+// blocks its neighbour READS touch (they stay unobserved forever and never influence a distance) -- see DESIGN.md.
+//
+// The map itself is UNBOUNDED like the reference's (any int voxel coordinate): the window MOVES.  It starts centred on
+// the map origin; an observation batch (or ray-cast frame) whose bounding box does not fit the current window recentres
+// it, per axis, on that box (ensure_window).  Pages whose tile leaves the window are PARKED: they keep their content and
+// their place in the pool and in download(), but take no part in queries, observations or UpdateESDF while parked; when
+// the window comes back over them they are re-attached and their distance field is rebuilt from the obstacles in and
+// around them at the next UpdateESDF (like voxels behind a deleted obstacle).  Inside the window the field is the ESDF
+// of the obstacles INSIDE THE WINDOW.  Closest-obstacle ids are map coordinates modulo 1024 decoded relative to their
+// voxel (common.hpp), so they never change when the window moves.
 #pragma once
 #include "../../include/fiesta_hip.h"
 #include "common.hpp"
@@ -19,18 +27,19 @@ namespace fiesta {
 
 class HashMap {
  public:
-  static constexpr int kWin = 1024, kHalf = 512;   // virtual window, voxels per axis / offset of voxel 0
+  static constexpr int kWin = 1024, kHalf = 512;   // window, voxels per axis / half of it (initial offset of map voxel 0)
   static constexpr int kTX = 16, kTY = 16, kTZ = 32;
   static constexpr int kNTX = kWin / kTX, kNTY = kWin / kTY, kNTZ = kWin / kTZ;
   static constexpr int kNTiles = kNTX * kNTY * kNTZ;
   static constexpr int kPageVox = kTX * kTY * kTZ, kPageRows = kTX * kTY;
 
-  // what SetOccupancy returns for a voxel: a key unique per voxel of the window, -10000 outside (see fiesta_hip_voxel_key)
-  static int32_t voxel_key(int vx, int vy, int vz) {
-    const int x = vx + kHalf, y = vy + kHalf, z = vz + kHalf;
-    const bool ok = (unsigned)x < (unsigned)kWin && (unsigned)y < (unsigned)kWin && (unsigned)z < (unsigned)kWin;
-    return ok ? (int32_t)pack_coc(x, y, z) : FIESTA_HIP_UNDEFINED;
-  }
+  // what SetOccupancy returns for a voxel: its map coordinates modulo 1024, packed -- unique among the voxels of any one
+  // window position (see fiesta_hip_voxel_key); never -10000: no voxel is outside an unbounded map
+  static int32_t voxel_key(int vx, int vy, int vz) { return (int32_t)pack_coc(vx, vy, vz); }
+  void window_origin(int32_t out[3]) const { out[0] = g_.gx0, out[1] = g_.gy0, out[2] = g_.gz0; }
+  int64_t window_moves() const { return moves_; }
+  // move the window so that map voxel `centre` is at its middle (rounded to whole tiles), whatever it holds now
+  void recentre(const int32_t centre[3]);
   explicit HashMap(const fiesta_hip_config &cfg);
   ~HashMap();
 
@@ -65,6 +74,10 @@ class HashMap {
 
  private:
   void use_device() const;
+  void ensure_window(const int64_t lo[3], const int64_t hi[3]);  // bounding box of a batch, map voxels, inclusive
+  void ensure_window_vox(const int32_t *vox, int64_t n, bool dev);
+  void move_window(const int32_t origin[3]);
+  void refresh_range();
   void ensure_pages(int64_t need_total);
   void allocate_marked();
   unsigned long long read_counter(int which);
@@ -74,7 +87,10 @@ class HashMap {
   struct RaycastState;
   RaycastState *rc_ = nullptr;
 
-  Geom g_;  // the virtual window as a "grid": nx = ny = nz = 1024, coordinates offset by kHalf
+  Geom g_;  // the window as a "grid": nx = ny = nz = 1024; (gx0, gy0, gz0) = map voxel of window voxel 0; wrap = 1
+  int64_t ur_[6], pr_[6];    // SetUpdateRange's current / previous box in MAP voxels (min xyz, max xyz); g_.w*/p* derive
+  bool force_scan_ = false;  // the window moved: the next UpdateESDF revalidates every resident voxel
+  int64_t moves_ = 0;
   ProbParams pp_{0, 0, 0, 0, 0};
   int device_ = 0;
   hipStream_t stream_ = nullptr;
@@ -86,7 +102,9 @@ class HashMap {
   DevBuf<double> logodds_;
   DevBuf<unsigned long long> cnt_;
   DevBuf<uint32_t> occbits_, rbits_, cbits_[2];
-  DevBuf<int32_t> page_tile_;
+  DevBuf<int32_t> page_tile_;   // window tile of a page, -1 while it is parked
+  DevBuf<int32_t> page_gtile_;  // 3 per page: its tile in MAP tile coordinates (voxel / (16, 16, 32)), never changes
+  DevBuf<uint32_t> page_fresh_; // 1: re-attached by the last window move, not yet rebuilt
   DevBuf<vox_t> shadow_;
   int64_t shadow_vox_ = -1;
   int64_t npages_ = 0, cap_pages_ = 0;

@@ -102,9 +102,9 @@ __device__ inline void count_observation(int64_t idx, int occ, unsigned long lon
   wave_append((uint32_t)old == 0, (uint32_t)idx, touched, &counters[C_TOUCHED]);
 }
 
-// ---- paged (hash-block) maps: window coordinates (map voxel + 512 per axis), pool address through the directory ----
+// ---- paged (hash-block) maps: window coordinates (map voxel - window origin g.gx0..), pool address through the directory ----
 namespace paged {
-constexpr int kWin = HashMap::kWin, kHalf = HashMap::kHalf, kNTY = HashMap::kNTY, kNTZ = HashMap::kNTZ, kPageVox = HashMap::kPageVox;
+constexpr int kWin = HashMap::kWin, kNTY = HashMap::kNTY, kNTZ = HashMap::kNTZ, kPageVox = HashMap::kPageVox;
 __device__ inline int tile_id(int x, int y, int z) { return ((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5); }
 __device__ inline bool in_win(int x, int y, int z) {
   return (unsigned)x < (unsigned)kWin && (unsigned)y < (unsigned)kWin && (unsigned)z < (unsigned)kWin;
@@ -146,8 +146,8 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
   // SetOccupancy(point, occ) (src/ESDFMap.cpp:401-437); every valid point counts its end point
   int eidx = -1;
   if (PAGED) {  // PosInMap is always true for the hash build (:46-48); the virtual window is the map
-    const int x = (int)floor((q[0] - g.org[0]) / g.res) + paged::kHalf, y = (int)floor((q[1] - g.org[1]) / g.res) + paged::kHalf,
-              z = (int)floor((q[2] - g.org[2]) / g.res) + paged::kHalf;
+    const int x = (int)floor((q[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((q[1] - g.org[1]) / g.res) - g.gy0,
+              z = (int)floor((q[2] - g.org[2]) / g.res) - g.gz0;
     if (paged::in_win(x, y, z)) {
       eidx = (int)(pack_coc(x, y, z) | ((uint32_t)occ << 30));
       need[paged::tile_id(x, y, z)] = 1u;
@@ -185,8 +185,8 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
       code = kCodeMinBreak;
     } else if (!(l2 > ra.maxr)) {
       if (PAGED) {
-        const int x = (int)floor((c[0] - g.org[0]) / g.res) + paged::kHalf, y = (int)floor((c[1] - g.org[1]) / g.res) + paged::kHalf,
-                  z = (int)floor((c[2] - g.org[2]) / g.res) + paged::kHalf;
+        const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
+                  z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
         if (paged::in_win(x, y, z)) {
           code = pack_coc(x, y, z) | (g.in_window(x, y, z) ? 0u : kCodeNoCount);
           need[paged::tile_id(x, y, z)] = 1u;
@@ -608,6 +608,17 @@ void HashMap::raycast_frame(const float *points, int64_t n, const double *T, con
   if (n <= 0) return;
   if (!rc_) rc_ = new RaycastState;
   RaycastState &rc = *rc_;
+  {  // everything a frame observes lies within max_ray_length of the sensor: keep that ball inside the window
+    const double reach = std::min(p->max_ray_length + 2 * g_.res, (kWin / 2 - 16) * g_.res);
+    int64_t lo[3], hi[3];
+    bool sane = reach > 0;
+    for (int k = 0; k < 3; ++k) {
+      const double a = std::floor((origin[k] - reach - g_.org[k]) / g_.res), b = std::floor((origin[k] + reach - g_.org[k]) / g_.res);
+      sane &= std::fabs(a) < 1e9 && std::fabs(b) < 1e9;
+      lo[k] = (int64_t)a, hi[k] = (int64_t)b;
+    }
+    if (sane) ensure_window(lo, hi);
+  }
   const int stride = ray_frame_buffers(rc, g_.res, n, p, stream_);
   const float *dpts = ray_points(rc, points, n, dev, stream_);
   const RayArgs ra = ray_args(T, origin, p);

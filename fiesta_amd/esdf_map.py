@@ -261,6 +261,18 @@ class ESDFMap:
         check(self._lib.fiesta_hip_download_hash(self._h, C.byref(n), _p(vox), _p(d2), _p(coc), _p(occ)))
         return {"vox": vox, "d2": d2, "coc": coc, "occ": occ}
 
+    def hash_window(self):
+        """Hash-block mode: (origin, moves) of the moving window -- map voxel of its lowest corner (it spans 1024 voxels per
+        axis) and how often it has moved (include/fiesta_hip.h, "the moving window")."""
+        org = np.zeros(3, np.int32)
+        moves = C.c_int64(0)
+        check(self._lib.fiesta_hip_hash_window(self._h, _p(org), C.byref(moves)))
+        return org, moves.value
+
+    def hash_recentre(self, centre_vox):
+        c = np.ascontiguousarray(centre_vox, np.int32).reshape(3)
+        check(self._lib.fiesta_hip_hash_recentre(self._h, _p(c)))
+
     def distance_from_d2(self, d2):
         """distance_buffer_ as the reference stores it: -10000 / +10000 sentinels, else sqrt(d2)*res."""
         d2 = np.asarray(d2)

@@ -77,9 +77,9 @@ typedef struct fiesta_hip_stats {
   int64_t ft_overflow[6];/* bulk path: column groups that outgrew the ring of pass A tiers 0-2, pass B tiers 0-2 */
   int64_t observed_voxels, occupied_voxels; /* map totals at entry (array mode): observed at least once / Exist() */
   int64_t ft_max_d2;     /* bulk path on a shard: largest squared distance written (decides whether the margin sufficed) */
-  int64_t dropped_observations; /* hash mode, cumulative: SetOccupancy calls (voxel, position or box form) that fell
-                                   outside the addressable window of +-512 voxels around the origin and were ignored --
-                                   the reference's hash build is unbounded, so a non-zero value means lost map data */
+  int64_t dropped_observations; /* hash mode, cumulative: observations that fell outside the window even after it moved
+                                   to their batch (a single batch or frame spanning more than 1024 voxels on an axis,
+                                   non-finite positions) and were ignored -- a non-zero value means lost map data */
 } fiesta_hip_stats;
 
 const char *fiesta_hip_last_error(void);
@@ -96,9 +96,23 @@ int fiesta_hip_grid_total_size(fiesta_hip_map *m, int64_t *out);
 /* What SetOccupancy(Vector3i) returns for each voxel WITHOUT observing it (host arithmetic only): the reference's
  * callers test the value against -10000 and use it as the per-frame de-duplication key (include/Fiesta.h:221-232,
  * 253-273), so it must identify the voxel.  Array mode: Vox2Idx = x*Ny*Nz + y*Nz + z (src/ESDFMap.cpp:84-93; no range
- * check, like the reference).  Hash mode: the reference returns an allocation-order slot number; here a packed key of
- * the voxel's window coordinates, unique per voxel, or FIESTA_HIP_UNDEFINED outside the addressable window. */
+ * check, like the reference).  Hash mode: the reference returns an allocation-order slot number; here the voxel's map
+ * coordinates modulo 1024, packed (30 bits, never negative): unique among the voxels of one window position, which is
+ * all a frame can observe. */
 int fiesta_hip_voxel_key(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32_t *out);
+
+/* ---- hash-block map: the moving window ----
+ * The hash-block map is unbounded like the reference's (src/ESDFMap.cpp:46-48: PosInMap/VoxInMap are always true); the
+ * part of it that queries, observations and UpdateESDF work on is a WINDOW of 1024^3 voxels that starts centred on map
+ * voxel (0,0,0) and FOLLOWS THE OBSERVATIONS: a SetOccupancy batch or ray-cast frame whose bounding box does not fit
+ * the window recentres it on that box (per axis, in whole tiles of 16 x 16 x 32 voxels).  Pages that leave the window
+ * are parked -- kept, listed by fiesta_hip_download_hash, not queried (they read "never observed") -- and rejoin, with
+ * their distance field rebuilt at the next UpdateESDF, when the window returns.  Inside the window the field is the
+ * ESDF of the obstacles inside the window (reach of a closest-obstacle id: 512 voxels).
+ *   fiesta_hip_hash_window    origin = map voxel of the window's lowest corner; moves (nullable) = moves so far
+ *   fiesta_hip_hash_recentre  move the window so that `centre` is at its middle (e.g. to query around a goal pose) */
+int fiesta_hip_hash_window(fiesta_hip_map *m, int32_t origin[3], int64_t *moves);
+int fiesta_hip_hash_recentre(fiesta_hip_map *m, const int32_t centre[3]);
 
 /* ---- parameters and window ---- */
 /* ESDFMap::SetParameters (src/ESDFMap.cpp:218-224). */

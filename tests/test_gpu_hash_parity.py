@@ -135,9 +135,17 @@ def test_hash_mode_errors_are_loud(hip_lib):
     import fiesta_amd
     m = fiesta_amd.ESDFMap((0, 0, 0), 0.1, reserve_size=0, mode="hash")
     m.SetParameters(*P_DEFAULT)
-    # outside the 1024^3 virtual window: rejected like an out-of-map position in array mode
-    assert m.SetOccupancy(np.array([[600, 0, 0]], np.int32), 1)[0] == -10000
+    # the map is unbounded (src/ESDFMap.cpp:46-48): a voxel outside the current window moves the window, nothing is lost
     assert m.SetOccupancy(np.array([[5, 5, 5]], np.int32), 1)[0] != -10000
+    assert m.SetOccupancy(np.array([[600, 0, 0]], np.int32), 1)[0] != -10000
+    org, moves = m.hash_window()
+    assert moves == 1 and org[0] <= 600 < org[0] + 1024 and org[0] % 16 == 0 and tuple(org[1:]) == (-512, -512)
+    m.UpdateOccupancy(True)
+    assert m.UpdateESDF()["dropped_observations"] == 0
+    # one batch wider than the window cannot be held at once: its far ends are dropped, and counted
+    m.SetOccupancy(np.array([[0, 0, 0], [0, 2000, 0]], np.int32), 1)
+    m.UpdateOccupancy(True)
+    assert m.UpdateESDF()["dropped_observations"] >= 1
     with pytest.raises(fiesta_amd.FiestaHipError):
         m.snapshot_restore(0)   # hash-mode maps keep one copy of the state words for the benchmark unit: no restore
     with pytest.raises(fiesta_amd.FiestaHipError):
@@ -194,3 +202,99 @@ def test_hash_c4_stream_box_observe(hip_lib, oracle_libs, best_oracle_kind):
     rep = compare(gpu, cpu)
     # frames 0..2 only observe (3 hits make an obstacle): frame 3 inserts the whole visible surface at once
     assert rep["finite"] > 500000 and rep["d2_mismatch"] <= 0.02 * rep["finite"], rep
+
+
+def _island(c, half, rng, n_obst):
+    lo = np.asarray(c) - half
+    box = np.stack(np.meshgrid(*[np.arange(2 * h) for h in half], indexing="ij"), -1).reshape(-1, 3).astype(np.int32) + lo
+    obst = (lo + np.stack([rng.randint(0, 2 * h, n_obst) for h in half], -1)).astype(np.int32)
+    return box.astype(np.int32), obst
+
+
+def test_hash_window_follows_a_travelling_sensor(hip_lib, oracle_libs, best_oracle_kind):
+    """The map is unbounded like the reference's: observed islands strung along 2400 voxels of travel (the window is 1024
+    wide and has to move several times; islands do not see each other through unobserved space, so every one of them --
+    resident or parked -- must equal the unbounded reference bit for bit), negative and positive coordinates."""
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.1, 1000)
+    rng = np.random.RandomState(12)
+    stations = [(-900 + 300 * k, 40 * k - 100, 10 * k) for k in range(9)]   # x from -900 to +1500
+    for c in stations:
+        box, obst = _island(c, (14, 14, 10), rng, 25)
+        cycles(gpu, cpu, [], box, 1)
+        cycles(gpu, cpu, obst, [], 3)
+        cycles(gpu, cpu, [], obst[:8], 6)       # some obstacles vanish again
+        org, moves = gpu.hash_window()
+        assert all(org[k] <= c[k] - 14 and c[k] + 14 <= org[k] + 1024 for k in range(3))
+    assert moves >= 2
+    rep = compare(gpu, cpu)
+    assert rep["d2_mismatch"] == 0 and rep["finite"] == len(stations) * 28 * 28 * 20, rep
+    # queries: resident voxels answer like the reference, parked ones read "never observed"
+    c = np.array(stations[-1], np.int32)
+    vox = (c + rng.randint(-16, 16, (400, 3))).astype(np.int32)
+    assert np.array_equal(gpu.GetDistance(vox), cpu.GetDistanceVox(vox))
+    pos = (c + rng.rand(300, 3) * 20 - 10) * 0.1
+    dg, gg = gpu.GetDistWithGradTrilinear(pos)
+    dc, gc = cpu.GetDistWithGradTrilinear(pos)
+    assert np.array_equal(dg, dc) and np.array_equal(gg, gc)
+    far = np.array([stations[0]], np.int32)
+    assert abs(gpu.GetDistance(far)[0]) == 10000.0 and abs(cpu.GetDistanceVox(far)[0]) != 10000.0
+    # ... until the window is brought back over them
+    gpu.hash_recentre(stations[0])
+    assert gpu.UpdateESDF()["dropped_observations"] == 0
+    vox = (np.array(stations[0], np.int32) + rng.randint(-14, 14, (400, 3))).astype(np.int32)
+    assert np.array_equal(gpu.GetDistance(vox), cpu.GetDistanceVox(vox))
+    rep = compare(gpu, cpu)
+    assert rep["d2_mismatch"] == 0, rep
+
+
+def _compare_away_from_faces(gpu, cpu, margin):
+    """Resident voxels farther than `margin` from the window's x faces against the unbounded reference: (mismatches, n)."""
+    g, c = gpu.download_hash(), cpu.dump_hash()
+    key = lambda v: (v[:, 0].astype(np.int64) + 100000) * (1 << 40) + (v[:, 1].astype(np.int64) + 100000) * (1 << 20) + v[:, 2] + 100000  # noqa: E731
+    ok = c["vox"][:, 0] != -10000
+    kc = key(c["vox"][ok])
+    order = np.argsort(kc)
+    kc, cdist, cocc = kc[order], c["dist"][ok][order], c["occ"][ok][order]
+    o = gpu.hash_window()[0]
+    gd = gpu.distance_from_d2(g["d2"])
+    x = g["vox"][:, 0].astype(np.int64)
+    sel = (gd != -10000.0) & (x >= o[0]) & (x < o[0] + 1024) & (np.abs(x - o[0]) > margin) & (np.abs(x - (o[0] + 1024)) > margin)
+    kg = key(g["vox"][sel])
+    at = np.searchsorted(kc, kg)
+    assert np.all(at < len(kc)) and np.array_equal(kc[at], kg)     # everything the GPU observed, the reference holds
+    bad = (np.abs(cdist[at] - gd[sel]) > 1e-12) | (cocc[at] != g["occ"][sel])
+    return int(bad.sum()), int(sel.sum())
+
+
+def test_hash_window_corridor_and_return(hip_lib, oracle_libs, best_oracle_kind):
+    """One CONTIGUOUS observed corridor 1500 voxels long, travelled twice (out: observe free space; back: obstacles
+    appear).  What the window leaves behind is parked; the field inside the window is that of the obstacles inside the
+    window, so away from the window's faces (farther than any distance in the scene) every resident voxel equals the
+    unbounded reference; pages that rejoin are rebuilt and pick up what changed next to them while they were parked."""
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.1, 100000)
+    rng = np.random.RandomState(5)
+    step, half = 48, (32, 12, 8)
+    xs = list(range(0, 1500, step))
+    for x in xs:                                   # out
+        box, _ = _island((x, 0, 0), half, rng, 1)
+        cycles(gpu, cpu, [], box, 1)
+    org, moves = gpu.hash_window()
+    assert moves >= 1 and org[0] > -512
+    for x in reversed(xs):                         # and back
+        _, obst = _island((x, 0, 0), half, rng, 30)
+        cycles(gpu, cpu, obst, [], 3)
+    org, moves2 = gpu.hash_window()
+    assert moves2 > moves and org[0] <= -32
+    bad, n = _compare_away_from_faces(gpu, cpu, 40)
+    assert bad == 0 and n > 150000, (bad, n)
+    # while the far end of the corridor is parked, obstacles appear right at the window's face
+    top = int(org[0]) + 1024
+    edge = np.array([[top - 2, 0, 0], [top - 5, 3, -2], [top - 1, -6, 4]], np.int32)
+    cycles(gpu, cpu, edge, [], 3)
+    # travel out again: the parked pages rejoin and are rebuilt -- they must pick up the new obstacles next to them
+    gpu.hash_recentre((top + 200, 0, 0))
+    gpu.UpdateESDF()
+    bad, n = _compare_away_from_faces(gpu, cpu, 40)
+    assert bad == 0 and n > 150000, (bad, n)
+    near = (edge[0] + np.stack(np.meshgrid(np.arange(1, 24), np.arange(-8, 8), np.arange(-6, 6), indexing="ij"), -1).reshape(-1, 3)).astype(np.int32)
+    assert np.array_equal(gpu.GetDistance(near), cpu.GetDistanceVox(near))

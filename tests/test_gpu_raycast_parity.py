@@ -133,10 +133,12 @@ def test_no_dedup_mode_counts_every_crossing(hip_lib, oracle_libs, best_oracle_k
     assert np.all((m1 > 0) <= (m0 > 0))
 
 
-def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind):
+@pytest.mark.parametrize("site", [(0.0, 0.0, 0.0), (83.0, -71.0, 26.0)], ids=["at-origin", "800-voxels-away"])
+def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind, site):
     """The same front end on the paged (hash-block) map against the reference built with -DHASH_TABLE: pages are
     allocated by the rays themselves; per-voxel hit/miss counters of every frame, queues and the ESDF must match voxel
-    by voxel (internal slots differ by design, so everything is keyed by voxel coordinates)."""
+    by voxel (internal slots differ by design, so everything is keyed by voxel coordinates).  The second site is outside
+    the map's initial window: the first frame has to move the window there (the reference's hash map is unbounded)."""
     import fiesta_amd
     from test_gpu_hash_parity import compare as compare_hash
     kind = best_oracle_kind if oracle_libs.available(best_oracle_kind, "hash") else "port"
@@ -146,15 +148,17 @@ def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind):
     for m in (gpu, cpu):
         m.SetParameters(*P_DEFAULT)
         m.SetOriginalRange()
-    lc, rc = (-20.0, -20.0, -20.0), (20.0, 20.0, 20.0)      # the hash build's l_cornor/r_cornor only clip the walk
-    spheres = [((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7), ((0.5, -2.0, -0.5), 0.4)]
+    site = np.array(site)
+    lc, rc = tuple(site - 20.0), tuple(site + 20.0)      # the hash build's l_cornor/r_cornor only clip the walk
+    spheres = [(tuple(site + c), r) for c, r in (((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7), ((0.5, -2.0, -0.5), 0.4))]
+    room = (tuple(site + (-3.0, -3.0, -1.5)), tuple(site + (3.0, 3.0, 1.5)))
     intr = dict(fx=96.1, fy=96.1, cx=80.7, cy=58.9)
-    pos = np.array([0.13, -0.21, 0.05])
+    pos = site + np.array([0.13, -0.21, 0.05])
     key = lambda v: (v[:, 0].astype(np.int64) + 100000) * (1 << 40) + (v[:, 1].astype(np.int64) + 100000) * (1 << 20) + v[:, 2] + 100000  # noqa: E731
     touched_total = 0
     for f in range(5):
         T = yaw_pose(25.0 * f, pos + 0.07 * f)
-        depth = render_depth(T, rows=120, cols=160, spheres=spheres, intr=intr)
+        depth = render_depth(T, rows=120, cols=160, room=room, spheres=spheres, intr=intr)
         pts = depth_to_points(depth, intr=intr)
         pts[::397] = np.nan
         o = T[:3, 3]
@@ -183,6 +187,7 @@ def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind):
         rep = compare_hash(gpu, cpu)
         assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]), rep
     assert touched_total > 30000 and rep["pages"] >= 8
+    assert gpu.hash_window()[1] == (1 if site.any() else 0) and sg["dropped_observations"] == 0
 
 
 def test_config3_640x480_frames_reference_intrinsics(hip_lib, oracle_libs, best_oracle_kind):
