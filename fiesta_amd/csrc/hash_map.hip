@@ -24,6 +24,7 @@ namespace {
 constexpr int kWin = HashMap::kWin, kHalf = HashMap::kHalf;
 constexpr int kNTY = HashMap::kNTY, kNTZ = HashMap::kNTZ, kNTiles = HashMap::kNTiles;
 constexpr int kPageVox = HashMap::kPageVox;
+constexpr int C_OUTSIDE = C_REMOTE_DEL;  // (dense shards only use that slot) a batch held a voxel outside the window
 
 __device__ inline int tile_id(int x, int y, int z) { return ((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5); }
 __device__ inline bool in_win(int x, int y, int z) {
@@ -88,10 +89,15 @@ __device__ inline bool obs_pos(const Geom &g, const double *pos, const int32_t *
   z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) - g.gz0;
   return in_win(x, y, z) && g.in_window(x, y, z);
 }
-__global__ void k_h_mark_vox(Geom g, const int32_t *vox, int64_t n, uint32_t *need) {
+// (outside: set when a voxel of the batch lies outside the window -- the host then moves the window and marks again)
+__global__ void k_h_mark_vox(Geom g, const int32_t *vox, int64_t n, uint32_t *need, unsigned long long *outside) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
   int x, y, z;
-  if (i < n && obs_vox(g, vox, i, x, y, z)) need[tile_id(x, y, z)] = 1u;
+  if (obs_vox(g, vox, i, x, y, z))
+    need[tile_id(x, y, z)] = 1u;
+  else if (outside && !in_win(x, y, z))
+    *outside = 1ull;
 }
 __global__ void k_h_mark_pos(Geom g, const double *pos, const int32_t *occ, int64_t n, uint32_t *need) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -138,10 +144,16 @@ __global__ void k_h_bbox(const int32_t *vox, int64_t n, int32_t *box) {
   int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     for (int k = 0; k < 3; ++k) lo[k] = min(lo[k], vox[3 * i + k]), hi[k] = max(hi[k], vox[3 * i + k]);
+  __shared__ int blo[3], bhi[3];
+  if (threadIdx.x < 3) blo[threadIdx.x] = INT32_MAX, bhi[threadIdx.x] = INT32_MIN;
+  __syncthreads();
   for (int k = 0; k < 3; ++k) {
     for (int off = 32; off; off >>= 1) lo[k] = min(lo[k], __shfl_xor(lo[k], off)), hi[k] = max(hi[k], __shfl_xor(hi[k], off));
-    if ((threadIdx.x & 63) == 0 && lo[k] <= hi[k]) atomicMin(&box[k], lo[k]), atomicMax(&box[3 + k], hi[k]);
+    if ((threadIdx.x & 63) == 0 && lo[k] <= hi[k]) atomicMin(&blo[k], lo[k]), atomicMax(&bhi[k], hi[k]);
   }
+  __syncthreads();
+  if (threadIdx.x < 3 && blo[threadIdx.x] <= bhi[threadIdx.x])
+    atomicMin(&box[threadIdx.x], blo[threadIdx.x]), atomicMax(&box[3 + threadIdx.x], bhi[threadIdx.x]);
 }
 
 // ---- SetOccupancy (src/ESDFMap.cpp:401-437) ----
@@ -620,7 +632,7 @@ void HashMap::ensure_window_vox(const int32_t *vox, int64_t n, bool dev) {
     const int32_t init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
     int32_t box[6];
     FIESTA_HIP_CHECK(hipMemcpyAsync(stage_c_.p, init, sizeof(init), hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL(k_h_bbox, dim3(grid_for(n, 256, 1024)), dim3(256), 0, stream_, vox, n, (int32_t *)stage_c_.p);
+    hipLaunchKernelGGL(k_h_bbox, dim3(grid_for(n, 1024, 256)), dim3(1024), 0, stream_, vox, n, (int32_t *)stage_c_.p);
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipMemcpyAsync(box, stage_c_.p, sizeof(box), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -629,20 +641,26 @@ void HashMap::ensure_window_vox(const int32_t *vox, int64_t n, bool dev) {
   ensure_window(lo, hi);
 }
 
-// Assign pages to every marked tile that has none yet.
-void HashMap::allocate_marked() {
+// Assign pages to every marked tile that has none yet.  Returns the "a voxel was outside the window" flag of the mark
+// kernel (k_h_mark_vox), read in the same round trip as the number of fresh tiles.
+bool HashMap::allocate_marked() {
   stage_d_.ensure((size_t)kNTiles * sizeof(uint32_t), stream_);
   zero_counter(C_SCRATCH);
   hipLaunchKernelGGL(k_h_collect, dim3(kNTiles / 256), dim3(256), 0, stream_, need_, (const int32_t *)dir_, (uint32_t *)stage_d_.p,
                      &counters_[C_SCRATCH]);
   FIESTA_HIP_CHECK(hipGetLastError());
-  const int64_t k = (int64_t)read_counter(C_SCRATCH);
-  if (k == 0) return;
+  static_assert(C_OUTSIDE == C_SCRATCH + 1, "read together");
+  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_SCRATCH], &counters_[C_SCRATCH], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  const int64_t k = (int64_t)h_counters_[C_SCRATCH];
+  const bool outside = h_counters_[C_OUTSIDE] != 0;
+  if (k == 0) return outside;
   ensure_pages(npages_ + k);
   hipLaunchKernelGGL(k_h_assign, dim3(grid_for(k)), dim3(256), 0, stream_, g_, (const uint32_t *)stage_d_.p, k, (int32_t)npages_,
                      dir_, page_tile_.p, page_gtile_.p);
   FIESTA_HIP_CHECK(hipGetLastError());
   npages_ += k;
+  return outside;
 }
 
 void HashMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret, bool dev) {
@@ -657,9 +675,20 @@ void HashMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, int
     dvox = (const int32_t *)stage_a_.p;
     docc = (const int32_t *)stage_b_.p;
   }
-  ensure_window_vox(dev ? dvox : vox, n, dev);
-  hipLaunchKernelGGL(k_h_mark_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, dvox, n, need_);
-  allocate_marked();
+  // host batches: the bounding box decides up front whether the window has to move; device batches: the mark kernel
+  // reports a voxel outside the window (no extra round trip when there is none), then the box is reduced on the device
+  if (!dev) ensure_window_vox(vox, n, false);
+  zero_counter(C_OUTSIDE);
+  hipLaunchKernelGGL(k_h_mark_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, dvox, n, need_, dev ? &counters_[C_OUTSIDE] : nullptr);
+  if (allocate_marked()) {
+    const int64_t before = moves_;
+    ensure_window_vox(dvox, n, true);
+    if (moves_ != before) {
+      zero_counter(C_OUTSIDE);
+      hipLaunchKernelGGL(k_h_mark_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, dvox, n, need_, (unsigned long long *)nullptr);
+      allocate_marked();
+    }
+  }
   touched_upper_ = std::min<int64_t>(npages_ * kPageVox, touched_upper_ + n);
   touched_.ensure((size_t)touched_upper_, stream_, touched_.cap);
   hipLaunchKernelGGL(k_h_observe_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, dvox, docc, n, cnt_.p,

@@ -79,7 +79,7 @@ class HashMap {
   void move_window(const int32_t origin[3]);
   void refresh_range();
   void ensure_pages(int64_t need_total);
-  void allocate_marked();
+  bool allocate_marked();
   unsigned long long read_counter(int which);
   void zero_counter(int which);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count);

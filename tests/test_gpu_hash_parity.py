@@ -247,6 +247,29 @@ def test_hash_window_follows_a_travelling_sensor(hip_lib, oracle_libs, best_orac
     assert rep["d2_mismatch"] == 0, rep
 
 
+def test_hash_window_moves_for_device_batches(hip_lib, oracle_libs, best_oracle_kind):
+    """fiesta_hip_set_occupancy_vox_dev: the batch lives in HBM, so the mark kernel reports "outside the window", the
+    bounding box is reduced on the device, and the window moves before anything is counted -- nothing may be dropped."""
+    import torch
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.1, 1000)
+    rng = np.random.RandomState(3)
+    for c in ((0, 0, 0), (700, -650, 40), (-3000, 90, 2100)):
+        box, obst = _island(c, (10, 10, 8), rng, 12)
+        for v, o, reps in ((box, 0, 1), (obst, 1, 3)):
+            for _ in range(reps):
+                dv = torch.from_numpy(v).cuda()
+                do = torch.full((len(v),), o, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                gpu.SetOccupancyDevice(dv.data_ptr(), do.data_ptr(), len(v))
+                cpu.SetOccupancyVox(v, o)
+                assert gpu.UpdateOccupancy(True) == cpu.UpdateOccupancy(True)
+            sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
+            assert (sg["inserted"], sg["deleted"], sg["dropped_observations"]) == (sc["inserted"], sc["deleted"], 0)
+    assert gpu.hash_window()[1] == 2
+    rep = compare(gpu, cpu)
+    assert rep["d2_mismatch"] == 0 and rep["finite"] == 3 * 20 * 20 * 16, rep
+
+
 def _compare_away_from_faces(gpu, cpu, margin):
     """Resident voxels farther than `margin` from the window's x faces against the unbounded reference: (mismatches, n)."""
     g, c = gpu.download_hash(), cpu.dump_hash()
