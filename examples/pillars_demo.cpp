@@ -9,6 +9,26 @@
 
 #include "fiesta/ESDFMap.h"
 
+// What a ROS build passes to GetPointCloud / GetSliceMarker are sensor_msgs::PointCloud and visualization_msgs::Marker;
+// the getters only need their field names, so plain structs of the same shape do here.
+namespace demo_msgs {
+struct Header { std::string frame_id; };
+struct P32 { float x, y, z; };
+struct P64 { double x, y, z; };
+struct Rgba { float r, g, b, a; };
+struct Quat { double x, y, z, w; };
+struct PointCloud { Header header; std::vector<P32> points; };
+struct Marker {
+  enum { POINTS = 8, MODIFY = 0 };
+  Header header;
+  int id, type, action;
+  P64 scale;
+  struct { P64 position; Quat orientation; } pose;
+  std::vector<P64> points;
+  std::vector<Rgba> colors;
+};
+}  // namespace demo_msgs
+
 template <class Map>
 static int run(Map &map, bool hash) {
   using Eigen::Vector3d;
@@ -58,6 +78,15 @@ static int run(Map &map, bool hash) {
   std::printf("checksum %.12f trilinear %.12f grad %.12f %.12f %.12f\n", sum, d, grad(0), grad(1), grad(2));
   if (!hash)
     std::printf("outside %.1f %d\n", map.GetDistance(Vector3d(100, 0, 0)), map.SetOccupancy(Vector3d(100, 0, 0), 1));
+  // the visualisation getters with the reference's signatures: 12 pillars of 25 voxels stand; the lower 10 layers of each
+  demo_msgs::PointCloud cloud;
+  map.GetPointCloud(cloud, 0, 9);
+  demo_msgs::Marker slice;
+  map.GetSliceMarker(slice, 3, 7, 0 /* colour argument, ignored like in the reference */, 2.0);
+  double red = 0;
+  for (const auto &c : slice.colors) red += c.r;
+  std::printf("cloud %zu in %s, slice marker %d: %zu points, type %d, red %.6f\n", cloud.points.size(), cloud.header.frame_id.c_str(),
+              slice.id, slice.points.size(), slice.type, red);
   std::printf("38 UpdateESDF calls: %.3f ms total\n", total_ms);
   return 0;
 }

@@ -108,6 +108,10 @@ def load():
         "fiesta_hip_grid_size": (C.c_int, [vp, vp]),
         "fiesta_hip_grid_total_size": (C.c_int, [vp, vp]),
         "fiesta_hip_voxel_key": (C.c_int, [vp, vp, C.c_int64, vp]),
+        "fiesta_hip_save": (C.c_int, [vp, C.c_char_p]),
+        "fiesta_hip_load": (C.c_int, [vp, C.c_char_p]),
+        "fiesta_hip_get_point_cloud": (C.c_int, [vp, i32, i32, vp, i64, vp]),
+        "fiesta_hip_get_slice_marker": (C.c_int, [vp, i32, dbl, vp, vp, i64, vp]),
         "fiesta_hip_hash_window": (C.c_int, [vp, vp, vp]),
         "fiesta_hip_hash_recentre": (C.c_int, [vp, vp]),
         "fiesta_hip_rccl_unique_id": (C.c_int, [vp]),

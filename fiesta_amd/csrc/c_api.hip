@@ -378,6 +378,40 @@ int fiesta_hip_get_slice(fiesta_hip_map *m, int32_t z_vox, double *out) {
     dense(m, "get_slice").slice_distances(z_vox, out);
   });
 }
+int fiesta_hip_save(fiesta_hip_map *m, const char *path) {
+  return guarded([&] {
+    need(m && path, "null argument");
+    if (m->dense)
+      m->dense->checkpoint(path, true);
+    else
+      m->hash->checkpoint(path, true);
+  });
+}
+int fiesta_hip_load(fiesta_hip_map *m, const char *path) {
+  return guarded([&] {
+    need(m && path, "null argument");
+    if (m->dense)
+      m->dense->checkpoint(path, false);
+    else
+      m->hash->checkpoint(path, false);
+  });
+}
+int fiesta_hip_get_point_cloud(fiesta_hip_map *m, int32_t vis_lower_bound, int32_t vis_upper_bound, float *xyz,
+                               int64_t capacity, int64_t *n_out) {
+  return guarded([&] {
+    need(m && n_out && capacity >= 0, "bad argument");
+    *n_out = m->dense ? m->dense->point_cloud(vis_lower_bound, vis_upper_bound, xyz, capacity)
+                      : m->hash->point_cloud(vis_lower_bound, vis_upper_bound, xyz, capacity);
+  });
+}
+int fiesta_hip_get_slice_marker(fiesta_hip_map *m, int32_t slice, double max_dist, double *xyz, float *rgba,
+                                int64_t capacity, int64_t *n_out) {
+  return guarded([&] {
+    need(m && n_out && capacity >= 0, "bad argument");
+    *n_out = m->dense ? m->dense->slice_marker(slice, max_dist, xyz, rgba, capacity)
+                      : m->hash->slice_marker(slice, max_dist, xyz, rgba, capacity);
+  });
+}
 int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
                              uint8_t *occ) {
   return guarded([&] {

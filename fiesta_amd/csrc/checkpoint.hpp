@@ -1,0 +1,94 @@
+// fiesta_amd/csrc/checkpoint.hpp -- raw dump / load of a map's device state to a file (host side).
+//
+// The reference has no checkpoint of its own (its state dies with the ROS node); SURVEY.md 5 lists dump/resume of the
+// field as the auxiliary subsystem a long-running mapper needs.  The format is the device layout itself, written in
+// pieces through a pinned staging buffer: a fixed header (magic, version, map mode, geometry), then named sections
+// (byte count + payload).  A file only loads into a map created with the same mode, resolution, origin and grid.
+#pragma once
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/fiesta_hip.h"
+#include "common.hpp"
+
+namespace fiesta {
+
+class DevFile {
+ public:
+  DevFile(const char *path, bool write, hipStream_t s) : s_(s), write_(write) {
+    f_ = fopen(path, write ? "wb" : "rb");
+    if (!f_) throw Error(FIESTA_HIP_ERR_INVALID, std::string("checkpoint: cannot open ") + path);
+    if (hipHostMalloc(&pin_, kChunk) != hipSuccess) {
+      fclose(f_);
+      throw Error(FIESTA_HIP_ERR_NOMEM, "checkpoint: no pinned staging buffer");
+    }
+  }
+  ~DevFile() {
+    if (pin_) (void)hipHostFree(pin_);
+    if (f_) fclose(f_);
+  }
+  DevFile(const DevFile &) = delete;
+  DevFile &operator=(const DevFile &) = delete;
+
+  void host(void *p, size_t bytes) {  // plain host data, written or read in place
+    if (bytes == 0) return;
+    const size_t k = write_ ? fwrite(p, 1, bytes, f_) : fread(p, 1, bytes, f_);
+    if (k != bytes) throw Error(FIESTA_HIP_ERR_INVALID, write_ ? "checkpoint: short write" : "checkpoint: truncated file");
+  }
+  // a device array: its byte count is part of the file and must match on load
+  void device(void *dev, size_t bytes) {
+    unsigned long long n = bytes;
+    host(&n, sizeof(n));
+    if (n != bytes) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: section size does not match this map");
+    for (size_t off = 0; off < bytes; off += kChunk) {
+      const size_t k = bytes - off < kChunk ? bytes - off : kChunk;
+      if (write_) {
+        FIESTA_HIP_CHECK(hipMemcpyAsync(pin_, (const char *)dev + off, k, hipMemcpyDeviceToHost, s_));
+        FIESTA_HIP_CHECK(hipStreamSynchronize(s_));
+        host(pin_, k);
+      } else {
+        host(pin_, k);
+        FIESTA_HIP_CHECK(hipMemcpyAsync((char *)dev + off, pin_, k, hipMemcpyHostToDevice, s_));
+        FIESTA_HIP_CHECK(hipStreamSynchronize(s_));
+      }
+    }
+  }
+  bool writing() const { return write_; }
+  void finish() {
+    if (write_ && fflush(f_) != 0) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: flush failed");
+  }
+
+ private:
+  static constexpr size_t kChunk = 64u << 20;
+  FILE *f_ = nullptr;
+  void *pin_ = nullptr;
+  hipStream_t s_;
+  bool write_;
+};
+
+struct CheckpointHeader {
+  char magic[8];  // "FIESTAHP"
+  uint32_t version, mode;
+  int32_t grid[3], shard_lo[3], global[3];
+  double res, org[3];
+};
+inline void checkpoint_header(DevFile &f, uint32_t mode, const Geom &g) {
+  CheckpointHeader h, mine;
+  memset(&mine, 0, sizeof(mine));
+  memcpy(mine.magic, "FIESTAHP", 8);
+  mine.version = 2;
+  mine.mode = mode;
+  mine.grid[0] = g.nx, mine.grid[1] = g.ny, mine.grid[2] = g.nz;
+  if (mode == FIESTA_HIP_MODE_ARRAY) mine.shard_lo[0] = g.gx0, mine.shard_lo[1] = g.gy0, mine.shard_lo[2] = g.gz0;
+  mine.global[0] = g.GX, mine.global[1] = g.GY, mine.global[2] = g.GZ;
+  mine.res = g.res;
+  for (int k = 0; k < 3; ++k) mine.org[k] = g.org[k];
+  h = mine;
+  f.host(&h, sizeof(h));
+  if (!f.writing() && memcmp(&h, &mine, sizeof(h)) != 0)
+    throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: file was written by a map of another mode, geometry or format version");
+}
+
+}  // namespace fiesta

@@ -69,6 +69,22 @@ __host__ __device__ inline void unpack_coc(vox_t c, int &x, int &y, int &z) {
 }
 __host__ __device__ inline int32_t dist2(int x, int y, int z, vox_t c) { return dist2(0, x, y, z, c); }
 
+// Colour of a distance in GetSliceMarker (src/ESDFMap.cpp:584-636, 673): hue h (taken modulo 1) around the colour circle
+// at full saturation and value; the six sectors only permute (1, 1 - f', 0).
+__host__ __device__ inline void rainbow_rgba(double h, float *rgba) {
+  h -= floor(h);
+  h *= 6;
+  const int sector = (int)floor(h);
+  double f = h - sector;
+  if (!(sector & 1)) f = 1 - f;
+  const double lvl[3] = {1.0, 1.0 - f, 0.0};
+  // which level goes to r, g, b in sector 0..5 (6 wraps to 0): two bits each
+  const unsigned perm[6] = {0u | 1u << 2 | 2u << 4, 1u | 0u << 2 | 2u << 4, 2u | 0u << 2 | 1u << 4,
+                            2u | 1u << 2 | 0u << 4, 1u | 2u << 2 | 0u << 4, 0u | 2u << 2 | 1u << 4};
+  const unsigned pm = perm[sector % 6];
+  rgba[0] = (float)lvl[pm & 3], rgba[1] = (float)lvl[(pm >> 2) & 3], rgba[2] = (float)lvl[(pm >> 4) & 3], rgba[3] = 1.0f;
+}
+
 // The 24-direction stencil (include/parameters.h:54-68): 6 faces, 12 edges, 6 two-step faces.
 // Order is the reference's; it is irrelevant for the fixed point.
 // the same stencil as two halves of 12 (for kernels that batch the neighbour reads but are short of registers)

@@ -23,6 +23,7 @@
 // tile's members of R are recorded in a bitmap, and neighbouring tiles whose halo saw a frontier voxel
 // are appended to the next round's tile list (level-synchronous rounds, one launch per round).
 #include "dense_map.hpp"
+#include "checkpoint.hpp"
 #include "ft_kernels.hpp"
 #include "relax_kernels.hpp"
 
@@ -570,6 +571,52 @@ __global__ void k_slice(Geom g, const vox_t *coc, int z, double *out) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int y = (int)(i % g.ny), x = (int)(i / g.ny);
     out[i] = vox_distance(g, coc, x, y, z);
+  }
+}
+
+// GetPointCloud (src/ESDFMap.cpp:544-582): centres (Vox2Pos, narrowed to float like geometry_msgs::Point32) of the
+// occupied voxels inside the update range whose z INDEX lies within the visualisation bounds.  Order unspecified.
+__global__ void k_point_cloud(Geom g, const uint32_t *occbits, int zlo, int zhi, float *out, unsigned long long cap,
+                              unsigned long long *count) {
+  const int64_t nwords = (int64_t)g.nx * g.ny * g.nzw;
+  for (int64_t wi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; wi < nwords; wi += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t bits = occbits[wi];
+    if (!bits) continue;
+    const int zw = (int)(wi % g.nzw), y = (int)((wi / g.nzw) % g.ny), x = (int)(wi / ((int64_t)g.nzw * g.ny));
+    if (x < g.wx0 || x > g.wx1 || y < g.wy0 || y > g.wy1) continue;
+    uint32_t keep = 0;
+    for (uint32_t b = bits; b; b &= b - 1) {
+      const int k = __ffs(b) - 1, z = zw * 32 + k, gz = z + g.gz0;
+      if (z >= g.wz0 && z <= g.wz1 && gz >= zlo && gz <= zhi) keep |= 1u << k;
+    }
+    if (!keep) continue;
+    unsigned long long k = atomicAdd(count, (unsigned long long)__popc(keep));
+    for (; keep; keep &= keep - 1, ++k) {
+      if (k >= cap) continue;
+      const int z = zw * 32 + __ffs(keep) - 1;
+      out[3 * k] = (float)((x + g.gx0 + 0.5) * g.res + g.org[0]);
+      out[3 * k + 1] = (float)((y + g.gy0 + 0.5) * g.res + g.org[1]);
+      out[3 * k + 2] = (float)((z + g.gz0 + 0.5) * g.res + g.org[2]);
+    }
+  }
+}
+// GetSliceMarker (src/ESDFMap.cpp:639-699): voxels of the plane z inside the x/y update range with a defined, finite
+// distance: centre (double, geometry_msgs::Point) and colour rainbow(min(d / max_dist, 1)).  Order unspecified.
+__global__ void k_slice_marker(Geom g, const vox_t *coc, int z, double max_dist, double *xyz, float *rgba,
+                               unsigned long long cap, unsigned long long *count) {
+  const int ex = g.wx1 - g.wx0 + 1, ey = g.wy1 - g.wy0 + 1;
+  const int64_t n = (int64_t)max(ex, 0) * max(ey, 0);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = g.wy0 + (int)(i % ey), x = g.wx0 + (int)(i / ey);
+    const vox_t w = coc[g.idx(x, y, z)];
+    if (w == kUnobserved || (w & kNoCoc)) continue;  // distance -10000 / +10000
+    const double d = vox_distance(g, coc, x, y, z);
+    const unsigned long long k = atomicAdd(count, 1ull);
+    if (k >= cap) continue;
+    xyz[3 * k] = (x + g.gx0 + 0.5) * g.res + g.org[0];
+    xyz[3 * k + 1] = (y + g.gy0 + 0.5) * g.res + g.org[1];
+    xyz[3 * k + 2] = (z + g.gz0 + 0.5) * g.res + g.org[2];
+    rainbow_rgba(d <= max_dist ? d / max_dist : 1, rgba + 4 * k);
   }
 }
 
@@ -1488,6 +1535,49 @@ int64_t DenseMap::occupied_voxels(int32_t *vox, int64_t cap) {
   return n;
 }
 
+int64_t DenseMap::point_cloud(int vis_lower_bound, int vis_upper_bound, float *xyz, int64_t cap) {
+  use_device();
+  zero_counter(C_SCRATCH);
+  float *dout = nullptr;
+  if (xyz && cap > 0) {
+    stage_a_.ensure((size_t)cap * 3 * sizeof(float), stream_);
+    dout = (float *)stage_a_.p;
+  }
+  hipLaunchKernelGGL(k_point_cloud, dim3(grid_for(nbitwords_, 256, 8192)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
+                     vis_lower_bound, vis_upper_bound, dout, (unsigned long long)(dout ? cap : 0), &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  const int64_t n = (int64_t)read_counter(C_SCRATCH);
+  if (dout && n) FIESTA_HIP_CHECK(hipMemcpyAsync(xyz, dout, (size_t)std::min(n, cap) * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  return n;
+}
+
+int64_t DenseMap::slice_marker(int slice, double max_dist, double *xyz, float *rgba, int64_t cap) {
+  use_device();
+  const int z = slice - g_.gz0;
+  if (z < 0 || z >= g_.nz) throw Error(FIESTA_HIP_ERR_INVALID, "slice outside the grid");
+  zero_counter(C_SCRATCH);
+  double *dx = nullptr;
+  float *dc = nullptr;
+  if (xyz && rgba && cap > 0) {
+    stage_a_.ensure((size_t)cap * 3 * sizeof(double), stream_);
+    stage_b_.ensure((size_t)cap * 4 * sizeof(float), stream_);
+    dx = (double *)stage_a_.p, dc = (float *)stage_b_.p;
+  }
+  const int64_t cells = (int64_t)g_.nx * g_.ny;
+  hipLaunchKernelGGL(k_slice_marker, dim3(grid_for(cells, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, z, max_dist, dx,
+                     dc, (unsigned long long)(dx ? cap : 0), &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  const int64_t n = (int64_t)read_counter(C_SCRATCH);
+  if (dx && n) {
+    const size_t k = (size_t)std::min(n, cap);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(xyz, dx, k * 3 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(rgba, dc, k * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  }
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  return n;
+}
+
 void DenseMap::slice_distances(int z_vox, double *out) {
   use_device();
   const int z = z_vox - g_.gz0;
@@ -1585,6 +1675,56 @@ void DenseMap::snapshot_restore(int slot) {
   stale_inf_ = s.stale_inf;
   host_counts_valid_ = false;
   if (track_) {  // the snapshot may predate the tracking: recompute the distance bound for the restored field
+    zero_counter(C_MAXD2);
+    hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// Raw dump (write) / load of the whole map state: one routine for both directions (checkpoint.hpp).
+void DenseMap::checkpoint(const char *path, bool write) {
+  use_device();
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  DevFile f(path, write, stream_);
+  checkpoint_header(f, FIESTA_HIP_MODE_ARRAY, g_);
+  if (write) {
+    FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+  unsigned long long c[C_COUNT];
+  memcpy(c, h_counters_, sizeof(c));
+  f.host(c, sizeof(c));
+  f.host(&pp_, sizeof(pp_));
+  Geom g = g_;
+  f.host(&g, sizeof(g));  // (the update ranges; the rest is pinned by the header)
+  uint32_t flags[4] = {stale_inf_ ? 1u : 0u, gocc_ ? 1u : 0u, 0u, 0u};
+  f.host(flags, sizeof(flags));
+  if ((flags[1] != 0) != (gocc_ != nullptr)) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: sharded / unsharded mismatch");
+  const size_t nt = c[C_TOUCHED], ni = c[C_INSERT], nd = c[C_DELETE];
+  if (!write) {
+    touched_.ensure(nt, stream_);
+    ins_.ensure(ni, stream_);
+    del_.ensure(nd, stream_);
+  }
+  f.device(coc_, (size_t)g_.n * sizeof(vox_t));
+  f.device(logodds_, (size_t)g_.n * sizeof(double));
+  f.device(cnt_, (size_t)g_.n * sizeof(unsigned long long));
+  f.device(occbits_, (size_t)nbitwords_ * sizeof(uint32_t));
+  if (gocc_) f.device(gocc_, (size_t)ngoccwords_ * sizeof(uint32_t));
+  f.device(touched_.p, nt * sizeof(uint32_t));
+  f.device(ins_.p, ni * sizeof(uint32_t));
+  f.device(del_.p, nd * sizeof(uint32_t));
+  f.finish();
+  if (write) return;
+  c[C_LIST0] = c[C_LIST1] = 0;
+  memcpy(h_counters_, c, sizeof(c));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
+  touched_upper_ = (int64_t)nt;
+  g_ = g;
+  stale_inf_ = flags[0] != 0;
+  host_counts_valid_ = false;
+  if (track_) {
     zero_counter(C_MAXD2);
     hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);
     FIESTA_HIP_CHECK(hipGetLastError());

@@ -114,6 +114,10 @@ class DenseMap {
   void download_counts(int32_t *num_hit, int32_t *num_miss);
   int64_t occupied_voxels(int32_t *vox, int64_t cap);  // returns the total count (may exceed cap)
   void slice_distances(int z_vox, double *out);        // nx * ny doubles, x-major
+  // GetPointCloud / GetSliceMarker as arrays; both return the total count (may exceed cap), order unspecified
+  void checkpoint(const char *path, bool write);  // raw dump / load of the whole state (checkpoint.hpp)
+  int64_t point_cloud(int vis_lower_bound, int vis_upper_bound, float *xyz, int64_t cap);
+  int64_t slice_marker(int slice, double max_dist, double *xyz, float *rgba, int64_t cap);
   void snapshot_save(int slot);
   void snapshot_restore(int slot);
   int64_t snapshot_count_updated(int slot);

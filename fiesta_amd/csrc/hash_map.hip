@@ -7,6 +7,7 @@
 //                                                                                k_relax_q<16,16,1024,PAGED>
 //   GetDistance / GetDistWithGradTrilinear / GetOccupancy :452-540           -> k_h_query_*
 #include "hash_map.hpp"
+#include "checkpoint.hpp"
 
 #include <vector>
 
@@ -441,6 +442,55 @@ __global__ void k_h_export(const int32_t *page_gtile, int64_t nvox, const vox_t 
     if (occ) occ[a] = hbit(occbits, a);
   }
 }
+// GetPointCloud / GetSliceMarker over the block store (src/ESDFMap.cpp:547-566, 657-677): every allocated voxel -- resident
+// or parked -- inside the x/y update range (map voxels), the z test as in the dense build.  Order unspecified.
+__global__ void k_h_point_cloud(Geom g, const int32_t *page_gtile, int64_t nrows, const uint32_t *occbits, int lox, int hix,
+                                int loy, int hiy, int zlo, int zhi, float *out, unsigned long long cap, unsigned long long *count) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t bits = occbits[r];  // one z-row of a page: 32 voxels
+    if (!bits) continue;
+    const int64_t page = r / HashMap::kPageRows;
+    const int row = (int)(r % HashMap::kPageRows);
+    const int x = page_gtile[3 * page] * 16 + (row >> 4), y = page_gtile[3 * page + 1] * 16 + (row & 15), z0 = page_gtile[3 * page + 2] * 32;
+    if (x < lox || x > hix || y < loy || y > hiy) continue;
+    uint32_t keep = 0;
+    for (uint32_t b = bits; b; b &= b - 1) {
+      const int k = __ffs(b) - 1;
+      if (z0 + k >= zlo && z0 + k <= zhi) keep |= 1u << k;
+    }
+    if (!keep) continue;
+    unsigned long long k = atomicAdd(count, (unsigned long long)__popc(keep));
+    for (; keep; keep &= keep - 1, ++k) {
+      if (k >= cap) continue;
+      const int z = z0 + __ffs(keep) - 1;
+      out[3 * k] = (float)((x + 0.5) * g.res + g.org[0]);
+      out[3 * k + 1] = (float)((y + 0.5) * g.res + g.org[1]);
+      out[3 * k + 2] = (float)((z + 0.5) * g.res + g.org[2]);
+    }
+  }
+}
+__global__ void k_h_slice_marker(Geom g, const int32_t *page_gtile, int64_t npages, const vox_t *coc, int lox, int hix, int loy,
+                                 int hiy, int slice, double max_dist, double *xyz, float *rgba, unsigned long long cap,
+                                 unsigned long long *count) {
+  // one thread per (page, row): the page's z-range holds the slice or it does not (uniform per page)
+  const int64_t n = npages * HashMap::kPageRows;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t page = r / HashMap::kPageRows;
+    const int row = (int)(r % HashMap::kPageRows), z0 = page_gtile[3 * page + 2] * 32;
+    if (slice < z0 || slice >= z0 + 32) continue;
+    const int x = page_gtile[3 * page] * 16 + (row >> 4), y = page_gtile[3 * page + 1] * 16 + (row & 15);
+    if (x < lox || x > hix || y < loy || y > hiy) continue;
+    const vox_t w = coc[page * kPageVox + row * 32 + (slice - z0)];
+    if (w == kUnobserved || (w & kNoCoc)) continue;
+    const double d = sqrt((double)dist2(1, x, y, slice, w & ~kAct)) * g.res;
+    const unsigned long long k = atomicAdd(count, 1ull);
+    if (k >= cap) continue;
+    xyz[3 * k] = (x + 0.5) * g.res + g.org[0];
+    xyz[3 * k + 1] = (y + 0.5) * g.res + g.org[1];
+    xyz[3 * k + 2] = (slice + 0.5) * g.res + g.org[2];
+    rainbow_rgba(d <= max_dist ? d / max_dist : 1, rgba + 4 * k);
+  }
+}
 }  // namespace
 
 // =====================================================================================================
@@ -532,14 +582,80 @@ void HashMap::ensure_pages(int64_t need_total) {
   grow_exact(page_gtile_, (size_t)cap * 3, keep_p * 3);
   grow_exact(page_fresh_, (size_t)cap, keep_p);
   FIESTA_HIP_CHECK(hipMemsetAsync(page_fresh_.p + keep_p, 0, (size_t)(cap - cap_pages_) * sizeof(uint32_t), stream_));
-  const int64_t nv = (cap - cap_pages_) * kPageVox, nr = (cap - cap_pages_) * kPageRows;
-  hipLaunchKernelGGL(k_h_fill<vox_t>, dim3(grid_for(nv, 256, 4096)), dim3(256), 0, stream_, coc_.p + keep_v, kUnobserved, nv);
-  FIESTA_HIP_CHECK(hipGetLastError());
-  FIESTA_HIP_CHECK(hipMemsetAsync(logodds_.p + keep_v, 0, nv * sizeof(double), stream_));
-  FIESTA_HIP_CHECK(hipMemsetAsync(cnt_.p + keep_v, 0, nv * sizeof(unsigned long long), stream_));
-  for (uint32_t *b : {occbits_.p, rbits_.p, cbits_[0].p, cbits_[1].p})
-    FIESTA_HIP_CHECK(hipMemsetAsync(b + keep_r, 0, nr * sizeof(uint32_t), stream_));
+  const int64_t first = cap_pages_;
   cap_pages_ = cap;
+  pristine_pages(first, cap - first);
+}
+// pages [first, first + count) as never-touched pool memory
+void HashMap::pristine_pages(int64_t first, int64_t count) {
+  if (count <= 0) return;
+  const int64_t v0 = first * kPageVox, r0 = first * kPageRows, nv = count * kPageVox, nr = count * kPageRows;
+  hipLaunchKernelGGL(k_h_fill<vox_t>, dim3(grid_for(nv, 256, 4096)), dim3(256), 0, stream_, coc_.p + v0, kUnobserved, nv);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipMemsetAsync(logodds_.p + v0, 0, nv * sizeof(double), stream_));
+  FIESTA_HIP_CHECK(hipMemsetAsync(cnt_.p + v0, 0, nv * sizeof(unsigned long long), stream_));
+  for (uint32_t *b : {occbits_.p, rbits_.p, cbits_[0].p, cbits_[1].p})
+    FIESTA_HIP_CHECK(hipMemsetAsync(b + r0, 0, nr * sizeof(uint32_t), stream_));
+}
+
+// Raw dump (write) / load of the whole map state -- pool, directory, window, queues (checkpoint.hpp).
+void HashMap::checkpoint(const char *path, bool write) {
+  use_device();
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  DevFile f(path, write, stream_);
+  Geom hdr = g_;
+  hdr.gx0 = hdr.gy0 = hdr.gz0 = 0;  // (the window origin is state, not identity)
+  checkpoint_header(f, FIESTA_HIP_MODE_HASH, hdr);
+  if (write) {
+    FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+  unsigned long long c[C_COUNT];
+  memcpy(c, h_counters_, sizeof(c));
+  f.host(c, sizeof(c));
+  f.host(&pp_, sizeof(pp_));
+  Geom g = g_;
+  f.host(&g, sizeof(g));
+  f.host(ur_, sizeof(ur_));
+  f.host(pr_, sizeof(pr_));
+  int64_t meta[4] = {npages_, moves_, dropped_host_, force_scan_ ? 1 : 0};
+  f.host(meta, sizeof(meta));
+  const size_t nt = c[C_TOUCHED], ni = c[C_INSERT], nd = c[C_DELETE];
+  if (!write) {
+    const int64_t had = npages_;
+    ensure_pages(std::max<int64_t>(meta[0], 8));
+    if (had > meta[0]) pristine_pages(meta[0], had - meta[0]);  // what this map held beyond the file's pages
+    npages_ = meta[0];
+    touched_.ensure(nt, stream_);
+    ins_.ensure(ni, stream_);
+    del_.ensure(nd, stream_);
+  }
+  const size_t nv = (size_t)npages_ * kPageVox, nr = (size_t)npages_ * kPageRows, np = (size_t)npages_;
+  f.device(coc_.p, nv * sizeof(vox_t));
+  f.device(logodds_.p, nv * sizeof(double));
+  f.device(cnt_.p, nv * sizeof(unsigned long long));
+  f.device(occbits_.p, nr * sizeof(uint32_t));
+  f.device(page_tile_.p, np * sizeof(int32_t));
+  f.device(page_gtile_.p, np * 3 * sizeof(int32_t));
+  f.device(page_fresh_.p, np * sizeof(uint32_t));
+  f.device(dir_, (size_t)kNTiles * sizeof(int32_t));
+  f.device(touched_.p, nt * sizeof(uint32_t));
+  f.device(ins_.p, ni * sizeof(uint32_t));
+  f.device(del_.p, nd * sizeof(uint32_t));
+  f.finish();
+  if (write) return;
+  c[C_LIST0] = c[C_LIST1] = 0;
+  memcpy(h_counters_, c, sizeof(c));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
+  for (uint32_t *p : {need_, tile_epoch_, cstamp_[0], cstamp_[1], tile_flag_[0], tile_flag_[1]})
+    FIESTA_HIP_CHECK(hipMemsetAsync(p, 0, kNTiles * sizeof(uint32_t), stream_));
+  g_ = g;
+  moves_ = meta[1];
+  dropped_host_ = meta[2];
+  force_scan_ = meta[3] != 0;
+  touched_upper_ = (int64_t)nt;
+  shadow_vox_ = -1;
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
 unsigned long long HashMap::read_counter(int which) {
@@ -1017,6 +1133,53 @@ int64_t HashMap::download(int32_t *vox, int32_t *d2, int32_t *coc, uint8_t *occ)
   if (coc) FIESTA_HIP_CHECK(hipMemcpyAsync(coc, dc, n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
   if (d2) FIESTA_HIP_CHECK(hipMemcpyAsync(d2, dd, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
   if (occ) FIESTA_HIP_CHECK(hipMemcpyAsync(occ, doc, n, hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  return n;
+}
+
+int64_t HashMap::point_cloud(int vis_lower_bound, int vis_upper_bound, float *xyz, int64_t cap) {
+  use_device();
+  zero_counter(C_SCRATCH);
+  float *dout = nullptr;
+  if (xyz && cap > 0) {
+    stage_a_.ensure((size_t)cap * 3 * sizeof(float), stream_);
+    dout = (float *)stage_a_.p;
+  }
+  auto c = [](int64_t v) { return (int)std::min<int64_t>(std::max<int64_t>(v, -(1ll << 30)), 1ll << 30); };
+  const int64_t nrows = npages_ * kPageRows;
+  if (nrows)
+    hipLaunchKernelGGL(k_h_point_cloud, dim3(grid_for(nrows, 256, 8192)), dim3(256), 0, stream_, g_, (const int32_t *)page_gtile_.p, nrows,
+                       (const uint32_t *)occbits_.p, c(ur_[0]), c(ur_[3]), c(ur_[1]), c(ur_[4]), vis_lower_bound, vis_upper_bound, dout,
+                       (unsigned long long)(dout ? cap : 0), &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  const int64_t n = (int64_t)read_counter(C_SCRATCH);
+  if (dout && n) FIESTA_HIP_CHECK(hipMemcpyAsync(xyz, dout, (size_t)std::min(n, cap) * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  return n;
+}
+
+int64_t HashMap::slice_marker(int slice, double max_dist, double *xyz, float *rgba, int64_t cap) {
+  use_device();
+  zero_counter(C_SCRATCH);
+  double *dx = nullptr;
+  float *dc = nullptr;
+  if (xyz && rgba && cap > 0) {
+    stage_a_.ensure((size_t)cap * 3 * sizeof(double), stream_);
+    stage_b_.ensure((size_t)cap * 4 * sizeof(float), stream_);
+    dx = (double *)stage_a_.p, dc = (float *)stage_b_.p;
+  }
+  auto c = [](int64_t v) { return (int)std::min<int64_t>(std::max<int64_t>(v, -(1ll << 30)), 1ll << 30); };
+  if (npages_)
+    hipLaunchKernelGGL(k_h_slice_marker, dim3(grid_for(npages_ * kPageRows, 256, 8192)), dim3(256), 0, stream_, g_,
+                       (const int32_t *)page_gtile_.p, npages_, (const vox_t *)coc_.p, c(ur_[0]), c(ur_[3]), c(ur_[1]), c(ur_[4]), slice,
+                       max_dist, dx, dc, (unsigned long long)(dx ? cap : 0), &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  const int64_t n = (int64_t)read_counter(C_SCRATCH);
+  if (dx && n) {
+    const size_t k = (size_t)std::min(n, cap);
+    FIESTA_HIP_CHECK(hipMemcpyAsync(xyz, dx, k * 3 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(rgba, dc, k * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  }
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   return n;
 }

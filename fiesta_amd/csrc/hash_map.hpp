@@ -70,6 +70,9 @@ class HashMap {
   // every voxel of every allocated page, page order: vox (map voxel coordinates), d2, coc, occ; returns the count
   int64_t download(int32_t *vox, int32_t *d2, int32_t *coc, uint8_t *occ);
   void download_counts(int32_t *num_hit, int32_t *num_miss);  // same order as download()
+  void checkpoint(const char *path, bool write);  // raw dump / load of the whole state (checkpoint.hpp)
+  int64_t point_cloud(int vis_lower_bound, int vis_upper_bound, float *xyz, int64_t cap);  // GetPointCloud, as arrays
+  int64_t slice_marker(int slice, double max_dist, double *xyz, float *rgba, int64_t cap);  // GetSliceMarker
   void synchronize();
 
  private:
@@ -79,6 +82,7 @@ class HashMap {
   void move_window(const int32_t origin[3]);
   void refresh_range();
   void ensure_pages(int64_t need_total);
+  void pristine_pages(int64_t first, int64_t count);
   bool allocate_marked();
   unsigned long long read_counter(int which);
   void zero_counter(int which);

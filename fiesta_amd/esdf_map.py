@@ -11,6 +11,7 @@ bench read like the reference's own driver (test/test_ESDF_Map.cpp:42-104).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -242,6 +243,32 @@ class ESDFMap:
         out = np.empty(self.grid_size[:2], np.float64)
         check(self._lib.fiesta_hip_get_slice(self._h, int(z_vox), _p(out)))
         return out
+
+    def save(self, path: str):
+        """Raw checkpoint of the whole map state (include/fiesta_hip.h: fiesta_hip_save)."""
+        check(self._lib.fiesta_hip_save(self._h, os.fsencode(path)))
+
+    def load(self, path: str):
+        check(self._lib.fiesta_hip_load(self._h, os.fsencode(path)))
+
+    def GetPointCloud(self, vis_lower_bound: int, vis_upper_bound: int) -> np.ndarray:
+        """ESDFMap::GetPointCloud (src/ESDFMap.cpp:544-582) as an (n, 3) float32 array of voxel centres (unordered)."""
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_get_point_cloud(self._h, vis_lower_bound, vis_upper_bound, None, 0, C.byref(n)))
+        out = np.empty((n.value, 3), np.float32)
+        if n.value:
+            check(self._lib.fiesta_hip_get_point_cloud(self._h, vis_lower_bound, vis_upper_bound, _p(out), n.value, C.byref(n)))
+        return out
+
+    def GetSliceMarker(self, slice_z: int, max_dist: float):
+        """ESDFMap::GetSliceMarker (src/ESDFMap.cpp:639-699): (points (n,3) float64, colours (n,4) float32), unordered."""
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_get_slice_marker(self._h, slice_z, max_dist, None, None, 0, C.byref(n)))
+        xyz = np.empty((n.value, 3), np.float64)
+        rgba = np.empty((n.value, 4), np.float32)
+        if n.value:
+            check(self._lib.fiesta_hip_get_slice_marker(self._h, slice_z, max_dist, _p(xyz), _p(rgba), n.value, C.byref(n)))
+        return xyz, rgba
 
     def download_counts(self):
         """Pending (num_hit_, num_miss_) per voxel; num_miss_ counts all observations (src/ESDFMap.cpp:424)."""

@@ -4,8 +4,8 @@
 // constructors, SetParameters, CheckUpdate, UpdateOccupancy, UpdateESDF, SetOccupancy x2, GetOccupancy x2,
 // GetDistance x2, GetDistWithGradTrilinear, SetUpdateRange, SetOriginalRange, the public data member
 // grid_total_size_, CheckConsistency / CheckWithGroundTruth.  The ROS-typed visualisation getters
-// (GetPointCloud / GetSliceMarker, :144-145) are replaced by plain-array equivalents (GetOccupiedVoxels,
-// GetSlice) that a ROS adapter can wrap -- there is no ROS in this build.
+// (GetPointCloud / GetSliceMarker, :144-145) are templates on the message type -- there is no ROS in this build -- next
+// to plain-array equivalents (GetOccupiedVoxels, GetSlice).
 //
 // Header-only and free of HIP types: everything goes through the C ABI of include/fiesta_hip.h.  Array vs
 // hash-block storage is a RUNTIME choice (the constructor overload), not the reference's -DHASH_TABLE macro.
@@ -158,6 +158,46 @@ class ESDFMap {
     for (int64_t i = 0; i < n; ++i)  // voxel centres, as GetPointCloud emits them (src/ESDFMap.cpp:560-575)
       centres->push_back(Eigen::Vector3d((vox[3 * i] + 0.5) * res_ + origin_[0], (vox[3 * i + 1] + 0.5) * res_ + origin_[1],
                                          (vox[3 * i + 2] + 0.5) * res_ + origin_[2]));
+  }
+  // The reference's own getters (include/ESDFMap.h:144-145, src/ESDFMap.cpp:544-699).  The message types are template
+  // parameters so that this header builds without ROS; sensor_msgs::PointCloud and visualization_msgs::Marker fit as
+  // they are (fields used: header.frame_id, points[i].x/y/z, and for the marker id, type, action, scale, pose.orientation,
+  // colors[i].r/g/b/a).  Filtering, Vox2Pos and the rainbow run on the device; the order of the points is unspecified.
+  template <class PointCloudMsg>
+  void GetPointCloud(PointCloudMsg &m, int vis_lower_bound, int vis_upper_bound) {
+    Flush();
+    m.header.frame_id = "world";
+    m.points.clear();
+    int64_t n = 0;
+    ck(fiesta_hip_get_point_cloud(h_, vis_lower_bound, vis_upper_bound, nullptr, 0, &n));
+    std::vector<float> xyz((size_t)3 * n);
+    if (n) ck(fiesta_hip_get_point_cloud(h_, vis_lower_bound, vis_upper_bound, xyz.data(), n, &n));
+    m.points.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) m.points[i].x = xyz[3 * i], m.points[i].y = xyz[3 * i + 1], m.points[i].z = xyz[3 * i + 2];
+  }
+  template <class MarkerMsg, class Color /* Eigen::Vector4d; the reference ignores it too */>
+  void GetSliceMarker(MarkerMsg &m, int slice, int id, Color /*color*/, double max_dist) {
+    Flush();
+    m.header.frame_id = "world";
+    m.id = id;
+    m.type = MarkerMsg::POINTS;
+    m.action = MarkerMsg::MODIFY;
+    m.scale.x = m.scale.y = m.scale.z = res_;
+    m.pose.orientation.w = 1;
+    m.pose.orientation.x = m.pose.orientation.y = m.pose.orientation.z = 0;
+    m.points.clear();
+    m.colors.clear();
+    int64_t n = 0;
+    ck(fiesta_hip_get_slice_marker(h_, slice, max_dist, nullptr, nullptr, 0, &n));
+    std::vector<double> xyz((size_t)3 * n);
+    std::vector<float> rgba((size_t)4 * n);
+    if (n) ck(fiesta_hip_get_slice_marker(h_, slice, max_dist, xyz.data(), rgba.data(), n, &n));
+    m.points.resize((size_t)n);
+    m.colors.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+      m.points[i].x = xyz[3 * i], m.points[i].y = xyz[3 * i + 1], m.points[i].z = xyz[3 * i + 2];
+      m.colors[i].r = rgba[4 * i], m.colors[i].g = rgba[4 * i + 1], m.colors[i].b = rgba[4 * i + 2], m.colors[i].a = rgba[4 * i + 3];
+    }
   }
   // distances of the plane z = z_vox, nx * ny values, x-major (the data behind GetSliceMarker)
   void GetSlice(int z_vox, std::vector<double> *dist) {

@@ -224,6 +224,13 @@ int fiesta_hip_download_field(fiesta_hip_map *m, int32_t *d2, int32_t *coc, uint
  * since the last UpdateOccupancy), dense order (hash-block maps: the order of fiesta_hip_download_hash); each output
  * nullable. */
 int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num_miss);
+/* Checkpoint: the whole map state (closest-obstacle field, log-odds, pending observation counters, occupancy bits,
+ * insert/delete queues, update ranges; hash-block maps: the page pool, the directory and the window position) written
+ * to / read from a raw file, streamed through a pinned buffer.  A file loads only into a map created with the same
+ * mode, origin, resolution and grid (array mode: same shard); afterwards the map behaves exactly like the one that
+ * was saved.  The reference has no counterpart (its state dies with the node). */
+int fiesta_hip_save(fiesta_hip_map *m, const char *path);
+int fiesta_hip_load(fiesta_hip_map *m, const char *path);
 /* Visualisation exports, compacted / sliced on the device (reference: ESDFMap::GetPointCloud and GetSliceMarker,
  * src/ESDFMap.cpp:544-699, which fill ROS messages -- a ROS adapter wraps these two calls).
  * get_occupied_voxels: map voxel coordinates of every occupied voxel, at most `capacity` triples are written,
@@ -231,6 +238,20 @@ int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num
  * get_slice: GetDistance(Vector3i) for every (x, y) of the plane z = z_vox, nx * ny doubles, x-major. */
 int fiesta_hip_get_occupied_voxels(fiesta_hip_map *m, int32_t *vox, int64_t capacity, int64_t *n_out);
 int fiesta_hip_get_slice(fiesta_hip_map *m, int32_t z_vox, double *out);
+/* The two getters themselves, filtered and converted on the device exactly as the reference fills its messages (array
+ * and hash-block maps; the C++ class include/fiesta/ESDFMap.h fills any message type with the reference's field names):
+ * get_point_cloud   ESDFMap::GetPointCloud(m, vis_lower_bound, vis_upper_bound), src/ESDFMap.cpp:544-582: voxel centres
+ *                   (float xyz, like geometry_msgs::Point32) of the occupied voxels inside the update range whose z
+ *                   INDEX lies in [vis_lower_bound, vis_upper_bound];
+ * get_slice_marker  ESDFMap::GetSliceMarker(m, slice, id, color, max_dist), :639-699: centres (double xyz) and colours
+ *                   (float rgba, the rainbow of :584-636) of the voxels of plane z = slice inside the x/y update range
+ *                   that hold a defined, finite distance.
+ * At most `capacity` entries are written, *n_out is the total (size the buffers with capacity 0). The reference's
+ * message order (x, y, z lexicographic / allocation order) is not reproduced: a point set is unordered. */
+int fiesta_hip_get_point_cloud(fiesta_hip_map *m, int32_t vis_lower_bound, int32_t vis_upper_bound, float *xyz,
+                               int64_t capacity, int64_t *n_out);
+int fiesta_hip_get_slice_marker(fiesta_hip_map *m, int32_t slice, double max_dist, double *xyz, float *rgba,
+                                int64_t capacity, int64_t *n_out);
 /* Hash mode: allocated voxels in allocation order (vox n x 3); with all outputs NULL only *n_out is set. */
 int fiesta_hip_download_hash(fiesta_hip_map *m, int64_t *n_out, int32_t *vox, int32_t *d2, int32_t *coc,
                              uint8_t *occ);

@@ -580,6 +580,86 @@ int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc
 }
 int oracle_check_consistency(oracle_map *m) { return m->p.lists_consistent(); }
 
+// GetPointCloud (src/ESDFMap.cpp:544-582), restated: occupied voxels inside the update range (hash flavour: x and y
+// only) whose z index lies within the visualisation bounds, as voxel centres narrowed to float (Point32).
+int64_t oracle_get_point_cloud(oracle_map *m, int vis_lower_bound, int vis_upper_bound, float *xyz, int64_t cap) {
+  Port &p = m->p;
+  int64_t n = 0;
+  auto emit = [&](I3 v) {
+    double c[3];
+    p.vox2pos(v, c);
+    if (n < cap) xyz[3 * n] = (float)c[0], xyz[3 * n + 1] = (float)c[1], xyz[3 * n + 2] = (float)c[2];
+    ++n;
+  };
+  if (p.mode == 1) {
+    for (int s = 1; s < p.count; ++s) {
+      const I3 v = p.slot_vox[s];
+      if (!p.occupied(s) || v.z < vis_lower_bound || v.z > vis_upper_bound || v.x < p.wmin.x || v.x > p.wmax.x ||
+          v.y < p.wmin.y || v.y > p.wmax.y)
+        continue;
+      emit(v);
+    }
+  } else {
+    for (int x = p.wmin.x; x <= p.wmax.x; ++x)
+      for (int y = p.wmin.y; y <= p.wmax.y; ++y)
+        for (int z = p.wmin.z; z <= p.wmax.z; ++z) {
+          if (!p.occupied(p.slot({x, y, z})) || z < vis_lower_bound || z > vis_upper_bound) continue;
+          emit({x, y, z});
+        }
+  }
+  return n;
+}
+// The rainbow of GetSliceMarker (src/ESDFMap.cpp:584-636): hue h in [0,1) around the colour circle at full
+// saturation and value.
+static void rainbow(double h, float *rgba) {
+  h -= std::floor(h);
+  h *= 6;
+  const int i = (int)std::floor(h);
+  double f = h - i;
+  if (!(i & 1)) f = 1 - f;
+  const double hi = 1.0, mid = 1.0 - f, lo = 0.0;
+  double r, g, b;
+  switch (i) {
+    case 1: r = mid, g = hi, b = lo; break;
+    case 2: r = lo, g = hi, b = mid; break;
+    case 3: r = lo, g = mid, b = hi; break;
+    case 4: r = mid, g = lo, b = hi; break;
+    case 5: r = hi, g = lo, b = mid; break;
+    default: r = hi, g = mid, b = lo; break;  // 0 and 6
+  }
+  rgba[0] = (float)r, rgba[1] = (float)g, rgba[2] = (float)b, rgba[3] = 1.0f;
+}
+// GetSliceMarker (src/ESDFMap.cpp:639-699), restated: voxels of the plane z = slice inside the x/y update range with a
+// finite, defined distance; colour = rainbow(min(d / max_dist, 1)).
+int64_t oracle_get_slice_marker(oracle_map *m, int slice, double max_dist, double *xyz, float *rgba, int64_t cap) {
+  Port &p = m->p;
+  int64_t n = 0;
+  auto emit = [&](I3 v, double d) {
+    if (n < cap) {
+      p.vox2pos(v, xyz + 3 * n);
+      rainbow(d <= max_dist ? d / max_dist : 1, rgba + 4 * n);
+    }
+    ++n;
+  };
+  if (p.mode == 1) {
+    for (int s = 1; s < p.count; ++s) {
+      const I3 v = p.slot_vox[s];
+      if (v.z != slice || p.dist[s] < 0 || p.dist[s] >= (double)kInf || v.x < p.wmin.x || v.x > p.wmax.x || v.y < p.wmin.y ||
+          v.y > p.wmax.y)
+        continue;
+      emit(v, p.dist[s]);
+    }
+  } else {
+    for (int x = p.wmin.x; x <= p.wmax.x; ++x)
+      for (int y = p.wmin.y; y <= p.wmax.y; ++y) {
+        const int s = p.slot({x, y, slice});
+        if (p.dist[s] < 0 || p.dist[s] >= (double)kInf) continue;
+        emit({x, y, slice}, p.dist[s]);
+      }
+  }
+  return n;
+}
+
 int oracle_raycast(const double start[3], const double end[3], const double minv[3], const double maxv[3],
                    double *out, int cap) {
   std::vector<I3> v;

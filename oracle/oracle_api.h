@@ -72,6 +72,13 @@ int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc
 
 int oracle_check_consistency(oracle_map *m); /* CheckConsistency(), src/ESDFMap.cpp:856-902 */
 
+/* GetPointCloud(m, vis_lower_bound, vis_upper_bound), src/ESDFMap.cpp:544-582: the points of the message (float xyz,
+ * message order), at most cap written; returns the number the reference produced. */
+int64_t oracle_get_point_cloud(oracle_map *m, int vis_lower_bound, int vis_upper_bound, float *xyz, int64_t cap);
+/* GetSliceMarker(m, slice, id, color, max_dist), src/ESDFMap.cpp:639-699: points (double xyz) and colours (float
+ * rgba) of the marker, message order; returns the number the reference produced. */
+int64_t oracle_get_slice_marker(oracle_map *m, int slice, double max_dist, double *xyz, float *rgba, int64_t cap);
+
 /* Raycast(start,end,min,max,&out), src/raycast.cpp:56-158; all in voxel units. Writes at most cap voxels
  * (3 doubles each), returns the number the reference produced, or -1 if it threw (>1500 voxels). */
 int oracle_raycast(const double start[3], const double end[3], const double minv[3], const double maxv[3],

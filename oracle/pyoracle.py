@@ -89,6 +89,8 @@ def _load(kind: str, mode: str):
         "oracle_dump_counts": (None, [vp, vp, vp]),
         "oracle_dump_hash": (i64, [vp, vp, vp, vp, vp]),
         "oracle_check_consistency": (i32, [vp]),
+        "oracle_get_point_cloud": (i64, [vp, i32, i32, vp, i64]),
+        "oracle_get_slice_marker": (i64, [vp, i32, C.c_double, vp, vp, i64]),
         "oracle_raycast": (i32, [vp, vp, vp, vp, vp, i32]),
         "oracle_raycast_frame": (None, [vp, vp, i64, vp, vp, vp]),
         "oracle_depth_conversion": (i64, [vp, vp, i32, i32, dbl, dbl, dbl, dbl, i32, vp, dbl, dbl, dbl, i32, vp]),
@@ -241,6 +243,19 @@ class OracleMap:
 
     def CheckConsistency(self):
         return bool(self.lib.oracle_check_consistency(self.h))
+
+    def GetPointCloud(self, vis_lower_bound, vis_upper_bound):
+        n = int(self.lib.oracle_get_point_cloud(self.h, vis_lower_bound, vis_upper_bound, None, 0))
+        out = np.empty((n, 3), np.float32)
+        self.lib.oracle_get_point_cloud(self.h, vis_lower_bound, vis_upper_bound, _p(out), n)
+        return out
+
+    def GetSliceMarker(self, slice_z, max_dist):
+        n = int(self.lib.oracle_get_slice_marker(self.h, slice_z, max_dist, None, None, 0))
+        xyz = np.empty((n, 3), np.float64)
+        rgba = np.empty((n, 4), np.float32)
+        self.lib.oracle_get_slice_marker(self.h, slice_z, max_dist, _p(xyz), _p(rgba), n)
+        return xyz, rgba
 
     def raycast_frame(self, points, transform, origin, min_ray, max_ray, l_cornor, r_cornor):
         pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)

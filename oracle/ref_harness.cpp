@@ -259,6 +259,23 @@ int oracle_check_consistency(oracle_map *m) {
   return m->map->CheckConsistency() ? 1 : 0;
 }
 
+int64_t oracle_get_point_cloud(oracle_map *m, int vis_lower_bound, int vis_upper_bound, float *xyz, int64_t cap) {
+  sensor_msgs::PointCloud pc;
+  m->map->GetPointCloud(pc, vis_lower_bound, vis_upper_bound);
+  for (size_t i = 0; i < pc.points.size() && (int64_t)i < cap; ++i)
+    xyz[3 * i] = pc.points[i].x, xyz[3 * i + 1] = pc.points[i].y, xyz[3 * i + 2] = pc.points[i].z;
+  return (int64_t)pc.points.size();
+}
+int64_t oracle_get_slice_marker(oracle_map *m, int slice, double max_dist, double *xyz, float *rgba, int64_t cap) {
+  visualization_msgs::Marker mk;
+  m->map->GetSliceMarker(mk, slice, 0, Eigen::Vector4d(0, 0, 0, 1), max_dist);
+  for (size_t i = 0; i < mk.points.size() && (int64_t)i < cap; ++i) {
+    xyz[3 * i] = mk.points[i].x, xyz[3 * i + 1] = mk.points[i].y, xyz[3 * i + 2] = mk.points[i].z;
+    rgba[4 * i] = mk.colors[i].r, rgba[4 * i + 1] = mk.colors[i].g, rgba[4 * i + 2] = mk.colors[i].b, rgba[4 * i + 3] = mk.colors[i].a;
+  }
+  return (int64_t)mk.points.size();
+}
+
 int oracle_raycast(const double start[3], const double end[3], const double minv[3], const double maxv[3],
                    double *out, int cap) {
   std::vector<Eigen::Vector3d> o;

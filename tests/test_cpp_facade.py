@@ -47,6 +47,8 @@ def test_pillars_demo_matches_oracle(tmp_path, oracle_libs, best_oracle_kind):
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     assert "grid_total_size_ 62500" in out and out.count("consistent 1") == 2, out
     assert "distinct keys 62500" in out, out
+    # GetPointCloud(m, 0, 9): 12 standing pillars x 10 layers; GetSliceMarker(m, 3, ...): the whole 50 x 50 plane is finite
+    assert "cloud 120 in world, slice marker 7: 2500 points, type 8" in out, out
     got = [float(x) for x in re.search(r"checksum (\S+) trilinear (\S+) grad (\S+) (\S+) (\S+)", out).groups()]
     assert "outside -10000.0 -10000" in out
     # the same workload on the oracle

@@ -344,3 +344,38 @@ def test_visualisation_exports(hip_lib, oracle_libs, best_oracle_kind):
         assert np.array_equal(b.gpu.GetSlice(z), d)
     with pytest.raises(Exception):
         b.gpu.GetSlice(gs[2])
+
+
+def _rows_sorted(a):
+    a = np.asarray(a)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def check_vis_getters(gpu, cpu, slices, bounds, max_dist=1.3):
+    """GetPointCloud / GetSliceMarker (src/ESDFMap.cpp:544-699): the same points (float / double bit patterns) and the
+    same colour per point as the reference's messages; only the order is free."""
+    total = 0
+    for lo, hi in bounds:
+        a, b = gpu.GetPointCloud(lo, hi), cpu.GetPointCloud(lo, hi)
+        assert a.shape == b.shape and np.array_equal(_rows_sorted(a), _rows_sorted(b))
+        total += len(a)
+    for z in slices:
+        (pa, ca), (pb, cb) = gpu.GetSliceMarker(z, max_dist), cpu.GetSliceMarker(z, max_dist)
+        ja, jb = np.concatenate([pa, ca.astype(np.float64)], 1), np.concatenate([pb, cb.astype(np.float64)], 1)
+        assert ja.shape == jb.shape and np.array_equal(_rows_sorted(ja), _rows_sorted(jb))
+        total += len(pa)
+    return total
+
+
+def test_visualisation_getters_match_the_reference_messages(hip_lib, oracle_libs, best_oracle_kind):
+    n = 40
+    b = make_pair(oracle_libs, best_oracle_kind, (n, 33, 37))
+    observe_all(b)
+    gs = b.gpu.grid_size
+    b.make_occupied((np.random.RandomState(4).rand(300, 3) * gs).astype(np.int32))
+    b.esdf()
+    assert check_vis_getters(b.gpu, b.cpu, (0, 17, gs[2] - 1), ((0, 100), (5, 9), (7, 7), (50, 60), (-5, 3))) > 4000
+    lo, hi = np.array([0.7, 0.4, 0.9]), np.array([2.9, 2.2, 2.6])
+    for m in (b.gpu, b.cpu):                      # the getters only show the update range (min_vec_ .. max_vec_)
+        m.SetUpdateRange(tuple(lo), tuple(hi))
+    assert 0 < check_vis_getters(b.gpu, b.cpu, (11, 17), ((0, 100), (12, 20))) < 3000

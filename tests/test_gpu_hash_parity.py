@@ -204,6 +204,22 @@ def test_hash_c4_stream_box_observe(hip_lib, oracle_libs, best_oracle_kind):
     assert rep["finite"] > 500000 and rep["d2_mismatch"] <= 0.02 * rep["finite"], rep
 
 
+def test_hash_visualisation_getters(hip_lib, oracle_libs, best_oracle_kind):
+    """GetPointCloud / GetSliceMarker on the block store (src/ESDFMap.cpp:547-566, 657-677) against the reference's own
+    messages, with and without an update range."""
+    from test_gpu_dense_parity import check_vis_getters
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.3, -0.2, 0.1), 0.1, 1000)
+    n = 36
+    g = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3).astype(np.int32) - 11
+    cycles(gpu, cpu, [], g, 1)
+    S = (np.random.RandomState(8).randint(0, n, (200, 3)) - 11).astype(np.int32)
+    cycles(gpu, cpu, S, [], 3)
+    assert check_vis_getters(gpu, cpu, (-11, 0, 13), ((-100, 100), (-3, 4), (5, 5), (60, 70))) > 3000
+    for m in (gpu, cpu):
+        m.SetUpdateRange((0.0, -0.5, -0.3), (1.9, 1.4, 1.6))
+    assert 0 < check_vis_getters(gpu, cpu, (0, 13), ((-100, 100), (2, 9))) < 3000
+
+
 def _island(c, half, rng, n_obst):
     lo = np.asarray(c) - half
     box = np.stack(np.meshgrid(*[np.arange(2 * h) for h in half], indexing="ij"), -1).reshape(-1, 3).astype(np.int32) + lo

@@ -136,6 +136,35 @@ def test_hash_flavour(pair_factory):
         assert np.array_equal(a[k], b[k]), k
 
 
+def _vis_same(ms, slices, bounds):
+    for lo, hi in bounds:
+        a, b = both(ms, lambda m: m.GetPointCloud(lo, hi))
+        assert np.array_equal(a, b)            # message order included
+    for z in slices:
+        (pa, ca), (pb, cb) = both(ms, lambda m: m.GetSliceMarker(z, 1.3))
+        assert np.array_equal(pa, pb) and np.array_equal(ca, cb)
+    return len(a), len(pa)
+
+
+@pytest.mark.parametrize("mode", ["array", "hash"])
+def test_visualisation_getters(pair_factory, mode):
+    """GetPointCloud / GetSliceMarker (src/ESDFMap.cpp:544-699): points, colours and message order of the restatement
+    against the reference's own functions (compiled against the message stand-ins of oracle/shim)."""
+    n, res = 24, 0.2
+    ms = pair_factory((-1.0, 0.5, 0.0), res, (n * res,) * 3, mode=mode, reserve=20000)
+    cycles(ms, [], all_voxels(n), 1)
+    esdf_same(ms)
+    S = np.random.RandomState(3).randint(2, n - 2, (90, 3)).astype(np.int32)
+    cycles(ms, S, [], 3)
+    esdf_same(ms)
+    npc, nsl = _vis_same(ms, (3, 11), ((0, n), (5, 9), (7, 7), (30, 40)))
+    assert nsl > 0
+    for m in ms:
+        m.SetUpdateRange((0.0, 1.0, 0.4), (2.5, 3.1, 3.0))
+    npc, nsl = _vis_same(ms, (3, 11), ((0, n), (5, 9)))
+    assert 0 < nsl < n * n
+
+
 def test_raycast_free_function(oracle_libs, pair_factory):
     rng = np.random.RandomState(0)
     lo, hi = np.array([-20.0, -20.0, -5.0]), np.array([20.0, 20.0, 5.0])
