@@ -1130,7 +1130,7 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   int rlo[3], rhi[3], mlo[3], mhi[3];  // region in GLOBAL coordinates (inclusive); margins actually obtained per side
   const int l0[3] = {g.gx0, g.gy0, g.gz0}, ln[3] = {g.nx, g.ny, g.nz}, G[3] = {g.GX, g.GY, g.GZ};
   bool open_side = false;  // some side of the region does not reach the global boundary (needs the margin test)
-  bool wide = g.wrap != 0;  // site packing of the transform (ft_kernels.hpp: FtMetricB)
+  bool wide = g.wrap != 0;  // site packing of the transform (ft_kernels.hpp: FtPack)
   for (int k = 0; k < 3; ++k) {
     rlo[k] = g.sharded ? std::max(0, l0[k] - margin) : l0[k];
     rhi[k] = g.sharded ? std::min(G[k] - 1, l0[k] + ln[k] - 1 + margin) : l0[k] + ln[k] - 1;
@@ -1211,11 +1211,12 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
     t.ovf_list = nullptr, t.ovf_count = nullptr;                                                   \
     launch_ft_x<LASTS, LASTL, 1, WIDE>(t, 1024, stream_);                                          \
   }
-    // the last tier's ring holds a whole column: it cannot overflow (1024 entries x 16 lanes, wide: 2048 x 8)
+    // the last tier's ring holds more entries than a column has positions (a ring of S holds S - 1): it cannot overflow
+    // (2048 slots x 8 lanes for columns up to 1024, wide: 4096 x 4 for columns up to 2048)
     if (wide) {
-      FIESTA_FT_TIERS(true, 2048, 8)
+      FIESTA_FT_TIERS(true, 4096, 4)
     } else {
-      FIESTA_FT_TIERS(false, 1024, 16)
+      FIESTA_FT_TIERS(false, 2048, 8)
     }
 #undef FIESTA_FT_TIERS
     FIESTA_HIP_CHECK(hipGetLastError());

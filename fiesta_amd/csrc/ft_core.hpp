@@ -60,80 +60,88 @@ FT_HD int floor_div_small(int N, int D) {
   return q;
 }
 
-// Ring:   uint32_t site(int i), void set(int i, uint32_t site, int start), int start(int i)   (i already < S)
-// Metric: int q(uint32_t site) position along the column, int f(uint32_t site) height; both pure
+// An envelope ENTRY is (q, f, tag): position along the column, height, and an opaque 20-bit tag that comes back when the
+// entry wins a position (pass A: the z of the site; pass B: its packed (y', z')).  In the ring an entry is two words,
+//     e1 = f << 11 | q            (q < 2048, f < 2^21)
+//     e2 = tag << 12 | start      (start < 4096: the first position the entry wins)
+// so that a pop or an advance is ONE 8-byte LDS read and a handful of shifts -- the first layout (packed site + 16-bit
+// start) re-derived q and f from the site's coordinates on every pop, a third of the instructions of a step.
+// Ring:   void get(int i, uint32_t &e1, uint32_t &e2), uint32_t second(int i), void set(int i, uint32_t e1, uint32_t e2)
+//         (i already < S)
 //
 // The operations are written for a WAVE that runs 64 envelopes in lock-step: no data-dependent branch inside -- every
 // lane executes every instruction, lanes that have nothing to do pass `doit = false` and get their state back through
 // selects -- and the loops around them (pop until no lane wants to, emit while every lane is final) are decided by
 // wave votes in the caller.  On the GPU that keeps the control flow scalar (the first version, with per-lane `while`
 // and `if`, compiled to ~700 instructions per step, most of them exec-mask bookkeeping; this form needs ~150).
-template <int S, class Ring, class Metric>
+constexpr int kQBits = 11, kStartBits = 12;
+template <int S, class Ring>
 struct LaneEnvelope {
   static_assert((S & (S - 1)) == 0, "ring size must be a power of two");
   Ring r;
-  Metric m;
   int bot, top;  // live entries are bot..top (monotone counters, ring slot = counter & (S-1)); empty iff top < bot
   // cached entries: position q and key = q^2 + f(q), so that cost(p) = p (p - 2 q) + key
-  uint32_t t_site, c_site;  // top entry; entry `bot` = the winner at the emission point
-  int t_q, t_key, t_s, c_q, c_key;
+  int t_q, t_key, t_s;  // top entry
+  uint32_t t_tag;
+  int c_q, c_key;       // entry `bot` = the winner at the emission point
+  uint32_t c_tag;
   int n_s;  // start of entry `bot + 1` (kNoStart: there is none)
   bool overflow;
 
   FT_HD void init() {
     bot = 0;
     top = -1;
-    t_site = c_site = 0;
+    t_tag = c_tag = 0;
     t_q = t_key = t_s = c_q = c_key = 0;
     n_s = kNoStart;
     overflow = false;
   }
   FT_HD bool empty() const { return top < bot; }
   FT_HD int depth() const { return top - bot + 1; }
-  FT_HD int key_of(uint32_t site) const {
-    const int q = m.q(site);
-    return mul24(q, q) + m.f(site);
-  }
+  static FT_HD int key_of(int q, int f) { return mul24(q, q) + f; }
 
   // ---- a new site at position q (beyond every site pushed before), key = q^2 + f: pop while any lane wants to,
   // then place.  The newcomer beats the top strictly at p  <=>  p * D > N  <=>  p >= floor(N / D) + 1.
   FT_HD bool wants_pop(int q, int key) const {
     const int D = 2 * (q - t_q), N = key - t_key;
-    return top >= bot && N < mul24(t_s, D);  // ... already at the top's first position: the top wins nowhere
+    return (top >= bot) & (N < mul24(t_s, D));  // ... already at the top's first position: the top wins nowhere
+    // (`&`, not `&&`, here and below: a short circuit becomes an exec-mask region with its scalar bookkeeping)
   }
   FT_HD void pop(bool doit) {
-    const int nt = top - 1, i = nt & (S - 1);
-    const uint32_t rs = r.site(i);  // (below the bottom this is a stale slot: read, not used)
-    const int rst = r.start(i);
-    const bool ld = doit && nt >= bot;
+    const int nt = top - 1;
+    uint32_t e1, e2;
+    r.get(nt & (S - 1), e1, e2);  // (below the bottom this is a stale slot: read, not used)
+    const bool ld = doit & (nt >= bot);
     top = doit ? nt : top;
-    const int nq = m.q(rs), nk = mul24(nq, nq) + m.f(rs);
-    t_site = ld ? rs : t_site;
-    t_s = ld ? rst : t_s;
+    const int nq = (int)(e1 & ((1u << kQBits) - 1u));
     t_q = ld ? nq : t_q;
-    t_key = ld ? nk : t_key;
+    t_key = ld ? mul24(nq, nq) + (int)(e1 >> kQBits) : t_key;
+    t_s = ld ? (int)(e2 & ((1u << kStartBits) - 1u)) : t_s;
+    t_tag = ld ? e2 >> kStartBits : t_tag;
   }
   // n_pos = column length, p_out = the next position to be emitted (everything before it is final and gone)
-  FT_HD void place(bool doit, uint32_t site, int q, int key, int n_pos, int p_out) {
+  FT_HD void place(bool doit, int q, int f, uint32_t tag, int key, int n_pos, int p_out) {
     const bool has = top >= bot;
     const int D = has ? 2 * (q - t_q) : 2, N = key - t_key;
-    const bool inside = !has || N < mul24(n_pos, D);  // else it beats the top only beyond the last position
-    const int sq = floor_div_small((has && inside) ? N : 0, D) + 1;  // (no lane wants a pop: N >= t_s * D >= 0)
+    const bool inside = !has | (N < mul24(n_pos, D));  // else it beats the top only beyond the last position
+    const int sq = floor_div_small((has & inside) ? N : 0, D) + 1;  // (no lane wants a pop: N >= t_s * D >= 0)
     const int s = has ? sq : p_out;  // alone, it owns everything that is not emitted yet
-    bool keep = doit && inside;
-    const bool ovf = keep && top - bot + 1 >= S;
-    overflow = overflow || ovf;
-    keep = keep && !ovf;
+    bool keep = doit & inside;
+    const bool ovf = keep & (top - bot + 1 >= S - 1);  // one slot stays free, see below
+    overflow = overflow | ovf;
+    keep = keep & !ovf;
     const int ntop = top + 1;
-    if (keep) r.set(ntop & (S - 1), site, s);
+    // every lane stores, no branch around it: the slot after the top is never live (at most S - 1 entries), a lane that
+    // keeps nothing just leaves a stale entry there
+    r.set(ntop & (S - 1), ((uint32_t)f << kQBits) | (uint32_t)q, (tag << kStartBits) | (uint32_t)s);
     top = keep ? ntop : top;
-    t_site = keep ? site : t_site;
+    t_tag = keep ? tag : t_tag;
     t_q = keep ? q : t_q;
     t_key = keep ? key : t_key;
     t_s = keep ? s : t_s;
     // the cached bottom follows pops and the push
     const bool one = top == bot;
-    c_site = one ? t_site : c_site;
+    c_tag = one ? t_tag : c_tag;
     c_q = one ? t_q : c_q;
     c_key = one ? t_key : c_key;
     n_s = top == bot + 1 ? t_s : (top <= bot ? kNoStart : n_s);
@@ -144,23 +152,25 @@ struct LaneEnvelope {
   // beats the released entry at p too, so the released entry never owns p again.
   FT_HD bool wants_advance(int p) const { return n_s <= p; }
   FT_HD void advance(bool doit) {
-    const int nb = bot + 1, i = nb & (S - 1), j = (nb + 1) & (S - 1);
-    const uint32_t rs = r.site(i);
-    const int rst = r.start(j);
-    const int nq = m.q(rs), nk = mul24(nq, nq) + m.f(rs);
+    const int nb = bot + 1;
+    uint32_t e1, e2;
+    r.get(nb & (S - 1), e1, e2);
+    const int rst = (int)(r.second((nb + 1) & (S - 1)) & ((1u << kStartBits) - 1u));
+    const int nq = (int)(e1 & ((1u << kQBits) - 1u));
     bot = doit ? nb : bot;
-    c_site = doit ? rs : c_site;
+    c_tag = doit ? e2 >> kStartBits : c_tag;
     c_q = doit ? nq : c_q;
-    c_key = doit ? nk : c_key;
+    c_key = doit ? mul24(nq, nq) + (int)(e1 >> kQBits) : c_key;
     n_s = doit ? (nb < top ? rst : kNoStart) : n_s;
   }
   // Is the winner at position p settled, given that every site still to come lies at x_next or beyond (p < x_next)?
   // (after advance: the winner is the bottom entry)
   FT_HD bool final_at(int p, int x_next) const {
     const int g = mul24(p, p - 2 * c_q) + c_key, dx = x_next - p;
-    return top >= bot && dx * dx >= g;
+    return (top >= bot) & (dx * dx >= g);
   }
-  FT_HD uint32_t winner() const { return c_site; }
+  FT_HD int winner_q() const { return c_q; }
+  FT_HD uint32_t winner_tag() const { return c_tag; }
   FT_HD int winner_cost(int p) const { return mul24(p, p - 2 * c_q) + c_key; }
 };
 

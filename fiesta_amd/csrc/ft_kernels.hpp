@@ -21,7 +21,7 @@
 namespace fiesta {
 
 // The transform runs over a REGION (nx x ny x nz voxels; at most 1024 per axis with the plain site packing, 2048 with
-// the WIDE one, see FtMetricB) whose occupancy comes from any bitmap -- the map's own (unsharded: region = the whole array) or a
+// the WIDE one, see FtPack) whose occupancy comes from any bitmap -- the map's own (unsharded: region = the whole array) or a
 // shard's replica of the GLOBAL bitmap (region = the shard's array grown by a margin, see DenseMap::run_bulk) -- and
 // writes the voxels of an OUTPUT box inside the region.
 struct FtArgs {
@@ -48,53 +48,27 @@ struct FtArgs {
   }
 };
 
-// LDS rings of one wave: site[slot][lane] (4 B) + start[slot][lane] (2 B).  LANES < 64: only the first LANES lanes of
-// the wave carry a column (the deepest tier trades lanes for depth).
+// LDS ring of one wave: entry[slot][lane], two 32-bit words (ft_core.hpp: e1 = f << 11 | q, e2 = tag << 12 | start), read
+// and written as one 8-byte access.  LANES < 64: only the first LANES lanes of the wave carry a column (the deepest tier
+// trades lanes for depth).
 template <int S, int LANES>
 struct LdsRing {
-  uint32_t *s;
-  uint16_t *st;
-  __device__ __forceinline__ uint32_t site(int i) const { return s[i * LANES]; }
-  __device__ __forceinline__ int start(int i) const { return st[i * LANES]; }
-  __device__ __forceinline__ void set(int i, uint32_t v, int b) {
-    s[i * LANES] = v;
-    st[i * LANES] = (uint16_t)b;
+  uint2 *e;
+  __device__ __forceinline__ void get(int i, uint32_t &e1, uint32_t &e2) const {
+    const uint2 v = e[i * LANES];
+    e1 = v.x, e2 = v.y;
   }
+  __device__ __forceinline__ uint32_t second(int i) const { return e[i * LANES].y; }
+  __device__ __forceinline__ void set(int i, uint32_t e1, uint32_t e2) { e[i * LANES] = make_uint2(e1, e2); }
 };
 // Site packing.  Regions of at most 1024 voxels per axis (every unsharded map up to the plain-id limit): ABSOLUTE region
 // coordinates, 10 bits each.  WIDE (regions up to 2048: a 1024^3 shard of config 5 plus its margin; grids beyond 1024 per
-// axis, whose ids reach 512 voxels anyway, common.hpp): pass A keeps 11-bit absolute (y', z'); pass B packs the plane
-// (11 bits) and the site's OFFSET from the column, (y' - y, z' - z) as signed 10-bit fields -- a candidate farther than
-// 511 voxels in y or z could never be stored and is dropped on arrival.
+// axis, whose ids reach 512 voxels anyway, common.hpp): pass A keeps 11-bit absolute (y', z'); pass B carries the site's
+// OFFSET from the column, (y' - y, z' - z) as signed 10-bit fields, as the envelope tag -- a candidate farther than 511
+// voxels in y or z could never be stored and is dropped on arrival.
 template <bool WIDE>
-struct FtMetricA {  // column along y at lane z; site = y' << SH | z'
-  static constexpr int SH = WIDE ? 11 : 10;
-  int z;
-  __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> SH); }
-  __device__ __forceinline__ int f(uint32_t s) const {
-    const int d = z - (int)(s & ((1u << SH) - 1u));
-    return ft::mul24(d, d);
-  }
-};
-template <bool WIDE>
-struct FtMetricB;
-template <>
-struct FtMetricB<false> {  // column along x at (y, z); site = x' << 20 | y' << 10 | z'
-  int y, z;
-  __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> 20); }
-  __device__ __forceinline__ int f(uint32_t s) const {
-    const int dy = y - (int)((s >> 10) & 1023u), dz = z - (int)(s & 1023u);
-    return ft::mul24(dy, dy) + ft::mul24(dz, dz);
-  }
-};
-template <>
-struct FtMetricB<true> {  // site = x' << 20 | (y' - y) << 10 | (z' - z), offsets as signed 10-bit fields
-  int y, z;
-  __device__ __forceinline__ int q(uint32_t s) const { return (int)(s >> 20); }
-  __device__ __forceinline__ int f(uint32_t s) const {
-    const int dy = ((int)(s << 12)) >> 22, dz = ((int)(s << 22)) >> 22;
-    return ft::mul24(dy, dy) + ft::mul24(dz, dz);
-  }
+struct FtPack {
+  static constexpr int SH = WIDE ? 11 : 10;  // pass A result: y' << SH | z'
 };
 
 // wave vote on a bool: the comparison result itself (no 0/1 round trip through a VGPR as with __ballot(int))
@@ -148,8 +122,7 @@ template <int S, int LANES, int WAVES, bool WIDE>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
   constexpr int RB = 16;               // bitmap rows staged per batch
   constexpr int RW = WIDE ? 64 : 32;   // 32-bit words of a staged row
-  __shared__ uint32_t ring_site[WAVES][S * LANES];
-  __shared__ uint16_t ring_start[WAVES][S * LANES];
+  __shared__ uint2 ring[WAVES][S * LANES];
   __shared__ uint32_t rowstage[WAVES][RB][RW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int SUB = 64 / LANES;  // sub-items per column group when a wave only carries LANES columns
@@ -163,9 +136,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
     const int k = sub * LANES + lane;  // position inside the 64-voxel group
     const int z = 64 * c + k;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;  // (pass B only reads these)
-    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricA<WIDE>> env;
-    env.r = LdsRing<S, LANES>{&ring_site[wave][lane % LANES], &ring_start[wave][lane % LANES]};
-    env.m = FtMetricA<WIDE>{z};
+    ft::LaneEnvelope<S, LdsRing<S, LANES>> env;  // entries: q = row y', f = (z - z')^2, tag = z'
+    env.r = LdsRing<S, LANES>{&ring[wave][lane % LANES]};
     env.init();
     int p_out = 0;
     bool failed = false;
@@ -206,24 +178,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         }
         int d;
         const int zp = ft::nearest_in_row(chunk, 64 * c, k, left_out, right_out, d);
-        const uint32_t site = ((uint32_t)yr << FtMetricA<WIDE>::SH) | (uint32_t)(zp & ((1 << FtMetricA<WIDE>::SH) - 1));
-        const int key = yr * yr + ft::mul24(d, d);
+        // (WIDE: a site farther than an id reaches -- 512 voxels, common.hpp -- cannot matter: d^2 >= kD2Cap reads
+        // "no obstacle" in the end; clamping keeps f inside its 21 bits)
+        const int dd = WIDE ? min(d, 1023) : d;
+        const int f = ft::mul24(dd, dd), key = yr * yr + f;
+        const uint32_t tag = (uint32_t)(zp & ((1 << FtPack<WIDE>::SH) - 1));
         for (;;) {  // pop while any lane wants to
-          const bool want = act && env.wants_pop(yr, key);
+          const bool want = act & env.wants_pop(yr, key);
           if (!ft_vote(want)) break;
           env.pop(want);
         }
-        env.place(act, site, yr, key, a.ny, p_out);
+        env.place(act, yr, f, tag, key, a.ny, p_out);
         if (ft_vote(env.overflow)) {
           failed = true;
           break;
         }
         while (p_out < a.ny && p_out < ynext) {
-          const bool adv = act && env.wants_advance(p_out);
+          const bool adv = act & env.wants_advance(p_out);
           if (ft_vote(adv)) env.advance(adv);
-          const bool fin = !act || env.final_at(p_out, ynext);
+          const bool fin = !act | env.final_at(p_out, ynext);
           if (ft_vote(fin) != ~0ull) break;
-          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = env.winner();
+          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = ((uint32_t)env.winner_q() << FtPack<WIDE>::SH) | env.winner_tag();
           out += a.nz;
           ++p_out;
         }
@@ -240,10 +215,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
 // issued between a prefetch and its use, the wait for the prefetch would also wait for those stores to reach HBM.
 template <int S, int LANES, int WAVES, bool WIDE>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
-  constexpr int P = 8, OB = 16;
+  constexpr int P = 8, OB = 8;
   static_assert(P == 8, "the hand-written wait below names eight registers");
-  __shared__ uint32_t ring_site[WAVES][S * LANES];
-  __shared__ uint16_t ring_start[WAVES][S * LANES];
+  __shared__ uint2 ring[WAVES][S * LANES];
   __shared__ uint32_t stage[WAVES][OB * LANES];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int SUB = 64 / LANES;
@@ -259,9 +233,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     const int z = 64 * c + sub * LANES + lane;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;
     if ((unsigned)(y - a.oy0) >= (unsigned)a.ony) continue;  // (the host only lists rows of the output box)
-    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtMetricB<WIDE>> env;
-    env.r = LdsRing<S, LANES>{&ring_site[wave][lane % LANES], &ring_start[wave][lane % LANES]};
-    env.m = FtMetricB<WIDE>{y, z};
+    // entries: q = plane x', f = (y - y')^2 + (z - z')^2, tag = y' << 10 | z' (WIDE: the offsets y' - y, z' - z)
+    ft::LaneEnvelope<S, LdsRing<S, LANES>> env;
+    env.r = LdsRing<S, LANES>{&ring[wave][lane % LANES]};
     env.init();
     int p_out = 0, p_stored = 0;  // positions [p_stored, p_out) sit in the staging buffer
     bool failed = false;
@@ -282,12 +256,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     // emits what is final (a burst longer than the staging buffer stores in between: rare)
     auto drain = [&](const int x_next) {
       while (p_out < a.nx && p_out < x_next) {
-        const bool adv = act && env.wants_advance(p_out);
+        const bool adv = act & env.wants_advance(p_out);
         if (ft_vote(adv)) env.advance(adv);
-        const bool fin = !act || env.final_at(p_out, x_next);
+        const bool fin = !act | env.final_at(p_out, x_next);
         if (ft_vote(fin) != ~0ull) break;
         if (p_out - p_stored == OB) flush();
-        const uint32_t s = env.winner();
+        const uint32_t s = ((uint32_t)env.winner_q() << 20) | env.winner_tag();
         // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc); plain when the region
         // starts at the global origin of a grid within the plain-id limit (every unsharded map up to 1024 per axis)
         vox_t word;
@@ -330,22 +304,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
         const int x = x0 + u;
         if (x >= a.nx || failed) break;
         if (plane_has(x)) {
-          uint32_t site;
+          uint32_t tag;
+          int dy, dz;
           bool use = act;
           if (WIDE) {  // offsets from the column; a site out of an id's reach in y or z is no candidate
-            const int dy = (int)(w[u] >> 11) - y, dz = (int)(w[u] & 2047u) - z;
+            dy = (int)(w[u] >> 11) - y, dz = (int)(w[u] & 2047u) - z;
             use = use && (unsigned)(dy + 511) < 1023u && (unsigned)(dz + 511) < 1023u;
-            site = ((uint32_t)x << 20) | (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u);
+            tag = (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u);
+            dy = use ? dy : 0, dz = use ? dz : 0;  // (f stays inside its bit field)
           } else {
-            site = ((uint32_t)x << 20) | (w[u] & 0xFFFFFu);
+            tag = w[u] & 0xFFFFFu;
+            dy = y - (int)(tag >> 10), dz = z - (int)(tag & 1023u);
           }
-          const int key = env.key_of(site);
+          const int f = ft::mul24(dy, dy) + ft::mul24(dz, dz), key = env.key_of(x, f);
           for (;;) {  // pop while any lane wants to
-            const bool want = use && env.wants_pop(x, key);
+            const bool want = use & env.wants_pop(x, key);
             if (!ft_vote(want)) break;
             env.pop(want);
           }
-          env.place(use, site, x, key, a.nx, p_out);
+          env.place(use, x, f, tag, key, a.nx, p_out);
           if (ft_vote(env.overflow)) {
             failed = true;
             break;

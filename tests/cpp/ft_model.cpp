@@ -17,31 +17,11 @@ namespace {
 constexpr uint32_t kNone = 0x80000000u;
 constexpr int W = 64;  // lanes per wave
 
-struct VecRing {
-  uint32_t *s;
-  uint16_t *st;
-  uint32_t site(int i) const { return s[i]; }
-  int start(int i) const { return st[i]; }
-  void set(int i, uint32_t v, int b) {
-    s[i] = v;
-    st[i] = (uint16_t)b;
-  }
-};
-struct MetricA {  // pass A: site = y' << 10 | z', column along y at lane z
-  int z;
-  int q(uint32_t s) const { return (int)(s >> 10); }
-  int f(uint32_t s) const {
-    const int d = z - (int)(s & 1023u);
-    return d * d;
-  }
-};
-struct MetricB {  // pass B: site = x' << 20 | y' << 10 | z', column along x at (y, z)
-  int y, z;
-  int q(uint32_t s) const { return (int)(s >> 20); }
-  int f(uint32_t s) const {
-    const int dy = y - (int)((s >> 10) & 1023u), dz = z - (int)(s & 1023u);
-    return dy * dy + dz * dz;
-  }
+struct VecRing {  // two words per entry, as the LDS ring of ft_kernels.hpp
+  uint32_t *e;
+  void get(int i, uint32_t &e1, uint32_t &e2) const { e1 = e[2 * i], e2 = e[2 * i + 1]; }
+  uint32_t second(int i) const { return e[2 * i + 1]; }
+  void set(int i, uint32_t e1, uint32_t e2) { e[2 * i] = e1, e[2 * i + 1] = e2; }
 };
 
 struct Model {
@@ -54,13 +34,11 @@ struct Model {
 
   template <int S>
   bool plane_item(int x, int c) {  // pass A for plane x, lanes z = 64 c + k; false: ring overflow
-    std::vector<uint32_t> rs(S * W);
-    std::vector<uint16_t> rst(S * W);
-    LaneEnvelope<S, VecRing, MetricA> env[W];
+    std::vector<uint32_t> rs(2 * S * W);
+    LaneEnvelope<S, VecRing> env[W];  // pass A: q = y', f = (z - z')^2, tag = z'
     bool act[W];
     for (int k = 0; k < W; ++k) {
-      env[k].r = VecRing{&rs[k * S], &rst[k * S]};
-      env[k].m = MetricA{64 * c + k};
+      env[k].r = VecRing{&rs[2 * k * S]};
       env[k].init();
       act[k] = 64 * c + k < nz;
     }
@@ -76,7 +54,7 @@ struct Model {
         for (int k = 0; k < W; ++k) all = all && (!act[k] || env[k].final_at(p_out, x_next));
         if (!all) break;
         for (int k = 0; k < W; ++k)
-          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = env[k].winner() & 0xFFFFFu;
+          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 10) | env[k].winner_tag();
         ++p_out;
       }
     };
@@ -90,13 +68,13 @@ struct Model {
         if (row[w]) left_out = 32 * w + 31 - __builtin_clz(row[w]);
       for (int w = nzw - 1; w >= 2 * c + 2; --w)
         if (row[w]) right_out = 32 * w + __builtin_ctz(row[w]);
-      uint32_t site[W];
-      int key[W];
+      uint32_t tag[W];
+      int f[W], key[W];
       for (int k = 0; k < W; ++k) {
         int d;
-        const int zp = nearest_in_row(chunk, 64 * c, k, left_out, right_out, d);
-        site[k] = ((uint32_t)yr << 10) | (uint32_t)zp;
-        key[k] = yr * yr + d * d;
+        tag[k] = (uint32_t)nearest_in_row(chunk, 64 * c, k, left_out, right_out, d);
+        f[k] = d * d;
+        key[k] = yr * yr + f[k];
       }
       for (;;) {  // pop while any lane wants to (wave vote), then place
         bool any = false;
@@ -106,7 +84,7 @@ struct Model {
         for (int k = 0; k < W; ++k) env[k].pop(want[k]);
       }
       for (int k = 0; k < W; ++k) {
-        env[k].place(act[k], site[k], yr, key[k], ny, p_out);
+        env[k].place(act[k], yr, f[k], tag[k], key[k], ny, p_out);
         if (env[k].overflow) return false;
         if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
       }
@@ -117,13 +95,11 @@ struct Model {
 
   template <int S>
   bool column_item(int y, int c, uint32_t *out) {  // pass B for row y, lanes z = 64 c + k
-    std::vector<uint32_t> rs(S * W);
-    std::vector<uint16_t> rst(S * W);
-    LaneEnvelope<S, VecRing, MetricB> env[W];
+    std::vector<uint32_t> rs(2 * S * W);
+    LaneEnvelope<S, VecRing> env[W];  // pass B: q = x', f = (y - y')^2 + (z - z')^2, tag = y' << 10 | z'
     bool act[W];
     for (int k = 0; k < W; ++k) {
-      env[k].r = VecRing{&rs[k * S], &rst[k * S]};
-      env[k].m = MetricB{y, 64 * c + k};
+      env[k].r = VecRing{&rs[2 * k * S]};
       env[k].init();
       act[k] = 64 * c + k < nz;
     }
@@ -138,7 +114,7 @@ struct Model {
         for (int k = 0; k < W; ++k) all = all && (!act[k] || env[k].final_at(p_out, x_next));
         if (!all) break;
         for (int k = 0; k < W; ++k)
-          if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = env[k].winner();
+          if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 20) | env[k].winner_tag();
         ++p_out;
       }
     };
@@ -147,12 +123,13 @@ struct Model {
       if (rowcnt[x]) last = x;
     for (int x = 0; x <= last; ++x) {
       if (rowcnt[x]) {
-        uint32_t site[W];
-        int key[W];
+        uint32_t tag[W];
+        int f[W], key[W];
         for (int k = 0; k < W; ++k) {
-          const uint32_t w = act[k] ? inter[((size_t)x * ny + y) * nz + 64 * c + k] : 0u;
-          site[k] = ((uint32_t)x << 20) | w;
-          key[k] = env[k].key_of(site[k]);
+          tag[k] = act[k] ? inter[((size_t)x * ny + y) * nz + 64 * c + k] : 0u;
+          const int dy = y - (int)(tag[k] >> 10), dz = 64 * c + k - (int)(tag[k] & 1023u);
+          f[k] = act[k] ? dy * dy + dz * dz : 0;
+          key[k] = env[k].key_of(x, f[k]);
         }
         for (;;) {
           bool any = false;
@@ -162,7 +139,7 @@ struct Model {
           for (int k = 0; k < W; ++k) env[k].pop(want[k]);
         }
         for (int k = 0; k < W; ++k) {
-          env[k].place(act[k], site[k], x, key[k], nx, p_out);
+          env[k].place(act[k], x, f[k], tag[k], key[k], nx, p_out);
           if (env[k].overflow) return false;
           if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
         }
