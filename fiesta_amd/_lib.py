@@ -54,7 +54,7 @@ class DepthFilter(C.Structure):
 
 class RaycastParams(C.Structure):
     _fields_ = [("min_ray_length", C.c_double), ("max_ray_length", C.c_double), ("l_cornor", C.c_double * 3),
-                ("r_cornor", C.c_double * 3), ("dedup", C.c_int32), ("reserved", C.c_int32)]
+                ("r_cornor", C.c_double * 3), ("dedup", C.c_int32), ("inverse", C.c_int32)]
 
 
 def declared_symbols(header_path: str = HEADER_PATH):

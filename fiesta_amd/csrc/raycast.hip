@@ -42,6 +42,7 @@ struct RayArgs {
   double minr, maxr;
   double lc[3], rc[3];  // l_cornor / r_cornor in metres
   int dedup;
+  int inverse;  // SIGNED_NEEDED companion map (include/Fiesta.h:216-218,249-251): end points count as free, crossings as occupied
 };
 
 __device__ inline int sgn_i(int v) { return v == 0 ? 0 : (v < 0 ? -1 : 1); }            // signum (:6-8)
@@ -143,6 +144,7 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
     for (int k = 0; k < 3; ++k) q[k] = (q[k] - ra.o[k]) / len * ra.maxr + ra.o[k];
     occ = 0;
   }
+  if (ra.inverse) occ = 0;  // inv_esdf_map_->SetOccupancy(point, 0) whatever the end point is (:216-218)
   // SetOccupancy(point, occ) (src/ESDFMap.cpp:401-437); every valid point counts its end point
   int eidx = -1;
   if (PAGED) {  // PosInMap is always true for the hash build (:46-48); the virtual window is the map
@@ -280,7 +282,7 @@ __global__ void k_ray_resolve(int64_t n, const uint32_t *entries, const int32_t 
 
 __global__ void k_ray_apply(int64_t n, const uint32_t *entries, const int32_t *m_count, const uint8_t *flags,
                             const int32_t *last_k, unsigned long long *cnt, uint32_t *touched,
-                            unsigned long long *counters) {
+                            unsigned long long *counters, int free_occ) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (!(flags[i] & 2)) return;
@@ -288,7 +290,7 @@ __global__ void k_ray_apply(int64_t n, const uint32_t *entries, const int32_t *m
   for (int k = m - 2; k >= lk; --k) {
     const uint32_t code = entries[(int64_t)k * n + i];
     if (code == kCodeSkip || (code & kCodeNoCount)) continue;
-    count_observation(code & kCodeIdxMask, 0, cnt, touched, counters);  // SetOccupancy(tmp, 0) (:248)
+    count_observation(code & kCodeIdxMask, free_occ, cnt, touched, counters);  // SetOccupancy(tmp, 0) (:248; inverse map: 1, :250)
   }
 }
 
@@ -450,13 +452,14 @@ static RayArgs ray_args(const double *T, const double *origin, const fiesta_hip_
   ra.minr = p->min_ray_length;
   ra.maxr = p->max_ray_length;
   ra.dedup = p->dedup ? 1 : 0;
+  ra.inverse = p->inverse ? 1 : 0;
   return ra;
 }
 
 // winners of the end-point voxels, the free-space fixed point, the counters; slots in `entries` / `end_idx` index
 // cnt[], the stamp arrays and the touched list
 static void ray_rounds(RayState &rc, int64_t n, int dedup, int ibits, uint32_t tag_occ, unsigned long long *cnt,
-                       uint32_t *touched, unsigned long long *counters, hipStream_t stream) {
+                       uint32_t *touched, unsigned long long *counters, hipStream_t stream, int inverse) {
   hipLaunchKernelGGL(k_ray_winner, dim3(rgrid(n)), dim3(256), 0, stream, n, dedup, (const int32_t *)rc.end_idx.p,
                      (const int32_t *)rc.m_count.p, rc.flags.p, (const uint32_t *)rc.stamp_occ,
                      dedup ? (tag_occ << ibits) : 0u, rc.last_k.p);
@@ -506,7 +509,7 @@ static void ray_rounds(RayState &rc, int64_t n, int dedup, int ibits, uint32_t t
   rc.last_iterations = iters;
   hipLaunchKernelGGL(k_ray_apply, dim3(rgrid(n)), dim3(256), 0, stream, n, (const uint32_t *)rc.entries.p,
                      (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, (const int32_t *)rc.last_k.p, cnt,
-                     touched, counters);
+                     touched, counters, inverse ? 1 : 0);
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
@@ -577,7 +580,7 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
                      rc.end_idx.p, rc.m_count.p, rc.flags.p, rc.stamp_occ, ra.dedup ? (tag_occ << ibits) : 0u, cnt_,
                      touched_.p, counters_, rc.d_flags + 1, (uint32_t *)nullptr);
   FIESTA_HIP_CHECK(hipGetLastError());
-  ray_rounds(rc, n, ra.dedup, ibits, tag_occ, cnt_, touched_.p, counters_, stream_);
+  ray_rounds(rc, n, ra.dedup, ibits, tag_occ, cnt_, touched_.p, counters_, stream_, ra.inverse);
 }
 
 void DenseMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
@@ -638,7 +641,7 @@ void HashMap::raycast_frame(const float *points, int64_t n, const double *T, con
                      rc.end_idx.p, (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.stamp_occ,
                      ra.dedup ? (tag_occ << ibits) : 0u, cnt_.p, touched_.p, counters_);
   FIESTA_HIP_CHECK(hipGetLastError());
-  ray_rounds(rc, n, ra.dedup, ibits, tag_occ, cnt_.p, touched_.p, counters_, stream_);
+  ray_rounds(rc, n, ra.dedup, ibits, tag_occ, cnt_.p, touched_.p, counters_, stream_, ra.inverse);
 }
 
 void HashMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,

@@ -139,21 +139,22 @@ class ESDFMap:
 
     # -- ray casting -----------------------------------------------------------------------------------
     def RaycastFrame(self, points, transform, origin, min_ray_length, max_ray_length, l_cornor, r_cornor,
-                     dedup=1):
-        """One frame of Fiesta::RaycastProcess (include/Fiesta.h:194-278) on sensor-frame points."""
+                     dedup=1, inverse=0):
+        """One frame of Fiesta::RaycastProcess (include/Fiesta.h:194-278) on sensor-frame points.  inverse=1: this map
+        is the SIGNED_NEEDED companion (inv_esdf_map_, :216-218, :249-251) -- end points free, crossed voxels occupied."""
         pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
         T = np.ascontiguousarray(transform, dtype=np.float64).reshape(16)
         prm = RaycastParams(min_ray_length, max_ray_length, (C.c_double * 3)(*l_cornor),
-                            (C.c_double * 3)(*r_cornor), int(dedup), 0)
+                            (C.c_double * 3)(*r_cornor), int(dedup), int(inverse))
         check(self._lib.fiesta_hip_raycast_frame(self._h, _p(pts), len(pts), _p(T), _p(_d3(origin)), C.byref(prm)))
 
     def RaycastDepth(self, depth_mm, fx, fy, cx, cy, transform, origin, min_ray_length, max_ray_length,
-                     l_cornor, r_cornor, dedup=1):
+                     l_cornor, r_cornor, dedup=1, inverse=0):
         """uint16 millimetre depth image -> points (include/Fiesta.h:341-351) -> ray cast, all on device."""
         d = np.ascontiguousarray(depth_mm, dtype=np.uint16)
         T = np.ascontiguousarray(transform, dtype=np.float64).reshape(16)
         prm = RaycastParams(min_ray_length, max_ray_length, (C.c_double * 3)(*l_cornor),
-                            (C.c_double * 3)(*r_cornor), int(dedup), 0)
+                            (C.c_double * 3)(*r_cornor), int(dedup), int(inverse))
         check(self._lib.fiesta_hip_raycast_depth(self._h, _p(d), d.shape[0], d.shape[1], fx, fy, cx, cy, _p(T),
                                                  _p(_d3(origin)), C.byref(prm)))
 
@@ -387,3 +388,12 @@ class ESDFMap:
         n = C.c_int64(0)
         check(self._lib.fiesta_hip_relax_pending(self._h, C.byref(st), C.byref(n)))
         return n.value, st.as_dict()
+
+
+def signed_distance(esdf_map: "ESDFMap", inverse_map: "ESDFMap", pos_or_vox) -> np.ndarray:
+    """Signed distance of a SIGNED_NEEDED pair (include/Fiesta.h:39-41; the reference leaves the combination as a TODO,
+    :515-518): the map's distance to the nearest occupied voxel minus the inverse map's distance to the nearest voxel
+    observed free -- positive in free space, negative inside obstacles.  NaN where either map holds no distance."""
+    d, di = esdf_map.GetDistance(pos_or_vox), inverse_map.GetDistance(pos_or_vox)
+    ok = (np.abs(d) < INFINITY) & (np.abs(di) < INFINITY)
+    return np.where(ok, d - di, np.nan)

@@ -319,4 +319,27 @@ inline void Raycast(const Eigen::Vector3d &start, const Eigen::Vector3d &end, co
   for (int i = 0; i < n; ++i) output->push_back(Eigen::Vector3d(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]));
 }
 
+
+// One sensor frame for a -DSIGNED_NEEDED pair (include/Fiesta.h:39-41, 216-218, 249-251, 515-518): what
+// Fiesta::RaycastMultithread does to esdf_map_ and inv_esdf_map_ -- the inverse map sees the end points as free and the
+// crossed voxels as occupied.  points: n x 3 floats in the sensor frame, transform row-major 4x4.  Both maps must have
+// the same geometry; the caller then runs UpdateOccupancy / UpdateESDF on both (:507-518).
+inline void RaycastFrameSigned(ESDFMap &esdf_map, ESDFMap &inv_esdf_map, const float *points, int64_t n,
+                               const double transform[16], const Eigen::Vector3d &raycast_origin, double min_ray_length,
+                               double max_ray_length, const Eigen::Vector3d &l_cornor, const Eigen::Vector3d &r_cornor) {
+  const double o[3] = {raycast_origin(0), raycast_origin(1), raycast_origin(2)};
+  fiesta_hip_raycast_params p{min_ray_length, max_ray_length, {l_cornor(0), l_cornor(1), l_cornor(2)},
+                              {r_cornor(0), r_cornor(1), r_cornor(2)}, /*dedup=*/1, /*inverse=*/0};
+  if (fiesta_hip_raycast_frame(esdf_map.Handle(), points, n, transform, o, &p) != FIESTA_HIP_OK)
+    throw std::runtime_error(fiesta_hip_last_error());
+  p.inverse = 1;
+  if (fiesta_hip_raycast_frame(inv_esdf_map.Handle(), points, n, transform, o, &p) != FIESTA_HIP_OK)
+    throw std::runtime_error(fiesta_hip_last_error());
+}
+// ... and the quantity the pair exists for (the reference leaves it as a TODO): distance to the nearest obstacle minus
+// distance to the nearest voxel observed free -- positive in free space, negative inside obstacles.
+inline double SignedDistance(ESDFMap &esdf_map, ESDFMap &inv_esdf_map, const Eigen::Vector3d &pos) {
+  return esdf_map.GetDistance(pos) - inv_esdf_map.GetDistance(pos);
+}
+
 }  // namespace fiesta

@@ -146,7 +146,12 @@ typedef struct fiesta_hip_raycast_params {
   int32_t dedup;                         /* 1: per-frame de-dup of end points and free-space voxels with
                                             the reference's early ray termination made order-independent
                                             (see DESIGN.md); 0: every ray marks every voxel it crosses */
-  int32_t reserved;
+  int32_t inverse;                       /* 1: this map is the -DSIGNED_NEEDED companion inv_esdf_map_ (include/Fiesta.h:39-41,
+                                            216-218, 249-251): the frame's end points are counted as FREE and the voxels
+                                            the rays cross as OCCUPIED; same rays, same de-duplication.  A caller that
+                                            wants the signed field keeps two maps of equal geometry, feeds every frame
+                                            to both (inverse = 0 / 1), updates both, and subtracts the inverse map's
+                                            distance (distance to the nearest free voxel) from the map's own */
 } fiesta_hip_raycast_params;
 /* One sensor frame: points are n x 3 float (sensor frame), transform the row-major 4x4 transform_,
  * origin the raycast_origin_. Equivalent to RaycastMultithread with ray_cast_num_thread_ == 0. */

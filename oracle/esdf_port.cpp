@@ -674,8 +674,20 @@ int oracle_raycast(const double start[3], const double end[3], const double minv
 
 // Fiesta::RaycastProcess(0, n, tt), single thread (include/Fiesta.h:194-278) + the frame stamp bump of
 // RaycastMultithread (:281-303).
+static void frame_impl(oracle_map *m, oracle_map *inv, const float *pts, int64_t n, const double T[16], const double o[3],
+                       const oracle_raycast_params *prm);
 void oracle_raycast_frame(oracle_map *m, const float *pts, int64_t n, const double T[16], const double o[3],
                           const oracle_raycast_params *prm) {
+  frame_impl(m, nullptr, pts, n, T, o, prm);
+}
+// ... with -DSIGNED_NEEDED (:216-218, :249-251): the inverse map sees every observation inverted (end points free,
+// traversed voxels occupied) and its return value is the one the de-duplication keys on
+void oracle_raycast_frame_signed(oracle_map *m, oracle_map *inv, const float *pts, int64_t n, const double T[16],
+                                 const double o[3], const oracle_raycast_params *prm) {
+  frame_impl(m, inv, pts, n, T, o, prm);
+}
+static void frame_impl(oracle_map *m, oracle_map *inv, const float *pts, int64_t n, const double T[16], const double o[3],
+                       const oracle_raycast_params *prm) {
   Port &p = m->p;
   if (p.mode == 1) {
     p.hstamp_free.clear();
@@ -713,6 +725,7 @@ void oracle_raycast_frame(oracle_map *m, const float *pts, int64_t n, const doub
     } else {
       s = p.observe_pos(q, 1);
     }
+    if (inv) s = inv->p.observe_pos(q, 0);
     if (s != kUndef && !first_visit(p.stamp_occ, p.hstamp_occ, s)) continue;
     const double qv[3] = {q[0] / res, q[1] / res, q[2] / res};
     walk_ray(ov, qv, lo, hi, &cells);
@@ -721,7 +734,8 @@ void oracle_raycast_frame(oracle_map *m, const float *pts, int64_t n, const doub
       len = norm3(c[0] - o[0], c[1] - o[1], c[2] - o[2]);
       if (len < prm->min_ray_length) break;
       if (len > prm->max_ray_length) continue;
-      const int f = p.observe_pos(c, 0);
+      int f = p.observe_pos(c, 0);
+      if (inv) f = inv->p.observe_pos(c, 1);
       if (f != kUndef && !first_visit(p.stamp_free, p.hstamp_free, f)) break;
     }
   }

@@ -95,6 +95,12 @@ typedef struct oracle_raycast_params {
 void oracle_raycast_frame(oracle_map *m, const float *points, int64_t n, const double transform[16],
                           const double origin[3], const oracle_raycast_params *p);
 
+/* The same frame with -DSIGNED_NEEDED (include/Fiesta.h:216-218,249-251): every SetOccupancy on the map is followed by
+ * one on the INVERSE map -- end points as free (0), traversed voxels as occupied (1) -- whose return value then feeds
+ * the per-frame de-duplication.  inv must have the same geometry as m. */
+void oracle_raycast_frame_signed(oracle_map *m, oracle_map *inv, const float *points, int64_t n,
+                                 const double transform[16], const double origin[3], const oracle_raycast_params *p);
+
 /* Fiesta::DepthConversion (include/Fiesta.h:319-382), restated: see depth_filter.inc. */
 int64_t oracle_depth_conversion(const uint16_t *cur, const uint16_t *last, int rows, int cols, double fx, double fy,
                                 double cx, double cy, int use_filter, const double rel[16], double tolerance,

@@ -89,6 +89,7 @@ def _load(kind: str, mode: str):
         "oracle_dump_counts": (None, [vp, vp, vp]),
         "oracle_dump_hash": (i64, [vp, vp, vp, vp, vp]),
         "oracle_check_consistency": (i32, [vp]),
+        "oracle_raycast_frame_signed": (None, [vp, vp, vp, i64, vp, vp, vp]),
         "oracle_get_point_cloud": (i64, [vp, i32, i32, vp, i64]),
         "oracle_get_slice_marker": (i64, [vp, i32, C.c_double, vp, vp, i64]),
         "oracle_raycast": (i32, [vp, vp, vp, vp, vp, i32]),
@@ -257,11 +258,15 @@ class OracleMap:
         self.lib.oracle_get_slice_marker(self.h, slice_z, max_dist, _p(xyz), _p(rgba), n)
         return xyz, rgba
 
-    def raycast_frame(self, points, transform, origin, min_ray, max_ray, l_cornor, r_cornor):
+    def raycast_frame(self, points, transform, origin, min_ray, max_ray, l_cornor, r_cornor, inverse_map=None):
+        """One frame; inverse_map: the SIGNED_NEEDED companion map fed with inverted observations (include/Fiesta.h:216,249)."""
         pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
         T = np.ascontiguousarray(transform, dtype=np.float64).reshape(16)
         prm = RaycastParams(min_ray, max_ray, (C.c_double * 3)(*l_cornor), (C.c_double * 3)(*r_cornor))
-        self.lib.oracle_raycast_frame(self.h, _p(pts), len(pts), _p(T), _p(_d3(origin)), C.byref(prm))
+        if inverse_map is None:
+            self.lib.oracle_raycast_frame(self.h, _p(pts), len(pts), _p(T), _p(_d3(origin)), C.byref(prm))
+        else:
+            self.lib.oracle_raycast_frame_signed(self.h, inverse_map.h, _p(pts), len(pts), _p(T), _p(_d3(origin)), C.byref(prm))
 
 
 def raycast(start, end, minv, maxv, kind="port", cap=4096):

@@ -299,8 +299,19 @@ int oracle_raycast(const double start[3], const double end[3], const double minv
 
 // Restatement of Fiesta::RaycastProcess(0, cloud.size(), tt) + the tt bump of RaycastMultithread with
 // ray_cast_num_thread_ == 0 (include/Fiesta.h:194-303). Same loop directions, same break/continue.
+static void frame_impl(oracle_map *m, oracle_map *inv, const float *points, int64_t n, const double T[16],
+                       const double origin_[3], const oracle_raycast_params *p);
 void oracle_raycast_frame(oracle_map *m, const float *points, int64_t n, const double T[16],
                           const double origin_[3], const oracle_raycast_params *p) {
+  frame_impl(m, nullptr, points, n, T, origin_, p);
+}
+void oracle_raycast_frame_signed(oracle_map *m, oracle_map *inv, const float *points, int64_t n, const double T[16],
+                                 const double origin_[3], const oracle_raycast_params *p) {
+  frame_impl(m, inv, points, n, T, origin_, p);
+}
+// inv != nullptr: the SIGNED_NEEDED lines (:216-218, :249-251)
+static void frame_impl(oracle_map *m, oracle_map *inv, const float *points, int64_t n, const double T[16],
+                       const double origin_[3], const oracle_raycast_params *p) {
   CoutMute mute;
 #ifdef HASH_TABLE
   m->set_free_.clear();
@@ -327,6 +338,7 @@ void oracle_raycast_frame(oracle_map *m, const float *points, int64_t n, const d
       tmp_idx = m->map->SetOccupancy((Eigen::Vector3d)point, 0);
     } else
       tmp_idx = m->map->SetOccupancy((Eigen::Vector3d)point, 1);  // :215
+    if (inv) tmp_idx = inv->map->SetOccupancy((Eigen::Vector3d)point, 0);  // :216-218
     if (tmp_idx != -10000) {  // :221-232
 #ifdef HASH_TABLE
       if (m->set_occ_.find(tmp_idx) != m->set_occ_.end()) continue;
@@ -345,6 +357,7 @@ void oracle_raycast_frame(oracle_map *m, const float *points, int64_t n, const d
       if (length < p->min_ray_length) break;
       if (length > p->max_ray_length) continue;
       int fidx = m->map->SetOccupancy(tmp, 0);
+      if (inv) fidx = inv->map->SetOccupancy(tmp, 1);  // :249-251
       if (fidx != -10000) {
 #ifdef HASH_TABLE
         if (m->set_free_.find(fidx) != m->set_free_.end()) {

@@ -265,3 +265,74 @@ def test_temporal_depth_filter_three_frames(hip_lib, oracle_libs, best_oracle_ki
     # a run can be restarted: reset forgets the previous image
     pts, n = conv.DepthConversion(depth, intr["fx"], intr["fy"], intr["cx"], intr["cy"], rel_transform=np.eye(4), reset=True, **flt)
     assert n == 0 and np.isnan(pts).all()
+
+
+@pytest.mark.parametrize("mode", ["array", "hash"])
+def test_signed_variant_inverse_map(hip_lib, oracle_libs, best_oracle_kind, mode):
+    """-DSIGNED_NEEDED (include/Fiesta.h:39-41, 92-99, 216-218, 249-251, 515-518): a second map of the same geometry is
+    fed every frame inverted -- end points free, crossed voxels occupied -- and updated alongside.  Per frame the
+    hit/miss counters of BOTH maps must equal the reference driver's, then queues and fields of the inverse map as well;
+    the signed distance (map minus inverse map) is negative exactly inside what the inverse map calls free."""
+    import fiesta_amd
+    kind = best_oracle_kind if oracle_libs.available(best_oracle_kind, mode) else "port"
+    origin, res, size = (-6.4, -6.4, -3.2), 0.1, (12.75, 12.75, 6.35)
+    if mode == "hash":
+        mk_g = lambda: fiesta_amd.ESDFMap(origin, res, reserve_size=1000, mode="hash")                       # noqa: E731
+        mk_c = lambda: oracle_libs.OracleMap(origin, res, reserve_size=1000, mode="hash", kind=kind)        # noqa: E731
+    else:
+        mk_g = lambda: fiesta_amd.ESDFMap(origin, res, size)                                                  # noqa: E731
+        mk_c = lambda: oracle_libs.OracleMap(origin, res, size, kind=kind)                                    # noqa: E731
+    g, gi, c, ci = mk_g(), mk_g(), mk_c(), mk_c()
+    for m in (g, gi, c, ci):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    lc, rc = origin, tuple(np.array(origin) + np.array(size))
+    spheres = [((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7)]
+    intr = dict(fx=96.1, fy=96.1, cx=80.7, cy=58.9)
+    key = lambda v: (v[:, 0].astype(np.int64) + 100000) * (1 << 40) + (v[:, 1].astype(np.int64) + 100000) * (1 << 20) + v[:, 2] + 100000  # noqa: E731
+
+    def counts(gm, cm):
+        gh, gmiss = gm.download_counts()
+        ch, cmiss = cm.dump_counts()
+        if mode == "array":
+            assert np.array_equal(gmiss, cmiss) and np.array_equal(gh, ch)
+            return int((gmiss > 0).sum())
+        gk, ck = key(gm.download_hash()["vox"]), key(cm.dump_hash()["vox"])
+        gs, cs = gmiss > 0, cmiss > 0
+        og, oc = np.argsort(gk[gs]), np.argsort(ck[cs])
+        assert np.array_equal(gk[gs][og], ck[cs][oc])
+        assert np.array_equal(gmiss[gs][og], cmiss[cs][oc]) and np.array_equal(gh[gs][og], ch[cs][oc])
+        return int(gs.sum())
+
+    for f in range(4):
+        T = yaw_pose(30.0 * f, np.array([0.13, -0.21, 0.05]) + 0.06 * f)
+        pts = depth_to_points(render_depth(T, rows=120, cols=160, spheres=spheres, intr=intr), intr=intr)
+        o = T[:3, 3]
+        g.RaycastFrame(pts, T, o, 0.5, 5.0, lc, rc, dedup=1)
+        gi.RaycastFrame(pts, T, o, 0.5, 5.0, lc, rc, dedup=1, inverse=1)
+        c.raycast_frame(pts, T, o, 0.5, 5.0, lc, rc, inverse_map=ci)
+        assert counts(g, c) > 5000 and counts(gi, ci) > 5000
+        for gm, cm in ((g, c), (gi, ci)):
+            assert gm.CheckUpdate() == cm.CheckUpdate()
+            assert gm.UpdateOccupancy(True) == cm.UpdateOccupancy(True)
+            assert (gm.last_insert, gm.last_delete) == (cm.last_insert, cm.last_delete)
+            sg, sc = gm.UpdateESDF(), cm.UpdateESDF()
+            assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+    # the inverse map: its occupied voxels are the observed-free ones; fields vs the oracle under the usual budget of
+    # partially observed maps
+    if mode == "array":
+        rep = compare_dense(gi, ci)
+        assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]) and rep["pair_violations"] == 0, rep
+        occ_main, occ_inv = g.download_field(("occ",))["occ"], gi.download_field(("occ",))["occ"]
+        assert occ_inv.sum() > occ_main.sum() > 0     # (a grazed voxel can be occupied in both: hit by some rays, crossed by others)
+    # signed distance of the pair, here and there
+    q = np.array([[1.5, 0.5, 0.0], [1.9, 0.5, 0.0], [0.6, 0.1, 0.0], [-1.0, 2.0, 0.3]])
+    d, di = g.GetDistance(q), gi.GetDistance(q)
+    assert np.array_equal(d, c.GetDistancePos(q)) and np.array_equal(di, ci.GetDistancePos(q))
+    sd = fiesta_amd.signed_distance(g, gi, q)
+    ok = (np.abs(d) < 10000) & (np.abs(di) < 10000)
+    assert ok[2] and np.array_equal(sd[ok], (d - di)[ok]) and np.all(np.isnan(sd[~ok]))
+    assert sd[2] > 0                                          # free space between sensor and sphere: positive
+    surf = g.GetOccupiedVoxels() if mode == "array" else g.download_hash()["vox"][g.download_hash()["occ"] == 1]
+    ssd = fiesta_amd.signed_distance(g, gi, surf[:200].astype(np.int32))
+    assert np.all(ssd[~np.isnan(ssd)] <= 0) and (ssd < 0).sum() > 100          # on observed surfaces: negative
