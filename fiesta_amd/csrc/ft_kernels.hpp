@@ -20,6 +20,8 @@
 
 namespace fiesta {
 
+#pragma clang diagnostic ignored "-Winline-asm"  // (m0 on a clobber list: it IS written by the LDS-DMA prefetch of k_ft_x)
+
 // The transform runs over a REGION (nx x ny x nz voxels; at most 1024 per axis with the plain site packing, 2048 with
 // the WIDE one, see FtPack) whose occupancy comes from any bitmap -- the map's own (unsharded: region = the whole array) or a
 // shard's replica of the GLOBAL bitmap (region = the shard's array grown by a margin, see DenseMap::run_bulk) -- and
@@ -209,16 +211,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
 }
 
 // ---- pass B: lower envelope along x.  item = y * nzc + c: row y, lanes z = 64 c + lane ------------------------------
-// Memory choreography of one wave: the planes' candidates are prefetched a whole batch (P planes, one 256-byte row
-// segment each) ahead into registers, and emitted words are parked in an LDS staging buffer and stored at the batch
-// boundary BEFORE the next prefetch is issued.  gfx9's vmcnt is one in-order counter for loads and stores: with stores
-// issued between a prefetch and its use, the wait for the prefetch would also wait for those stores to reach HBM.
+// Memory choreography of one wave, per batch of P planes: wait for the batch's candidates (prefetched during the
+// previous batch, one 256-byte row segment per plane, by LDS-DMA), copy them to registers, start the DMA of the next
+// batch, push the P sites, then emit every position that has become final -- straight to HBM, one row segment each.
+// gfx9's vmcnt is one counter for loads and stores, so the wait at the top of a batch also covers the stores of the
+// batch before: they are issued last, right in front of it, and the other waves of the SIMD fill the gap.
 template <int S, int LANES, int WAVES, bool WIDE>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
-  constexpr int P = 8, OB = 8;
-  static_assert(P == 8, "the hand-written wait below names eight registers");
-  __shared__ uint2 ring[WAVES][S * LANES];
-  __shared__ uint32_t stage[WAVES][OB * LANES];
+  constexpr int P = 8;
+  // per wave: the ring, then the landing zone of the prefetch (P planes x 64 lanes x 4 B)
+  __shared__ uint2 lds[WAVES][S * LANES + P * 32];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int SUB = 64 / LANES;
   const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
@@ -235,32 +237,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     if ((unsigned)(y - a.oy0) >= (unsigned)a.ony) continue;  // (the host only lists rows of the output box)
     // entries: q = plane x', f = (y - y')^2 + (z - z')^2, tag = y' << 10 | z' (WIDE: the offsets y' - y, z' - z)
     ft::LaneEnvelope<S, LdsRing<S, LANES>> env;
-    env.r = LdsRing<S, LANES>{&ring[wave][lane % LANES]};
+    env.r = LdsRing<S, LANES>{&lds[wave][lane % LANES]};
     env.init();
-    int p_out = 0, p_stored = 0;  // positions [p_stored, p_out) sit in the staging buffer
+    uint32_t *land = reinterpret_cast<uint32_t *>(&lds[wave][S * LANES]);
+    int p_out = 0;
     bool failed = false;
     const int64_t plane = (int64_t)a.ny * a.nz, col = (int64_t)y * a.nz + (act ? z : 0);
     const uint32_t *in = a.inter + col;
     const int64_t oplane = (int64_t)a.ony * a.onz;
-    // -> output voxel of region position p_stored of this column (valid to dereference only inside the output box)
+    // -> output voxel of region position p_out of this column (valid to dereference only inside the output box)
     vox_t *optr = a.coc + ((int64_t)(0 - a.ox0) * a.ony + (y - a.oy0)) * a.onz + (act ? z - a.oz0 : 0);
-    uint32_t *stg = &stage[wave][lane % LANES];
     const bool shifted = (a.gx0 | a.gy0 | a.gz0) != 0;
-    auto flush = [&]() {
-      for (int p = p_stored; p < p_out; ++p) {
-        if (act && (unsigned)(p - a.ox0) < (unsigned)a.onx) *optr = stg[(p & (OB - 1)) * LANES];
-        optr += oplane;
-      }
-      p_stored = p_out;
-    };
-    // emits what is final (a burst longer than the staging buffer stores in between: rare)
+    // emits what is final, one 256-byte row segment per position
     auto drain = [&](const int x_next) {
       while (p_out < a.nx && p_out < x_next) {
         const bool adv = act & env.wants_advance(p_out);
         if (ft_vote(adv)) env.advance(adv);
         const bool fin = !act | env.final_at(p_out, x_next);
         if (ft_vote(fin) != ~0ull) break;
-        if (p_out - p_stored == OB) flush();
         const uint32_t s = ((uint32_t)env.winner_q() << 20) | env.winner_tag();
         // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc); plain when the region
         // starts at the global origin of a grid within the plain-id limit (every unsharded map up to 1024 per axis)
@@ -272,33 +266,36 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
         } else {
           word = shifted ? pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0) : s;
         }
-        if (act) stg[(p_out & (OB - 1)) * LANES] = word;
-        if (a.maxd2 && act && (unsigned)(p_out - a.ox0) < (unsigned)a.onx) acc_maxd2 = max(acc_maxd2, (uint32_t)env.winner_cost(p_out));
+        const bool inbox = (unsigned)(p_out - a.ox0) < (unsigned)a.onx;
+        if (act && inbox) *optr = word;
+        if (a.maxd2 && act && inbox) acc_maxd2 = max(acc_maxd2, (uint32_t)env.winner_cost(p_out));
+        optr += oplane;
         ++p_out;
       }
     };
-    // The prefetch is issued and waited for BY HAND (inline asm): hipcc's wait-count pass otherwise drains vmcnt to 0
-    // in front of every inner loop that might store (one full HBM round trip per step).  Loads are unconditional: a
-    // plane without sites is simply never looked at.
-    uint32_t w[P], wn[P];
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      const uint32_t *ptr = in + (int64_t)min(u, a.nx - 1) * plane;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(wn[u]) : "v"(ptr) : "memory");
-    }
-    for (int x0 = 0; x0 < a.nx && !failed; x0 += P) {
-      flush();
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(wn[4]), "+v"(wn[5]), "+v"(wn[6]), "+v"(wn[7])
-                   :
-                   : "memory");
-#pragma unroll
-      for (int u = 0; u < P; ++u) w[u] = wn[u];
+    // The planes' candidates are prefetched a batch ahead by LDS-DMA (global_load_lds_dword: the data lands in the wave's
+    // slice of LDS -- lane i at byte m0 + 4 i -- and no register is in flight), issued and waited for BY HAND in inline
+    // asm.  hipcc must not see the transfer: it tracks an ordinary load by draining vmcnt to 0 in front of every inner
+    // loop (one full HBM round trip per step), and a visible LDS-DMA by a vmcnt(0) in front of every LDS read.  (An
+    // earlier version kept the batch in flight in VGPRs named by asm operands; the register allocator is free to copy
+    // such a value before it has arrived, and with one more live range it did.)  Loads are unconditional: a plane
+    // without sites is simply never looked at.
+    uint32_t w[P];
+    const uint32_t land_lds = (uint32_t)(size_t)land;  // LDS byte offset: the low half of the generic address
+    auto issue = [&](const int xb) {
 #pragma unroll
       for (int u = 0; u < P; ++u) {
-        const uint32_t *ptr = in + (int64_t)min(x0 + P + u, a.nx - 1) * plane;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(wn[u]) : "v"(ptr) : "memory");
+        const uint32_t *ptr = in + (int64_t)min(xb + u, a.nx - 1) * plane;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" : : "s"(land_lds + u * 256), "v"(ptr) : "memory", "m0");
       }
+    };
+    issue(0);
+    for (int x0 = 0; x0 < a.nx && !failed; x0 += P) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the batch has landed (and the previous batch's stores are out)
+#pragma unroll
+      for (int u = 0; u < P; ++u) w[u] = land[u * 64 + lane];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and is in registers before the next one may land
+      issue(x0 + P);
 #pragma unroll
       for (int u = 0; u < P; ++u) {
         const int x = x0 + u;
@@ -328,17 +325,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
             break;
           }
         }
-        drain(x + 1);
+        // positions are emitted once per batch: a failed finality vote (the way every drain ends) costs as much as an
+        // emission, and a batch's stores then sit right in front of the next batch's wait
+        if (u == P - 1 || x + 1 >= a.nx) drain(x + 1);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, unused prefetch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, unused prefetch must not land in the next item's batch)
     if (failed) {
       ft_overflow(a, id, lane);
       continue;
     }
     if (ft_vote(act && !env.empty())) {
       drain(ft::kFarAhead);
-      flush();
     } else {  // no occupied voxel anywhere in the region: "observed, no obstacle"
       for (int p = 0; p < a.nx; ++p) {
         if (act && (unsigned)(p - a.ox0) < (unsigned)a.onx) *optr = kInf;
