@@ -165,6 +165,10 @@ struct LaneEnvelope {
   }
   // Is the winner at position p settled, given that every site still to come lies at x_next or beyond (p < x_next)?
   // (after advance: the winner is the bottom entry)
+  // Finality is MONOTONE: sqrt(cost(.)) is 1-Lipschitz (a minimum of 1-Lipschitz functions), so a position that is
+  // final makes every position before it final as well.  And judged by the bottom entry BEFORE advancing, the test is
+  // merely conservative (the bottom's parabola lies on or above the envelope).  Together: final_at(p + k, x_next) on the
+  // un-advanced bottom settles p .. p + k at once -- the emission loops use it to skip k of k + 1 finality votes.
   FT_HD bool final_at(int p, int x_next) const {
     const int g = mul24(p, p - 2 * c_q) + c_key, dx = x_next - p;
     return (top >= bot) & (dx * dx >= g);

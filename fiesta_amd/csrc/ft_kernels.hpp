@@ -195,14 +195,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
           failed = true;
           break;
         }
-        while (p_out < a.ny && p_out < ynext) {
+        const int pend = min(a.ny, ynext);
+        auto emit = [&]() {
+          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = ((uint32_t)env.winner_q() << FtPack<WIDE>::SH) | env.winner_tag();
+          out += a.nz;
+          ++p_out;
+        };
+        // four positions per finality vote while that holds (ft_core.hpp: finality is monotone) ...
+        while (p_out + 3 < pend) {
+          const bool fin4 = !act | env.final_at(p_out + 3, ynext);
+          if (ft_vote(fin4) != ~0ull) break;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool adv = act & env.wants_advance(p_out);
+            if (ft_vote(adv)) env.advance(adv);
+            emit();
+          }
+        }
+        // ... then one by one
+        while (p_out < pend) {
           const bool adv = act & env.wants_advance(p_out);
           if (ft_vote(adv)) env.advance(adv);
           const bool fin = !act | env.final_at(p_out, ynext);
           if (ft_vote(fin) != ~0ull) break;
-          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = ((uint32_t)env.winner_q() << FtPack<WIDE>::SH) | env.winner_tag();
-          out += a.nz;
-          ++p_out;
+          emit();
         }
       }
     }
@@ -249,28 +265,44 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     vox_t *optr = a.coc + ((int64_t)(0 - a.ox0) * a.ony + (y - a.oy0)) * a.onz + (act ? z - a.oz0 : 0);
     const bool shifted = (a.gx0 | a.gy0 | a.gz0) != 0;
     // emits what is final, one 256-byte row segment per position
+    auto emit = [&]() {
+      const uint32_t s = ((uint32_t)env.winner_q() << 20) | env.winner_tag();
+      // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc); plain when the region
+      // starts at the global origin of a grid within the plain-id limit (every unsharded map up to 1024 per axis)
+      vox_t word;
+      if (WIDE) {
+        const int dy = ((int)(s << 12)) >> 22, dz = ((int)(s << 22)) >> 22;
+        word = pack_coc((int)(s >> 20) + a.gx0, y + dy + a.gy0, z + dz + a.gz0);
+        if (env.winner_cost(p_out) >= kD2Cap) word = kInf;  // beyond the reach of an id on such grids
+      } else {
+        word = shifted ? pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0) : s;
+      }
+      const bool inbox = (unsigned)(p_out - a.ox0) < (unsigned)a.onx;
+      if (act && inbox) *optr = word;
+      if (a.maxd2 && act && inbox) acc_maxd2 = max(acc_maxd2, (uint32_t)env.winner_cost(p_out));
+      optr += oplane;
+      ++p_out;
+    };
     auto drain = [&](const int x_next) {
-      while (p_out < a.nx && p_out < x_next) {
+      const int pend = min(a.nx, x_next);
+      // four positions per finality vote while that holds (ft_core.hpp: finality is monotone) ...
+      while (p_out + 3 < pend) {
+        const bool fin4 = !act | env.final_at(p_out + 3, x_next);
+        if (ft_vote(fin4) != ~0ull) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool adv = act & env.wants_advance(p_out);
+          if (ft_vote(adv)) env.advance(adv);
+          emit();
+        }
+      }
+      // ... then one by one
+      while (p_out < pend) {
         const bool adv = act & env.wants_advance(p_out);
         if (ft_vote(adv)) env.advance(adv);
         const bool fin = !act | env.final_at(p_out, x_next);
         if (ft_vote(fin) != ~0ull) break;
-        const uint32_t s = ((uint32_t)env.winner_q() << 20) | env.winner_tag();
-        // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc); plain when the region
-        // starts at the global origin of a grid within the plain-id limit (every unsharded map up to 1024 per axis)
-        vox_t word;
-        if (WIDE) {
-          const int dy = ((int)(s << 12)) >> 22, dz = ((int)(s << 22)) >> 22;
-          word = pack_coc((int)(s >> 20) + a.gx0, y + dy + a.gy0, z + dz + a.gz0);
-          if (env.winner_cost(p_out) >= kD2Cap) word = kInf;  // beyond the reach of an id on such grids
-        } else {
-          word = shifted ? pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0) : s;
-        }
-        const bool inbox = (unsigned)(p_out - a.ox0) < (unsigned)a.onx;
-        if (act && inbox) *optr = word;
-        if (a.maxd2 && act && inbox) acc_maxd2 = max(acc_maxd2, (uint32_t)env.winner_cost(p_out));
-        optr += oplane;
-        ++p_out;
+        emit();
       }
     };
     // The planes' candidates are prefetched a batch ahead by LDS-DMA (global_load_lds_dword: the data lands in the wave's

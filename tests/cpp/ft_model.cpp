@@ -45,6 +45,21 @@ struct Model {
     const int cnt = rowcnt[x];
     int p_out = 0;
     auto drain = [&](int x_next) {
+      while (p_out + 3 < ny && p_out + 3 < x_next) {  // four positions per finality vote (ft_core.hpp: monotone)
+        bool all4 = true;
+        for (int k = 0; k < W; ++k) all4 = all4 && (!act[k] || env[k].final_at(p_out + 3, x_next));
+        if (!all4) break;
+        for (int j = 0; j < 4; ++j) {
+          bool any = false;
+          bool adv[W];
+          for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
+          if (any)
+            for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
+          for (int k = 0; k < W; ++k)
+            if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 10) | env[k].winner_tag();
+          ++p_out;
+        }
+      }
       while (p_out < ny && p_out < x_next) {
         bool any = false, all = true;
         bool adv[W];
@@ -105,6 +120,21 @@ struct Model {
     }
     int p_out = 0;
     auto drain = [&](int x_next) {
+      while (p_out + 3 < nx && p_out + 3 < x_next) {
+        bool all4 = true;
+        for (int k = 0; k < W; ++k) all4 = all4 && (!act[k] || env[k].final_at(p_out + 3, x_next));
+        if (!all4) break;
+        for (int j = 0; j < 4; ++j) {
+          bool any = false;
+          bool adv[W];
+          for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
+          if (any)
+            for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
+          for (int k = 0; k < W; ++k)
+            if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 20) | env[k].winner_tag();
+          ++p_out;
+        }
+      }
       while (p_out < nx && p_out < x_next) {
         bool any = false, all = true;
         bool adv[W];
