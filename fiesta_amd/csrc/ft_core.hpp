@@ -120,6 +120,7 @@ struct LaneEnvelope {
     t_tag = ld ? e2 >> kStartBits : t_tag;
   }
   // n_pos = column length, p_out = the next position to be emitted (everything before it is final and gone)
+  template <bool BOTTOM = true>
   FT_HD void place(bool doit, int q, int f, uint32_t tag, int key, int n_pos, int p_out) {
     const bool has = top >= bot;
     const int D = has ? 2 * (q - t_q) : 2, N = key - t_key;
@@ -139,12 +140,26 @@ struct LaneEnvelope {
     t_q = keep ? q : t_q;
     t_key = keep ? key : t_key;
     t_s = keep ? s : t_s;
-    // the cached bottom follows pops and the push
-    const bool one = top == bot;
-    c_tag = one ? t_tag : c_tag;
-    c_q = one ? t_q : c_q;
-    c_key = one ? t_key : c_key;
-    n_s = top == bot + 1 ? t_s : (top <= bot ? kNoStart : n_s);
+    // the cached bottom follows pops and the push -- unless the caller emits only every few sites and reloads it then
+    if (BOTTOM) {
+      const bool one = top == bot;
+      c_tag = one ? t_tag : c_tag;
+      c_q = one ? t_q : c_q;
+      c_key = one ? t_key : c_key;
+      n_s = top == bot + 1 ? t_s : (top <= bot ? kNoStart : n_s);
+    }
+  }
+  // after a run of place<false>() calls: the cached bottom from the ring (two LDS reads instead of five selects per site)
+  FT_HD void reload_bottom() {
+    uint32_t e1, e2;
+    r.get(bot & (S - 1), e1, e2);
+    const uint32_t e2n = r.second((bot + 1) & (S - 1));
+    const bool has = top >= bot;
+    const int nq = (int)(e1 & ((1u << kQBits) - 1u));
+    c_q = has ? nq : c_q;
+    c_key = has ? mul24(nq, nq) + (int)(e1 >> kQBits) : c_key;
+    c_tag = has ? e2 >> kStartBits : c_tag;
+    n_s = top > bot ? (int)(e2n & ((1u << kStartBits) - 1u)) : kNoStart;
   }
 
   // ---- emission.  Before position p is judged, the bottom moves on to the entry that wins there (advance): that is

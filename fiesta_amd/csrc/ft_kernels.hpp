@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     };
     auto drain = [&](const int x_next) {
       const int pend = min(a.nx, x_next);
+      env.reload_bottom();  // (the sites of this batch were placed without keeping the cached bottom up to date)
       // four positions per finality vote while that holds (ft_core.hpp: finality is monotone) ...
       while (p_out + 3 < pend) {
         const bool fin4 = !act | env.final_at(p_out + 3, x_next);
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
             if (!ft_vote(want)) break;
             env.pop(want);
           }
-          env.place(use, x, f, tag, key, a.nx, p_out);
+          env.template place<false>(use, x, f, tag, key, a.nx, p_out);
           if (ft_vote(env.overflow)) {
             failed = true;
             break;

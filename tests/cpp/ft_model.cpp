@@ -120,6 +120,7 @@ struct Model {
     }
     int p_out = 0;
     auto drain = [&](int x_next) {
+      for (int k = 0; k < W; ++k) env[k].reload_bottom();
       while (p_out + 3 < nx && p_out + 3 < x_next) {
         bool all4 = true;
         for (int k = 0; k < W; ++k) all4 = all4 && (!act[k] || env[k].final_at(p_out + 3, x_next));
@@ -169,7 +170,7 @@ struct Model {
           for (int k = 0; k < W; ++k) env[k].pop(want[k]);
         }
         for (int k = 0; k < W; ++k) {
-          env[k].place(act[k], x, f[k], tag[k], key[k], nx, p_out);
+          env[k].template place<false>(act[k], x, f[k], tag[k], key[k], nx, p_out);
           if (env[k].overflow) return false;
           if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
         }
