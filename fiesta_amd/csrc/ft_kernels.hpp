@@ -358,10 +358,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
             break;
           }
         }
-        // positions are emitted once per batch: a failed finality vote (the way every drain ends) costs as much as an
-        // emission, and a batch's stores then sit right in front of the next batch's wait
-        if (u == P - 1 || x + 1 >= a.nx) drain(x + 1);
       }
+      // positions are emitted once per batch: a failed finality vote (the way every drain ends) costs as much as an
+      // emission, and a batch's stores then sit right in front of the next batch's wait
+      if (!failed) drain(min(x0 + P, a.nx));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, unused prefetch must not land in the next item's batch)
     if (failed) {
