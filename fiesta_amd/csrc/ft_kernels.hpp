@@ -190,11 +190,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
           if (!ft_vote(want)) break;
           env.pop(want);
         }
-        env.place(act, yr, f, tag, key, a.ny, p_out);
+        env.template place<false>(act, yr, f, tag, key, a.ny, p_out);
         if (ft_vote(env.overflow)) {
           failed = true;
           break;
         }
+        // positions are emitted every fourth site row (and at the end of a staged batch): a run of emissions ends with a
+        // failed finality vote, and sites placed in between need not keep the cached bottom entry current
+        if ((r & 3) != 3 && r + 1 < nb) continue;
+        env.reload_bottom();
         const int pend = min(a.ny, ynext);
         auto emit = [&]() {
           if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = ((uint32_t)env.winner_q() << FtPack<WIDE>::SH) | env.winner_tag();
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
           const bool fin4 = !act | env.final_at(p_out + 3, ynext);
           if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int j = 0; j < 4; ++j) {
             const bool adv = act & env.wants_advance(p_out);
             if (ft_vote(adv)) env.advance(adv);
             emit();
