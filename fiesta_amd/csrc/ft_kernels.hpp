@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         }
         // positions are emitted every fourth site row (and at the end of a staged batch): a run of emissions ends with a
         // failed finality vote, and sites placed in between need not keep the cached bottom entry current
-        if ((r & 3) != 3 && r + 1 < nb) continue;
+        if ((r & 7) != 7 && r + 1 < nb) continue;
         env.reload_bottom();
         const int pend = min(a.ny, ynext);
         auto emit = [&]() {
