@@ -1189,27 +1189,31 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
       t.items = t.ovf_list, t.n_items_dev = t.ovf_count, t.n_items = 0;
       t.ovf_list += cap, t.ovf_count = t.ovf_count + 1;
     };
+    // the overflow tiers walk their list with a grid stride: when the tier before spilled nothing in the last update,
+    // a small grid does (the launch is then all an empty tier costs); a scene that spills gets the full grid back
+    const int h = pass_a ? 0 : 3;
+    const int g1 = ft_last_ovf_[h] ? 2048 : 64, g2 = ft_last_ovf_[h + 1] ? 1024 : 64, g3 = ft_last_ovf_[h + 2] ? 1024 : 64;
 #define FIESTA_FT_TIERS(WIDE, LASTS, LASTL)                                                        \
   if (pass_a) {                                                                                    \
     if (ft_s0_ == 16) launch_ft_plane<16, 64, 4, WIDE>(t, blocks0, stream_);                       \
     else launch_ft_plane<32, 64, 4, WIDE>(t, blocks0, stream_);                                    \
     next();                                                                                        \
-    launch_ft_plane<64, 64, 2, WIDE>(t, 2048, stream_);                                            \
+    launch_ft_plane<64, 64, 2, WIDE>(t, g1, stream_);                                              \
     next();                                                                                        \
-    launch_ft_plane<256, 64, 1, WIDE>(t, 1024, stream_);                                           \
+    launch_ft_plane<256, 64, 1, WIDE>(t, g2, stream_);                                             \
     next();                                                                                        \
     t.ovf_list = nullptr, t.ovf_count = nullptr;                                                   \
-    launch_ft_plane<LASTS, LASTL, 1, WIDE>(t, 1024, stream_);                                      \
+    launch_ft_plane<LASTS, LASTL, 1, WIDE>(t, g3, stream_);                                        \
   } else {                                                                                         \
     if (ft_s0_ == 16) launch_ft_x<16, 64, 4, WIDE>(t, blocks0, stream_);                           \
     else launch_ft_x<32, 64, 4, WIDE>(t, blocks0, stream_);                                        \
     next();                                                                                        \
-    launch_ft_x<64, 64, 2, WIDE>(t, 2048, stream_);                                                \
+    launch_ft_x<64, 64, 2, WIDE>(t, g1, stream_);                                                  \
     next();                                                                                        \
-    launch_ft_x<256, 64, 1, WIDE>(t, 1024, stream_);                                               \
+    launch_ft_x<256, 64, 1, WIDE>(t, g2, stream_);                                                 \
     next();                                                                                        \
     t.ovf_list = nullptr, t.ovf_count = nullptr;                                                   \
-    launch_ft_x<LASTS, LASTL, 1, WIDE>(t, 1024, stream_);                                          \
+    launch_ft_x<LASTS, LASTL, 1, WIDE>(t, g3, stream_);                                            \
   }
     // the last tier's ring holds more entries than a column has positions (a ring of S holds S - 1): it cannot overflow
     // (2048 slots x 8 lanes for columns up to 1024, wide: 4096 x 4 for columns up to 2048)
@@ -1292,6 +1296,7 @@ void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time
     for (int k = 0; k < 6; ++k) st->ft_overflow[k] = (int64_t)h_counters_[C_FT_OVF0 + k];
     st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
   }
+  for (int k = 0; k < 6; ++k) ft_last_ovf_[k] = (int64_t)h_counters_[C_FT_OVF0 + k];
   // adapt the first tier to the scene: deep deques (far from obstacles) -> start with the 32-entry rings next time
   const int64_t spill = (int64_t)h_counters_[C_FT_OVF0] + (int64_t)h_counters_[C_FT_OVF0 + 3];
   if (!ft_s0_fixed_ && ft_s0_ == 16 && spill * 50 > (int64_t)(g_.nx + g_.ny) * ((g_.nz + 63) / 64)) ft_s0_ = 32;

@@ -208,6 +208,7 @@ class DenseMap {
   bool stale_inf_ = false;
   int ft_s0_ = 16;            // ring size of the bulk path's first tier: 16, or 32 once a scene needed deeper deques
   bool ft_s0_fixed_ = false;  // (FIESTA_HIP_FT_S0 pins it)
+  int64_t ft_last_ovf_[6] = {1, 1, 1, 1, 1, 1};  // ring spills of the last bulk update per tier (sizes the overflow tiers' grids)
   DevBuf<uint32_t> ft_inter_, ft_ovf_, ft_out_;
   DevBuf<uint16_t> ft_rowlist_;
   DevBuf<int32_t> ft_rowcnt_;
