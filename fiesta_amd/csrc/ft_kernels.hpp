@@ -191,13 +191,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
           env.pop(want);
         }
         env.template place<false>(act, yr, f, tag, key, a.ny, p_out);
-        if (ft_vote(env.overflow)) {
+        // positions are emitted every eighth site row (and at the end of a staged batch): a run of emissions ends with a
+        // failed finality vote, and sites placed in between need not keep the cached bottom entry current
+        if ((r & 7) != 7 && r + 1 < nb) continue;
+        if (ft_vote(env.overflow)) {  // (a lane that overflowed has emitted nothing since: the next tier redoes the item)
           failed = true;
           break;
         }
-        // positions are emitted every fourth site row (and at the end of a staged batch): a run of emissions ends with a
-        // failed finality vote, and sites placed in between need not keep the cached bottom entry current
-        if ((r & 7) != 7 && r + 1 < nb) continue;
         env.reload_bottom();
         const int pend = min(a.ny, ynext);
         auto emit = [&]() {
@@ -357,12 +357,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
             env.pop(want);
           }
           env.template place<false>(use, x, f, tag, key, a.nx, p_out);
-          if (ft_vote(env.overflow)) {
-            failed = true;
-            break;
-          }
         }
       }
+      if (ft_vote(env.overflow)) failed = true;  // (nothing has been emitted since the ring spilled: the next tier redoes the item)
       // positions are emitted once per batch: a failed finality vote (the way every drain ends) costs as much as an
       // emission, and a batch's stores then sit right in front of the next batch's wait
       if (!failed) drain(min(x0 + P, a.nx));
