@@ -45,6 +45,7 @@ struct Model {
     const int cnt = rowcnt[x];
     int p_out = 0;
     auto drain = [&](int x_next) {
+      for (int k = 0; k < W; ++k) env[k].reload_bottom();
       while (p_out + 3 < ny && p_out + 3 < x_next) {  // four positions per finality vote (ft_core.hpp: monotone)
         bool all4 = true;
         for (int k = 0; k < W; ++k) all4 = all4 && (!act[k] || env[k].final_at(p_out + 3, x_next));
@@ -99,11 +100,12 @@ struct Model {
         for (int k = 0; k < W; ++k) env[k].pop(want[k]);
       }
       for (int k = 0; k < W; ++k) {
-        env[k].place(act[k], yr, f[k], tag[k], key[k], ny, p_out);
+        env[k].template place<false>(act[k], yr, f[k], tag[k], key[k], ny, p_out);
         if (env[k].overflow) return false;
         if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
       }
-      drain(i + 1 < cnt ? (int)rowlist[(size_t)x * ny + i + 1] : kFarAhead);
+      // the kernel emits every eighth site row of a staged batch of 16 (and after the last row)
+      if ((i & 7) == 7 || i + 1 == cnt) drain(i + 1 < cnt ? (int)rowlist[(size_t)x * ny + i + 1] : kFarAhead);
     }
     return p_out == ny;
   }
@@ -175,7 +177,11 @@ struct Model {
           if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
         }
       }
-      drain(x == last ? kFarAhead : x + 1);
+      // the kernel emits once per batch of 8 planes (and after the last plane)
+      if (x == last)
+        drain(kFarAhead);
+      else if ((x & 7) == 7)
+        drain(x + 1);
     }
     if (last < 0) {
       for (int p = 0; p < nx; ++p)
@@ -203,7 +209,7 @@ int run_tier(Model &m, uint32_t *out, std::vector<int> &items_a, std::vector<int
 }  // namespace
 
 // occ: nx*ny*nz bytes (x-major, z fastest).  out: packed closest site x<<20|y<<10|z, or 0x80000000 when there is no
-// site at all.  S0: ring size of the first tier (4, 8, 32 or 64); overflowing items go to 256, then 1024.
+// site at all.  S0: ring size of the first tier (4, 8, 32 or 64); overflowing items go to 256, then 2048 (a ring of S holds S - 1 entries).
 // stats[0] = deepest ring seen, stats[1] = items that overflowed tier 0 (pass A + pass B), stats[2] = tier 1.
 extern "C" int ft_model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, uint32_t *out, int *stats) {
   if (nx > 1024 || ny > 1024 || nz > 1024) return -1;
@@ -245,7 +251,7 @@ extern "C" int ft_model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, 
   stats[1] = (int)ia.size();
   if (!ia.empty()) run_tier<256>(m, out, ia, none);
   stats[2] = (int)ia.size();
-  if (!ia.empty()) run_tier<1024>(m, out, ia, none);
+  if (!ia.empty()) run_tier<2048>(m, out, ia, none);
   if (!ia.empty()) return -2;
   switch (S0) {
     case 4: r = run_tier<4>(m, out, none, ib); break;
@@ -256,7 +262,7 @@ extern "C" int ft_model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, 
   stats[1] += (int)ib.size();
   if (!ib.empty()) run_tier<256>(m, out, none, ib);
   stats[2] += (int)ib.size();
-  if (!ib.empty()) run_tier<1024>(m, out, none, ib);
+  if (!ib.empty()) run_tier<2048>(m, out, none, ib);
   (void)r;
   stats[0] = m.max_depth;
   return ib.empty() ? 0 : -3;
