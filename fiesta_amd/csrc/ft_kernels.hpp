@@ -56,12 +56,16 @@ struct FtArgs {
 template <int S, int LANES>
 struct LdsRing {
   uint2 *e;
+  bool live;  // LANES < 64: the lanes beyond LANES carry no column and share the ring of lane % LANES -- they may read it
+              // (and ignore what they read) but must not take part in the envelope's unconditional store
   __device__ __forceinline__ void get(int i, uint32_t &e1, uint32_t &e2) const {
     const uint2 v = e[i * LANES];
     e1 = v.x, e2 = v.y;
   }
   __device__ __forceinline__ uint32_t second(int i) const { return e[i * LANES].y; }
-  __device__ __forceinline__ void set(int i, uint32_t e1, uint32_t e2) { e[i * LANES] = make_uint2(e1, e2); }
+  __device__ __forceinline__ void set(int i, uint32_t e1, uint32_t e2) {
+    if (LANES == 64 || live) e[i * LANES] = make_uint2(e1, e2);
+  }
 };
 // Site packing.  Regions of at most 1024 voxels per axis (every unsharded map up to the plain-id limit): ABSOLUTE region
 // coordinates, 10 bits each.  WIDE (regions up to 2048: a 1024^3 shard of config 5 plus its margin; grids beyond 1024 per
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
     const int z = 64 * c + k;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;  // (pass B only reads these)
     ft::LaneEnvelope<S, LdsRing<S, LANES>> env;  // entries: q = row y', f = (z - z')^2, tag = z'
-    env.r = LdsRing<S, LANES>{&ring[wave][lane % LANES]};
+    env.r = LdsRing<S, LANES>{&ring[wave][lane % LANES], lane < LANES};
     env.init();
     int p_out = 0;
     bool failed = false;
@@ -239,7 +243,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
 template <int S, int LANES, int WAVES, bool WIDE>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
   constexpr int P = 8;
-  // per wave: the ring, then the landing zone of the prefetch (P planes x 64 lanes x 4 B)
+  // per wave: the landing zone of the prefetch (P planes x 64 lanes x 4 B) -- first, so that the LDS address the DMA
+  // takes from m0 stays below 64 KB in every tier -- then the ring
   __shared__ uint2 lds[WAVES][S * LANES + P * 32];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int SUB = 64 / LANES;
@@ -257,9 +262,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     if ((unsigned)(y - a.oy0) >= (unsigned)a.ony) continue;  // (the host only lists rows of the output box)
     // entries: q = plane x', f = (y - y')^2 + (z - z')^2, tag = y' << 10 | z' (WIDE: the offsets y' - y, z' - z)
     ft::LaneEnvelope<S, LdsRing<S, LANES>> env;
-    env.r = LdsRing<S, LANES>{&lds[wave][lane % LANES]};
+    env.r = LdsRing<S, LANES>{&lds[wave][P * 32 + lane % LANES], lane < LANES};
     env.init();
-    uint32_t *land = reinterpret_cast<uint32_t *>(&lds[wave][S * LANES]);
+    uint32_t *land = reinterpret_cast<uint32_t *>(&lds[wave][0]);
     int p_out = 0;
     bool failed = false;
     const int64_t plane = (int64_t)a.ny * a.nz, col = (int64_t)y * a.nz + (act ? z : 0);
