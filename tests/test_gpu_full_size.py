@@ -277,36 +277,43 @@ def test_config2_density_192cube_exact_vs_reference(hip_lib, oracle_libs, best_o
     assert rep["finite"] == G ** 3
 
 
-def test_bulk_engine_every_ring_tier_320cube(hip_lib):
-    """A floor (z = 0) and a wall (y = 0) in a fully observed 320^3 grid: along every scan axis consecutive sites are
-    equally good, so a lane's deque holds about as many entries as its voxels are far from the planes -- up to 319.  That
-    walks BOTH passes of the bulk transform through every ring tier (16 -> 64 -> 256 -> 2048 slots, the prefetch landing
-    in LDS next to rings of 32 KB to 128 KB), and the answer has a closed form: d^2 = min(y, z)^2 everywhere."""
+@pytest.mark.parametrize("dims", [(320, 320, 320), (1100, 300, 300)], ids=["320cube", "1100x300x300-wide-ids"])
+def test_bulk_engine_every_ring_tier(hip_lib, dims):
+    """A floor (z = 0) and a wall (y = 0) in a fully observed grid: along every scan axis consecutive sites are equally
+    good, so a lane's deque holds about as many entries as its voxels are far from the planes -- up to ~300.  That walks
+    BOTH passes of the bulk transform through their ring tiers (16 -> 64 -> 256 -> 2048 slots, wide: 4096; the prefetch
+    landing in LDS next to rings of 32 KB to 128 KB), and the answer has a closed form: d^2 = min(y, z)^2 everywhere.
+    The second shape has an axis beyond 1024: ids modulo 1024, the WIDE site packing and its own deepest tier."""
     import fiesta_amd
-    G, res = 320, 0.1
-    m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, update_engine="bulk")
+    nx, ny, nz = dims
+    res = 0.1
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, (nx * res, ny * res, nz * res), update_engine="bulk")
+    assert m.grid_size == dims
     m.SetParameters(*P_DEFAULT)
     m.SetOriginalRange()
-    _observe_all(m, G)
+    m.SetOccupancyBox((0, 0, 0), (nx - 1, ny - 1, nz - 1), 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
     for _ in range(3):
-        m.SetOccupancyBox((0, 0, 0), (G - 1, G - 1, 0), 1)
-        m.SetOccupancyBox((0, 0, 0), (G - 1, 0, G - 1), 1)
+        m.SetOccupancyBox((0, 0, 0), (nx - 1, ny - 1, 0), 1)
+        m.SetOccupancyBox((0, 0, 0), (nx - 1, 0, nz - 1), 1)
         m.UpdateOccupancy(True)
     st = m.UpdateESDF()
-    assert st["bulk"] and st["inserted"] == 2 * G * G - G
+    assert st["bulk"] and st["inserted"] == nx * ny + nx * nz - nx
     ovf = st["ft_overflow"]
-    # pass B spills through all its tiers (16 -> 64 -> 256 -> 2048), pass A -- whose far rows lose to the wall early -- through two
+    # pass B spills through all its tiers, pass A -- whose far rows lose to the wall early -- through two
     assert all(v > 0 for v in ovf[3:]) and ovf[0] > 0 and ovf[1] > 0, ovf
-    d2 = m.download_field(("d2",))["d2"].reshape(G, G, G)
-    y, z = np.meshgrid(np.arange(G), np.arange(G), indexing="ij")
+    y, z = np.meshgrid(np.arange(ny), np.arange(nz), indexing="ij")
     want = (np.minimum(y, z) ** 2).astype(np.int32)
-    assert np.array_equal(d2, np.broadcast_to(want, (G, G, G)))
+    d2 = m.download_field(("d2",))["d2"].reshape(nx, ny, nz)
+    assert np.array_equal(d2, np.broadcast_to(want, dims))
+    del d2
     # and back: without the wall only the floor counts
     for _ in range(6):
-        m.SetOccupancyBox((0, 0, 1), (G - 1, 0, G - 1), 0)
+        m.SetOccupancyBox((0, 0, 1), (nx - 1, 0, nz - 1), 0)
         m.UpdateOccupancy(True)
     st = m.UpdateESDF()
-    assert st["bulk"] and st["deleted"] == G * (G - 1)
-    d2 = m.download_field(("d2",))["d2"].reshape(G, G, G)
-    assert np.array_equal(d2, np.broadcast_to((z ** 2).astype(np.int32), (G, G, G)))
+    assert st["bulk"] and st["deleted"] == nx * (nz - 1)
+    d2 = m.download_field(("d2",))["d2"].reshape(nx, ny, nz)
+    assert np.array_equal(d2, np.broadcast_to((z ** 2).astype(np.int32), dims))
     m.close()
