@@ -237,12 +237,25 @@ class ShardedESDFMap:
         self._group = None
         n_here = len(self.shards)
         can = default_shards and (n_here == n_shards or (n_here == 1 and getattr(self.transport, "on_gpu", False)))
-        if native is None:
+        auto = native is None
+        if auto:
             native = can
         if native:
             if not can:
                 raise ValueError("native shard group: needs HIP shards, all local or one per rank on the RCCL transport")
-            self._open_native_group()
+            try:
+                self._open_native_group()
+                failed = 0
+            except Exception as e:  # noqa: BLE001  (e.g. the RCCL communicator could not be formed)
+                if not auto:
+                    raise
+                failed, self._group = 1, None
+                import warnings
+                warnings.warn(f"native shard group unavailable ({e}); the torch.distributed protocol takes over")
+            # one shard per rank: every rank must drive the same protocol, or the collectives would not match up
+            if auto and n_here == 1 and n_shards > 1 and self.transport.allreduce_sum(failed) and self._group is not None:
+                self._glib.fiesta_hip_shard_group_destroy(self._group)
+                self._group = None
 
     def _open_native_group(self):
         import ctypes as C
@@ -251,10 +264,13 @@ class ShardedESDFMap:
         ranks = sorted(self.shards)
         rccl_id = None
         if self.n_shards > 1 and len(ranks) == 1:
-            buf = np.zeros(128, np.uint8)
+            buf = np.zeros(129, np.uint8)  # 128 bytes of id + "rank 0 got one" (every rank takes part in the broadcast)
             if self.transport.rank == 0:
-                _lib.check(lib.fiesta_hip_rccl_unique_id(buf.ctypes.data_as(C.c_void_p)))
-            rccl_id = self.transport.broadcast_bytes(buf)
+                buf[128] = lib.fiesta_hip_rccl_unique_id(buf.ctypes.data_as(C.c_void_p)) == 0
+            got = self.transport.broadcast_bytes(buf)
+            if not got[128]:
+                raise RuntimeError("rank 0 could not create an RCCL unique id (librccl.so not loadable?)")
+            rccl_id = np.ascontiguousarray(got[:128])
         handles = (C.c_void_p * len(ranks))(*[self.shards[r]._h for r in ranks])
         rk = (C.c_int32 * len(ranks))(*ranks)
         g = C.c_void_p()
