@@ -31,6 +31,14 @@ constexpr vox_t kInf = 0x80000000u;
 constexpr vox_t kAct = 0x40000000u;
 constexpr vox_t kReset = kInf | kAct;
 constexpr int32_t kD2Inf = 0x7FFFFFFF;
+// A "no obstacle" word may still carry a STALE LINK in its low 30 bits (kAct clear): the local-map reset of UpdateOccupancy
+// (src/ESDFMap.cpp:256-259) sets the distance to infinity but leaves closest_obstacle_ -- and the voxel's membership in
+// that obstacle's list -- alone, so the voxel is re-seeded from its neighbours when that obstacle is deleted later
+// (:308-321).  Everything that asks "is there an obstacle" keeps testing kNoCoc; only the delete scan follows the link.
+// (An id of all zeros cannot be told from plain kInf: a link to map voxel (0,0,0) mod 1024 is dropped.)
+constexpr vox_t kIdMask = 0x3FFFFFFFu;
+__host__ __device__ inline bool has_link(vox_t w) { return !(w & kNoCoc) || (!(w & kAct) && (w & kIdMask) != 0u); }
+__host__ __device__ inline vox_t stale_link(vox_t w) { return (w & kNoCoc) ? w : (kNoCoc | (w & kIdMask)); }
 constexpr int kCoordBits = 10;
 constexpr int kMaxDim = 1 << kCoordBits;
 

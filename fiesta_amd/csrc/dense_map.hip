@@ -149,9 +149,9 @@ __device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_
     first_obs = true;
   }
   if ((step >= 0 && L >= pp.l_max) || (step <= 0 && L <= pp.l_min)) return;  // already clamped (:250-255)
-  if (!global_map && !g.in_prev_window(x, y, z)) {  // local-map reset (:256-259); see DESIGN.md
+  if (!global_map && !g.in_prev_window(x, y, z)) {  // local-map reset (:256-259): distance = infinity, the link stays
     L = 0;
-    coc[idx] = kInf;
+    coc[idx] = stale_link(coc[idx]);
   }
   L = fmin(fmax(L + step, pp.l_min), pp.l_max);  // (:260-262)
   logodds[idx] = L;
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
         bool dead_prev = false;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-          if (!(w[r][k] & kNoCoc)) {
-            const vox_t c = w[r][k] & ~kAct;
+          if (has_link(w[r][k])) {  // (a valid id, or the stale link of a voxel reset by the local-map rule)
+            const vox_t c = w[r][k] & kIdMask;
             bool dead;
-            if (k > 0 && c == (w[r][k - 1] & ~kAct)) {
+            if (k > 0 && has_link(w[r][k - 1]) && c == (w[r][k - 1] & kIdMask)) {
               dead = dead_prev;
             } else {
               int cx, cy, cz;
@@ -973,6 +973,7 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
     nd = host_counts_[1];
     // voxels observed for the first time while obstacles (or pending deletes of obstacles) exist: see stale_inf_
     if (host_counts_[2] != obs_before && (nocc_before > 0 || nd > 0)) stale_inf_ = true;
+    if (!global_map) stale_inf_ = true;  // (the local-map reset may have put observed voxels back to +10000: same rule)
   }
   if (n_ins) *n_ins = (int64_t)ni;
   if (n_del) *n_del = (int64_t)nd;

@@ -272,9 +272,9 @@ __global__ void k_h_fuse(Geom g, ProbParams pp, int global_map, const int32_t *p
   if (!global_map && page_tile[a / kPageVox] >= 0) {  // (a page parked since the observation fuses like a global map's)
     int x, y, z;
     vcoords(page_tile, a, x, y, z);
-    if (!g.in_prev_window(x, y, z)) {
+    if (!g.in_prev_window(x, y, z)) {  // (distance = infinity, the link stays: common.hpp, stale_link)
       L = 0;
-      coc[a] = kInf;
+      coc[a] = stale_link(coc[a]);
     }
   }
   L = fmin(fmax(L + step, pp.l_min), pp.l_max);
@@ -326,10 +326,10 @@ __global__ __launch_bounds__(256) void k_h_invalidate(Geom g, const int32_t *dir
         coc[a] = nw;
         reset = true;
       }
-    } else if (tile >= 0 && !(w & kNoCoc)) {
+    } else if (tile >= 0 && has_link(w)) {
       int x, y, z;
       vcoords(page_tile, (uint32_t)a, x, y, z);
-      if (!h_alive(g, dir, occbits, x, y, z, w & ~kAct)) {
+      if (!h_alive(g, dir, occbits, x, y, z, w & kIdMask)) {
         coc[a] = kReset;
         reset = true;
       }
