@@ -102,21 +102,25 @@ struct LaneEnvelope {
 
   // ---- a new site at position q (beyond every site pushed before), key = q^2 + f: pop while any lane wants to,
   // then place.  The newcomer beats the top strictly at p  <=>  p * D > N  <=>  p >= floor(N / D) + 1.
+  // An EMPTY ring keeps t_s = t_key = 0 (init, pop): then N = key >= 0 is never below t_s * D = 0 and the one compare
+  // answers "no" by itself -- the vote on it is the compare's own lane mask, no select-and-recompare in between.  A lane
+  // that must not pop for another reason passes a key of kNoPop.
+  static constexpr int kNoPop = 1 << 30;
   FT_HD bool wants_pop(int q, int key) const {
     const int D = 2 * (q - t_q), N = key - t_key;
-    return (top >= bot) & (N < mul24(t_s, D));  // ... already at the top's first position: the top wins nowhere
-    // (`&`, not `&&`, here and below: a short circuit becomes an exec-mask region with its scalar bookkeeping)
+    return N < mul24(t_s, D);  // ... already at the top's first position: the top wins nowhere
   }
   FT_HD void pop(bool doit) {
     const int nt = top - 1;
     uint32_t e1, e2;
     r.get(nt & (S - 1), e1, e2);  // (below the bottom this is a stale slot: read, not used)
-    const bool ld = doit & (nt >= bot);
-    top = doit ? nt : top;
+    const bool more = nt >= bot, ld = doit & more;  // (`&`, not `&&`, here and below: a short circuit becomes an
+    top = doit ? nt : top;                            //  exec-mask region with its scalar bookkeeping)
     const int nq = (int)(e1 & ((1u << kQBits) - 1u));
+    const int nk = more ? mul24(nq, nq) + (int)(e1 >> kQBits) : 0, ns = more ? (int)(e2 & ((1u << kStartBits) - 1u)) : 0;
     t_q = ld ? nq : t_q;
-    t_key = ld ? mul24(nq, nq) + (int)(e1 >> kQBits) : t_key;
-    t_s = ld ? (int)(e2 & ((1u << kStartBits) - 1u)) : t_s;
+    t_key = doit ? nk : t_key;  // (the ring ran empty: 0, see wants_pop)
+    t_s = doit ? ns : t_s;
     t_tag = ld ? e2 >> kStartBits : t_tag;
   }
   // n_pos = column length, p_out = the next position to be emitted (everything before it is final and gone)

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         const int f = ft::mul24(dd, dd), key = yr * yr + f;
         const uint32_t tag = (uint32_t)(zp & ((1 << FtPack<WIDE>::SH) - 1));
         for (;;) {  // pop while any lane wants to
-          const bool want = act & env.wants_pop(yr, key);
+          const bool want = env.wants_pop(yr, key);  // (a lane without a column has an empty ring: never)
           if (!ft_vote(want)) break;
           env.pop(want);
         }
@@ -356,8 +356,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
             dy = y - (int)(tag >> 10), dz = z - (int)(tag & 1023u);
           }
           const int f = ft::mul24(dy, dy) + ft::mul24(dz, dz), key = env.key_of(x, f);
+          const int pkey = (WIDE && !use) ? env.kNoPop : key;  // (plain packing: use == act, and an idle lane's ring is empty)
           for (;;) {  // pop while any lane wants to
-            const bool want = use & env.wants_pop(x, key);
+            const bool want = env.wants_pop(x, pkey);
             if (!ft_vote(want)) break;
             env.pop(want);
           }

@@ -95,7 +95,7 @@ struct Model {
       for (;;) {  // pop while any lane wants to (wave vote), then place
         bool any = false;
         bool want[W];
-        for (int k = 0; k < W; ++k) any = (want[k] = act[k] && env[k].wants_pop(yr, key[k])) || any;
+        for (int k = 0; k < W; ++k) any = (want[k] = env[k].wants_pop(yr, key[k])) || any;
         if (!any) break;
         for (int k = 0; k < W; ++k) env[k].pop(want[k]);
       }
@@ -167,7 +167,7 @@ struct Model {
         for (;;) {
           bool any = false;
           bool want[W];
-          for (int k = 0; k < W; ++k) any = (want[k] = act[k] && env[k].wants_pop(x, key[k])) || any;
+          for (int k = 0; k < W; ++k) any = (want[k] = env[k].wants_pop(x, key[k])) || any;
           if (!any) break;
           for (int k = 0; k < W; ++k) env[k].pop(want[k]);
         }
