@@ -215,14 +215,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
           if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const bool adv = act & env.wants_advance(p_out);
+            const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
             if (ft_vote(adv)) env.advance(adv);
             emit();
           }
         }
         // ... then one by one
         while (p_out < pend) {
-          const bool adv = act & env.wants_advance(p_out);
+          const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
           if (ft_vote(adv)) env.advance(adv);
           const bool fin = !act | env.final_at(p_out, ynext);
           if (ft_vote(fin) != ~0ull) break;
@@ -301,14 +301,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
         if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const bool adv = act & env.wants_advance(p_out);
+          const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
           if (ft_vote(adv)) env.advance(adv);
           emit();
         }
       }
       // ... then one by one
       while (p_out < pend) {
-        const bool adv = act & env.wants_advance(p_out);
+        const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
         if (ft_vote(adv)) env.advance(adv);
         const bool fin = !act | env.final_at(p_out, x_next);
         if (ft_vote(fin) != ~0ull) break;
