@@ -188,9 +188,14 @@ struct LaneEnvelope {
   // final makes every position before it final as well.  And judged by the bottom entry BEFORE advancing, the test is
   // merely conservative (the bottom's parabola lies on or above the envelope).  Together: final_at(p + k, x_next) on the
   // un-advanced bottom settles p .. p + k at once -- the emission loops use it to skip k of k + 1 finality votes.
+  // The same folding as in wants_pop: while the ring is empty the cached bottom reads c_q = 0, c_key = +kNeverFinal
+  // (set_idle(false), the start of every column) -- no position is final; a lane that carries no column reads
+  // -kNeverFinal (set_idle(true)) -- it never holds up the wave's vote.  One compare, its mask is the vote.
+  static constexpr int kNeverFinal = (1 << 30) + 1;  // above any (x_next - p)^2, and p^2 on top still fits an int
+  FT_HD void set_idle(bool idle) { c_key = idle ? -kNeverFinal : kNeverFinal; }
   FT_HD bool final_at(int p, int x_next) const {
     const int g = mul24(p, p - 2 * c_q) + c_key, dx = x_next - p;
-    return (top >= bot) & (dx * dx >= g);
+    return dx * dx >= g;
   }
   FT_HD int winner_q() const { return c_q; }
   FT_HD uint32_t winner_tag() const { return c_tag; }

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
     ft::LaneEnvelope<S, LdsRing<S, LANES>> env;  // entries: q = row y', f = (z - z')^2, tag = z'
     env.r = LdsRing<S, LANES>{&ring[wave][lane % LANES], lane < LANES};
     env.init();
+    env.set_idle(!act);
     int p_out = 0;
     bool failed = false;
     uint32_t *out = a.inter + (int64_t)x * a.ny * a.nz + (act ? z : 0);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         };
         // four positions per finality vote while that holds (ft_core.hpp: finality is monotone) ...
         while (p_out + 3 < pend) {
-          const bool fin4 = !act | env.final_at(p_out + 3, ynext);
+          const bool fin4 = env.final_at(p_out + 3, ynext);
           if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         while (p_out < pend) {
           const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
           if (ft_vote(adv)) env.advance(adv);
-          const bool fin = !act | env.final_at(p_out, ynext);
+          const bool fin = env.final_at(p_out, ynext);
           if (ft_vote(fin) != ~0ull) break;
           emit();
         }
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     ft::LaneEnvelope<S, LdsRing<S, LANES>> env;
     env.r = LdsRing<S, LANES>{&lds[wave][P * 32 + lane % LANES], lane < LANES};
     env.init();
+    env.set_idle(!act);
     uint32_t *land = reinterpret_cast<uint32_t *>(&lds[wave][0]);
     int p_out = 0;
     bool failed = false;
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     vox_t *optr = a.coc + ((int64_t)(0 - a.ox0) * a.ony + (y - a.oy0)) * a.onz + (act ? z - a.oz0 : 0);
     const bool shifted = (a.gx0 | a.gy0 | a.gz0) != 0;
     // emits what is final, one 256-byte row segment per position
+    bool no_site = false;  // WIDE: every site of the column was out of an id's reach for this lane (set before the last run)
     auto emit = [&]() {
       const uint32_t s = ((uint32_t)env.winner_q() << 20) | env.winner_tag();
       // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc); plain when the region
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       if (WIDE) {
         const int dy = ((int)(s << 12)) >> 22, dz = ((int)(s << 22)) >> 22;
         word = pack_coc((int)(s >> 20) + a.gx0, y + dy + a.gy0, z + dz + a.gz0);
-        if (env.winner_cost(p_out) >= kD2Cap) word = kInf;  // beyond the reach of an id on such grids
+        if (no_site | (env.winner_cost(p_out) >= kD2Cap)) word = kInf;  // beyond the reach of an id on such grids
       } else {
         word = shifted ? pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0) : s;
       }
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       env.reload_bottom();  // (the sites of this batch were placed without keeping the cached bottom up to date)
       // four positions per finality vote while that holds (ft_core.hpp: finality is monotone) ...
       while (p_out + 3 < pend) {
-        const bool fin4 = !act | env.final_at(p_out + 3, x_next);
+        const bool fin4 = env.final_at(p_out + 3, x_next);
         if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       while (p_out < pend) {
         const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
         if (ft_vote(adv)) env.advance(adv);
-        const bool fin = !act | env.final_at(p_out, x_next);
+        const bool fin = env.final_at(p_out, x_next);
         if (ft_vote(fin) != ~0ull) break;
         emit();
       }
@@ -376,6 +379,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       continue;
     }
     if (ft_vote(act && !env.empty())) {
+      if (WIDE) {  // a lane that found no site in reach must not hold up its neighbours' last run: it reads "no obstacle"
+        no_site = act & env.empty();
+        if (no_site) env.set_idle(true);
+        if (a.maxd2 && no_site) acc_maxd2 = 1u << 30;
+      }
       drain(ft::kFarAhead);
     } else {  // no occupied voxel anywhere in the region: "observed, no obstacle"
       for (int p = 0; p < a.nx; ++p) {

@@ -41,6 +41,7 @@ struct Model {
       env[k].r = VecRing{&rs[2 * k * S]};
       env[k].init();
       act[k] = 64 * c + k < nz;
+      env[k].set_idle(!act[k]);
     }
     const int cnt = rowcnt[x];
     int p_out = 0;
@@ -48,7 +49,7 @@ struct Model {
       for (int k = 0; k < W; ++k) env[k].reload_bottom();
       while (p_out + 3 < ny && p_out + 3 < x_next) {  // four positions per finality vote (ft_core.hpp: monotone)
         bool all4 = true;
-        for (int k = 0; k < W; ++k) all4 = all4 && (!act[k] || env[k].final_at(p_out + 3, x_next));
+        for (int k = 0; k < W; ++k) all4 = all4 && (env[k].final_at(p_out + 3, x_next));
         if (!all4) break;
         for (int j = 0; j < 4; ++j) {
           bool any = false;
@@ -67,7 +68,7 @@ struct Model {
         for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
         if (any)
           for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
-        for (int k = 0; k < W; ++k) all = all && (!act[k] || env[k].final_at(p_out, x_next));
+        for (int k = 0; k < W; ++k) all = all && (env[k].final_at(p_out, x_next));
         if (!all) break;
         for (int k = 0; k < W; ++k)
           if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 10) | env[k].winner_tag();
@@ -119,13 +120,14 @@ struct Model {
       env[k].r = VecRing{&rs[2 * k * S]};
       env[k].init();
       act[k] = 64 * c + k < nz;
+      env[k].set_idle(!act[k]);
     }
     int p_out = 0;
     auto drain = [&](int x_next) {
       for (int k = 0; k < W; ++k) env[k].reload_bottom();
       while (p_out + 3 < nx && p_out + 3 < x_next) {
         bool all4 = true;
-        for (int k = 0; k < W; ++k) all4 = all4 && (!act[k] || env[k].final_at(p_out + 3, x_next));
+        for (int k = 0; k < W; ++k) all4 = all4 && (env[k].final_at(p_out + 3, x_next));
         if (!all4) break;
         for (int j = 0; j < 4; ++j) {
           bool any = false;
@@ -144,7 +146,7 @@ struct Model {
         for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
         if (any)
           for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
-        for (int k = 0; k < W; ++k) all = all && (!act[k] || env[k].final_at(p_out, x_next));
+        for (int k = 0; k < W; ++k) all = all && (env[k].final_at(p_out, x_next));
         if (!all) break;
         for (int k = 0; k < W; ++k)
           if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 20) | env[k].winner_tag();
