@@ -21,6 +21,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 P_DEFAULT = (0.70, 0.35, 0.12, 0.97, 0.80)
+D2_INF = 0x7FFFFFFF   # "observed, no obstacle" in download_field
 
 
 def _observe_all(m, G):
@@ -316,4 +317,30 @@ def test_bulk_engine_every_ring_tier(hip_lib, dims):
     assert st["bulk"] and st["deleted"] == nx * (nz - 1)
     d2 = m.download_field(("d2",))["d2"].reshape(nx, ny, nz)
     assert np.array_equal(d2, np.broadcast_to((z ** 2).astype(np.int32), dims))
+    m.close()
+
+
+def test_bulk_engine_wide_ids_reach_boundary_inside_a_wave(hip_lib):
+    """A map beyond 1024 voxels per axis stores ids modulo 1024 with a reach of 512 voxels.  One obstacle at z = 10: the
+    column group z = 512..575 holds lanes that still see it (z <= 521) next to lanes for which every site is out of
+    reach -- those must read "no obstacle" without holding up their neighbours' emission."""
+    import fiesta_amd
+    dims, res = (1100, 64, 640), 0.1
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, tuple(d * res for d in dims), update_engine="bulk")
+    assert m.grid_size == dims
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    m.SetOccupancyBox((0, 0, 0), tuple(d - 1 for d in dims), 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    obst = np.array([[550, 0, 10]], np.int32)
+    _cycles(m, obst, [], 3)
+    st = m.UpdateESDF()
+    assert st["bulk"] and st["inserted"] == 1
+    d2 = m.download_field(("d2",))["d2"].reshape(dims)
+    x, y, z = np.meshgrid(*[np.arange(d) for d in dims], indexing="ij", sparse=True)
+    e = (x - 550) ** 2 + y ** 2 + (z - 10) ** 2
+    want = np.where(e < (1 << 18), e, D2_INF).astype(np.int64)
+    assert np.array_equal(d2, want)
+    assert (want[550, 0, 512:522] < D2_INF).all() and (want[550, 0, 522:576] == D2_INF).all()
     m.close()
