@@ -104,3 +104,17 @@ def test_far_field_of_a_wall(model):
     out, stats = run(model, occ, 8)
     check_exact(occ, out)
     assert stats[0] >= 8 and stats[1] > 0
+
+
+def test_column_as_long_as_the_deepest_ring_allows(model):
+    """Every site of a 1024-long column equally good and 1023 voxels away: nothing is final before the last site has
+    arrived, so the deque holds one entry per position.  A ring of S slots holds S - 1 entries (one slot stays free for
+    the unconditional store), which is why the deepest tier has twice as many slots as a column has positions."""
+    occ = np.zeros((1024, 1024, 1), np.uint8)
+    occ[:, 0, 0] = 1
+    out, stats = run(model, occ, 64)
+    y = np.arange(1024)
+    got_x, got_y = (out >> 20).astype(np.int64)[:, :, 0], ((out >> 10) & 1023).astype(np.int64)[:, :, 0]
+    assert np.array_equal(got_y, np.zeros((1024, 1024), np.int64))                       # the obstacle straight "below"
+    assert np.array_equal(got_x, np.broadcast_to(np.arange(1024)[:, None], (1024, 1024)))
+    assert stats[0] >= 1022 and stats[2] > 0        # deque as deep as the column is long; the 256-slot tier spilled too
