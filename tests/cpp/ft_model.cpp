@@ -31,6 +31,8 @@ struct Model {
   std::vector<int> rowcnt;        // [nx]
   std::vector<uint32_t> inter;    // [nx][ny][nz]: y' << 10 | z' of the in-plane nearest site (planes with sites only)
   int max_depth = 0;
+  bool wide = false;  // the kernels' WIDE site packing (regions up to 2048 per axis, ids reach 512 voxels): pass B then emits
+                      // d^2 (0x7FFFFFFF: nothing in reach) instead of a packed site
 
   template <int S>
   bool plane_item(int x, int c) {  // pass A for plane x, lanes z = 64 c + k; false: ring overflow
@@ -58,7 +60,7 @@ struct Model {
           if (any)
             for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
           for (int k = 0; k < W; ++k)
-            if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 10) | env[k].winner_tag();
+            if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << (wide ? 11 : 10)) | env[k].winner_tag();
           ++p_out;
         }
       }
@@ -71,7 +73,7 @@ struct Model {
         for (int k = 0; k < W; ++k) all = all && (env[k].final_at(p_out, x_next));
         if (!all) break;
         for (int k = 0; k < W; ++k)
-          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 10) | env[k].winner_tag();
+          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << (wide ? 11 : 10)) | env[k].winner_tag();
         ++p_out;
       }
     };
@@ -90,6 +92,7 @@ struct Model {
       for (int k = 0; k < W; ++k) {
         int d;
         tag[k] = (uint32_t)nearest_in_row(chunk, 64 * c, k, left_out, right_out, d);
+        if (wide && d > 1023) d = 1023;  // (out of an id's reach anyway; keeps f inside its 21 bits)
         f[k] = d * d;
         key[k] = yr * yr + f[k];
       }
@@ -123,6 +126,12 @@ struct Model {
       env[k].set_idle(!act[k]);
     }
     int p_out = 0;
+    bool no_site[W] = {};
+    auto word = [&](int k) -> uint32_t {  // what the kernel's emit() stores (wide: as a squared distance)
+      if (!wide) return ((uint32_t)env[k].winner_q() << 20) | env[k].winner_tag();
+      const int cost = env[k].winner_cost(p_out);
+      return (no_site[k] || cost >= (1 << 18)) ? 0x7FFFFFFFu : (uint32_t)cost;
+    };
     auto drain = [&](int x_next) {
       for (int k = 0; k < W; ++k) env[k].reload_bottom();
       while (p_out + 3 < nx && p_out + 3 < x_next) {
@@ -136,7 +145,7 @@ struct Model {
           if (any)
             for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
           for (int k = 0; k < W; ++k)
-            if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 20) | env[k].winner_tag();
+            if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = word(k);
           ++p_out;
         }
       }
@@ -149,7 +158,7 @@ struct Model {
         for (int k = 0; k < W; ++k) all = all && (env[k].final_at(p_out, x_next));
         if (!all) break;
         for (int k = 0; k < W; ++k)
-          if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << 20) | env[k].winner_tag();
+          if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = word(k);
         ++p_out;
       }
     };
@@ -160,35 +169,58 @@ struct Model {
       if (rowcnt[x]) {
         uint32_t tag[W];
         int f[W], key[W];
+        bool use[W];
+        int pkey[W];
         for (int k = 0; k < W; ++k) {
-          tag[k] = act[k] ? inter[((size_t)x * ny + y) * nz + 64 * c + k] : 0u;
-          const int dy = y - (int)(tag[k] >> 10), dz = 64 * c + k - (int)(tag[k] & 1023u);
+          const uint32_t w = act[k] ? inter[((size_t)x * ny + y) * nz + 64 * c + k] : 0u;
+          use[k] = act[k];
+          int dy, dz;
+          if (wide) {  // offsets from the column as signed 10-bit fields; out of an id's reach: no candidate
+            dy = (int)(w >> 11) - y, dz = (int)(w & 2047u) - (64 * c + k);
+            use[k] = use[k] && (unsigned)(dy + 511) < 1023u && (unsigned)(dz + 511) < 1023u;
+            tag[k] = (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u);
+            if (!use[k]) dy = dz = 0;
+          } else {
+            tag[k] = w;
+            dy = y - (int)(w >> 10), dz = 64 * c + k - (int)(w & 1023u);
+          }
           f[k] = act[k] ? dy * dy + dz * dz : 0;
           key[k] = env[k].key_of(x, f[k]);
+          pkey[k] = (wide && !use[k]) ? env[k].kNoPop : key[k];
         }
         for (;;) {
           bool any = false;
           bool want[W];
-          for (int k = 0; k < W; ++k) any = (want[k] = env[k].wants_pop(x, key[k])) || any;
+          for (int k = 0; k < W; ++k) any = (want[k] = env[k].wants_pop(x, pkey[k])) || any;
           if (!any) break;
           for (int k = 0; k < W; ++k) env[k].pop(want[k]);
         }
         for (int k = 0; k < W; ++k) {
-          env[k].template place<false>(act[k], x, f[k], tag[k], key[k], nx, p_out);
+          env[k].template place<false>(use[k], x, f[k], tag[k], key[k], nx, p_out);
           if (env[k].overflow) return false;
           if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
         }
       }
       // the kernel emits once per batch of 8 planes (and after the last plane)
-      if (x == last)
+      if (x == last) {
+        bool any_site = false;
+        for (int k = 0; k < W; ++k) any_site = any_site || (act[k] && !env[k].empty());
+        if (!any_site) {  // (wide: every site out of reach for the whole wave)
+          for (int p = p_out; p < nx; ++p)
+            for (int k = 0; k < W; ++k)
+              if (act[k]) out[((size_t)p * ny + y) * nz + 64 * c + k] = wide ? 0x7FFFFFFFu : kNone;
+          return true;
+        }
+        for (int k = 0; k < W; ++k)
+          if (wide && act[k] && env[k].empty()) no_site[k] = true, env[k].set_idle(true);
         drain(kFarAhead);
-      else if ((x & 7) == 7)
+      } else if ((x & 7) == 7)
         drain(x + 1);
     }
     if (last < 0) {
       for (int p = 0; p < nx; ++p)
         for (int k = 0; k < W; ++k)
-          if (act[k]) out[((size_t)p * ny + y) * nz + 64 * c + k] = kNone;
+          if (act[k]) out[((size_t)p * ny + y) * nz + 64 * c + k] = wide ? 0x7FFFFFFFu : kNone;
       return true;
     }
     return p_out == nx;
@@ -213,9 +245,20 @@ int run_tier(Model &m, uint32_t *out, std::vector<int> &items_a, std::vector<int
 // occ: nx*ny*nz bytes (x-major, z fastest).  out: packed closest site x<<20|y<<10|z, or 0x80000000 when there is no
 // site at all.  S0: ring size of the first tier (4, 8, 32 or 64); overflowing items go to 256, then 2048 (a ring of S holds S - 1 entries).
 // stats[0] = deepest ring seen, stats[1] = items that overflowed tier 0 (pass A + pass B), stats[2] = tier 1.
+static int model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, uint32_t *out, int *stats, bool wide);
 extern "C" int ft_model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, uint32_t *out, int *stats) {
   if (nx > 1024 || ny > 1024 || nz > 1024) return -1;
+  return model_run(occ, nx, ny, nz, S0, out, stats, false);
+}
+// The WIDE packing of the kernels (regions up to 2048 per axis): out receives SQUARED DISTANCES, 0x7FFFFFFF where no
+// occupied voxel lies within the reach of an id (d^2 >= 2^18).
+extern "C" int ft_model_run_wide(const uint8_t *occ, int nx, int ny, int nz, int S0, uint32_t *out, int *stats) {
+  if (nx > 2048 || ny > 2048 || nz > 2048) return -1;
+  return model_run(occ, nx, ny, nz, S0, out, stats, true);
+}
+static int model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, uint32_t *out, int *stats, bool wide) {
   Model m;
+  m.wide = wide;
   m.nx = nx, m.ny = ny, m.nz = nz, m.nzw = (nz + 31) / 32;
   std::vector<uint32_t> bits((size_t)nx * ny * m.nzw, 0u);
   for (size_t i = 0; i < (size_t)nx * ny * nz; ++i)
@@ -253,7 +296,7 @@ extern "C" int ft_model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, 
   stats[1] = (int)ia.size();
   if (!ia.empty()) run_tier<256>(m, out, ia, none);
   stats[2] = (int)ia.size();
-  if (!ia.empty()) run_tier<2048>(m, out, ia, none);
+  if (!ia.empty()) wide ? run_tier<4096>(m, out, ia, none) : run_tier<2048>(m, out, ia, none);
   if (!ia.empty()) return -2;
   switch (S0) {
     case 4: r = run_tier<4>(m, out, none, ib); break;
@@ -264,7 +307,7 @@ extern "C" int ft_model_run(const uint8_t *occ, int nx, int ny, int nz, int S0, 
   stats[1] += (int)ib.size();
   if (!ib.empty()) run_tier<256>(m, out, none, ib);
   stats[2] += (int)ib.size();
-  if (!ib.empty()) run_tier<2048>(m, out, none, ib);
+  if (!ib.empty()) wide ? run_tier<4096>(m, out, none, ib) : run_tier<2048>(m, out, none, ib);
   (void)r;
   stats[0] = m.max_depth;
   return ib.empty() ? 0 : -3;

@@ -23,6 +23,8 @@ def model():
     lib = C.CDLL(LIB)
     lib.ft_model_run.restype = C.c_int
     lib.ft_model_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ft_model_run_wide.restype = C.c_int
+    lib.ft_model_run_wide.argtypes = lib.ft_model_run.argtypes
     return lib
 
 
@@ -118,3 +120,27 @@ def test_column_as_long_as_the_deepest_ring_allows(model):
     assert np.array_equal(got_y, np.zeros((1024, 1024), np.int64))                       # the obstacle straight "below"
     assert np.array_equal(got_x, np.broadcast_to(np.arange(1024)[:, None], (1024, 1024)))
     assert stats[0] >= 1022 and stats[2] > 0        # deque as deep as the column is long; the 256-slot tier spilled too
+
+
+def test_wide_packing_reach_of_an_id(model):
+    """The kernels' WIDE variant (regions beyond 1024 voxels: ids are stored modulo 1024 and reach 512 voxels): offsets
+    instead of absolute sites, candidates out of reach dropped on arrival, lanes that never see a site in reach, and the
+    cap d^2 < 2^18 -- against brute force on a 1100 x 24 x 700 slab (the first and the last axis exceed the reach)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.RandomState(11)
+    shape = (1100, 24, 700)
+    occ = np.zeros(shape, np.uint8)
+    pts = np.stack([rng.randint(0, 1100, 40), rng.randint(0, 24, 40), rng.randint(0, 40, 40)], -1)   # all near z = 0
+    pts = np.concatenate([pts, [[5, 3, 699]]])                                                        # and one far corner
+    occ[tuple(pts.T)] = 1
+    out = np.empty(shape, np.uint32)
+    stats = np.zeros(3, np.int32)
+    o = np.ascontiguousarray(occ)
+    rc = model.ft_model_run_wide(o.ctypes.data, *shape, 64, out.ctypes.data, stats.ctypes.data)
+    assert rc == 0, rc
+    g = np.stack(np.meshgrid(*[np.arange(n) for n in shape], indexing="ij"), -1).reshape(-1, 3)
+    d, _ = cKDTree(np.argwhere(occ)).query(g)
+    d2 = np.rint(d ** 2).astype(np.int64)
+    want = np.where(d2 < (1 << 18), d2, 0x7FFFFFFF).reshape(shape)
+    assert np.array_equal(out.astype(np.int64), want)
+    assert (want == 0x7FFFFFFF).any() and (want < 0x7FFFFFFF).any()
