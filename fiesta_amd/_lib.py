@@ -117,6 +117,8 @@ def load():
         "fiesta_hip_rccl_unique_id": (C.c_int, [vp]),
         "fiesta_hip_shard_box": (C.c_int, [vp, C.c_int32, C.c_int32, vp, vp]),
         "fiesta_hip_shard_group_create": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),
+        "fiesta_hip_shard_group_precheck": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32]),
+        "fiesta_hip_shard_group_comm_info": (C.c_int, [vp, vp, vp]),
         "fiesta_hip_shard_group_destroy": (C.c_int, [vp]),
         "fiesta_hip_shard_group_update_occupancy": (C.c_int, [vp, C.c_int32, vp, vp, vp]),
         "fiesta_hip_shard_group_update_esdf": (C.c_int, [vp, vp, vp, vp]),
@@ -170,6 +172,10 @@ def load():
     lib._fiesta_signatures = sig
     _lib = lib
     return lib
+
+
+def last_error() -> str:
+    return load().fiesta_hip_last_error().decode(errors="replace")
 
 
 def check(status: int):

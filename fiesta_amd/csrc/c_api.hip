@@ -576,6 +576,27 @@ int fiesta_hip_shard_group_create(fiesta_hip_map *const *shards, const int32_t *
     *out = h;
   });
 }
+int fiesta_hip_shard_group_precheck(fiesta_hip_map *const *shards, const int32_t *ranks, int32_t n_local, int32_t world, int32_t use_rccl) {
+  return guarded([&] {
+    need(shards && ranks && n_local > 0, "null argument");
+    std::vector<DenseMap *> maps;
+    std::vector<int> rk;
+    for (int i = 0; i < n_local; ++i) {
+      maps.push_back(&dense(shards[i], "shard_group_precheck"));
+      rk.push_back(ranks[i]);
+    }
+    fiesta::ShardGroup::precheck(maps, rk, world, use_rccl != 0);
+  });
+}
+int fiesta_hip_shard_group_comm_info(fiesta_hip_shard_group *g, int32_t *nranks, int32_t *rank) {
+  return guarded([&] {
+    need(g && g->g, "null shard group");
+    int n = 0, r = 0;
+    g->g->comm_info(&n, &r);
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+  });
+}
 int fiesta_hip_shard_group_destroy(fiesta_hip_shard_group *g) {
   return guarded([&] {
     if (!g) return;

@@ -7,6 +7,7 @@
 #pragma once
 #include <stdio.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <string>
 
@@ -17,9 +18,15 @@ namespace fiesta {
 
 class DevFile {
  public:
-  DevFile(const char *path, bool write, hipStream_t s) : s_(s), write_(write) {
-    f_ = fopen(path, write ? "wb" : "rb");
+  // Writing goes to "<path>.tmp" and is renamed over <path> by finish(): a crash or a full disk never leaves a
+  // half-written file under the real name.
+  DevFile(const char *path, bool write, hipStream_t s) : s_(s), write_(write), path_(path), tmp_(std::string(path) + ".tmp") {
+    f_ = fopen(write ? tmp_.c_str() : path, write ? "wb" : "rb");
     if (!f_) throw Error(FIESTA_HIP_ERR_INVALID, std::string("checkpoint: cannot open ") + path);
+    if (!write) {
+      struct stat st;
+      if (fstat(fileno(f_), &st) == 0) size_ = (unsigned long long)st.st_size;
+    }
     if (hipHostMalloc(&pin_, kChunk) != hipSuccess) {
       fclose(f_);
       throw Error(FIESTA_HIP_ERR_NOMEM, "checkpoint: no pinned staging buffer");
@@ -27,7 +34,10 @@ class DevFile {
   }
   ~DevFile() {
     if (pin_) (void)hipHostFree(pin_);
-    if (f_) fclose(f_);
+    if (f_) {
+      fclose(f_);
+      if (write_) (void)remove(tmp_.c_str());  // (finish() was never reached)
+    }
   }
   DevFile(const DevFile &) = delete;
   DevFile &operator=(const DevFile &) = delete;
@@ -56,8 +66,17 @@ class DevFile {
     }
   }
   bool writing() const { return write_; }
+  unsigned long long file_size() const { return size_; }  // (reading only)
+  unsigned long long position() const { return (unsigned long long)ftell(f_); }
   void finish() {
-    if (write_ && fflush(f_) != 0) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: flush failed");
+    if (!write_) return;
+    const bool ok = fflush(f_) == 0;
+    const bool closed = fclose(f_) == 0;
+    f_ = nullptr;
+    if (!ok || !closed || rename(tmp_.c_str(), path_.c_str()) != 0) {
+      (void)remove(tmp_.c_str());
+      throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: flush / rename failed");
+    }
   }
 
  private:
@@ -66,26 +85,30 @@ class DevFile {
   void *pin_ = nullptr;
   hipStream_t s_;
   bool write_;
+  std::string path_, tmp_;
+  unsigned long long size_ = 0;
 };
 
 struct CheckpointHeader {
   char magic[8];  // "FIESTAHP"
   uint32_t version, mode;
   int32_t grid[3], shard_lo[3], global[3];
+  uint32_t pad;  // (explicit: the header is compared byte by byte)
   double res, org[3];
 };
+static_assert(sizeof(CheckpointHeader) == 8 + 8 + 36 + 4 + 32, "checkpoint header has no implicit padding");
 inline void checkpoint_header(DevFile &f, uint32_t mode, const Geom &g) {
   CheckpointHeader h, mine;
   memset(&mine, 0, sizeof(mine));
   memcpy(mine.magic, "FIESTAHP", 8);
-  mine.version = 2;
+  mine.version = 3;
   mine.mode = mode;
   mine.grid[0] = g.nx, mine.grid[1] = g.ny, mine.grid[2] = g.nz;
   if (mode == FIESTA_HIP_MODE_ARRAY) mine.shard_lo[0] = g.gx0, mine.shard_lo[1] = g.gy0, mine.shard_lo[2] = g.gz0;
   mine.global[0] = g.GX, mine.global[1] = g.GY, mine.global[2] = g.GZ;
   mine.res = g.res;
   for (int k = 0; k < 3; ++k) mine.org[k] = g.org[k];
-  h = mine;
+  memcpy(&h, &mine, sizeof(h));
   f.host(&h, sizeof(h));
   if (!f.writing() && memcmp(&h, &mine, sizeof(h)) != 0)
     throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: file was written by a map of another mode, geometry or format version");

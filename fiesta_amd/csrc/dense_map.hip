@@ -733,8 +733,6 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
 
   if (cfg.update_engine < 0 || cfg.update_engine > 2) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
   update_engine_ = cfg.update_engine;
-  if (update_engine_ == 0)  // (test suites run every scenario on both engines through this)
-    if (const char *e = getenv("FIESTA_HIP_UPDATE_ENGINE")) update_engine_ = std::min(2, std::max(0, atoi(e)));
   ntx_ = (g.nx + tx_ - 1) / tx_;
   nty_ = (g.ny + ty_ - 1) / ty_;
   ntz_ = (g.nz + 31) / 32;
@@ -1702,14 +1700,32 @@ void DenseMap::checkpoint(const char *path, bool write) {
   unsigned long long c[C_COUNT];
   memcpy(c, h_counters_, sizeof(c));
   f.host(c, sizeof(c));
-  f.host(&pp_, sizeof(pp_));
+  ProbParams pp = pp_;
+  f.host(&pp, sizeof(pp));
   Geom g = g_;
-  f.host(&g, sizeof(g));  // (the update ranges; the rest is pinned by the header)
+  f.host(&g, sizeof(g));  // (only the update ranges are taken from the file; the rest must equal this map's)
   uint32_t flags[4] = {stale_inf_ ? 1u : 0u, gocc_ ? 1u : 0u, 0u, 0u};
   f.host(flags, sizeof(flags));
   if ((flags[1] != 0) != (gocc_ != nullptr)) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: sharded / unsharded mismatch");
   const size_t nt = c[C_TOUCHED], ni = c[C_INSERT], nd = c[C_DELETE];
   if (!write) {
+    // Everything the file claims is checked BEFORE any device state is replaced: the layout half of its Geom against
+    // this map's, the queue lengths against the grid, and the file's size against the sum of its sections -- a
+    // truncated or foreign file is refused with the map untouched.  (An I/O error after this point leaves the map
+    // undefined: the caller must discard it.)
+    Geom a = g, b = g_;
+    a.wx0 = a.wy0 = a.wz0 = a.wx1 = a.wy1 = a.wz1 = a.px0 = a.py0 = a.pz0 = a.px1 = a.py1 = a.pz1 = 0;
+    b.wx0 = b.wy0 = b.wz0 = b.wx1 = b.wy1 = b.wz1 = b.px0 = b.py0 = b.pz0 = b.px1 = b.py1 = b.pz1 = 0;
+    if (memcmp(&a, &b, sizeof(Geom)) != 0) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: geometry of the file does not match this map");
+    const int wlo[3] = {g.wx0, g.wy0, g.wz0}, whi[3] = {g.wx1, g.wy1, g.wz1}, plo[3] = {g.px0, g.py0, g.pz0}, phi[3] = {g.px1, g.py1, g.pz1};
+    for (int k = 0; k < 3; ++k)  // (windows are voxel coordinates of Pos2Vox of clamped positions: a few voxels around the array at most)
+      if (wlo[k] < -4 || whi[k] > 4096 + 4 || plo[k] < -4 || phi[k] > 4096 + 4) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: update range of the file is out of bounds");
+    if (nt > (size_t)g_.n || ni > (size_t)g_.n || nd > (size_t)g_.n) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: queue lengths of the file exceed the grid");
+    const unsigned long long sections = 7 + (gocc_ ? 1 : 0);
+    const unsigned long long expect = f.position() + sections * sizeof(unsigned long long) + (unsigned long long)g_.n * (sizeof(vox_t) + sizeof(double) + sizeof(unsigned long long)) +
+                                      (unsigned long long)nbitwords_ * sizeof(uint32_t) + (gocc_ ? (unsigned long long)ngoccwords_ * sizeof(uint32_t) : 0ull) +
+                                      (unsigned long long)(nt + ni + nd) * sizeof(uint32_t);
+    if (f.file_size() != expect) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: file size does not match its header (truncated or corrupt)");
     touched_.ensure(nt, stream_);
     ins_.ensure(ni, stream_);
     del_.ensure(nd, stream_);
@@ -1728,7 +1744,9 @@ void DenseMap::checkpoint(const char *path, bool write) {
   memcpy(h_counters_, c, sizeof(c));
   FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
   touched_upper_ = (int64_t)nt;
-  g_ = g;
+  pp_ = pp;
+  g_.wx0 = g.wx0, g_.wy0 = g.wy0, g_.wz0 = g.wz0, g_.wx1 = g.wx1, g_.wy1 = g.wy1, g_.wz1 = g.wz1;  // (the ranges only)
+  g_.px0 = g.px0, g_.py0 = g.py0, g_.pz0 = g.pz0, g_.px1 = g.px1, g_.py1 = g.py1, g_.pz1 = g.pz1;
   stale_inf_ = flags[0] != 0;
   host_counts_valid_ = false;
   if (track_) {

@@ -613,19 +613,40 @@ void HashMap::checkpoint(const char *path, bool write) {
   unsigned long long c[C_COUNT];
   memcpy(c, h_counters_, sizeof(c));
   f.host(c, sizeof(c));
-  f.host(&pp_, sizeof(pp_));
+  ProbParams pp = pp_;
+  f.host(&pp, sizeof(pp));
   Geom g = g_;
   f.host(&g, sizeof(g));
-  f.host(ur_, sizeof(ur_));
-  f.host(pr_, sizeof(pr_));
+  int64_t ur[6], pr[6];
+  memcpy(ur, ur_, sizeof(ur));
+  memcpy(pr, pr_, sizeof(pr));
+  f.host(ur, sizeof(ur));
+  f.host(pr, sizeof(pr));
   int64_t meta[4] = {npages_, moves_, dropped_host_, force_scan_ ? 1 : 0};
   f.host(meta, sizeof(meta));
   const size_t nt = c[C_TOUCHED], ni = c[C_INSERT], nd = c[C_DELETE];
   if (!write) {
+    // validate everything the file claims before any state of this map is replaced (see DenseMap::checkpoint)
+    Geom a = g, b = g_;
+    for (Geom *q : {&a, &b}) {  // the window origin and the update ranges are state; the rest is identity
+      q->gx0 = q->gy0 = q->gz0 = 0;
+      q->wx0 = q->wy0 = q->wz0 = q->wx1 = q->wy1 = q->wz1 = q->px0 = q->py0 = q->pz0 = q->px1 = q->py1 = q->pz1 = 0;
+    }
+    if (memcmp(&a, &b, sizeof(Geom)) != 0) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: geometry of the file does not match this map");
+    if (meta[0] < 0 || meta[0] > (int64_t)kNTiles * 64) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: page count of the file is out of bounds");
+    const unsigned long long pv = (unsigned long long)meta[0] * kPageVox;
+    if (nt > pv || ni > pv || nd > pv) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: queue lengths of the file exceed its pages");
+    const unsigned long long expect = f.position() + 11ull * sizeof(unsigned long long) + pv * (sizeof(vox_t) + sizeof(double) + sizeof(unsigned long long)) +
+                                      (unsigned long long)meta[0] * kPageRows * sizeof(uint32_t) + (unsigned long long)meta[0] * (sizeof(int32_t) * 4 + sizeof(uint32_t)) +
+                                      (unsigned long long)kNTiles * sizeof(int32_t) + (unsigned long long)(nt + ni + nd) * sizeof(uint32_t);
+    if (f.file_size() != expect) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: file size does not match its header (truncated or corrupt)");
     const int64_t had = npages_;
     ensure_pages(std::max<int64_t>(meta[0], 8));
     if (had > meta[0]) pristine_pages(meta[0], had - meta[0]);  // what this map held beyond the file's pages
     npages_ = meta[0];
+    pp_ = pp;
+    memcpy(ur_, ur, sizeof(ur_));
+    memcpy(pr_, pr, sizeof(pr_));
     touched_.ensure(nt, stream_);
     ins_.ensure(ni, stream_);
     del_.ensure(nd, stream_);

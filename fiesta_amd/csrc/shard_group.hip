@@ -40,6 +40,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -62,6 +64,8 @@ struct Rccl {
       r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
       r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
       r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+      r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+      r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
       r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
       r.Send = (decltype(r.Send))sym("ncclSend");
       r.Recv = (decltype(r.Recv))sym("ncclRecv");
@@ -134,25 +138,52 @@ static void local_array(const int gg[3], int world, int rank, int org[3], int di
   }
 }
 
-ShardGroup::ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id)
-    : world_(world) {
+void ShardGroup::precheck(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, bool rccl) {
   if (maps.empty() || maps.size() != ranks.size()) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: bad shard list");
   const Geom &g0 = maps[0]->geom();
   if (!g0.sharded) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: maps must be created as shards (global_grid / shard_lo)");
+  const int gg[3] = {g0.GX, g0.GY, g0.GZ};
+  int l[3];
+  layout_of(world, l);
+  if (rccl && maps.size() != 1) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: one shard per process under RCCL");
+  if (!rccl && (int)maps.size() != world) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: without RCCL every shard must be local");
+  for (size_t i = 0; i < maps.size(); ++i) {
+    if (ranks[i] < 0 || ranks[i] >= world) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: rank out of range");
+    const Geom &g = maps[i]->geom();
+    int org[3], dims[3], olo[3], osz[3];
+    local_array(gg, world, ranks[i], org, dims, olo, osz);
+    if (!g.sharded || g.GX != gg[0] || g.GY != gg[1] || g.GZ != gg[2] || org[0] != g.gx0 || org[1] != g.gy0 || org[2] != g.gz0 ||
+        dims[0] != g.nx || dims[1] != g.ny || dims[2] != g.nz)
+      throw Error(FIESTA_HIP_ERR_INVALID, "shard group: a shard's box does not match the regular cut of the global grid");
+  }
+  if (rccl) (void)Rccl::get();  // (throws when librccl cannot be loaded)
+}
+
+void ShardGroup::comm_info(int *nranks, int *rank) const {
+  int n = 0, r = locals_.empty() ? 0 : locals_[0]->rank;
+  if (comm_) {
+    FIESTA_RCCL_CHECK(Rccl::get().CommCount((ncclComm_t)comm_, &n));
+    FIESTA_RCCL_CHECK(Rccl::get().CommUserRank((ncclComm_t)comm_, &r));
+  }
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+}
+
+ShardGroup::ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id)
+    : world_(world) {
+  precheck(maps, ranks, world, rccl_id != nullptr);
+  const Geom &g0 = maps[0]->geom();
   gg_[0] = g0.GX, gg_[1] = g0.GY, gg_[2] = g0.GZ;
   int l[3];
   layout_of(world, l);
-  if (rccl_id && maps.size() != 1) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: one shard per process under RCCL");
-  if (!rccl_id && (int)maps.size() != world) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: without RCCL every shard must be local");
   for (size_t i = 0; i < maps.size(); ++i) {
     auto L = std::make_unique<Local>();
     L->map = maps[i];
     L->rank = ranks[i];
     const Geom &g = maps[i]->geom();
     int org[3], dims[3], olo[3], osz[3];
-    local_array(gg_, world, ranks[i], org, dims, olo, osz);
-    if (org[0] != g.gx0 || org[1] != g.gy0 || org[2] != g.gz0 || dims[0] != g.nx || dims[1] != g.ny || dims[2] != g.nz)
-      throw Error(FIESTA_HIP_ERR_INVALID, "shard group: a shard's box does not match the regular cut of the global grid");
+    local_array(gg_, world, ranks[i], org, dims, olo, osz);  // (validated by precheck)
+    (void)g;
     const int c[3] = {ranks[i] / (l[1] * l[2]), (ranks[i] / l[2]) % l[1], ranks[i] % l[2]};
     // neighbours in a fixed order (dx, dy, dz lexicographic): both sides enumerate their links the same way
     for (int dx = -1; dx <= 1; ++dx)
@@ -351,6 +382,14 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
       if (!exact) continue;
       for (size_t i = 0; i < locals_.size(); ++i) {
         locals_[i]->map->bulk_commit(&ss[i]);
+        // The transform rewrote owned AND ghost cells on every shard behind the exchange's back: what was "last sent" no
+        // longer describes what the peers hold (a later frontier update could find w == shadow for a cell whose ghost
+        // copy differs and send nothing -- ADVICE r2).  Forget it: the next diff resends the boundary, and
+        // halo_apply_sparse skips the cells that are equal anyway.
+        for (Link &k : locals_[i]->links) {
+          FIESTA_HIP_CHECK(hipSetDevice(locals_[i]->map->device()));
+          FIESTA_HIP_CHECK(hipMemsetAsync(k.shadow.p, 0xFF, (size_t)k.cells * sizeof(uint32_t), locals_[i]->map->stream()));
+        }
         total.inserted += ss[i].inserted, total.deleted += ss[i].deleted;
         total.relax_ms = std::max(total.relax_ms, ss[i].relax_ms);
         total.ft_rows_ms = std::max(total.ft_rows_ms, ss[i].ft_rows_ms);

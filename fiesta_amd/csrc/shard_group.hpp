@@ -20,6 +20,12 @@ class ShardGroup {
   // rccl_id == nullptr: all `world` shards live in this process (tests, N shards multiplexed on one GPU).
   ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id);
   ~ShardGroup();
+  // Everything the constructor checks LOCALLY (shard boxes against the regular cut, set-up rules, librccl loadable when
+  // `rccl`), without the collective ncclCommInitRank: ranks agree on the outcome of this first, so that one rank's local
+  // failure cannot leave the others blocked inside the communicator set-up.  Throws like the constructor would.
+  static void precheck(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, bool rccl);
+  // ranks the RCCL communicator reports (ncclCommCount; 0 on the local transport) and this process's rank in it
+  void comm_info(int *nranks, int *rank) const;
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
   void update_esdf(fiesta_hip_stats *st, int32_t *sweeps, int64_t *entries_sent);
 

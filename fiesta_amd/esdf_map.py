@@ -21,6 +21,9 @@ from ._lib import Config, FiestaHipError, RaycastParams, Stats, check
 UNDEFINED = -10000   # undefined_  (src/ESDFMap.cpp:182)
 INFINITY = 10000     # infinity_   (src/ESDFMap.cpp:181)
 D2_INF = 0x7FFFFFFF
+# what `update_engine=None` means (the library itself reads no environment: the test suites switch this attribute to run
+# every scenario on both UpdateESDF engines)
+DEFAULT_UPDATE_ENGINE = 0
 
 
 def _p(a):
@@ -35,7 +38,7 @@ class ESDFMap:
     """Drop-in for ``fiesta::ESDFMap``; array mode by default, hash-block mode with ``mode="hash"``."""
 
     def __init__(self, origin, resolution, map_size=None, reserve_size=0, mode="array", device=0,
-                 update_engine=0, shard_lo=None, global_grid=None):
+                 update_engine=None, shard_lo=None, global_grid=None):
         self._lib = _lib.load()
         cfg = Config()
         cfg.mode = 0 if mode == "array" else 1
@@ -44,6 +47,8 @@ class ESDFMap:
         cfg.resolution = float(resolution)
         cfg.map_size[:] = list(_d3(map_size if map_size is not None else (0, 0, 0)))
         cfg.reserve_size = int(reserve_size)
+        if update_engine is None or update_engine == 0 or update_engine == "auto":
+            update_engine = DEFAULT_UPDATE_ENGINE
         cfg.update_engine = {"auto": 0, "rounds": 1, "bulk": 2}.get(update_engine, update_engine)
         if shard_lo is not None:
             cfg.shard_lo[:] = [int(v) for v in shard_lo]

@@ -263,7 +263,18 @@ class ShardedESDFMap:
         lib = _lib.load()
         ranks = sorted(self.shards)
         rccl_id = None
-        if self.n_shards > 1 and len(ranks) == 1:
+        handles = (C.c_void_p * len(ranks))(*[self.shards[r]._h for r in ranks])
+        rk = (C.c_int32 * len(ranks))(*ranks)
+        use_rccl = self.n_shards > 1 and len(ranks) == 1
+        # local preconditions first, agreed on by every rank BEFORE the collective communicator set-up: a rank that
+        # fails here must not leave the others blocked inside ncclCommInitRank
+        bad = int(lib.fiesta_hip_shard_group_precheck(handles, rk, len(ranks), self.n_shards, int(use_rccl)) != 0)
+        why = _lib.last_error() if bad else ""
+        if use_rccl:
+            bad = int(self.transport.allreduce_sum(bad))
+        if bad:
+            raise RuntimeError(f"native shard group: local preconditions failed on {bad} rank(s) {why}")
+        if use_rccl:
             buf = np.zeros(129, np.uint8)  # 128 bytes of id + "rank 0 got one" (every rank takes part in the broadcast)
             if self.transport.rank == 0:
                 buf[128] = lib.fiesta_hip_rccl_unique_id(buf.ctypes.data_as(C.c_void_p)) == 0
@@ -271,12 +282,19 @@ class ShardedESDFMap:
             if not got[128]:
                 raise RuntimeError("rank 0 could not create an RCCL unique id (librccl.so not loadable?)")
             rccl_id = np.ascontiguousarray(got[:128])
-        handles = (C.c_void_p * len(ranks))(*[self.shards[r]._h for r in ranks])
-        rk = (C.c_int32 * len(ranks))(*ranks)
         g = C.c_void_p()
         idp = rccl_id.ctypes.data_as(C.c_void_p) if rccl_id is not None else None
         _lib.check(lib.fiesta_hip_shard_group_create(handles, rk, len(ranks), self.n_shards, idp, C.byref(g)))
         self._group, self._glib, self._check = g, lib, _lib.check
+
+    def comm_info(self):
+        """(ranks the RCCL communicator itself reports -- 0 on the in-process transport --, this process's rank in it)."""
+        import ctypes as C
+        if self._group is None:
+            return 0, 0
+        n, r = C.c_int32(0), C.c_int32(0)
+        self._check(self._glib.fiesta_hip_shard_group_comm_info(self._group, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     # -- plumbing ---------------------------------------------------------------------------------------------
     def _owner_masks(self, vox):

@@ -328,6 +328,8 @@ inline void RaycastFrameSigned(ESDFMap &esdf_map, ESDFMap &inv_esdf_map, const f
                                const double transform[16], const Eigen::Vector3d &raycast_origin, double min_ray_length,
                                double max_ray_length, const Eigen::Vector3d &l_cornor, const Eigen::Vector3d &r_cornor) {
   const double o[3] = {raycast_origin(0), raycast_origin(1), raycast_origin(2)};
+  esdf_map.Flush();  // buffered SetOccupancy calls come BEFORE the frame, as they would in the reference
+  inv_esdf_map.Flush();
   fiesta_hip_raycast_params p{min_ray_length, max_ray_length, {l_cornor(0), l_cornor(1), l_cornor(2)},
                               {r_cornor(0), r_cornor(1), r_cornor(2)}, /*dedup=*/1, /*inverse=*/0};
   if (fiesta_hip_raycast_frame(esdf_map.Handle(), points, n, transform, o, &p) != FIESTA_HIP_OK)
@@ -338,8 +340,12 @@ inline void RaycastFrameSigned(ESDFMap &esdf_map, ESDFMap &inv_esdf_map, const f
 }
 // ... and the quantity the pair exists for (the reference leaves it as a TODO): distance to the nearest obstacle minus
 // distance to the nearest voxel observed free -- positive in free space, negative inside obstacles.
+// NaN where either map holds no distance there (-10000 outside the map / +10000 unobserved or no obstacle), like the
+// Python helper fiesta_amd.signed_distance.
 inline double SignedDistance(ESDFMap &esdf_map, ESDFMap &inv_esdf_map, const Eigen::Vector3d &pos) {
-  return esdf_map.GetDistance(pos) - inv_esdf_map.GetDistance(pos);
+  const double d = esdf_map.GetDistance(pos), di = inv_esdf_map.GetDistance(pos);
+  if (!(std::fabs(d) < 10000.0) || !(std::fabs(di) < 10000.0)) return std::nan("");
+  return d - di;
 }
 
 }  // namespace fiesta

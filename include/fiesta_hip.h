@@ -325,6 +325,14 @@ int fiesta_hip_rccl_unique_id(uint8_t id[128]);
 int fiesta_hip_shard_box(const int32_t global_grid[3], int32_t world, int32_t rank, int32_t lo[3], int32_t size[3]);
 int fiesta_hip_shard_group_create(fiesta_hip_map *const *local_shards, const int32_t *local_ranks, int32_t n_local,
                                   int32_t world, const uint8_t *rccl_id, fiesta_hip_shard_group **out);
+/* The LOCAL half of _create's checks (shard boxes against the regular cut, set-up rules, librccl loadable when
+ * use_rccl) without the collective communicator set-up: ranks exchange the outcome of this first (out of band), so that
+ * one rank's local failure cannot leave the others blocked inside ncclCommInitRank. */
+int fiesta_hip_shard_group_precheck(fiesta_hip_map *const *local_shards, const int32_t *local_ranks, int32_t n_local,
+                                    int32_t world, int32_t use_rccl);
+/* What the RCCL communicator itself reports: *nranks = ncclCommCount (0: local transport, no communicator),
+ * *rank = ncclCommUserRank.  For self-verifying multi-GPU runs (bench.py prints it). */
+int fiesta_hip_shard_group_comm_info(fiesta_hip_shard_group *g, int32_t *nranks, int32_t *rank);
 int fiesta_hip_shard_group_destroy(fiesta_hip_shard_group *g);
 /* ESDFMap::UpdateOccupancy of the whole map: *n_insert / *n_delete are the queue sizes summed over all shards. */
 int fiesta_hip_shard_group_update_occupancy(fiesta_hip_shard_group *g, int32_t global_map, int64_t *n_insert,

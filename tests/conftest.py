@@ -39,7 +39,10 @@ def hip_lib():
 @pytest.fixture(params=["rounds", "bulk"])
 def engine(request, monkeypatch):
     """Runs a GPU test once per UpdateESDF engine: frontier rounds only / bulk feature transform wherever the map state
-    allows it (maps created without an explicit update_engine read FIESTA_HIP_UPDATE_ENGINE).  On fully observed maps
-    both must reproduce the reference exactly; elsewhere "bulk" falls back to the rounds by itself."""
-    monkeypatch.setenv("FIESTA_HIP_UPDATE_ENGINE", {"rounds": "1", "bulk": "2"}[request.param])
+    allows it (maps created without an explicit update_engine take fiesta_amd.esdf_map.DEFAULT_UPDATE_ENGINE; the library
+    itself reads no environment).  On fully observed maps both must reproduce the reference exactly; elsewhere "bulk"
+    falls back to the rounds by itself."""
+    import fiesta_amd.esdf_map as em
+    monkeypatch.setattr(em, "DEFAULT_UPDATE_ENGINE", {"rounds": 1, "bulk": 2}[request.param])
+    monkeypatch.setenv("FIESTA_TEST_UPDATE_ENGINE", {"rounds": "1", "bulk": "2"}[request.param])  # (spawned workers)
     return request.param

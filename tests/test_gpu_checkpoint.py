@@ -65,6 +65,22 @@ def test_dense_checkpoint_mid_frame(hip_lib, oracle_libs, best_oracle_kind, tmp_
         other.load(path)
     with pytest.raises(fiesta_amd.FiestaHipError):
         b.load(str(tmp_path / "missing.ckpt"))
+    # ... and so is a damaged one, BEFORE any state of the map is replaced: truncated, grown, and one whose
+    # queue length field claims more entries than the grid has voxels
+    import os
+    raw = open(path, "rb").read()
+    assert not os.path.exists(path + ".tmp")            # (written to a temporary name, renamed when complete)
+    before = b.download_field()
+    # (88-byte header, then the counters: C_TOUCHED, C_INSERT, C_DELETE lead)
+    for name, blob in (("short", raw[:len(raw) // 2]), ("long", raw + b"\0" * 64),
+                       ("queues", raw[:88 + 8] + (2 ** 40).to_bytes(8, "little") + raw[88 + 16:])):
+        bad = str(tmp_path / f"{name}.ckpt")
+        open(bad, "wb").write(blob)
+        with pytest.raises(fiesta_amd.FiestaHipError):
+            b.load(bad)
+        after = b.download_field()
+        assert all(np.array_equal(before[k], after[k]) for k in before), name
+    b.load(path)                                        # the map is still usable
 
 
 def test_hash_checkpoint_with_moved_window(hip_lib, oracle_libs, best_oracle_kind, tmp_path):

@@ -70,6 +70,54 @@ def test_sharded_matches_single_grid_oracle(hip_lib, oracle_libs, best_oracle_ki
     sm.close()
 
 
+@pytest.mark.parametrize("n_shards", [2, 8])
+def test_bulk_then_rounds_updates_next_to_a_cut(hip_lib, oracle_libs, best_oracle_kind, n_shards):
+    """ADVICE r2 (shard_group.hip): a committed bulk transform rewrites owned and ghost cells behind the ghost exchange's
+    back; the per-link "last sent" shadows must not survive it.  Sequence: frontier update inserting an obstacle A next to
+    a cut (shadows = field with A), bulk update that deletes A, small frontier update that re-inserts A -- the owner
+    relaxes straight back to the words it sent last, and only a forgotten shadow makes it resend them.  Engine chosen per
+    update (auto): the large deltas go bulk, the single-voxel ones take the rounds."""
+    from fiesta_amd.sharded import ShardedESDFMap
+    import fiesta_amd.esdf_map as em
+    gs, res = (64, 64, 64), 0.1
+    old, em.DEFAULT_UPDATE_ENGINE = em.DEFAULT_UPDATE_ENGINE, 0
+    try:
+        sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards)
+    finally:
+        em.DEFAULT_UPDATE_ENGINE = old
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res), kind=best_oracle_kind)
+    for m in (sm, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    allv = np.stack(np.meshgrid(*[np.arange(n) for n in gs], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    rng = np.random.RandomState(5)
+    A = np.array([[30, 20, 20]], np.int32)                 # two voxels from the cut at x = 32
+    far = np.unique((rng.rand(90, 3) * gs).astype(np.int32), axis=0)
+    far = far[np.abs(far[:, 0] - 32) > 14][:60]            # A's cell reaches well across the cut
+    none = np.zeros((0, 3), np.int32)
+
+    def step(occ, free, want_bulk):
+        for _ in range(6 if len(free) else 3):
+            for v, o in ((occ, 1), (free, 0)):
+                if len(v):
+                    sm.SetOccupancy(v, o)
+                    cpu.SetOccupancyVox(v, o)
+            assert sm.UpdateOccupancy(True) == cpu.UpdateOccupancy(True)
+        sg, sc = sm.UpdateESDF(), cpu.UpdateESDF()
+        assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+        assert bool(sg["bulk"]) == want_bulk, sg
+        compare(sm, cpu, gs)
+    drive(sm, cpu, [(none, allv, 1)])
+    step(far, none, True)              # bulk: the whole obstacle set at once
+    step(A, none, False)               # rounds: boundary words sent, shadows = the field with A
+    step(far[:20] + 1, np.concatenate([A, far[:10]]), True)    # bulk: deletes A, rewrites the field on every shard
+    step(A, none, False)               # rounds: the owner returns to the words it sent two updates ago
+    step(none, A, False)               # rounds: ... and leaves them again
+    step(far[:10], far[20:50], True)   # bulk once more, then a frontier update on top of it
+    step(A, none, False)
+    sm.close()
+
+
 def test_single_obstacle_wave_crosses_every_shard(hip_lib, oracle_libs, best_oracle_kind, engine):
     """The adversarial case of SURVEY.md 8e: one obstacle in a corner, its wave must cross all 8 shards."""
     from fiesta_amd.sharded import ShardedESDFMap
@@ -139,6 +187,8 @@ def _dist_worker(rank, world, port, gs, q):
         sys.path.insert(0, here)
         sys.path.insert(0, os.path.dirname(here))
         from fiesta_amd.sharded import DistTransport, ShardedESDFMap
+        import fiesta_amd.esdf_map as em
+        em.DEFAULT_UPDATE_ENGINE = int(os.environ.get("FIESTA_TEST_UPDATE_ENGINE", "0"))  # (the `engine` fixture of the parent)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world)
         sm = ShardedESDFMap((0, 0, 0), 0.1, gs, world, transport=DistTransport(), devices=(0,))
