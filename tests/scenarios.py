@@ -83,6 +83,16 @@ def oracle_d2(dump, grid_size):
     return d2.astype(np.int64), vox
 
 
+def d2_from_dist(dist, res):
+    """distance_buffer_ (metres) -> integer squared voxel distance: -1 never observed, D2_INF observed / no obstacle.
+    (Where the local-map reset left closest_obstacle_ stale, src/ESDFMap.cpp:256-259, this -- not the id -- is what a
+    query returns.)"""
+    d2 = np.rint((np.asarray(dist, np.float64) / res) ** 2).astype(np.int64)
+    d2[dist >= 10000] = D2_INF
+    d2[dist < 0] = -1
+    return d2
+
+
 def compare_dense(gpu_map, cpu_map, check_logodds=True):
     """The parity contract: d^2 exact; closest obstacle tie-equivalent; occupancy exact.
     Returns a report dict; raises AssertionError on any violation."""
@@ -124,6 +134,8 @@ def compare_dense(gpu_map, cpu_map, check_logodds=True):
     report["gpu_closer"] = int((gd2[mism] < od2[mism]).sum())
     report["gpu_farther"] = int((gd2[mism] > od2[mism]).sum())
     report["pair_violations"] = fixed_point_violations(gd2, gc, gs, mism)
+    if hasattr(cpu_map, "judge"):        # an EnvelopeOracle: the reference's own order spread on this very scenario
+        report["envelope"] = cpu_map.judge(gd2)
     return report
 
 
@@ -307,3 +319,142 @@ def c4_frame(k, res=0.05):
 def box_voxels(lo, hi):
     g = np.stack(np.meshgrid(*(np.arange(lo[i], hi[i] + 1, dtype=np.int32) for i in range(3)), indexing="ij"), -1)
     return np.ascontiguousarray(g.reshape(-1, 3))
+
+
+# ---- the reference's own order spread as the parity contract on partially observed maps ---------------------------------
+class EnvelopeOracle:
+    """The oracle map a test drives (``primary``) plus K companions that receive THE SAME observations in shuffled
+    first-touch order -- same hit/miss counters, hence bit-identical occupancy and queues' contents; only the order of
+    occupancy_queue_ (src/ESDFMap.cpp:426,239) and with it of insert_queue_/delete_queue_ and of the BFS differs.
+
+    On partially observed maps the reference's distances depend on that order (tests/test_oracle_order_sensitivity.py),
+    so "equal to the reference" is not defined voxel by voxel there.  What IS defined: the K + 1 runs of the verbatim
+    reference span, per voxel, an interval [min, max] of squared distances (a single value wherever they agree, which is
+    the case on 98-99 % of the voxels).  An engine is judged against that envelope (``judge``), and the allowance for
+    voxels outside it is not a constant: it is measured on the same scenario, from the reference itself, as the number of
+    voxels on which ONE of its runs leaves the envelope of the OTHERS (leave-one-out) -- an engine with its own processing
+    order is one more such run.
+
+    Used exactly like an OracleMap (attribute access falls through to the primary); UpdateOccupancy first replays the
+    primary's pending counters into the companions."""
+
+    def __init__(self, make, k=4, seed=20240924):
+        self.primary = make()
+        self.companions = [make() for _ in range(k)]
+        self._rng = np.random.RandomState(seed)
+        self.mode = getattr(self.primary, "mode", "array")
+
+    def __getattr__(self, name):          # everything not overridden below (queries, dumps, grid_size, ...) -> primary
+        return getattr(self.primary, name)
+
+    @property
+    def maps(self):
+        return [self.primary] + self.companions
+
+    def close(self):
+        for m in self.maps:
+            m.close()
+
+    def SetParameters(self, *p):
+        for m in self.maps:
+            m.SetParameters(*p)
+
+    def SetOriginalRange(self):
+        for m in self.maps:
+            m.SetOriginalRange()
+
+    def SetUpdateRange(self, a, b, new_vec=True):
+        for m in self.maps:
+            m.SetUpdateRange(a, b, new_vec)
+
+    def _pending(self):
+        hit, total = self.primary.dump_counts()       # (num_miss_ counts every observation, src/ESDFMap.cpp:424-434)
+        idx = np.flatnonzero(total > 0)
+        if self.mode == "hash":
+            vox = self.primary.dump_hash()["vox"][idx]
+        else:
+            nx, ny, nz = self.primary.grid_size
+            vox = np.stack([idx // (ny * nz), (idx // nz) % ny, idx % nz], -1)
+        return vox.astype(np.int32), hit[idx].astype(np.int64), total[idx].astype(np.int64)
+
+    def _replay(self):
+        vox, hit, total = self._pending()
+        if len(vox) == 0:
+            return
+        for c in self.companions:
+            order = self._rng.permutation(len(vox))
+            t, h = total[order], hit[order]
+            v = np.repeat(vox[order], t, 0)
+            start = np.repeat(np.cumsum(t) - t, t)
+            occ = ((np.arange(len(v)) - start) < np.repeat(h, t)).astype(np.int32)
+            c.SetOccupancyVox(v, occ)
+
+    def UpdateOccupancy(self, global_map=True):
+        self._replay()
+        r = self.primary.UpdateOccupancy(global_map)
+        self.last_insert, self.last_delete = self.primary.last_insert, self.primary.last_delete
+        for c in self.companions:
+            rc = c.UpdateOccupancy(global_map)
+            assert rc == r and (c.last_insert, c.last_delete) == (self.last_insert, self.last_delete), "shuffled replay diverged"
+        return r
+
+    def UpdateESDF(self):
+        st = self.primary.UpdateESDF()
+        for c in self.companions:
+            c.UpdateESDF()
+        return st
+
+    # -- the envelope ---------------------------------------------------------------------------------------------------
+    def _fields(self, keys=None):
+        """Squared distances of every run, aligned: dense -> (K+1, n); hash -> aligned on `keys` (sorted voxel keys of the
+        engine's dump), a voxel a run never allocated reads -1 like a pristine one."""
+        res = self.primary.resolution
+        if self.mode != "hash":
+            return np.stack([d2_from_dist(m.dump_dense(("dist",))["dist"], res) for m in self.maps])
+        out = []
+        for m in self.maps:
+            d = m.dump_hash()
+            ok = d["vox"][:, 0] != -10000
+            k = hash_key(d["vox"][ok])
+            d2 = d2_from_dist(d["dist"][ok], res)
+            o = np.argsort(k)
+            k, d2 = k[o], d2[o]
+            pos = np.clip(np.searchsorted(k, keys), 0, max(len(k) - 1, 0))
+            hitk = (k[pos] == keys) if len(k) else np.zeros(len(keys), bool)
+            out.append(np.where(hitk, d2[pos] if len(k) else -1, -1))
+        return np.stack(out)
+
+    def judge(self, engine_d2, keys=None):
+        """engine_d2: the engine's squared distances in the same layout (-1 unobserved, D2_INF no obstacle).  Returns the
+        counts the parity contract is stated in."""
+        D = self._fields(keys)
+        g = np.asarray(engine_d2, np.int64)
+        lo, hi = D.min(0), D.max(0)
+        outside = (g < lo) | (g > hi)
+        loo = []
+        for k in range(len(D)):
+            rest = np.delete(D, k, 0)
+            loo.append(int(((D[k] < rest.min(0)) | (D[k] > rest.max(0))).sum()) if len(rest) else 0)
+        fin = (D[0] >= 0) & (D[0] != D2_INF)
+        return {"voxels": int(D.shape[1]), "finite": int(fin.sum()), "runs": int(len(D)), "disagree": int((lo != hi).sum()),
+                "outside": int(outside.sum()), "outside_where_runs_agree": int((outside & (lo == hi)).sum()),
+                "closer": int((g < lo).sum()), "farther": int((g > hi).sum()), "leave_one_out": loo,
+                "vs_primary": int((g != D[0]).sum()), "outside_idx": np.flatnonzero(outside)[:10]}
+
+
+def hash_key(v):
+    v = np.asarray(v, np.int64)
+    return (v[:, 0] + 100000) * (1 << 40) + (v[:, 1] + 100000) * (1 << 20) + v[:, 2] + 100000
+
+
+def assert_envelope(rep, what=""):
+    """The contract on partially observed maps (and wherever else the reference's result depends on its queue / list
+    order): every squared distance inside the interval the reference's own K + 1 shuffled runs span at that voxel -- equal
+    where they agree -- except on at most as many voxels as those runs DISAGREE on among themselves on this very scenario.
+    No constant: a scenario on which the reference is order-independent (disagree == 0) demands equality everywhere.
+    (Why not zero: an engine with its own processing order is one more run; on the CPU one more shuffled run of the
+    verbatim reference leaves the envelope of 5-8 others on 3-30 voxels where they disagree on 50-150,
+    tests/test_oracle_order_sensitivity.py::test_order_envelope_*.)"""
+    env = rep.get("envelope", rep)
+    assert env["outside"] <= env["disagree"], \
+        f"{what}: {env['outside']} voxels outside the reference's order envelope, its own runs disagree on {env['disagree']}: {env}"

@@ -116,7 +116,8 @@ def test_hash_checkpoint_with_moved_window(hip_lib, oracle_libs, best_oracle_kin
     for k in ("vox", "d2", "occ"):
         assert np.array_equal(da[k], db[k]), k
     rep = compare(b, cpu)
-    assert rep["d2_mismatch"] <= 2, rep          # (freshly observed free space next to a field: order-dependent regime)
+    assert rep["d2_mismatch"] <= 2, rep          # (freshly observed free space next to a field: order-dependent regime;
+                                                 #  the envelope form of this bound: test_hash_wave_reaches_unallocated_space)
     # bring the window back: the parked island rejoins in the restored map as well
     b.hash_recentre((0, 0, 0))
     b.UpdateESDF()

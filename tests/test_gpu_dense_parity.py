@@ -9,16 +9,18 @@ results bit-exact (tolerance stated by BASELINE.json: 1e-4, we assert 0).
 import numpy as np
 import pytest
 
-from scenarios import Both, all_voxels, assert_exact, compare_dense
+from scenarios import Both, EnvelopeOracle, all_voxels, assert_envelope, assert_exact, compare_dense
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("engine")]
 
 
-def make_pair(oracle_libs, kind, n, res=0.1, origin=(0, 0, 0)):
+def make_pair(oracle_libs, kind, n, res=0.1, origin=(0, 0, 0), envelope=0):
+    """envelope = K: the oracle side is the reference plus K shuffled-order replays of it (scenarios.EnvelopeOracle)."""
     import fiesta_amd
     size = tuple(np.asarray(n if not np.isscalar(n) else (n, n, n)) * res)
     gpu = fiesta_amd.ESDFMap(origin, res, size)
-    cpu = oracle_libs.OracleMap(origin, res, size, kind=kind)
+    mk = lambda: oracle_libs.OracleMap(origin, res, size, kind=kind)   # noqa: E731
+    cpu = EnvelopeOracle(mk, k=envelope) if envelope else mk()
     assert gpu.grid_size == cpu.grid_size
     assert gpu.grid_total_size_ == cpu.grid_total_size
     b = Both(gpu, cpu)
@@ -111,9 +113,9 @@ def test_non_cubic_ragged_grid_and_walls(hip_lib, oracle_libs, best_oracle_kind)
 
 def test_partial_observation_frontier_semantics(hip_lib, oracle_libs, best_oracle_kind):
     """Propagation only passes through observed voxels and only voxels reached by the work-list change
-    (SURVEY.md 7.3-B). The reference itself is order-dependent here, so a tiny mismatch budget applies."""
+    (SURVEY.md 7.3-B). The reference itself is order-dependent here: judged against the envelope of its own shuffled runs."""
     n = 40
-    b = make_pair(oracle_libs, best_oracle_kind, n)
+    b = make_pair(oracle_libs, best_oracle_kind, n, envelope=6)
     rng = np.random.RandomState(3)
     g = all_voxels(b.gpu.grid_size)
     blocks = rng.rand(n // 4 + 1, n // 4 + 1, n // 4 + 1) > 0.27
@@ -125,20 +127,20 @@ def test_partial_observation_frontier_semantics(hip_lib, oracle_libs, best_oracl
     b.make_occupied(S)
     b.esdf()
     rep = compare_dense(b.gpu, b.cpu)
-    assert rep["d2_mismatch"] <= 20, rep
+    assert_envelope(rep, "inserts into a partially observed map")
     assert rep["pair_violations"] == 0, rep
     # now observe the rest: freshly observed free voxels must stay at "infinity" until a wave passes
     b.observe(g[~keep], 0)
     b.fuse()
     b.esdf()
     rep2 = compare_dense(b.gpu, b.cpu)
-    assert rep2["d2_mismatch"] <= 20, rep2
+    assert_envelope(rep2, "late observation")
     assert rep2["pair_violations"] == 0, rep2
     # a new insert sends a wave through
     b.make_occupied(rng.randint(0, n, (50, 3)).astype(np.int32))
     b.esdf()
     rep3 = compare_dense(b.gpu, b.cpu)
-    assert rep3["d2_mismatch"] <= 0.002 * n ** 3, rep3
+    assert_envelope(rep3, "wave through late observations")
     assert rep3["pair_violations"] == 0, rep3
 
 
@@ -175,7 +177,7 @@ def test_occupancy_fusion_logodds_and_positions(hip_lib, oracle_libs, best_oracl
     """SetOccupancy(Vector3d) + majority vote + clamping (src/ESDFMap.cpp:235-271) with mixed hits/misses,
     invalid occ values and out-of-map positions."""
     n = 24
-    b = make_pair(oracle_libs, best_oracle_kind, n, res=0.25, origin=(-3.0, -3.0, -1.0))
+    b = make_pair(oracle_libs, best_oracle_kind, n, res=0.25, origin=(-3.0, -3.0, -1.0), envelope=6)
     rng = np.random.RandomState(5)
     for cycle in range(8):
         pos = np.array([-3.0, -3.0, -1.0]) + (rng.rand(5000, 3) * 1.2 - 0.1) * n * 0.25
@@ -189,8 +191,8 @@ def test_occupancy_fusion_logodds_and_positions(hip_lib, oracle_libs, best_oracl
         rep = compare_dense(b.gpu, b.cpu)
         # sparse random observation is the regime where the reference itself is order-dependent: re-running
         # the reference with the same observations shuffled changes up to 15 of ~5000 finite distances
-        # ("parity contract"); budget 1 % of the finite voxels.
-        assert rep["d2_mismatch"] <= max(30, 0.01 * rep["finite"]), rep
+        # ("parity contract") -> judged against the envelope of those runs.
+        assert_envelope(rep, f"cycle {cycle}")
         assert rep["pair_violations"] == 0, rep
 
 
@@ -249,11 +251,13 @@ def test_local_sliding_window_mode(hip_lib, oracle_libs, best_oracle_kind):
     and a touched voxel outside the PREVIOUS window is reset (:256-259). The reference's reset is inconsistent: it sets
     distance = infinity but leaves closest_obstacle_ (and the list link) pointing at the old obstacle, so its own
     state stops satisfying dist == |v - coc| * res there. This engine stores no separate distance, so the reset clears
-    the obstacle. Occupancy, log-odds, queues and observed sets must still agree exactly; distances are
-    compared where the reference is self-consistent, with a small budget for what the stale obstacles leak."""
-    from scenarios import D2_INF, oracle_d2
+    the obstacle. Occupancy, log-odds, queues and observed sets must still agree exactly; distances (as a
+    query reads them: distance_buffer_, not the stale id) are judged against the envelope of the reference's own runs of
+    the same sequence in shuffled queue order -- what the orphans of a delete are re-seeded from depends on the order of
+    the reference's linked lists (:300-321), i.e. on that order."""
+    from scenarios import d2_from_dist
     n = 48
-    b = make_pair(oracle_libs, best_oracle_kind, n)
+    b = make_pair(oracle_libs, best_oracle_kind, n, envelope=6)
     observe_all(b, n)
     rng = np.random.RandomState(21)
     S = rng.randint(4, n - 4, (250, 3)).astype(np.int32)
@@ -264,14 +268,10 @@ def test_local_sliding_window_mode(hip_lib, oracle_libs, best_oracle_kind):
     def compare_local():
         f, o = b.gpu.download_field(), b.cpu.dump_dense()
         assert np.array_equal(f["occ"], o["occ"]) and np.array_equal(f["logodds"], o["logodds"])
-        od2, _ = oracle_d2(o, b.gpu.grid_size)
+        od2 = d2_from_dist(o["dist"], b.gpu.resolution)
         gd2 = f["d2"].astype(np.int64)
         assert np.array_equal(gd2 < 0, od2 < 0)
-        finite = (od2 >= 0) & (od2 != D2_INF)
-        consistent = np.ones(len(od2), bool)
-        consistent[finite] = np.sqrt(od2[finite].astype(np.float64)) * b.gpu.resolution == o["dist"][finite]
-        return int(((gd2 != od2) & consistent).sum()), int((~consistent).sum())
-    worst = 0
+        return b.cpu.judge(gd2)
     for step in range(4):
         c = np.array([1.2 + 0.5 * step, 2.0, 2.4])
         for m in (b.gpu, b.cpu):
@@ -283,9 +283,7 @@ def test_local_sliding_window_mode(hip_lib, oracle_libs, best_oracle_kind):
             b.observe(gone, 0)
             b.fuse(global_map=False)
         b.esdf()
-        mism, inconsistent = compare_local()
-        worst = max(worst, mism)
-    assert worst <= 0.02 * n ** 3, worst
+        assert_envelope(compare_local(), f"window step {step}")
 
 
 def test_window_then_delete_with_dependents_outside_the_window(hip_lib, oracle_libs, best_oracle_kind):
@@ -293,9 +291,10 @@ def test_window_then_delete_with_dependents_outside_the_window(hip_lib, oracle_l
     first in-window neighbour with a live obstacle, wherever the orphan lies (src/ESDFMap.cpp:308-321: VoxInRange gates the
     neighbour), and never propagates into it while it stays outside.  Then the window moves over those voxels and a second
     delete runs: no stale frontier tag may turn them into fresh seeds.  (global_map = true: no local reset involved, the
-    reference's state stays self-consistent and is compared voxel by voxel, with the budget of an order-dependent regime.)"""
+    reference's state stays self-consistent and is compared voxel by voxel against the envelope of its own runs in
+    shuffled queue order -- the re-seed walks the deleted obstacle's list, whose order is the history of that queue.)"""
     n = 40
-    b = make_pair(oracle_libs, best_oracle_kind, n)
+    b = make_pair(oracle_libs, best_oracle_kind, n, envelope=6)
     observe_all(b, n)
     rng = np.random.RandomState(5)
     S = rng.randint(2, n - 2, (120, 3)).astype(np.int32)
@@ -311,8 +310,7 @@ def test_window_then_delete_with_dependents_outside_the_window(hip_lib, oracle_l
     sg, sc = b.esdf()
     assert sg["deleted"] == sc["deleted"] > 0
     rep = compare_dense(b.gpu, b.cpu)
-    assert rep["cpu_finite_gpu_inf"] + rep["gpu_finite_cpu_inf"] <= 0.01 * n ** 3, rep
-    assert rep["d2_mismatch"] <= 0.03 * n ** 3, rep
+    assert_envelope(rep, "delete with orphans outside the window")
     # the window moves over the former outside; a second delete and an insert there
     for m in (b.gpu, b.cpu):
         m.SetUpdateRange((1.0, 0.0, 0.0), (n * res, n * res, n * res))
@@ -321,7 +319,7 @@ def test_window_then_delete_with_dependents_outside_the_window(hip_lib, oracle_l
     sg, sc = b.esdf()
     assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
     rep = compare_dense(b.gpu, b.cpu)
-    assert rep["gpu_finite_cpu_inf"] <= 0.01 * n ** 3 and rep["d2_mismatch"] <= 0.03 * n ** 3, rep
+    assert_envelope(rep, "window moved over the former outside")
 
 
 def test_visualisation_exports(hip_lib, oracle_libs, best_oracle_kind):

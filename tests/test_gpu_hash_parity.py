@@ -9,17 +9,19 @@ obstacle tie-equivalent, and a voxel that only one side has allocated must be in
 import numpy as np
 import pytest
 
-from scenarios import D2_INF, P_DEFAULT
+from scenarios import D2_INF, P_DEFAULT, EnvelopeOracle, assert_envelope
 
 pytestmark = pytest.mark.gpu
 
 
-def make(oracle_libs, kind, origin, res, reserve):
+def make(oracle_libs, kind, origin, res, reserve, envelope=0):
+    """envelope = K: the oracle side is the reference plus K shuffled-order replays of it (scenarios.EnvelopeOracle)."""
     import fiesta_amd
     if kind == "ref" and not oracle_libs.available("ref", "hash"):
         kind = "port"
     gpu = fiesta_amd.ESDFMap(origin, res, reserve_size=reserve, mode="hash")
-    cpu = oracle_libs.OracleMap(origin, res, reserve_size=reserve, mode="hash", kind=kind)
+    mk = lambda: oracle_libs.OracleMap(origin, res, reserve_size=reserve, mode="hash", kind=kind)   # noqa: E731
+    cpu = EnvelopeOracle(mk, k=envelope) if envelope else mk()
     for m in (gpu, cpu):
         m.SetParameters(*P_DEFAULT)
         m.SetOriginalRange()
@@ -68,7 +70,10 @@ def compare(gpu, cpu):
     occ_keys = set(kg[g["occ"] == 1].tolist())
     ck = key(gcoc[have].astype(np.int64))
     assert all(k in occ_keys for k in np.unique(ck).tolist())
-    return {"common": int(both_g.sum()), "finite": int(have.sum()), "d2_mismatch": mism, "pages": len(kg) // 8192}
+    rep = {"common": int(both_g.sum()), "finite": int(have.sum()), "d2_mismatch": mism, "pages": len(kg) // 8192}
+    if hasattr(cpu, "judge"):   # an EnvelopeOracle: the reference's own order spread on this scenario (scenarios.py)
+        rep["envelope"] = cpu.judge(gd2, kg[both_g])
+    return rep
 
 
 def test_hash_insert_delete_fully_observed_region(hip_lib, oracle_libs, best_oracle_kind):
@@ -105,7 +110,7 @@ def test_hash_insert_delete_fully_observed_region(hip_lib, oracle_libs, best_ora
 def test_hash_streaming_window_positions(hip_lib, oracle_libs, best_oracle_kind):
     """Config-4 shape: a moving observation window streams in new space (pages appear), obstacles come and go."""
     res = 0.05
-    gpu, cpu = make(oracle_libs, best_oracle_kind, (1.0, -2.0, 0.5), res, 100000)
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (1.0, -2.0, 0.5), res, 100000, envelope=5)
     rng = np.random.RandomState(2)
     live = np.zeros((0, 3))
     for frame in range(5):
@@ -126,8 +131,9 @@ def test_hash_streaming_window_positions(hip_lib, oracle_libs, best_oracle_kind)
         sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
         assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
         rep = compare(gpu, cpu)
-        # the union of boxes is only partially observed at its rim: the reference's order dependence applies
-        assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]), rep
+        # the union of boxes is only partially observed at its rim: the reference's order dependence applies -> judged
+        # against the envelope of its own shuffled runs
+        assert_envelope(rep, f"frame {frame}")
     assert rep["pages"] >= 2
 
 
@@ -156,7 +162,7 @@ def test_hash_mode_errors_are_loud(hip_lib):
 def test_hash_wave_reaches_unallocated_space(hip_lib, oracle_libs, best_oracle_kind):
     """The observed region is exactly ONE page (tile-aligned 16x16x32 box): every wave runs into unallocated
     neighbour tiles, which must be neither woken nor visited (regression: bitmap writes at page index -1)."""
-    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.1, 0)
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.1, 0, envelope=5)
     g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(32), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
     cycles(gpu, cpu, [], g, 1)
     cycles(gpu, cpu, np.array([[8, 8, 16], [0, 0, 0], [15, 15, 31]], np.int32), [], 3)
@@ -170,7 +176,8 @@ def test_hash_wave_reaches_unallocated_space(hip_lib, oracle_libs, best_oracle_k
     cycles(gpu, cpu, [], g2, 1)
     cycles(gpu, cpu, np.array([[20, 3, 5]], np.int32), [], 3)
     rep = compare(gpu, cpu)
-    assert rep["d2_mismatch"] <= 2 and rep["pages"] == 2, rep  # freshly observed free space: order-dependent regime
+    assert rep["pages"] == 2, rep
+    assert_envelope(rep, "freshly observed free space next to a field")  # (the order-dependent regime)
 
 
 def test_hash_c4_stream_box_observe(hip_lib, oracle_libs, best_oracle_kind):
@@ -178,7 +185,7 @@ def test_hash_c4_stream_box_observe(hip_lib, oracle_libs, best_oracle_kind):
     frames, against the hash-table reference fed voxel by voxel; and the device-side "updated voxels" unit against a
     count made from two downloads."""
     from scenarios import box_voxels, c4_frame
-    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.05, 1000000)
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.05, 1000000, envelope=3)
     for k in range(4):
         lo, hi, occ = c4_frame(k)
         gpu.SetOccupancyBox(lo, hi, 0)
@@ -201,7 +208,8 @@ def test_hash_c4_stream_box_observe(hip_lib, oracle_libs, best_oracle_kind):
             assert d2_changed <= n_upd <= any_changed, (d2_changed, n_upd, any_changed)
     rep = compare(gpu, cpu)
     # frames 0..2 only observe (3 hits make an obstacle): frame 3 inserts the whole visible surface at once
-    assert rep["finite"] > 500000 and rep["d2_mismatch"] <= 0.02 * rep["finite"], rep
+    assert rep["finite"] > 500000
+    assert_envelope(rep, "C4 frame 3")
 
 
 def test_hash_visualisation_getters(hip_lib, oracle_libs, best_oracle_kind):

@@ -7,17 +7,20 @@ frame EXACTLY, including the reference's order-dependent per-frame de-duplicatio
 import numpy as np
 import pytest
 
-from scenarios import (INTRINSICS, P_DEFAULT, assert_exact, compare_dense, depth_to_points, render_depth, yaw_pose)
+from scenarios import (INTRINSICS, P_DEFAULT, EnvelopeOracle, assert_envelope, assert_exact, compare_dense, depth_to_points,
+                       render_depth, yaw_pose)
 
 pytestmark = pytest.mark.gpu
 
 RAY = dict(min_ray_length=0.5, max_ray_length=5.0)
 
 
-def make(oracle_libs, kind, origin, size, res):
+def make(oracle_libs, kind, origin, size, res, envelope=0):
+    """envelope = K: the oracle side is the reference plus K shuffled-order replays of it (scenarios.EnvelopeOracle)."""
     import fiesta_amd
     gpu = fiesta_amd.ESDFMap(origin, res, size)
-    cpu = oracle_libs.OracleMap(origin, res, size, kind=kind)
+    mk = lambda: oracle_libs.OracleMap(origin, res, size, kind=kind)   # noqa: E731
+    cpu = EnvelopeOracle(mk, k=envelope) if envelope else mk()
     assert gpu.grid_size == cpu.grid_size
     for m in (gpu, cpu):
         m.SetParameters(*P_DEFAULT)
@@ -70,7 +73,7 @@ def check_counts(gpu, cpu):
 def test_frames_counts_exact_with_reference_dedup(hip_lib, oracle_libs, best_oracle_kind):
     """Yaw sweep in a box room with spheres: per-frame counters, fusion, queues and ESDF vs the oracle."""
     origin, size, res = (-6.4, -6.4, -3.2), (12.75, 12.75, 6.35), 0.1
-    gpu, cpu = make(oracle_libs, best_oracle_kind, origin, size, res)
+    gpu, cpu = make(oracle_libs, best_oracle_kind, origin, size, res, envelope=5)
     assert gpu.grid_size == (128, 128, 64)
     lc, rc = origin, tuple(np.array(origin) + np.array(size))
     spheres = [((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7), ((0.5, -2.0, -0.5), 0.4)]
@@ -92,8 +95,9 @@ def test_frames_counts_exact_with_reference_dedup(hip_lib, oracle_libs, best_ora
         gpu.UpdateESDF()
         cpu.UpdateESDF()
         rep = compare_dense(gpu, cpu)
-        # partially observed map: the reference itself is order-dependent here
-        assert rep["d2_mismatch"] <= max(30, 0.01 * rep["finite"]), rep
+        # partially observed map: the reference itself is order-dependent here -> judged against the
+        # envelope of its own shuffled runs on these very frames
+        assert_envelope(rep, f"frame {f}")
         assert rep["pair_violations"] == 0, rep
     assert touched_total > 30000
     assert gpu.download_field(("occ",))["occ"].sum() > 500
@@ -144,7 +148,7 @@ def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind, si
     kind = best_oracle_kind if oracle_libs.available(best_oracle_kind, "hash") else "port"
     origin, res = (0.3, -0.2, 0.1), 0.1
     gpu = fiesta_amd.ESDFMap(origin, res, reserve_size=1000, mode="hash")
-    cpu = oracle_libs.OracleMap(origin, res, reserve_size=1000, mode="hash", kind=kind)
+    cpu = EnvelopeOracle(lambda: oracle_libs.OracleMap(origin, res, reserve_size=1000, mode="hash", kind=kind), k=4)
     for m in (gpu, cpu):
         m.SetParameters(*P_DEFAULT)
         m.SetOriginalRange()
@@ -185,7 +189,7 @@ def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind, si
         sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
         assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
         rep = compare_hash(gpu, cpu)
-        assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]), rep
+        assert_envelope(rep, f"frame {f}")
     assert touched_total > 30000 and rep["pages"] >= 8
     assert gpu.hash_window()[1] == (1 if site.any() else 0) and sg["dropped_observations"] == 0
 
@@ -282,7 +286,8 @@ def test_signed_variant_inverse_map(hip_lib, oracle_libs, best_oracle_kind, mode
     else:
         mk_g = lambda: fiesta_amd.ESDFMap(origin, res, size)                                                  # noqa: E731
         mk_c = lambda: oracle_libs.OracleMap(origin, res, size, kind=kind)                                    # noqa: E731
-    g, gi, c, ci = mk_g(), mk_g(), mk_c(), mk_c()
+    g, gi, c = mk_g(), mk_g(), mk_c()
+    ci = EnvelopeOracle(mk_c, k=4) if mode == "array" else mk_c()   # (the inverse map's field is judged below)
     for m in (g, gi, c, ci):
         m.SetParameters(*P_DEFAULT)
         m.SetOriginalRange()
@@ -318,11 +323,12 @@ def test_signed_variant_inverse_map(hip_lib, oracle_libs, best_oracle_kind, mode
             assert (gm.last_insert, gm.last_delete) == (cm.last_insert, cm.last_delete)
             sg, sc = gm.UpdateESDF(), cm.UpdateESDF()
             assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
-    # the inverse map: its occupied voxels are the observed-free ones; fields vs the oracle under the usual budget of
-    # partially observed maps
+    # the inverse map: its occupied voxels are the observed-free ones; fields vs the envelope of the reference's own
+    # shuffled runs (a partially observed map)
     if mode == "array":
         rep = compare_dense(gi, ci)
-        assert rep["d2_mismatch"] <= max(30, 0.02 * rep["finite"]) and rep["pair_violations"] == 0, rep
+        assert_envelope(rep, "inverse map")
+        assert rep["pair_violations"] == 0, rep
         occ_main, occ_inv = g.download_field(("occ",))["occ"], gi.download_field(("occ",))["occ"]
         assert occ_inv.sum() > occ_main.sum() > 0     # (a grazed voxel can be occupied in both: hit by some rays, crossed by others)
     # signed distance of the pair, here and there

@@ -120,3 +120,39 @@ def test_fully_observed_surface_scene_is_not_an_exact_transform_and_depends_on_o
     assert int((fields[0] != fields[1]).sum()) > 0                # and WHICH ones depends on the insert order
     worst = max(float((np.sqrt(f) - np.sqrt(exact)).max()) for f in fields)
     assert worst <= 0.75, worst                                   # by a fraction of a voxel
+
+
+def test_order_envelope_of_the_reference_contains_one_more_of_its_runs(oracle_libs, best_oracle_kind):
+    """The parity contract of the GPU tests on partially observed maps (scenarios.EnvelopeOracle / assert_envelope),
+    exercised on the CPU with the reference itself as the engine under test: K + 1 shuffled runs span an interval per
+    voxel; ONE MORE run (another order: what any engine with its own processing order amounts to) lies inside it except
+    on a handful of voxels -- far fewer than the runs disagree on among themselves, which is the allowance the contract
+    grants.  Also: the committed envelope of the golden raycast program contains the restatement's shuffled run."""
+    import os
+    from golden_programs import PROGRAMS
+    from scenarios import EnvelopeOracle, assert_envelope, d2_from_dist
+    res = 0.1
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fixture, env = np.load(os.path.join(gold, "raycast_frames.npz")), np.load(os.path.join(gold, "raycast_frames_envelope.npz"))
+    seen = 0
+
+    def make(o, r, s):   # primary: the recorded order; companions: 5 more orders; the LAST companion plays the engine
+        return EnvelopeOracle(lambda: oracle_libs.OracleMap(o, r, s, kind=best_oracle_kind), k=6, seed=99)
+    for cp, m, _ in PROGRAMS["raycast_frames"](make):
+        engine = m.companions.pop()                       # judged against the other 6 runs
+        gd2 = d2_from_dist(engine.dump_dense(("dist",))["dist"], res)
+        rep = m.judge(gd2)
+        m.companions.append(engine)
+        assert rep["runs"] == 6
+        assert_envelope(rep, cp)
+        if rep["finite"]:
+            assert rep["disagree"] > 20 and rep["outside"] * 3 <= rep["disagree"], rep
+            assert max(rep["leave_one_out"]) * 3 <= rep["disagree"], rep
+            seen += 1
+        # ... and against the committed 10-run envelope of the verbatim reference
+        lo = d2_from_dist(fixture[f"{cp}/dist"], res)
+        hi = lo.copy()
+        lo[env[f"{cp}/idx"]], hi[env[f"{cp}/idx"]] = env[f"{cp}/lo"], env[f"{cp}/hi"]
+        outside = int(((gd2 < lo) | (gd2 > hi)).sum())
+        assert outside <= len(env[f"{cp}/idx"]), (cp, outside)
+    assert seen == 2
