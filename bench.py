@@ -63,6 +63,15 @@ def parse():
                     help="C2 obstacle distribution: uniform scatter (headline) or depth-sensor-like shells (scene C)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=224)
+    ap.add_argument("--no-cpu-full", action="store_true",
+                    help="skip the full-size leg of cpu_baseline (the verbatim reference on the SAME 512^3 step, one host core, "
+                         "about 4 minutes and 7.4 GB; default on at N = 1 when oracle/_ref is present)")
+    ap.add_argument("--delta", type=int, default=None,
+                    help="voxels replaced per step (inserts + deletes; default: the whole obstacle count = config 2's 50k delta)")
+    ap.add_argument("--delta-sweep", action="store_true",
+                    help="engine crossover table instead of the headline: UpdateESDF p50 for deltas 100 ... 50k on every engine")
+    ap.add_argument("--verify-samples", type=int, default=20000,
+                    help="owned voxels per rank checked after the timed region against a k-d tree over the GLOBAL obstacle list")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2 = the headline metric; c3 = depth-frame pipeline; c4 = hash-block map, streaming window")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
@@ -77,8 +86,9 @@ class Workload:
     uniform voxels (SURVEY.md 8d, C2 scenes A/B); "surfaces": voxels sampled on 3 axis-aligned planes and 20 spheres
     of radius 8-40 voxels, the shells a depth sensor produces (C2 scene C)."""
 
-    def __init__(self, grid, n_obs, seed=12345, scene="scatter"):
-        self.grid, self.n_obs, self.half, self.scene = grid, n_obs, n_obs // 2, scene
+    def __init__(self, grid, n_obs, seed=12345, scene="scatter", delta=None):
+        self.grid, self.n_obs, self.scene = grid, n_obs, scene
+        self.half = (n_obs if delta is None else min(delta, n_obs)) // 2   # inserts (= deletes) per step
         self.rng = np.random.RandomState(seed)
         g = grid
         srng = np.random.RandomState(4242)  # the surfaces themselves are the same for every rank / step
@@ -129,24 +139,28 @@ class Workload:
         return new, old.copy()
 
 
-def run_cpu_baseline(args):
-    """The oracle on one host core, same obstacle density on a smaller grid, one steady-state step timed."""
+def run_cpu_baseline(args, grid=None):
+    """The oracle on one host core: same obstacle density on `grid`^3 (default: the --cpu-grid sample), one steady-state
+    step timed.  grid = args.grid is the SAME step the GPU ran (same seeds, same voxels): the full-size leg."""
     from oracle import pyoracle
     pyoracle.build("port")
     kind = "ref" if pyoracle.available("ref", "array") else "port"
-    g = args.cpu_grid
+    g = args.cpu_grid if grid is None else grid
     n_obs = max(2, int(round(args.obstacles * (g / args.grid) ** 3)))
     res = 0.1
+    t_all = time.perf_counter()
     m = pyoracle.OracleMap((0, 0, 0), res, ((g - 0.5) * res,) * 3, kind=kind)  # ceil() rounding, SURVEY 7.3-G
     assert m.grid_total_size == g ** 3
     m.SetParameters(*P_DEFAULT)
     m.SetOriginalRange()
-    idx = np.arange(g ** 3, dtype=np.int64)
-    allv = np.stack([idx // (g * g), (idx // g) % g, idx % g], -1).astype(np.int32)
-    m.SetOccupancyVox(allv, 0)
+    for x0 in range(0, g, 64):      # observe everything free, in slabs (the coordinate list of 512^3 would be 1.6 GB)
+        xs = np.arange(x0, min(g, x0 + 64))
+        allv = np.stack(np.meshgrid(xs, np.arange(g), np.arange(g), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+        m.SetOccupancyVox(allv, 0)
+    del allv
     m.UpdateOccupancy(True)
     m.UpdateESDF()
-    w = Workload(g, n_obs, scene=args.scene)
+    w = Workload(g, n_obs, scene=args.scene, delta=args.delta)
     for _ in range(3):
         m.SetOccupancyVox(w.initial(), 1)
         m.UpdateOccupancy(True)
@@ -173,8 +187,52 @@ def run_cpu_baseline(args):
         "sample": f"{g}^3 grid at the same obstacle density ({n_obs} obstacles), one steady-state UpdateESDF "
                   f"({st['inserted']} inserts + {st['deleted']} deletes, {updated} updated voxels, {st['seconds']:.3f} s); "
                   f"full scatter insert of the sample: {g ** 3} voxels in {st_scatter['seconds']:.3f} s",
-        "update_esdf_s": st["seconds"], "updated_voxels": updated, "host_cpus": os.cpu_count(),
+        "update_esdf_s": st["seconds"], "updated_voxels": updated, "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+        "wall_s": time.perf_counter() - t_all,
     }
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def free_host_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def verify_against_kdtree(query_d2, owned_lo, owned_size, obstacles, n_samples, seed, wrap):
+    """Self-check of a run (N = 1 and every rank of N > 1): n_samples voxels of this rank's owned box -- a third of them
+    within 3 voxels of the box faces, where shards meet -- against the exact nearest obstacle of the GLOBAL list (k-d tree;
+    squared distances recomputed in integers).  wrap: on grids beyond 1024 voxels per axis an id reaches 512 voxels
+    (d^2 < 2^18), farther voxels read "no obstacle".  Returns (sampled, mismatches)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.RandomState(seed)
+    lo, size = np.asarray(owned_lo, np.int64), np.asarray(owned_size, np.int64)
+    v = lo + (rng.rand(n_samples, 3) * size).astype(np.int64)
+    k = n_samples // 3
+    ax = rng.randint(0, 3, k)
+    side = rng.randint(0, 2, k)
+    off = rng.randint(0, 3, k)
+    v[np.arange(k), ax] = np.where(side == 0, lo[ax] + off, lo[ax] + size[ax] - 1 - off)
+    obs = np.asarray(obstacles, np.int64)
+    _, nn = cKDTree(obs.astype(np.float64)).query(v.astype(np.float64), k=4)   # (ties / float rounding: best of 4 in integers)
+    want = ((v[:, None, :] - obs[nn]) ** 2).sum(-1).min(1)
+    if wrap:
+        want = np.where(want >= (1 << 18), 0x7FFFFFFF, want)
+    got = np.asarray(query_d2(v.astype(np.int32)), np.int64)
+    return int(len(v)), int((got != want).sum())
 
 
 def run_c3(args):
@@ -359,12 +417,81 @@ def run_c4(args):
     m.close()
 
 
+def run_delta_sweep(args):
+    """`--delta-sweep`: where do the two UpdateESDF engines cross?  C2's map (512^3, 50k obstacles, fully observed), both
+    scenes; per step `delta` voxels are replaced (delta/2 inserts + delta/2 deletes in one UpdateESDF); every delta on
+    every engine setting (rounds / bulk-whenever-valid / auto).  One JSON line with the table and, per point, how much
+    slower `auto` is than the better fixed engine (the engine choice is right when that never exceeds a few percent)."""
+    import torch
+    import fiesta_amd
+    G, res = args.grid, 0.1
+    dev = torch.device("cuda", 0)
+    deltas = [100, 500, 2000, 5000, 10000, 25000, 50000]
+    table = []
+    for scene in ("scatter", "surfaces"):
+        for engine in ("rounds", "bulk", "auto"):
+            m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, update_engine=engine)
+            m.SetParameters(*P_DEFAULT)
+            m.SetOriginalRange()
+            m.SetOccupancyBox((0, 0, 0), (G - 1, G - 1, G - 1), 0)
+            m.UpdateOccupancy(True)
+            m.UpdateESDF()
+            w = Workload(G, args.obstacles, scene=scene)
+
+            def observe(vox, occ):
+                v = torch.from_numpy(np.ascontiguousarray(vox, dtype=np.int32)).to(dev)
+                o = torch.from_numpy(np.ascontiguousarray(occ, dtype=np.int32)).to(dev)
+                m.SetOccupancyDevice(v.data_ptr(), o.data_ptr(), v.shape[0])
+                m.synchronize()
+            for _ in range(3):
+                observe(w.initial(), np.ones(args.obstacles, np.int32))
+                m.UpdateOccupancy(True)
+            m.UpdateESDF()
+            for delta in deltas:
+                w.half = delta // 2
+                host, devms, bulk = [], [], []
+                for r in range(1 + args.steps):
+                    new, old = w.next_step()
+                    for c in range(3):
+                        if c < 2:
+                            observe(new, np.ones(len(new), np.int32))
+                        else:
+                            observe(np.concatenate([new, old]), np.concatenate([np.ones(len(new), np.int32), np.zeros(len(old), np.int32)]))
+                        m.UpdateOccupancy(True)
+                    m.synchronize()
+                    t0 = time.perf_counter()
+                    st = m.UpdateESDF()
+                    t1 = time.perf_counter()
+                    assert (st["inserted"], st["deleted"]) == (len(new), len(old))
+                    if r:
+                        host.append((t1 - t0) * 1e3), devms.append(st["device_ms"]), bulk.append(int(st["bulk"]))
+                table.append({"scene": scene, "engine": engine, "delta": delta, "update_esdf_p50_ms": statistics.median(host),
+                              "device_p50_ms": statistics.median(devms), "bulk_updates": int(sum(bulk)), "updates": len(bulk)})
+            m.close()
+    worst = 0.0
+    for scene in ("scatter", "surfaces"):
+        for delta in deltas:
+            t = {e["engine"]: e["update_esdf_p50_ms"] for e in table if e["scene"] == scene and e["delta"] == delta}
+            slow = t["auto"] / min(t["rounds"], t["bulk"]) - 1.0
+            worst = max(worst, slow)
+            for e in table:
+                if e["scene"] == scene and e["delta"] == delta and e["engine"] == "auto":
+                    e["auto_slower_than_best_fixed"] = slow
+    print(json.dumps({"metric": "esdf_engine_crossover", "value": worst, "unit": "worst relative slowdown of auto vs the better fixed engine",
+                      "n_gpus": 1, "steps": args.steps, "higher_is_better": False,
+                      "config": {"workload": f"C2 map {G}^3, {args.obstacles} obstacles, scenes scatter + surfaces, deltas {deltas}"},
+                      "table": table}), flush=True)
+
+
 def main():
     args = parse()
     if args.grid is None:
         args.grid = 512 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 1024
     if args.obstacles is None:
         args.obstacles = int(round(50000 * (args.grid / 512.0) ** 3))
+    if args.delta_sweep:
+        args.steps = min(args.steps, 5)
+        return run_delta_sweep(args)
     if args.workload == "c3":
         import torch  # noqa: F401  (one HIP runtime per process: torch first)
         return run_c3(args)
@@ -434,7 +561,7 @@ def main():
     top.UpdateESDF()
 
     # ---- scene A: scatter insert of all obstacles into the empty observed grid (reported, not the step)
-    w = Workload(G, args.obstacles, seed=12345 + 1000 * rank, scene=args.scene)
+    w = Workload(G, args.obstacles, seed=12345 + 1000 * rank, scene=args.scene, delta=args.delta)
     init = dev_batch(w.initial() + box_lo.astype(np.int32), np.ones(args.obstacles, np.int32))
     for _ in range(3):
         observe(init)
@@ -507,6 +634,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_updated = float(t.item())
 
+    # ---- self-check of the run (every rank): sampled owned voxels against a k-d tree over the GLOBAL obstacle list --
+    # what makes an N > 1 line evidence, not just a number (the field now is the one the K timed steps produced)
+    verify = None
+    if args.verify_samples > 0:
+        mine = (w.live + box_lo.astype(np.int32)).astype(np.int32)
+        if dist:
+            parts = [torch.empty((args.obstacles, 3), dtype=torch.int32, device=cdev) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(mine)).to(cdev))
+            everything = torch.cat(parts).cpu().numpy()
+        else:
+            everything = mine
+        gext = G * (max(layout) if sharded_map is not None else 1)
+
+        def query_d2(v):
+            d = m.GetDistance(v)
+            return np.where(d >= 10000.0, 0x7FFFFFFF, np.rint((d / res) ** 2)).astype(np.int64)
+        t_v = time.perf_counter()
+        sampled, bad = verify_against_kdtree(query_d2, box_lo, (G, G, G), everything, args.verify_samples, 777 + rank, gext > 1024)
+        nranks_rccl, rank_rccl = sharded_map.comm_info() if sharded_map is not None else (0, 0)
+        tv = torch.tensor([sampled, bad, 1, nranks_rccl], device=cdev, dtype=torch.float64)
+        if dist:
+            tmax = tv.clone()
+            dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            nranks_rccl = int(tmax[3].item())
+        verify = {"sampled": int(tv[0].item()), "mismatches": int(tv[1].item()), "ranks_reporting": int(tv[2].item()),
+                  "ranks_seen_by_rccl": nranks_rccl, "global_obstacles": int(len(everything)),
+                  "method": "exact nearest obstacle (scipy cKDTree over the all-gathered global obstacle list, d^2 recomputed in "
+                            "integers); a third of the samples within 3 voxels of the owned box's faces",
+                  "seconds": time.perf_counter() - t_v}
+
     if rank == 0:
         # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
         # read from inside the process); the newest committed summary of tools/pmc_traffic.py is quoted here.
@@ -517,7 +675,9 @@ def main():
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if tag in f and f.endswith(".json"))
             if cands and world == 1 and args.scene == "scatter" and G == 512:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{cands[-1]} ({tj['kernel']}, {tj['command']})"
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_src = (f"profiles/{cands[-1]} ({tj['kernel']}, {tj['command']}); NOT measured in this run: counters "
+                               f"collected at commit {tj.get('commit', 'unrecorded (round 2)')}")
         except Exception:
             pass
         relax_ms = sum(s["relax_ms"] for s in timed)
@@ -528,8 +688,11 @@ def main():
         if n_bulk == len(timed):
             kernel = "k_ft_rows + k_ft_plane + k_ft_x (bulk feature transform: every kernel of UpdateESDF)"
             phases = {k: statistics.median(s[k] for s in timed) for k in ("ft_rows_ms", "ft_plane_ms", "ft_x_ms")}
-            dominant = {"kernel": "k_ft_x", "ms": phases["ft_x_ms"],
-                        "frac": my_updated / args.steps * ALGO_BYTES_PER_UPDATED_VOXEL / (phases["ft_x_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # the dominant kernel on ITS OWN bytes: pass B reads 4 B and writes 4 B per voxel of the grid
+            own = float(G) ** 3 * 8.0
+            dominant = {"kernel": "k_ft_x", "ms": phases["ft_x_ms"], "own_bytes": own, "own_bytes_what": "4 B read + 4 B written per grid voxel",
+                        "achieved_GBs": own / (phases["ft_x_ms"] * 1e-3) / 1e9,
+                        "frac": own / (phases["ft_x_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
             overflow = [int(sum(s["ft_overflow"][k] for s in timed)) for k in range(6)]
         else:
             kernel, phases, dominant, overflow = "k_relax_q (frontier rounds)", None, None, None
@@ -577,20 +740,56 @@ def main():
                 "frac_of_measured_copy_6.29TBs": achieved / 6290.0,
                 "phases_p50_ms": phases, "dominant_kernel": dominant, "ring_overflows": overflow,
             },
+            "verify": verify,
+            "parity": parity_summary(args, G, world),
         }
         if world == 1 and not args.no_cpu_baseline:
+            if sharded_map is None:
+                m.close()   # (the GPU side is finished; the CPU legs get the host to themselves)
             out["cpu_baseline"] = run_cpu_baseline(args)
-            try:  # the one-off full-size run of the reference (build container, tests/golden/make_golden_c2.py)
-                full = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_512.json")))[args.scene]["steady_state_step"]
-                out["cpu_baseline"]["full_size_512"] = {"voxels_per_sec": full["voxels_per_sec"], "seconds": full["seconds"],
-                                                        "updated_voxels": full["updated_voxels"], "source": "profiles/r02_cpu_512.json"}
-            except Exception:
-                pass
+            # ... and the SAME step at the SAME size in the same run on this box: the verbatim reference, one core
+            from oracle import pyoracle
+            full_ok = (not args.no_cpu_full and pyoracle.available("ref", "array") and G <= 512 and free_host_gb() > 0.09 * (G / 512.0) ** 3 * 100)
+            if full_ok:
+                full = run_cpu_baseline(args, grid=G)
+                out["cpu_baseline"]["sample_value"] = out["cpu_baseline"]["value"]
+                out["cpu_baseline"]["sample"] = "SAME box, SAME run, SAME size: " + full["sample"] + " [bounded sample beside it: " + out["cpu_baseline"]["sample"] + "]"
+                for k in ("value", "update_esdf_s", "updated_voxels", "wall_s"):
+                    out["cpu_baseline"][k] = full[k]
+                out["cpu_baseline"]["full_size"] = True
+            else:
+                out["cpu_baseline"]["full_size"] = False
+                try:  # the one-off full-size run of the reference in the build container (tests/golden/make_golden_c2.py)
+                    full = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_512.json")))[args.scene]["steady_state_step"]
+                    out["cpu_baseline"]["full_size_512_other_box"] = {"voxels_per_sec": full["voxels_per_sec"], "seconds": full["seconds"],
+                                                                      "updated_voxels": full["updated_voxels"], "source": "profiles/r02_cpu_512.json"}
+                except Exception:
+                    pass
         print(json.dumps(out), flush=True)
     m.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_summary(args, G, world):
+    """What pins the distances of THIS workload to the reference (tests/test_gpu_full_size.py): at the headline size the
+    verbatim reference ran once on these very inputs (tests/golden/make_golden_c2.py); its per-x-slab CRC32s of d^2 are
+    reproduced by the GPU field except on the listed voxels, where the reference holds an artefact of its own insert order
+    (a larger distance, by at most half a voxel) and the GPU the exact transform."""
+    if world != 1 or G != 512 or args.obstacles != 50000 or args.delta is not None:
+        return {"pinned_by": "sampled k-d tree check of this run (verify); the full-size digest covers the 512^3 / 50k workload only"}
+    try:
+        d = np.load(os.path.join(ROOT, "tests", "golden", f"c2_512_{args.scene}_digest.npz"))
+        n = int(np.prod(d["grid"]))
+        return {"pinned_by": f"tests/golden/c2_512_{args.scene}_digest.npz (verbatim reference, all {n} voxels of both checkpoints, "
+                             "test_config2_512cube_matches_reference_digest)",
+                "exact_voxels": {"scatter_insert": n - int(len(d["scatter/exc_idx"])), "steady_state_step": n - int(len(d["step/exc_idx"]))},
+                "reference_order_artefacts": {"scatter_insert": int(len(d["scatter/exc_idx"])), "steady_state_step": int(len(d["step/exc_idx"]))},
+                "artefact_note": "voxels where the reference itself deviates from the exact transform depending on its insert order "
+                                 "(tests/test_oracle_order_sensitivity.py); the GPU holds the exact value there"}
+    except Exception as e:  # noqa: BLE001
+        return {"pinned_by": None, "error": repr(e)}
 
 
 if __name__ == "__main__":
