@@ -180,6 +180,14 @@ int fiesta_hip_set_original_range(fiesta_hip_map *m) {
   });
 }
 
+int fiesta_hip_set_update_engine(fiesta_hip_map *m, int32_t engine) {
+  return guarded([&] {
+    need(m != nullptr, "null map handle");
+    need(engine >= 0 && engine <= 2, "unknown update_engine");
+    if (m->dense) m->dense->set_update_engine(engine);  // (hash-block maps have one engine)
+  });
+}
+
 int fiesta_hip_set_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret) {
   return guarded([&] {
     need(m && (n == 0 || (vox && occ)) && n >= 0, "bad argument");

@@ -272,14 +272,55 @@ __global__ __launch_bounds__(1024) void k_del_bbox(Geom g, const uint32_t *del, 
   }
 }
 
-// A voxel OUTSIDE the update window whose obstacle vanished (local / sliding-window maps only).  The reference re-seeds
-// every orphan, wherever it lies, from the first stencil neighbour IN the window that still has a live obstacle
-// (src/ESDFMap.cpp:308-321: dirs_ order, VoxInRange gates the neighbour, not the orphan) and never pushes into it again
-// while it stays outside (the BFS gates its targets with VoxInRange, :367).  The frontier rounds only stage voxels of the
-// window, so that re-seed is done here, once, and the word is left WITHOUT a frontier tag: when the window later covers
-// the voxel it holds what the reference holds, not a stale seed.
-__device__ inline vox_t reseed_outside_window(const Geom &g, const vox_t *coc, const uint32_t *occbits, const uint32_t *gocc,
-                                              int x, int y, int z) {
+// A voxel OUTSIDE the update window whose obstacle vanished (local / sliding-window maps only).  In the reference such an
+// orphan is re-seeded from the first stencil neighbour IN the window that holds a live obstacle (src/ESDFMap.cpp:308-321:
+// dirs_ order, VoxInRange gates the neighbour, not the orphan -- and the neighbours include orphans re-seeded a moment
+// earlier in the same list walk, which runs from the rim of the dead cell inwards), is then put on the update queue like
+// any other orphan, PULLS the best obstacle of its in-window neighbours when it is popped (:345-366: only the neighbour is
+// range-checked) -- and is never pushed into while it stays outside (:378).  So it ends with the best of what its
+// in-window neighbours hold once they have been re-seeded themselves.  The frontier rounds only stage voxels of the
+// window; the orphans outside keep their reset tag through the rounds and take that pull afterwards (k_reseed_outside),
+// from the relaxed field.  The tag is gone after that: when the window later covers the voxel it holds what the
+// reference holds, not a stale seed.
+__global__ __launch_bounds__(256) void k_reseed_outside(Geom g, vox_t *coc, const uint32_t *occbits, const uint32_t *gocc,
+                                                        const unsigned long long *counters, int bounded) {
+  int bx0 = 0, by0 = 0, bz0 = 0, bx1 = g.nx - 1, by1 = g.ny - 1, bz1 = g.nz - 1;
+  if (bounded) {  // the box k_invalidate scanned
+    const int r = (int)ceil(sqrt((double)counters[C_MAXD2])) + 1;
+    bx0 = max(bx0, (int)(long long)counters[C_DBOX0 + 0] - r), bx1 = min(bx1, (int)(long long)counters[C_DBOX0 + 3] + r);
+    by0 = max(by0, (int)(long long)counters[C_DBOX0 + 1] - r), by1 = min(by1, (int)(long long)counters[C_DBOX0 + 4] + r);
+    bz0 = max(bz0, (int)(long long)counters[C_DBOX0 + 2] - r), bz1 = min(bz1, (int)(long long)counters[C_DBOX0 + 5] + r);
+    if (bx0 > bx1 || by0 > by1 || bz0 > bz1) return;
+  }
+  const int ez = bz1 - bz0 + 1, ey = by1 - by0 + 1;
+  const int64_t nbox = (int64_t)(bx1 - bx0 + 1) * ey * ez;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nbox; i += (int64_t)gridDim.x * blockDim.x) {
+    const int z = bz0 + (int)(i % ez), y = by0 + (int)((i / ez) % ey), x = bx0 + (int)(i / ((int64_t)ez * ey));
+    const int64_t idx = g.idx(x, y, z);
+    if (coc[idx] != kReset || g.in_window(x, y, z)) continue;
+    vox_t best = kInf;
+    int32_t bestd = kD2Inf;
+#define FIESTA_RESEED(DX, DY, DZ)                                                                   \
+  {                                                                                                 \
+    const int ux = x + (DX), uy = y + (DY), uz = z + (DZ);                                          \
+    if (g.in_grid(ux, uy, uz) && g.in_window(ux, uy, uz)) {                                         \
+      const vox_t w = coc[g.idx(ux, uy, uz)];                                                       \
+      if (!(w & kNoCoc)) {                                                                          \
+        int cx, cy, cz;                                                                             \
+        unpack_coc(g.wrap, ux + g.gx0, uy + g.gy0, uz + g.gz0, w & ~kAct, cx, cy, cz);                \
+        const int32_t d = dist2(g.wrap, x + g.gx0, y + g.gy0, z + g.gz0, pack_coc(cx, cy, cz));     \
+        if (d < bestd && (!g.wrap || d < kD2Cap) && obstacle_alive(g, occbits, gocc, cx, cy, cz)) bestd = d, best = w & ~kAct; \
+      }                                                                                             \
+    }                                                                                               \
+  }
+    FIESTA_STENCIL24(FIESTA_RESEED)
+#undef FIESTA_RESEED
+    coc[idx] = best;
+  }
+}
+
+__device__ inline vox_t reseed_first_neighbour(const Geom &g, const vox_t *coc, const uint32_t *occbits, const uint32_t *gocc,
+                                               int x, int y, int z) {
 #define FIESTA_RESEED(DX, DY, DZ)                                                                   \
   {                                                                                                 \
     const int ux = x + (DX), uy = y + (DY), uz = z + (DZ);                                          \
@@ -384,11 +425,14 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
             if (dead && (!g.sharded || g.owned(x, y, z8 + k))) rmask |= 1u << k;
           }
         }
-        if (rmask && !win_all) {  // orphans outside the update window: re-seeded here, not by the rounds
+        // (orphans outside the update window are reset and tagged like the others; the rounds never stage them -- they
+        //  are re-seeded after the rounds, k_reseed_outside.  A shard has no such pass -- its rounds are driven from outside,
+        //  relax_pending -- and settles them here, from the first in-window neighbour of the pre-delete field.)
+        if (rmask && !win_all && g.sharded) {
 #pragma unroll
           for (int k = 0; k < V; ++k)
             if (((rmask >> k) & 1u) && !g.in_window(x, y, z8 + k)) {
-              coc[base + z8 + k] = reseed_outside_window(g, coc, occbits, gocc, x, y, z8 + k);
+              coc[base + z8 + k] = reseed_first_neighbour(g, coc, occbits, gocc, x, y, z8 + k);
               rmask &= ~(1u << k);
               ++local;
             }
@@ -1274,6 +1318,18 @@ bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
   return !stale_inf_;
 }
 
+// The cost half of the engine choice, from the measured crossover (profiles/r03a_delta_sweep.json: C2's map, both scenes,
+// deltas 100 ... 50 k on either engine).  The transform is one fixed sweep, ~6 ps per voxel of the grid; the rounds cost a
+// fixed ~0.8 ms of launches and scans on a 512^3 map plus ~0.3 ns per voxel whose obstacle changes, about
+// delta x (voxels per obstacle) of them.  In voxel units: bulk pays iff  n <= 1.3e8 + 50 x (estimated updated voxels) --
+// on every grid up to 512^3 that is always (measured: 0.80 vs 0.93 ms at a delta of 100), on a 1024^3 shard from a delta of
+// ~2 % of the obstacles.  FIESTA_HIP_BULK_RATIO (a fraction of the occupied voxels) overrides the model.
+bool DenseMap::bulk_pays(double delta, double nocc, double n) const {
+  if (bulk_ratio_ >= 0) return delta >= bulk_ratio_ * std::max(nocc, 1.0);
+  const double updated = std::min(n, delta * n / std::max(nocc, 1.0));
+  return n <= 1.3e8 + 50.0 * updated;
+}
+
 // After a successful bulk transform: the queues are consumed, timings and counters reported.
 void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
   zero_counter(C_INSERT);
@@ -1358,8 +1414,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   // Engine choice.  The bulk transform costs one fixed sweep over the grid; the frontier rounds cost in proportion to
   // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).
   if (!seed_only && !g_.sharded && bulk_eligible(ni, nd)) {
-    const double nocc = (double)(long long)h_counters_[C_NOCC];
-    if (update_engine_ == 2 || (double)(ni + nd) >= bulk_ratio_ * std::max(nocc, 1.0)) {
+    if (update_engine_ == 2 || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n)) {
       bool exact = true;
       if (run_bulk(st, 0, &exact)) {
         bulk_finish(st, h0);
@@ -1398,6 +1453,15 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   // a small delta (a depth frame): do not even read how many tiles were seeded, the chain of rounds finds out on the device
   const uint32_t n0 = (ni + nd <= (unsigned long long)small_update_ && !remote_del) ? kCountOnDevice : (uint32_t)read_counter(C_LIST0);
   run_rounds(st, n0, 0);
+  {  // orphans outside the update window (local / sliding-window maps): their pull, after the rounds
+    const Geom &g = g_;
+    const bool win_all = g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1;
+    if (!win_all && (nd || remote_del)) {
+      hipLaunchKernelGGL(k_reseed_outside, dim3(grid_for(g_.n, 256, 8192)), dim3(256), 0, stream_, g_, coc_, (const uint32_t *)occbits_,
+                         (const uint32_t *)gocc_, (const unsigned long long *)counters_, (track_ && nd) ? 1 : 0);
+      FIESTA_HIP_CHECK(hipGetLastError());
+    }
+  }
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
   collect_stats(st);
   FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));

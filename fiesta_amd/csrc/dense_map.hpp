@@ -100,7 +100,8 @@ class DenseMap {
   bool bulk_try(fiesta_hip_stats *st, int margin, bool *exact);
   void bulk_commit(fiesta_hip_stats *st);
   int update_engine() const { return update_engine_; }
-  double bulk_ratio() const { return bulk_ratio_; }
+  void set_update_engine(int e) { update_engine_ = e; }
+  bool bulk_pays(double delta, double nocc, double n) const;  // is the fixed sweep cheaper than the frontier rounds?
   // continue relaxing tiles that are already flagged (after ghost entries were applied)
   void relax_pending(fiesta_hip_stats *st, int64_t *pending);
 
@@ -201,7 +202,7 @@ class DenseMap {
   // UpdateESDF engine (fiesta_hip_config.update_engine): 0 = choose per update, 1 = frontier rounds only,
   // 2 = bulk feature transform whenever the map state allows it
   int update_engine_ = 0;
-  double bulk_ratio_ = 0.04;  // auto: bulk when (inserts + deletes) exceed this fraction of the occupied voxels
+  double bulk_ratio_ = -1;  // >= 0 (FIESTA_HIP_BULK_RATIO): bulk when inserts + deletes exceed this fraction of the occupied voxels
   // Late observations: a voxel first observed while obstacles exist stays at "no obstacle" until a wave reaches it
   // (the reference never queues it), so the field is no longer the transform of the occupied set and the bulk path is
   // off until a scan finds no such voxel left (k_count_stale) or the map holds no obstacle.

@@ -361,7 +361,9 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
       force = force && t[4] == 2;
       ni += t[1], nd += t[2], nocc += t[3];
     }
-    const bool want = all && (ni + nd) > 0 && (force || (double)(ni + nd) >= locals_[0]->map->bulk_ratio() * std::max<double>(nocc, 1.0));
+    // (the cost model per shard: its share of the delta and of the obstacles against its own array)
+    const bool want = all && (ni + nd) > 0 &&
+                      (force || locals_[0]->map->bulk_pays((double)(ni + nd) / world_, (double)nocc / world_, (double)locals_[0]->map->total()));
     for (int m = margin_; want; m *= 2) {
       std::vector<fiesta_hip_stats> ss(locals_.size());
       for (size_t i = 0; i < locals_.size(); ++i) {

@@ -97,6 +97,10 @@ class ESDFMap:
     def SetOriginalRange(self):
         check(self._lib.fiesta_hip_set_original_range(self._h))
 
+    def set_update_engine(self, update_engine):
+        """"auto" / "rounds" / "bulk" (0 / 1 / 2) from the next UpdateESDF on."""
+        check(self._lib.fiesta_hip_set_update_engine(self._h, {"auto": 0, "rounds": 1, "bulk": 2}.get(update_engine, update_engine)))
+
     # -- occupancy ingest ----------------------------------------------------------------------------
     def SetOccupancy(self, where, occ, want_ret=True):
         """SetOccupancy(Vector3i|Vector3d, int).  Integer input -> voxel overload, float -> position."""

@@ -122,6 +122,9 @@ int fiesta_hip_set_prob_params(fiesta_hip_map *m, double p_hit, double p_miss, d
 int fiesta_hip_set_update_range(fiesta_hip_map *m, const double min_pos[3], const double max_pos[3],
                                 int new_vec);
 int fiesta_hip_set_original_range(fiesta_hip_map *m);
+/* fiesta_hip_config.update_engine, changed on a live map (takes effect with the next UpdateESDF; array maps only, a
+ * hash-block map has one engine).  No reference counterpart: the reference has one engine. */
+int fiesta_hip_set_update_engine(fiesta_hip_map *m, int32_t engine);
 
 /* ---- occupancy ingest: ESDFMap::SetOccupancy x2 (src/ESDFMap.cpp:401-437), batched ----
  * Observations are applied as if SetOccupancy had been called once per entry; hit/total counters are

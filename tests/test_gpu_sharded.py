@@ -75,16 +75,12 @@ def test_bulk_then_rounds_updates_next_to_a_cut(hip_lib, oracle_libs, best_oracl
     """ADVICE r2 (shard_group.hip): a committed bulk transform rewrites owned and ghost cells behind the ghost exchange's
     back; the per-link "last sent" shadows must not survive it.  Sequence: frontier update inserting an obstacle A next to
     a cut (shadows = field with A), bulk update that deletes A, small frontier update that re-inserts A -- the owner
-    relaxes straight back to the words it sent last, and only a forgotten shadow makes it resend them.  Engine chosen per
-    update (auto): the large deltas go bulk, the single-voxel ones take the rounds."""
+    relaxes straight back to the words it sent last, and only a forgotten shadow makes it resend them.  The engine is
+    switched per update (fiesta_hip_set_update_engine): large deltas bulk, single-voxel ones the rounds -- what the
+    engine choice does by itself on a large map."""
     from fiesta_amd.sharded import ShardedESDFMap
-    import fiesta_amd.esdf_map as em
     gs, res = (64, 64, 64), 0.1
-    old, em.DEFAULT_UPDATE_ENGINE = em.DEFAULT_UPDATE_ENGINE, 0
-    try:
-        sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards)
-    finally:
-        em.DEFAULT_UPDATE_ENGINE = old
+    sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards)
     cpu = oracle_libs.OracleMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res), kind=best_oracle_kind)
     for m in (sm, cpu):
         m.SetParameters(*P_DEFAULT)
@@ -97,6 +93,8 @@ def test_bulk_then_rounds_updates_next_to_a_cut(hip_lib, oracle_libs, best_oracl
     none = np.zeros((0, 3), np.int32)
 
     def step(occ, free, want_bulk):
+        for sh in sm.shards.values():          # (on a map this small the cost model would always pick the transform)
+            sh.set_update_engine("bulk" if want_bulk else "rounds")
         for _ in range(6 if len(free) else 3):
             for v, o in ((occ, 1), (free, 0)):
                 if len(v):
