@@ -638,11 +638,19 @@ def main():
     # what makes an N > 1 line evidence, not just a number (the field now is the one the K timed steps produced)
     verify = None
     if args.verify_samples > 0:
-        mine = (w.live + box_lo.astype(np.int32)).astype(np.int32)
+        # the occupied set as the map holds it (the workload's own list is not it: a voxel that left and was drawn again
+        # carries more log-odds than a fresh one and survives the single miss that frees the others)
+        mine = np.ascontiguousarray(m.GetOccupiedVoxels(), dtype=np.int32)
         if dist:
-            parts = [torch.empty((args.obstacles, 3), dtype=torch.int32, device=cdev) for _ in range(world)]
-            dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(mine)).to(cdev))
-            everything = torch.cat(parts).cpu().numpy()
+            cnt = torch.tensor([len(mine)], device=cdev, dtype=torch.int64)
+            cnts = [torch.zeros_like(cnt) for _ in range(world)]
+            dist.all_gather(cnts, cnt)
+            cap = int(max(int(c.item()) for c in cnts))
+            pad = np.zeros((cap, 3), np.int32)
+            pad[: len(mine)] = mine
+            parts = [torch.empty((cap, 3), dtype=torch.int32, device=cdev) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(pad).to(cdev))
+            everything = np.concatenate([p_.cpu().numpy()[: int(c.item())] for p_, c in zip(parts, cnts)])
         else:
             everything = mine
         gext = G * (max(layout) if sharded_map is not None else 1)

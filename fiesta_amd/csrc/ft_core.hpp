@@ -60,44 +60,53 @@ FT_HD int floor_div_small(int N, int D) {
   return q;
 }
 
-// An envelope ENTRY is (q, f, tag): position along the column, height, and an opaque 20-bit tag that comes back when the
-// entry wins a position (pass A: the z of the site; pass B: its packed (y', z')).  In the ring an entry is two words,
-//     e1 = f << 11 | q            (q < 2048, f < 2^21)
-//     e2 = tag << 12 | start      (start < 4096: the first position the entry wins)
-// so that a pop or an advance is ONE 8-byte LDS read and a handful of shifts -- the first layout (packed site + 16-bit
-// start) re-derived q and f from the site's coordinates on every pop, a third of the instructions of a step.
-// Ring:   void get(int i, uint32_t &e1, uint32_t &e2), uint32_t second(int i), void set(int i, uint32_t e1, uint32_t e2)
-//         (i already < S)
+// An envelope ENTRY is (q, f, tag): position along the column, height, and an opaque tag that comes back when the entry
+// wins a position (pass A: the z of the site; pass B: its packed (y', z')).  In the ring an entry is two words,
+//     e1 = f << SB | start        (start: the first position the entry wins; SB = 11, or 12 for columns up to 2048)
+//     e2 = q << QSH | tag         -- the OUTPUT WORD itself: what the kernels store when the entry wins a position
+// so that a pop is ONE 8-byte LDS read and three shifts, and an emission needs no packing at all (r02's layout
+// f << 11 | q, tag << 12 | start re-assembled the output word per position and cached five fields of the bottom entry).
+// Ring:   void get(int c, uint32_t &e1, uint32_t &e2), void set(int c, uint32_t e1, uint32_t e2), static int kStep:
+//         c is a MONOTONE counter that advances by kStep per entry (the ring reduces it to a slot itself): an LDS ring
+//         counts in bytes, so that a slot address is one and-or of the counter (ft_kernels.hpp: LdsRing).
 //
 // The operations are written for a WAVE that runs 64 envelopes in lock-step: no data-dependent branch inside -- every
 // lane executes every instruction, lanes that have nothing to do pass `doit = false` and get their state back through
 // selects -- and the loops around them (pop until no lane wants to, emit while every lane is final) are decided by
-// wave votes in the caller.  On the GPU that keeps the control flow scalar (the first version, with per-lane `while`
-// and `if`, compiled to ~700 instructions per step, most of them exec-mask bookkeeping; this form needs ~150).
-constexpr int kQBits = 11, kStartBits = 12;
-template <int S, class Ring>
+// wave votes in the caller.  What a wave executes per step is therefore the MAXIMUM over its lanes, not the mean: with 64
+// lanes some lane advances its bottom entry at 98 % of the positions and some lane pops at every other site (measured on
+// config 2's scene), so the operations that used to sit behind a vote "because most lanes skip them" ran nearly always --
+// r03 makes the common ones unconditional and cheap instead:
+//   * the bottom entry follows the emission point by ONE ring read, one compare and two selects per position (step_to),
+//     no vote and no branch (r02: a vote per position and a 20-instruction advance behind it);
+//   * place() needs no "does it win anywhere inside the column" test -- the start is clamped to the column length, an
+//     entry that starts there simply never wins -- and, on columns up to 1024, no fix-up of the division (see start_of).
+// QSH: bit position of q in the output word (pass A: 10 or 11, pass B: 20).  LONG: columns up to 2048 positions.
+template <int S, class Ring, int QSH, bool LONG = false>
 struct LaneEnvelope {
   static_assert((S & (S - 1)) == 0, "ring size must be a power of two");
+  static constexpr int SB = LONG ? 12 : 11;               // bits of `start` in e1; f gets the other 32 - SB
+  static constexpr uint32_t kSMask = (1u << SB) - 1u;
+  static constexpr int K = Ring::kStep;
   Ring r;
-  int bot, top;  // live entries are bot..top (monotone counters, ring slot = counter & (S-1)); empty iff top < bot
-  // cached entries: position q and key = q^2 + f(q), so that cost(p) = p (p - 2 q) + key
-  int t_q, t_key, t_s;  // top entry
-  uint32_t t_tag;
-  int c_q, c_key;       // entry `bot` = the winner at the emission point
-  uint32_t c_tag;
-  int n_s;  // start of entry `bot + 1` (kNoStart: there is none)
+  int bot, top;  // live entries are bot..top (monotone counters in units of K, see Ring); empty iff top < bot
+  // cached top entry: position q and key = q^2 + f(q), so that cost(p) = p (p - 2 q) + key; t_s = its start
+  int t_q, t_key, t_s;
+  // cached bottom entry = the winner at the emission point: its output word and height
+  uint32_t c_word;
+  int c_f;
   bool overflow;
 
   FT_HD void init() {
     bot = 0;
-    top = -1;
-    t_tag = c_tag = 0;
-    t_q = t_key = t_s = c_q = c_key = 0;
-    n_s = kNoStart;
+    top = -K;
+    t_q = t_key = t_s = 0;
+    c_word = 0;
+    c_f = 0;
     overflow = false;
   }
   FT_HD bool empty() const { return top < bot; }
-  FT_HD int depth() const { return top - bot + 1; }
+  FT_HD int depth() const { return (top - bot) / K + 1; }
   static FT_HD int key_of(int q, int f) { return mul24(q, q) + f; }
 
   // ---- a new site at position q (beyond every site pushed before), key = q^2 + f: pop while any lane wants to,
@@ -111,95 +120,95 @@ struct LaneEnvelope {
     return N < mul24(t_s, D);  // ... already at the top's first position: the top wins nowhere
   }
   FT_HD void pop(bool doit) {
-    const int nt = top - 1;
+    const int nt = top - K;
     uint32_t e1, e2;
-    r.get(nt & (S - 1), e1, e2);  // (below the bottom this is a stale slot: read, not used)
-    const bool more = nt >= bot, ld = doit & more;  // (`&`, not `&&`, here and below: a short circuit becomes an
-    top = doit ? nt : top;                            //  exec-mask region with its scalar bookkeeping)
-    const int nq = (int)(e1 & ((1u << kQBits) - 1u));
-    const int nk = more ? mul24(nq, nq) + (int)(e1 >> kQBits) : 0, ns = more ? (int)(e2 & ((1u << kStartBits) - 1u)) : 0;
-    t_q = ld ? nq : t_q;
+    r.get(nt, e1, e2);  // (below the bottom this is a stale slot: read, not used)
+    const bool more = nt >= bot;   // (`&`, not `&&`, here and below: a short circuit becomes an exec-mask region)
+    const int nq = (int)(e2 >> QSH);
+    const int nk = more ? mul24(nq, nq) + (int)(e1 >> SB) : 0, ns = more ? (int)(e1 & kSMask) : 0;
+    top = doit ? nt : top;
+    t_q = doit ? nq : t_q;      // (an emptied ring: whatever the stale slot held -- harmless, N = key >= 0 = t_s * D)
     t_key = doit ? nk : t_key;  // (the ring ran empty: 0, see wants_pop)
     t_s = doit ? ns : t_s;
-    t_tag = ld ? e2 >> kStartBits : t_tag;
+  }
+  // floor(N / (2 d)) + 1 for the start of a newcomer d positions beyond the top, N = key - t_key >= 0 (no lane wants a
+  // pop).  floor(N / 2d) = floor((N >> 1) / d).  Short columns: ONE float multiply decides it -- (M + 1/2) / d lies at
+  // least 1 / 2d >= 4.9e-4 away from every integer (d <= 1023), the product with the 1-ulp reciprocal is off by at most
+  // 1.8e-7 relative, i.e. < 3.7e-4 up to the quotient 2048, beyond which the start is clamped anyway.  Long columns
+  // (d up to 2047) keep the exact integer fix-up.
+  static FT_HD int start_of(int N, int d) {
+    const int M = N >> 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!LONG) return (int)(((float)M + 0.5f) * __builtin_amdgcn_rcpf((float)d)) + 1;
+#else
+    if (d <= 0) return 0;  // (an empty ring's stale top: the caller replaces the result)
+    if (!LONG) return (int)(((float)M + 0.5f) / (float)d) + 1;
+#endif
+    return floor_div_small(M, d) + 1;
   }
   // n_pos = column length, p_out = the next position to be emitted (everything before it is final and gone)
-  template <bool BOTTOM = true>
-  FT_HD void place(bool doit, int q, int f, uint32_t tag, int key, int n_pos, int p_out) {
+  FT_HD void place(bool doit, int q, int f, uint32_t word, int key, int n_pos, int p_out) {
     const bool has = top >= bot;
-    const int D = has ? 2 * (q - t_q) : 2, N = key - t_key;
-    const bool inside = !has | (N < mul24(n_pos, D));  // else it beats the top only beyond the last position
-    const int sq = floor_div_small((has & inside) ? N : 0, D) + 1;  // (no lane wants a pop: N >= t_s * D >= 0)
-    const int s = has ? sq : p_out;  // alone, it owns everything that is not emitted yet
-    bool keep = doit & inside;
-    const bool ovf = keep & (top - bot + 1 >= S - 1);  // one slot stays free, see below
+    int s = start_of(key - t_key, q - t_q);  // (an empty ring: garbage in, garbage out, replaced below)
+    s = s < n_pos ? s : n_pos;               // clamped: an entry that starts at the end of the column never wins
+    s = has ? s : p_out;                     // alone, it owns everything that is not emitted yet
+    const bool ovf = doit & (top - bot >= (S - 2) * K);  // one slot stays free, see below
     overflow = overflow | ovf;
-    keep = keep & !ovf;
-    const int ntop = top + 1;
+    const bool keep = doit & !ovf;
+    const int ntop = top + K;
     // every lane stores, no branch around it: the slot after the top is never live (at most S - 1 entries), a lane that
     // keeps nothing just leaves a stale entry there
-    r.set(ntop & (S - 1), ((uint32_t)f << kQBits) | (uint32_t)q, (tag << kStartBits) | (uint32_t)s);
+    r.set(ntop, ((uint32_t)f << SB) | ((uint32_t)s & kSMask), word);
     top = keep ? ntop : top;
-    t_tag = keep ? tag : t_tag;
     t_q = keep ? q : t_q;
     t_key = keep ? key : t_key;
     t_s = keep ? s : t_s;
-    // the cached bottom follows pops and the push -- unless the caller emits only every few sites and reloads it then
-    if (BOTTOM) {
-      const bool one = top == bot;
-      c_tag = one ? t_tag : c_tag;
-      c_q = one ? t_q : c_q;
-      c_key = one ? t_key : c_key;
-      n_s = top == bot + 1 ? t_s : (top <= bot ? kNoStart : n_s);
-    }
   }
-  // after a run of place<false>() calls: the cached bottom from the ring (two LDS reads instead of five selects per site)
+  // before a run of emissions: the cached bottom from the ring (sites placed since the last run did not maintain it)
   FT_HD void reload_bottom() {
     uint32_t e1, e2;
-    r.get(bot & (S - 1), e1, e2);
-    const uint32_t e2n = r.second((bot + 1) & (S - 1));
+    r.get(bot, e1, e2);
     const bool has = top >= bot;
-    const int nq = (int)(e1 & ((1u << kQBits) - 1u));
-    c_q = has ? nq : c_q;
-    c_key = has ? mul24(nq, nq) + (int)(e1 >> kQBits) : c_key;
-    c_tag = has ? e2 >> kStartBits : c_tag;
-    n_s = top > bot ? (int)(e2n & ((1u << kStartBits) - 1u)) : kNoStart;
+    c_word = has ? e2 : c_word;
+    c_f = has ? (int)(e1 >> SB) : c_f;
   }
 
-  // ---- emission.  Before position p is judged, the bottom moves on to the entry that wins there (advance): that is
-  // safe although p may not be final yet -- whatever later pops the new bottom beats it at its first position <= p, hence
-  // beats the released entry at p too, so the released entry never owns p again.
-  FT_HD bool wants_advance(int p) const { return n_s <= p; }
-  FT_HD void advance(bool doit) {
-    const int nb = bot + 1;
+  // ---- emission.  Before position p is emitted the bottom moves on to the entry that wins there: the entry after the
+  // bottom takes over iff its start has been reached -- starts are strictly increasing, positions are visited one by one,
+  // so one look ahead per position suffices.  Safe although p may not be final yet: whatever later pops the new bottom
+  // beats it at its first position <= p, hence beats the released entry at p too -- it never owns p again.
+  FT_HD void step_to(int p) {
+    const int nb = bot + K;
     uint32_t e1, e2;
-    r.get(nb & (S - 1), e1, e2);
-    const int rst = (int)(r.second((nb + 1) & (S - 1)) & ((1u << kStartBits) - 1u));
-    const int nq = (int)(e1 & ((1u << kQBits) - 1u));
-    bot = doit ? nb : bot;
-    c_tag = doit ? e2 >> kStartBits : c_tag;
-    c_q = doit ? nq : c_q;
-    c_key = doit ? mul24(nq, nq) + (int)(e1 >> kQBits) : c_key;
-    n_s = doit ? (nb < top ? rst : kNoStart) : n_s;
+    r.get(nb, e1, e2);  // (beyond the top: a stale slot, read and ignored)
+    const bool adv = (nb <= top) & ((int)(e1 & kSMask) <= p);
+    bot = adv ? nb : bot;
+    c_word = adv ? e2 : c_word;
+    c_f = adv ? (int)(e1 >> SB) : c_f;
   }
   // Is the winner at position p settled, given that every site still to come lies at x_next or beyond (p < x_next)?
-  // (after advance: the winner is the bottom entry)
   // Finality is MONOTONE: sqrt(cost(.)) is 1-Lipschitz (a minimum of 1-Lipschitz functions), so a position that is
-  // final makes every position before it final as well.  And judged by the bottom entry BEFORE advancing, the test is
+  // final makes every position before it final as well.  And judged by the bottom entry BEFORE stepping, the test is
   // merely conservative (the bottom's parabola lies on or above the envelope).  Together: final_at(p + k, x_next) on the
-  // un-advanced bottom settles p .. p + k at once -- the emission loops use it to skip k of k + 1 finality votes.
-  // The same folding as in wants_pop: while the ring is empty the cached bottom reads c_q = 0, c_key = +kNeverFinal
-  // (set_idle(false), the start of every column) -- no position is final; a lane that carries no column reads
-  // -kNeverFinal (set_idle(true)) -- it never holds up the wave's vote.  One compare, its mask is the vote.
+  // un-stepped bottom settles p .. p + k at once -- the emission loops use it to skip k of k + 1 finality votes.
+  // While the ring is empty the cached bottom reads c_f = +kNeverFinal (set_idle(false), the start of every column) --
+  // no position is final; a lane that carries no column reads -kNeverFinal (set_idle(true)) -- it never holds up the
+  // wave's vote.  One compare, its mask is the vote.
   static constexpr int kNeverFinal = (1 << 30) + 1;  // above any (x_next - p)^2, and p^2 on top still fits an int
-  FT_HD void set_idle(bool idle) { c_key = idle ? -kNeverFinal : kNeverFinal; }
-  FT_HD bool final_at(int p, int x_next) const {
-    const int g = mul24(p, p - 2 * c_q) + c_key, dx = x_next - p;
-    return dx * dx >= g;
+  FT_HD void set_idle(bool idle) {
+    c_f = idle ? -kNeverFinal : kNeverFinal;
+    c_word = 0;
   }
-  FT_HD int winner_q() const { return c_q; }
-  FT_HD uint32_t winner_tag() const { return c_tag; }
-  FT_HD int winner_cost(int p) const { return mul24(p, p - 2 * c_q) + c_key; }
+  FT_HD int winner_q() const { return (int)(c_word >> QSH); }
+  FT_HD uint32_t winner_word() const { return c_word; }
+  FT_HD int winner_cost(int p) const {
+    const int dq = p - winner_q();
+    return mul24(dq, dq) + c_f;
+  }
+  FT_HD bool final_at(int p, int x_next) const {
+    const int dx = x_next - p;
+    return dx * dx >= winner_cost(p);
+  }
 };
 
 // Nearest set bit of a bitmap row to position z, for the 64 positions [cbase, cbase + 64) that share the 64-bit chunk

@@ -50,23 +50,38 @@ struct FtArgs {
   }
 };
 
-// LDS ring of one wave: entry[slot][lane], two 32-bit words (ft_core.hpp: e1 = f << 11 | q, e2 = tag << 12 | start), read
-// and written as one 8-byte access.  LANES < 64: only the first LANES lanes of the wave carry a column (the deepest tier
+// LDS ring of one wave: entry[slot][lane], two 32-bit words (ft_core.hpp: e1 = f << SB | start, e2 = the output word
+// q << QSH | tag), read and written as one 8-byte access.  LANES < 64: only the first LANES lanes of the wave carry a column (the deepest tier
 // trades lanes for depth).
+// Counters of the envelope advance by kStep = the byte stride of a slot, and the rings of the small tiers are aligned to
+// their own size: a slot address is then ONE v_and_or_b32 of the counter (r02: shift, mask, add).
+typedef unsigned int ft_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) ft_u32x2 lds_uint2;
 template <int S, int LANES>
 struct LdsRing {
-  uint2 *e;
+  static constexpr int kStep = LANES * 8;                       // bytes from one slot of a lane to its next
+  static constexpr uint32_t kBytes = (uint32_t)S * LANES * 8u;  // one wave's ring
+  static constexpr bool kAligned = kBytes <= 16384u;            // (bigger rings are not worth the padding in LDS)
+  static constexpr uint32_t kMask = (uint32_t)(S - 1) * kStep;
+  uint32_t base;  // LDS byte address of this lane's slot 0 (kAligned: the wave's ring starts at a multiple of kBytes)
   bool live;  // LANES < 64: the lanes beyond LANES carry no column and share the ring of lane % LANES -- they may read it
               // (and ignore what they read) but must not take part in the envelope's unconditional store
-  __device__ __forceinline__ void get(int i, uint32_t &e1, uint32_t &e2) const {
-    const uint2 v = e[i * LANES];
+  __device__ __forceinline__ lds_uint2 *slot(int c) const {
+    const uint32_t off = (uint32_t)c & kMask;
+    return reinterpret_cast<lds_uint2 *>(kAligned ? (base | off) : (base + off));
+  }
+  __device__ __forceinline__ void get(int c, uint32_t &e1, uint32_t &e2) const {
+    const ft_u32x2 v = *slot(c);
     e1 = v.x, e2 = v.y;
   }
-  __device__ __forceinline__ uint32_t second(int i) const { return e[i * LANES].y; }
-  __device__ __forceinline__ void set(int i, uint32_t e1, uint32_t e2) {
-    if (LANES == 64 || live) e[i * LANES] = make_uint2(e1, e2);
+  __device__ __forceinline__ void set(int c, uint32_t e1, uint32_t e2) {
+    if (LANES == 64 || live) *slot(c) = ft_u32x2{e1, e2};
   }
 };
+template <int S, int LANES>
+__device__ __forceinline__ LdsRing<S, LANES> make_ring(const uint2 *wave_ring, int lane) {
+  return LdsRing<S, LANES>{(uint32_t)(size_t)(wave_ring + lane % LANES), lane < LANES};  // (low half of a generic LDS pointer: the offset)
+}
 // Site packing.  Regions of at most 1024 voxels per axis (every unsharded map up to the plain-id limit): ABSOLUTE region
 // coordinates, 10 bits each.  WIDE (regions up to 2048: a 1024^3 shard of config 5 plus its margin; grids beyond 1024 per
 // axis, whose ids reach 512 voxels anyway, common.hpp): pass A keeps 11-bit absolute (y', z'); pass B carries the site's
@@ -128,8 +143,13 @@ template <int S, int LANES, int WAVES, bool WIDE>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
   constexpr int RB = 16;               // bitmap rows staged per batch
   constexpr int RW = WIDE ? 64 : 32;   // 32-bit words of a staged row
-  __shared__ uint2 ring[WAVES][S * LANES];
-  __shared__ uint32_t rowstage[WAVES][RB][RW];
+  struct __attribute__((aligned(LdsRing<S, LANES>::kAligned ? S * LANES * 8 : 16))) Lds {
+    uint2 ring[WAVES][S * LANES];
+    uint32_t rowstage[WAVES][RB][RW];
+  };
+  __shared__ Lds lds;
+  auto &ring = lds.ring;
+  auto &rowstage = lds.rowstage;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int SUB = 64 / LANES;  // sub-items per column group when a wave only carries LANES columns
   const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
@@ -142,8 +162,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
     const int k = sub * LANES + lane;  // position inside the 64-voxel group
     const int z = 64 * c + k;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;  // (pass B only reads these)
-    ft::LaneEnvelope<S, LdsRing<S, LANES>> env;  // entries: q = row y', f = (z - z')^2, tag = z'
-    env.r = LdsRing<S, LANES>{&ring[wave][lane % LANES], lane < LANES};
+    ft::LaneEnvelope<S, LdsRing<S, LANES>, FtPack<WIDE>::SH, WIDE> env;  // entries: q = row y', f = (z - z')^2, tag = z'
+    env.r = make_ring<S, LANES>(&ring[wave][0], lane);
     env.init();
     env.set_idle(!act);
     int p_out = 0;
@@ -189,13 +209,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         // "no obstacle" in the end; clamping keeps f inside its 21 bits)
         const int dd = WIDE ? min(d, 1023) : d;
         const int f = ft::mul24(dd, dd), key = yr * yr + f;
-        const uint32_t tag = (uint32_t)(zp & ((1 << FtPack<WIDE>::SH) - 1));
+        const uint32_t word = ((uint32_t)yr << FtPack<WIDE>::SH) | (uint32_t)(zp & ((1 << FtPack<WIDE>::SH) - 1));
         for (;;) {  // pop while any lane wants to
           const bool want = env.wants_pop(yr, key);  // (a lane without a column has an empty ring: never)
           if (!ft_vote(want)) break;
           env.pop(want);
         }
-        env.template place<false>(act, yr, f, tag, key, a.ny, p_out);
+        env.place(act, yr, f, word, key, a.ny, p_out);
         // positions are emitted every eighth site row (and at the end of a staged batch): a run of emissions ends with a
         // failed finality vote, and sites placed in between need not keep the cached bottom entry current
         if ((r & 7) != 7 && r + 1 < nb) continue;
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         env.reload_bottom();
         const int pend = min(a.ny, ynext);
         auto emit = [&]() {
-          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = ((uint32_t)env.winner_q() << FtPack<WIDE>::SH) | env.winner_tag();
+          if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = env.winner_word();
           out += a.nz;
           ++p_out;
         };
@@ -216,15 +236,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
           if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
-            if (ft_vote(adv)) env.advance(adv);
+            env.step_to(p_out);
             emit();
           }
         }
         // ... then one by one
         while (p_out < pend) {
-          const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
-          if (ft_vote(adv)) env.advance(adv);
+          env.step_to(p_out);
           const bool fin = env.final_at(p_out, ynext);
           if (ft_vote(fin) != ~0ull) break;
           emit();
@@ -241,12 +259,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
 // batch, push the P sites, then emit every position that has become final -- straight to HBM, one row segment each.
 // gfx9's vmcnt is one counter for loads and stores, so the wait at the top of a batch also covers the stores of the
 // batch before: they are issued last, right in front of it, and the other waves of the SIMD fill the gap.
-template <int S, int LANES, int WAVES, bool WIDE>
+template <int S, int LANES, int WAVES, bool WIDE, bool TRACK>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
   constexpr int P = 8;
-  // per wave: the landing zone of the prefetch (P planes x 64 lanes x 4 B) -- first, so that the LDS address the DMA
-  // takes from m0 stays below 64 KB in every tier -- then the ring
-  __shared__ uint2 lds[WAVES][S * LANES + P * 32];
+  // the landing zones of the prefetch (per wave: P planes x 64 lanes x 4 B) come first, so that the LDS address the DMA
+  // takes from m0 stays below 64 KB in every tier; then the rings, each aligned to its own size in the small tiers
+  constexpr int RA = LdsRing<S, LANES>::kAligned ? S * LANES * 8 : 16;
+  struct __attribute__((aligned(RA))) Lds {
+    uint32_t land[WAVES][P * 64];
+    __attribute__((aligned(RA))) uint2 ring[WAVES][S * LANES];
+  };
+  __shared__ Lds lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int SUB = 64 / LANES;
   const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
@@ -257,28 +280,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
   for (uint32_t it = blockIdx.x * WAVES + wave; it < n; it += gridDim.x * WAVES) {
     const uint32_t id = a.items ? a.items[it / SUB] : it / SUB;
     const int sub = (int)(it % SUB);
-    const int y = (int)(id / (uint32_t)a.nzc), c = (int)(id % (uint32_t)a.nzc);
+    const int y = __builtin_amdgcn_readfirstlane((int)(id / (uint32_t)a.nzc)), c = __builtin_amdgcn_readfirstlane((int)(id % (uint32_t)a.nzc));
     const int z = 64 * c + sub * LANES + lane;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;
     if ((unsigned)(y - a.oy0) >= (unsigned)a.ony) continue;  // (the host only lists rows of the output box)
     // entries: q = plane x', f = (y - y')^2 + (z - z')^2, tag = y' << 10 | z' (WIDE: the offsets y' - y, z' - z)
-    ft::LaneEnvelope<S, LdsRing<S, LANES>> env;
-    env.r = LdsRing<S, LANES>{&lds[wave][P * 32 + lane % LANES], lane < LANES};
+    ft::LaneEnvelope<S, LdsRing<S, LANES>, 20, WIDE> env;
+    env.r = make_ring<S, LANES>(&lds.ring[wave][0], lane);
     env.init();
     env.set_idle(!act);
-    uint32_t *land = reinterpret_cast<uint32_t *>(&lds[wave][0]);
+    uint32_t *land = &lds.land[wave][0];
     int p_out = 0;
     bool failed = false;
     const int64_t plane = (int64_t)a.ny * a.nz, col = (int64_t)y * a.nz + (act ? z : 0);
     const uint32_t *in = a.inter + col;
     const int64_t oplane = (int64_t)a.ony * a.onz;
-    // -> output voxel of region position p_out of this column (valid to dereference only inside the output box)
-    vox_t *optr = a.coc + ((int64_t)(0 - a.ox0) * a.ony + (y - a.oy0)) * a.onz + (act ? z - a.oz0 : 0);
+    // -> output voxel of region position p_out of this column (valid to dereference only inside the output box): a
+    // wave-uniform row pointer that walks the planes (scalar arithmetic) + the lane's byte offset inside the row
+    char *orow = reinterpret_cast<char *>(a.coc + ((int64_t)(0 - a.ox0) * a.ony + (y - a.oy0)) * a.onz);
+    const uint32_t ooff = (uint32_t)(act ? z - a.oz0 : 0) * (uint32_t)sizeof(vox_t);
     const bool shifted = (a.gx0 | a.gy0 | a.gz0) != 0;
     // emits what is final, one 256-byte row segment per position
     bool no_site = false;  // WIDE: every site of the column was out of an id's reach for this lane (set before the last run)
     auto emit = [&]() {
-      const uint32_t s = ((uint32_t)env.winner_q() << 20) | env.winner_tag();
+      const uint32_t s = env.winner_word();
       // region coordinates -> the id: global coordinates modulo 1024 (common.hpp: pack_coc); plain when the region
       // starts at the global origin of a grid within the plain-id limit (every unsharded map up to 1024 per axis)
       vox_t word;
@@ -290,9 +315,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
         word = shifted ? pack_coc((int)(s >> 20) + a.gx0, (int)((s >> 10) & 1023u) + a.gy0, (int)(s & 1023u) + a.gz0) : s;
       }
       const bool inbox = (unsigned)(p_out - a.ox0) < (unsigned)a.onx;
-      if (act && inbox) *optr = word;
-      if (a.maxd2 && act && inbox) acc_maxd2 = max(acc_maxd2, (uint32_t)env.winner_cost(p_out));
-      optr += oplane;
+      if (act && inbox) *reinterpret_cast<vox_t *>(orow + ooff) = word;
+      if (TRACK && act && inbox) acc_maxd2 = max(acc_maxd2, (uint32_t)env.winner_cost(p_out));
+      orow += oplane * (int64_t)sizeof(vox_t);
       ++p_out;
     };
     auto drain = [&](const int x_next) {
@@ -304,15 +329,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
         if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
-          if (ft_vote(adv)) env.advance(adv);
+          env.step_to(p_out);
           emit();
         }
       }
       // ... then one by one
       while (p_out < pend) {
-        const bool adv = env.wants_advance(p_out);  // (an idle lane's ring is empty: never)
-        if (ft_vote(adv)) env.advance(adv);
+        env.step_to(p_out);
         const bool fin = env.final_at(p_out, x_next);
         if (ft_vote(fin) != ~0ull) break;
         emit();
@@ -352,11 +375,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
           if (WIDE) {  // offsets from the column; a site out of an id's reach in y or z is no candidate
             dy = (int)(w[u] >> 11) - y, dz = (int)(w[u] & 2047u) - z;
             use = use && (unsigned)(dy + 511) < 1023u && (unsigned)(dz + 511) < 1023u;
-            tag = (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u);
+            tag = (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u) | ((uint32_t)x << 20);
             dy = use ? dy : 0, dz = use ? dz : 0;  // (f stays inside its bit field)
           } else {
-            tag = w[u] & 0xFFFFFu;
-            dy = y - (int)(tag >> 10), dz = z - (int)(tag & 1023u);
+            tag = (w[u] & 0xFFFFFu) | ((uint32_t)x << 20);  // (the output word; x is wave-uniform: one v_and_or)
+            dy = y - (int)((w[u] >> 10) & 1023u), dz = z - (int)(w[u] & 1023u);
           }
           const int f = ft::mul24(dy, dy) + ft::mul24(dz, dz), key = env.key_of(x, f);
           const int pkey = (WIDE && !use) ? env.kNoPop : key;  // (plain packing: use == act, and an idle lane's ring is empty)
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
             if (!ft_vote(want)) break;
             env.pop(want);
           }
-          env.template place<false>(use, x, f, tag, key, a.nx, p_out);
+          env.place(use, x, f, tag, key, a.nx, p_out);
         }
       }
       if (ft_vote(env.overflow)) failed = true;  // (nothing has been emitted since the ring spilled: the next tier redoes the item)
@@ -382,18 +405,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       if (WIDE) {  // a lane that found no site in reach must not hold up its neighbours' last run: it reads "no obstacle"
         no_site = act & env.empty();
         if (no_site) env.set_idle(true);
-        if (a.maxd2 && no_site) acc_maxd2 = 1u << 30;
+        if (TRACK && no_site) acc_maxd2 = 1u << 30;
       }
       drain(ft::kFarAhead);
     } else {  // no occupied voxel anywhere in the region: "observed, no obstacle"
       for (int p = 0; p < a.nx; ++p) {
-        if (act && (unsigned)(p - a.ox0) < (unsigned)a.onx) *optr = kInf;
-        optr += oplane;
+        if (act && (unsigned)(p - a.ox0) < (unsigned)a.onx) *reinterpret_cast<vox_t *>(orow + ooff) = kInf;
+        orow += oplane * (int64_t)sizeof(vox_t);
       }
-      if (a.maxd2 && act) acc_maxd2 = 1u << 30;
+      if (TRACK && act) acc_maxd2 = 1u << 30;
     }
   }
-  if (a.maxd2) {
+  if (TRACK) {
     for (int off = 32; off > 0; off >>= 1) acc_maxd2 = max(acc_maxd2, (uint32_t)__shfl_xor((int)acc_maxd2, off));
     if (lane == 0 && (unsigned long long)acc_maxd2 > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)acc_maxd2);
   }

@@ -17,11 +17,18 @@ namespace {
 constexpr uint32_t kNone = 0x80000000u;
 constexpr int W = 64;  // lanes per wave
 
-struct VecRing {  // two words per entry, as the LDS ring of ft_kernels.hpp
+template <int S>
+struct VecRing {  // two words per entry, as the LDS ring of ft_kernels.hpp; counters advance by kStep (there: bytes)
+  static constexpr int kStep = 8;
   uint32_t *e;
-  void get(int i, uint32_t &e1, uint32_t &e2) const { e1 = e[2 * i], e2 = e[2 * i + 1]; }
-  uint32_t second(int i) const { return e[2 * i + 1]; }
-  void set(int i, uint32_t e1, uint32_t e2) { e[2 * i] = e1, e[2 * i + 1] = e2; }
+  void get(int c, uint32_t &e1, uint32_t &e2) const {
+    const int i = (c / kStep) & (S - 1);
+    e1 = e[2 * i], e2 = e[2 * i + 1];
+  }
+  void set(int c, uint32_t e1, uint32_t e2) {
+    const int i = (c / kStep) & (S - 1);
+    e[2 * i] = e1, e[2 * i + 1] = e2;
+  }
 };
 
 struct Model {
@@ -34,13 +41,13 @@ struct Model {
   bool wide = false;  // the kernels' WIDE site packing (regions up to 2048 per axis, ids reach 512 voxels): pass B then emits
                       // d^2 (0x7FFFFFFF: nothing in reach) instead of a packed site
 
-  template <int S>
+  template <int S, bool WIDE>
   bool plane_item(int x, int c) {  // pass A for plane x, lanes z = 64 c + k; false: ring overflow
     std::vector<uint32_t> rs(2 * S * W);
-    LaneEnvelope<S, VecRing> env[W];  // pass A: q = y', f = (z - z')^2, tag = z'
+    LaneEnvelope<S, VecRing<S>, WIDE ? 11 : 10, WIDE> env[W];  // pass A: q = y', f = (z - z')^2, tag = z'
     bool act[W];
     for (int k = 0; k < W; ++k) {
-      env[k].r = VecRing{&rs[2 * k * S]};
+      env[k].r = VecRing<S>{&rs[2 * k * S]};
       env[k].init();
       act[k] = 64 * c + k < nz;
       env[k].set_idle(!act[k]);
@@ -54,26 +61,19 @@ struct Model {
         for (int k = 0; k < W; ++k) all4 = all4 && (env[k].final_at(p_out + 3, x_next));
         if (!all4) break;
         for (int j = 0; j < 4; ++j) {
-          bool any = false;
-          bool adv[W];
-          for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
-          if (any)
-            for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
+          for (int k = 0; k < W; ++k) env[k].step_to(p_out);
           for (int k = 0; k < W; ++k)
-            if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << (wide ? 11 : 10)) | env[k].winner_tag();
+            if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = env[k].winner_word();
           ++p_out;
         }
       }
       while (p_out < ny && p_out < x_next) {
-        bool any = false, all = true;
-        bool adv[W];
-        for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
-        if (any)
-          for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
+        bool all = true;
+        for (int k = 0; k < W; ++k) env[k].step_to(p_out);
         for (int k = 0; k < W; ++k) all = all && (env[k].final_at(p_out, x_next));
         if (!all) break;
         for (int k = 0; k < W; ++k)
-          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = ((uint32_t)env[k].winner_q() << (wide ? 11 : 10)) | env[k].winner_tag();
+          if (act[k]) inter[((size_t)x * ny + p_out) * nz + 64 * c + k] = env[k].winner_word();
         ++p_out;
       }
     };
@@ -104,7 +104,7 @@ struct Model {
         for (int k = 0; k < W; ++k) env[k].pop(want[k]);
       }
       for (int k = 0; k < W; ++k) {
-        env[k].template place<false>(act[k], yr, f[k], tag[k], key[k], ny, p_out);
+        env[k].place(act[k], yr, f[k], ((uint32_t)yr << (WIDE ? 11 : 10)) | tag[k], key[k], ny, p_out);
         if (env[k].overflow) return false;
         if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
       }
@@ -114,13 +114,13 @@ struct Model {
     return p_out == ny;
   }
 
-  template <int S>
+  template <int S, bool WIDE>
   bool column_item(int y, int c, uint32_t *out) {  // pass B for row y, lanes z = 64 c + k
     std::vector<uint32_t> rs(2 * S * W);
-    LaneEnvelope<S, VecRing> env[W];  // pass B: q = x', f = (y - y')^2 + (z - z')^2, tag = y' << 10 | z'
+    LaneEnvelope<S, VecRing<S>, 20, WIDE> env[W];  // pass B: q = x', f = (y - y')^2 + (z - z')^2, tag = y' << 10 | z'
     bool act[W];
     for (int k = 0; k < W; ++k) {
-      env[k].r = VecRing{&rs[2 * k * S]};
+      env[k].r = VecRing<S>{&rs[2 * k * S]};
       env[k].init();
       act[k] = 64 * c + k < nz;
       env[k].set_idle(!act[k]);
@@ -128,7 +128,7 @@ struct Model {
     int p_out = 0;
     bool no_site[W] = {};
     auto word = [&](int k) -> uint32_t {  // what the kernel's emit() stores (wide: as a squared distance)
-      if (!wide) return ((uint32_t)env[k].winner_q() << 20) | env[k].winner_tag();
+      if (!wide) return env[k].winner_word();
       const int cost = env[k].winner_cost(p_out);
       return (no_site[k] || cost >= (1 << 18)) ? 0x7FFFFFFFu : (uint32_t)cost;
     };
@@ -139,22 +139,15 @@ struct Model {
         for (int k = 0; k < W; ++k) all4 = all4 && (env[k].final_at(p_out + 3, x_next));
         if (!all4) break;
         for (int j = 0; j < 4; ++j) {
-          bool any = false;
-          bool adv[W];
-          for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
-          if (any)
-            for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
+          for (int k = 0; k < W; ++k) env[k].step_to(p_out);
           for (int k = 0; k < W; ++k)
             if (act[k]) out[((size_t)p_out * ny + y) * nz + 64 * c + k] = word(k);
           ++p_out;
         }
       }
       while (p_out < nx && p_out < x_next) {
-        bool any = false, all = true;
-        bool adv[W];
-        for (int k = 0; k < W; ++k) any = (adv[k] = act[k] && env[k].wants_advance(p_out)) || any;
-        if (any)
-          for (int k = 0; k < W; ++k) env[k].advance(adv[k]);
+        bool all = true;
+        for (int k = 0; k < W; ++k) env[k].step_to(p_out);
         for (int k = 0; k < W; ++k) all = all && (env[k].final_at(p_out, x_next));
         if (!all) break;
         for (int k = 0; k < W; ++k)
@@ -181,7 +174,7 @@ struct Model {
             tag[k] = (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u);
             if (!use[k]) dy = dz = 0;
           } else {
-            tag[k] = w;
+            tag[k] = w & 0xFFFFFu;
             dy = y - (int)(w >> 10), dz = 64 * c + k - (int)(w & 1023u);
           }
           f[k] = act[k] ? dy * dy + dz * dz : 0;
@@ -196,7 +189,7 @@ struct Model {
           for (int k = 0; k < W; ++k) env[k].pop(want[k]);
         }
         for (int k = 0; k < W; ++k) {
-          env[k].template place<false>(use[k], x, f[k], tag[k], key[k], nx, p_out);
+          env[k].place(use[k], x, f[k], ((uint32_t)x << 20) | tag[k], key[k], nx, p_out);
           if (env[k].overflow) return false;
           if (act[k] && env[k].depth() > max_depth) max_depth = env[k].depth();
         }
@@ -232,11 +225,11 @@ int run_tier(Model &m, uint32_t *out, std::vector<int> &items_a, std::vector<int
   const int nzc = (m.nz + 63) / 64;
   std::vector<int> oa, ob;
   for (int it : items_a)
-    if (!m.plane_item<S>(it / nzc, it % nzc)) oa.push_back(it);
+    if (!(m.wide ? m.plane_item<S, true>(it / nzc, it % nzc) : m.plane_item<S, false>(it / nzc, it % nzc))) oa.push_back(it);
   items_a.swap(oa);
   if (!items_a.empty()) return 1;  // pass B needs every plane
   for (int it : items_b)
-    if (!m.column_item<S>(it / nzc, it % nzc, out)) ob.push_back(it);
+    if (!(m.wide ? m.column_item<S, true>(it / nzc, it % nzc, out) : m.column_item<S, false>(it / nzc, it % nzc, out))) ob.push_back(it);
   items_b.swap(ob);
   return items_b.empty() ? 0 : 1;
 }

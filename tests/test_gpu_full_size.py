@@ -320,6 +320,52 @@ def test_bulk_engine_every_ring_tier(hip_lib, dims):
     m.close()
 
 
+def test_bulk_engine_scene_starts_to_spill_while_the_overflow_tiers_are_off(hip_lib):
+    """The overflow tiers of the transform are only launched when the previous update spilled into them (an empty tier
+    costs a launch).  A scatter scene needs none; then a wall arrives, the 16-entry rings spill with the tiers off -- the
+    update notices from its own spill counters, runs again with the tiers on, and must still be the exact transform
+    (scipy's EDT of the same occupancy); the update after that has them on from the start."""
+    from scipy import ndimage
+    import fiesta_amd
+    dims, res = (160, 144, 128), 0.1
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, tuple(d * res for d in dims), update_engine="bulk")
+    assert m.grid_size == dims
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    m.SetOccupancyBox((0, 0, 0), tuple(d - 1 for d in dims), 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    rng = np.random.RandomState(3)
+    S = np.unique((rng.rand(4000, 3) * dims).astype(np.int32), axis=0)   # dense scatter: every deque stays shallow
+
+    def exact(occ):
+        idx = ndimage.distance_transform_edt(occ == 0, return_distances=False, return_indices=True)
+        g = np.meshgrid(*[np.arange(d) for d in dims], indexing="ij", sparse=True)
+        return sum((idx[k] - g[k]) ** 2 for k in range(3)).astype(np.int64)
+
+    def check(st):
+        f = m.download_field(("d2", "occ"))
+        assert np.array_equal(f["d2"].reshape(dims).astype(np.int64), exact(f["occ"].reshape(dims)))
+    for k in range(2):   # two scatter updates: the second one runs with the tiers switched off
+        _cycles(m, S[k::2], [], 3)
+        st = m.UpdateESDF()
+        assert st["bulk"] and sum(st["ft_overflow"]) == 0, st
+        check(st)
+    assert st["relax_launches"] == 3                     # rows + pass A + pass B, no empty tier launches
+    for _ in range(6):                                   # the scatter goes, a wall comes: along x every position of a
+        m.SetOccupancyBox((0, 0, 0), (dims[0] - 1, 0, dims[2] - 1), 1)   # column is a different winner, deques as deep
+        m.SetOccupancy(S, 0, want_ret=False)                              # as the column is far from the wall
+        m.UpdateOccupancy(True)
+    st = m.UpdateESDF()
+    assert st["bulk"] and sum(st["ft_overflow"]) > 0 and st["relax_launches"] > 3, st
+    check(st)
+    _cycles(m, (rng.rand(50, 3) * dims).astype(np.int32), [], 3)
+    st = m.UpdateESDF()
+    assert st["bulk"] and sum(st["ft_overflow"]) > 0, st
+    check(st)
+    m.close()
+
+
 def test_bulk_engine_wide_ids_reach_boundary_inside_a_wave(hip_lib):
     """A map beyond 1024 voxels per axis stores ids modulo 1024 with a reach of 512 voxels.  One obstacle at z = 10: the
     column group z = 512..575 holds lanes that still see it (z <= 521) next to lanes for which every site is out of
