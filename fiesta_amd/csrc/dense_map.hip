@@ -1032,9 +1032,12 @@ void DenseMap::enable_distance_tracking() {
   track_ = true;
 }
 
-void DenseMap::reset_stats_counters() {
-  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INVALIDATED], 0, (C_COUNT - C_INVALIDATED) * sizeof(unsigned long long),
-                                  stream_));
+// ONE memset: the statistics, the transform's spill counters and -- at the start of an update (lists) -- the tile-list counters
+void DenseMap::reset_stats_counters(bool lists) {
+  static_assert(C_LIST1 == C_LIST0 + 1 && C_INVALIDATED == C_LIST1 + 1 && C_FT_MAXD2 < C_COUNT, "counter layout");
+  const int first = lists ? C_LIST0 : C_INVALIDATED;
+  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[first], 0, (C_COUNT - first) * sizeof(unsigned long long), stream_));
+  ft_counters_clean_ = true;
 }
 
 void DenseMap::collect_stats(fiesta_hip_stats *st) {
@@ -1211,7 +1214,6 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   a.rowlist = ft_rowlist_.p;
   a.rowcnt = ft_rowcnt_.p;
   a.planemask = reinterpret_cast<uint32_t *>(ft_rowcnt_.p + a.nx);
-  FIESTA_HIP_CHECK(hipMemsetAsync(a.planemask, 0, 64 * sizeof(uint32_t), stream_));
   a.inter = ft_inter_.p;
   // a shard's transform lands in a side buffer first: it only replaces the field once every shard has confirmed that
   // its margin sufficed (bulk_commit); if not, the frontier rounds take over from the untouched field
@@ -1219,7 +1221,9 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   a.coc = g.sharded ? ft_out_.p : coc_;
   const bool want_max = track_ || open_side;
   a.maxd2 = want_max ? &counters_[C_FT_MAXD2] : nullptr;
-  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
+  if (!ft_counters_clean_)  // (a second run within one update: the spill counters of the first are still there)
+    FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
+  ft_counters_clean_ = false;
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[0], stream_));
   hipLaunchKernelGGL(k_ft_rows, dim3(a.nx), dim3(256), 0, stream_, a);
   FIESTA_HIP_CHECK(hipGetLastError());
@@ -1458,8 +1462,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   ++epoch_;
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
-  reset_stats_counters();
-  zero_counter(C_LIST0);
+  reset_stats_counters(/*lists=*/true);
   // Engine choice.  The bulk transform costs one fixed sweep over the grid; the frontier rounds cost in proportion to
   // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).
   if (!seed_only && !g_.sharded && bulk_eligible(ni, nd)) {

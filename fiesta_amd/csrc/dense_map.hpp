@@ -174,7 +174,7 @@ class DenseMap {
   bool run_bulk(fiesta_hip_stats *st, int margin, bool *exact);
   bool bulk_spilled_untiered();
   void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0);
-  void reset_stats_counters();
+  void reset_stats_counters(bool lists = false);
   void enable_distance_tracking();
   void collect_stats(fiesta_hip_stats *st);
 
@@ -211,6 +211,7 @@ class DenseMap {
   int ft_s0_ = 16;            // ring size of the bulk path's first tier: 16, or 32 once a scene needed deeper deques
   bool ft_s0_fixed_ = false;  // (FIESTA_HIP_FT_S0 pins it)
   double ft_last_ms_ = 0;      // kernel time of the last bulk update (the engine choice's idea of this scene's sweep)
+  bool ft_counters_clean_ = false;  // reset_stats_counters() ran and no transform has used the spill counters since
   bool ft_tiers_off_ = false;  // the last run_bulk skipped the overflow tiers of a pass
   int ft_tier_hold_[2] = {1, 1};  // updates for which pass A / pass B still launch their overflow tiers
   int64_t ft_last_ovf_[6] = {1, 1, 1, 1, 1, 1};  // ring spills of the last bulk update per tier (sizes the overflow tiers' grids)

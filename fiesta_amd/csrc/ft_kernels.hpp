@@ -33,7 +33,7 @@ struct FtArgs {
   int sx0, sy0, sw0, sny, snzw;
   uint16_t *rowlist;         // [nx][ny]: non-empty rows of plane x, ascending
   int32_t *rowcnt;           // [nx]
-  uint32_t *planemask;       // [64]: bit x = plane x holds a site (zeroed before k_ft_rows)
+  uint32_t *planemask;       // unused (r02: a bit mask built with atomics, zeroed by a memset per update); pass B reads rowcnt
   uint32_t *inter;           // [nx][ny][nz]: pass A result, y' << 10 | z' (WIDE: << 11), region coordinates
   vox_t *coc;                // output array (the map's voxel words) with extents (., ony, onz); region voxel (x,y,z) is
   int ox0, oy0, oz0;         // output voxel (x - ox0, y - oy0, z - oz0), written iff inside [0,onx) x [0,ony) x [0,onz)
@@ -130,7 +130,6 @@ __global__ __launch_bounds__(256) void k_ft_rows(FtArgs a) {
   }
   if (tid == 0) {
     a.rowcnt[x] = base;
-    if (base) atomicOr(&a.planemask[x >> 5], 1u << (x & 31));
   }
 }
 
@@ -275,7 +274,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
   const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
   uint32_t acc_maxd2 = 0;
   // which planes hold any site: bit x of the 2048-bit mask, word w in lane w
-  const uint32_t pm = a.planemask[lane];
+  // (lane w holds planes 32 w .. 32 w + 31, built from the planes' row counts: no mask to zero and fill with atomics)
+  uint32_t pm = 0;
+  if (32 * lane < a.nx) {  // (rowcnt is padded by 64 entries: eight 16-byte loads stay inside it)
+    const int4 *rc = reinterpret_cast<const int4 *>(a.rowcnt + 32 * lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int4 v = rc[q];
+      const int x = 32 * lane + 4 * q;
+      pm |= ((x < a.nx && v.x) ? 1u : 0u) << (4 * q) | ((x + 1 < a.nx && v.y) ? 2u : 0u) << (4 * q) |
+            ((x + 2 < a.nx && v.z) ? 4u : 0u) << (4 * q) | ((x + 3 < a.nx && v.w) ? 8u : 0u) << (4 * q);
+    }
+  }
   auto plane_has = [&](const int x) -> bool { return (__builtin_amdgcn_readlane(pm, (x >> 5) & 63) >> (x & 31)) & 1u; };
   for (uint32_t it = blockIdx.x * WAVES + wave; it < n; it += gridDim.x * WAVES) {
     const uint32_t id = a.items ? a.items[it / SUB] : it / SUB;

@@ -1,11 +1,7 @@
-set -u
-R=gpurun_out/r03d
-mkdir -p $R
-( time python -m pytest tests/test_gpu_full_size.py -m gpu -q --timeout 900 -k "tier or spill" 2>&1 | grep -v new_size | tail -5 ) 2>&1
-python bench.py --delta-sweep --steps 3 2>&1 | grep metric > $R/delta_sweep.json
+python bench.py --no-cpu-baseline 2>&1 | grep metric > /tmp/b.json
 python - <<'PY'
 import json
-d=json.load(open("gpurun_out/r03d/delta_sweep.json")); print("sweep worst", d["value"])
-for e in d['table']:
-    if e['engine']!='rounds': print(e['scene'], e['engine'], e['delta'], round(e['update_esdf_p50_ms'],3))
+d=json.load(open('/tmp/b.json'))
+print("frac", d["roofline"]["frac"], "ms/step", d["ms_per_step"], "esdf p50", d["update_esdf_p50_ms"], "dev", d["update_esdf_device_p50_ms"], d["roofline"]["phases_p50_ms"], "verify", d["verify"]["mismatches"])
 PY
+python -m pytest tests/test_gpu_full_size.py tests/test_gpu_sharded.py -m gpu -q -x --timeout 900 2>&1 | grep -v new_size | tail -3
