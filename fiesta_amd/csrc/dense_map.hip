@@ -1329,6 +1329,14 @@ bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
   if (!(g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1)) return false;
   const long long owned = (long long)(g.ox1 - g.ox0 + 1) * (g.oy1 - g.oy0 + 1) * (g.oz1 - g.oz0 + 1);
   if ((long long)h_counters_[C_OBSERVED] != owned) return false;
+  // An update that ran under a partial window left the voxels outside it as they were (inserts never reach them, the
+  // orphans of a delete keep what one pull gave them, src/ESDFMap.cpp:351,378): from then on the reference's field is a
+  // function of its history, not the transform of the occupied set -- until the map holds no obstacle again.
+  if (win_dirty_) {
+    const long long before = (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd;
+    if (!g.sharded && before <= 0) win_dirty_ = false;
+  }
+  if (win_dirty_) return false;
   if (stale_inf_) {  // re-validate: does any observed voxel still wait for its first wave?
     zero_counter(C_SCRATCH);
     hipLaunchKernelGGL(k_count_stale, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
@@ -1463,6 +1471,8 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
   reset_stats_counters(/*lists=*/true);
+  const bool full_window = g_.wx0 <= 0 && g_.wy0 <= 0 && g_.wz0 <= 0 && g_.wx1 >= g_.nx - 1 && g_.wy1 >= g_.ny - 1 && g_.wz1 >= g_.nz - 1;
+  if (!full_window) win_dirty_ = true;  // (see bulk_eligible)
   // Engine choice.  The bulk transform costs one fixed sweep over the grid; the frontier rounds cost in proportion to
   // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).
   if (!seed_only && !g_.sharded && bulk_eligible(ni, nd)) {
@@ -1763,6 +1773,7 @@ void DenseMap::snapshot_save(int slot) {
   }
   s.g = g_;
   s.stale_inf = stale_inf_;
+  s.win_dirty = win_dirty_;
   s.valid = true;
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -1798,6 +1809,7 @@ void DenseMap::snapshot_restore(int slot) {
   touched_upper_ = (int64_t)nt;
   g_ = s.g;
   stale_inf_ = s.stale_inf;
+  win_dirty_ = s.win_dirty;
   host_counts_valid_ = false;
   if (track_) {  // the snapshot may predate the tracking: recompute the distance bound for the restored field
     zero_counter(C_MAXD2);
@@ -1824,7 +1836,7 @@ void DenseMap::checkpoint(const char *path, bool write) {
   f.host(&pp, sizeof(pp));
   Geom g = g_;
   f.host(&g, sizeof(g));  // (only the update ranges are taken from the file; the rest must equal this map's)
-  uint32_t flags[4] = {stale_inf_ ? 1u : 0u, gocc_ ? 1u : 0u, 0u, 0u};
+  uint32_t flags[4] = {stale_inf_ ? 1u : 0u, gocc_ ? 1u : 0u, win_dirty_ ? 1u : 0u, 0u};
   f.host(flags, sizeof(flags));
   if ((flags[1] != 0) != (gocc_ != nullptr)) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: sharded / unsharded mismatch");
   const size_t nt = c[C_TOUCHED], ni = c[C_INSERT], nd = c[C_DELETE];
@@ -1868,6 +1880,7 @@ void DenseMap::checkpoint(const char *path, bool write) {
   g_.wx0 = g.wx0, g_.wy0 = g.wy0, g_.wz0 = g.wz0, g_.wx1 = g.wx1, g_.wy1 = g.wy1, g_.wz1 = g.wz1;  // (the ranges only)
   g_.px0 = g.px0, g_.py0 = g.py0, g_.pz0 = g.pz0, g_.px1 = g.px1, g_.py1 = g.py1, g_.pz1 = g.pz1;
   stale_inf_ = flags[0] != 0;
+  win_dirty_ = flags[2] != 0;
   host_counts_valid_ = false;
   if (track_) {
     zero_counter(C_MAXD2);

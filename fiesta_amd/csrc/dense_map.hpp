@@ -72,6 +72,7 @@ struct Snapshot {
   unsigned long long counters[C_COUNT];
   Geom g;
   bool stale_inf = false;
+  bool win_dirty = false;
   bool valid = false;
 };
 
@@ -208,6 +209,7 @@ class DenseMap {
   // (the reference never queues it), so the field is no longer the transform of the occupied set and the bulk path is
   // off until a scan finds no such voxel left (k_count_stale) or the map holds no obstacle.
   bool stale_inf_ = false;
+  bool win_dirty_ = false;  // an update ran under a partial window while obstacles existed (see bulk_eligible)
   int ft_s0_ = 16;            // ring size of the bulk path's first tier: 16, or 32 once a scene needed deeper deques
   bool ft_s0_fixed_ = false;  // (FIESTA_HIP_FT_S0 pins it)
   double ft_last_ms_ = 0;      // kernel time of the last bulk update (the engine choice's idea of this scene's sweep)
