@@ -374,6 +374,12 @@ int fiesta_hip_download_counts(fiesta_hip_map *m, int32_t *num_hit, int32_t *num
       m->hash->download_counts(num_hit, num_miss);
   });
 }
+int fiesta_hip_count_no_obstacle(fiesta_hip_map *m, int64_t *n_out) {
+  return guarded([&] {
+    need(m && n_out, "null argument");
+    *n_out = dense(m, "count_no_obstacle").count_no_obstacle();
+  });
+}
 int fiesta_hip_get_occupied_voxels(fiesta_hip_map *m, int32_t *vox, int64_t capacity, int64_t *n_out) {
   return guarded([&] {
     need(n_out != nullptr && capacity >= 0, "bad argument");

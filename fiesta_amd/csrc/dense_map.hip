@@ -694,7 +694,8 @@ __global__ void k_count_stale(Geom g, const vox_t *coc, unsigned long long *out)
   unsigned long long local = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * blockDim.x) {
     const vox_t w = coc[i];
-    local += (w != kUnobserved) && (w & kNoCoc);
+    const int z = (int)(i % g.nz), y = (int)((i / g.nz) % g.ny), x = (int)(i / ((int64_t)g.nz * g.ny));
+    local += (w != kUnobserved) && (w & kNoCoc) && g.owned(x, y, z);
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
@@ -1650,6 +1651,17 @@ void DenseMap::download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *l
   if (occ) FIESTA_HIP_CHECK(hipMemcpyAsync(occ, docc, n, hipMemcpyDeviceToHost, stream_));
   if (logodds) FIESTA_HIP_CHECK(hipMemcpyAsync(logodds, logodds_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// Observed voxels of the owned box that hold no obstacle (distance +10000): freshly observed ones that wait for a wave,
+// everything while the map is empty -- and, on grids beyond 1024 voxels per axis, whatever lies farther than the 512
+// voxels an id reaches from every obstacle (common.hpp: kD2Cap).
+int64_t DenseMap::count_no_obstacle() {
+  use_device();
+  zero_counter(C_SCRATCH);
+  hipLaunchKernelGGL(k_count_stale, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, &counters_[C_SCRATCH]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  return (int64_t)read_counter(C_SCRATCH);
 }
 
 int64_t DenseMap::occupied_voxels(int32_t *vox, int64_t cap) {

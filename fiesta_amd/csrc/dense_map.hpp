@@ -115,6 +115,7 @@ class DenseMap {
   void download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds);
   void download_counts(int32_t *num_hit, int32_t *num_miss);
   int64_t occupied_voxels(int32_t *vox, int64_t cap);  // returns the total count (may exceed cap)
+  int64_t count_no_obstacle();
   void slice_distances(int z_vox, double *out);        // nx * ny doubles, x-major
   // GetPointCloud / GetSliceMarker as arrays; both return the total count (may exceed cap), order unspecified
   void checkpoint(const char *path, bool write);  // raw dump / load of the whole state (checkpoint.hpp)

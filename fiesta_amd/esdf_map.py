@@ -248,6 +248,13 @@ class ESDFMap:
             check(self._lib.fiesta_hip_get_occupied_voxels(self._h, _p(out), n.value, C.byref(n)))
         return out
 
+    def count_no_obstacle(self) -> int:
+        """Observed voxels whose distance reads +10000 (on grids beyond 1024 per axis this includes everything farther than
+        512 voxels from every obstacle: the reach of a stored id, include/fiesta_hip.h)."""
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_count_no_obstacle(self._h, C.byref(n)))
+        return n.value
+
     def GetSlice(self, z_vox: int) -> np.ndarray:
         """Distances of the plane z = z_vox as an (nx, ny) array (ESDFMap::GetSliceMarker, src/ESDFMap.cpp:639-699)."""
         out = np.empty(self.grid_size[:2], np.float64)

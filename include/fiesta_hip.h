@@ -245,6 +245,12 @@ int fiesta_hip_load(fiesta_hip_map *m, const char *path);
  * *n_out is the total (call with vox NULL / capacity 0 to size the buffer). Order is unspecified.
  * get_slice: GetDistance(Vector3i) for every (x, y) of the plane z = z_vox, nx * ny doubles, x-major. */
 int fiesta_hip_get_occupied_voxels(fiesta_hip_map *m, int32_t *vox, int64_t capacity, int64_t *n_out);
+/* Observed voxels (of the owned box of a shard) whose distance reads +10000, "no obstacle" (src/ESDFMap.cpp:246-249,
+ * 306, 328): voxels observed late that no wave has reached yet, everything while the map holds no obstacle -- and, on a
+ * grid beyond 1024 voxels per axis ONLY, voxels farther than 512 voxels from every obstacle: the reach of a stored id there
+ * (the reference's closest_obstacle_ is a full Vector3i, include/ESDFMap.h:90, but it cannot hold such a grid).  A
+ * deployment on a large grid watches this number: it is the count of distances truncated to "none".  Array maps only. */
+int fiesta_hip_count_no_obstacle(fiesta_hip_map *m, int64_t *n_out);
 int fiesta_hip_get_slice(fiesta_hip_map *m, int32_t z_vox, double *out);
 /* The two getters themselves, filtered and converted on the device exactly as the reference fills its messages (array
  * and hash-block maps; the C++ class include/fiesta/ESDFMap.h fills any message type with the reference's field names):

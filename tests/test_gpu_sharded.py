@@ -309,6 +309,36 @@ def test_global_extent_2048_ids_beyond_30_bits(hip_lib, n_shards):
     sm.close()
 
 
+@pytest.mark.parametrize("n_shards", [1, 2])
+def test_single_obstacle_in_a_2048_long_map_and_the_count_of_truncated_distances(hip_lib, engine, n_shards):
+    """SURVEY.md 8e's adversarial case at config 5's axis length: ONE obstacle in an otherwise empty, fully observed
+    2048 x 64 x 64 map (unsharded and as 2 shards of 1024): its wave has to cross the cut.  Within the reach of an id
+    (512 voxels, common.hpp) every distance equals the closed form -- what the reference would hold; beyond it a voxel
+    reads "no obstacle", and fiesta_hip_count_no_obstacle reports exactly how many do (the deviation is loud, not silent)."""
+    from fiesta_amd.sharded import ShardedESDFMap
+    gs, res = (2048, 64, 64), 0.1
+    sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards)
+    sm.SetParameters(*P_DEFAULT)
+    sm.SetOriginalRange()
+    sm.SetOccupancyBox((0, 0, 0), tuple(np.array(gs) - 1), 0)
+    sm.UpdateOccupancy(True)
+    sm.UpdateESDF()
+    assert sum(sh.count_no_obstacle() for sh in sm.shards.values()) == gs[0] * gs[1] * gs[2]   # an empty map: everything
+    obst = np.array([[900, 30, 31]], np.int32)               # 124 voxels from the cut at x = 1024
+    for _ in range(3):
+        sm.SetOccupancy(obst, 1)
+        sm.UpdateOccupancy(True)
+    sm.UpdateESDF()
+    f = sm.assemble(("d2",))["d2"].reshape(gs).astype(np.int64)
+    x, y, z = np.meshgrid(*[np.arange(d) for d in gs], indexing="ij", sparse=True)
+    e = (x - 900) ** 2 + (y - 30) ** 2 + (z - 31) ** 2
+    want = np.where(e < (1 << 18), e, D2_INF)
+    assert np.array_equal(f, want)
+    assert (want[1024:1400] < D2_INF).all() and (want[1500:] == D2_INF).all()               # across the cut, then out of reach
+    assert sum(sh.count_no_obstacle() for sh in sm.shards.values()) == int((want == D2_INF).sum())
+    sm.close()
+
+
 def test_wrap_ids_reach_512_voxels(hip_lib):
     """On a grid larger than 1024 the reach of an id is 512 voxels (d^2 < 2^18): a voxel farther than that from every
     obstacle reads "no obstacle" (documented limit; the reference cannot hold such a grid)."""
