@@ -1218,8 +1218,11 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   a.inter = ft_inter_.p;
   // a shard's transform lands in a side buffer first: it only replaces the field once every shard has confirmed that
   // its margin sufficed (bulk_commit); if not, the frontier rounds take over from the untouched field
-  if (g.sharded) ft_out_.ensure((size_t)g.n, stream_);
-  a.coc = g.sharded ? ft_out_.p : coc_;
+  // ... unless the margin test cannot fail: a region that reaches the global boundary on every side (a single shard, or
+  // margins grown to the whole grid) holds every obstacle there is -- the result is final and goes in place
+  ft_in_place_ = !g.sharded || !open_side;
+  if (!ft_in_place_) ft_out_.ensure((size_t)g.n, stream_);
+  a.coc = ft_in_place_ ? coc_ : ft_out_.p;
   const bool want_max = track_ || open_side;
   a.maxd2 = want_max ? &counters_[C_FT_MAXD2] : nullptr;
   if (!ft_counters_clean_)  // (a second run within one update: the spill counters of the first are still there)
@@ -1430,7 +1433,7 @@ bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
 }
 void DenseMap::bulk_commit(fiesta_hip_stats *st) {
   use_device();
-  if (g_.sharded) FIESTA_HIP_CHECK(hipMemcpyAsync(coc_, ft_out_.p, (size_t)g_.n * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
+  if (!ft_in_place_) FIESTA_HIP_CHECK(hipMemcpyAsync(coc_, ft_out_.p, (size_t)g_.n * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
   bulk_finish(st, std::chrono::steady_clock::now());
 }
 void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long long *nocc, bool *eligible) {
@@ -2103,6 +2106,33 @@ void DenseMap::halo_apply_sparse(const uint32_t *entries_dev, int64_t n, unsigne
                      tile_flag_[0], tile_list_[0], &counters_[C_LIST0], changed_dev);
   FIESTA_HIP_CHECK(hipGetLastError());
 }
+
+// The scratch buffers of a sharded bulk transform with this margin, allocated now (group creation) instead of inside the
+// first update (measured: 250 ms of hipMalloc on the critical path of the first UpdateESDF at 1024^3).
+void DenseMap::bulk_reserve(int margin) {
+  use_device();
+  const Geom &g = g_;
+  if (!g.sharded) return;
+  const int l0[3] = {g.gx0, g.gy0, g.gz0}, ln[3] = {g.nx, g.ny, g.nz}, G[3] = {g.GX, g.GY, g.GZ};
+  int64_t ext[3];
+  bool open_side = false;
+  for (int k = 0; k < 3; ++k) {
+    const int lo = std::max(0, l0[k] - margin), hi = std::min(G[k] - 1, l0[k] + ln[k] - 1 + margin + (k == 2 ? 31 : 0));
+    ext[k] = hi - lo + 1;
+    open_side = open_side || lo > 0 || hi < G[k] - 1;
+    if (ext[k] > 2048) return;
+  }
+  const int64_t nzc = (ext[2] + 63) / 64;
+  ft_inter_.ensure((size_t)(ext[0] * ext[1] * ext[2]), stream_);
+  ft_rowlist_.ensure((size_t)(ext[0] * ext[1]), stream_);
+  ft_rowcnt_.ensure((size_t)ext[0] + 64, stream_);
+  ft_ovf_.ensure((size_t)std::max(ext[0] * nzc, ext[1] * nzc) * 6, stream_);
+  if (open_side) ft_out_.ensure((size_t)g.n, stream_);
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// device address of a counter (the shard group assembles its per-sweep row on the device)
+const unsigned long long *DenseMap::counter_dev(int which) const { return &counters_[which]; }
 
 int64_t DenseMap::pending_tiles() {
   use_device();

@@ -132,6 +132,8 @@ class DenseMap {
                  uint32_t *entries_dev, unsigned long long *count_dev);
   void halo_apply_sparse(const uint32_t *entries_dev, int64_t n, unsigned long long *changed_dev);
   int64_t pending_tiles();
+  void bulk_reserve(int margin);
+  const unsigned long long *counter_dev(int which) const;
   int64_t export_transitions(uint32_t *out_dev, int64_t cap);
   void apply_transitions(const uint32_t *ent_dev, int64_t n);
 
@@ -214,6 +216,7 @@ class DenseMap {
   int ft_s0_ = 16;            // ring size of the bulk path's first tier: 16, or 32 once a scene needed deeper deques
   bool ft_s0_fixed_ = false;  // (FIESTA_HIP_FT_S0 pins it)
   double ft_last_ms_ = 0;      // kernel time of the last bulk update (the engine choice's idea of this scene's sweep)
+  bool ft_in_place_ = true;   // the last transform wrote the field itself (no side buffer: its result could not be inexact)
   bool ft_counters_clean_ = false;  // reset_stats_counters() ran and no transform has used the spill counters since
   bool ft_tiers_off_ = false;  // the last run_bulk skipped the overflow tiers of a pass
   int ft_tier_hold_[2] = {1, 1};  // updates for which pass A / pass B still launch their overflow tiers

@@ -242,6 +242,7 @@ ShardGroup::ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<in
     }
     L->counts.ensure(kMaxLinks + 2, s);
     FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+    L->map->bulk_reserve(margin_);  // (the transform's scratch: not inside the first update)
     locals_.push_back(std::move(L));
   }
   FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_table_, (size_t)world_ * kRow * sizeof(long long)));
@@ -268,7 +269,7 @@ ShardGroup::~ShardGroup() {
 // Every shard contributes one row of kRow numbers; afterwards h_table_[rank * kRow + j] holds them all on the host.
 // (RCCL: ONE small all-gather + one stream synchronisation; local: the rows are simply written in place.)
 void ShardGroup::gather_rows(const std::vector<std::vector<long long>> &rows) {
-  if (comm_) {
+  if (comm_ && world_ > 1) {  // (a group of one has nobody to ask: no collective, no synchronisation)
     Local &L = *locals_[0];
     hipStream_t s = L.map->stream();
     memcpy(&h_table_[(size_t)L.rank * kRow], rows[0].data(), kRow * sizeof(long long));
@@ -290,6 +291,13 @@ ShardGroup::Local *ShardGroup::find_local(int rank) {
 
 bool ShardGroup::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
   // 1. local fusion; 2. every shard's transitions to every shard
+  if (world_ == 1) {  // nobody to tell: the shard's own fusion already keeps its replica of the global bitmap
+    int64_t ni = 0, nd = 0;
+    const bool any = locals_[0]->map->update_occupancy(global_map, &ni, &nd);
+    if (n_ins) *n_ins = ni;
+    if (n_del) *n_del = nd;
+    return any;
+  }
   std::vector<std::vector<long long>> rows(locals_.size(), std::vector<long long>(kRow, 0));
   for (size_t i = 0; i < locals_.size(); ++i) {
     Local &L = *locals_[i];
@@ -435,15 +443,30 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
     }
     // ---- counts (the receivers' message sizes) + pending tiles: one gather, one host read
     std::vector<std::vector<long long>> rows(locals_.size(), std::vector<long long>(kRow, 0));
-    for (size_t i = 0; i < locals_.size(); ++i) {
-      Local &L = *locals_[i];
-      unsigned long long h[kMaxLinks];
-      FIESTA_HIP_CHECK(hipMemcpyAsync(h, L.counts.p, kMaxLinks * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.map->stream()));
-      FIESTA_HIP_CHECK(hipStreamSynchronize(L.map->stream()));
-      for (size_t k = 0; k < L.links.size(); ++k) rows[i][k] = (long long)h[k];
-      rows[i][kMaxLinks] = L.map->pending_tiles();
+    if (comm_ && world_ > 1) {
+      // the row is assembled ON THE DEVICE (entry counts + the pending-tile counter) and goes straight into the
+      // all-gather: ONE synchronisation per sweep (r02: one for the counts, one for the tiles, one for the gather)
+      Local &L = *locals_[0];
+      hipStream_t s = L.map->stream();
+      static_assert(sizeof(long long) == sizeof(unsigned long long), "row layout");
+      FIESTA_HIP_CHECK(hipMemsetAsync(d_row_, 0, kRow * sizeof(long long), s));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(d_row_, L.counts.p, L.links.size() * sizeof(long long), hipMemcpyDeviceToDevice, s));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(d_row_ + kMaxLinks, L.map->counter_dev(C_LIST0), sizeof(long long), hipMemcpyDeviceToDevice, s));
+      FIESTA_RCCL_CHECK(Rccl::get().AllGather(d_row_, d_table_, kRow, ncclInt64, (ncclComm_t)comm_, s));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(h_table_, d_table_, (size_t)world_ * kRow * sizeof(long long), hipMemcpyDeviceToHost, s));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+      for (size_t i = 0; i < locals_.size(); ++i) {  // local transport: one copy + one synchronisation per shard
+        Local &L = *locals_[i];
+        unsigned long long h[kMaxLinks + 1];
+        FIESTA_HIP_CHECK(hipMemcpyAsync(h, L.counts.p, kMaxLinks * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.map->stream()));
+        FIESTA_HIP_CHECK(hipMemcpyAsync(&h[kMaxLinks], L.map->counter_dev(C_LIST0), sizeof(unsigned long long), hipMemcpyDeviceToHost, L.map->stream()));
+        FIESTA_HIP_CHECK(hipStreamSynchronize(L.map->stream()));
+        for (size_t k = 0; k < L.links.size(); ++k) rows[i][k] = (long long)h[k];
+        rows[i][kMaxLinks] = (long long)h[kMaxLinks];
+      }
+      gather_rows(rows);
     }
-    gather_rows(rows);
     long long any = 0;
     for (int r = 0; r < world_; ++r)
       for (int j = 0; j <= kMaxLinks; ++j) any += h_table_[(size_t)r * kRow + j];
