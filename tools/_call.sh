@@ -1,10 +1,4 @@
 set -u
-python -m pytest tests/test_gpu_sharded.py -m gpu -q -x --timeout 900 2>&1 | grep -v new_size | tail -4
-for mode in "" "--force-sharded"; do
-python bench.py --no-cpu-baseline $mode 2>&1 | grep metric > /tmp/b.json
-python - <<PY
-import json
-d=json.load(open('/tmp/b.json'))
-print("mode [$mode] frac", round(d["roofline"]["frac"],4), "ms/step", round(d["ms_per_step"],4), "esdf p50", round(d["update_esdf_p50_ms"],4), "dev", round(d["update_esdf_device_p50_ms"],4), "verify", d["verify"]["mismatches"], d["verify"]["ranks_seen_by_rccl"])
-PY
-done
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03e/stats2 -o bench -- python bench.py --no-cpu-baseline --steps 5 --verify-samples 0 > /tmp/p.log 2>&1
+grep -E "k_ft_" gpurun_out/r03e/stats2/bench_kernel_stats.csv | cut -c1-120
