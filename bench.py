@@ -506,8 +506,8 @@ def main():
 
     if not torch.cuda.is_available() or fiesta_amd.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if args.backend != "nccl":
-        local_rank = 0  # gloo smoke test: every rank uses the one visible GPU
+    if args.backend != "nccl" or os.environ.get("FIESTA_BENCH_ALL_RANKS_ON_GPU0"):
+        local_rank = 0  # smoke tests: every rank uses the one visible GPU (with nccl: RCCL refuses)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_sharded:

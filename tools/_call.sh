@@ -1,4 +1,6 @@
 set -u
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03e/stats2 -o bench -- python bench.py --no-cpu-baseline --steps 5 --verify-samples 0 > /tmp/p.log 2>&1
-grep -E "k_ft_" gpurun_out/r03e/stats2/bench_kernel_stats.csv | cut -c1-120
+mkdir -p gpurun_out/r03e
+export FIESTA_BENCH_ALL_RANKS_ON_GPU0=1
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --grid 128 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03e/two_ranks_one_gpu.log 2>&1
+echo rc=$?
+grep -iE "error|duplicate|invalid|metric" gpurun_out/r03e/two_ranks_one_gpu.log | cut -c1-300 | head -12
