@@ -116,45 +116,58 @@ __device__ inline int64_t vaddr(const int32_t *dir, int x, int y, int z) {
 }
 }  // namespace paged
 
-// flags: bit0 valid ray, bit1 casts (winner of its end-point voxel), bit2 traversal overflow
-// PAGED: a voxel's slot in the page pool is only known once its page exists, so this pass stores packed WINDOW
-// coordinates instead of slots (end_idx: coords | occ << 30), marks the tiles it touches (the reference's Vox2Idx
-// allocates on every SetOccupancy, in or out of the update window, src/ESDFMap.cpp:418-421,732-765) and leaves the
-// counting and stamping of the end points to k_ray_translate, after the pages have been allocated.
-template <bool PAGED>
-__global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, int stride, uint32_t *entries,
-                              int32_t *end_idx, int32_t *m_count, uint8_t *flags, uint32_t *stamp_occ,
-                              uint32_t tagged, unsigned long long *cnt, uint32_t *touched,
-                              unsigned long long *counters, int *err, uint32_t *need) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  flags[i] = 0;
-  m_count[i] = 0;
-  end_idx[i] = -1;
+// The end point of cloud point i as RaycastProcess computes it (include/Fiesta.h:202-218): transformed, clipped to
+// max_ray_length (then counted FREE). false: the point is skipped (NaN, or closer than min_ray_length).
+__device__ inline bool ray_end_point(const RayArgs &ra, const float *pts, int64_t i, double *q, int &occ) {
   const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
-  if (isnan(px) || isnan(py) || isnan(pz)) return;  // include/Fiesta.h:202
+  if (isnan(px) || isnan(py) || isnan(pz)) return false;  // include/Fiesta.h:202
   double h[4];
   for (int r = 0; r < 4; ++r) h[r] = ra.T[4 * r] * px + ra.T[4 * r + 1] * py + ra.T[4 * r + 2] * pz + ra.T[4 * r + 3] * 1.0;
-  double q[3] = {h[0] / h[3], h[1] / h[3], h[2] / h[3]};  // :204-205
-  double d0 = q[0] - ra.o[0], d1 = q[1] - ra.o[1], d2 = q[2] - ra.o[2];
-  double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-  if (len < ra.minr) return;  // :209
-  int occ = 1;
+  q[0] = h[0] / h[3], q[1] = h[1] / h[3], q[2] = h[2] / h[3];  // :204-205
+  const double d0 = q[0] - ra.o[0], d1 = q[1] - ra.o[1], d2 = q[2] - ra.o[2];
+  const double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  if (len < ra.minr) return false;  // :209
+  occ = 1;
   if (len > ra.maxr) {  // clip to max range and mark the clipped end point FREE (:211-213)
     for (int k = 0; k < 3; ++k) q[k] = (q[k] - ra.o[k]) / len * ra.maxr + ra.o[k];
     occ = 0;
   }
   if (ra.inverse) occ = 0;  // inv_esdf_map_->SetOccupancy(point, 0) whatever the end point is (:216-218)
+  return true;
+}
+
+// The free-space visit of walk voxel (vx,vy,vz) as RaycastProcess would do it (include/Fiesta.h:240-248), dense map:
+// what the replay needs to know about it.
+__device__ inline uint32_t ray_visit_code(const Geom &g, const RayArgs &ra, int vx, int vy, int vz) {
+  const double c[3] = {(vx + 0.5) * g.res, (vy + 0.5) * g.res, (vz + 0.5) * g.res};
+  const double e0 = c[0] - ra.o[0], e1 = c[1] - ra.o[1], e2 = c[2] - ra.o[2];
+  const double l2 = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+  if (l2 < ra.minr) return kCodeMinBreak;
+  if (l2 > ra.maxr || !ray_pos_in_map(g, c)) return kCodeSkip;
+  const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
+            z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
+  if (!g.in_grid(x, y, z)) return kCodeSkip;
+  return (uint32_t)g.idx(x, y, z) | ((g.in_window(x, y, z) && g.owned(x, y, z)) ? 0u : kCodeNoCount);
+}
+
+// ---- dense maps: end points for every point of the cloud, walks only for the rays that cast -------------------------
+// A 640x480 depth image holds ~300 k points but only a few thousand distinct end-point voxels, and only the first point
+// of each casts a ray (set_occ_, include/Fiesta.h:221-232).  So the frame is split: k_ray_ends (one lane per point:
+// count the end point, stamp set_occ_), k_ray_cast_list (the winners, compacted), k_ray_walk (one lane per CASTING
+// ray: the traversal, stored ray-major), then the de-duplication rounds and the counting with one WAVE per casting
+// ray -- a lane per walk entry, so that a round costs two memory latencies instead of one per voxel of the walk.
+// flags: bit0 valid point, bit1 casts (winner of its end-point voxel)
+__global__ void k_ray_ends(Geom g, RayArgs ra, const float *pts, int64_t n, int32_t *end_idx, uint8_t *flags,
+                           uint32_t *stamp_occ, uint32_t tagged, unsigned long long *cnt, uint32_t *touched,
+                           unsigned long long *counters) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double q[3];
+  int occ = 0;
+  const bool valid = ray_end_point(ra, pts, i, q, occ);
   // SetOccupancy(point, occ) (src/ESDFMap.cpp:401-437); every valid point counts its end point
   int eidx = -1;
-  if (PAGED) {  // PosInMap is always true for the hash build (:46-48); the virtual window is the map
-    const int x = (int)floor((q[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((q[1] - g.org[1]) / g.res) - g.gy0,
-              z = (int)floor((q[2] - g.org[2]) / g.res) - g.gz0;
-    if (paged::in_win(x, y, z)) {
-      eidx = (int)(pack_coc(x, y, z) | ((uint32_t)occ << 30));
-      need[paged::tile_id(x, y, z)] = 1u;
-    }
-  } else if (ray_pos_in_map(g, q)) {
+  if (valid && ray_pos_in_map(g, q)) {
     const int x = (int)floor((q[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((q[1] - g.org[1]) / g.res) - g.gy0,
               z = (int)floor((q[2] - g.org[2]) / g.res) - g.gz0;
     if (g.in_grid(x, y, z)) {
@@ -162,8 +175,153 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
       if (g.in_window(x, y, z) && g.owned(x, y, z)) count_observation(eidx, occ, cnt, touched, counters);
     }
   }
+  flags[i] = valid ? 1 : 0;
   end_idx[i] = eidx;
-  if (!PAGED && ra.dedup && eidx >= 0) atomicMin(&stamp_occ[eidx], tagged | (uint32_t)i);  // set_occ_ (:221-232)
+  if (ra.dedup && eidx >= 0) atomicMin(&stamp_occ[eidx], tagged | (uint32_t)i);  // set_occ_ (:221-232)
+}
+
+// the casting rays, compacted (any order: every later step identifies a ray by its cloud index)
+__global__ void k_ray_cast_list(int64_t n, int dedup, const int32_t *end_idx, uint8_t *flags, const uint32_t *stamp_occ,
+                                uint32_t tagged, int32_t *cast, int *n_cast) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool casts = false;
+  if (i < n) {
+    const uint8_t f = flags[i];
+    const int32_t e = end_idx[i];
+    casts = (f & 1) && (!dedup || e < 0 || stamp_occ[e] == (tagged | (uint32_t)i));
+    if (casts) flags[i] = f | 2;
+  }
+  const unsigned long long m = __ballot(casts);
+  if (!m) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(n_cast, __popcll(m));
+  base = __shfl(base, leader);
+  if (casts) cast[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
+
+// Raycast(origin/res, point/res, l_cornor/res, r_cornor/res) (include/Fiesta.h:233-237) for casting ray c: the walk,
+// one code per voxel, at entries[c * stride ..]
+__global__ void k_ray_walk(Geom g, RayArgs ra, const float *pts, const int32_t *cast, const int *n_cast, int stride,
+                           uint32_t *entries, int32_t *m_count, int32_t *last_k, int *err) {
+  const int nc = *n_cast;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    double q[3], a[3], b[3], lo[3], hi[3];
+    int occ;
+    (void)ray_end_point(ra, pts, cast[c], q, occ);
+    for (int k = 0; k < 3; ++k) {
+      a[k] = ra.o[k] / g.res;
+      b[k] = q[k] / g.res;
+      lo[k] = ra.lc[k] / g.res;
+      hi[k] = ra.rc[k] / g.res;
+    }
+    uint32_t *row = entries + (int64_t)c * stride;
+    bool overflow = false;
+    int m = dda_walk(a, b, lo, hi, [&](int vx, int vy, int vz, int k) {
+      if (k >= stride) {
+        overflow = true;
+        return;
+      }
+      row[k] = ray_visit_code(g, ra, vx, vy, vz);
+    });
+    if (m < 0 || overflow) {  // (the reference throws; so does the host once the frame is through)
+      atomicExch(err, 1);
+      m = 0;
+    }
+    m_count[c] = m;
+    last_k[c] = m;  // "nothing visited yet"
+  }
+}
+
+// One fixed-point round, one wave per casting ray: truncate the ray with the previous round's first-stamper array and
+// rebuild the array for the next round (see k_ray_resolve for the iteration).  Lane l of a chunk looks at walk entry
+// top - l; the first lane that meets the min-length break or an earlier ray's stamp ends the walk.
+__global__ void k_ray_resolve_w(int stride, const uint32_t *entries, const int32_t *cast, const int *n_cast,
+                                const int32_t *m_count, int32_t *last_k, int have_prev, int stamp, const uint32_t *fprev,
+                                uint32_t tag_prev, uint32_t *fnext, uint32_t tag_next, int ibits, int *changed, int it) {
+  if (it >= 3 && changed[it - 1] == 0) return;  // round 1 always "changes" (from nothing visited to the full walk)
+  const int lane = threadIdx.x & 63, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nc = *n_cast;
+  const uint32_t imask = (1u << ibits) - 1u;
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < nc; c += nwaves) {
+    const uint32_t i = (uint32_t)cast[c];
+    const int m = m_count[c];
+    const uint32_t *row = entries + (int64_t)c * stride;
+    int lk = m;  // lowest visited entry
+    for (int top = m - 2; top >= 0; top -= 64) {
+      const int k = top - lane;
+      const uint32_t code = k >= 0 ? row[k] : kCodeSkip;
+      const bool mb = code == kCodeMinBreak;  // include/Fiesta.h:243-244
+      const bool noop = mb || code == kCodeSkip;  // :245-246 and the "-10000" case of :253
+      const uint32_t idx = code & kCodeIdxMask;
+      bool stop = false;
+      if (have_prev && !noop) {
+        const uint32_t v = fprev[idx];
+        stop = (v >> ibits) == tag_prev && (v & imask) < i;  // set_free_[idx] == tt (:265-269)
+      }
+      const unsigned long long bm = __ballot(mb), bs = __ballot(stop);
+      const int first_mb = bm ? __ffsll((long long)bm) - 1 : 64, first_stop = bs ? __ffsll((long long)bs) - 1 : 64;
+      // visited lanes: everything before the break; up to and including the stamped voxel
+      const int nvis = min(min(first_mb, first_stop + 1), min(64, top + 1));
+      if (stamp && lane < nvis && !noop) atomicMin(&fnext[idx], (tag_next << ibits) | i);
+      if (nvis > 0) lk = top - (nvis - 1);
+      if (first_mb < 64 || first_stop < 64) break;
+    }
+    if (lane == 0 && lk != last_k[c]) {
+      last_k[c] = lk;
+      changed[it] = 1;
+    }
+  }
+}
+
+// SetOccupancy(tmp, 0) along the final walks (include/Fiesta.h:248; inverse map: 1, :250), one wave per casting ray
+__global__ void k_ray_apply_w(int stride, const uint32_t *entries, const int *n_cast, const int32_t *m_count,
+                              const int32_t *last_k, unsigned long long *cnt, uint32_t *touched, unsigned long long *counters,
+                              int free_occ) {
+  const int lane = threadIdx.x & 63, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nc = *n_cast;
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < nc; c += nwaves) {
+    const int m = m_count[c], lk = last_k[c];
+    const uint32_t *row = entries + (int64_t)c * stride;
+    for (int top = m - 2; top >= lk; top -= 64) {
+      const int k = top - lane;
+      const uint32_t code = k >= lk ? row[k] : kCodeSkip;
+      const bool counts = code != kCodeSkip && !(code & kCodeNoCount);
+      unsigned long long old = 1;
+      if (counts) old = atomicAdd(&cnt[code & kCodeIdxMask], ((unsigned long long)(uint32_t)free_occ << 32) | 1ull);
+      wave_append(counts && (uint32_t)old == 0, code & kCodeIdxMask, touched, &counters[C_TOUCHED]);
+    }
+  }
+}
+
+// ---- paged (hash-block) maps: one lane per point of the cloud, walk included ------------------------------------------
+// flags: bit0 valid ray, bit1 casts (winner of its end-point voxel), bit2 traversal overflow
+// A voxel's slot in the page pool is only known once its page exists, so this pass stores packed WINDOW
+// coordinates instead of slots (end_idx: coords | occ << 30), marks the tiles it touches (the reference's Vox2Idx
+// allocates on every SetOccupancy, in or out of the update window, src/ESDFMap.cpp:418-421,732-765) and leaves the
+// counting and stamping of the end points to k_ray_translate, after the pages have been allocated.
+__global__ void k_ray_prepare_paged(Geom g, RayArgs ra, const float *pts, int64_t n, int stride, uint32_t *entries,
+                                    int32_t *end_idx, int32_t *m_count, uint8_t *flags, int *err, uint32_t *need) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flags[i] = 0;
+  m_count[i] = 0;
+  end_idx[i] = -1;
+  double q[3];
+  int occ = 0;
+  if (!ray_end_point(ra, pts, i, q, occ)) return;
+  // SetOccupancy(point, occ) (src/ESDFMap.cpp:401-437); PosInMap is always true for the hash build (:46-48): the
+  // virtual window is the map
+  int eidx = -1;
+  {
+    const int x = (int)floor((q[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((q[1] - g.org[1]) / g.res) - g.gy0,
+              z = (int)floor((q[2] - g.org[2]) / g.res) - g.gz0;
+    if (paged::in_win(x, y, z)) {
+      eidx = (int)(pack_coc(x, y, z) | ((uint32_t)occ << 30));
+      need[paged::tile_id(x, y, z)] = 1u;
+    }
+  }
+  end_idx[i] = eidx;
   // Raycast(origin/res, point/res, l_cornor/res, r_cornor/res) (:233-237)
   double a[3], b[3], lo[3], hi[3];
   for (int k = 0; k < 3; ++k) {
@@ -186,18 +344,11 @@ __global__ void k_ray_prepare(Geom g, RayArgs ra, const float *pts, int64_t n, i
     if (l2 < ra.minr) {
       code = kCodeMinBreak;
     } else if (!(l2 > ra.maxr)) {
-      if (PAGED) {
-        const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
-                  z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
-        if (paged::in_win(x, y, z)) {
-          code = pack_coc(x, y, z) | (g.in_window(x, y, z) ? 0u : kCodeNoCount);
-          need[paged::tile_id(x, y, z)] = 1u;
-        }
-      } else if (ray_pos_in_map(g, c)) {
-        const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
-                  z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
-        if (g.in_grid(x, y, z))
-          code = (uint32_t)g.idx(x, y, z) | ((g.in_window(x, y, z) && g.owned(x, y, z)) ? 0u : kCodeNoCount);
+      const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
+                z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
+      if (paged::in_win(x, y, z)) {
+        code = pack_coc(x, y, z) | (g.in_window(x, y, z) ? 0u : kCodeNoCount);
+        need[paged::tile_id(x, y, z)] = 1u;
       }
     }
     entries[(int64_t)k * n + i] = code;
@@ -359,6 +510,7 @@ __global__ void k_raycast_one(const double *io, double *out, int cap, int *n_out
 struct RayState {
   DevBuf<uint32_t> entries;
   DevBuf<int32_t> end_idx, m_count, last_k;
+  DevBuf<int32_t> cast;  // dense maps: cloud indices of the casting rays (m_count, last_k, entries rows are per casting ray)
   DevBuf<uint8_t> flags;
   DevBuf<float> points;
   DevBuf<uint16_t> depth, last_depth;  // the image being converted; the previous one (temporal depth filter)
@@ -369,7 +521,7 @@ struct RayState {
   int ibits = 0;
   uint32_t tag = 0;
   static constexpr int kMaxRounds = 240, kFlagInts = kMaxRounds + 8;
-  int *d_flags = nullptr;  // [0] unused, [1] error, [2 + it] "round it changed something"
+  int *d_flags = nullptr;  // [0] casting rays of the frame (dense maps), [1] error, [2 + it] "round it changed something"
   int *h_flags = nullptr;
   int64_t last_iterations = 0;
   RayState() {
@@ -517,6 +669,72 @@ static void ray_rounds(RayState &rc, int64_t n, int dedup, int ibits, uint32_t t
     throw Error(FIESTA_HIP_ERR_INVALID, "Too many raycast voxels (a ray crosses more than 1500 voxels)");
 }
 
+// Dense maps: the casting rays of the frame (compacted), their walks, the free-space fixed point with one wave per
+// casting ray, the counters.  Nothing here waits for the host except the batches of the fixed point.
+static void ray_rounds_cast(RayState &rc, const Geom &g, const RayArgs &ra, const float *dpts, int64_t n, int stride, int ibits,
+                            uint32_t tag_occ, unsigned long long *cnt, uint32_t *touched, unsigned long long *counters,
+                            hipStream_t stream) {
+  rc.cast.ensure(n, stream);
+  int *n_cast = rc.d_flags;  // [0]: casting rays of this frame (zeroed with the flags)
+  hipLaunchKernelGGL(k_ray_cast_list, dim3(rgrid(n)), dim3(256), 0, stream, n, ra.dedup, (const int32_t *)rc.end_idx.p, rc.flags.p,
+                     (const uint32_t *)rc.stamp_occ, ra.dedup ? (tag_occ << ibits) : 0u, rc.cast.p, n_cast);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  // (grids are sized for the cloud, not for the casting rays -- their number stays on the device; surplus waves leave)
+  const int walk_blocks = (int)std::min<int64_t>((n + 63) / 64, 4096);
+  hipLaunchKernelGGL(k_ray_walk, dim3(walk_blocks), dim3(64), 0, stream, g, ra, dpts, (const int32_t *)rc.cast.p, (const int *)n_cast,
+                     stride, rc.entries.p, rc.m_count.p, rc.last_k.p, rc.d_flags + 1);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  const int wave_blocks = (int)std::min<int64_t>((n + 3) / 4, 2048);  // 4 waves per block
+  auto resolve = [&](int have_prev, int stamp, const uint32_t *fprev, uint32_t tag_prev, uint32_t *fnext, uint32_t tag_next, int it) {
+    hipLaunchKernelGGL(k_ray_resolve_w, dim3(wave_blocks), dim3(256), 0, stream, stride, (const uint32_t *)rc.entries.p,
+                       (const int32_t *)rc.cast.p, (const int *)n_cast, (const int32_t *)rc.m_count.p, rc.last_k.p, have_prev, stamp,
+                       fprev, tag_prev, fnext, tag_next, ibits, rc.d_flags + 2, it);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  };
+  int64_t iters = 0;
+  if (!ra.dedup) {
+    resolve(0, 0, nullptr, 0u, nullptr, 0u, 1);
+  } else {
+    uint32_t *fprev = rc.fa, *fnext = rc.fb;
+    uint32_t tag_prev = 0;
+    constexpr int kBatch = 8;  // rounds per host round trip
+    bool done = false;
+    int64_t base = 0;  // rounds whose flag slots were recycled (see ray_rounds)
+    while (!done) {
+      const int64_t first = iters + 1;
+      for (int b = 0; b < kBatch; ++b) {
+        const uint32_t tag_next = rc.tag--;
+        ++iters;
+        resolve(iters > 1 ? 1 : 0, 1, fprev, tag_prev, fnext, tag_next, (int)(iters - base));
+        std::swap(fprev, fnext);
+        tag_prev = tag_next;
+      }
+      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, (2 + (iters - base) + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
+      if (rc.h_flags[1]) break;
+      for (int64_t it = std::max<int64_t>(first, 2); it <= iters; ++it)  // the first round (after round 1) that changed nothing
+        if (!rc.h_flags[2 + (it - base)]) {
+          iters = it;
+          done = true;
+          break;
+        }
+      if (!done && (iters - base) + kBatch > RayState::kMaxRounds) {
+        FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags + 2, 0, (RayState::kFlagInts - 2) * sizeof(int), stream));
+        base = iters;
+      }
+      if (!done && iters > n + kBatch) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup: more rounds than rays (internal error)");
+    }
+  }
+  rc.last_iterations = iters;
+  hipLaunchKernelGGL(k_ray_apply_w, dim3(wave_blocks), dim3(256), 0, stream, stride, (const uint32_t *)rc.entries.p, (const int *)n_cast,
+                     (const int32_t *)rc.m_count.p, (const int32_t *)rc.last_k.p, cnt, touched, counters, ra.inverse ? 1 : 0);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+  FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
+  if (rc.h_flags[1])  // the reference throws std::out_of_range("Too many RaycasMultithread voxels")
+    throw Error(FIESTA_HIP_ERR_INVALID, "Too many raycast voxels (a ray crosses more than 1500 voxels)");
+}
+
 static const float *ray_points(RayState &rc, const float *points, int64_t n, bool dev, hipStream_t stream) {
   if (dev) return points;
   rc.points.ensure(3 * n, stream);
@@ -576,11 +794,10 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
   ensure_touched_capacity(std::min<int64_t>(g.n, n * (int64_t)(stride + 1)));
   FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, RayState::kFlagInts * sizeof(int), stream_));
   const uint32_t tag_occ = ra.dedup ? rc.tag-- : 0;
-  hipLaunchKernelGGL(k_ray_prepare<false>, dim3(rgrid(n)), dim3(256), 0, stream_, g, ra, dpts, n, stride, rc.entries.p,
-                     rc.end_idx.p, rc.m_count.p, rc.flags.p, rc.stamp_occ, ra.dedup ? (tag_occ << ibits) : 0u, cnt_,
-                     touched_.p, counters_, rc.d_flags + 1, (uint32_t *)nullptr);
+  hipLaunchKernelGGL(k_ray_ends, dim3(rgrid(n)), dim3(256), 0, stream_, g, ra, dpts, n, rc.end_idx.p, rc.flags.p, rc.stamp_occ,
+                     ra.dedup ? (tag_occ << ibits) : 0u, cnt_, touched_.p, counters_);
   FIESTA_HIP_CHECK(hipGetLastError());
-  ray_rounds(rc, n, ra.dedup, ibits, tag_occ, cnt_, touched_.p, counters_, stream_, ra.inverse);
+  ray_rounds_cast(rc, g, ra, dpts, n, stride, ibits, tag_occ, cnt_, touched_.p, counters_, stream_);
 }
 
 void DenseMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
@@ -626,9 +843,8 @@ void HashMap::raycast_frame(const float *points, int64_t n, const double *T, con
   const float *dpts = ray_points(rc, points, n, dev, stream_);
   const RayArgs ra = ray_args(T, origin, p);
   FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, RayState::kFlagInts * sizeof(int), stream_));
-  hipLaunchKernelGGL(k_ray_prepare<true>, dim3(rgrid(n)), dim3(256), 0, stream_, g_, ra, dpts, n, stride, rc.entries.p,
-                     rc.end_idx.p, rc.m_count.p, rc.flags.p, (uint32_t *)nullptr, 0u, (unsigned long long *)nullptr,
-                     (uint32_t *)nullptr, (unsigned long long *)nullptr, rc.d_flags + 1, need_);
+  hipLaunchKernelGGL(k_ray_prepare_paged, dim3(rgrid(n)), dim3(256), 0, stream_, g_, ra, dpts, n, stride, rc.entries.p,
+                     rc.end_idx.p, rc.m_count.p, rc.flags.p, rc.d_flags + 1, need_);
   FIESTA_HIP_CHECK(hipGetLastError());
   allocate_marked();
   if ((int64_t)cap_pages_ * kPageVox > (1ll << 30))
