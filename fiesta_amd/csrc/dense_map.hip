@@ -172,33 +172,36 @@ __device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_
 __global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *touched, int64_t n,
                        unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *gocc,
                        uint32_t *ins, uint32_t *del, unsigned long long *counters) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  bool to_ins = false, to_del = false, first_obs = false;
-  uint32_t idx = 0;
   if (n < 0) n = (int64_t)counters[C_TOUCHED];  // the host only knows an upper bound (it sized the grid with it)
-  if (i < n) {
-    idx = touched[i];
-    fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, to_ins, to_del, first_obs);
-  }
-  // queue appends: ONE atomic per wave and queue (tens of thousands of transitions would otherwise serialise on
-  // the two counters)
   const int lane = threadIdx.x & 63;
-  const unsigned long long mi = __ballot(to_ins), md = __ballot(to_del), mo = __ballot(first_obs);
-  // bookkeeping for the choice of the UpdateESDF engine: observed voxels and occupied voxels of the map
-  if (lane == 0 && mo) atomicAdd(&counters[C_OBSERVED], (unsigned long long)__popcll(mo));
-  if (lane == 0 && (mi | md))
-    atomicAdd(&counters[C_NOCC], (unsigned long long)((long long)__popcll(mi) - (long long)__popcll(md)));
-  if (mi) {
-    uint32_t base = 0;  // (queues hold < 2^32 entries: voxel indices are 32-bit)
-    if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_INSERT], (unsigned long long)__popcll(mi));
-    base = __shfl(base, 0);
-    if (to_ins) ins[base + __popcll(mi & ((1ull << lane) - 1ull))] = idx;
-  }
-  if (md) {
-    uint32_t base = 0;
-    if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_DELETE], (unsigned long long)__popcll(md));
-    base = __shfl(base, 0);
-    if (to_del) del[base + __popcll(md & ((1ull << lane) - 1ull))] = idx;
+  // (whole waves stride over the list: the ballots below need every lane of a wave in the same iteration)
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i0 + lane;
+    bool to_ins = false, to_del = false, first_obs = false;
+    uint32_t idx = 0;
+    if (i < n) {
+      idx = touched[i];
+      fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, to_ins, to_del, first_obs);
+    }
+    // queue appends: ONE atomic per wave and queue (tens of thousands of transitions would otherwise serialise on
+    // the two counters)
+    const unsigned long long mi = __ballot(to_ins), md = __ballot(to_del), mo = __ballot(first_obs);
+    // bookkeeping for the choice of the UpdateESDF engine: observed voxels and occupied voxels of the map
+    if (lane == 0 && mo) atomicAdd(&counters[C_OBSERVED], (unsigned long long)__popcll(mo));
+    if (lane == 0 && (mi | md))
+      atomicAdd(&counters[C_NOCC], (unsigned long long)((long long)__popcll(mi) - (long long)__popcll(md)));
+    if (mi) {
+      uint32_t base = 0;  // (queues hold < 2^32 entries: voxel indices are 32-bit)
+      if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_INSERT], (unsigned long long)__popcll(mi));
+      base = __shfl(base, 0);
+      if (to_ins) ins[base + __popcll(mi & ((1ull << lane) - 1ull))] = idx;
+    }
+    if (md) {
+      uint32_t base = 0;
+      if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_DELETE], (unsigned long long)__popcll(md));
+      base = __shfl(base, 0);
+      if (to_del) del[base + __popcll(md & ((1ull << lane) - 1ull))] = idx;
+    }
   }
 }
 
@@ -1002,7 +1005,7 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
   if (nt) {
     ins_.ensure(ni + nt, stream_, ni);
     del_.ensure(nd + nt, stream_, nd);
-    hipLaunchKernelGGL(k_fuse, dim3(grid_for((int64_t)nt)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
+    hipLaunchKernelGGL(k_fuse, dim3(grid_for((int64_t)nt, 256, 8192)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
                        (const uint32_t *)touched_.p, (int64_t)-1, cnt_, logodds_, coc_, occbits_, gocc_, ins_.p,
                        del_.p, counters_);
     FIESTA_HIP_CHECK(hipGetLastError());

@@ -161,28 +161,45 @@ __global__ void k_ray_ends(Geom g, RayArgs ra, const float *pts, int64_t n, int3
                            uint32_t *stamp_occ, uint32_t tagged, unsigned long long *cnt, uint32_t *touched,
                            unsigned long long *counters) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
   double q[3];
   int occ = 0;
-  const bool valid = ray_end_point(ra, pts, i, q, occ);
+  const bool valid = i < n && ray_end_point(ra, pts, i, q, occ);
   // SetOccupancy(point, occ) (src/ESDFMap.cpp:401-437); every valid point counts its end point
   int eidx = -1;
+  bool counts = false;
   if (valid && ray_pos_in_map(g, q)) {
     const int x = (int)floor((q[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((q[1] - g.org[1]) / g.res) - g.gy0,
               z = (int)floor((q[2] - g.org[2]) / g.res) - g.gz0;
     if (g.in_grid(x, y, z)) {
       eidx = (int)g.idx(x, y, z);
-      if (g.in_window(x, y, z) && g.owned(x, y, z)) count_observation(eidx, occ, cnt, touched, counters);
+      counts = g.in_window(x, y, z) && g.owned(x, y, z);
     }
   }
-  flags[i] = valid ? 1 : 0;
-  end_idx[i] = eidx;
-  if (ra.dedup && eidx >= 0) atomicMin(&stamp_occ[eidx], tagged | (uint32_t)i);  // set_occ_ (:221-232)
+  if (i < n) {
+    flags[i] = valid ? 1 : 0;
+    end_idx[i] = eidx;
+  }
+  // Neighbouring pixels end in the same voxel a dozen at a time: one atomic per RUN of equal end points inside the wave
+  // (the counter word takes the run's observations and hits at once; the run's first lane carries its smallest index)
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(eidx, 1);
+  const unsigned long long heads = __ballot(lane == 0 || eidx != prev), hits = __ballot(occ == 1);
+  if (eidx >= 0 && ((heads >> lane) & 1ull)) {
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int len = above ? __ffsll((long long)above) : 64 - lane;
+    const unsigned long long run = (len == 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
+    if (counts) {
+      const unsigned long long old = atomicAdd(&cnt[eidx], ((unsigned long long)__popcll(hits & run) << 32) | (unsigned long long)len);
+      wave_append((uint32_t)old == 0, (uint32_t)eidx, touched, &counters[C_TOUCHED]);
+    }
+    if (ra.dedup) atomicMin(&stamp_occ[eidx], tagged | (uint32_t)i);  // set_occ_ (:221-232)
+  }
 }
 
 // the casting rays, compacted (any order: every later step identifies a ray by its cloud index)
-__global__ void k_ray_cast_list(int64_t n, int dedup, const int32_t *end_idx, uint8_t *flags, const uint32_t *stamp_occ,
-                                uint32_t tagged, int32_t *cast, int *n_cast) {
+__global__ __launch_bounds__(1024) void k_ray_cast_list(int64_t n, int dedup, const int32_t *end_idx, uint8_t *flags,
+                                                        const uint32_t *stamp_occ, uint32_t tagged, int32_t *cast, int *n_cast) {
+  __shared__ int wcount[16], wbase[16];
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   bool casts = false;
   if (i < n) {
@@ -192,18 +209,27 @@ __global__ void k_ray_cast_list(int64_t n, int dedup, const int32_t *end_idx, ui
     if (casts) flags[i] = f | 2;
   }
   const unsigned long long m = __ballot(casts);
-  if (!m) return;
-  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(n_cast, __popcll(m));
-  base = __shfl(base, leader);
-  if (casts) cast[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wcount[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one atomic per work-group
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) wbase[w] = tot, tot += wcount[w];
+    const int base = tot ? atomicAdd(n_cast, tot) : 0;
+    for (int w = 0; w < 16; ++w) wbase[w] += base;
+  }
+  __syncthreads();
+  if (casts) cast[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
 }
 
-// Raycast(origin/res, point/res, l_cornor/res, r_cornor/res) (include/Fiesta.h:233-237) for casting ray c: the walk,
-// one code per voxel, at entries[c * stride ..]
+// Raycast(origin/res, point/res, l_cornor/res, r_cornor/res) (include/Fiesta.h:233-237) for casting ray c, one lane per
+// ray.  The traversal is serial but light; what the visit of each voxel needs (a square root and three divisions in
+// f64) is not, and does not depend on the step before.  So this pass only records the PATH: the first voxel of the walk
+// (walk0) and, per further voxel, which axis stepped and in which direction -- the voxels a ray emits are consecutive
+// steps, the clipping box being convex -- and k_ray_codes turns the path into visit codes with a lane per voxel.
+constexpr uint32_t kStepNone = 6;
 __global__ void k_ray_walk(Geom g, RayArgs ra, const float *pts, const int32_t *cast, const int *n_cast, int stride,
-                           uint32_t *entries, int32_t *m_count, int32_t *last_k, int *err) {
+                           uint32_t *entries, int32_t *walk0, int32_t *m_count, int32_t *last_k, int *err) {
   const int nc = *n_cast;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
     double q[3], a[3], b[3], lo[3], hi[3];
@@ -217,12 +243,19 @@ __global__ void k_ray_walk(Geom g, RayArgs ra, const float *pts, const int32_t *
     }
     uint32_t *row = entries + (int64_t)c * stride;
     bool overflow = false;
+    int px = 0, py = 0, pz = 0;
     int m = dda_walk(a, b, lo, hi, [&](int vx, int vy, int vz, int k) {
       if (k >= stride) {
         overflow = true;
         return;
       }
-      row[k] = ray_visit_code(g, ra, vx, vy, vz);
+      if (k == 0) {
+        walk0[3 * c] = vx, walk0[3 * c + 1] = vy, walk0[3 * c + 2] = vz;
+        row[0] = kStepNone;
+      } else {
+        row[k] = vx != px ? (vx < px ? 1u : 0u) : (vy != py ? (vy < py ? 3u : 2u) : (vz < pz ? 5u : 4u));
+      }
+      px = vx, py = vy, pz = vz;
     });
     if (m < 0 || overflow) {  // (the reference throws; so does the host once the frame is through)
       atomicExch(err, 1);
@@ -230,6 +263,34 @@ __global__ void k_ray_walk(Geom g, RayArgs ra, const float *pts, const int32_t *
     }
     m_count[c] = m;
     last_k[c] = m;  // "nothing visited yet"
+  }
+}
+
+// path -> visit codes, in place: one wave per casting ray, a lane per voxel of the walk (the voxel = walk0 + the steps
+// so far: an inclusive wave scan of the three axes packed in one word, every lane adding 1 to each field so that
+// no field ever borrows)
+__global__ void k_ray_codes(Geom g, RayArgs ra, const int *n_cast, int stride, uint32_t *entries, const int32_t *walk0,
+                            const int32_t *m_count) {
+  const int lane = threadIdx.x & 63, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nc = *n_cast;
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < nc; c += nwaves) {
+    const int m = m_count[c];
+    uint32_t *row = entries + (int64_t)c * stride;
+    int cx = walk0[3 * c], cy = walk0[3 * c + 1], cz = walk0[3 * c + 2];
+    for (int base = 0; base < m; base += 64) {
+      const int k = base + lane;
+      const uint32_t st = k < m ? row[k] : kStepNone;
+      uint32_t v = 0x00100401u;  // +1 in each 10-bit field
+      if (st < kStepNone) v += (st & 1u) ? -(1u << (10 * (st >> 1))) : (1u << (10 * (st >> 1)));
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+      }
+      const int dx = (int)(v & 1023u) - (lane + 1), dy = (int)((v >> 10) & 1023u) - (lane + 1), dz = (int)((v >> 20) & 1023u) - (lane + 1);
+      if (k < m) row[k] = ray_visit_code(g, ra, cx + dx, cy + dy, cz + dz);
+      const uint32_t tot = __shfl(v, 63);
+      cx += (int)(tot & 1023u) - 64, cy += (int)((tot >> 10) & 1023u) - 64, cz += (int)((tot >> 20) & 1023u) - 64;
+    }
   }
 }
 
@@ -510,6 +571,7 @@ __global__ void k_raycast_one(const double *io, double *out, int cap, int *n_out
 struct RayState {
   DevBuf<uint32_t> entries;
   DevBuf<int32_t> end_idx, m_count, last_k;
+  DevBuf<int32_t> walk0;  // dense maps: first voxel of each casting ray's walk
   DevBuf<int32_t> cast;  // dense maps: cloud indices of the casting rays (m_count, last_k, entries rows are per casting ray)
   DevBuf<uint8_t> flags;
   DevBuf<float> points;
@@ -676,15 +738,19 @@ static void ray_rounds_cast(RayState &rc, const Geom &g, const RayArgs &ra, cons
                             hipStream_t stream) {
   rc.cast.ensure(n, stream);
   int *n_cast = rc.d_flags;  // [0]: casting rays of this frame (zeroed with the flags)
-  hipLaunchKernelGGL(k_ray_cast_list, dim3(rgrid(n)), dim3(256), 0, stream, n, ra.dedup, (const int32_t *)rc.end_idx.p, rc.flags.p,
+  hipLaunchKernelGGL(k_ray_cast_list, dim3((int)((n + 1023) / 1024)), dim3(1024), 0, stream, n, ra.dedup, (const int32_t *)rc.end_idx.p, rc.flags.p,
                      (const uint32_t *)rc.stamp_occ, ra.dedup ? (tag_occ << ibits) : 0u, rc.cast.p, n_cast);
   FIESTA_HIP_CHECK(hipGetLastError());
   // (grids are sized for the cloud, not for the casting rays -- their number stays on the device; surplus waves leave)
   const int walk_blocks = (int)std::min<int64_t>((n + 63) / 64, 4096);
-  hipLaunchKernelGGL(k_ray_walk, dim3(walk_blocks), dim3(64), 0, stream, g, ra, dpts, (const int32_t *)rc.cast.p, (const int *)n_cast,
-                     stride, rc.entries.p, rc.m_count.p, rc.last_k.p, rc.d_flags + 1);
-  FIESTA_HIP_CHECK(hipGetLastError());
   const int wave_blocks = (int)std::min<int64_t>((n + 3) / 4, 2048);  // 4 waves per block
+  rc.walk0.ensure(3 * n, stream);
+  hipLaunchKernelGGL(k_ray_walk, dim3(walk_blocks), dim3(64), 0, stream, g, ra, dpts, (const int32_t *)rc.cast.p, (const int *)n_cast,
+                     stride, rc.entries.p, rc.walk0.p, rc.m_count.p, rc.last_k.p, rc.d_flags + 1);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_ray_codes, dim3(wave_blocks), dim3(256), 0, stream, g, ra, (const int *)n_cast, stride, rc.entries.p,
+                     (const int32_t *)rc.walk0.p, (const int32_t *)rc.m_count.p);
+  FIESTA_HIP_CHECK(hipGetLastError());
   auto resolve = [&](int have_prev, int stamp, const uint32_t *fprev, uint32_t tag_prev, uint32_t *fnext, uint32_t tag_next, int it) {
     hipLaunchKernelGGL(k_ray_resolve_w, dim3(wave_blocks), dim3(256), 0, stream, stride, (const uint32_t *)rc.entries.p,
                        (const int32_t *)rc.cast.p, (const int *)n_cast, (const int32_t *)rc.m_count.p, rc.last_k.p, have_prev, stamp,
@@ -697,12 +763,15 @@ static void ray_rounds_cast(RayState &rc, const Geom &g, const RayArgs &ra, cons
   } else {
     uint32_t *fprev = rc.fa, *fnext = rc.fb;
     uint32_t tag_prev = 0;
-    constexpr int kBatch = 8;  // rounds per host round trip
+    // rounds per host round trip: as many as the previous frame needed plus one (consecutive frames of a sensor need
+    // about the same number: one round trip per frame), then a few at a time
+    constexpr int kBatch = 4;
+    int batch = (int)std::min<int64_t>(std::max<int64_t>(rc.last_iterations + 1, kBatch), 64);
     bool done = false;
     int64_t base = 0;  // rounds whose flag slots were recycled (see ray_rounds)
     while (!done) {
       const int64_t first = iters + 1;
-      for (int b = 0; b < kBatch; ++b) {
+      for (int b = 0; b < batch; ++b) {
         const uint32_t tag_next = rc.tag--;
         ++iters;
         resolve(iters > 1 ? 1 : 0, 1, fprev, tag_prev, fnext, tag_next, (int)(iters - base));
@@ -718,11 +787,12 @@ static void ray_rounds_cast(RayState &rc, const Geom &g, const RayArgs &ra, cons
           done = true;
           break;
         }
+      batch = kBatch;
       if (!done && (iters - base) + kBatch > RayState::kMaxRounds) {
         FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags + 2, 0, (RayState::kFlagInts - 2) * sizeof(int), stream));
         base = iters;
       }
-      if (!done && iters > n + kBatch) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup: more rounds than rays (internal error)");
+      if (!done && iters > n + 64) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup: more rounds than rays (internal error)");
     }
   }
   rc.last_iterations = iters;

@@ -6,3 +6,4 @@ d=json.load(open('gpurun_out/r03f_bench_c3.json'))
 print({k:d[k] for k in ('value','ms_per_step','raycast_p50_ms','update_occupancy_p50_ms','update_esdf_p50_ms')}, d['cpu_baseline'].get('counters_bit_identical'))
 P
 tail -3 gpurun_out/c3.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c3 -o c3 --output-format csv -- python bench.py --workload c3 --steps 12 --warmup 3 --no-cpu-baseline > gpurun_out/c3p.json 2> gpurun_out/c3p.err
