@@ -107,6 +107,8 @@ __host__ __device__ inline void rainbow_rgba(double h, float *rgba) {
 #define FIESTA_STENCIL6B(X) X(-1, -1, 0) X(1, 1, 0) X(0, -1, -1) X(0, 1, 1) X(-1, 0, -1) X(1, 0, 1)
 #define FIESTA_STENCIL6C(X) X(-1, 1, 0) X(1, -1, 0) X(0, -1, 1) X(0, 1, -1) X(1, 0, -1) X(-1, 0, 1)
 #define FIESTA_STENCIL6D(X) X(-2, 0, 0) X(2, 0, 0) X(0, -2, 0) X(0, 2, 0) X(0, 0, -2) X(0, 0, 2)
+// (as initialiser lists)
+#define FIESTA_DIR3(DX, DY, DZ) {DX, DY, DZ},
 #define FIESTA_STENCIL24(X)                                                                             \
   X(-1, 0, 0) X(1, 0, 0) X(0, -1, 0) X(0, 1, 0) X(0, 0, -1) X(0, 0, 1) X(-1, -1, 0) X(1, 1, 0)          \
   X(0, -1, -1) X(0, 1, 1) X(-1, 0, -1) X(1, 0, 1) X(-1, 1, 0) X(1, -1, 0) X(0, -1, 1) X(0, 1, -1)       \

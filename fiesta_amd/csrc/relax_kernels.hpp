@@ -538,6 +538,99 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
       }
     };
 
+    // Sparse levels: one frontier item = FOUR lanes, six directions each (the stencil's four groups of 6, in the
+    // reference's order).  A sparse frontier -- a depth frame's update is a few hundred items per level -- leaves most
+    // of the work-group idle, and what a level costs is one item's dependent chain: a quarter of the neighbour reads
+    // and atomics per lane is a quarter of that chain.  The directions are per-lane data (no branch on the lane's
+    // quarter, so a wave never diverges over them); the results are those of one lane doing all 24 (the pull keeps the
+    // FIRST strictly smaller candidate in stencil order: the lower quarter wins ties; pushes are commutative ds_min).
+    auto process_split = [&](const uint32_t total, uint32_t *Fn) {
+      const int part = tl & 3;
+      int ex[6], ey[6], ez[6], nd[6];
+      {
+        constexpr int8_t A[6][3] = {FIESTA_STENCIL6A(FIESTA_DIR3)}, B[6][3] = {FIESTA_STENCIL6B(FIESTA_DIR3)},
+                         C[6][3] = {FIESTA_STENCIL6C(FIESTA_DIR3)}, D[6][3] = {FIESTA_STENCIL6D(FIESTA_DIR3)};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          ex[q] = part == 0 ? A[q][0] : (part == 1 ? B[q][0] : (part == 2 ? C[q][0] : D[q][0]));
+          ey[q] = part == 0 ? A[q][1] : (part == 1 ? B[q][1] : (part == 2 ? C[q][1] : D[q][1]));
+          ez[q] = part == 0 ? A[q][2] : (part == 1 ? B[q][2] : (part == 2 ? C[q][2] : D[q][2]));
+          nd[q] = (ex[q] * RY + ey[q]) * RZ + ez[q];
+        }
+      }
+      for (uint32_t j = (uint32_t)tl >> 2; j < total; j += NT / 4) {
+        const int v = Q[j];
+        const uint32_t vbit = 1u << (v & 31);
+        const int rz = v % RZ, ry = (v / RZ) % RY, rx = v / (RZ * RY);
+        const int vx = bx + rx, vy = by + ry, vz = bz + rz;
+        unsigned long long key = __hip_atomic_load(&K64(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+        if (a.prof == 1 && part == 0) ++n_items;
+        if (P[v >> 5] & vbit) {  // had no obstacle when the tile was staged, not asked yet (the same answer in all four lanes)
+          if (part == 0) __hip_atomic_fetch_and(&P[v >> 5], ~vbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (pulls_enabled) {
+            if (a.prof == 1 && part == 0) ++n_pulls;
+            vox_t un[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) un[q] = KW(2 * (v + nd[q]));
+            vox_t best = lo;
+            uint32_t bestd = hi;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+              const vox_t u = un[q];
+              if (!(u & (kNoCoc | kAct))) {
+                const uint32_t d = (uint32_t)dist2(g.wrap, vx, vy, vz, u);
+                if (d < bestd) {
+                  bestd = d;
+                  best = u;
+                }
+              }
+            }
+#pragma unroll
+            for (int m = 1; m <= 2; m <<= 1) {  // the four quarters' minima; on a tie the lower quarter's
+              const uint32_t od = (uint32_t)__shfl_xor((int)bestd, m);
+              const vox_t ob = (vox_t)__shfl_xor((int)best, m);
+              if ((part & m) ? od <= bestd : od < bestd) {
+                bestd = od;
+                best = ob;
+              }
+            }
+            if (bestd < hi) {
+              const unsigned long long mine = ((unsigned long long)bestd << 32) | best | kAct;
+              unsigned long long res = mine;
+              if (part == 0) {
+                const unsigned long long old = atomicMin(&K64(v), mine);
+                res = old < mine ? old : mine;
+              }
+              lo = (uint32_t)__shfl((int)(uint32_t)res, lane & ~3);
+              hi = (uint32_t)__shfl((int)(uint32_t)(res >> 32), lane & ~3);
+            }
+          }
+        }
+        if (lo & kNoCoc) continue;
+        // push: |v+e-c|^2 = d(v) + 2 e.(v-c) + |e|^2
+        const vox_t c = lo & ~kAct;
+        int rcx, rcy, rcz;
+        coc_offset(g.wrap, vx, vy, vz, c, rcx, rcy, rcz);
+        const int32_t dv = (int32_t)hi;
+        const unsigned long long keylo = (unsigned long long)(c | kAct);
+        const int ax = 2 * rcx, ay = 2 * rcy, az = 2 * rcz;
+        uint32_t dnv[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dnv[q] = KW(2 * (v + nd[q]) + 1);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const uint32_t cand = (uint32_t)(dv + ex[q] * ax + ey[q] * ay + ez[q] * az + (ex[q] * ex[q] + ey[q] * ey[q] + ez[q] * ez[q]));
+          if (cand < dnv[q]) {
+            if (a.prof == 1) ++n_succ;
+            const int n = v + nd[q];
+            __hip_atomic_fetch_min(&K64(n), ((unsigned long long)cand << 32) | keylo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&Fn[n >> 5], 1u << (n & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    };
+
     // pass before level 0: the source-only voxels offer their obstacles; what they improve joins level 0
     if (prof) tmark = clock64();
     {
@@ -563,7 +656,10 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
         tmark = now;
       }
       if (total == 0) break;
-      process(std::false_type{}, total, F[cur ^ 1]);
+      if (total > (uint32_t)NT)  // (a dense level keeps every lane busy with one item each: fewer instructions per item)
+        process(std::false_type{}, total, F[cur ^ 1]);
+      else
+        process_split(total, F[cur ^ 1]);
       if (prof) tp += clock64() - tmark;
     }
     if (prof) t2 = clock64();
