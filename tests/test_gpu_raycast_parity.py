@@ -103,6 +103,35 @@ def test_frames_counts_exact_with_reference_dedup(hip_lib, oracle_libs, best_ora
     assert gpu.download_field(("occ",))["occ"].sum() > 500
 
 
+def test_long_rays_in_random_cloud_order_counts_exact(hip_lib, oracle_libs, best_oracle_kind):
+    """Walks of several hundred voxels (a wave covers 64 entries of a casting ray at a time: the chunked truncation, the
+    packed coordinate scan and its carries), a cloud in random order (the de-duplication depends on it), a ray box
+    smaller than the map, end points beyond the map (those rays always cast), beyond max range (clipped, counted free)
+    and closer than min range, runs of equal end points (one counter update per run): counters equal the oracle's."""
+    origin, size, res = (-9.6, -9.6, -1.2), (19.15, 19.15, 2.35), 0.05
+    gpu, cpu = make(oracle_libs, best_oracle_kind, origin, size, res)
+    assert gpu.grid_size == (383, 383, 47)
+    lc, rc = (-9.0, -8.0, -1.0), (8.5, 9.3, 1.1)          # rays are clipped to this box (l_cornor / r_cornor)
+    rng = np.random.RandomState(5)
+    for f in range(3):
+        o = np.array([0.37, -0.22, 0.11]) + 0.4 * f
+        T = np.eye(4)
+        T[:3, 3] = o
+        n = 3000
+        d = rng.normal(size=(n, 3)) * [1.0, 1.0, 0.06]
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        r = rng.uniform(0.3, 14.0, n)                       # some closer than min range, some beyond max range and the map
+        pts = (d * r[:, None]).astype(np.float32)
+        pts[::7] = pts[1::7][: len(pts[::7])]              # duplicates: several points per end voxel ...
+        pts[100:160] = pts[100]                             # ... and a run of equal end points inside one wave
+        pts[::333] = np.nan
+        gpu.RaycastFrame(pts, T, o, 1.0, 12.0, lc, rc, dedup=1)
+        cpu.raycast_frame(pts, T, o, 1.0, 12.0, lc, rc)
+        assert check_counts(gpu, cpu) > 20000
+        assert gpu.UpdateOccupancy(True) == cpu.UpdateOccupancy(True)
+        assert (gpu.last_insert, gpu.last_delete) == (cpu.last_insert, cpu.last_delete)
+
+
 def test_depth_image_entry_point_matches_point_path(hip_lib, oracle_libs, best_oracle_kind):
     """fiesta_hip_raycast_depth (device-side pinhole conversion) == host conversion + raycast_frame == oracle."""
     origin, size, res = (-6.4, -6.4, -3.2), (12.75, 12.75, 6.35), 0.1

@@ -1,6 +1,2 @@
 mkdir -p gpurun_out
-FIESTA_HIP_PROF=1 timeout 300 python tools/dev/prof_c4.py 2>&1 | grep -E "tile_visits|rounds|relax_us|per visit"
-timeout 300 python bench.py --workload c3 --steps 20 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c3',{k:round(d[k],4) for k in ('ms_per_step','raycast_p50_ms','update_occupancy_p50_ms','update_esdf_p50_ms')})"
-timeout 300 python bench.py --workload c4 --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c4',{k:round(d[k],4) for k in ('ms_per_step','observe_p50_ms','update_occupancy_p50_ms','update_esdf_p50_ms')})"
-timeout 300 python bench.py --engine rounds --steps 5 --warmup 1 --no-cpu-baseline --no-cpu-full 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c2 rounds',{k:round(d[k],4) for k in ('ms_per_step','update_esdf_p50_ms')}, d['roofline']['frac'])"
-timeout 1500 python -m pytest tests/test_gpu_dense_parity.py tests/test_gpu_fuzz.py tests/test_gpu_hash_parity.py tests/test_gpu_raycast_parity.py -q -m gpu -x > gpurun_out/pt.log 2>&1; grep -E "passed|failed|error" gpurun_out/pt.log | tail -3; grep -E "^(FAILED|ERROR)" gpurun_out/pt.log | head -20
+timeout 600 python -m pytest tests/test_gpu_raycast_parity.py -q -m gpu -x -k "long_rays or frames_counts" > gpurun_out/pt.log 2>&1; echo "rc=$?"; grep -E "passed|failed|rror" gpurun_out/pt.log | tail -8
