@@ -1045,9 +1045,12 @@ void DenseMap::reset_stats_counters(bool lists) {
 }
 
 void DenseMap::collect_stats(fiesta_hip_stats *st) {
-  FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, stream_));
-  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (!h_counters_fresh_) {  // (the last chain of rounds brought the counters with it and nothing ran since)
+    FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+  h_counters_fresh_ = false;
   if (st) {
     st->invalidated = (int64_t)h_counters_[C_INVALIDATED];
     st->sweeps = (int64_t)h_counters_[C_SWEEPS];
@@ -1069,7 +1072,8 @@ hipEvent_t DenseMap::pool_event(size_t i) {
 void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list) {
   int cur = first_list;
   uint32_t ncur = first_count;
-  int64_t rounds = 0, device_rounds = -1, spatial_rounds = 0;  // launches; rounds that found work (counted on the device)
+  int64_t launches = 0, device_rounds = -1, spatial_rounds = 0;  // rounds that found work are counted on the device
+  size_t nev = 0;  // event pairs: one per spatial round, one per chain
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   serial_ += 2;  // no stamp of an earlier update may validate this update's first round
   // one round of the work-queue engine: active tiles of list/flags `cur_list` -> `cur_list ^ 1`
@@ -1100,57 +1104,61 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     a.prof = prof_;
     a.dir = nullptr;
     a.spatial = spatial;
-    // spatial walk: a multiple of 8 blocks (one stream per XCD), a few per CU for load balance
+    // spatial walk: a multiple of 8 blocks (one stream per XCD), a few per CU for load balance.  A round of a chain: one
+    // work-group per CU striding over the list -- the tile's keys fill a CU's LDS, so more work-groups than CUs only
+    // queue, and a round that finds its list empty should cost as little as a launch can.
     const int blocks = spatial ? (int)std::min<uint32_t>((uint32_t)((ntiles_ + 7) / 8 * 8), (uint32_t)spatial_blocks_)
-                       : n_dev ? (int)std::min<uint32_t>(16384u, std::max<uint32_t>(256u, 4u * ncur))
+                       : n_dev ? 256
                                : (int)std::min<uint32_t>(n_host, 16384u);
-    FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds), stream_));
     if (track_)
       hipLaunchKernelGGL((k_relax_q<16, 16, 1024, false, true>), dim3(blocks), dim3(1024), 0, stream_, a);
     else
       hipLaunchKernelGGL((k_relax_q<16, 16, 1024>), dim3(blocks), dim3(1024), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
-    FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * rounds + 1), stream_));
-    ++rounds;
+    ++launches;
   };
   const bool unknown = first_count == kCountOnDevice;  // small update: nobody has read the length of the first list
   while (ncur) {
-    const int nxt = cur ^ 1;
     // Large updates walk all tiles in XCD-chunked spatial order, one round per host round trip.  Small ones (few active
-    // tiles: depth frames) use the compact list and go out in chains of kChain rounds, each reading the length of its
-    // list on the device and doing nothing once a predecessor activated no tile: ONE host round trip per chain instead
-    // of one per round (a depth frame's update is a handful of ~10 us kernels; the round trips were most of its time).
+    // tiles: depth frames) use the compact list and go out in chains, each round reading the length of its list on the
+    // device and doing nothing once a predecessor activated no tile: ONE host round trip per chain instead of one per
+    // round (a depth frame's update is a handful of short kernels; the round trips were most of its time).  A chain is
+    // as long as the previous update's rounds plus one: consecutive frames of a sensor need about the same number.
+    FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * nev), stream_));
     if (!unknown && spatial_ && ncur >= (uint32_t)list_threshold_) {
       launch_q(cur, ncur, nullptr, 1);
+      FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * nev + 1), stream_));
+      ++nev;
       ++spatial_rounds;
-      ncur = (uint32_t)read_counter(C_LIST0 + nxt);
-      cur = nxt;
+      cur ^= 1;
+      ncur = (uint32_t)read_counter(C_LIST0 + cur);
     } else {
-      constexpr int kChain = 4;
-      if (unknown) ncur = 256;  // (sizes the grids of the chain: 1024 work-groups striding over the list)
-      const int64_t before = rounds;
-      for (int k = 0; k < kChain; ++k) launch_q((k & 1) ? nxt : cur, 0, &counters_[C_LIST0 + ((k & 1) ? nxt : cur)], 0);
-      FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_LIST0], &counters_[C_LIST0], 2 * sizeof(unsigned long long),
-                                      hipMemcpyDeviceToHost, stream_));
-      FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_ROUNDS], &counters_[C_ROUNDS], sizeof(unsigned long long),
-                                      hipMemcpyDeviceToHost, stream_));
+      const int chain = device_rounds < 0 ? std::min(std::max(chain_hint_, 2), 12) : 4;
+      for (int k = 0; k < chain; ++k) {
+        launch_q(cur, 0, &counters_[C_LIST0 + cur], 0);
+        cur ^= 1;
+      }
+      FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * nev + 1), stream_));
+      ++nev;
+      // (everything collect_stats wants is in this copy too: an update that ends here needs no second round trip)
+      FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
       FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-      // kChain is even: the chain ends with list `cur` as the next input
       ncur = (uint32_t)h_counters_[C_LIST0 + cur];
       device_rounds = (int64_t)h_counters_[C_ROUNDS];
-      (void)before;
+      h_counters_fresh_ = ncur == 0;
     }
   }
+  if (device_rounds >= 0) chain_hint_ = (int)device_rounds + 1;
   if (st) {
-    st->rounds = device_rounds >= 0 ? device_rounds + spatial_rounds : rounds;
+    st->rounds = device_rounds >= 0 ? device_rounds + spatial_rounds : launches;
     double sum = 0;
-    for (int64_t r = 0; r < rounds; ++r) {
+    for (size_t r = 0; r < nev; ++r) {
       float ms = 0;
       FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, evpool_[2 * r], evpool_[2 * r + 1]));
       sum += ms;
     }
     st->relax_ms = sum;
-    st->relax_launches = rounds;
+    st->relax_launches = launches;
   }
 }
 
@@ -1387,8 +1395,8 @@ bool DenseMap::bulk_spilled_untiered() {
 
 // After a successful bulk transform: the queues are consumed, timings and counters reported.
 void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
-  zero_counter(C_INSERT);
-  zero_counter(C_DELETE);
+  static_assert(C_DELETE == C_INSERT + 1, "counter layout");
+  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INSERT], 0, 2 * sizeof(unsigned long long), stream_));  // both queues are drained
   host_counts_[0] = host_counts_[1] = 0;
   if (g_.sharded) zero_counter(C_REMOTE_DEL);
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
@@ -1514,8 +1522,8 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
                        &counters_[C_LIST0], counters_, bounded);
     FIESTA_HIP_CHECK(hipGetLastError());
   }
-  zero_counter(C_INSERT);
-  zero_counter(C_DELETE);
+  static_assert(C_DELETE == C_INSERT + 1, "counter layout");
+  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INSERT], 0, 2 * sizeof(unsigned long long), stream_));  // both queues are drained
   host_counts_[0] = host_counts_[1] = 0;
   if (g_.sharded) zero_counter(C_REMOTE_DEL);
   if (seed_only) {  // sharded driver: ghost exchange comes next, then relax_pending()

@@ -258,35 +258,36 @@ __global__ void k_h_count_updated(Geom g, const int32_t *dir, const int32_t *pag
 __global__ void k_h_fuse(Geom g, ProbParams pp, int global_map, const int32_t *page_tile, const uint32_t *touched,
                          int64_t n, unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *ins,
                          uint32_t *del, unsigned long long *counters) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t a = touched[i];
-  const unsigned long long c = cnt[a];
-  cnt[a] = 0;
-  const int64_t hits = (int64_t)(int32_t)(c >> 32), seen = (int64_t)(uint32_t)c;
-  const double step = (hits >= seen - hits) ? pp.l_hit : pp.l_miss;
-  double L = logodds[a];
-  const bool was = L > pp.l_occ;
-  if (coc[a] == kUnobserved) coc[a] = kInf;
-  if ((step >= 0 && L >= pp.l_max) || (step <= 0 && L <= pp.l_min)) return;
-  if (!global_map && page_tile[a / kPageVox] >= 0) {  // (a page parked since the observation fuses like a global map's)
-    int x, y, z;
-    vcoords(page_tile, a, x, y, z);
-    if (!g.in_prev_window(x, y, z)) {  // (distance = infinity, the link stays: common.hpp, stale_link)
-      L = 0;
-      coc[a] = stale_link(coc[a]);
+  if (n < 0) n = (int64_t)counters[C_TOUCHED];  // the host only knows an upper bound (it sized the grid with it)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t a = touched[i];
+    const unsigned long long c = cnt[a];
+    cnt[a] = 0;
+    const int64_t hits = (int64_t)(int32_t)(c >> 32), seen = (int64_t)(uint32_t)c;
+    const double step = (hits >= seen - hits) ? pp.l_hit : pp.l_miss;
+    double L = logodds[a];
+    const bool was = L > pp.l_occ;
+    if (coc[a] == kUnobserved) coc[a] = kInf;
+    if ((step >= 0 && L >= pp.l_max) || (step <= 0 && L <= pp.l_min)) continue;
+    if (!global_map && page_tile[a / kPageVox] >= 0) {  // (a page parked since the observation fuses like a global map's)
+      int x, y, z;
+      vcoords(page_tile, a, x, y, z);
+      if (!g.in_prev_window(x, y, z)) {  // (distance = infinity, the link stays: common.hpp, stale_link)
+        L = 0;
+        coc[a] = stale_link(coc[a]);
+      }
     }
-  }
-  L = fmin(fmax(L + step, pp.l_min), pp.l_max);
-  logodds[a] = L;
-  const bool now = L > pp.l_occ;
-  const uint32_t bit = 1u << (a & 31);
-  if (now && !was) {
-    atomicOr(&occbits[a >> 5], bit);
-    wave_append(true, a, ins, &counters[C_INSERT]);  // one atomic per wave on the hot counter
-  } else if (!now && was) {
-    atomicAnd(&occbits[a >> 5], ~bit);
-    wave_append(true, a, del, &counters[C_DELETE]);
+    L = fmin(fmax(L + step, pp.l_min), pp.l_max);
+    logodds[a] = L;
+    const bool now = L > pp.l_occ;
+    const uint32_t bit = 1u << (a & 31);
+    if (now && !was) {
+      atomicOr(&occbits[a >> 5], bit);
+      wave_append(true, a, ins, &counters[C_INSERT]);  // one atomic per wave on the hot counter
+    } else if (!now && was) {
+      atomicAnd(&occbits[a >> 5], ~bit);
+      wave_append(true, a, del, &counters[C_DELETE]);
+    }
   }
 }
 
@@ -675,6 +676,7 @@ void HashMap::checkpoint(const char *path, bool write) {
   dropped_host_ = meta[2];
   force_scan_ = meta[3] != 0;
   touched_upper_ = (int64_t)nt;
+  host_queues_valid_ = false;
   shadow_vox_ = -1;
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -938,27 +940,31 @@ bool HashMap::check_update() {
 
 bool HashMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
   use_device();
-  const unsigned long long nt = touched_upper_ ? read_counter(C_TOUCHED) : 0;
-  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-  unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
+  // ONE host synchronisation per call (none when nothing was observed): the host keeps the queue lengths of its last
+  // read and an upper bound of the touched list; the fusion kernel reads the exact length itself.
+  if (!host_queues_valid_) {
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    host_ni_ = h_counters_[C_INSERT], host_nd_ = h_counters_[C_DELETE];
+    host_queues_valid_ = true;
+  }
+  const unsigned long long nt = (unsigned long long)touched_upper_;
   if (nt) {
-    ins_.ensure(ni + nt, stream_, ni);
-    del_.ensure(nd + nt, stream_, nd);
-    hipLaunchKernelGGL(k_h_fuse, dim3(grid_for((int64_t)nt)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
-                       (const int32_t *)page_tile_.p, (const uint32_t *)touched_.p, (int64_t)nt, cnt_.p, logodds_.p, coc_.p,
+    ins_.ensure(host_ni_ + nt, stream_, host_ni_);
+    del_.ensure(host_nd_ + nt, stream_, host_nd_);
+    hipLaunchKernelGGL(k_h_fuse, dim3(grid_for((int64_t)nt, 256, 8192)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
+                       (const int32_t *)page_tile_.p, (const uint32_t *)touched_.p, (int64_t)-1, cnt_.p, logodds_.p, coc_.p,
                        occbits_.p, ins_.p, del_.p, counters_);
     FIESTA_HIP_CHECK(hipGetLastError());
     zero_counter(C_TOUCHED);
     touched_upper_ = 0;
     FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-    ni = h_counters_[C_INSERT];
-    nd = h_counters_[C_DELETE];
+    host_ni_ = h_counters_[C_INSERT], host_nd_ = h_counters_[C_DELETE];
   }
-  if (n_ins) *n_ins = (int64_t)ni;
-  if (n_del) *n_del = (int64_t)nd;
-  return ni != 0 || nd != 0;
+  if (n_ins) *n_ins = (int64_t)host_ni_;
+  if (n_del) *n_del = (int64_t)host_nd_;
+  return host_ni_ != 0 || host_nd_ != 0;
 }
 
 void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
@@ -996,31 +1002,37 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
     a.prof = prof_;
     a.dir = dir_;
     a.spatial = 0;
-    const uint32_t blocks = n_dev ? std::min<uint32_t>(16384u, std::max<uint32_t>(256u, 4u * ncur)) : std::min<uint32_t>(n_host, 16384u);
+    // (a round of a chain: one work-group per CU striding over the list -- a tile's keys fill a CU's LDS, more work-groups
+    //  only queue, and a round that finds its list empty should cost as little as a launch can)
+    const uint32_t blocks = n_dev ? 256u : std::min<uint32_t>(n_host, 16384u);
     hipLaunchKernelGGL((k_relax_q<kTX, kTY, 1024, true>), dim3(blocks), dim3(1024), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
   };
-  // Rounds go out in chains of kChain: every round reads the length of its list on the device and does nothing once a
-  // predecessor activated no tile -- one host round trip per chain (a streaming frame's update is a handful of ~10 us
-  // kernels; the round trips were most of its time).  first_count == 0xFFFFFFFF: nobody read the first list's length.
+  // Rounds go out in chains: every round reads the length of its list on the device and does nothing once a
+  // predecessor activated no tile -- one host round trip per chain (a streaming frame's update is a handful of short
+  // kernels; the round trips were most of its time).  The first chain is as long as the previous update's rounds plus
+  // one.  first_count == 0xFFFFFFFF: nobody read the first list's length.
   if (ncur == 0xFFFFFFFFu) ncur = 256;
+  bool first = true;
   while (ncur) {
-    constexpr int kChain = 4;
-    const int nxt = cur ^ 1;
+    const int chain = first ? std::min(std::max(chain_hint_, 2), 12) : 4;
+    first = false;
     FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
-    for (int k = 0; k < kChain; ++k) launch((k & 1) ? nxt : cur, 0, &counters_[C_LIST0 + ((k & 1) ? nxt : cur)]);
+    for (int k = 0; k < chain; ++k) {
+      launch(cur, 0, &counters_[C_LIST0 + cur]);
+      cur ^= 1;
+    }
     FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
-    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_LIST0], &counters_[C_LIST0], 2 * sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, stream_));
-    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_ROUNDS], &counters_[C_ROUNDS], sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, stream_));
+    // (the whole block: an update that ends with this chain has its statistics with it)
+    FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-    ncur = (uint32_t)h_counters_[C_LIST0 + cur];  // (kChain is even: the lists are back in place)
+    ncur = (uint32_t)h_counters_[C_LIST0 + cur];
     rounds = (int64_t)h_counters_[C_ROUNDS];
     float ms = 0;
     FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
     relax_ms += ms;
   }
+  chain_hint_ = (int)rounds + 1;
   if (st) {
     st->rounds = rounds;
     st->relax_ms = relax_ms;
@@ -1031,20 +1043,23 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
 void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const auto h0 = std::chrono::steady_clock::now();
-  // C_INSERT, C_DELETE, (C_OBSERVED, C_NOCC,) C_DROPPED are adjacent: one copy, one synchronisation
-  FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-  FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-  const unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
+  // the queue lengths as UpdateOccupancy read them (nothing else appends); C_DROPPED comes with the statistics
+  if (!host_queues_valid_) {
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    host_ni_ = h_counters_[C_INSERT], host_nd_ = h_counters_[C_DELETE];
+    host_queues_valid_ = true;
+  }
+  const unsigned long long ni = host_ni_, nd = host_nd_;
   if (st) {
     memset(st, 0, sizeof(*st));
     st->inserted = (int64_t)ni;
     st->deleted = (int64_t)nd;
-    st->dropped_observations = (int64_t)h_counters_[C_DROPPED] + dropped_host_;
   }
   if (ni || nd || force_scan_) {
     ++epoch_;
-    FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INVALIDATED], 0, (C_COUNT - C_INVALIDATED) * sizeof(unsigned long long), stream_));
-    zero_counter(C_LIST0);
+    static_assert(C_LIST1 == C_LIST0 + 1 && C_INVALIDATED == C_LIST1 + 1, "counter layout");
+    FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_LIST0], 0, (C_COUNT - C_LIST0) * sizeof(unsigned long long), stream_));
     if (ni) {
       hipLaunchKernelGGL(k_h_seed_insert, dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, g_, (const int32_t *)page_tile_.p,
                          (const uint32_t *)ins_.p, (int64_t)ni, coc_.p, (const uint32_t *)occbits_.p, tile_flag_[0], tile_list_[0],
@@ -1060,12 +1075,11 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
       if (force_scan_) FIESTA_HIP_CHECK(hipMemsetAsync(page_fresh_.p, 0, (size_t)npages_ * sizeof(uint32_t), stream_));
       force_scan_ = false;
     }
-    zero_counter(C_INSERT);
-    zero_counter(C_DELETE);
+    static_assert(C_DELETE == C_INSERT + 1, "counter layout");
+    FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INSERT], 0, 2 * sizeof(unsigned long long), stream_));  // both queues are drained
+    host_ni_ = host_nd_ = 0;
     const auto d0 = std::chrono::steady_clock::now();
-    run_rounds(st, 0xFFFFFFFFu);  // (the chain of rounds finds the seeded tiles' count on the device)
-    FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    run_rounds(st, 0xFFFFFFFFu);  // (the chain of rounds finds the seeded tiles' count on the device and brings the counters back)
     if (st) {
       st->invalidated = (int64_t)h_counters_[C_INVALIDATED];
       st->sweeps = (int64_t)h_counters_[C_SWEEPS];
@@ -1073,7 +1087,10 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
       st->tile_visits = (int64_t)h_counters_[C_VISITS];
       for (int k = 0; k < 8; ++k) st->prof[k] = (int64_t)h_counters_[C_PROF0 + k];
       st->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
+      st->dropped_observations = (int64_t)h_counters_[C_DROPPED] + dropped_host_;
     }
+  } else if (st) {
+    st->dropped_observations = (int64_t)read_counter(C_DROPPED) + dropped_host_;
   }
   if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
 }

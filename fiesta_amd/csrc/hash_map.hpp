@@ -122,6 +122,9 @@ class HashMap {
 
   DevBuf<uint32_t> touched_, ins_, del_;
   int64_t touched_upper_ = 0;
+  unsigned long long host_ni_ = 0, host_nd_ = 0;  // insert / delete queue lengths as last read
+  bool host_queues_valid_ = false;
+  int chain_hint_ = 4;  // rounds in the first chain of the next update (the previous update's count + 1)
   int64_t dropped_host_ = 0;  // voxels of observe_box() requests clipped away by the window (added to C_DROPPED in stats)
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   DevBuf<unsigned char> stage_a_, stage_b_, stage_c_, stage_d_;
