@@ -1139,6 +1139,7 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
         cur ^= 1;
       }
       FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * nev + 1), stream_));
+      last_chain_event_ = evpool_[2 * nev + 1];
       ++nev;
       // (everything collect_stats wants is in this copy too: an update that ends here needs no second round trip)
       FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
@@ -1534,21 +1535,30 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   // a small delta (a depth frame): do not even read how many tiles were seeded, the chain of rounds finds out on the device
   const uint32_t n0 = (ni + nd <= (unsigned long long)small_update_ && !remote_del) ? kCountOnDevice : (uint32_t)read_counter(C_LIST0);
   run_rounds(st, n0, 0);
+  bool reseeded = false;
   {  // orphans outside the update window (local / sliding-window maps): their pull, after the rounds
     const Geom &g = g_;
     const bool win_all = g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1;
     if (!win_all && (nd || remote_del)) {
+      reseeded = true;
       hipLaunchKernelGGL(k_reseed_outside, dim3(grid_for(g_.n, 256, 8192)), dim3(256), 0, stream_, g_, coc_, (const uint32_t *)occbits_,
                          (const uint32_t *)gocc_, (const unsigned long long *)counters_, (track_ && nd) ? 1 : 0);
       FIESTA_HIP_CHECK(hipGetLastError());
     }
   }
-  FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
-  collect_stats(st);
-  FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  // (an update that ended with a chain of rounds is already synchronised and has its counters: its last event is the end)
+  hipEvent_t end = ev1_;
+  if (h_counters_fresh_ && !reseeded && last_chain_event_) {
+    end = last_chain_event_;
+    collect_stats(st);
+  } else {
+    FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
+    collect_stats(st);
+    FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  }
   if (st) {
     float ms = 0;
-    FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, end));
     st->device_ms = ms;
     st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
   }

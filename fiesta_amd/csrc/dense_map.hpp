@@ -233,6 +233,7 @@ class DenseMap {
   int bound_scan_ = 1;  // bound the delete scan by the delete queue's box + the largest stored distance (FIESTA_HIP_BOUND_SCAN=0: whole grid)
   static constexpr uint32_t kCountOnDevice = 0xFFFFFFFFu;  // run_rounds: the first list's length was never read
   int chain_hint_ = 4;             // rounds per chain of the next small update (the previous one's count + 1)
+  hipEvent_t last_chain_event_ = nullptr;  // recorded after the last round of the last chain
   bool h_counters_fresh_ = false;  // h_counters_ holds the device counters as of the end of the last chain
   int small_update_ = 4096;  // updates with at most this many inserts + deletes skip that read (FIESTA_HIP_SMALL_UPDATE)
   int list_threshold_ = 1024;  // updates that start with fewer active tiles use the compact list + paired rounds
