@@ -901,9 +901,11 @@ unsigned long long DenseMap::read_counter(int which) {
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   return h_counters_[which];
 }
-void DenseMap::zero_counter(int which) {
-  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[which], 0, sizeof(unsigned long long), stream_));
+void DenseMap::zero_counters(int first, int n) {
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream_, &counters_[first], n);
+  FIESTA_HIP_CHECK(hipGetLastError());
 }
+void DenseMap::zero_counter(int which) { zero_counters(which, 1); }
 
 void DenseMap::ensure_touched_capacity(int64_t extra) {
   touched_upper_ = std::min<int64_t>(g_.n, touched_upper_ + extra);
@@ -1038,9 +1040,9 @@ void DenseMap::enable_distance_tracking() {
 
 // ONE memset: the statistics, the transform's spill counters and -- at the start of an update (lists) -- the tile-list counters
 void DenseMap::reset_stats_counters(bool lists) {
-  static_assert(C_LIST1 == C_LIST0 + 1 && C_INVALIDATED == C_LIST1 + 1 && C_FT_MAXD2 < C_COUNT, "counter layout");
+  static_assert(C_LIST2 == C_LIST0 + 2 && C_INVALIDATED == C_LIST2 + 1 && C_FT_MAXD2 < C_COUNT, "counter layout");
   const int first = lists ? C_LIST0 : C_INVALIDATED;
-  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[first], 0, (C_COUNT - first) * sizeof(unsigned long long), stream_));
+  zero_counters(first, C_COUNT - first);
   ft_counters_clean_ = true;
 }
 
@@ -1074,12 +1076,14 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
   uint32_t ncur = first_count;
   int64_t launches = 0, device_rounds = -1, spatial_rounds = 0;  // rounds that found work are counted on the device
   size_t nev = 0;  // event pairs: one per spatial round, one per chain
+  bool lists_dirty = false;
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   serial_ += 2;  // no stamp of an earlier update may validate this update's first round
   // one round of the work-queue engine: active tiles of list/flags `cur_list` -> `cur_list ^ 1`
-  auto launch_q = [&](const int cur_list, const uint32_t n_host, const unsigned long long *n_dev, const int spatial) {
+  auto launch_q = [&](const int cur_list, const uint32_t n_host, const bool n_on_device, const int spatial) {
     const int nxt = cur_list ^ 1;
-    zero_counter(C_LIST0 + nxt);
+    const int c_in = C_LIST0 + (int)(launches % 3), c_out = C_LIST0 + (int)((launches + 1) % 3), c_zero = C_LIST0 + (int)((launches + 2) % 3);
+    const unsigned long long *n_dev = n_on_device ? &counters_[c_in] : nullptr;
     ++serial_;
     RelaxQArgs a;
     a.g = g_;
@@ -1099,7 +1103,8 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     a.flag_cur = tile_flag_[cur_list];
     a.flag_next = tile_flag_[nxt];
     a.list_next = tile_list_[nxt];
-    a.count_next = &counters_[C_LIST0 + nxt];
+    a.count_next = &counters_[c_out];
+    a.count_zero = &counters_[c_zero];
     a.counters = counters_;
     a.prof = prof_;
     a.dir = nullptr;
@@ -1126,16 +1131,17 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
     // as long as the previous update's rounds plus one: consecutive frames of a sensor need about the same number.
     FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * nev), stream_));
     if (!unknown && spatial_ && ncur >= (uint32_t)list_threshold_) {
-      launch_q(cur, ncur, nullptr, 1);
+      launch_q(cur, ncur, false, 1);
       FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * nev + 1), stream_));
       ++nev;
       ++spatial_rounds;
       cur ^= 1;
-      ncur = (uint32_t)read_counter(C_LIST0 + cur);
+      ncur = (uint32_t)read_counter(C_LIST0 + (int)(launches % 3));
+      lists_dirty = true;  // (the round's own input counter is still set)
     } else {
       const int chain = device_rounds < 0 ? std::min(std::max(chain_hint_, 2), 12) : 4;
       for (int k = 0; k < chain; ++k) {
-        launch_q(cur, 0, &counters_[C_LIST0 + cur], 0);
+        launch_q(cur, 0, true, 0);
         cur ^= 1;
       }
       FIESTA_HIP_CHECK(hipEventRecord(pool_event(2 * nev + 1), stream_));
@@ -1144,11 +1150,14 @@ void DenseMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_
       // (everything collect_stats wants is in this copy too: an update that ends here needs no second round trip)
       FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
       FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-      ncur = (uint32_t)h_counters_[C_LIST0 + cur];
+      ncur = (uint32_t)h_counters_[C_LIST0 + (int)(launches % 3)];
       device_rounds = (int64_t)h_counters_[C_ROUNDS];
       h_counters_fresh_ = ncur == 0;
+      // (a chain that ends on a round with work leaves that round's input counter set; trailing idle rounds clear it)
+      lists_dirty = h_counters_[C_LIST0] || h_counters_[C_LIST1] || h_counters_[C_LIST2];
     }
   }
+  if (lists_dirty) zero_counters(C_LIST0, 3);  // between updates the three list counters are zero
   if (device_rounds >= 0) chain_hint_ = (int)device_rounds + 1;
   if (st) {
     st->rounds = device_rounds >= 0 ? device_rounds + spatial_rounds : launches;
@@ -1397,7 +1406,7 @@ bool DenseMap::bulk_spilled_untiered() {
 // After a successful bulk transform: the queues are consumed, timings and counters reported.
 void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
   static_assert(C_DELETE == C_INSERT + 1, "counter layout");
-  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INSERT], 0, 2 * sizeof(unsigned long long), stream_));  // both queues are drained
+  zero_counters(C_INSERT, 2);  // both queues are drained
   host_counts_[0] = host_counts_[1] = 0;
   if (g_.sharded) zero_counter(C_REMOTE_DEL);
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
@@ -1524,7 +1533,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     FIESTA_HIP_CHECK(hipGetLastError());
   }
   static_assert(C_DELETE == C_INSERT + 1, "counter layout");
-  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INSERT], 0, 2 * sizeof(unsigned long long), stream_));  // both queues are drained
+  zero_counters(C_INSERT, 2);  // both queues are drained
   host_counts_[0] = host_counts_[1] = 0;
   if (g_.sharded) zero_counter(C_REMOTE_DEL);
   if (seed_only) {  // sharded driver: ghost exchange comes next, then relax_pending()
@@ -1839,7 +1848,7 @@ void DenseMap::snapshot_restore(int slot) {
   }
   unsigned long long c[C_COUNT];
   memcpy(c, s.counters, sizeof(c));
-  c[C_LIST0] = c[C_LIST1] = 0;
+  c[C_LIST0] = c[C_LIST1] = c[C_LIST2] = 0;
   memcpy(h_counters_, c, sizeof(c));
   FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
   touched_upper_ = (int64_t)nt;
@@ -1908,7 +1917,7 @@ void DenseMap::checkpoint(const char *path, bool write) {
   f.device(del_.p, nd * sizeof(uint32_t));
   f.finish();
   if (write) return;
-  c[C_LIST0] = c[C_LIST1] = 0;
+  c[C_LIST0] = c[C_LIST1] = c[C_LIST2] = 0;
   memcpy(h_counters_, c, sizeof(c));
   FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
   touched_upper_ = (int64_t)nt;

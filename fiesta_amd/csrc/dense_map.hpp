@@ -47,8 +47,9 @@ enum Counter {
   C_MAXD2,         // upper bound of every finite d^2 the work-queue engine ever stored (bounds the delete scan)
   C_DBOX0,         // bounding box of the pending delete queue, local voxel coordinates: min x,y,z then max x,y,z
   C_DBOX5 = C_DBOX0 + 5,
-  C_LIST0,         // active-tile list, even rounds
-  C_LIST1,         // active-tile list, odd rounds
+  C_LIST0,         // lengths of the active-tile lists: round r of an update reads counter r % 3, appends to (r + 1) % 3
+  C_LIST1,         //   and clears (r + 2) % 3 (consumed by round r - 1, needed empty by round r + 1): no memset between rounds.
+  C_LIST2,         //   Between updates pending tiles sit in list 0 / C_LIST0 and the other two are zero.
   C_INVALIDATED,   // stats
   C_SWEEPS,
   C_WRITES,
@@ -172,6 +173,7 @@ class DenseMap {
   void use_device() const;
   unsigned long long read_counter(int which);
   void zero_counter(int which);
+  void zero_counters(int first, int n);
   void ensure_touched_capacity(int64_t extra);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list);
   bool bulk_eligible(unsigned long long ni, unsigned long long nd);

@@ -666,7 +666,7 @@ void HashMap::checkpoint(const char *path, bool write) {
   f.device(del_.p, nd * sizeof(uint32_t));
   f.finish();
   if (write) return;
-  c[C_LIST0] = c[C_LIST1] = 0;
+  c[C_LIST0] = c[C_LIST1] = c[C_LIST2] = 0;
   memcpy(h_counters_, c, sizeof(c));
   FIESTA_HIP_CHECK(hipMemcpyAsync(counters_, h_counters_, sizeof(c), hipMemcpyHostToDevice, stream_));
   for (uint32_t *p : {need_, tile_epoch_, cstamp_[0], cstamp_[1], tile_flag_[0], tile_flag_[1]})
@@ -686,9 +686,11 @@ unsigned long long HashMap::read_counter(int which) {
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   return h_counters_[which];
 }
-void HashMap::zero_counter(int which) {
-  FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[which], 0, sizeof(unsigned long long), stream_));
+void HashMap::zero_counters(int first, int n) {
+  hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream_, &counters_[first], n);
+  FIESTA_HIP_CHECK(hipGetLastError());
 }
+void HashMap::zero_counter(int which) { zero_counters(which, 1); }
 
 void HashMap::set_prob_params(double p_hit, double p_miss, double p_min, double p_max, double p_occ) {
   auto logit = [](double x) { return std::log(x / (1 - x)); };
@@ -975,9 +977,13 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
   TileGrid tg{kTX, kTY, kNTX, kNTY, kNTZ};
   serial_ += 2;
   // one round: the active-tile list `cur` (length known to the host, or read on the device) -> list `cur ^ 1`
-  auto launch = [&](const int cur_list, const uint32_t n_host, const unsigned long long *n_dev) {
+  int64_t launches = 0;
+  auto launch = [&](const int cur_list) {
     const int nxt = cur_list ^ 1;
-    zero_counter(C_LIST0 + nxt);
+    // list counters rotate (dense_map.hpp, C_LIST0): no memset between rounds
+    const int c_in = C_LIST0 + (int)(launches % 3), c_out = C_LIST0 + (int)((launches + 1) % 3), c_zero = C_LIST0 + (int)((launches + 2) % 3);
+    const unsigned long long *n_dev = &counters_[c_in];
+    ++launches;
     ++serial_;
     RelaxQArgs a;
     a.g = g_;
@@ -992,19 +998,20 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
     a.cstamp_cur = cstamp_[serial_ & 1];
     a.serial = serial_;
     a.list_cur = tile_list_[cur_list];
-    a.n_cur = n_host;
+    a.n_cur = 0;
     a.n_cur_dev = n_dev;
     a.flag_cur = tile_flag_[cur_list];
     a.flag_next = tile_flag_[nxt];
     a.list_next = tile_list_[nxt];
-    a.count_next = &counters_[C_LIST0 + nxt];
+    a.count_next = &counters_[c_out];
+    a.count_zero = &counters_[c_zero];
     a.counters = counters_;
     a.prof = prof_;
     a.dir = dir_;
     a.spatial = 0;
     // (a round of a chain: one work-group per CU striding over the list -- a tile's keys fill a CU's LDS, more work-groups
     //  only queue, and a round that finds its list empty should cost as little as a launch can)
-    const uint32_t blocks = n_dev ? 256u : std::min<uint32_t>(n_host, 16384u);
+    const uint32_t blocks = 256u;
     hipLaunchKernelGGL((k_relax_q<kTX, kTY, 1024, true>), dim3(blocks), dim3(1024), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
   };
@@ -1019,19 +1026,21 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
     first = false;
     FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
     for (int k = 0; k < chain; ++k) {
-      launch(cur, 0, &counters_[C_LIST0 + cur]);
+      launch(cur);
       cur ^= 1;
     }
     FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
     // (the whole block: an update that ends with this chain has its statistics with it)
     FIESTA_HIP_CHECK(hipMemcpyAsync(h_counters_, counters_, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-    ncur = (uint32_t)h_counters_[C_LIST0 + cur];
+    ncur = (uint32_t)h_counters_[C_LIST0 + (int)(launches % 3)];
     rounds = (int64_t)h_counters_[C_ROUNDS];
     float ms = 0;
     FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
     relax_ms += ms;
   }
+  // (a chain that ends on a round with work leaves that round's input counter set; trailing idle rounds clear it)
+  if (h_counters_[C_LIST0] || h_counters_[C_LIST1] || h_counters_[C_LIST2]) zero_counters(C_LIST0, 3);
   chain_hint_ = (int)rounds + 1;
   if (st) {
     st->rounds = rounds;
@@ -1058,8 +1067,8 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
   }
   if (ni || nd || force_scan_) {
     ++epoch_;
-    static_assert(C_LIST1 == C_LIST0 + 1 && C_INVALIDATED == C_LIST1 + 1, "counter layout");
-    FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_LIST0], 0, (C_COUNT - C_LIST0) * sizeof(unsigned long long), stream_));
+    static_assert(C_LIST2 == C_LIST0 + 2 && C_INVALIDATED == C_LIST2 + 1, "counter layout");
+    zero_counters(C_LIST0, C_COUNT - C_LIST0);
     if (ni) {
       hipLaunchKernelGGL(k_h_seed_insert, dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, g_, (const int32_t *)page_tile_.p,
                          (const uint32_t *)ins_.p, (int64_t)ni, coc_.p, (const uint32_t *)occbits_.p, tile_flag_[0], tile_list_[0],
@@ -1076,7 +1085,7 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
       force_scan_ = false;
     }
     static_assert(C_DELETE == C_INSERT + 1, "counter layout");
-    FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_INSERT], 0, 2 * sizeof(unsigned long long), stream_));  // both queues are drained
+    zero_counters(C_INSERT, 2);  // both queues are drained
     host_ni_ = host_nd_ = 0;
     const auto d0 = std::chrono::steady_clock::now();
     run_rounds(st, 0xFFFFFFFFu);  // (the chain of rounds finds the seeded tiles' count on the device and brings the counters back)

@@ -86,6 +86,7 @@ class HashMap {
   bool allocate_marked();
   unsigned long long read_counter(int which);
   void zero_counter(int which);
+  void zero_counters(int first, int n);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count);
   void free_raycast_state();
   struct RaycastState;

@@ -12,6 +12,13 @@ __device__ inline bool occ_test(const uint32_t *occbits, const Geom &g, int x, i
   return (occbits[g.bitword(x, y, z)] >> (z & 31)) & 1u;
 }
 
+// a few 64-bit counters to zero: ONE small kernel (a memset of an unaligned range goes out as up to three)
+namespace {  // (this header is included by two translation units)
+__global__ void k_zero_words(unsigned long long *p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+}  // namespace
+
 struct TileGrid {
   int tx, ty;  // tile extent in x and y (z extent is 32)
   int ntx, nty, ntz;
@@ -64,6 +71,7 @@ struct RelaxQArgs {
   uint32_t *flag_next;
   uint32_t *list_next;
   unsigned long long *count_next;
+  unsigned long long *count_zero;  // the list counter nobody uses during this round: cleared here for the round after next
   unsigned long long *counters;
   int spatial;  // dense maps: 1 = walk all tiles in XCD-chunked spatial order (flag_cur is the list)
   int prof;  // 1: accumulate per-phase cycle counters into counters[C_PROF0..]
@@ -114,6 +122,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
   const uint32_t ntiles = (uint32_t)(a.tg.ntx * a.tg.nty * a.tg.ntz);
   const uint32_t n_list = a.n_cur_dev ? (uint32_t)*a.n_cur_dev : a.n_cur;
   if (a.n_cur_dev && n_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.counters[C_ROUNDS], 1ull);
+  if (a.count_zero && blockIdx.x == 0 && threadIdx.x == 0) *a.count_zero = 0;
   // statistics are summed per work-group and flushed once after the walk (tens of thousands of visits would
   // otherwise queue their atomics on three hot addresses)
   uint32_t acc_writes = 0, acc_levels = 0, acc_visits = 0, acc_maxd2 = 0;
