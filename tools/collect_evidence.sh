@@ -2,14 +2,18 @@
 # Reproduces the files under profiles/ for one round tag (run ON a GPU box, from the repo root):
 #     tools/collect_evidence.sh r02a
 # rocprofv3 wants a writable TMPDIR; counters are collected in their own passes (never together with sys/hip traces).
-set -euo pipefail
+set -uo pipefail
 TAG=${1:?round tag, e.g. r02a}
 R=gpurun_out/$TAG
 mkdir -p "$R"
 export TMPDIR=/tmp
-# C2 headline under the kernel trace (the JSON line carries roofline + cpu_baseline)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -o bench -- python bench.py > "$R/bench_default.log" 2>&1
+# FIESTA_REV=<commit> in the environment is recorded in the traffic summary (the GPU box has no .git)
+# C2 headline as the driver runs it (the JSON line carries roofline + cpu_baseline incl. the full-size CPU leg, ~4 min) ...
+python bench.py > "$R/bench_default.log" 2>&1
 grep metric "$R/bench_default.log" > "$R/bench_default.json"
+# ... and the same GPU work under the kernel trace (without the 4-minute CPU leg)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -o bench -- python bench.py --no-cpu-full > "$R/bench_default_profiled.log" 2>&1
+grep metric "$R/bench_default_profiled.log" > "$R/bench_default_profiled.json"
 # HBM traffic of UpdateESDF's kernels: two PMC passes, calibrated inside the same runs (tools/pmc_traffic.py)
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/pmc_$C" -o bench -- \
@@ -28,9 +32,10 @@ python bench.py --engine rounds --scene surfaces --no-cpu-baseline 2>&1 | grep m
 python bench.py --workload c3 --steps 20 --warmup 4 2>&1 | grep metric > "$R/bench_c3.json"
 python bench.py --workload c4 --steps 40 --warmup 5 2>&1 | grep metric > "$R/bench_c4.json"
 python bench.py --gpus 1 --force-sharded --no-cpu-baseline 2>&1 | grep metric > "$R/bench_sharded_1rank.json"
+python bench.py --delta-sweep --no-cpu-baseline 2>&1 | grep -E "^\{" > "$R/delta_sweep.json"
 # copy what is to be judged into profiles/ (gpurun_out/ is scratch)
 cp "$R/stats/bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats_default.csv"
-for f in bench_default bench_c2_surfaces bench_c2_rounds bench_c2_surfaces_rounds bench_c3 bench_c4 bench_sharded_1rank pmc_traffic_ft; do
+for f in bench_default bench_default_profiled delta_sweep bench_c2_surfaces bench_c2_rounds bench_c2_surfaces_rounds bench_c3 bench_c4 bench_sharded_1rank pmc_traffic_ft; do
   cp "$R/$f.json" "profiles/${TAG}_$f.json"
 done
 for C in FETCH_SIZE WRITE_SIZE SQ LDS; do

@@ -63,6 +63,7 @@ def main():
     }
     out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
     out["command"] = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (two rocprofv3 --pmc passes)"
+    out["commit"] = os.environ.get("FIESTA_REV", "unrecorded")  # the commit whose binary ran (the GPU box has no .git)
     print(json.dumps(out, indent=1))
 
 
