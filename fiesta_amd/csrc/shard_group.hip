@@ -269,7 +269,8 @@ ShardGroup::~ShardGroup() {
 // Every shard contributes one row of kRow numbers; afterwards h_table_[rank * kRow + j] holds them all on the host.
 // (RCCL: ONE small all-gather + one stream synchronisation; local: the rows are simply written in place.)
 void ShardGroup::gather_rows(const std::vector<std::vector<long long>> &rows) {
-  if (comm_ && world_ > 1) {  // (a group of one has nobody to ask: no collective, no synchronisation)
+  if (comm_) {  // (a group of one on the local transport has nobody to ask; one that was GIVEN a communicator uses it --
+                //  that is how the RCCL entry points are exercised on a one-GPU box)
     Local &L = *locals_[0];
     hipStream_t s = L.map->stream();
     memcpy(&h_table_[(size_t)L.rank * kRow], rows[0].data(), kRow * sizeof(long long));
@@ -291,7 +292,7 @@ ShardGroup::Local *ShardGroup::find_local(int rank) {
 
 bool ShardGroup::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
   // 1. local fusion; 2. every shard's transitions to every shard
-  if (world_ == 1) {  // nobody to tell: the shard's own fusion already keeps its replica of the global bitmap
+  if (world_ == 1 && !comm_) {  // nobody to tell: the shard's own fusion already keeps its replica of the global bitmap
     int64_t ni = 0, nd = 0;
     const bool any = locals_[0]->map->update_occupancy(global_map, &ni, &nd);
     if (n_ins) *n_ins = ni;
@@ -443,7 +444,7 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
     }
     // ---- counts (the receivers' message sizes) + pending tiles: one gather, one host read
     std::vector<std::vector<long long>> rows(locals_.size(), std::vector<long long>(kRow, 0));
-    if (comm_ && world_ > 1) {
+    if (comm_) {
       // the row is assembled ON THE DEVICE (entry counts + the pending-tile counter) and goes straight into the
       // all-gather: ONE synchronisation per sweep (r02: one for the counts, one for the tiles, one for the gather)
       Local &L = *locals_[0];

@@ -200,7 +200,10 @@ class ShardedESDFMap:
     builds one shard engine; the default builds fiesta_amd.ESDFMap on `devices[rank % len(devices)]`."""
 
     def __init__(self, origin, resolution, global_grid, n_shards, transport=None, devices=(0,), make_shard=None,
-                 update_engine=0, native=None):
+                 update_engine=0, native=None, rccl_group_of_one=False):
+        # rccl_group_of_one: a single shard whose native group is GIVEN an RCCL communicator (of one rank) and therefore
+        # runs the protocol's collectives over it -- how the RCCL entry points are exercised on a one-GPU box
+        self._rccl_group_of_one = bool(rccl_group_of_one) and n_shards == 1
         self.origin = np.asarray(origin, np.float64).reshape(3)
         self.resolution = float(resolution)
         self.global_grid = tuple(int(v) for v in global_grid)
@@ -265,20 +268,20 @@ class ShardedESDFMap:
         rccl_id = None
         handles = (C.c_void_p * len(ranks))(*[self.shards[r]._h for r in ranks])
         rk = (C.c_int32 * len(ranks))(*ranks)
-        use_rccl = self.n_shards > 1 and len(ranks) == 1
+        use_rccl = (self.n_shards > 1 and len(ranks) == 1) or self._rccl_group_of_one
         # local preconditions first, agreed on by every rank BEFORE the collective communicator set-up: a rank that
         # fails here must not leave the others blocked inside ncclCommInitRank
         bad = int(lib.fiesta_hip_shard_group_precheck(handles, rk, len(ranks), self.n_shards, int(use_rccl)) != 0)
         why = _lib.last_error() if bad else ""
-        if use_rccl:
+        if use_rccl and self.n_shards > 1:
             bad = int(self.transport.allreduce_sum(bad))
         if bad:
             raise RuntimeError(f"native shard group: local preconditions failed on {bad} rank(s) {why}")
         if use_rccl:
             buf = np.zeros(129, np.uint8)  # 128 bytes of id + "rank 0 got one" (every rank takes part in the broadcast)
-            if self.transport.rank == 0:
+            if self.n_shards == 1 or self.transport.rank == 0:
                 buf[128] = lib.fiesta_hip_rccl_unique_id(buf.ctypes.data_as(C.c_void_p)) == 0
-            got = self.transport.broadcast_bytes(buf)
+            got = buf if self.n_shards == 1 else self.transport.broadcast_bytes(buf)
             if not got[128]:
                 raise RuntimeError("rank 0 could not create an RCCL unique id (librccl.so not loadable?)")
             rccl_id = np.ascontiguousarray(got[:128])

@@ -70,6 +70,30 @@ def test_sharded_matches_single_grid_oracle(hip_lib, oracle_libs, best_oracle_ki
     sm.close()
 
 
+@pytest.mark.parametrize("engine", ["rounds", "auto"])
+def test_group_of_one_runs_its_protocol_over_an_rccl_communicator(hip_lib, oracle_libs, best_oracle_kind, engine):
+    """The only RCCL a one-GPU box can run: a shard group of ONE that is given a communicator (ncclGetUniqueId,
+    ncclCommInitRank with one rank) uses it -- the per-sweep row all-gather, the transition all-gather, the (empty)
+    send/receive group -- instead of the shortcuts of a group on the local transport.  Same fields as the oracle, and the
+    communicator itself reports one rank."""
+    from fiesta_amd.sharded import ShardedESDFMap
+    gs, res = (72, 64, 80), 0.1
+    sm = ShardedESDFMap((0, 0, 0), res, gs, 1, native=True, rccl_group_of_one=True, update_engine=engine)
+    assert sm._group is not None and sm.comm_info() == (1, 0)
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res), kind=best_oracle_kind)
+    for m in (sm, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    allv = np.stack(np.meshgrid(*[np.arange(n) for n in gs], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    rng = np.random.RandomState(11)
+    S = (rng.rand(400, 3) * gs).astype(np.int32)
+    drive(sm, cpu, [([], allv, 1), (S, [], 3)])
+    compare(sm, cpu, gs)
+    drive(sm, cpu, [((rng.rand(100, 3) * gs).astype(np.int32), S[:200], 6)])
+    compare(sm, cpu, gs)
+    sm.close()
+
+
 @pytest.mark.parametrize("n_shards", [2, 8])
 def test_bulk_then_rounds_updates_next_to_a_cut(hip_lib, oracle_libs, best_oracle_kind, n_shards):
     """ADVICE r2 (shard_group.hip): a committed bulk transform rewrites owned and ghost cells behind the ghost exchange's

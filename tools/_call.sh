@@ -1,4 +1,3 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_full_size.py -q -m gpu -x -k "bulk_engine or tier or spill or closed" > gpurun_out/pt.log 2>&1; grep -E "passed|failed|error" gpurun_out/pt.log | tail -3; grep -E "^(FAILED|ERROR)|^E " gpurun_out/pt.log | head -20
-python bench.py --scene surfaces --no-cpu-baseline --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('surfaces', d['update_esdf_p50_ms'], d['roofline']['frac'], d['roofline']['phases_p50_ms'], d['roofline']['ring_overflows'], d.get('verify',{}).get('mismatches'))"
-python bench.py --no-cpu-baseline --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('scatter', d['update_esdf_p50_ms'], d['roofline']['frac'], d['roofline']['phases_p50_ms'], d['roofline']['ring_overflows'], d.get('verify',{}).get('mismatches'))"
+timeout 900 python -m pytest tests/test_gpu_sharded.py -q -m gpu -x -k "group_of_one or matches_single_grid" > gpurun_out/pt.log 2>&1; grep -E "passed|failed|error" gpurun_out/pt.log | tail -3; grep -E "^(FAILED|ERROR)|^E " gpurun_out/pt.log | head -20
+python bench.py --gpus 1 --force-sharded --no-cpu-baseline --steps 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('sharded1', d['ms_per_step'], d['update_esdf_p50_ms'], d['roofline']['frac'], d['verify'])"
