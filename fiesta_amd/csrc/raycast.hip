@@ -1,9 +1,9 @@
 // fiesta_amd/csrc/raycast.hip -- per-ray HIP kernels that turn one sensor frame into the occupancy delta.
 //
 // Replaces (reference = HKUST-Aerial-Robotics/FIESTA):
-//   Raycast(start,end,min,max,&out)          src/raycast.cpp:56-158   -> dda_walk (device, one ray per lane)
-//   Fiesta::RaycastProcess / Multithread     include/Fiesta.h:194-303 -> k_ray_prepare / k_ray_winner /
-//                                                                       k_ray_resolve / k_ray_apply
+//   Raycast(start,end,min,max,&out)          src/raycast.cpp:56-158   -> dda_walk (device, one CASTING ray per lane)
+//   Fiesta::RaycastProcess / Multithread     include/Fiesta.h:194-303 -> k_ray_ends / k_ray_cast_list / k_ray_walk /
+//                                                                       k_ray_codes / k_ray_resolve_w / k_ray_apply_w
 //   pinhole part of Fiesta::DepthConversion  include/Fiesta.h:341-351 -> k_depth_points
 //
 // The reference processes the cloud sequentially and de-duplicates per frame with two stamp arrays:
@@ -17,9 +17,9 @@
 //     truncated at the first voxel with F[v] < i. F and the truncations are a fixed point of each other and
 //     the fixed point is unique (ray 0 is never truncated, ray 1 only depends on ray 0, ...), so iterating
 //     "truncate with the previous F, rebuild F with atomicMin" from "nobody is truncated" converges to
-//     exactly the sequential result; the loop stops when no ray's truncation changed (a few rounds in
-//     practice, each a cheap replay of the per-ray voxel lists that k_ray_prepare stored).
-// Counters are applied once, by k_ray_apply, along the final truncated walks.
+//     exactly the sequential result; the loop stops when no ray's truncation changed (a dozen or two rounds on a
+//     depth image, each a replay of the casting rays' stored walks, a wave per ray).
+// Counters are applied once, by k_ray_apply_w, along the final truncated walks.
 // All ray arithmetic is f64 in the reference's operation order and this file is compiled with
 // -ffp-contract=off, so voxel decisions (floor, comparisons with min/max ray length) match bit for bit.
 #include <cmath>
@@ -150,6 +150,20 @@ __device__ inline uint32_t ray_visit_code(const Geom &g, const RayArgs &ra, int 
   return (uint32_t)g.idx(x, y, z) | ((g.in_window(x, y, z) && g.owned(x, y, z)) ? 0u : kCodeNoCount);
 }
 
+// ... on a paged map: packed window coordinates for now (k_ray_translate_codes), the tile marked for allocation
+__device__ inline uint32_t ray_visit_code_paged(const Geom &g, const RayArgs &ra, int vx, int vy, int vz, uint32_t *need) {
+  const double c[3] = {(vx + 0.5) * g.res, (vy + 0.5) * g.res, (vz + 0.5) * g.res};
+  const double e0 = c[0] - ra.o[0], e1 = c[1] - ra.o[1], e2 = c[2] - ra.o[2];
+  const double l2 = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+  if (l2 < ra.minr) return kCodeMinBreak;
+  if (l2 > ra.maxr) return kCodeSkip;
+  const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
+            z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
+  if (!paged::in_win(x, y, z)) return kCodeSkip;
+  need[paged::tile_id(x, y, z)] = 1u;
+  return pack_coc(x, y, z) | (g.in_window(x, y, z) ? 0u : kCodeNoCount);
+}
+
 // ---- dense maps: end points for every point of the cloud, walks only for the rays that cast -------------------------
 // A 640x480 depth image holds ~300 k points but only a few thousand distinct end-point voxels, and only the first point
 // of each casts a ray (set_occ_, include/Fiesta.h:221-232).  So the frame is split: k_ray_ends (one lane per point:
@@ -269,8 +283,9 @@ __global__ void k_ray_walk(Geom g, RayArgs ra, const float *pts, const int32_t *
 // path -> visit codes, in place: one wave per casting ray, a lane per voxel of the walk (the voxel = walk0 + the steps
 // so far: an inclusive wave scan of the three axes packed in one word, every lane adding 1 to each field so that
 // no field ever borrows)
+template <bool PAGED>
 __global__ void k_ray_codes(Geom g, RayArgs ra, const int *n_cast, int stride, uint32_t *entries, const int32_t *walk0,
-                            const int32_t *m_count) {
+                            const int32_t *m_count, uint32_t *need) {
   const int lane = threadIdx.x & 63, nwaves = (gridDim.x * blockDim.x) >> 6;
   const int nc = *n_cast;
   for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < nc; c += nwaves) {
@@ -287,7 +302,7 @@ __global__ void k_ray_codes(Geom g, RayArgs ra, const int *n_cast, int stride, u
         if (lane >= off) v += o;
       }
       const int dx = (int)(v & 1023u) - (lane + 1), dy = (int)((v >> 10) & 1023u) - (lane + 1), dz = (int)((v >> 20) & 1023u) - (lane + 1);
-      if (k < m) row[k] = ray_visit_code(g, ra, cx + dx, cy + dy, cz + dz);
+      if (k < m) row[k] = PAGED ? ray_visit_code_paged(g, ra, cx + dx, cy + dy, cz + dz, need) : ray_visit_code(g, ra, cx + dx, cy + dy, cz + dz);
       const uint32_t tot = __shfl(v, 63);
       cx += (int)(tot & 1023u) - 64, cy += (int)((tot >> 10) & 1023u) - 64, cz += (int)((tot >> 20) & 1023u) - 64;
     }
@@ -295,7 +310,9 @@ __global__ void k_ray_codes(Geom g, RayArgs ra, const int *n_cast, int stride, u
 }
 
 // One fixed-point round, one wave per casting ray: truncate the ray with the previous round's first-stamper array and
-// rebuild the array for the next round (see k_ray_resolve for the iteration).  Lane l of a chunk looks at walk entry
+// rebuild the array for the next round.  Rounds are launched in batches without a host round trip: round `it` (1-based)
+// reports into changed[it]; a round that finds its predecessor unchanged (the fixed point) does nothing, and so do all
+// later rounds of the batch (their changed[] entries stay 0).  Lane l of a chunk looks at walk entry
 // top - l; the first lane that meets the min-length break or an earlier ray's stamp ends the walk.
 __global__ void k_ray_resolve_w(int stride, const uint32_t *entries, const int32_t *cast, const int *n_cast,
                                 const int32_t *m_count, int32_t *last_k, int have_prev, int stamp, const uint32_t *fprev,
@@ -355,26 +372,21 @@ __global__ void k_ray_apply_w(int stride, const uint32_t *entries, const int *n_
   }
 }
 
-// ---- paged (hash-block) maps: one lane per point of the cloud, walk included ------------------------------------------
-// flags: bit0 valid ray, bit1 casts (winner of its end-point voxel), bit2 traversal overflow
-// A voxel's slot in the page pool is only known once its page exists, so this pass stores packed WINDOW
-// coordinates instead of slots (end_idx: coords | occ << 30), marks the tiles it touches (the reference's Vox2Idx
-// allocates on every SetOccupancy, in or out of the update window, src/ESDFMap.cpp:418-421,732-765) and leaves the
-// counting and stamping of the end points to k_ray_translate, after the pages have been allocated.
-__global__ void k_ray_prepare_paged(Geom g, RayArgs ra, const float *pts, int64_t n, int stride, uint32_t *entries,
-                                    int32_t *end_idx, int32_t *m_count, uint8_t *flags, int *err, uint32_t *need) {
+// ---- paged (hash-block) maps: the same organisation, in two steps around the allocation of pages ----------------------
+// A voxel's slot in the page pool is only known once its page exists.  End points: k_ray_ends_paged stores packed WINDOW
+// coordinates (end_idx: coords | occ << 30) and marks the tiles it touches (the reference's Vox2Idx allocates on every
+// SetOccupancy, in or out of the update window, src/ESDFMap.cpp:418-421,732-765); after the pages have been allocated
+// k_ray_translate_ends turns coordinates into slots, counts the observations and stamps set_occ_.  Walks: the path pass
+// is the dense map's; k_ray_codes<true> leaves window coordinates in the entries and marks the tiles of the CASTING
+// rays' walks (the reference never touches a voxel of a ray it does not cast); k_ray_translate_codes makes them slots.
+__global__ void k_ray_ends_paged(Geom g, RayArgs ra, const float *pts, int64_t n, int32_t *end_idx, uint8_t *flags, uint32_t *need) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
-  flags[i] = 0;
-  m_count[i] = 0;
-  end_idx[i] = -1;
   double q[3];
   int occ = 0;
-  if (!ray_end_point(ra, pts, i, q, occ)) return;
-  // SetOccupancy(point, occ) (src/ESDFMap.cpp:401-437); PosInMap is always true for the hash build (:46-48): the
-  // virtual window is the map
+  const bool valid = ray_end_point(ra, pts, i, q, occ);
   int eidx = -1;
-  {
+  if (valid) {  // PosInMap is always true for the hash build (src/ESDFMap.cpp:46-48): the virtual window is the map
     const int x = (int)floor((q[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((q[1] - g.org[1]) / g.res) - g.gy0,
               z = (int)floor((q[2] - g.org[2]) / g.res) - g.gz0;
     if (paged::in_win(x, y, z)) {
@@ -382,127 +394,53 @@ __global__ void k_ray_prepare_paged(Geom g, RayArgs ra, const float *pts, int64_
       need[paged::tile_id(x, y, z)] = 1u;
     }
   }
+  flags[i] = valid ? 1 : 0;
   end_idx[i] = eidx;
-  // Raycast(origin/res, point/res, l_cornor/res, r_cornor/res) (:233-237)
-  double a[3], b[3], lo[3], hi[3];
-  for (int k = 0; k < 3; ++k) {
-    a[k] = ra.o[k] / g.res;
-    b[k] = q[k] / g.res;
-    lo[k] = ra.lc[k] / g.res;
-    hi[k] = ra.rc[k] / g.res;
-  }
-  bool overflow = false;
-  const int m = dda_walk(a, b, lo, hi, [&](int vx, int vy, int vz, int k) {
-    if (k >= stride) {
-      overflow = true;
-      return;
-    }
-    // the free-space visit of this voxel, as RaycastProcess would do it (:240-248)
-    const double c[3] = {(vx + 0.5) * g.res, (vy + 0.5) * g.res, (vz + 0.5) * g.res};
-    const double e0 = c[0] - ra.o[0], e1 = c[1] - ra.o[1], e2 = c[2] - ra.o[2];
-    const double l2 = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
-    uint32_t code = kCodeSkip;
-    if (l2 < ra.minr) {
-      code = kCodeMinBreak;
-    } else if (!(l2 > ra.maxr)) {
-      const int x = (int)floor((c[0] - g.org[0]) / g.res) - g.gx0, y = (int)floor((c[1] - g.org[1]) / g.res) - g.gy0,
-                z = (int)floor((c[2] - g.org[2]) / g.res) - g.gz0;
-      if (paged::in_win(x, y, z)) {
-        code = pack_coc(x, y, z) | (g.in_window(x, y, z) ? 0u : kCodeNoCount);
-        need[paged::tile_id(x, y, z)] = 1u;
-      }
-    }
-    entries[(int64_t)k * n + i] = code;
-  });
-  if (m < 0 || overflow) {
-    atomicExch(err, 1);
-    flags[i] = 4;
-    return;
-  }
-  m_count[i] = m;
-  flags[i] = 1;
 }
 
-// PAGED, after the pages exist: window coordinates -> pool slots (end points and walk entries), and the end-point part
-// of k_ray_prepare (count the observation, stamp set_occ_).
-__global__ void k_ray_translate(Geom g, const int32_t *dir, int64_t n, int dedup, uint32_t *entries, int32_t *end_idx,
-                                const int32_t *m_count, const uint8_t *flags, uint32_t *stamp_occ, uint32_t tagged,
-                                unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
+// (one counter update and one stamp per run of equal end points inside the wave, as in k_ray_ends)
+__global__ void k_ray_translate_ends(Geom g, const int32_t *dir, int64_t n, int dedup, int32_t *end_idx, uint32_t *stamp_occ,
+                                     uint32_t tagged, unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t e = end_idx[i];
+  const int32_t e = i < n ? end_idx[i] : -1;
+  int64_t addr = -1;
+  bool counts = false;
   if (e >= 0) {
     int x, y, z;
     unpack_coc((vox_t)e & kCodeIdxMask, x, y, z);
-    const int64_t addr = paged::vaddr(dir, x, y, z);
+    addr = paged::vaddr(dir, x, y, z);
+    counts = g.in_window(x, y, z);
     end_idx[i] = (int32_t)addr;
-    if (g.in_window(x, y, z)) count_observation(addr, (e >> 30) & 1, cnt, touched, counters);
-    if (dedup) atomicMin(&stamp_occ[addr], tagged | (uint32_t)i);
   }
-  if (!(flags[i] & 1)) return;
-  const int m = m_count[i];
-  for (int k = 0; k < m; ++k) {
-    const uint32_t code = entries[(int64_t)k * n + i];
-    if (code == kCodeSkip || code == kCodeMinBreak) continue;
-    int x, y, z;
-    unpack_coc(code & kCodeIdxMask, x, y, z);
-    entries[(int64_t)k * n + i] = (uint32_t)paged::vaddr(dir, x, y, z) | (code & kCodeNoCount);
-  }
-}
-
-__global__ void k_ray_winner(int64_t n, int dedup, const int32_t *end_idx, const int32_t *m_count, uint8_t *flags,
-                             const uint32_t *stamp_occ, uint32_t tagged, int32_t *last_k) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint8_t f = flags[i];
-  if ((f & 1) && (!dedup || end_idx[i] < 0 || stamp_occ[end_idx[i]] == (tagged | (uint32_t)i))) f |= 2;
-  flags[i] = f;
-  last_k[i] = m_count[i];  // "nothing visited yet"
-}
-
-// One fixed-point round: truncate every casting ray with the previous round's first-stamper array and rebuild
-// the array for the next round. Rounds are launched in batches without a host round trip: round `it` (1-based)
-// reports into changed[it]; a round that finds its predecessor unchanged (the fixed point) does nothing, and so
-// do all later rounds of the batch (their changed[] entries stay 0).
-__global__ void k_ray_resolve(int64_t n, const uint32_t *entries, const int32_t *m_count, const uint8_t *flags,
-                              int32_t *last_k, int have_prev, int stamp, const uint32_t *fprev, uint32_t tag_prev,
-                              uint32_t *fnext, uint32_t tag_next, int ibits, int *changed, int it) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (it >= 3 && changed[it - 1] == 0) return;  // round 1 always "changes" (from nothing visited to the full walk)
-  if (!(flags[i] & 2)) return;
-  const int m = m_count[i];
-  const uint32_t imask = (1u << ibits) - 1u;
-  int lk = m;  // lowest visited entry
-  for (int k = m - 2; k >= 0; --k) {
-    const uint32_t code = entries[(int64_t)k * n + i];
-    if (code == kCodeMinBreak) break;  // include/Fiesta.h:243-244
-    lk = k;
-    if (code == kCodeSkip) continue;   // :245-246 and the "-10000" case of :253
-    const uint32_t idx = code & kCodeIdxMask;
-    if (stamp) atomicMin(&fnext[idx], (tag_next << ibits) | (uint32_t)i);
-    if (have_prev) {
-      const uint32_t v = fprev[idx];
-      if ((v >> ibits) == tag_prev && (v & imask) < (uint32_t)i) break;  // set_free_[idx] == tt (:265-269)
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(e, 1);
+  const unsigned long long heads = __ballot(lane == 0 || e != prev);
+  if (e >= 0 && addr >= 0 && ((heads >> lane) & 1ull)) {
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int len = above ? __ffsll((long long)above) : 64 - lane;
+    if (counts) {
+      const unsigned long long hits = ((e >> 30) & 1) ? (unsigned long long)len : 0ull;
+      const unsigned long long old = atomicAdd(&cnt[addr], (hits << 32) | (unsigned long long)len);
+      wave_append((uint32_t)old == 0, (uint32_t)addr, touched, &counters[C_TOUCHED]);
     }
-  }
-  if (lk != last_k[i]) {
-    last_k[i] = lk;
-    changed[it] = 1;
+    if (dedup) atomicMin(&stamp_occ[addr], tagged | (uint32_t)i);  // set_occ_ (include/Fiesta.h:221-232)
   }
 }
 
-__global__ void k_ray_apply(int64_t n, const uint32_t *entries, const int32_t *m_count, const uint8_t *flags,
-                            const int32_t *last_k, unsigned long long *cnt, uint32_t *touched,
-                            unsigned long long *counters, int free_occ) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (!(flags[i] & 2)) return;
-  const int m = m_count[i], lk = last_k[i];
-  for (int k = m - 2; k >= lk; --k) {
-    const uint32_t code = entries[(int64_t)k * n + i];
-    if (code == kCodeSkip || (code & kCodeNoCount)) continue;
-    count_observation(code & kCodeIdxMask, free_occ, cnt, touched, counters);  // SetOccupancy(tmp, 0) (:248; inverse map: 1, :250)
+// window coordinates -> pool slots, in place (one wave per casting ray)
+__global__ void k_ray_translate_codes(const int32_t *dir, const int *n_cast, int stride, uint32_t *entries, const int32_t *m_count) {
+  const int lane = threadIdx.x & 63, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nc = *n_cast;
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < nc; c += nwaves) {
+    const int m = m_count[c];
+    uint32_t *row = entries + (int64_t)c * stride;
+    for (int k = lane; k < m; k += 64) {
+      const uint32_t code = row[k];
+      if (code == kCodeSkip || code == kCodeMinBreak) continue;
+      int x, y, z;
+      unpack_coc(code & kCodeIdxMask, x, y, z);
+      row[k] = (uint32_t)paged::vaddr(dir, x, y, z) | (code & kCodeNoCount);
+    }
   }
 }
 
@@ -670,72 +608,10 @@ static RayArgs ray_args(const double *T, const double *origin, const fiesta_hip_
   return ra;
 }
 
-// winners of the end-point voxels, the free-space fixed point, the counters; slots in `entries` / `end_idx` index
-// cnt[], the stamp arrays and the touched list
-static void ray_rounds(RayState &rc, int64_t n, int dedup, int ibits, uint32_t tag_occ, unsigned long long *cnt,
-                       uint32_t *touched, unsigned long long *counters, hipStream_t stream, int inverse) {
-  hipLaunchKernelGGL(k_ray_winner, dim3(rgrid(n)), dim3(256), 0, stream, n, dedup, (const int32_t *)rc.end_idx.p,
-                     (const int32_t *)rc.m_count.p, rc.flags.p, (const uint32_t *)rc.stamp_occ,
-                     dedup ? (tag_occ << ibits) : 0u, rc.last_k.p);
-  FIESTA_HIP_CHECK(hipGetLastError());
-  int64_t iters = 0;
-  if (!dedup) {
-    hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream, n, (const uint32_t *)rc.entries.p,
-                       (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, 0, 0,
-                       (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u, ibits, rc.d_flags + 2, 1);
-    FIESTA_HIP_CHECK(hipGetLastError());
-  } else {
-    uint32_t *fprev = rc.fa, *fnext = rc.fb;
-    uint32_t tag_prev = 0;
-    constexpr int kBatch = 8;  // rounds per host round trip
-    bool done = false;
-    int64_t base = 0;  // rounds whose flag slots were recycled (the fixed point needs at most n rounds: ray i depends
-                       // only on rays before it; a valid frame never fails here, however long its dependency chains)
-    while (!done) {
-      const int64_t first = iters + 1;
-      for (int b = 0; b < kBatch; ++b) {
-        const uint32_t tag_next = rc.tag--;
-        ++iters;
-        hipLaunchKernelGGL(k_ray_resolve, dim3(rgrid(n)), dim3(256), 0, stream, n, (const uint32_t *)rc.entries.p,
-                           (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.last_k.p, iters > 1 ? 1 : 0, 1,
-                           (const uint32_t *)fprev, tag_prev, fnext, tag_next, ibits, rc.d_flags + 2, (int)(iters - base));
-        FIESTA_HIP_CHECK(hipGetLastError());
-        std::swap(fprev, fnext);
-        tag_prev = tag_next;
-      }
-      FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, (2 + (iters - base) + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
-      FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
-      if (rc.h_flags[1]) break;
-      // stop at the first round (after round 1) that changed nothing
-      for (int64_t it = std::max<int64_t>(first, 2); it <= iters; ++it)
-        if (!rc.h_flags[2 + (it - base)]) {
-          iters = it;
-          done = true;
-          break;
-        }
-      if (!done && (iters - base) + kBatch > RayState::kMaxRounds) {  // recycle the per-round flag slots
-        FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags + 2, 0, (RayState::kFlagInts - 2) * sizeof(int), stream));
-        base = iters;
-      }
-      if (!done && iters > n + kBatch) throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup: more rounds than rays (internal error)");
-    }
-  }
-  rc.last_iterations = iters;
-  hipLaunchKernelGGL(k_ray_apply, dim3(rgrid(n)), dim3(256), 0, stream, n, (const uint32_t *)rc.entries.p,
-                     (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, (const int32_t *)rc.last_k.p, cnt,
-                     touched, counters, inverse ? 1 : 0);
-  FIESTA_HIP_CHECK(hipGetLastError());
-  FIESTA_HIP_CHECK(hipMemcpyAsync(rc.h_flags, rc.d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
-  FIESTA_HIP_CHECK(hipStreamSynchronize(stream));
-  if (rc.h_flags[1])  // the reference throws std::out_of_range("Too many RaycasMultithread voxels")
-    throw Error(FIESTA_HIP_ERR_INVALID, "Too many raycast voxels (a ray crosses more than 1500 voxels)");
-}
-
-// Dense maps: the casting rays of the frame (compacted), their walks, the free-space fixed point with one wave per
-// casting ray, the counters.  Nothing here waits for the host except the batches of the fixed point.
-static void ray_rounds_cast(RayState &rc, const Geom &g, const RayArgs &ra, const float *dpts, int64_t n, int stride, int ibits,
-                            uint32_t tag_occ, unsigned long long *cnt, uint32_t *touched, unsigned long long *counters,
-                            hipStream_t stream) {
+// The casting rays of the frame (compacted) and their walks, as visit codes (paged maps: still window coordinates, tiles
+// marked in `need`).  Nothing here waits for the host.
+static void ray_cast_walks(RayState &rc, const Geom &g, const RayArgs &ra, const float *dpts, int64_t n, int stride, int ibits,
+                           uint32_t tag_occ, hipStream_t stream, uint32_t *need) {
   rc.cast.ensure(n, stream);
   int *n_cast = rc.d_flags;  // [0]: casting rays of this frame (zeroed with the flags)
   hipLaunchKernelGGL(k_ray_cast_list, dim3((int)((n + 1023) / 1024)), dim3(1024), 0, stream, n, ra.dedup, (const int32_t *)rc.end_idx.p, rc.flags.p,
@@ -748,9 +624,21 @@ static void ray_rounds_cast(RayState &rc, const Geom &g, const RayArgs &ra, cons
   hipLaunchKernelGGL(k_ray_walk, dim3(walk_blocks), dim3(64), 0, stream, g, ra, dpts, (const int32_t *)rc.cast.p, (const int *)n_cast,
                      stride, rc.entries.p, rc.walk0.p, rc.m_count.p, rc.last_k.p, rc.d_flags + 1);
   FIESTA_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_ray_codes, dim3(wave_blocks), dim3(256), 0, stream, g, ra, (const int *)n_cast, stride, rc.entries.p,
-                     (const int32_t *)rc.walk0.p, (const int32_t *)rc.m_count.p);
+  if (need)
+    hipLaunchKernelGGL(k_ray_codes<true>, dim3(wave_blocks), dim3(256), 0, stream, g, ra, (const int *)n_cast, stride, rc.entries.p,
+                       (const int32_t *)rc.walk0.p, (const int32_t *)rc.m_count.p, need);
+  else
+    hipLaunchKernelGGL(k_ray_codes<false>, dim3(wave_blocks), dim3(256), 0, stream, g, ra, (const int *)n_cast, stride, rc.entries.p,
+                       (const int32_t *)rc.walk0.p, (const int32_t *)rc.m_count.p, (uint32_t *)nullptr);
   FIESTA_HIP_CHECK(hipGetLastError());
+}
+
+// The free-space fixed point with one wave per casting ray, then the counters.  Entries index cnt[], the stamp arrays and
+// the touched list (dense: voxel index; paged: pool slot).  The batches of the fixed point are the only host round trips.
+static void ray_cast_rounds(RayState &rc, const RayArgs &ra, int64_t n, int stride, int ibits, unsigned long long *cnt,
+                            uint32_t *touched, unsigned long long *counters, hipStream_t stream) {
+  int *n_cast = rc.d_flags;
+  const int wave_blocks = (int)std::min<int64_t>((n + 3) / 4, 2048);  // 4 waves per block
   auto resolve = [&](int have_prev, int stamp, const uint32_t *fprev, uint32_t tag_prev, uint32_t *fnext, uint32_t tag_next, int it) {
     hipLaunchKernelGGL(k_ray_resolve_w, dim3(wave_blocks), dim3(256), 0, stream, stride, (const uint32_t *)rc.entries.p,
                        (const int32_t *)rc.cast.p, (const int *)n_cast, (const int32_t *)rc.m_count.p, rc.last_k.p, have_prev, stamp,
@@ -768,7 +656,8 @@ static void ray_rounds_cast(RayState &rc, const Geom &g, const RayArgs &ra, cons
     constexpr int kBatch = 4;
     int batch = (int)std::min<int64_t>(std::max<int64_t>(rc.last_iterations + 1, kBatch), 64);
     bool done = false;
-    int64_t base = 0;  // rounds whose flag slots were recycled (see ray_rounds)
+    int64_t base = 0;  // rounds whose flag slots were recycled (the fixed point needs at most n rounds: ray i depends
+                       // only on rays before it; a valid frame never fails here, however long its dependency chains)
     while (!done) {
       const int64_t first = iters + 1;
       for (int b = 0; b < batch; ++b) {
@@ -788,7 +677,7 @@ static void ray_rounds_cast(RayState &rc, const Geom &g, const RayArgs &ra, cons
           break;
         }
       batch = kBatch;
-      if (!done && (iters - base) + kBatch > RayState::kMaxRounds) {
+      if (!done && (iters - base) + kBatch > RayState::kMaxRounds) {  // recycle the per-round flag slots
         FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags + 2, 0, (RayState::kFlagInts - 2) * sizeof(int), stream));
         base = iters;
       }
@@ -867,7 +756,8 @@ void DenseMap::raycast_frame(const float *points, int64_t n, const double *T, co
   hipLaunchKernelGGL(k_ray_ends, dim3(rgrid(n)), dim3(256), 0, stream_, g, ra, dpts, n, rc.end_idx.p, rc.flags.p, rc.stamp_occ,
                      ra.dedup ? (tag_occ << ibits) : 0u, cnt_, touched_.p, counters_);
   FIESTA_HIP_CHECK(hipGetLastError());
-  ray_rounds_cast(rc, g, ra, dpts, n, stride, ibits, tag_occ, cnt_, touched_.p, counters_, stream_);
+  ray_cast_walks(rc, g, ra, dpts, n, stride, ibits, tag_occ, stream_, nullptr);
+  ray_cast_rounds(rc, ra, n, stride, ibits, cnt_, touched_.p, counters_, stream_);
 }
 
 void DenseMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
@@ -913,21 +803,32 @@ void HashMap::raycast_frame(const float *points, int64_t n, const double *T, con
   const float *dpts = ray_points(rc, points, n, dev, stream_);
   const RayArgs ra = ray_args(T, origin, p);
   FIESTA_HIP_CHECK(hipMemsetAsync(rc.d_flags, 0, RayState::kFlagInts * sizeof(int), stream_));
-  hipLaunchKernelGGL(k_ray_prepare_paged, dim3(rgrid(n)), dim3(256), 0, stream_, g_, ra, dpts, n, stride, rc.entries.p,
-                     rc.end_idx.p, rc.m_count.p, rc.flags.p, rc.d_flags + 1, need_);
+  hipLaunchKernelGGL(k_ray_ends_paged, dim3(rgrid(n)), dim3(256), 0, stream_, g_, ra, dpts, n, rc.end_idx.p, rc.flags.p, need_);
   FIESTA_HIP_CHECK(hipGetLastError());
-  allocate_marked();
-  if ((int64_t)cap_pages_ * kPageVox > (1ll << 30))
-    throw Error(FIESTA_HIP_ERR_INVALID, "ray cast: page pool larger than 2^30 voxels (walk entries hold 30-bit slots)");
-  const int ibits = ra.dedup ? ray_stamps(rc, (size_t)cap_pages_ * kPageVox, n, stream_) : 20;
-  touched_upper_ = std::min<int64_t>(npages_ * kPageVox, touched_upper_ + n * (int64_t)(stride + 1));
+  allocate_marked();  // the end points' pages
+  auto slots_fit = [&]() {
+    if ((int64_t)cap_pages_ * kPageVox > (1ll << 30))
+      throw Error(FIESTA_HIP_ERR_INVALID, "ray cast: page pool larger than 2^30 voxels (walk entries hold 30-bit slots)");
+  };
+  slots_fit();
+  int ibits = ra.dedup ? ray_stamps(rc, (size_t)cap_pages_ * kPageVox, n, stream_) : 20;
+  touched_upper_ = std::min<int64_t>(npages_ * kPageVox, touched_upper_ + n);
   touched_.ensure((size_t)touched_upper_, stream_, touched_.cap);
   const uint32_t tag_occ = ra.dedup ? rc.tag-- : 0;
-  hipLaunchKernelGGL(k_ray_translate, dim3(rgrid(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, n, ra.dedup, rc.entries.p,
-                     rc.end_idx.p, (const int32_t *)rc.m_count.p, (const uint8_t *)rc.flags.p, rc.stamp_occ,
-                     ra.dedup ? (tag_occ << ibits) : 0u, cnt_.p, touched_.p, counters_);
+  hipLaunchKernelGGL(k_ray_translate_ends, dim3(rgrid(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, n, ra.dedup, rc.end_idx.p,
+                     rc.stamp_occ, ra.dedup ? (tag_occ << ibits) : 0u, cnt_.p, touched_.p, counters_);
   FIESTA_HIP_CHECK(hipGetLastError());
-  ray_rounds(rc, n, ra.dedup, ibits, tag_occ, cnt_.p, touched_.p, counters_, stream_, ra.inverse);
+  ray_cast_walks(rc, g_, ra, dpts, n, stride, ibits, tag_occ, stream_, need_);
+  allocate_marked();  // the pages the casting rays cross
+  slots_fit();
+  // (a pool that had to grow takes the stamp arrays with it: the end points' stamps have done their work by now)
+  if (ra.dedup) ibits = ray_stamps(rc, (size_t)cap_pages_ * kPageVox, n, stream_);
+  touched_upper_ = std::min<int64_t>(npages_ * kPageVox, touched_upper_ + n * (int64_t)stride);
+  touched_.ensure((size_t)touched_upper_, stream_, touched_.cap);
+  hipLaunchKernelGGL(k_ray_translate_codes, dim3((int)std::min<int64_t>((n + 3) / 4, 2048)), dim3(256), 0, stream_, (const int32_t *)dir_,
+                     (const int *)rc.d_flags, stride, rc.entries.p, (const int32_t *)rc.m_count.p);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  ray_cast_rounds(rc, ra, n, stride, ibits, cnt_.p, touched_.p, counters_, stream_);
 }
 
 void HashMap::raycast_depth(const uint16_t *depth, int rows, int cols, double fx, double fy, double cx, double cy,
