@@ -830,7 +830,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   if (const char *e = getenv("FIESTA_HIP_BOUND_SCAN")) bound_scan_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
   if (const char *e = getenv("FIESTA_HIP_BULK_RATIO")) bulk_ratio_ = atof(e);
-  if (const char *e = getenv("FIESTA_HIP_FT_S0")) ft_s0_ = atoi(e), ft_s0_fixed_ = true;
+  if (const char *e = getenv("FIESTA_HIP_FT_S0")) ft_s0_ = atoi(e);
   if (ft_s0_ != 16 && ft_s0_ != 32) throw Error(FIESTA_HIP_ERR_INVALID, "FIESTA_HIP_FT_S0 must be 16 or 32");
   for (auto &e : ft_ev_) FIESTA_HIP_CHECK(hipEventCreate(&e));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1232,7 +1232,10 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   ft_inter_.ensure((size_t)rn, stream_);
   ft_rowlist_.ensure((size_t)a.nx * a.ny, stream_);
   ft_rowcnt_.ensure((size_t)a.nx + 64, stream_);  // + the 2048-bit plane mask
-  ft_ovf_.ensure((size_t)cap * 6, stream_);
+  // backing store of the rings: one slice per wave of the passes' grid (at most kFtBlocks work-groups of 4 waves), one
+  // 512-byte slot row per counter value of the longest column (ft_core.hpp: a deque deeper than its ring)
+  const uint32_t spill_stride = (uint32_t)(std::max(a.nx, a.ny) + 2) * 512u;
+  ft_spill_.ensure((size_t)kFtBlocks * 4 * spill_stride, stream_);
   a.rowlist = ft_rowlist_.p;
   a.rowcnt = ft_rowcnt_.p;
   a.planemask = reinterpret_cast<uint32_t *>(ft_rowcnt_.p + a.nx);
@@ -1253,73 +1256,40 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   hipLaunchKernelGGL(k_ft_rows, dim3(a.nx), dim3(256), 0, stream_, a);
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[1], stream_));
-  // four tiers per pass: rings of S0 (16 or 32) entries for everybody, then 64, 256 and finally 1024 entries x 16
-  // lanes for the column groups whose deque outgrew the tier before (lists and their lengths stay on the device)
-  // The overflow tiers are launched only when the previous update spilled into them (an empty tier still costs a launch:
-  // six of them were 27 us, 3.8 % of config 2's update).  A scene that starts to spill while its tiers are off is caught
-  // when the spill counters arrive on the host with the update's statistics (bulk_spilled_untiered): the transform is
-  // then run again, tiers on.
-  // (with hysteresis: a pass that spilled keeps its tiers for the next 32 updates -- a scene at the edge of a ring size
-  //  would otherwise pay the second run every other update)
-  const bool tiers_a = ft_tier_hold_[0] > 0, tiers_b = ft_tier_hold_[1] > 0;
-  auto tiers = [&](const bool pass_a, const uint32_t n0, const int ovf0, const bool first, const bool deeper) {
+  // ONE kernel per pass, whatever the scene: rings of ft_s0_ entries in LDS, and a deque that outgrows its ring goes on
+  // in the backing store (r02/r03a: overflowing column groups were redone by further launches with bigger rings -- a
+  // pass is one round of waves, as long as one item takes, so every such launch cost a whole pass however few items
+  // it held: 0.45 ms for 11 % of pass B's items on the surfaces scene).  The grid is capped at what is resident at once.
+  a.spill = reinterpret_cast<char *>(ft_spill_.p);
+  a.spill_stride = spill_stride;
+  auto pass = [&](const bool pass_a, const uint32_t n0, const int counter) {
     FtArgs t = a;
-    t.items = nullptr, t.n_items_dev = nullptr, t.n_items = n0;
-    t.ovf_list = ft_ovf_.p + (size_t)(pass_a ? 0 : 3) * cap, t.ovf_count = &counters_[ovf0];
-    const int blocks0 = (int)((n0 + 3) / 4);
-    auto next = [&]() {
-      t.items = t.ovf_list, t.n_items_dev = t.ovf_count, t.n_items = 0;
-      t.ovf_list += cap, t.ovf_count = t.ovf_count + 1;
-    };
-    // the overflow tiers walk their list with a grid stride: when the tier before spilled nothing in the last update,
-    // a small grid does (the launch is then all an empty tier costs); a scene that spills gets the full grid back
-    const int h = pass_a ? 0 : 3;
-    const int g1 = ft_last_ovf_[h] ? 2048 : 64, g2 = ft_last_ovf_[h + 1] ? 1024 : 64, g3 = ft_last_ovf_[h + 2] ? 1024 : 64;
-#define FIESTA_FT_TIERS(WIDE, LASTS, LASTL)                                                        \
-  if (pass_a) {                                                                                    \
-    if (first) {                                                                                   \
-      if (ft_s0_ == 16) launch_ft_plane<16, 64, 4, WIDE>(t, blocks0, stream_);                     \
-      else launch_ft_plane<32, 64, 4, WIDE>(t, blocks0, stream_);                                  \
-    }                                                                                              \
-    next();                                                                                        \
-    if (deeper) {                                                                                  \
-      launch_ft_plane<64, 64, 2, WIDE>(t, g1, stream_);                                            \
-      next();                                                                                      \
-      launch_ft_plane<256, 64, 1, WIDE>(t, g2, stream_);                                           \
-      next();                                                                                      \
-      t.ovf_list = nullptr, t.ovf_count = nullptr;                                                 \
-      launch_ft_plane<LASTS, LASTL, 1, WIDE>(t, g3, stream_);                                      \
-    }                                                                                              \
-  } else {                                                                                         \
-    if (first) {                                                                                   \
-      if (ft_s0_ == 16) launch_ft_x<16, 64, 4, WIDE>(t, blocks0, stream_);                         \
-      else launch_ft_x<32, 64, 4, WIDE>(t, blocks0, stream_);                                      \
-    }                                                                                              \
-    next();                                                                                        \
-    if (deeper) {                                                                                  \
-      launch_ft_x<64, 64, 2, WIDE>(t, g1, stream_);                                                \
-      next();                                                                                      \
-      launch_ft_x<256, 64, 1, WIDE>(t, g2, stream_);                                               \
-      next();                                                                                      \
-      t.ovf_list = nullptr, t.ovf_count = nullptr;                                                 \
-      launch_ft_x<LASTS, LASTL, 1, WIDE>(t, g3, stream_);                                          \
-    }                                                                                              \
-  }
-    // the last tier's ring holds more entries than a column has positions (a ring of S holds S - 1): it cannot overflow
-    // (2048 slots x 8 lanes for columns up to 1024, wide: 4096 x 4 for columns up to 2048)
-    if (wide) {
-      FIESTA_FT_TIERS(true, 4096, 4)
+    t.n_items = n0;
+    t.spill_count = &counters_[counter];
+    const int blocks = (int)std::min<uint32_t>((n0 + 3) / 4, (uint32_t)kFtBlocks);
+    if (pass_a) {
+      if (wide) {
+        if (ft_s0_ == 16) launch_ft_plane<16, 64, 4, true>(t, blocks, stream_);
+        else launch_ft_plane<32, 64, 4, true>(t, blocks, stream_);
+      } else {
+        if (ft_s0_ == 16) launch_ft_plane<16, 64, 4, false>(t, blocks, stream_);
+        else launch_ft_plane<32, 64, 4, false>(t, blocks, stream_);
+      }
     } else {
-      FIESTA_FT_TIERS(false, 2048, 8)
+      if (wide) {
+        if (ft_s0_ == 16) launch_ft_x<16, 64, 4, true>(t, blocks, stream_);
+        else launch_ft_x<32, 64, 4, true>(t, blocks, stream_);
+      } else {
+        if (ft_s0_ == 16) launch_ft_x<16, 64, 4, false>(t, blocks, stream_);
+        else launch_ft_x<32, 64, 4, false>(t, blocks, stream_);
+      }
     }
-#undef FIESTA_FT_TIERS
     FIESTA_HIP_CHECK(hipGetLastError());
   };
-  tiers(true, items_a, C_FT_OVF0, true, tiers_a);
+  pass(true, items_a, C_FT_OVF0);
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[2], stream_));
-  tiers(false, items_b, C_FT_OVF0 + 3, true, tiers_b);
-  const int launches = 3 + (tiers_a ? 3 : 0) + (tiers_b ? 3 : 0);
-  ft_tiers_off_ = !tiers_a || !tiers_b;  // (bulk_spilled_untiered() looks at the spill counters once they are on the host)
+  pass(false, items_b, C_FT_OVF0 + 3);
+  const int launches = 3;
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[3], stream_));
   if (st) {
     st->bulk = 1;
@@ -1390,19 +1360,6 @@ bool DenseMap::bulk_pays(double delta, double nocc, double n) const {
   return n <= 1.3e8 + 50.0 * updated;
 }
 
-// Did the transform just run spill rings while the overflow tiers were switched off (run_bulk)?  h_counters_ must hold the
-// spill counters of that run.  If so the result is incomplete: the caller runs it again (ft_last_ovf_ now switches them on).
-bool DenseMap::bulk_spilled_untiered() {
-  if (!ft_tiers_off_) return false;
-  bool spilled = false;
-  for (int k = 0; k < 6; ++k) {
-    spilled = spilled || h_counters_[C_FT_OVF0 + k] != 0;
-    ft_last_ovf_[k] = std::max<int64_t>(ft_last_ovf_[k], (int64_t)h_counters_[C_FT_OVF0 + k]);
-  }
-  if (spilled) ft_tier_hold_[0] = ft_tier_hold_[1] = 32;
-  return spilled;
-}
-
 // After a successful bulk transform: the queues are consumed, timings and counters reported.
 void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
   static_assert(C_DELETE == C_INSERT + 1, "counter layout");
@@ -1430,11 +1387,6 @@ void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time
         hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]) == hipSuccess)
       ft_last_ms_ = (double)m1 + m2 + m3;
   }
-  for (int k = 0; k < 6; ++k) ft_last_ovf_[k] = (int64_t)h_counters_[C_FT_OVF0 + k];
-  for (int k = 0; k < 2; ++k) ft_tier_hold_[k] = ft_last_ovf_[3 * k] ? 32 : std::max(0, ft_tier_hold_[k] - 1);
-  // adapt the first tier to the scene: deep deques (far from obstacles) -> start with the 32-entry rings next time
-  const int64_t spill = (int64_t)h_counters_[C_FT_OVF0] + (int64_t)h_counters_[C_FT_OVF0 + 3];
-  if (!ft_s0_fixed_ && ft_s0_ == 16 && spill * 50 > (int64_t)(g_.nx + g_.ny) * ((g_.nz + 63) / 64)) ft_s0_ = 32;
 }
 
 // The sharded driver's bulk step (shard_group.hip): transform with `margin`, report exactness; commit consumes the queues.
@@ -1444,13 +1396,7 @@ bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
   reset_stats_counters();
   if (st) memset(st, 0, sizeof(*st));
-  if (!run_bulk(st, margin, exact)) return false;
-  if (ft_tiers_off_) {
-    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_FT_OVF0], &counters_[C_FT_OVF0], 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-    if (bulk_spilled_untiered()) return run_bulk(st, margin, exact);
-  }
-  return true;
+  return run_bulk(st, margin, exact);
 }
 void DenseMap::bulk_commit(fiesta_hip_stats *st) {
   use_device();
@@ -1505,10 +1451,6 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
       bool exact = true;
       if (run_bulk(st, 0, &exact)) {
         bulk_finish(st, h0);
-        if (bulk_spilled_untiered()) {  // (a scene that starts to need the deeper rings: once, then the tiers stay on)
-          run_bulk(st, 0, &exact);
-          bulk_finish(st, h0);
-        }
         return;
       }
     }
@@ -2156,7 +2098,8 @@ void DenseMap::bulk_reserve(int margin) {
   ft_inter_.ensure((size_t)(ext[0] * ext[1] * ext[2]), stream_);
   ft_rowlist_.ensure((size_t)(ext[0] * ext[1]), stream_);
   ft_rowcnt_.ensure((size_t)ext[0] + 64, stream_);
-  ft_ovf_.ensure((size_t)std::max(ext[0] * nzc, ext[1] * nzc) * 6, stream_);
+  (void)nzc;
+  ft_spill_.ensure((size_t)kFtBlocks * 4 * ((size_t)std::max(ext[0], ext[1]) + 2) * 512u, stream_);
   if (open_side) ft_out_.ensure((size_t)g.n, stream_);
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }

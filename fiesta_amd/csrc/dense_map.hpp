@@ -57,7 +57,7 @@ enum Counter {
   C_ROUNDS,      // rounds of the compact-list mode that found a non-empty list (counted by the kernel)
   C_SCRATCH,
   C_REMOTE_DEL,  // sharded maps: some shard reported an occupied->free transition since the last UpdateESDF
-  C_FT_OVF0,     // bulk path: lengths of the ring-overflow lists (pass A tiers 0-2, pass B tiers 0-2)
+  C_FT_OVF0,     // bulk path: column groups that went through spill mode in pass A ([0]) and pass B ([3]); the others unused
   C_FT_OVF5 = C_FT_OVF0 + 5,
   C_FT_MAXD2,    // bulk path: largest d^2 written (2^30: a voxel found no obstacle in its region)
   C_PROF0,  // 8 profiling slots (FIESTA_HIP_PROF=1): cycles in stage / propagate / write-back, queue items, ...
@@ -178,7 +178,6 @@ class DenseMap {
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list);
   bool bulk_eligible(unsigned long long ni, unsigned long long nd);
   bool run_bulk(fiesta_hip_stats *st, int margin, bool *exact);
-  bool bulk_spilled_untiered();
   void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0);
   void reset_stats_counters(bool lists = false);
   void enable_distance_tracking();
@@ -215,15 +214,13 @@ class DenseMap {
   // off until a scan finds no such voxel left (k_count_stale) or the map holds no obstacle.
   bool stale_inf_ = false;
   bool win_dirty_ = false;  // an update ran under a partial window while obstacles existed (see bulk_eligible)
-  int ft_s0_ = 16;            // ring size of the bulk path's first tier: 16, or 32 once a scene needed deeper deques
-  bool ft_s0_fixed_ = false;  // (FIESTA_HIP_FT_S0 pins it)
+  int ft_s0_ = 16;            // ring entries per lane in LDS (16 or 32; FIESTA_HIP_FT_S0: an experiment's knob)
+  static constexpr int kFtBlocks = 1024;  // work-groups of a pass (4 waves each): what 256 CUs hold at once with 16-entry rings
   double ft_last_ms_ = 0;      // kernel time of the last bulk update (the engine choice's idea of this scene's sweep)
   bool ft_in_place_ = true;   // the last transform wrote the field itself (no side buffer: its result could not be inexact)
   bool ft_counters_clean_ = false;  // reset_stats_counters() ran and no transform has used the spill counters since
-  bool ft_tiers_off_ = false;  // the last run_bulk skipped the overflow tiers of a pass
-  int ft_tier_hold_[2] = {1, 1};  // updates for which pass A / pass B still launch their overflow tiers
-  int64_t ft_last_ovf_[6] = {1, 1, 1, 1, 1, 1};  // ring spills of the last bulk update per tier (sizes the overflow tiers' grids)
-  DevBuf<uint32_t> ft_inter_, ft_ovf_, ft_out_;
+  DevBuf<uint32_t> ft_inter_, ft_out_;
+  DevBuf<unsigned long long> ft_spill_;  // backing store of the transform's rings (run_bulk)
   DevBuf<uint16_t> ft_rowlist_;
   DevBuf<int32_t> ft_rowcnt_;
   hipEvent_t ft_ev_[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -69,6 +69,8 @@ FT_HD int floor_div_small(int N, int D) {
 // Ring:   void get(int c, uint32_t &e1, uint32_t &e2), void set(int c, uint32_t e1, uint32_t e2), static int kStep:
 //         c is a MONOTONE counter that advances by kStep per entry (the ring reduces it to a slot itself): an LDS ring
 //         counts in bytes, so that a slot address is one and-or of the counter (ft_kernels.hpp: LdsRing).
+//         void bget(int c, ...), void bset(int c, ...): the BACKING STORE behind the ring, one slot per counter value (in
+//         the kernels: global memory) -- see "a deque deeper than its ring" below.
 //
 // The operations are written for a WAVE that runs 64 envelopes in lock-step: no data-dependent branch inside -- every
 // lane executes every instruction, lanes that have nothing to do pass `doit = false` and get their state back through
@@ -90,20 +92,20 @@ struct LaneEnvelope {
   static constexpr int K = Ring::kStep;
   Ring r;
   int bot, top;  // live entries are bot..top (monotone counters in units of K, see Ring); empty iff top < bot
+  int lo;        // spill mode only: the oldest entry still in the ring; entries bot .. lo - K live in the backing store
   // cached top entry: position q and key = q^2 + f(q), so that cost(p) = p (p - 2 q) + key; t_s = its start
   int t_q, t_key, t_s;
   // cached bottom entry = the winner at the emission point: its output word and height
   uint32_t c_word;
   int c_f;
-  bool overflow;
 
   FT_HD void init() {
     bot = 0;
     top = -K;
+    lo = 0;
     t_q = t_key = t_s = 0;
     c_word = 0;
     c_f = 0;
-    overflow = false;
   }
   FT_HD bool empty() const { return top < bot; }
   FT_HD int depth() const { return (top - bot) / K + 1; }
@@ -152,9 +154,7 @@ struct LaneEnvelope {
     int s = start_of(key - t_key, q - t_q);  // (an empty ring: garbage in, garbage out, replaced below)
     s = s < n_pos ? s : n_pos;               // clamped: an entry that starts at the end of the column never wins
     s = has ? s : p_out;                     // alone, it owns everything that is not emitted yet
-    const bool ovf = doit & (top - bot >= (S - 2) * K);  // one slot stays free, see below
-    overflow = overflow | ovf;
-    const bool keep = doit & !ovf;
+    const bool keep = doit;  // (the caller has made room: full() / evict())
     const int ntop = top + K;
     // every lane stores, no branch around it: the slot after the top is never live (at most S - 1 entries), a lane that
     // keeps nothing just leaves a stale entry there
@@ -164,6 +164,60 @@ struct LaneEnvelope {
     t_key = keep ? key : t_key;
     t_s = keep ? s : t_s;
   }
+  // ---- a deque deeper than its ring.  The ring holds S - 1 entries (one slot stays free for the unconditional store of
+  // place).  When a lane's deque outgrows that, its OLDEST ring entry moves to the backing store -- one slot per counter
+  // value, so an entry keeps its address for life -- and the lane goes on where it stands: the ring is then the window
+  // lo .. top of the deque, bot .. lo - K lie in the backing store and come back one at a time when the emission point
+  // (step_to) or, rarely, a run of pops reaches them.  The wave as a whole is in SPILL MODE while any lane has entries
+  // out there (a wave-uniform flag in the kernels): only then are the *_sp variants below executed, so a scene whose
+  // deques fit their rings pays one vote per batch of sites for all of this.
+  // Room is checked once per BATCH of sites (the kernels place up to P sites between two emission runs): a batch that
+  // starts with P free slots in every lane's ring needs no check at all; otherwise it runs "carefully" -- spill mode,
+  // where every site asks full_sp() first.  (Bare compares: the wave's vote on them is the compare's own mask.)
+  FT_HD bool near_full(int P) const { return top - bot >= (S - 1 - P) * K; }  // fewer than P free slots (plain mode)
+  FT_HD bool full_sp() const { return top - lo >= (S - 2) * K; }              // place() would need the free slot
+  FT_HD void enter_spill() { lo = bot; }                                             // (every lane, spilling or not)
+  FT_HD bool spilled() const { return bot < lo; }
+  FT_HD void evict(bool doit) {  // the oldest entry of the ring -> backing store (doit => the window is not empty)
+    uint32_t e1, e2;
+    r.get(lo, e1, e2);
+    if (doit) r.bset(lo, e1, e2);
+    lo = doit ? lo + K : lo;
+  }
+  FT_HD void pop_sp(bool doit) {
+    const int nt = top - K;
+    uint32_t e1, e2;
+    r.get(nt, e1, e2);
+    const bool more = nt >= bot;
+    if (doit & more & (nt < lo)) r.bget(nt, e1, e2);  // the new top was evicted earlier
+    const int nq = (int)(e2 >> QSH);
+    const int nk = more ? mul24(nq, nq) + (int)(e1 >> SB) : 0, ns = more ? (int)(e1 & kSMask) : 0;
+    top = doit ? nt : top;
+    t_q = doit ? nq : t_q;
+    t_key = doit ? nk : t_key;
+    t_s = doit ? ns : t_s;
+    lo = (doit & (nt + K < lo)) ? nt + K : lo;  // the window never reaches beyond the slot place() writes next
+  }
+  FT_HD void reload_bottom_sp() {
+    uint32_t e1, e2;
+    r.get(bot, e1, e2);
+    const bool has = top >= bot;
+    if (has & (bot < lo)) r.bget(bot, e1, e2);
+    c_word = has ? e2 : c_word;
+    c_f = has ? (int)(e1 >> SB) : c_f;
+  }
+  FT_HD void step_to_sp(int p) {
+    const int nb = bot + K;
+    uint32_t e1, e2;
+    r.get(nb, e1, e2);
+    if ((nb <= top) & (nb < lo)) r.bget(nb, e1, e2);
+    const bool adv = (nb <= top) & ((int)(e1 & kSMask) <= p);
+    bot = adv ? nb : bot;
+    c_word = adv ? e2 : c_word;
+    c_f = adv ? (int)(e1 >> SB) : c_f;
+    lo = lo < bot ? bot : lo;  // (a lane whose backing store has run dry: window = deque again)
+  }
+
   // before a run of emissions: the cached bottom from the ring (sites placed since the last run did not maintain it)
   FT_HD void reload_bottom() {
     uint32_t e1, e2;

@@ -15,6 +15,7 @@
 // is written when it is final in all 64 lanes) so that stores stay coalesced.  If a ring of S entries overflows, the
 // wave appends its item to a list and the next tier (bigger rings, fewer resident waves) redoes those items.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "ft_core.hpp"
 
@@ -38,12 +39,13 @@ struct FtArgs {
   vox_t *coc;                // output array (the map's voxel words) with extents (., ony, onz); region voxel (x,y,z) is
   int ox0, oy0, oz0;         // output voxel (x - ox0, y - oy0, z - oz0), written iff inside [0,onx) x [0,ony) x [0,onz)
   int onx, ony, onz;
-  // work items: implicit 0..n_items-1 (items == nullptr) or an explicit list whose length lives on the device
-  const uint32_t *items;
-  const unsigned long long *n_items_dev;
-  uint32_t n_items;
-  uint32_t *ovf_list;  // items whose ring overflowed, for the next tier
-  unsigned long long *ovf_count;
+  uint32_t n_items;  // work items 0 .. n_items - 1 (pass A: x * nzc + c, pass B: y * nzc + c), walked with a grid stride
+  // backing store of the rings (ft_core.hpp: a deque deeper than its ring): spill_stride bytes per wave of the grid, one
+  // 512-byte slot row (64 lanes x 8 B) per counter value, i.e. (longest column + 2) x 512; the wave with linear index
+  // blockIdx.x * WAVES + wave owns its slice for every item it walks
+  char *spill;
+  uint32_t spill_stride;
+  unsigned long long *spill_count;  // statistics: items (column groups) that moved ring entries to the backing store
   unsigned long long *maxd2;  // optional: atomicMax of every d^2 written; a voxel without any site counts as 2^30
   __device__ __forceinline__ const uint32_t *row(int x, int y) const {
     return src + ((int64_t)(x + sx0) * sny + (y + sy0)) * snzw + sw0;
@@ -64,6 +66,7 @@ struct LdsRing {
   static constexpr bool kAligned = kBytes <= 16384u;            // (bigger rings are not worth the padding in LDS)
   static constexpr uint32_t kMask = (uint32_t)(S - 1) * kStep;
   uint32_t base;  // LDS byte address of this lane's slot 0 (kAligned: the wave's ring starts at a multiple of kBytes)
+  char *bk;       // backing store: this lane's 8 bytes of slot row 0; the row of counter c starts c bytes further (LANES == 64)
   bool live;  // LANES < 64: the lanes beyond LANES carry no column and share the ring of lane % LANES -- they may read it
               // (and ignore what they read) but must not take part in the envelope's unconditional store
   __device__ __forceinline__ lds_uint2 *slot(int c) const {
@@ -77,10 +80,16 @@ struct LdsRing {
   __device__ __forceinline__ void set(int c, uint32_t e1, uint32_t e2) {
     if (LANES == 64 || live) *slot(c) = ft_u32x2{e1, e2};
   }
+  __device__ __forceinline__ void bget(int c, uint32_t &e1, uint32_t &e2) const {
+    const uint2 v = *reinterpret_cast<const uint2 *>(bk + (uint32_t)c);
+    e1 = v.x, e2 = v.y;
+  }
+  __device__ __forceinline__ void bset(int c, uint32_t e1, uint32_t e2) { *reinterpret_cast<uint2 *>(bk + (uint32_t)c) = make_uint2(e1, e2); }
 };
 template <int S, int LANES>
-__device__ __forceinline__ LdsRing<S, LANES> make_ring(const uint2 *wave_ring, int lane) {
-  return LdsRing<S, LANES>{(uint32_t)(size_t)(wave_ring + lane % LANES), lane < LANES};  // (low half of a generic LDS pointer: the offset)
+__device__ __forceinline__ LdsRing<S, LANES> make_ring(const uint2 *wave_ring, int lane, char *wave_spill) {
+  static_assert(LANES == 64, "the backing store is laid out for full waves");
+  return LdsRing<S, LANES>{(uint32_t)(size_t)(wave_ring + lane % LANES), wave_spill + 8 * lane, lane < LANES};  // (low half of a generic LDS pointer: the offset)
 }
 // Site packing.  Regions of at most 1024 voxels per axis (every unsharded map up to the plain-id limit): ABSOLUTE region
 // coordinates, 10 bits each.  WIDE (regions up to 2048: a 1024^3 shard of config 5 plus its margin; grids beyond 1024 per
@@ -133,10 +142,6 @@ __global__ __launch_bounds__(256) void k_ft_rows(FtArgs a) {
   }
 }
 
-__device__ __forceinline__ void ft_overflow(const FtArgs &a, uint32_t id, int lane) {
-  if (lane == 0 && a.ovf_list) a.ovf_list[atomicAdd(a.ovf_count, 1ull)] = id;
-}
-
 // ---- pass A: in-plane nearest site.  item = x * nzc + c: plane x, lanes z = 64 c + lane ------------------------------
 template <int S, int LANES, int WAVES, bool WIDE>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
@@ -150,11 +155,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
   auto &ring = lds.ring;
   auto &rowstage = lds.rowstage;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  constexpr int SUB = 64 / LANES;  // sub-items per column group when a wave only carries LANES columns
-  const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
-  for (uint32_t it = blockIdx.x * WAVES + wave; it < n; it += gridDim.x * WAVES) {
-    const uint32_t id = a.items ? a.items[it / SUB] : it / SUB;
-    const int sub = (int)(it % SUB);
+  char *const wave_spill = a.spill + (size_t)(blockIdx.x * WAVES + wave) * a.spill_stride;
+  for (uint32_t id = blockIdx.x * WAVES + wave; id < a.n_items; id += gridDim.x * WAVES) {
+    constexpr int sub = 0;
     const int x = (int)(id / (uint32_t)a.nzc), c = (int)(id % (uint32_t)a.nzc);
     const int cnt = __builtin_amdgcn_readfirstlane(a.rowcnt[x]);
     if (cnt == 0) continue;  // pass B never reads an empty plane
@@ -162,14 +165,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
     const int z = 64 * c + k;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;  // (pass B only reads these)
     ft::LaneEnvelope<S, LdsRing<S, LANES>, FtPack<WIDE>::SH, WIDE> env;  // entries: q = row y', f = (z - z')^2, tag = z'
-    env.r = make_ring<S, LANES>(&ring[wave][0], lane);
+    env.r = make_ring<S, LANES>(&ring[wave][0], lane, wave_spill);
     env.init();
     env.set_idle(!act);
     int p_out = 0;
-    bool failed = false;
+    bool sp = false;  // wave-uniform: some lane keeps entries in the backing store (ft_core.hpp, spill mode)
+    bool careful = false, counted = false;
     uint32_t *out = a.inter + (int64_t)x * a.ny * a.nz + (act ? z : 0);
     const uint16_t *rows = a.rowlist + (int64_t)x * a.ny;
-    for (int i0 = 0; i0 < cnt && !failed; i0 += RB) {
+    for (int i0 = 0; i0 < cnt; i0 += RB) {
       // stage the bitmap words of the next RB non-empty rows: two dependent loads per batch instead of per row
       const int nb = min(RB, cnt - i0);
       const int ylist = rows[min(i0 + lane, cnt - 1)];  // lanes 0..nb-1: the rows of this batch; lane RB: the one after
@@ -209,46 +213,80 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_plane(FtArgs a) {
         const int dd = WIDE ? min(d, 1023) : d;
         const int f = ft::mul24(dd, dd), key = yr * yr + f;
         const uint32_t word = ((uint32_t)yr << FtPack<WIDE>::SH) | (uint32_t)(zp & ((1 << FtPack<WIDE>::SH) - 1));
-        for (;;) {  // pop while any lane wants to
-          const bool want = env.wants_pop(yr, key);  // (a lane without a column has an empty ring: never)
-          if (!ft_vote(want)) break;
-          env.pop(want);
+        // a batch of up to 8 rows begins (the rows between two emission runs): plain if every lane has 8 free ring slots
+        // and nothing is out in the backing store, else careful -- spill mode (ft_core.hpp)
+        if ((r & 7) == 0) {
+          careful = sp || ft_vote(env.near_full(8)) != 0;
+          if (careful && !sp) env.enter_spill();
         }
-        env.place(act, yr, f, word, key, a.ny, p_out);
+        if (!careful) {
+          for (;;) {  // pop while any lane wants to
+            const bool want = env.wants_pop(yr, key);  // (a lane without a column has an empty ring: never)
+            if (!ft_vote(want)) break;
+            env.pop(want);
+          }
+          env.place(act, yr, f, word, key, a.ny, p_out);
+        } else {
+          for (;;) {
+            const bool want = env.wants_pop(yr, key);
+            if (!ft_vote(want)) break;
+            env.pop_sp(want);
+          }
+          const bool full = env.full_sp();  // a lane whose ring is full moves its oldest entry to the backing store
+          if (ft_vote(full)) {
+            env.evict(full);
+            if (!counted && lane == 0 && a.spill_count) atomicAdd(a.spill_count, 1ull);
+            counted = true;
+          }
+          env.place(act, yr, f, word, key, a.ny, p_out);
+        }
         // positions are emitted every eighth site row (and at the end of a staged batch): a run of emissions ends with a
         // failed finality vote, and sites placed in between need not keep the cached bottom entry current
         if ((r & 7) != 7 && r + 1 < nb) continue;
-        if (ft_vote(env.overflow)) {  // (a lane that overflowed has emitted nothing since: the next tier redoes the item)
-          failed = true;
-          break;
-        }
-        env.reload_bottom();
         const int pend = min(a.ny, ynext);
         auto emit = [&]() {
           if (act && (unsigned)(p_out - a.oy0) < (unsigned)a.ony) *out = env.winner_word();
           out += a.nz;
           ++p_out;
         };
-        // four positions per finality vote while that holds (ft_core.hpp: finality is monotone) ...
-        while (p_out + 3 < pend) {
-          const bool fin4 = env.final_at(p_out + 3, ynext);
-          if (ft_vote(fin4) != ~0ull) break;
+        auto run = [&](auto sp_tag) {
+          constexpr bool SP = decltype(sp_tag)::value;
+          if (SP)
+            env.reload_bottom_sp();
+          else
+            env.reload_bottom();
+          // four positions per finality vote while that holds (ft_core.hpp: finality is monotone) ...
+          while (p_out + 3 < pend) {
+            const bool fin4 = env.final_at(p_out + 3, ynext);
+            if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            env.step_to(p_out);
+            for (int j = 0; j < 4; ++j) {
+              if (SP)
+                env.step_to_sp(p_out);
+              else
+                env.step_to(p_out);
+              emit();
+            }
+          }
+          // ... then one by one
+          while (p_out < pend) {
+            if (SP)
+              env.step_to_sp(p_out);
+            else
+              env.step_to(p_out);
+            const bool fin = env.final_at(p_out, ynext);
+            if (ft_vote(fin) != ~0ull) break;
             emit();
           }
-        }
-        // ... then one by one
-        while (p_out < pend) {
-          env.step_to(p_out);
-          const bool fin = env.final_at(p_out, ynext);
-          if (ft_vote(fin) != ~0ull) break;
-          emit();
+        };
+        if (careful) {
+          run(std::true_type{});
+          sp = ft_vote(env.spilled()) != 0;  // (nothing left out there: the next batch may be a plain one again)
+        } else {
+          run(std::false_type{});
         }
       }
     }
-    if (failed) ft_overflow(a, id, lane);
   }
 }
 
@@ -270,8 +308,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
   };
   __shared__ Lds lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  constexpr int SUB = 64 / LANES;
-  const uint32_t n = (a.n_items_dev ? (uint32_t)*a.n_items_dev : a.n_items) * SUB;
+  char *const wave_spill = a.spill + (size_t)(blockIdx.x * WAVES + wave) * a.spill_stride;
   uint32_t acc_maxd2 = 0;
   // which planes hold any site: bit x of the 2048-bit mask, word w in lane w
   // (lane w holds planes 32 w .. 32 w + 31, built from the planes' row counts: no mask to zero and fill with atomics)
@@ -287,21 +324,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
     }
   }
   auto plane_has = [&](const int x) -> bool { return (__builtin_amdgcn_readlane(pm, (x >> 5) & 63) >> (x & 31)) & 1u; };
-  for (uint32_t it = blockIdx.x * WAVES + wave; it < n; it += gridDim.x * WAVES) {
-    const uint32_t id = a.items ? a.items[it / SUB] : it / SUB;
-    const int sub = (int)(it % SUB);
+  for (uint32_t id = blockIdx.x * WAVES + wave; id < a.n_items; id += gridDim.x * WAVES) {
+    constexpr int sub = 0;
     const int y = __builtin_amdgcn_readfirstlane((int)(id / (uint32_t)a.nzc)), c = __builtin_amdgcn_readfirstlane((int)(id % (uint32_t)a.nzc));
     const int z = 64 * c + sub * LANES + lane;
     const bool act = lane < LANES && z < a.nz && (unsigned)(z - a.oz0) < (unsigned)a.onz;
     if ((unsigned)(y - a.oy0) >= (unsigned)a.ony) continue;  // (the host only lists rows of the output box)
     // entries: q = plane x', f = (y - y')^2 + (z - z')^2, tag = y' << 10 | z' (WIDE: the offsets y' - y, z' - z)
     ft::LaneEnvelope<S, LdsRing<S, LANES>, 20, WIDE> env;
-    env.r = make_ring<S, LANES>(&lds.ring[wave][0], lane);
+    env.r = make_ring<S, LANES>(&lds.ring[wave][0], lane, wave_spill);
     env.init();
     env.set_idle(!act);
     uint32_t *land = &lds.land[wave][0];
     int p_out = 0;
-    bool failed = false;
+    bool sp = false;  // wave-uniform: some lane keeps entries in the backing store (ft_core.hpp, spill mode)
+    bool counted = false;
     const int64_t plane = (int64_t)a.ny * a.nz, col = (int64_t)y * a.nz + (act ? z : 0);
     const uint32_t *in = a.inter + col;
     const int64_t oplane = (int64_t)a.ony * a.onz;
@@ -330,22 +367,33 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       orow += oplane * (int64_t)sizeof(vox_t);
       ++p_out;
     };
-    auto drain = [&](const int x_next) {
+    auto run = [&](auto sp_tag, const int x_next) {
+      constexpr bool SP = decltype(sp_tag)::value;
       const int pend = min(a.nx, x_next);
-      env.reload_bottom();  // (the sites of this batch were placed without keeping the cached bottom up to date)
+      // (the sites of this batch were placed without keeping the cached bottom up to date)
+      if (SP)
+        env.reload_bottom_sp();
+      else
+        env.reload_bottom();
       // four positions per finality vote while that holds (ft_core.hpp: finality is monotone) ...
       while (p_out + 3 < pend) {
         const bool fin4 = env.final_at(p_out + 3, x_next);
         if (ft_vote(fin4) != ~0ull) break;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          env.step_to(p_out);
+          if (SP)
+            env.step_to_sp(p_out);
+          else
+            env.step_to(p_out);
           emit();
         }
       }
       // ... then one by one
       while (p_out < pend) {
-        env.step_to(p_out);
+        if (SP)
+          env.step_to_sp(p_out);
+        else
+          env.step_to(p_out);
         const bool fin = env.final_at(p_out, x_next);
         if (ft_vote(fin) != ~0ull) break;
         emit();
@@ -368,56 +416,78 @@ __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
       }
     };
     issue(0);
-    for (int x0 = 0; x0 < a.nx && !failed; x0 += P) {
+    for (int x0 = 0; x0 < a.nx; x0 += P) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the batch has landed (and the previous batch's stores are out)
 #pragma unroll
       for (int u = 0; u < P; ++u) w[u] = land[u * 64 + lane];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and is in registers before the next one may land
       issue(x0 + P);
+      // the batch's sites, then the positions they made final.  A batch is PLAIN if every lane has P free ring slots and
+      // nothing is out in the backing store -- no room check at any site -- else CAREFUL: spill mode (ft_core.hpp)
+      auto sites = [&](auto sp_tag) {
+        constexpr bool SP = decltype(sp_tag)::value;
 #pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const int x = x0 + u;
-        if (x >= a.nx || failed) break;
-        if (plane_has(x)) {
-          uint32_t tag;
-          int dy, dz;
-          bool use = act;
-          if (WIDE) {  // offsets from the column; a site out of an id's reach in y or z is no candidate
-            dy = (int)(w[u] >> 11) - y, dz = (int)(w[u] & 2047u) - z;
-            use = use && (unsigned)(dy + 511) < 1023u && (unsigned)(dz + 511) < 1023u;
-            tag = (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u) | ((uint32_t)x << 20);
-            dy = use ? dy : 0, dz = use ? dz : 0;  // (f stays inside its bit field)
-          } else {
-            tag = (w[u] & 0xFFFFFu) | ((uint32_t)x << 20);  // (the output word; x is wave-uniform: one v_and_or)
-            dy = y - (int)((w[u] >> 10) & 1023u), dz = z - (int)(w[u] & 1023u);
+        for (int u = 0; u < P; ++u) {
+          const int x = x0 + u;
+          if (x >= a.nx) break;
+          if (plane_has(x)) {
+            uint32_t tag;
+            int dy, dz;
+            bool use = act;
+            if (WIDE) {  // offsets from the column; a site out of an id's reach in y or z is no candidate
+              dy = (int)(w[u] >> 11) - y, dz = (int)(w[u] & 2047u) - z;
+              use = use && (unsigned)(dy + 511) < 1023u && (unsigned)(dz + 511) < 1023u;
+              tag = (((uint32_t)dy & 1023u) << 10) | ((uint32_t)dz & 1023u) | ((uint32_t)x << 20);
+              dy = use ? dy : 0, dz = use ? dz : 0;  // (f stays inside its bit field)
+            } else {
+              tag = (w[u] & 0xFFFFFu) | ((uint32_t)x << 20);  // (the output word; x is wave-uniform: one v_and_or)
+              dy = y - (int)((w[u] >> 10) & 1023u), dz = z - (int)(w[u] & 1023u);
+            }
+            const int f = ft::mul24(dy, dy) + ft::mul24(dz, dz), key = env.key_of(x, f);
+            const int pkey = (WIDE && !use) ? env.kNoPop : key;  // (plain packing: use == act, and an idle lane's ring is empty)
+            for (;;) {  // pop while any lane wants to
+              const bool want = env.wants_pop(x, pkey);
+              if (!ft_vote(want)) break;
+              if (SP)
+                env.pop_sp(want);
+              else
+                env.pop(want);
+            }
+            if (SP) {  // a lane whose ring is full moves its oldest entry to the backing store
+              const bool full = env.full_sp();
+              if (ft_vote(full)) {
+                env.evict(full);
+                if (!counted && lane == 0 && a.spill_count) atomicAdd(a.spill_count, 1ull);
+                counted = true;
+              }
+            }
+            env.place(use, x, f, tag, key, a.nx, p_out);
           }
-          const int f = ft::mul24(dy, dy) + ft::mul24(dz, dz), key = env.key_of(x, f);
-          const int pkey = (WIDE && !use) ? env.kNoPop : key;  // (plain packing: use == act, and an idle lane's ring is empty)
-          for (;;) {  // pop while any lane wants to
-            const bool want = env.wants_pop(x, pkey);
-            if (!ft_vote(want)) break;
-            env.pop(want);
-          }
-          env.place(use, x, f, tag, key, a.nx, p_out);
         }
-      }
-      if (ft_vote(env.overflow)) failed = true;  // (nothing has been emitted since the ring spilled: the next tier redoes the item)
-      // positions are emitted once per batch: a failed finality vote (the way every drain ends) costs as much as an
+      };
+      // positions are emitted once per batch: a failed finality vote (the way every run ends) costs as much as an
       // emission, and a batch's stores then sit right in front of the next batch's wait
-      if (!failed) drain(min(x0 + P, a.nx));
+      if (sp || ft_vote(env.near_full(P)) != 0) {
+        if (!sp) env.enter_spill();
+        sites(std::true_type{});
+        run(std::true_type{}, min(x0 + P, a.nx));
+        sp = ft_vote(env.spilled()) != 0;  // (nothing left out there: the next batch may be a plain one again)
+      } else {
+        sites(std::false_type{});
+        run(std::false_type{}, min(x0 + P, a.nx));
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, unused prefetch must not land in the next item's batch)
-    if (failed) {
-      ft_overflow(a, id, lane);
-      continue;
-    }
     if (ft_vote(act && !env.empty())) {
       if (WIDE) {  // a lane that found no site in reach must not hold up its neighbours' last run: it reads "no obstacle"
         no_site = act & env.empty();
         if (no_site) env.set_idle(true);
         if (TRACK && no_site) acc_maxd2 = 1u << 30;
       }
-      drain(ft::kFarAhead);
+      if (sp)
+        run(std::true_type{}, ft::kFarAhead);
+      else
+        run(std::false_type{}, ft::kFarAhead);
     } else {  // no occupied voxel anywhere in the region: "observed, no obstacle"
       for (int p = 0; p < a.nx; ++p) {
         if (act && (unsigned)(p - a.ox0) < (unsigned)a.onx) *reinterpret_cast<vox_t *>(orow + ooff) = kInf;

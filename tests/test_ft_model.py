@@ -1,6 +1,7 @@
 """The bulk path's integer machinery (fiesta_amd/csrc/ft_core.hpp: streaming lower envelope, nearest set bit of a row)
 checked on the CPU: tests/cpp/ft_model.cpp drives the very header the HIP kernels instantiate -- 64-lane waves,
-lock-step emission, ring overflow and the retry tiers -- and the result must be the exact Euclidean feature transform
+lock-step emission, a deque that outgrows its ring and goes on in the backing store (the wave's spill mode: eviction of the
+oldest ring entry, pops and the emission point reaching into the store) -- and the result must be the exact Euclidean feature transform
 (squared distances equal to scipy's EDT; every closest site occupied).  No GPU, no oracle."""
 import ctypes as C
 import os
@@ -71,7 +72,7 @@ def test_random_scatter_is_exact(model, shape, density, seed, S0):
     out, stats = run(model, occ, S0)
     check_exact(occ, out)
     if S0 == 4 and density <= 0.01 and min(shape) > 8:
-        assert stats[1] > 0, "a 4-entry ring must overflow somewhere on sparse fields (the retry tiers were not exercised)"
+        assert stats[1] > 0 and stats[2] > 0, "a 4-entry ring must spill somewhere on sparse fields (spill mode was not exercised)"
 
 
 def test_no_site_and_single_site(model):
@@ -85,7 +86,7 @@ def test_no_site_and_single_site(model):
 
 def test_walls_and_shells_need_deep_rings(model):
     """A wall parallel to a column makes every position a different winner: the deque is as deep as twice the
-    distance; a 32-entry ring overflows and the 256/1024 tiers take over."""
+    distance; rings of 32, 16, 8 and 4 entries spill more and more of it into the backing store."""
     occ = np.zeros((70, 40, 66), np.uint8)
     occ[:, 2, :] = 1          # wall y = 2
     occ[35, 30:40, 10:60] = 1  # plate
@@ -94,9 +95,13 @@ def test_walls_and_shells_need_deep_rings(model):
     occ[np.abs(r - 14) < 0.6] = 1
     out, stats = run(model, occ, 32)
     check_exact(occ, out)
-    out2, stats2 = run(model, occ, 8)
-    check_exact(occ, out2)
-    assert stats2[1] > 0
+    seen = []
+    for S0 in (16, 8, 4):
+        out2, stats2 = run(model, occ, S0)
+        check_exact(occ, out2)
+        assert stats2[1] > 0 and stats2[2] > 0
+        seen.append(int(stats2[2]))
+    assert seen[0] < seen[1] < seen[2], seen      # a smaller ring evicts more
 
 
 def test_far_field_of_a_wall(model):
@@ -110,8 +115,8 @@ def test_far_field_of_a_wall(model):
 
 def test_column_as_long_as_the_deepest_ring_allows(model):
     """Every site of a 1024-long column equally good and 1023 voxels away: nothing is final before the last site has
-    arrived, so the deque holds one entry per position.  A ring of S slots holds S - 1 entries (one slot stays free for
-    the unconditional store), which is why the deepest tier has twice as many slots as a column has positions."""
+    arrived, so the deque holds one entry per position -- all but the ring's S - 1 newest in the backing store, which
+    has one slot per counter value (a column's positions + 2)."""
     occ = np.zeros((1024, 1024, 1), np.uint8)
     occ[:, 0, 0] = 1
     out, stats = run(model, occ, 64)
@@ -119,7 +124,7 @@ def test_column_as_long_as_the_deepest_ring_allows(model):
     got_x, got_y = (out >> 20).astype(np.int64)[:, :, 0], ((out >> 10) & 1023).astype(np.int64)[:, :, 0]
     assert np.array_equal(got_y, np.zeros((1024, 1024), np.int64))                       # the obstacle straight "below"
     assert np.array_equal(got_x, np.broadcast_to(np.arange(1024)[:, None], (1024, 1024)))
-    assert stats[0] >= 1022 and stats[2] > 0        # deque as deep as the column is long; the 256-slot tier spilled too
+    assert stats[0] >= 1022 and stats[2] > 900 * 1024   # deque as deep as the column is long: nearly every entry of every column was evicted
 
 
 def test_wide_packing_reach_of_an_id(model):
