@@ -12,8 +12,8 @@
 // load and store of a step is one 256-byte row segment) -- and walks the scan axis serially; each lane runs its own
 // LaneEnvelope with its deque in LDS (ring[slot][lane]: a lane always hits its own bank, no conflicts).  The deque is
 // bounded because positions are emitted as soon as they are final; emission is lock-step across the wave (a position
-// is written when it is final in all 64 lanes) so that stores stay coalesced.  If a ring of S entries overflows, the
-// wave appends its item to a list and the next tier (bigger rings, fewer resident waves) redoes those items.
+// is written when it is final in all 64 lanes) so that stores stay coalesced.  A deque that outgrows its ring of S
+// entries goes on in a backing store in global memory (ft_core.hpp, spill mode): one kernel per pass, whatever the scene.
 #pragma once
 #include <type_traits>
 #include "common.hpp"
@@ -53,10 +53,9 @@ struct FtArgs {
 };
 
 // LDS ring of one wave: entry[slot][lane], two 32-bit words (ft_core.hpp: e1 = f << SB | start, e2 = the output word
-// q << QSH | tag), read and written as one 8-byte access.  LANES < 64: only the first LANES lanes of the wave carry a column (the deepest tier
-// trades lanes for depth).
-// Counters of the envelope advance by kStep = the byte stride of a slot, and the rings of the small tiers are aligned to
-// their own size: a slot address is then ONE v_and_or_b32 of the counter (r02: shift, mask, add).
+// q << QSH | tag), read and written as one 8-byte access.
+// Counters of the envelope advance by kStep = the byte stride of a slot, and a wave's ring is aligned to its own
+// size: a slot address is then ONE v_and_or_b32 of the counter (r02: shift, mask, add).
 typedef unsigned int ft_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) ft_u32x2 lds_uint2;
 template <int S, int LANES>
@@ -300,7 +299,7 @@ template <int S, int LANES, int WAVES, bool WIDE, bool TRACK>
 __global__ __launch_bounds__(64 * WAVES) void k_ft_x(FtArgs a) {
   constexpr int P = 8;
   // the landing zones of the prefetch (per wave: P planes x 64 lanes x 4 B) come first, so that the LDS address the DMA
-  // takes from m0 stays below 64 KB in every tier; then the rings, each aligned to its own size in the small tiers
+  // takes from m0 stays below 64 KB; then the rings, each aligned to its own size
   constexpr int RA = LdsRing<S, LANES>::kAligned ? S * LANES * 8 : 16;
   struct __attribute__((aligned(RA))) Lds {
     uint32_t land[WAVES][P * 64];

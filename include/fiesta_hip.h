@@ -74,7 +74,8 @@ typedef struct fiesta_hip_stats {
   int64_t prof[8];       /* engine profiling counters (only with FIESTA_HIP_PROF=1 in the environment) */
   int64_t bulk;          /* 1: this update ran the bulk feature transform (rounds == 0), relax_ms = its kernels */
   double ft_rows_ms, ft_plane_ms, ft_x_ms; /* bulk path: HIP-event time of k_ft_rows / pass A / pass B */
-  int64_t ft_overflow[6];/* bulk path: column groups that outgrew the ring of pass A tiers 0-2, pass B tiers 0-2 */
+  int64_t ft_overflow[6];/* bulk path: column groups that moved ring entries to the backing store (deques deeper than
+                            their LDS ring): [0] pass A, [3] pass B; the other entries are unused (0) */
   int64_t observed_voxels, occupied_voxels; /* map totals at entry (array mode): observed at least once / Exist() */
   int64_t ft_max_d2;     /* bulk path on a shard: largest squared distance written (decides whether the margin sufficed) */
   int64_t dropped_observations; /* hash mode, cumulative: observations that fell outside the window even after it moved
