@@ -1235,7 +1235,8 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   // backing store of the rings: one slice per wave of the passes' grid (at most kFtBlocks work-groups of 4 waves), one
   // 512-byte slot row per counter value of the longest column (ft_core.hpp: a deque deeper than its ring)
   const uint32_t spill_stride = (uint32_t)(std::max(a.nx, a.ny) + 2) * 512u;
-  ft_spill_.ensure((size_t)kFtBlocks * 4 * spill_stride, stream_);
+  const uint32_t spill_blocks = std::min<uint32_t>((cap + 3) / 4, (uint32_t)kFtBlocks);  // (the larger pass's grid)
+  ft_spill_.ensure_exact((size_t)spill_blocks * 4 * (spill_stride / sizeof(unsigned long long)), stream_);
   a.rowlist = ft_rowlist_.p;
   a.rowcnt = ft_rowcnt_.p;
   a.planemask = reinterpret_cast<uint32_t *>(ft_rowcnt_.p + a.nx);
@@ -2098,8 +2099,7 @@ void DenseMap::bulk_reserve(int margin) {
   ft_inter_.ensure((size_t)(ext[0] * ext[1] * ext[2]), stream_);
   ft_rowlist_.ensure((size_t)(ext[0] * ext[1]), stream_);
   ft_rowcnt_.ensure((size_t)ext[0] + 64, stream_);
-  (void)nzc;
-  ft_spill_.ensure((size_t)kFtBlocks * 4 * ((size_t)std::max(ext[0], ext[1]) + 2) * 512u, stream_);
+  ft_spill_.ensure_exact((size_t)std::min<int64_t>((std::max(ext[0], ext[1]) * nzc + 3) / 4, kFtBlocks) * 4 * ((size_t)std::max(ext[0], ext[1]) + 2) * (512u / sizeof(unsigned long long)), stream_);
   if (open_side) ft_out_.ensure((size_t)g.n, stream_);
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }

@@ -19,6 +19,17 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+  // Exactly n elements if there are fewer now, contents dropped (large scratch: no doubling).
+  void ensure_exact(size_t n, hipStream_t s) {
+    if (n <= cap) return;
+    if (p) {
+      FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+      (void)hipFree(p);
+      p = nullptr, cap = 0;
+    }
+    FIESTA_HIP_CHECK(hipMalloc((void **)&p, n * sizeof(T)));
+    cap = n;
+  }
   // Grow to at least n elements; optionally preserve the first `keep` elements.
   void ensure(size_t n, hipStream_t s, size_t keep = 0) {
     if (n <= cap) return;
