@@ -1,2 +1,3 @@
-FIESTA_HIP_FT_S0=32 python bench.py --scene surfaces --no-cpu-baseline --steps 20 2>/dev/null | grep metric | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('surfaces S32', d['update_esdf_p50_ms'], d['roofline']['frac'], d['roofline']['phases_p50_ms'], d['roofline']['ring_overflows'])"
-FIESTA_HIP_FT_S0=32 python bench.py --no-cpu-baseline --steps 20 2>/dev/null | grep metric | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('scatter S32', d['update_esdf_p50_ms'], d['roofline']['frac'], d['roofline']['phases_p50_ms'], d['roofline']['ring_overflows'])"
+export FIESTA_REV=5d221c3
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+bash tools/collect_evidence.sh r03g 2>&1 | tail -3
