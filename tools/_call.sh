@@ -1,7 +1,4 @@
 mkdir -p gpurun_out
-timeout 900 python bench.py --gpus 1 --force-sharded --grid 1024 --no-cpu-baseline --steps 5 --warmup 1 2>gpurun_out/g1024.err | grep metric > gpurun_out/r03g_bench_1024_one_shard.json; python - <<'P'
-import json
-d=json.load(open('gpurun_out/r03g_bench_1024_one_shard.json'))
-print(round(d['value']/1e9,1), d['ms_per_step'], d.get('update_esdf_p50_ms'), d['roofline']['frac'], d['roofline'].get('phases_p50_ms'), d['verify'])
-P
-tail -2 gpurun_out/g1024.err
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/pt.log 2>&1; grep -E "passed|failed|error" gpurun_out/pt.log | tail -3; grep -E "^(FAILED|ERROR)|^E " gpurun_out/pt.log | head -20
+python bench.py --no-cpu-full 2>/dev/null | grep metric | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('default', d['value']/1e9, d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline']['value'], d['verify']['mismatches'])"
