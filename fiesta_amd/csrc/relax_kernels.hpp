@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NT, ((NT >= 1024 || NT * 4 >= TX * TY * 32) ? 4 : 2
       if (vec) {  // z and nz are multiples of N: the run is inside the array or outside as a whole
         const bool in = okxy && (region_inside || (unsigned)z < (unsigned)g.nz);
         vox_t q[N];
-        if (N == 4) {
+        if constexpr (N == 4) {
           const uint4 t = *reinterpret_cast<const uint4 *>(a.coc + (in ? idx : 0));
           q[0] = t.x, q[1] = t.y, q[2] = t.z, q[3] = t.w;
         } else {
