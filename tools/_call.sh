@@ -1,2 +1,4 @@
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_dense_parity.py tests/test_gpu_hash_parity.py tests/test_gpu_fuzz.py tests/test_gpu_sharded.py -q -m gpu > gpurun_out/pt.log 2>&1; grep -E "passed|failed|error" gpurun_out/pt.log | tail -2
+mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c3g -o c3 --output-format csv -- python bench.py --workload c3 --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c4g -o c4 --output-format csv -- python bench.py --workload c4 --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+ls gpurun_out/prof_c3g gpurun_out/prof_c4g | head
