@@ -1,4 +1,2 @@
-mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c3g -o c3 --output-format csv -- python bench.py --workload c3 --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c4g -o c4 --output-format csv -- python bench.py --workload c4 --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-ls gpurun_out/prof_c3g gpurun_out/prof_c4g | head
+mkdir -p gpurun_out
+timeout 280 python tools/c5_smoke.py 2>gpurun_out/c5.err | tail -1 > gpurun_out/r03g_c5_two_shards_bulk.json; cat gpurun_out/r03g_c5_two_shards_bulk.json | cut -c1-900; tail -2 gpurun_out/c5.err
