@@ -56,7 +56,7 @@ def parse():
                          "2048^3 as 2x2x2 shards at N = 8 = config 5)")
     ap.add_argument("--obstacles", type=int, default=None,
                     help="live obstacle voxels per rank (default: config 2's density, 50000 per 512^3)")
-    ap.add_argument("--engine", default="auto", choices=["auto", "rounds", "bulk"],
+    ap.add_argument("--engine", default="auto", choices=["auto", "rounds", "bulk", "levels"],
                     help="UpdateESDF engine: chosen per update (default), frontier rounds only, or the bulk feature "
                          "transform whenever the map state allows it")
     ap.add_argument("--scene", default="scatter", choices=["scatter", "surfaces"],
@@ -235,6 +235,21 @@ def verify_against_kdtree(query_d2, owned_lo, owned_size, obstacles, n_samples, 
     return int(len(v)), int((got != want).sum())
 
 
+def esdf_summary(stats):
+    """What the timed UpdateESDF calls were: medians of the engine's own counters (fiesta_hip_stats)."""
+    if not stats:
+        return None
+    med = lambda k: float(statistics.median([st[k] for st in stats]))   # noqa: E731
+    out = {k: med(k) for k in ("inserted", "deleted", "rounds", "relax_launches", "voxel_writes", "device_ms", "relax_ms")}
+    out["engine"] = {"levels": sum(int(st.get("levels", 0)) for st in stats), "bulk": sum(int(st.get("bulk", 0)) for st in stats), "calls": len(stats)}
+    if any(st.get("levels") for st in stats):   # level engine: time inside its one-work-group kernel, entries processed, largest frontier
+        lv = [st for st in stats if st.get("levels")]
+        out["level_kernel_us"] = float(statistics.median([st["prof"][0] for st in lv])) / 1e3
+        out["frontier_entries"] = float(statistics.median([st["prof"][6] for st in lv]))
+        out["frontier_peak"] = float(statistics.median([st["prof"][7] for st in lv]))
+    return out
+
+
 def run_c3(args):
     """BASELINE config 3 (`--workload c3`): 512^3 @0.1 m fed by 640x480 synthetic depth frames through the HIP ray cast
     (fiesta_hip_raycast_depth) -> UpdateOccupancy -> UpdateESDF on one MI355X.  Scene: 6x6x3 m box
@@ -267,7 +282,7 @@ def run_c3(args):
         T = yaw_pose(2.0 * f, (0.0, 0.0, 0.0))
         frames.append((T, render_depth(T, rows=480, cols=640, spheres=spheres, intr=intr)))
     lc, rc = origin, tuple(np.add(origin, size))
-    t_ray, t_fuse, t_esdf, t_all, cpu_t = [], [], [], [], []
+    t_ray, t_fuse, t_esdf, t_all, cpu_t, esdf_stats = [], [], [], [], [], []
     for f, (T, depth) in enumerate(frames):
         checked = cpu is not None and f < cpu_frames
         t0 = time.perf_counter()
@@ -301,6 +316,7 @@ def run_c3(args):
             t_fuse.append((t2 - t1b) * 1e3)
             t_esdf.append((t3 - t2) * 1e3)
             t_all.append((t1 - t0 + t3 - t1b) * 1e3)
+            esdf_stats.append(st)
     p50 = statistics.median
     out = {
         "metric": "c3_depth_frames_per_sec", "value": 1e3 / p50(t_all), "unit": "frames/s", "n_gpus": 1, "steps": len(t_all),
@@ -310,6 +326,7 @@ def run_c3(args):
                                "uint16 image uploaded inside the timed ray cast (PCIe-inclusive)"},
         "raycast_p50_ms": p50(t_ray), "rays_per_sec": 307200 / (p50(t_ray) * 1e-3),
         "update_occupancy_p50_ms": p50(t_fuse), "update_esdf_p50_ms": p50(t_esdf),
+        "update_esdf": esdf_summary(esdf_stats),
         "cpu_baseline": {"kind": "reference" if cpu is not None and cpu.describe.startswith("reference") else "port",
                          "cores": 1, "unit": "ms per stage", "sample": "the first frames of the same sequence",
                          "frames": cpu_t, "counters_bit_identical": bool(cpu_t)} if cpu_t else None,
@@ -341,7 +358,7 @@ def run_c4(args):
         v = torch.from_numpy(occ).to(dev)
         frames.append((lo, hi, occ, v, torch.ones(len(occ), dtype=torch.int32, device=dev)))
     torch.cuda.synchronize()
-    t_obs, t_fuse, t_esdf, upd, relax_ms, launches = [], [], [], [], [], []
+    t_obs, t_fuse, t_esdf, upd, relax_ms, launches, esdf_stats = [], [], [], [], [], [], []
     for k, (lo, hi, occ, v, o) in enumerate(frames):
         t0 = time.perf_counter()
         m.SetOccupancyBox(lo, hi, 0)
@@ -359,6 +376,7 @@ def run_c4(args):
         if k >= args.warmup:
             t_obs.append(t1 - t0), t_fuse.append(t2 - t1), t_esdf.append(t4 - t3), upd.append(n_upd)
             relax_ms.append(st["relax_ms"]), launches.append(st["relax_launches"])
+            esdf_stats.append(st)
     total_s = sum(t_obs) + sum(t_fuse) + sum(t_esdf)
     pages = m.grid_total_size_ // 8192
     cpu = None
@@ -407,8 +425,8 @@ def run_c4(args):
         "observe_p50_ms": 1e3 * statistics.median(t_obs), "update_occupancy_p50_ms": 1e3 * statistics.median(t_fuse),
         "update_esdf_p50_ms": 1e3 * statistics.median(t_esdf), "updated_voxels_per_frame": sum(upd) / len(upd),
         "update_esdf_voxels_per_sec": sum(upd) / sum(t_esdf), "allocated_pages": int(pages),
-        "allocated_voxels": int(m.grid_total_size_),
-        "roofline": {"bound": "hbm", "kernel": "k_relax_q<16,16,1024,PAGED>", "achieved": 16.0 * sum(upd) / max(sum_relax_s, 1e-12) / 1e9,
+        "allocated_voxels": int(m.grid_total_size_), "update_esdf": esdf_summary(esdf_stats),
+        "roofline": {"bound": "hbm", "kernel": "k_level_run / k_level_pull+push<PagedSpace>" if any(st.get("levels") for st in esdf_stats) else "k_relax_q<16,16,1024,PAGED>", "achieved": 16.0 * sum(upd) / max(sum_relax_s, 1e-12) / 1e9,
                      "peak": 8000.0, "unit": "GB/s", "frac": 16.0 * sum(upd) / max(sum_relax_s, 1e-12) / 8e12, "traffic": None,
                      "launches": n_launch, "avg_launch_us": 1e6 * sum_relax_s / n_launch},
         "cpu_baseline": cpu,

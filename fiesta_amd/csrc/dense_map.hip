@@ -25,6 +25,7 @@
 #include "dense_map.hpp"
 #include "checkpoint.hpp"
 #include "ft_kernels.hpp"
+#include "level_kernels.hpp"
 #include "relax_kernels.hpp"
 
 #include <algorithm>
@@ -341,9 +342,14 @@ __device__ inline vox_t reseed_first_neighbour(const Geom &g, const vox_t *coc, 
   return kInf;
 }
 
+// LEVELS (the level engine seeds itself from this scan, level_kernels.hpp): an orphan inside the window is reset with the
+// dead id still in the word (kReset | id: k_level_outside wants to know whose orphan it was) and appended to level 0's
+// frontier; one outside the window is only listed (lv.outside) and keeps its word until k_level_outside has judged it.
+template <bool LEVELS>
 __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *coc, const uint32_t *occbits,
                                                     const uint32_t *gocc, uint32_t *flag, uint32_t *list,
-                                                    unsigned long long *count, unsigned long long *counters, int bounded) {
+                                                    unsigned long long *count, unsigned long long *counters, int bounded,
+                                                    LevelArgs lv) {
   // one wave per z-row, 16-byte loads: a lane owns 8 consecutive voxels (512 voxels = 2 KiB per wave step); its
   // obstacle-occupancy gathers are independent of each other instead of one dependent load -> gather -> store chain per
   // voxel. Row and tile arithmetic is wave-uniform 32-bit math. (nz % 4 != 0: the same loop with scalar loads.)
@@ -439,6 +445,22 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
               rmask &= ~(1u << k);
               ++local;
             }
+        }
+        if (LEVELS) {
+          if (__ballot(rmask != 0)) {
+            bool fits = true;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+              const bool dead = (rmask >> k) & 1u;
+              const bool inw = win_all || g.in_window(x, y, z8 + k);
+              if (dead && inw) coc[base + z8 + k] = kReset | (w[r][k] & kIdMask);
+              fits &= lv_append(dead && inw, lv_pack(x, y, z8 + k), lv.list[0], &lv.ctl->n[0], lv.cap);
+              if (!win_all) fits &= lv_append(dead && !inw, lv_pack(x, y, z8 + k), lv.outside, &lv.ctl->nout, lv.cap);
+            }
+            if (!fits) lv.ctl->overflow = 1;
+            if (const uint32_t c = (uint32_t)__popc(rmask)) atomicAdd(&lv.ctl->invalidated, c);
+          }
+          continue;
         }
 #pragma unroll
         for (int u = 0; u < V / 4; ++u) {
@@ -779,7 +801,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   g.oz1 = glo[2] + gs[2] - 1;
   nbitwords_ = (int64_t)g.nx * g.ny * g.nzw;
 
-  if (cfg.update_engine < 0 || cfg.update_engine > 2) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
+  if (cfg.update_engine < 0 || cfg.update_engine > 3) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
   update_engine_ = cfg.update_engine;
   ntx_ = (g.nx + tx_ - 1) / tx_;
   nty_ = (g.ny + ty_ - 1) / ty_;
@@ -846,6 +868,8 @@ DenseMap::~DenseMap() {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
+  delete lv_;
+  if (lv_done_) (void)hipEventDestroy(lv_done_);
   for (hipEvent_t e : evpool_) (void)hipEventDestroy(e);
   for (hipEvent_t e : ft_ev_)
     if (e) (void)hipEventDestroy(e);
@@ -1321,7 +1345,7 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 // The map-local half of the engine choice: may this update be served by the bulk transform at all?
 bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
   const Geom &g = g_;
-  if (update_engine_ == 1) return false;
+  if (update_engine_ == 1 || update_engine_ == 3) return false;
   if (!(g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1)) return false;
   const long long owned = (long long)(g.ox1 - g.ox0 + 1) * (g.oy1 - g.oy0 + 1) * (g.oz1 - g.oz0 + 1);
   if ((long long)h_counters_[C_OBSERVED] != owned) return false;
@@ -1416,6 +1440,86 @@ void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long l
   *eligible = bulk_eligible(*ni, *nd);
 }
 
+// UpdateESDF by the level engine (level_kernels.hpp).  Seeds: the insert queue, and the orphans the delete scan finds.
+// Returns false if the update did not fit the engine's lists: the field then carries frontier tags and the list of active
+// tiles is set up for the frontier rounds, which the caller runs.
+bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd) {
+  if (!lv_) lv_ = new LevelEngine;
+  if (!lv_done_) FIESTA_HIP_CHECK(hipEventCreate(&lv_done_));
+  // list capacity: what a frame needs is a few thousand entries; a forced level engine gets room for a large update
+  const uint32_t want = update_engine_ == 3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(g_.n / 4, 1 << 20), 1 << 26) : (1u << 20);
+  lv_->ensure(want, stream_);
+  lv_->begin();
+  LevelArgs a = lv_->args(coc_, counters_, track_);
+  DenseSpace sp{g_, occbits_, lv_box(g_)};
+  TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
+  const bool win_all = g_.wx0 <= 0 && g_.wy0 <= 0 && g_.wz0 <= 0 && g_.wx1 >= g_.nx - 1 && g_.wy1 >= g_.ny - 1 && g_.wz1 >= g_.nz - 1;
+  if (ni) {
+    hipLaunchKernelGGL((k_level_seed_insert<DenseSpace>), dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, sp, a,
+                       (const uint32_t *)ins_.p, (int64_t)ni);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  const int bounded = (track_ && nd) ? 1 : 0;
+  if (nd) {
+    if (bounded) {
+      hipLaunchKernelGGL(k_del_bbox, dim3(1), dim3(1024), 0, stream_, g_, (const uint32_t *)del_.p, (int64_t)nd, counters_);
+      FIESTA_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_invalidate<true>, dim3((grid_for(g_.n / 16 + 1, 256, 4096) + 7) / 8 * 8), dim3(256), 0, stream_, g_, tg, coc_,
+                       (const uint32_t *)occbits_, (const uint32_t *)gocc_, tile_flag_[0], tile_list_[0], &counters_[C_LIST0],
+                       counters_, bounded, a);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    if (!win_all) {
+      hipLaunchKernelGGL((k_level_outside<DenseSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
+      FIESTA_HIP_CHECK(hipGetLastError());
+    }
+  }
+  host_counts_[0] = host_counts_[1] = 0;  // (k_level_run clears the device's queue counters)
+  int64_t launches = 0;
+  const LevelEngine::Outcome how = lv_->run(sp, a, stream_, lv_done_, update_engine_ == 3, &launches);
+  const LevelCtl &c = *lv_->h_ctl;
+  if (how == LevelEngine::kDone) {
+    h_counters_fresh_ = false;
+    if (st) {
+      float ms = 0;
+      FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, lv_done_));
+      st->device_ms = ms;
+      st->relax_ms = ms;
+      st->rounds = (int64_t)c.work;
+      st->relax_launches = launches;
+      st->voxel_writes = (int64_t)c.writes;
+      st->invalidated = (int64_t)c.invalidated;
+      st->levels = 1;
+      st->prof[0] = (int64_t)c.ticks * 10, st->prof[1] = (int64_t)c.level;  // ns inside k_level_run, levels
+      for (int k = 0; k < 4; ++k) st->prof[2 + k] = (int64_t)c.phase[k] * 10;
+      st->prof[6] = (int64_t)c.items, st->prof[7] = (int64_t)c.peak;
+    }
+    return true;
+  }
+  if (st) st->prof[1] = (int64_t)c.level, st->prof[6] = (int64_t)c.items, st->prof[7] = (int64_t)c.peak;  // (how far the levels got)
+  if (how == LevelEngine::kHandOver) {  // the frontier grew beyond one work-group's reach: its entries become active tiles
+    a.level = c.level;  // (phase A of the level the engine stopped in front of: see k_level_list_to_tiles)
+    hipLaunchKernelGGL((k_level_pull<DenseSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
+    hipLaunchKernelGGL((k_level_list_to_tiles<DenseSpace>), dim3(16), dim3(256), 0, stream_, sp, a, tg, tile_flag_[0], tile_list_[0],
+                       &counters_[C_LIST0]);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    return false;
+  }
+  // Overflow.  What the level engine left behind: frontier tags on queued voxels, reset orphans that still carry their
+  // dead id, and -- if the scan's own lists overflowed -- orphans outside the window that nobody touched.  The ordinary scan
+  // finds the latter (their links are still dead), k_level_to_tiles turns the tags into active tiles.
+  if (nd) {
+    hipLaunchKernelGGL(k_invalidate<false>, dim3((grid_for(g_.n / 16 + 1, 256, 4096) + 7) / 8 * 8), dim3(256), 0, stream_, g_, tg, coc_,
+                       (const uint32_t *)occbits_, (const uint32_t *)gocc_, tile_flag_[0], tile_list_[0], &counters_[C_LIST0],
+                       counters_, bounded, LevelArgs{});
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL((k_level_to_tiles<DenseSpace>), dim3(grid_for(g_.n, 256, 8192)), dim3(256), 0, stream_, sp, a, g_.n, tg,
+                     tile_flag_[0], tile_list_[0], &counters_[C_LIST0]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  return false;
+}
+
 void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const auto h0 = std::chrono::steady_clock::now();
@@ -1442,21 +1546,37 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   ++epoch_;
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
-  reset_stats_counters(/*lists=*/true);
   const bool full_window = g_.wx0 <= 0 && g_.wy0 <= 0 && g_.wz0 <= 0 && g_.wx1 >= g_.nx - 1 && g_.wy1 >= g_.ny - 1 && g_.wz1 >= g_.nz - 1;
   if (!full_window) win_dirty_ = true;  // (see bulk_eligible)
   // Engine choice.  The bulk transform costs one fixed sweep over the grid; the frontier rounds cost in proportion to
-  // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).
-  if (!seed_only && !g_.sharded && bulk_eligible(ni, nd)) {
-    if (update_engine_ == 2 || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n)) {
-      bool exact = true;
-      if (run_bulk(st, 0, &exact)) {
-        bulk_finish(st, h0);
-        return;
-      }
+  // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).  The level engine
+  // (level_kernels.hpp) takes every update of a few thousand voxels -- a sensor frame -- that the transform does not, and,
+  // if asked for (update_engine 3), every update its lists can hold; one that outgrows them is finished by the rounds.
+  bool levels_fell_back = false;
+  const bool try_levels = !seed_only && !g_.sharded && !g_.wrap && update_engine_ != 1 && (update_engine_ == 3 || ni + nd <= (unsigned long long)small_update_);
+  const bool try_bulk = !seed_only && !g_.sharded && bulk_eligible(ni, nd) &&
+                        (update_engine_ == 2 || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
+  bool counters_reset = false;
+  if (try_bulk) {
+    reset_stats_counters(/*lists=*/true);
+    counters_reset = true;
+    bool exact = true;
+    if (run_bulk(st, 0, &exact)) {
+      bulk_finish(st, h0);
+      return;
     }
   }
-  if (ni) {
+  if (try_levels) {  // (the level engine keeps its statistics in its own control block: no counter reset on its path)
+    if (run_levels(st, ni, nd)) {
+      if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+      return;
+    }
+    levels_fell_back = true;
+    zero_counters(C_INVALIDATED, C_COUNT - C_INVALIDATED);  // (the tile list is set up: its counters stay)
+  } else if (!counters_reset) {
+    reset_stats_counters(/*lists=*/true);
+  }
+  if (ni && !levels_fell_back) {
     hipLaunchKernelGGL(k_seed_insert, dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, g_, tg,
                        (const uint32_t *)ins_.p, (int64_t)ni, coc_, (const uint32_t *)occbits_, tile_flag_[0],
                        tile_list_[0], &counters_[C_LIST0]);
@@ -1466,13 +1586,13 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     // the scan is bounded by (delete queue's box) + (largest stored distance) where that bound is tracked
     // (enable_distance_tracking)
     const int bounded = (track_ && nd) ? 1 : 0;
-    if (bounded) {
+    if (bounded && !levels_fell_back) {
       hipLaunchKernelGGL(k_del_bbox, dim3(1), dim3(1024), 0, stream_, g_, (const uint32_t *)del_.p, (int64_t)nd, counters_);
       FIESTA_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_invalidate, dim3((grid_for(g_.n / 16 + 1, 256, 4096) + 7) / 8 * 8), dim3(256), 0, stream_, g_, tg, coc_,
+    hipLaunchKernelGGL(k_invalidate<false>, dim3((grid_for(g_.n / 16 + 1, 256, 4096) + 7) / 8 * 8), dim3(256), 0, stream_, g_, tg, coc_,
                        (const uint32_t *)occbits_, (const uint32_t *)gocc_, tile_flag_[0], tile_list_[0],
-                       &counters_[C_LIST0], counters_, bounded);
+                       &counters_[C_LIST0], counters_, bounded, LevelArgs{});
     FIESTA_HIP_CHECK(hipGetLastError());
   }
   static_assert(C_DELETE == C_INSERT + 1, "counter layout");
@@ -1485,7 +1605,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     return;
   }
   // a small delta (a depth frame): do not even read how many tiles were seeded, the chain of rounds finds out on the device
-  const uint32_t n0 = (ni + nd <= (unsigned long long)small_update_ && !remote_del) ? kCountOnDevice : (uint32_t)read_counter(C_LIST0);
+  const uint32_t n0 = (ni + nd <= (unsigned long long)small_update_ && !remote_del && !levels_fell_back) ? kCountOnDevice : (uint32_t)read_counter(C_LIST0);
   run_rounds(st, n0, 0);
   bool reseeded = false;
   {  // orphans outside the update window (local / sliding-window maps): their pull, after the rounds

@@ -75,6 +75,8 @@ enum Counter {
   C_COUNT = C_PROF0 + 8
 };
 
+struct LevelEngine;  // level_kernels.hpp
+
 struct Snapshot {
   DevBuf<vox_t> coc;
   DevBuf<double> logodds;
@@ -187,6 +189,7 @@ class DenseMap {
   void zero_counters(int first, int n);
   void ensure_touched_capacity(int64_t extra);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count, int first_list);
+  bool run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd);  // false: the rounds have to finish
   bool bulk_eligible(unsigned long long ni, unsigned long long nd);
   bool run_bulk(fiesta_hip_stats *st, int margin, bool *exact);
   void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0);
@@ -217,8 +220,10 @@ class DenseMap {
   int ntx_ = 0, nty_ = 0, ntz_ = 0, ntiles_ = 0;
   uint32_t *tile_epoch_ = nullptr;
   // UpdateESDF engine (fiesta_hip_config.update_engine): 0 = choose per update, 1 = frontier rounds only,
-  // 2 = bulk feature transform whenever the map state allows it
+  // 2 = bulk feature transform whenever the map state allows it, 3 = level engine for every update it can hold
   int update_engine_ = 0;
+  LevelEngine *lv_ = nullptr;   // the level engine's lists and control block (level_kernels.hpp), created on first use
+  hipEvent_t lv_done_ = nullptr;
   double bulk_ratio_ = -1;  // >= 0 (FIESTA_HIP_BULK_RATIO): bulk when inserts + deletes exceed this fraction of the occupied voxels
   // Late observations: a voxel first observed while obstacles exist stays at "no obstacle" until a wave reaches it
   // (the reference never queues it), so the field is no longer the transform of the occupied set and the bulk path is

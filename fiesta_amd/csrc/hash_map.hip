@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "level_kernels.hpp"
 #include "relax_kernels.hpp"
 
 namespace fiesta {
@@ -303,15 +304,19 @@ __global__ void k_h_seed_insert(Geom g, const int32_t *page_tile, const uint32_t
   coc[a] = h_pack(g, x, y, z) | kAct;
   activate_tile((uint32_t)page_tile[a / kPageVox], flag, list, count);
 }
+// LEVELS: the level engine seeds itself from this scan (level_kernels.hpp; as dense_map.hip: k_invalidate<true>).
+template <bool LEVELS>
 __global__ __launch_bounds__(256) void k_h_invalidate(Geom g, const int32_t *dir, const int32_t *page_tile,
                                                       const uint32_t *page_fresh, int64_t nvox, vox_t *coc,
                                                       const uint32_t *occbits, uint32_t *flag, uint32_t *list,
-                                                      unsigned long long *count, unsigned long long *counters) {
+                                                      unsigned long long *count, unsigned long long *counters, LevelArgs lv) {
   const int lane = threadIdx.x & 63;
   unsigned long long local = 0;
+  const bool win_all = g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= kWin - 1 && g.wy1 >= kWin - 1 && g.wz1 >= kWin - 1;
   for (int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < nvox; base += (int64_t)gridDim.x * 256) {
     const int64_t a = base + lane;  // 64 consecutive pool words = two z-rows of one page
-    bool reset = false;
+    bool reset = false, outside = false;
+    uint32_t entry = 0;  // (LEVELS: the level engine names a voxel by its packed window coordinates)
     const vox_t w = coc[a];
     const int32_t tile = page_tile[a / kPageVox];  // (wave-uniform; < 0: the page left the window)
     if (tile >= 0 && page_fresh[a / kPageVox]) {
@@ -319,10 +324,11 @@ __global__ __launch_bounds__(256) void k_h_invalidate(Geom g, const int32_t *dir
       // observed voxel asks its neighbours
       if (w != kUnobserved) {
         vox_t nw = kReset;
-        if (hbit(occbits, a)) {
+        if (LEVELS || hbit(occbits, a)) {
           int x, y, z;
           vcoords(page_tile, (uint32_t)a, x, y, z);
-          nw = h_pack(g, x, y, z) | kAct;
+          if (hbit(occbits, a)) nw = h_pack(g, x, y, z) | kAct;
+          entry = ((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)z;
         }
         coc[a] = nw;
         reset = true;
@@ -330,10 +336,25 @@ __global__ __launch_bounds__(256) void k_h_invalidate(Geom g, const int32_t *dir
     } else if (tile >= 0 && has_link(w)) {
       int x, y, z;
       vcoords(page_tile, (uint32_t)a, x, y, z);
+      entry = ((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)z;
       if (!h_alive(g, dir, occbits, x, y, z, w & kIdMask)) {
-        coc[a] = kReset;
-        reset = true;
+        if (LEVELS && !win_all && !g.in_window(x, y, z)) {
+          outside = true;  // (keeps its word until k_level_outside has judged it)
+        } else {
+          coc[a] = LEVELS ? (kReset | (w & kIdMask)) : kReset;
+          reset = true;
+        }
       }
+    }
+    if (LEVELS) {
+      const unsigned long long mm = __ballot(reset || outside);
+      if (mm) {
+        bool fits = lv_append(reset, entry, lv.list[0], &lv.ctl->n[0], lv.cap);
+        if (!win_all) fits &= lv_append(outside, entry, lv.outside, &lv.ctl->nout, lv.cap);
+        if (!fits) lv.ctl->overflow = 1;
+        if (lane == 0) atomicAdd(&lv.ctl->invalidated, (uint32_t)__popcll(mm));
+      }
+      continue;
     }
     const unsigned long long m = __ballot(reset);
     if (m && lane == 0) {
@@ -521,6 +542,8 @@ HashMap::HashMap(const fiesta_hip_config &cfg) {
   g.wrap = 1;                      // ids are map coordinates modulo 1024, decoded relative to their voxel
   set_original_range();
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
+  if (cfg.update_engine < 0 || cfg.update_engine > 3) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
+  update_engine_ = cfg.update_engine;
 
   FIESTA_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   FIESTA_HIP_CHECK(hipEventCreate(&ev0_));
@@ -548,6 +571,8 @@ HashMap::~HashMap() {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
+  delete lv_;
+  if (lv_done_) (void)hipEventDestroy(lv_done_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -960,7 +985,9 @@ bool HashMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) 
     FIESTA_HIP_CHECK(hipGetLastError());
     zero_counter(C_TOUCHED);
     touched_upper_ = 0;
-    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    // (C_INSERT .. C_DROPPED: the queue lengths, and the lost-observation count UpdateESDF reports without a read of its own)
+    static_assert(C_DROPPED == C_INSERT + 4, "counter layout");
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
     host_ni_ = h_counters_[C_INSERT], host_nd_ = h_counters_[C_DELETE];
   }
@@ -1049,6 +1076,77 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
   }
 }
 
+// UpdateESDF by the level engine (level_kernels.hpp; as DenseMap::run_levels).  false: the update did not fit its lists,
+// the field carries frontier tags and the tile list is set up for the frontier rounds.
+bool HashMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd, bool scan) {
+  if (!lv_) lv_ = new LevelEngine;
+  if (!lv_done_) FIESTA_HIP_CHECK(hipEventCreate(&lv_done_));
+  lv_->ensure(update_engine_ == 3 ? (1u << 24) : (1u << 20), stream_);
+  lv_->begin();
+  LevelArgs a = lv_->args(coc_.p, counters_, false);
+  PagedSpace sp{g_, occbits_.p, dir_, page_tile_.p, lv_box(g_)};
+  TileGrid tg{kTX, kTY, kNTX, kNTY, kNTZ};
+  const bool win_all = g_.wx0 <= 0 && g_.wy0 <= 0 && g_.wz0 <= 0 && g_.wx1 >= kWin - 1 && g_.wy1 >= kWin - 1 && g_.wz1 >= kWin - 1;
+  const int64_t nvox = npages_ * kPageVox;
+  if (nvox >= (1ll << 32)) throw Error(FIESTA_HIP_ERR_STATE, "page pool too large for the level engine's 32-bit addresses");
+  FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+  if (ni) {
+    hipLaunchKernelGGL((k_level_seed_insert<PagedSpace>), dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, sp, a,
+                       (const uint32_t *)ins_.p, (int64_t)ni);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  if (scan) {
+    hipLaunchKernelGGL(k_h_invalidate<true>, dim3(grid_for(nvox / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, (const int32_t *)dir_,
+                       (const int32_t *)page_tile_.p, (const uint32_t *)page_fresh_.p, nvox, coc_.p, (const uint32_t *)occbits_.p,
+                       tile_flag_[0], tile_list_[0], &counters_[C_LIST0], counters_, a);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    if (force_scan_) FIESTA_HIP_CHECK(hipMemsetAsync(page_fresh_.p, 0, (size_t)npages_ * sizeof(uint32_t), stream_));
+    force_scan_ = false;
+    if (!win_all) {
+      hipLaunchKernelGGL((k_level_outside<PagedSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
+      FIESTA_HIP_CHECK(hipGetLastError());
+    }
+  }
+  host_ni_ = host_nd_ = 0;  // (k_level_run clears the device's queue counters)
+  int64_t launches = 0;
+  const LevelEngine::Outcome how = lv_->run(sp, a, stream_, lv_done_, update_engine_ == 3, &launches);
+  const LevelCtl &c = *lv_->h_ctl;
+  if (how == LevelEngine::kDone) {
+    if (st) {
+      float ms = 0;
+      FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, lv_done_));
+      st->relax_ms = ms;
+      st->rounds = (int64_t)c.work;
+      st->relax_launches = launches;
+      st->voxel_writes = (int64_t)c.writes;
+      st->invalidated = (int64_t)c.invalidated;
+      st->levels = 1;
+      st->prof[0] = (int64_t)c.ticks * 10, st->prof[1] = (int64_t)c.level;  // ns inside k_level_run, levels
+      for (int k = 0; k < 4; ++k) st->prof[2 + k] = (int64_t)c.phase[k] * 10;
+      st->prof[6] = (int64_t)c.items, st->prof[7] = (int64_t)c.peak;
+    }
+    return true;
+  }
+  if (how == LevelEngine::kHandOver) {  // (see DenseMap::run_levels)
+    a.level = c.level;  // (phase A of the level the engine stopped in front of: see k_level_list_to_tiles)
+    hipLaunchKernelGGL((k_level_pull<PagedSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
+    hipLaunchKernelGGL((k_level_list_to_tiles<PagedSpace>), dim3(16), dim3(256), 0, stream_, sp, a, tg, tile_flag_[0], tile_list_[0],
+                       &counters_[C_LIST0]);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    return false;
+  }
+  if (nd) {  // (see DenseMap::run_levels)
+    hipLaunchKernelGGL(k_h_invalidate<false>, dim3(grid_for(nvox / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, (const int32_t *)dir_,
+                       (const int32_t *)page_tile_.p, (const uint32_t *)page_fresh_.p, nvox, coc_.p, (const uint32_t *)occbits_.p,
+                       tile_flag_[0], tile_list_[0], &counters_[C_LIST0], counters_, LevelArgs{});
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL((k_level_to_tiles<PagedSpace>), dim3(grid_for(nvox, 256, 8192)), dim3(256), 0, stream_, sp, a, nvox, tg,
+                     tile_flag_[0], tile_list_[0], &counters_[C_LIST0]);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  return false;
+}
+
 void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const auto h0 = std::chrono::steady_clock::now();
@@ -1068,18 +1166,35 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
   if (ni || nd || force_scan_) {
     ++epoch_;
     static_assert(C_LIST2 == C_LIST0 + 2 && C_INVALIDATED == C_LIST2 + 1, "counter layout");
-    zero_counters(C_LIST0, C_COUNT - C_LIST0);
-    if (ni) {
+    const auto d00 = std::chrono::steady_clock::now();
+    bool levels_fell_back = false;
+    if (update_engine_ != 1 && (update_engine_ == 3 || ni + nd <= (unsigned long long)small_update_)) {
+      // (the level engine keeps its statistics in its own control block: no counter reset, no read-back of counters --
+      //  dropped observations are reported from the last value the host saw plus what it clipped itself)
+      if (run_levels(st, ni, nd, nd || force_scan_)) {
+        if (st) {
+          st->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d00).count();
+          st->dropped_observations = (int64_t)h_counters_[C_DROPPED] + dropped_host_;
+          st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+        }
+        return;
+      }
+      levels_fell_back = true;  // (seeds and scans are done; the field carries tags, the tile list is set up)
+      zero_counters(C_INVALIDATED, C_COUNT - C_INVALIDATED);
+    } else {
+      zero_counters(C_LIST0, C_COUNT - C_LIST0);
+    }
+    if (ni && !levels_fell_back) {
       hipLaunchKernelGGL(k_h_seed_insert, dim3(grid_for((int64_t)ni)), dim3(256), 0, stream_, g_, (const int32_t *)page_tile_.p,
                          (const uint32_t *)ins_.p, (int64_t)ni, coc_.p, (const uint32_t *)occbits_.p, tile_flag_[0], tile_list_[0],
                          &counters_[C_LIST0]);
       FIESTA_HIP_CHECK(hipGetLastError());
     }
-    if (nd || force_scan_) {  // (a window move: obstacles left the window, parked pages came back)
+    if ((nd || force_scan_) && !levels_fell_back) {  // (a window move: obstacles left the window, parked pages came back)
       const int64_t nvox = npages_ * kPageVox;
-      hipLaunchKernelGGL(k_h_invalidate, dim3(grid_for(nvox / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, (const int32_t *)dir_,
+      hipLaunchKernelGGL(k_h_invalidate<false>, dim3(grid_for(nvox / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, (const int32_t *)dir_,
                          (const int32_t *)page_tile_.p, (const uint32_t *)page_fresh_.p, nvox, coc_.p, (const uint32_t *)occbits_.p, tile_flag_[0], tile_list_[0],
-                         &counters_[C_LIST0], counters_);
+                         &counters_[C_LIST0], counters_, LevelArgs{});
       FIESTA_HIP_CHECK(hipGetLastError());
       if (force_scan_) FIESTA_HIP_CHECK(hipMemsetAsync(page_fresh_.p, 0, (size_t)npages_ * sizeof(uint32_t), stream_));
       force_scan_ = false;

@@ -62,6 +62,7 @@ class HashMap {
   bool check_update();
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
   void update_esdf(fiesta_hip_stats *st);
+  void set_update_engine(int e) { update_engine_ = e; }
   void get_distance_vox(const int32_t *vox, int64_t n, double *out);
   void get_distance_pos(const double *pos, int64_t n, double *out);
   void get_dist_grad(const double *pos, int64_t n, double *dist, double *grad);
@@ -88,6 +89,7 @@ class HashMap {
   void zero_counter(int which);
   void zero_counters(int first, int n);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count);
+  bool run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd, bool scan);  // false: the rounds finish
   void free_raycast_state();
   struct RaycastState;
   RaycastState *rc_ = nullptr;
@@ -126,6 +128,12 @@ class HashMap {
   unsigned long long host_ni_ = 0, host_nd_ = 0;  // insert / delete queue lengths as last read
   bool host_queues_valid_ = false;
   int chain_hint_ = 4;  // rounds in the first chain of the next update (the previous update's count + 1)
+  // UpdateESDF engine: 1 = frontier rounds only, 3 = level engine whenever its lists hold the update, else: level engine
+  // for updates of at most small_update_ voxels (a sensor frame), rounds otherwise
+  int update_engine_ = 0;
+  int small_update_ = 4096;
+  LevelEngine *lv_ = nullptr;  // level_kernels.hpp
+  hipEvent_t lv_done_ = nullptr;
   int64_t dropped_host_ = 0;  // voxels of observe_box() requests clipped away by the window (added to C_DROPPED in stats)
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   DevBuf<unsigned char> stage_a_, stage_b_, stage_c_, stage_d_;

@@ -1,0 +1,816 @@
+// fiesta_amd/csrc/level_kernels.hpp -- the LEVEL engine of UpdateESDF: a globally level-synchronous sparse-frontier sweep
+// that works on the voxel words in HBM directly (no tiles, no staging).  Shared by the dense-array map (dense_map.hip) and
+// the paged hash-block map (hash_map.hip) through an address-space policy.
+//
+// The reference's update queue is a FIFO (src/ESDFMap.cpp:339-392), so its entries are processed in LAYERS: layer L + 1 is
+// what the processing of layer L enqueued.  The order INSIDE a layer is an accident of the queue history and cannot be
+// reproduced by a parallel machine; the layers can.  One level here = one layer:
+//   phase A (pull, :349-367)  every frontier voxel looks at its 24 stencil neighbours IN THE FIELD AS THE LEVEL FOUND IT
+//                             (nothing but frontier tags is written during this phase) and remembers the best obstacle;
+//   phase B (:369-391)        a voxel that improved stores its new obstacle and stays in the frontier (re-queued, :371);
+//                             one that did not offers ITS obstacle to the 24 neighbours: a compare-and-swap minimum on the
+//                             neighbour's word (d^2 is recomputed from the ids, exact int32); a neighbour that improves joins
+//                             the next frontier -- once: bit 30 of the word (kAct) is the "already queued" mark, set by
+//                             whoever improves the voxel first and cleared when the voxel is processed.
+// The next frontier is compacted with a wave ballot + prefix count and ONE atomic per wave.  Two grid-wide barriers per
+// level.  For the frontiers of a sensor frame (a few hundred voxels) the whole update is ONE launch of ONE work-group
+// (k_level_run: the barriers are __syncthreads, ~2 memory latencies per level); a level that outgrows one work-group goes
+// on as a pair of launches per level over any number of work-groups (k_level_pull / k_level_push: the kernel boundary is
+// the barrier), chained without host round trips.
+//
+// Deletes (:292-337).  The reference walks the vanished obstacle's list and re-seeds every member from its first valid
+// neighbour; those re-seeded voxels then pull and push like everybody else.  Here the orphans are found by the scan of
+// dense_map.hip: k_invalidate / hash_map.hip: k_h_invalidate, reset to "no obstacle" and put into level 0 as PULL-ONLY
+// entries: a voxel without an obstacle has nothing to push, its first pull is its re-seed.
+// Orphans OUTSIDE the update window (local maps) are the one place where the reference's list order shows: such a voxel is
+// re-seeded from its first IN-WINDOW neighbour that is valid at that moment of the list walk -- a live obstacle, or an
+// orphan walked earlier -- and one that finds nothing stays at infinity for good (never queued :329, never pushed into
+// :378).  The list is push-front in adoption order, i.e. walked from the rim of the dead cell inwards; "walked earlier" is
+// modelled as "orphan of another vanished obstacle, or of the same one and not closer to it" (k_level_outside).  An
+// out-of-window orphan that passes keeps asking its in-window neighbours once per level (nobody pushes into it) until it
+// holds a value, goes on while it improves, and is frozen after that -- as in the reference (:345-373).
+//
+// oracle/esdf_port.cpp: relax_levels() is the CPU model of exactly this schedule; tests/test_levelsync_model.py judges
+// it against the order spread of the verbatim reference without a GPU.
+#pragma once
+#include "common.hpp"
+#include "dense_map.hpp"
+#include "hash_map.hpp"
+#include "relax_kernels.hpp"
+
+namespace fiesta {
+
+// ---- control block of one map's level engine (device memory; a pinned host copy travels back once per chain) ----------
+struct LevelCtl {
+  uint32_t n[3];      // frontier lengths: level l reads n[l % 3], appends to n[(l + 1) % 3], clears n[(l + 2) % 3]
+  uint32_t nwait[3];  // of those: out-of-window orphans that only wait (a frontier of nothing else is a finished update)
+  uint32_t level;     // levels run so far in this update; the current frontier is list[level & 1]
+  uint32_t overflow;  // an append did not fit its list: the frontier-round engine has to finish this update
+  uint32_t nout;      // out-of-window orphans collected by the delete scan (list `outside`)
+  uint32_t writes;    // voxel words replaced (statistics)
+  uint32_t maxd2;     // largest squared distance adopted (feeds C_MAXD2, the bound of the delete scan)
+  uint32_t work;      // levels that found a non-empty frontier
+  uint32_t invalidated;  // orphans the delete scan found (statistics)
+  uint32_t ticks;     // time inside k_level_run, 10 ns units (statistics)
+  uint32_t phase[4];  // of that, thread 0's view: fetch + pull, barrier, push, append + barriers
+  uint32_t items;     // frontier entries processed, summed over the levels (statistics)
+  uint32_t peak;      // the largest frontier
+};
+
+struct LevelArgs {
+  vox_t *coc;
+  uint32_t *list[2];
+  uint32_t *res;       // phase A's verdict per frontier entry
+  uint32_t *outside;   // out-of-window orphans of the delete scan
+  LevelCtl *ctl;
+  LevelCtl *ctl_other; // the NEXT update's control block: k_level_run clears it (no memset on the next update's path)
+  uint32_t cap;        // entries a list holds
+  uint32_t single_cap; // k_level_run leaves a frontier larger than this to the multi-work-group kernels
+  uint32_t level;      // k_level_pull / k_level_push: which level this launch is (host-side count; the device checks)
+  unsigned long long *counters;
+  int track;           // maintain counters[C_MAXD2]
+};
+
+// phase A's verdict, one word per frontier entry
+constexpr uint32_t kLvNone = 0xFFFFFFFFu;   // nothing to do (no obstacle yet, inside the window: a push will find it)
+constexpr uint32_t kLvWait = 0xFFFFFFFEu;   // no obstacle yet, OUTSIDE the window: ask again next level
+constexpr uint32_t kLvPush = 0x40000000u;   // | id: did not improve, offers this obstacle to its neighbours
+                                            // otherwise: the id it improved to
+
+// ---- address spaces ---------------------------------------------------------------------------------------------------
+// A frontier ENTRY names a voxel by its packed coordinates (x << 20 | y << 10 | z: local coordinates of a dense array of at
+// most 1024 voxels per axis, window coordinates of the paged map), so decoding one needs no memory access and no division;
+// its ADDRESS (index of its word) may need one load (the paged map's directory).  The steps are split so that a lane can
+// request all its directory entries, then all its words, each as ONE batch of loads.
+// `box` = update window intersected with the array: the voxels the propagation may read and write (VoxInRange :63-72).
+struct LvBox {
+  int x0, y0, z0;
+  unsigned ex, ey, ez;  // extents - 1
+  __device__ inline bool has(int x, int y, int z) const {
+    return (unsigned)(x - x0) <= ex && (unsigned)(y - y0) <= ey && (unsigned)(z - z0) <= ez;
+  }
+};
+inline LvBox lv_box(const Geom &g) {
+  LvBox b;
+  const int x0 = std::max(g.wx0, 0), y0 = std::max(g.wy0, 0), z0 = std::max(g.wz0, 0);
+  const int x1 = std::min(g.wx1, g.nx - 1), y1 = std::min(g.wy1, g.ny - 1), z1 = std::min(g.wz1, g.nz - 1);
+  if (x1 < x0 || y1 < y0 || z1 < z0) {  // an empty window: no voxel is in it
+    b.x0 = b.y0 = b.z0 = 1 << 30, b.ex = b.ey = b.ez = 0;
+  } else {
+    b.x0 = x0, b.y0 = y0, b.z0 = z0, b.ex = (unsigned)(x1 - x0), b.ey = (unsigned)(y1 - y0), b.ez = (unsigned)(z1 - z0);
+  }
+  return b;
+}
+__host__ __device__ inline uint32_t lv_pack(int x, int y, int z) { return ((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)z; }
+
+// Dense array (at most 1024 voxels per axis: larger arrays keep to the other engines): address = linear index; ids are
+// plain global coordinates (no wrap).
+struct DenseSpace {
+  Geom g;
+  const uint32_t *occbits;
+  LvBox box;
+  static constexpr int kWrap = 0;
+  __device__ inline void decode(uint32_t e, int &x, int &y, int &z) const { x = (int)(e >> 20) & 1023, y = (int)(e >> 10) & 1023, z = (int)e & 1023; }
+  __device__ inline void coords(uint32_t a, int &x, int &y, int &z) const {  // of an ADDRESS
+    z = (int)(a % (uint32_t)g.nz);
+    const uint32_t r = a / (uint32_t)g.nz;
+    y = (int)(r % (uint32_t)g.ny), x = (int)(r / (uint32_t)g.ny);
+  }
+  __device__ inline bool valid(int x, int y, int z) const { return box.has(x, y, z); }
+  __device__ inline int32_t doff(int dx, int dy, int dz) const { return (dx * g.ny + dy) * g.nz + dz; }
+  // the own word of voxel (x,y,z): a voxel that made it into a list exists
+  __device__ inline int32_t page_self(bool live, int, int, int) const { return live ? 0 : -1; }
+  __device__ inline uint32_t addr_self(int32_t, int x, int y, int z) const { return ((uint32_t)x * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nz + (uint32_t)z; }
+  // a neighbour's word: step 1 its page (>= 0: it has a word), step 2 its address
+  __device__ inline int32_t page(bool ok, int, int, int) const { return ok ? 0 : -1; }
+  __device__ inline uint32_t addr(int32_t, uint32_t self, int32_t off, int, int, int) const { return self + (uint32_t)off; }
+  __device__ inline bool resident(uint32_t) const { return true; }
+  __device__ inline bool occupied(uint32_t, int x, int y, int z) const { return occ_test(occbits, g, x, y, z); }
+  __device__ inline uint32_t tile_of(const TileGrid &tg, uint32_t, int x, int y, int z) const { return (uint32_t)tg.tile_of(x, y, z); }
+  // is the obstacle that word `id` names (held by voxel x,y,z) still occupied?
+  __device__ inline bool alive(int x, int y, int z, vox_t id) const {
+    int cx, cy, cz;
+    unpack_coc(0, x + g.gx0, y + g.gy0, z + g.gz0, id, cx, cy, cz);
+    cx -= g.gx0, cy -= g.gy0, cz -= g.gz0;
+    return g.in_grid(cx, cy, cz) && occ_test(occbits, g, cx, cy, cz);
+  }
+};
+// Paged hash-block map: address = place in the page pool, through the directory; ids are map coordinates modulo 1024
+// decoded relative to the voxel (wrap).
+struct PagedSpace {
+  Geom g;
+  const uint32_t *occbits;
+  const int32_t *dir;        // window tile -> page (-1: none)
+  const int32_t *page_tile;  // page -> window tile (-1: parked)
+  LvBox box;
+  static constexpr int kWrap = 1;
+  static constexpr int kWin = HashMap::kWin, kNTY = HashMap::kNTY, kNTZ = HashMap::kNTZ, kPageVox = HashMap::kPageVox;
+  __device__ inline void decode(uint32_t e, int &x, int &y, int &z) const { x = (int)(e >> 20) & 1023, y = (int)(e >> 10) & 1023, z = (int)e & 1023; }
+  __device__ inline void coords(uint32_t a, int &x, int &y, int &z) const {  // of an ADDRESS (one dependent load)
+    const int t = page_tile[a / (uint32_t)kPageVox], off = (int)(a % (uint32_t)kPageVox);
+    x = (t / (kNTY * kNTZ)) * 16 + (off >> 9);
+    y = ((t / kNTZ) % kNTY) * 16 + ((off >> 5) & 15);
+    z = (t % kNTZ) * 32 + (off & 31);
+  }
+  __device__ inline bool valid(int x, int y, int z) const { return box.has(x, y, z); }
+  __device__ inline int32_t doff(int, int, int) const { return 0; }
+  __device__ inline int32_t page_self(bool live, int x, int y, int z) const { return live ? dir[((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5)] : -1; }
+  __device__ inline uint32_t addr_self(int32_t p, int x, int y, int z) const {
+    return (uint32_t)p * (uint32_t)kPageVox + (uint32_t)(((x & 15) * 16 + (y & 15)) * 32 + (z & 31));
+  }
+  __device__ inline int32_t page(bool ok, int x, int y, int z) const { return ok ? dir[((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5)] : -1; }
+  __device__ inline uint32_t addr(int32_t p, uint32_t, int32_t, int x, int y, int z) const { return addr_self(p, x, y, z); }
+  __device__ inline bool resident(uint32_t a) const { return page_tile[a / (uint32_t)kPageVox] >= 0; }
+  __device__ inline bool occupied(uint32_t a, int, int, int) const { return (occbits[a >> 5] >> (a & 31)) & 1u; }
+  __device__ inline uint32_t tile_of(const TileGrid &, uint32_t a, int, int, int) const { return (uint32_t)page_tile[a / (uint32_t)kPageVox]; }
+  __device__ inline bool alive(int x, int y, int z, vox_t id) const {
+    int dx, dy, dz;
+    coc_offset(1, x + g.gx0, y + g.gy0, z + g.gz0, id, dx, dy, dz);
+    const int cx = x - dx, cy = y - dy, cz = z - dz;
+    if ((unsigned)cx >= (unsigned)kWin || (unsigned)cy >= (unsigned)kWin || (unsigned)cz >= (unsigned)kWin) return false;
+    const int32_t p = page(true, cx, cy, cz);
+    if (p < 0) return false;  // (its page left the window with it, or never existed)
+    const uint32_t ca = addr_self(p, cx, cy, cz);
+    return (occbits[ca >> 5] >> (ca & 31)) & 1u;
+  }
+};
+
+// ---- small device helpers ---------------------------------------------------------------------------------------------
+// A field word as the L2 holds it now (k_level_run keeps running across levels: a plain load may be served from the CU's
+// L1, which atomics of an earlier phase never refreshed).
+template <bool COHERENT>
+__device__ inline vox_t lv_load(const vox_t *p) {
+  if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+// The field's read-modify-writes: ONE = issued by k_level_run (a single work-group, hence a single L2 for the whole
+// update; on coarse-grained device memory both forms execute in the L2 -- same instruction, measured the same).
+template <bool ONE>
+__device__ inline vox_t lv_cas(vox_t *p, vox_t expect, vox_t want) {
+  if (ONE) {
+    __hip_atomic_compare_exchange_strong(p, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return expect;  // (the value found)
+  }
+  return atomicCAS(p, expect, want);
+}
+template <bool ONE>
+__device__ inline void lv_and(vox_t *p, vox_t mask) {
+  if (ONE)
+    (void)__hip_atomic_fetch_and(p, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    atomicAnd(p, mask);
+}
+// Appends `value` for every lane whose `pred` holds; ONE atomic per wave.  Returns false if the list was full.
+__device__ inline bool lv_append(bool pred, uint32_t value, uint32_t *list, uint32_t *count, uint32_t cap) {
+  const unsigned long long m = __ballot(pred);
+  if (!m) return true;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (pred && at < cap) list[at] = value;
+  return base + (uint32_t)__popcll(m) <= cap;
+}
+template <class S>
+__device__ inline int32_t lv_d2(const S &sp, int x, int y, int z, vox_t id) {
+  return dist2(S::kWrap, x + sp.g.gx0, y + sp.g.gy0, z + sp.g.gz0, id);
+}
+// what "no obstacle" is worth in a comparison (wrap maps never adopt a candidate at or beyond the reach of an id)
+template <class S>
+__device__ inline int32_t lv_inf(const S &) {
+  return S::kWrap ? kD2Cap : kD2Inf;
+}
+template <class S>
+__device__ inline int32_t lv_have(const S &sp, int x, int y, int z, vox_t w) {
+  return (w & kNoCoc) ? lv_inf(sp) : lv_d2(sp, x, y, z, w & kIdMask);
+}
+
+// The 24 stencil offsets (include/parameters.h:54-68, the reference's order).  FOUR LANES SHARE A FRONTIER ENTRY, six
+// directions each (lane & 3 = which quarter): the per-direction code exists six times, not twenty-four -- with everything
+// unrolled for one lane the kernel was ~90 KB of instructions -- and a level's loads and atomics are spread over four
+// times as many lanes.  Directions are per-lane data, so the four quarters run the same instructions.
+#define FIESTA_LV_DX(DX, DY, DZ) DX,
+#define FIESTA_LV_DY(DX, DY, DZ) DY,
+#define FIESTA_LV_DZ(DX, DY, DZ) DZ,
+__device__ const signed char kLvDx[24] = {FIESTA_STENCIL24(FIESTA_LV_DX)};
+__device__ const signed char kLvDy[24] = {FIESTA_STENCIL24(FIESTA_LV_DY)};
+__device__ const signed char kLvDz[24] = {FIESTA_STENCIL24(FIESTA_LV_DZ)};
+struct LvDirs {
+  int dx[6], dy[6], dz[6];
+  int e2[6];       // |direction|^2
+  int32_t off[6];  // dense arrays: the direction as an address offset
+  int q;           // the lane's quarter: directions 6q .. 6q + 5
+  template <class S>
+  __device__ inline void init(const S &sp) {
+    q = (int)(threadIdx.x & 3u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      dx[j] = kLvDx[6 * q + j], dy[j] = kLvDy[6 * q + j], dz[j] = kLvDz[6 * q + j];
+      e2[j] = dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j];
+      off[j] = sp.doff(dx[j], dy[j], dz[j]);
+    }
+  }
+};
+
+// A lane's share of one frontier entry's stencil, as it sits in registers between the two phases of a level.
+struct LvItem {
+  int x, y, z;
+  uint32_t self;    // address of the entry's own word
+  vox_t w;          // that word when phase A read it (kUnobserved: the entry names no voxel of the map)
+  uint32_t an[6];   // addresses of the lane's six neighbours' words (valid where nb != kUnobserved)
+  vox_t nb[6];      // their words when phase A read them; kUnobserved: no such voxel / outside the window / never observed
+};
+
+// Loads a lane's share of an entry's stencil: the directory entries as one batch, then the words as one batch.
+template <class S, bool COHERENT>
+__device__ inline void lv_fetch(const S &sp, const vox_t *coc, uint32_t e, bool live, const LvDirs &dr, LvItem &it) {
+  sp.decode(e, it.x, it.y, it.z);
+  int32_t pg[6];
+  const int32_t pself = sp.page_self(live, it.x, it.y, it.z);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int ux = it.x + dr.dx[j], uy = it.y + dr.dy[j], uz = it.z + dr.dz[j];
+    pg[j] = sp.page(live && sp.valid(ux, uy, uz), ux, uy, uz);
+  }
+  it.self = pself >= 0 ? sp.addr_self(pself, it.x, it.y, it.z) : 0u;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    it.an[j] = pg[j] >= 0 ? sp.addr(pg[j], it.self, dr.off[j], it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j]) : 0u;
+    it.nb[j] = kUnobserved;
+    if (pg[j] >= 0) it.nb[j] = lv_load<COHERENT>(coc + it.an[j]);
+  }
+  it.w = kUnobserved;
+  if (pself >= 0) it.w = lv_load<COHERENT>(coc + it.self);
+}
+
+// ---- phase A for one frontier entry (the four lanes of its quad call this together; all four return the verdict) ---------
+template <class S, bool ONE>
+__device__ inline uint32_t lv_pull(const S &sp, vox_t *coc, const LvItem &it, const LvDirs &dr) {
+  const vox_t w = it.w;
+  // the entry is being processed: its "queued" mark goes (and with it whatever a reset word still carried)
+  if (dr.q == 0 && w != kUnobserved) {
+    if (w & kNoCoc) {
+      if (w != kInf) lv_and<ONE>(coc + it.self, kNoCoc);
+    } else if (w & kAct) {
+      lv_and<ONE>(coc + it.self, ~kAct);
+    }
+  }
+  const bool have = !(w & kNoCoc);
+  int32_t best = lv_have(sp, it.x, it.y, it.z, w);
+  vox_t bid = kNoCoc;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const vox_t wn = it.nb[j];
+    if (has_link(wn)) {  // an obstacle, or the stale link of a voxel the local-map rule reset (:353 tests the id only)
+      const vox_t id = wn & kIdMask;
+      const int32_t d = lv_d2(sp, it.x, it.y, it.z, id);
+      if (d < best) best = d, bid = id;
+    }
+  }
+  // the best of the four quarters; the lower quarter wins a tie (= the first in the reference's direction order)
+#pragma unroll
+  for (int m = 1; m <= 2; m <<= 1) {
+    const int32_t ob = __shfl_xor(best, m);
+    const vox_t oi = (vox_t)__shfl_xor((int)bid, m);
+    const bool other_lower = (dr.q & m) != 0;
+    if (ob < best || (ob == best && other_lower && !(oi & kNoCoc))) best = ob, bid = oi;
+  }
+  if (w == kUnobserved) return kLvNone;  // (not a voxel of the map any more: a page that left; never for dense maps)
+  if (!(bid & kNoCoc)) return bid;
+  if (have) return kLvPush | (w & kIdMask);
+  return sp.valid(it.x, it.y, it.z) ? kLvNone : kLvWait;
+}
+
+// compare-and-swap minimum: voxel (address a, coordinates x,y,z) takes obstacle `id` at squared distance d iff that is
+// strictly closer than what it holds (:357, :382).  `seen` is a recent value of the word.  Returns 0: no change, 1: changed
+// and the voxel was not queued yet (the caller appends it), 2: changed, already queued.
+template <class S, bool ONE>
+__device__ inline int lv_min(const S &sp, vox_t *coc, uint32_t a, int x, int y, int z, vox_t id, int32_t d, vox_t seen) {
+  for (;;) {
+    if (seen == kUnobserved) return 0;  // never observed: propagation does not enter (:382, -10000 > tmp is false)
+    if (!(d < lv_have(sp, x, y, z, seen))) return 0;
+    const vox_t old = lv_cas<ONE>(coc + a, seen, id | kAct);
+    if (old == seen) return ((seen & kAct) && !(seen & kNoCoc)) ? 2 : 1;
+    seen = old;
+  }
+}
+
+// ---- phase B for one frontier entry (again the whole quad) ---------------------------------------------------------------
+// An entry that improved stores its new obstacle into its own word (quarter 0 does); one that did not offers its obstacle
+// to its 24 neighbours, six per lane.  Either way: compare-and-swap minima, ALL issued before the first result is looked
+// at (one atomic latency per level), losers retried one by one (rare), and the voxels that enter the next frontier
+// appended with wave votes + one atomic per wave.  `put(at, entry)` stores into the next frontier.  Every lane of a wave
+// calls this (dead lanes with verdict kLvNone).  Returns the number of words the lane replaced.
+template <class S, bool ONE, class Put>
+__device__ inline uint32_t lv_push(const S &sp, vox_t *coc, uint32_t e, const LvItem &it, const LvDirs &dr, uint32_t verdict,
+                                   uint32_t *n_next, uint32_t *n_wait, uint32_t &maxd2, Put put) {
+  const bool waits = verdict == kLvWait && dr.q == 0;
+  const bool active = verdict != kLvNone && verdict != kLvWait;
+  const bool pushes = active && (verdict & kLvPush) != 0;
+  const bool improved = active && !pushes && dr.q == 0;
+  const vox_t id = verdict & kIdMask;
+  uint32_t tried = 0, queue = 0, wrote = 0;
+  vox_t got[6];
+  vox_t got_self = 0;
+  // the voxel's offset from the obstacle: a neighbour's squared distance to it is d + 2 e.u + |e|^2 (e: the direction)
+  int ux, uy, uz;
+  coc_offset(S::kWrap, it.x + sp.g.gx0, it.y + sp.g.gy0, it.z + sp.g.gz0, id, ux, uy, uz);
+  const int32_t dv = ux * ux + uy * uy + uz * uz;
+  // -- issue.  What a word read during phase A looks like now, unless somebody's push of THIS phase got there first: every
+  //    frontier entry cleared its own mark in phase A (a reset orphan became plain "no obstacle"), nobody set one.
+  auto settled = [](vox_t w) { return (w & kNoCoc) ? ((w & kAct) ? kInf : w) : (w & ~kAct); };
+  const vox_t expect = settled(it.w);
+  if (improved) got_self = lv_cas<ONE>(coc + it.self, expect, id | kAct);
+  int32_t dn[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    got[j] = 0;
+    dn[j] = dv + 2 * (dr.dx[j] * ux + dr.dy[j] * uy + dr.dz[j] * uz) + dr.e2[j];
+    if (pushes && it.nb[j] != kUnobserved && (!S::kWrap || dn[j] < kD2Cap) &&
+        dn[j] < lv_have(sp, it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j], it.nb[j])) {
+      tried |= 1u << j;
+      got[j] = lv_cas<ONE>(coc + it.an[j], settled(it.nb[j]), id | kAct);
+    }
+  }
+  // -- judge
+  if (improved) {
+    const int r = got_self == expect ? 1 : lv_min<S, ONE>(sp, coc, it.self, it.x, it.y, it.z, id, dv, got_self);
+    // (r == 0: a push of this very phase got there first with something at least as close -- it set the mark and queued
+    //  the voxel; r == 2: the same, and this store still improved on it)
+    if (r) ++wrote, maxd2 = max(maxd2, (uint32_t)dv);
+    if (r == 1) queue |= 1u << 6;  // re-queued (:371)
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    if (tried & (1u << j)) {
+      const int r = got[j] == settled(it.nb[j])
+                        ? 1
+                        : lv_min<S, ONE>(sp, coc, it.an[j], it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j], id, dn[j], got[j]);
+      if (r) ++wrote, maxd2 = max(maxd2, (uint32_t)dn[j]);
+      if (r == 1) queue |= 1u << j;
+    }
+  }
+  if (waits) queue |= 1u << 6, atomicAdd(n_wait, 1u);
+  // -- append: one vote per kind of entry (own voxel, direction 0..5), positions from the votes, ONE atomic per wave
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t mine[7], total = 0;
+#pragma unroll
+  for (int b = 0; b < 7; ++b) {
+    const unsigned long long m = __ballot((queue >> b) & 1u);
+    mine[b] = total + (uint32_t)__popcll(m & below);
+    total += (uint32_t)__popcll(m);
+  }
+  if (total) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(n_next, total);
+    base = (uint32_t)__shfl((int)base, 0);
+    if (queue & (1u << 6)) put(base + mine[6], e);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      if (queue & (1u << j)) put(base + mine[j], lv_pack(it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j]));
+  }
+  return wrote;
+}
+
+// ---- seeding ----------------------------------------------------------------------------------------------------------
+// Insert drain (:278-291): a queued voxel that is still occupied becomes its own obstacle and enters level 0.
+template <class S>
+__global__ void k_level_seed_insert(S sp, LevelArgs a, const uint32_t *ins, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool add = false;
+  uint32_t e = 0;
+  if (i < n) {
+    const uint32_t at = ins[i];
+    int x = 0, y = 0, z = 0;
+    const bool here = sp.resident(at);
+    if (here) sp.coords(at, x, y, z);
+    if (here && sp.occupied(at, x, y, z)) {  // "Exist after a whole bunch of updates" (:282)
+      const vox_t self = pack_coc(x + sp.g.gx0, y + sp.g.gy0, z + sp.g.gz0) | kAct;
+      add = atomicExch(a.coc + at, self) != self;  // (a voxel may sit in the queue twice: inserted, deleted, inserted)
+      e = lv_pack(x, y, z);
+    }
+  }
+  if (!lv_append(add, e, a.list[0], &a.ctl->n[0], a.cap)) a.ctl->overflow = 1;
+}
+
+// Out-of-window orphans of the delete scan (their words are still untouched, the in-window orphans carry kReset | dead id):
+// which of them would the reference's list walk have re-seeded?  See the header comment.
+template <class S>
+__global__ void k_level_outside(S sp, LevelArgs a) {
+  const uint32_t n = min(a.ctl->nout, a.cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (n + 63u) / 64u * 64u; i += gridDim.x * blockDim.x) {
+    bool valid = false;
+    uint32_t e = 0;
+    if (i < n) {
+      e = a.outside[i];
+      int x, y, z;
+      sp.decode(e, x, y, z);
+      const uint32_t at = sp.addr_self(sp.page_self(true, x, y, z), x, y, z);
+      const vox_t dead = a.coc[at] & kIdMask;
+      int cx, cy, cz;  // the vanished obstacle, in the coordinates ids are made of
+      unpack_coc(S::kWrap, x + sp.g.gx0, y + sp.g.gy0, z + sp.g.gz0, dead, cx, cy, cz);
+      const int32_t own = lv_d2(sp, x, y, z, dead);
+#pragma unroll
+      for (int k = 0; k < 24; ++k) {
+        const int ux = x + kLvDx[k], uy = y + kLvDy[k], uz = z + kLvDz[k];
+        const int32_t pg = sp.page(!valid && sp.valid(ux, uy, uz), ux, uy, uz);
+        if (pg >= 0) {
+          const vox_t wn = a.coc[sp.addr(pg, at, sp.doff(kLvDx[k], kLvDy[k], kLvDz[k]), ux, uy, uz)];
+          if (wn != kUnobserved) {
+            if ((wn & kNoCoc) && (wn & kAct)) {  // an orphan the scan reset: walked before this one?
+              const vox_t nd = wn & kIdMask;
+              if (nd != dead) {
+                valid = true;
+              } else {
+                const int ex = ux + sp.g.gx0 - cx, ey = uy + sp.g.gy0 - cy, ez = uz + sp.g.gz0 - cz;
+                valid = ex * ex + ey * ey + ez * ez >= own;
+              }
+            } else if (has_link(wn)) {
+              valid = sp.alive(ux, uy, uz, wn & kIdMask);
+            }
+          }
+        }
+      }
+      a.coc[at] = valid ? kReset : kInf;
+    }
+    if (!lv_append(valid, e, a.list[0], &a.ctl->n[0], a.cap)) a.ctl->overflow = 1;
+  }
+}
+
+// ---- the levels -------------------------------------------------------------------------------------------------------
+// ONE work-group runs levels until the frontier is empty (or only waits), outgrows `single_cap`, or a list overflows.
+// The frontier lives in LDS (entries beyond the LDS lists' size go to the global list at the same position: the launch
+// that takes over finds them there), phase A's verdicts too; a level of at most NT entries keeps every entry's stencil in
+// registers from phase A to phase B -- what a level costs then is one batch of loads and one batch of atomics.
+template <class S, int NT, int CAP>
+__global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
+  __shared__ uint32_t s_list[2][CAP];
+  __shared__ uint32_t s_res[CAP];
+  __shared__ uint32_t s_next, s_nextwait, s_wrote, s_maxd2;
+  LevelCtl *ctl = a.ctl;
+  const int tid = threadIdx.x;
+  const unsigned long long t_in = wall_clock64();
+  if (tid == 0) {  // (what the host used to do with two small launches of its own)
+    *a.ctl_other = LevelCtl{};
+    a.counters[C_INSERT] = 0, a.counters[C_DELETE] = 0;  // both queues are drained (the seeds ran before this launch)
+  }
+  uint32_t level = ctl->level;
+  uint32_t n = ctl->n[level % 3u], nwait = ctl->nwait[level % 3u], work = 0;
+  bool fits = ctl->overflow == 0;
+  if (tid == 0) s_wrote = 0, s_maxd2 = 0;
+  bool in_lds = n <= (uint32_t)CAP;  // the current frontier is (also) in s_list
+  if (in_lds)
+    for (uint32_t i = tid; i < n; i += NT) s_list[level & 1u][i] = a.list[level & 1u][i];
+  __syncthreads();
+  uint32_t wrote = 0, maxd2 = 0;
+  // (an update is over after at most a few thousand levels -- the longest chain of voxels the grid holds; the bound on the
+  //  loop only keeps a damaged field from hanging the device: the rounds take over)
+  LvDirs dr;
+  dr.init(sp);
+  constexpr uint32_t QT = NT / 4;  // entries a pass of the work-group covers
+  while (fits && n != 0 && n != nwait && n <= a.single_cap && n <= (uint32_t)CAP && work < 65536u) {
+    const uint32_t *in = s_list[level & 1u];
+    uint32_t *out = s_list[(level + 1u) & 1u];
+    uint32_t *gout = a.list[(level + 1u) & 1u];
+    if (tid == 0) s_next = 0, s_nextwait = 0;
+    auto put = [&](uint32_t at, uint32_t e) {
+      if (at < (uint32_t)CAP)
+        out[at] = e;
+      else if (at < a.cap)
+        gout[at] = e;
+    };
+    if (tid == 0) ctl->items += n, ctl->peak = max(ctl->peak, n);
+    const unsigned long long p0 = wall_clock64();
+    unsigned long long p1 = p0, p2 = p0, p3 = p0;
+    if (n <= QT) {
+      LvItem it;
+      const uint32_t i = (uint32_t)tid >> 2;
+      const bool live = i < n;
+      const uint32_t e = live ? in[i] : 0u;
+      uint32_t verdict = kLvNone;
+      if (__ballot(live)) {  // (a wave without an entry goes straight to the barrier: at a handful of entries most do)
+        lv_fetch<S, true>(sp, a.coc, e, live, dr, it);
+        verdict = lv_pull<S, true>(sp, a.coc, it, dr);
+      }
+      if (verdict == 0x12345678u) ++wrote;  // (keeps the verdict -- and the loads behind it -- ahead of the clock read)
+      p1 = wall_clock64();
+      __syncthreads();  // every pull has read the field; s_next is reset
+      p2 = wall_clock64();
+      if (__ballot(live && verdict != kLvNone)) wrote += lv_push<S, true>(sp, a.coc, e, it, dr, live ? verdict : kLvNone, &s_next, &s_nextwait, maxd2, put);
+      p3 = wall_clock64();
+    } else {
+      const uint32_t n_up = (n + 15u) / 16u * 16u;  // whole waves (16 entries each) walk the loops together
+      for (uint32_t i = (uint32_t)tid >> 2; i < n_up; i += QT) {
+        LvItem it;
+        const bool live = i < n;
+        lv_fetch<S, true>(sp, a.coc, live ? in[i] : 0u, live, dr, it);
+        const uint32_t verdict = lv_pull<S, true>(sp, a.coc, it, dr);
+        if (live && dr.q == 0) s_res[i] = verdict;
+      }
+      __syncthreads();
+      for (uint32_t i = (uint32_t)tid >> 2; i < n_up; i += QT) {
+        const bool live = i < n;
+        const uint32_t verdict = live ? s_res[i] : kLvNone;
+        if (!__ballot(verdict != kLvNone)) continue;
+        LvItem it;
+        const uint32_t e = live ? in[i] : 0u;
+        lv_fetch<S, true>(sp, a.coc, e, live && verdict != kLvNone && verdict != kLvWait, dr, it);
+        wrote += lv_push<S, true>(sp, a.coc, e, it, dr, verdict, &s_next, &s_nextwait, maxd2, put);
+      }
+    }
+    __syncthreads();
+    n = s_next, nwait = s_nextwait;
+    if (n > a.cap) fits = false;
+    ++level, ++work;
+    __syncthreads();  // (s_next is reset at the top of the next level)
+    if (tid == 0) {
+      const unsigned long long p4 = wall_clock64();
+      ctl->phase[0] += (uint32_t)(p1 - p0), ctl->phase[1] += (uint32_t)(p2 - p1), ctl->phase[2] += (uint32_t)(p3 - p2), ctl->phase[3] += (uint32_t)(p4 - p3);
+    }
+  }
+  // hand the state back: the next launch (or the host) goes on from here
+  if (in_lds && work && n <= a.cap)
+    for (uint32_t i = tid; i < min(n, (uint32_t)CAP); i += NT) a.list[level & 1u][i] = s_list[level & 1u][i];
+  atomicAdd(&s_wrote, wrote);
+  atomicMax(&s_maxd2, maxd2);
+  __syncthreads();
+  if (tid == 0) {
+    ctl->level = level;
+    ctl->n[level % 3u] = min(n, a.cap), ctl->nwait[level % 3u] = nwait;
+    ctl->n[(level + 1u) % 3u] = 0, ctl->nwait[(level + 1u) % 3u] = 0;
+    ctl->n[(level + 2u) % 3u] = 0, ctl->nwait[(level + 2u) % 3u] = 0;
+    if (!fits || work >= 65536u) ctl->overflow = 1;
+    ctl->writes += s_wrote;
+    ctl->work += work;
+    if (s_maxd2 > ctl->maxd2) ctl->maxd2 = s_maxd2;
+    if (a.track && s_maxd2) atomicMax(&a.counters[C_MAXD2], (unsigned long long)s_maxd2);
+    ctl->ticks += (uint32_t)(wall_clock64() - t_in);
+  }
+}
+
+// A level as two launches over any number of work-groups.  `a.level` is the level the host believes this launch to be; the
+// device's own count decides (a launch that finds the update finished, or at another level, does nothing).
+template <class S>
+__global__ __launch_bounds__(256) void k_level_pull(S sp, LevelArgs a) {
+  LevelCtl *ctl = a.ctl;
+  const uint32_t level = ctl->level;
+  if (level != a.level || ctl->overflow) return;
+  const uint32_t n = ctl->n[level % 3u];
+  if (n == 0 || n == ctl->nwait[level % 3u]) return;
+  const uint32_t *in = a.list[level & 1u];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->n[(level + 2u) % 3u] = 0, ctl->nwait[(level + 2u) % 3u] = 0;
+  LvDirs dr;
+  dr.init(sp);
+  const uint32_t n_up = (n + 15u) / 16u * 16u;
+  for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < n_up; i += (gridDim.x * blockDim.x) >> 2) {
+    LvItem it;
+    const bool live = i < n;
+    lv_fetch<S, false>(sp, a.coc, live ? in[i] : 0u, live, dr, it);
+    const uint32_t verdict = lv_pull<S, false>(sp, a.coc, it, dr);
+    if (live && dr.q == 0) a.res[i] = verdict;
+  }
+}
+template <class S>
+__global__ __launch_bounds__(256) void k_level_push(S sp, LevelArgs a) {
+  LevelCtl *ctl = a.ctl;
+  const uint32_t level = ctl->level;
+  if (level != a.level || ctl->overflow) return;
+  const uint32_t n = ctl->n[level % 3u];
+  if (n == 0 || n == ctl->nwait[level % 3u]) return;
+  const uint32_t *in = a.list[level & 1u];
+  uint32_t *out = a.list[(level + 1u) & 1u];
+  uint32_t wrote = 0, maxd2 = 0;
+  auto put = [&](uint32_t at, uint32_t e) {
+    if (at < a.cap) out[at] = e;
+  };
+  LvDirs dr;
+  dr.init(sp);
+  const uint32_t n_up = (n + 15u) / 16u * 16u;
+  for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < n_up; i += (gridDim.x * blockDim.x) >> 2) {
+    const bool live = i < n;
+    const uint32_t verdict = live ? a.res[i] : kLvNone;
+    if (!__ballot(verdict != kLvNone)) continue;
+    LvItem it;
+    const uint32_t e = live ? in[i] : 0u;
+    lv_fetch<S, false>(sp, a.coc, e, live && verdict != kLvNone && verdict != kLvWait, dr, it);
+    wrote += lv_push<S, false>(sp, a.coc, e, it, dr, verdict, &ctl->n[(level + 1u) % 3u], &ctl->nwait[(level + 1u) % 3u], maxd2, put);
+  }
+  __shared__ uint32_t s_wrote, s_maxd2;
+  if (threadIdx.x == 0) s_wrote = 0, s_maxd2 = 0;
+  __syncthreads();
+  if (wrote) atomicAdd(&s_wrote, wrote);
+  if (maxd2) atomicMax(&s_maxd2, maxd2);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_wrote) atomicAdd(&ctl->writes, s_wrote);
+    if (s_maxd2) {
+      atomicMax(&ctl->maxd2, s_maxd2);
+      if (a.track) atomicMax(&a.counters[C_MAXD2], (unsigned long long)s_maxd2);
+    }
+  }
+}
+// closes a level of the two-launch form (ONE thread): the counters move on
+namespace {  // (this header is included by two translation units)
+__global__ void k_level_next(LevelArgs a) {
+  LevelCtl *ctl = a.ctl;
+  const uint32_t level = ctl->level;
+  if (level != a.level || ctl->overflow) return;
+  const uint32_t n = ctl->n[level % 3u];
+  if (n == 0 || n == ctl->nwait[level % 3u]) return;
+  if (ctl->n[(level + 1u) % 3u] > a.cap) ctl->n[(level + 1u) % 3u] = a.cap, ctl->overflow = 1;
+  ctl->level = level + 1u;
+  ctl->work += 1u;
+  ctl->items += n, ctl->peak = max(ctl->peak, n);
+}
+}  // namespace
+
+// The update did not fit the level engine's lists: the frontier-round engine finishes it.  It starts from frontier TAGS
+// in the field and a list of active tiles, so every tagged word gets its tile activated (and a reset word loses the dead
+// id it still carried).  A tagged voxel that holds an obstacle may still owe its pull (see k_level_list_to_tiles): it takes
+// it here, from the neighbours that are NOT tagged -- those will never push; the tagged ones push in the rounds.
+template <class S>
+__global__ void k_level_to_tiles(S sp, LevelArgs a, int64_t nvox, TileGrid tg, uint32_t *flag, uint32_t *list, unsigned long long *count) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * blockDim.x) {
+    const vox_t w = a.coc[i];
+    if (w == kUnobserved || !(w & kAct)) continue;
+    if (!sp.resident((uint32_t)i)) continue;
+    if (w & kNoCoc) a.coc[i] = kReset;
+    int x, y, z;
+    sp.coords((uint32_t)i, x, y, z);
+    if (!(w & kNoCoc)) {
+      int32_t best = lv_d2(sp, x, y, z, w & kIdMask);
+      vox_t bid = kNoCoc;
+      for (int k = 0; k < 24; ++k) {
+        const int ux = x + kLvDx[k], uy = y + kLvDy[k], uz = z + kLvDz[k];
+        const int32_t pg = sp.page(sp.valid(ux, uy, uz), ux, uy, uz);
+        if (pg < 0) continue;
+        const vox_t wn = a.coc[sp.addr(pg, (uint32_t)i, sp.doff(kLvDx[k], kLvDy[k], kLvDz[k]), ux, uy, uz)];
+        if (wn == kUnobserved || (wn & kAct) || !has_link(wn)) continue;
+        const int32_t d = lv_d2(sp, x, y, z, wn & kIdMask);
+        if (d < best) best = d, bid = wn & kIdMask;
+      }
+      if (!(bid & kNoCoc)) (void)lv_min<S, false>(sp, a.coc, (uint32_t)i, x, y, z, bid, best, a.coc[i]);
+    }
+    const uint32_t t = sp.tile_of(tg, (uint32_t)i, x, y, z);
+    if (flag[t] == 0u) activate_tile(t, flag, list, count);
+  }
+}
+
+// A level outgrew what one work-group should carry: the frontier-round engine goes on from the CURRENT frontier.  Its
+// entries wear the tag the rounds start from (the "queued" mark) -- but the rounds only let a voxel PULL that has no
+// obstacle when its tile is staged, and a frontier entry here may have just received its first obstacle from a push and
+// still owe its pull (:349-367).  So the hand-over is: phase A of this level (k_level_pull: the verdicts), then this
+// kernel: an entry that improved stores its obstacle; every entry gets its tag back and its tile activated.  An orphan
+// outside the window that still waits gets its reset word back: the rounds' own pass for such voxels (k_reseed_outside)
+// finds it.
+template <class S>
+__global__ void k_level_list_to_tiles(S sp, LevelArgs a, TileGrid tg, uint32_t *flag, uint32_t *list, unsigned long long *count) {
+  const LevelCtl *ctl = a.ctl;
+  const uint32_t level = ctl->level, n = min(ctl->n[level % 3u], a.cap);
+  const uint32_t *in = a.list[level & 1u];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int x, y, z;
+    sp.decode(in[i], x, y, z);
+    const int32_t pg = sp.page_self(true, x, y, z);
+    if (pg < 0) continue;
+    const uint32_t at = sp.addr_self(pg, x, y, z);
+    const uint32_t verdict = a.res[i];
+    if (verdict == kLvWait) {
+      a.coc[at] = kReset;
+      continue;  // (outside the window: the rounds never stage it)
+    }
+    if (verdict != kLvNone && !(verdict & kLvPush))
+      (void)lv_min<S, false>(sp, a.coc, at, x, y, z, verdict & kIdMask, lv_d2(sp, x, y, z, verdict & kIdMask), a.coc[at]);
+    if (!(a.coc[at] & kNoCoc)) atomicOr(a.coc + at, kAct);
+    if (!sp.valid(x, y, z)) continue;
+    const uint32_t t = sp.tile_of(tg, at, x, y, z);
+    if (flag[t] == 0u) activate_tile(t, flag, list, count);
+  }
+}
+
+// ---- host side: buffers and the launch sequence, shared by both map classes ------------------------------------------
+struct LevelEngine {
+  DevBuf<uint32_t> list[2], res, outside;
+  LevelCtl *ctl2 = nullptr;   // device: two blocks, alternating between updates (the idle one is cleared by k_level_run)
+  LevelCtl *ctl = nullptr;    // the current update's
+  LevelCtl *h_ctl = nullptr;  // pinned
+  uint32_t serial = 0;
+  uint32_t cap = 0;
+  static constexpr uint32_t kSingleCap = 1024;  // frontier one work-group keeps to itself (one CU: ~25 ns per entry)
+  enum Outcome { kDone = 0, kOverflow = 1, kHandOver = 2 };
+  static constexpr int kNT = 1024;
+  ~LevelEngine() {
+    if (ctl2) (void)hipFree(ctl2);
+    if (h_ctl) (void)hipHostFree(h_ctl);
+  }
+  void ensure(uint32_t want, hipStream_t s) {
+    if (!ctl2) {
+      FIESTA_HIP_CHECK(hipMalloc((void **)&ctl2, 2 * sizeof(LevelCtl)));
+      FIESTA_HIP_CHECK(hipMemsetAsync(ctl2, 0, 2 * sizeof(LevelCtl), s));
+      FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_ctl, sizeof(LevelCtl)));
+      ctl = ctl2;
+    }
+    if (want <= cap) return;
+    for (auto &l : list) l.ensure_exact(want, s);
+    res.ensure_exact(want, s);
+    outside.ensure_exact(want, s);
+    cap = want;
+  }
+  LevelArgs args(vox_t *coc, unsigned long long *counters, bool track) const {
+    LevelArgs a;
+    a.coc = coc;
+    a.list[0] = list[0].p, a.list[1] = list[1].p;
+    a.res = res.p;
+    a.outside = outside.p;
+    a.ctl = ctl;
+    a.ctl_other = ctl2 + ((ctl - ctl2) ^ 1);
+    a.cap = cap;
+    a.single_cap = kSingleCap;
+    a.level = 0;
+    a.counters = counters;
+    a.track = track ? 1 : 0;
+    return a;
+  }
+  // a new update: the block the previous update's k_level_run cleared
+  void begin() { ctl = ctl2 + (++serial & 1u); }
+  // Runs the levels.  kDone: the update is finished.  kOverflow: a list overflowed, the caller rebuilds the rounds' state by
+  // a scan (k_level_to_tiles).  kHandOver (only if !wide): a level outgrew the one work-group; the current frontier is in
+  // the list, the caller passes it to the rounds (k_level_list_to_tiles).  wide: such levels go on as launches over many
+  // work-groups instead.  One host round trip per chain; a sensor frame's update is one launch and one round trip.
+  // `done` is recorded behind the last kernel of every chain: when run() returns it marks the end of the levels' device work.
+  template <class S>
+  Outcome run(const S &sp, LevelArgs a, hipStream_t s, hipEvent_t done, bool wide, int64_t *launches) {
+    for (;;) {
+      hipLaunchKernelGGL((k_level_run<S, kNT, (int)kSingleCap>), dim3(1), dim3(kNT), 0, s, sp, a);
+      FIESTA_HIP_CHECK(hipGetLastError());
+      ++*launches;
+      FIESTA_HIP_CHECK(hipEventRecord(done, s));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(LevelCtl), hipMemcpyDeviceToHost, s));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+      for (;;) {
+        if (h_ctl->overflow) return kOverflow;
+        const uint32_t l = h_ctl->level, n = h_ctl->n[l % 3u];
+        if (n == 0 || n == h_ctl->nwait[l % 3u]) return kDone;
+        if (n <= a.single_cap) break;  // small again: back to the one work-group
+        if (!wide) return kHandOver;
+        // a chain of wide levels; work-groups in proportion to the frontier this chain starts with
+        const int blocks = (int)std::min<uint32_t>((n + 63u) / 64u * 2u, 16384u), chain = 8;  // (64 entries per work-group pass)
+        for (int k = 0; k < chain; ++k) {
+          a.level = l + (uint32_t)k;
+          hipLaunchKernelGGL((k_level_pull<S>), dim3(blocks), dim3(256), 0, s, sp, a);
+          hipLaunchKernelGGL((k_level_push<S>), dim3(blocks), dim3(256), 0, s, sp, a);
+          hipLaunchKernelGGL(k_level_next, dim3(1), dim3(1), 0, s, a);
+          *launches += 3;
+        }
+        FIESTA_HIP_CHECK(hipGetLastError());
+        FIESTA_HIP_CHECK(hipEventRecord(done, s));
+        FIESTA_HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(LevelCtl), hipMemcpyDeviceToHost, s));
+        FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+      }
+    }
+  }
+};
+
+}  // namespace fiesta

@@ -49,7 +49,7 @@ class ESDFMap:
         cfg.reserve_size = int(reserve_size)
         if update_engine is None or update_engine == 0 or update_engine == "auto":
             update_engine = DEFAULT_UPDATE_ENGINE
-        cfg.update_engine = {"auto": 0, "rounds": 1, "bulk": 2}.get(update_engine, update_engine)
+        cfg.update_engine = {"auto": 0, "rounds": 1, "bulk": 2, "levels": 3}.get(update_engine, update_engine)
         if shard_lo is not None:
             cfg.shard_lo[:] = [int(v) for v in shard_lo]
             cfg.global_grid[:] = [int(v) for v in global_grid]
@@ -98,8 +98,8 @@ class ESDFMap:
         check(self._lib.fiesta_hip_set_original_range(self._h))
 
     def set_update_engine(self, update_engine):
-        """"auto" / "rounds" / "bulk" (0 / 1 / 2) from the next UpdateESDF on."""
-        check(self._lib.fiesta_hip_set_update_engine(self._h, {"auto": 0, "rounds": 1, "bulk": 2}.get(update_engine, update_engine)))
+        """"auto" / "rounds" / "bulk" / "levels" (0 / 1 / 2 / 3) from the next UpdateESDF on."""
+        check(self._lib.fiesta_hip_set_update_engine(self._h, {"auto": 0, "rounds": 1, "bulk": 2, "levels": 3}.get(update_engine, update_engine)))
 
     # -- occupancy ingest ----------------------------------------------------------------------------
     def SetOccupancy(self, where, occ, want_ret=True):

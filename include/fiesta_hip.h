@@ -49,8 +49,9 @@ typedef struct fiesta_hip_config {
   double map_size[3];   /* array mode: grid = ceil(map_size/resolution) (src/ESDFMap.cpp:175-176) */
   int32_t reserve_size; /* hash mode: initial voxel reserve (src/ESDFMap.cpp:141-145) */
   int32_t update_engine; /* UpdateESDF engine: 0 = chosen per update (default), 1 = frontier rounds only, 2 = bulk
-                            feature transform whenever the map is fully observed; on maps where both
-                            apply the distances do not depend on it */
+                            feature transform whenever the map is fully observed, 3 = level engine for
+                            every update its lists can hold (DESIGN.md 3a'); on fully observed maps the distances do not
+                            depend on it */
   /* Spatial sharding. A map may be one shard of a larger global grid: it owns the global
    * voxel box [shard_lo, shard_lo + grid) and stores closest-obstacle ids in GLOBAL coordinates. For an
    * unsharded map leave these zero. */
@@ -81,6 +82,9 @@ typedef struct fiesta_hip_stats {
   int64_t dropped_observations; /* hash mode, cumulative: observations that fell outside the window even after it moved
                                    to their batch (a single batch or frame spanning more than 1024 voxels on an axis,
                                    non-finite positions) and were ignored -- a non-zero value means lost map data */
+  int64_t levels;        /* 1: this update ran the level engine from start to end (rounds = its levels, one per layer of the
+                            reference's FIFO); 0 with bulk == 0: the frontier rounds ran (possibly after the level engine's
+                            lists overflowed) */
 } fiesta_hip_stats;
 
 const char *fiesta_hip_last_error(void);

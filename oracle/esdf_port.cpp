@@ -326,6 +326,200 @@ struct Port {
     }
   }
 
+  // ---- NOT the reference: a CPU model of the GPU's level-synchronous schedule (fiesta_amd/csrc/level_kernels.hpp) -------
+  // The reference's update queue is a FIFO, so its entries are processed in LAYERS: layer L + 1 is what the processing
+  // of layer L enqueued.  A parallel engine cannot reproduce the order inside a layer, but it can keep the layers: every
+  // valid entry of a layer first PULLS (from the field as the layer found it), the voxels that improved go to the next
+  // layer, the others PUSH (a minimum per target voxel; a target that improves goes to the next layer).  This model runs
+  // exactly that on the port's arrays so that the schedule can be judged against the reference's own order spread
+  // (tests/test_levelsync_model.py) without a GPU.  The per-obstacle lists are not maintained (the engine has none: the
+  // orphans of a delete are found by a scan); a map driven through this schedule must never go back to relax().
+  //   reseed = 1: orphans are re-seeded in waves from their first valid stencil neighbour (:308-321) before the layers
+  //   reseed = 0: orphans are reset and enter layer 0 as pull-only entries
+  int schedule = 0;  // 0: relax() (the reference's FIFO); 1: levels, wave re-seed; 2: levels, orphans pull
+  int64_t levels_run = 0;
+  int nslots() const { return mode == 1 ? count : total; }
+  void relax_levels(oracle_esdf_stats *st) {
+    std::vector<int> F, Fn;
+    std::vector<char> inF(reserve + 1, 0);
+    auto add = [&](std::vector<int> &L, int s) {
+      if ((size_t)s >= inF.size()) inF.resize(reserve + 1, 0);
+      if (!inF[s]) inF[s] = 1, L.push_back(s);
+    };
+    while (!q_ins.empty()) {  // :278-291
+      const Item e = q_ins.front();
+      q_ins.pop_front();
+      const int s = slot(e.p);
+      if (!occupied(s)) continue;
+      coc[s] = e.p;
+      dist[s] = 0.0;
+      add(F, s);
+    }
+    bool any_del = false;
+    while (!q_del.empty()) {
+      const Item e = q_del.front();
+      q_del.pop_front();
+      if (!occupied(slot(e.p))) any_del = true;
+    }
+    if (any_del) {  // :292-337 without the lists: every voxel whose (possibly stale) link names a vanished obstacle
+      std::vector<int> orphans;
+      const int n0 = nslots();
+      for (int s = (mode == 1 ? 1 : 0); s < n0; ++s)
+        if (defined(coc[s]) && dist[s] >= 0 && !occupied(slot(coc[s]))) orphans.push_back(s);
+      // Orphans OUTSIDE the window (:308-321 gates the neighbour, not the orphan): the reference re-seeds one from its first
+      // in-window neighbour that is valid AT THAT MOMENT of the list walk -- a live obstacle, or an orphan walked earlier.
+      // The list is push-front in adoption order, i.e. walked from the rim of the dead cell inwards: "walked earlier" is
+      // modelled as "orphan of the same obstacle, strictly farther from it".  One that finds nothing stays at infinity for
+      // good (never queued :329, never pushed into :378).
+      std::vector<char> may_wait(reserve + 1, 0);
+      for (int o : orphans) {
+        const I3 ov = vox_of(o);
+        if (in_window(ov)) continue;
+        const I3 X = coc[o];
+        const double dox = metric(ov, X);
+        for (const I3 &dir : kDirs) {
+          const I3 nv = ov + dir;
+          if (!in_window(nv)) continue;
+          const int ns = slot(nv);
+          if (!defined(coc[ns]) || dist[ns] < 0) continue;
+          const bool dead = !occupied(slot(coc[ns]));
+          if (!dead || !(coc[ns].x == X.x && coc[ns].y == X.y && coc[ns].z == X.z) || metric(nv, X) >= dox) {
+            may_wait[o] = 1;
+            break;
+          }
+        }
+      }
+      for (int o : orphans) coc[o] = kNone, dist[o] = kInf;
+      if (schedule != 2) {
+        std::vector<int> rest = orphans, keep;
+        std::vector<std::pair<int, I3>> got;
+        for (;;) {
+          got.clear(), keep.clear();
+          for (int o : rest) {
+            const I3 ov = vox_of(o);
+            bool found = false;
+            for (const I3 &dir : kDirs) {
+              const I3 nv = ov + dir;
+              if (!in_window(nv)) continue;
+              const int ns = slot(nv);
+              if (defined(coc[ns])) {
+                got.push_back({o, coc[ns]});
+                found = true;
+                break;
+              }
+            }
+            if (!found) keep.push_back(o);
+          }
+          if (got.empty()) break;
+          for (auto &g : got) {
+            coc[g.first] = g.second;
+            dist[g.first] = metric(vox_of(g.first), g.second);
+            add(F, g.first);
+          }
+          rest.swap(keep);
+        }
+      } else {
+        for (int o : orphans)
+          if (in_window(vox_of(o)) || may_wait[o]) add(F, o);
+      }
+    }
+    int64_t expanded = 0, changes = 0;
+    std::vector<std::pair<int, I3>> better;
+    std::vector<std::pair<int, I3>> pushers;
+    std::vector<int> waiting;
+    if (schedule >= 3) {  // experiment: layers kept, entries of a layer one after the other (3: list order, 4: shuffled)
+      uint64_t rs = 88172645463325252ull;
+      while (!F.empty()) {
+        ++levels_run;
+        if (schedule == 4)
+          for (size_t i = F.size(); i > 1; --i) {
+            rs ^= rs << 13, rs ^= rs >> 7, rs ^= rs << 17;
+            std::swap(F[i - 1], F[rs % i]);
+          }
+        for (int s : F) inF[s] = 0;
+        Fn.clear();
+        for (int s : F) {
+          if (inF[s]) continue;  // re-queued meanwhile: this entry is stale (:345)
+          const I3 v = vox_of(s);
+          bool improved = false;
+          for (int i = 0; i < 24; ++i) {
+            const I3 nv = v + kDirs[i];
+            if (!in_window(nv)) continue;
+            const int ns = slot(nv);
+            if (!defined(coc[ns])) continue;
+            const double t = metric(v, coc[ns]);
+            if (dist[s] > t) dist[s] = t, coc[s] = coc[ns], improved = true;
+          }
+          ++expanded;
+          if (improved) {
+            add(Fn, s);
+            continue;
+          }
+          if (!defined(coc[s])) continue;
+          for (const I3 &dir : kDirs) {
+            const I3 nv = v + dir;
+            if (!in_window(nv)) continue;
+            const int ns = slot(nv);
+            const double t = metric(nv, coc[s]);
+            if (dist[ns] > t) dist[ns] = t, coc[ns] = coc[s], add(Fn, ns);
+          }
+        }
+        F.swap(Fn);
+      }
+    }
+    while (!F.empty()) {
+      ++levels_run;
+      better.clear(), pushers.clear();
+      for (int s : F) {  // pull, from the field as this layer found it (:349-367)
+        const I3 v = vox_of(s);
+        double best = dist[s];
+        I3 bc = kNone;
+        for (int i = 0; i < 24; ++i) {
+          const I3 nv = v + kDirs[i];
+          if (!in_window(nv)) continue;
+          const int ns = slot(nv);
+          if (!defined(coc[ns])) continue;
+          const double t = metric(v, coc[ns]);
+          if (best > t) best = t, bc = coc[ns];
+        }
+        ++expanded;
+        if (defined(bc))
+          better.push_back({s, bc});
+        else if (defined(coc[s]))
+          pushers.push_back({s, coc[s]});
+        else if (!in_window(v))
+          waiting.push_back(s);  // an orphan outside the window: nobody will push into it, it has to ask again
+      }
+      for (int s : F) inF[s] = 0;
+      Fn.clear();
+      for (auto &b : better) {  // :369-373
+        coc[b.first] = b.second;
+        dist[b.first] = metric(vox_of(b.first), b.second);
+        add(Fn, b.first);
+        ++changes;
+      }
+      for (auto &p : pushers) {  // push (:375-391): a minimum per target
+        const I3 v = vox_of(p.first);
+        for (const I3 &dir : kDirs) {
+          const I3 nv = v + dir;
+          if (!in_window(nv)) continue;
+          const int ns = slot(nv);
+          const double t = metric(nv, p.second);
+          if (dist[ns] > t) {
+            dist[ns] = t;
+            coc[ns] = p.second;
+            add(Fn, ns);
+          }
+        }
+      }
+      if (!Fn.empty())
+        for (int s : waiting) add(Fn, s);
+      waiting.clear();
+      F.swap(Fn);
+    }
+    if (st) st->expanded = expanded, st->change_num = changes;
+  }
+
   double distance_vox(I3 v) {  // GetDistance(Vector3i) (src/ESDFMap.cpp:477-479): no bounds check
     const int s = slot(v);
     return dist[s] < 0 ? (double)kInf : dist[s];
@@ -507,7 +701,10 @@ void oracle_update_esdf(oracle_map *m, oracle_esdf_stats *st) {
   st->inserted = (int64_t)m->p.q_ins.size();
   st->deleted = (int64_t)m->p.q_del.size();
   auto t0 = std::chrono::steady_clock::now();
-  m->p.relax(st);
+  if (m->p.schedule)
+    m->p.relax_levels(st);
+  else
+    m->p.relax(st);
   st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 void oracle_get_distance_vox(oracle_map *m, const int32_t *vox, int64_t n, double *out) {
@@ -579,6 +776,9 @@ int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc
   return n;
 }
 int oracle_check_consistency(oracle_map *m) { return m->p.lists_consistent(); }
+// port only: the schedule UpdateESDF runs (0 = the reference's FIFO; 1, 2 = the level-synchronous model, see relax_levels)
+void oracle_set_schedule(oracle_map *m, int schedule) { m->p.schedule = schedule; }
+int64_t oracle_levels_run(oracle_map *m) { return m->p.levels_run; }
 
 // GetPointCloud (src/ESDFMap.cpp:544-582), restated: occupied voxels inside the update range (hash flavour: x and y
 // only) whose z index lies within the visualisation bounds, as voxel centres narrowed to float (Point32).

@@ -96,6 +96,9 @@ def _load(kind: str, mode: str):
         "oracle_raycast_frame": (None, [vp, vp, i64, vp, vp, vp]),
         "oracle_depth_conversion": (i64, [vp, vp, i32, i32, dbl, dbl, dbl, dbl, i32, vp, dbl, dbl, dbl, i32, vp]),
     }
+    if kind == "port":   # the model of the GPU's level-synchronous schedule lives in the restatement only
+        sig["oracle_set_schedule"] = (None, [vp, i32])
+        sig["oracle_levels_run"] = (i64, [vp])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -241,6 +244,14 @@ class OracleMap:
         occ = np.empty(n, np.uint8)
         self.lib.oracle_dump_hash(self.h, _p(vox), _p(dist), _p(coc), _p(occ))
         return {"vox": vox, "dist": dist, "coc": coc, "occ": occ}
+
+    def set_schedule(self, schedule):
+        """port only: 0 = the reference's FIFO, 1 / 2 = the level-synchronous model of the GPU engine (esdf_port.cpp)."""
+        self.lib.oracle_set_schedule(self.h, int(schedule))
+
+    @property
+    def levels_run(self):
+        return int(self.lib.oracle_levels_run(self.h))
 
     def CheckConsistency(self):
         return bool(self.lib.oracle_check_consistency(self.h))

@@ -36,13 +36,15 @@ def hip_lib():
     return lib
 
 
-@pytest.fixture(params=["rounds", "bulk"])
+@pytest.fixture(params=["rounds", "bulk", "levels"])
 def engine(request, monkeypatch):
     """Runs a GPU test once per UpdateESDF engine: frontier rounds only / bulk feature transform wherever the map state
-    allows it (maps created without an explicit update_engine take fiesta_amd.esdf_map.DEFAULT_UPDATE_ENGINE; the library
-    itself reads no environment).  On fully observed maps both must reproduce the reference exactly; elsewhere "bulk"
-    falls back to the rounds by itself."""
+    allows it (and, where it does not, the library's own choice: level engine for small updates, rounds for large ones) /
+    level engine for everything its lists hold (maps created without an explicit update_engine take
+    fiesta_amd.esdf_map.DEFAULT_UPDATE_ENGINE; the library itself reads no environment).  On fully observed maps all three
+    must reproduce the reference exactly."""
     import fiesta_amd.esdf_map as em
-    monkeypatch.setattr(em, "DEFAULT_UPDATE_ENGINE", {"rounds": 1, "bulk": 2}[request.param])
-    monkeypatch.setenv("FIESTA_TEST_UPDATE_ENGINE", {"rounds": "1", "bulk": "2"}[request.param])  # (spawned workers)
+    code = {"rounds": 1, "bulk": 2, "levels": 3}[request.param]
+    monkeypatch.setattr(em, "DEFAULT_UPDATE_ENGINE", code)
+    monkeypatch.setenv("FIESTA_TEST_UPDATE_ENGINE", str(code))  # (spawned workers)
     return request.param

@@ -27,4 +27,4 @@ for mode in ("array", "hash"):
             if k >= 8 and st["inserted"] == 1:
                 ts["occ"].append((t1 - t0) * 1e6); ts["esdf"].append((t2 - t1) * 1e6); ts["dev"].append(st["device_ms"] * 1e3); ts["relax"].append(st["relax_ms"] * 1e3)
                 last = st
-    print(mode, {k: round(float(np.median(v)), 1) for k, v in ts.items()}, "us; last stats:", len(ts["esdf"]), {k: last[k] for k in ("inserted", "deleted", "rounds", "tile_visits", "relax_launches", "sweeps", "voxel_writes")}, "prof", list(last["prof"]))
+    print(mode, {k: round(float(np.median(v)), 1) for k, v in ts.items()}, "us; in-kernel ns", last["prof"][0], "last stats:", len(ts["esdf"]), {k: last[k] for k in ("inserted", "deleted", "rounds", "tile_visits", "relax_launches", "sweeps", "voxel_writes")}, "prof", list(last["prof"]))
