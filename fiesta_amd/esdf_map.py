@@ -62,6 +62,7 @@ class ESDFMap:
         check(self._lib.fiesta_hip_grid_size(self._h, _p(gs)))
         self.grid_size = tuple(int(v) for v in gs)
         self.last_insert = self.last_delete = 0
+        self.served = {"levels": 0, "rounds": 0, "bulk": 0}   # UpdateESDF calls with work, by the engine that served them
 
     # -- life cycle ------------------------------------------------------------------------------
     def close(self):
@@ -144,7 +145,16 @@ class ESDFMap:
     def UpdateESDF(self) -> dict:
         st = Stats()
         check(self._lib.fiesta_hip_update_esdf(self._h, C.byref(st)))
-        return st.as_dict()
+        d = st.as_dict()
+        if d["inserted"] or d["deleted"] or d["rounds"] or d["bulk"]:   # (an update that had something to do)
+            self.served["bulk" if d["bulk"] else "levels" if d["levels"] else "rounds"] += 1
+        return d
+
+    @property
+    def only_levels(self) -> bool:
+        """Every UpdateESDF of this map so far that had work ran the level engine from start to end (fiesta_hip_stats.levels):
+        what the parity tests key their contract on (tests/scenarios.py: assert_envelope)."""
+        return self.served["rounds"] == 0 and self.served["bulk"] == 0
 
     # -- ray casting -----------------------------------------------------------------------------------
     def RaycastFrame(self, points, transform, origin, min_ray_length, max_ray_length, l_cornor, r_cornor,

@@ -326,17 +326,17 @@ struct Port {
     }
   }
 
-  // ---- NOT the reference: a CPU model of the GPU's level-synchronous schedule (fiesta_amd/csrc/level_kernels.hpp) -------
+  // ---- NOT the reference: a CPU model of the GPU's level engine (fiesta_amd/csrc/level_kernels.hpp) --------------------
   // The reference's update queue is a FIFO, so its entries are processed in LAYERS: layer L + 1 is what the processing
   // of layer L enqueued.  A parallel engine cannot reproduce the order inside a layer, but it can keep the layers: every
-  // valid entry of a layer first PULLS (from the field as the layer found it), the voxels that improved go to the next
-  // layer, the others PUSH (a minimum per target voxel; a target that improves goes to the next layer).  This model runs
-  // exactly that on the port's arrays so that the schedule can be judged against the reference's own order spread
-  // (tests/test_levelsync_model.py) without a GPU.  The per-obstacle lists are not maintained (the engine has none: the
-  // orphans of a delete are found by a scan); a map driven through this schedule must never go back to relax().
-  //   reseed = 1: orphans are re-seeded in waves from their first valid stencil neighbour (:308-321) before the layers
-  //   reseed = 0: orphans are reset and enter layer 0 as pull-only entries
-  int schedule = 0;  // 0: relax() (the reference's FIFO); 1: levels, wave re-seed; 2: levels, orphans pull
+  // entry of a layer first PULLS (from the field as the layer found it), the voxels that improved go to the next layer,
+  // the others PUSH (a minimum per target voxel; a target that improves goes to the next layer).  This model runs exactly
+  // that on the port's arrays, so that the schedule can be judged against the reference's own order spread without a GPU
+  // (tests/test_levelsync_model.py).  The per-obstacle lists are not maintained (the engine has none: the orphans of a
+  // delete are found by a scan); a map driven through this schedule must never go back to relax().
+  // Orphans of a delete are reset and enter layer 0 as pull-only entries (their first pull is their re-seed, :308-321).
+  // Orphans OUTSIDE the update window: see level_kernels.hpp (k_level_outside) -- the same rule, the same order of tests.
+  int schedule = 0;  // 0: relax() (the reference's FIFO); 1: relax_levels()
   int64_t levels_run = 0;
   int nslots() const { return mode == 1 ? count : total; }
   void relax_levels(oracle_esdf_stats *st) {
@@ -369,8 +369,8 @@ struct Port {
       // Orphans OUTSIDE the window (:308-321 gates the neighbour, not the orphan): the reference re-seeds one from its first
       // in-window neighbour that is valid AT THAT MOMENT of the list walk -- a live obstacle, or an orphan walked earlier.
       // The list is push-front in adoption order, i.e. walked from the rim of the dead cell inwards: "walked earlier" is
-      // modelled as "orphan of the same obstacle, strictly farther from it".  One that finds nothing stays at infinity for
-      // good (never queued :329, never pushed into :378).
+      // modelled as "orphan of another vanished obstacle, or of the same one and not closer to it".  One that finds nothing
+      // stays at infinity for good (never queued :329, never pushed into :378).
       std::vector<char> may_wait(reserve + 1, 0);
       for (int o : orphans) {
         const I3 ov = vox_of(o);
@@ -390,83 +390,12 @@ struct Port {
         }
       }
       for (int o : orphans) coc[o] = kNone, dist[o] = kInf;
-      if (schedule != 2) {
-        std::vector<int> rest = orphans, keep;
-        std::vector<std::pair<int, I3>> got;
-        for (;;) {
-          got.clear(), keep.clear();
-          for (int o : rest) {
-            const I3 ov = vox_of(o);
-            bool found = false;
-            for (const I3 &dir : kDirs) {
-              const I3 nv = ov + dir;
-              if (!in_window(nv)) continue;
-              const int ns = slot(nv);
-              if (defined(coc[ns])) {
-                got.push_back({o, coc[ns]});
-                found = true;
-                break;
-              }
-            }
-            if (!found) keep.push_back(o);
-          }
-          if (got.empty()) break;
-          for (auto &g : got) {
-            coc[g.first] = g.second;
-            dist[g.first] = metric(vox_of(g.first), g.second);
-            add(F, g.first);
-          }
-          rest.swap(keep);
-        }
-      } else {
-        for (int o : orphans)
-          if (in_window(vox_of(o)) || may_wait[o]) add(F, o);
-      }
+      for (int o : orphans)
+        if (in_window(vox_of(o)) || may_wait[o]) add(F, o);
     }
     int64_t expanded = 0, changes = 0;
-    std::vector<std::pair<int, I3>> better;
-    std::vector<std::pair<int, I3>> pushers;
+    std::vector<std::pair<int, I3>> better, pushers;
     std::vector<int> waiting;
-    if (schedule >= 3) {  // experiment: layers kept, entries of a layer one after the other (3: list order, 4: shuffled)
-      uint64_t rs = 88172645463325252ull;
-      while (!F.empty()) {
-        ++levels_run;
-        if (schedule == 4)
-          for (size_t i = F.size(); i > 1; --i) {
-            rs ^= rs << 13, rs ^= rs >> 7, rs ^= rs << 17;
-            std::swap(F[i - 1], F[rs % i]);
-          }
-        for (int s : F) inF[s] = 0;
-        Fn.clear();
-        for (int s : F) {
-          if (inF[s]) continue;  // re-queued meanwhile: this entry is stale (:345)
-          const I3 v = vox_of(s);
-          bool improved = false;
-          for (int i = 0; i < 24; ++i) {
-            const I3 nv = v + kDirs[i];
-            if (!in_window(nv)) continue;
-            const int ns = slot(nv);
-            if (!defined(coc[ns])) continue;
-            const double t = metric(v, coc[ns]);
-            if (dist[s] > t) dist[s] = t, coc[s] = coc[ns], improved = true;
-          }
-          ++expanded;
-          if (improved) {
-            add(Fn, s);
-            continue;
-          }
-          if (!defined(coc[s])) continue;
-          for (const I3 &dir : kDirs) {
-            const I3 nv = v + dir;
-            if (!in_window(nv)) continue;
-            const int ns = slot(nv);
-            const double t = metric(nv, coc[s]);
-            if (dist[ns] > t) dist[ns] = t, coc[ns] = coc[s], add(Fn, ns);
-          }
-        }
-        F.swap(Fn);
-      }
-    }
     while (!F.empty()) {
       ++levels_run;
       better.clear(), pushers.clear();
@@ -776,7 +705,7 @@ int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc
   return n;
 }
 int oracle_check_consistency(oracle_map *m) { return m->p.lists_consistent(); }
-// port only: the schedule UpdateESDF runs (0 = the reference's FIFO; 1, 2 = the level-synchronous model, see relax_levels)
+// port only: the schedule UpdateESDF runs (0 = the reference's FIFO; 1 = the model of the GPU's level engine, relax_levels)
 void oracle_set_schedule(oracle_map *m, int schedule) { m->p.schedule = schedule; }
 int64_t oracle_levels_run(oracle_map *m) { return m->p.levels_run; }
 

@@ -246,7 +246,7 @@ class OracleMap:
         return {"vox": vox, "dist": dist, "coc": coc, "occ": occ}
 
     def set_schedule(self, schedule):
-        """port only: 0 = the reference's FIFO, 1 / 2 = the level-synchronous model of the GPU engine (esdf_port.cpp)."""
+        """port only: 0 = the reference's FIFO, 1 = the CPU model of the GPU's level engine (esdf_port.cpp: relax_levels)."""
         self.lib.oracle_set_schedule(self.h, int(schedule))
 
     @property

@@ -23,6 +23,11 @@ class Both:
     def __init__(self, gpu, cpu):
         self.gpu, self.cpu = gpu, cpu
 
+    @property
+    def only_levels(self):
+        """every UpdateESDF so far was served by the level engine alone: the strict contract of assert_envelope applies"""
+        return bool(getattr(self.gpu, "only_levels", False))
+
     def params(self, p=P_DEFAULT):
         self.gpu.SetParameters(*p)
         self.cpu.SetParameters(*p)
@@ -465,26 +470,30 @@ def _log_envelope(env, what):
         f.write(json.dumps(rec) + "\n")
 
 
-def assert_envelope(rep, what="", farther_allow=None):
+def assert_envelope(rep, what="", farther_allow=None, strict=False):
     """The contract on partially observed maps (and wherever else the reference's result depends on its queue / list
     order).  The reference's K + 1 runs in shuffled queue order span an interval [min, max] of squared distances per voxel
-    (a single value on the 98-99.9 % of the voxels where they agree).  Measured on the GPU (gpurun_out/r03a/envelope.jsonl,
-    DESIGN.md 3c): on depth-frame maps the engine behaves like one more such run -- it leaves the envelope on 4-90 voxels
-    where the runs disagree on 52-234 and a further run of the reference itself on 3-114.  On adversarial fragmentary
-    observation patterns it leaves it on up to 0.4 % of the finite voxels even where all FIFO runs agree, and then almost
-    always on the NEAR side: the engine's schedule is not a FIFO order (a tile relaxes to quiescence before its neighbours
-    see anything), so obstacles reach voxels they never reach in the reference -- values closer to the exact transform,
-    still fixed points of the reference's operator (pair inequalities, checked by compare_dense), never below the true
-    distance to the nearest occupied voxel.  Hence two one-sided bounds, both tied to the scenario:
-      farther   (above every run of the reference: a distance the reference never over-estimates that much)
-                <= the number of voxels the reference's own runs disagree on;
-      closer    (below every run: nearer to the exact transform than the reference gets)
-                <= max(that number, 0.5 % of the finite voxels).
-    A scenario on which the reference is order-independent and the observation pattern benign demands equality."""
+    (a single value on the 98-99.9 % of the voxels where they agree).
+
+    strict (every UpdateESDF so far ran the LEVEL engine, level_kernels.hpp -- the reference's FIFO layers as levels):
+      the engine may leave the envelope, on either side, on at most as many voxels as the reference's own runs disagree on.
+      No constant.  Measured (tests/test_levelsync_model.py, profiles/r04*_envelope*.jsonl): on depth-frame maps it leaves
+      it on FEWER voxels than one more run of the reference itself does (leave-one-out); "zero voxels where the sampled
+      runs agree" is not a property any order has -- a further run of the verbatim reference fails it too (3-31 voxels on
+      the same frames).
+
+    not strict (the frontier-ROUND engine took part: forced, or a frontier outgrew the level engine and was handed over):
+      that engine's schedule is not a FIFO order (a tile relaxes to quiescence before its neighbours see anything), so
+      obstacles reach voxels they never reach in the reference -- values closer to the exact transform, still fixed points
+      of the reference's operator (pair inequalities, checked by compare_dense), never below the true distance to the
+      nearest occupied voxel.  Its documented allowance:
+        farther   <= the number of voxels the reference's own runs disagree on;
+        closer    <= max(that number, 0.5 % of the finite voxels)."""
     env = rep.get("envelope", rep)
-    _log_envelope(env, what)
+    _log_envelope(dict(env, strict=bool(strict)), what)
     far_ok = env["disagree"] if farther_allow is None else farther_allow
     assert env["farther"] <= far_ok, \
         f"{what}: {env['farther']} voxels farther than every run of the reference (its own runs disagree on {env['disagree']}): {env}"
-    assert env["closer"] <= max(env["disagree"], 0.005 * env.get("finite", 0)), \
-        f"{what}: {env['closer']} voxels closer than every run of the reference (its own runs disagree on {env['disagree']}): {env}"
+    near_ok = env["disagree"] if strict else max(env["disagree"], 0.005 * env.get("finite", 0))
+    assert env["closer"] <= near_ok, \
+        f"{what}: {env['closer']} voxels closer than every run of the reference (its own runs disagree on {env['disagree']}; strict={strict}): {env}"

@@ -127,20 +127,20 @@ def test_partial_observation_frontier_semantics(hip_lib, oracle_libs, best_oracl
     b.make_occupied(S)
     b.esdf()
     rep = compare_dense(b.gpu, b.cpu)
-    assert_envelope(rep, "inserts into a partially observed map")
+    assert_envelope(rep, "inserts into a partially observed map", strict=b.only_levels)
     assert rep["pair_violations"] == 0, rep
     # now observe the rest: freshly observed free voxels must stay at "infinity" until a wave passes
     b.observe(g[~keep], 0)
     b.fuse()
     b.esdf()
     rep2 = compare_dense(b.gpu, b.cpu)
-    assert_envelope(rep2, "late observation")
+    assert_envelope(rep2, "late observation", strict=b.only_levels)
     assert rep2["pair_violations"] == 0, rep2
     # a new insert sends a wave through
     b.make_occupied(rng.randint(0, n, (50, 3)).astype(np.int32))
     b.esdf()
     rep3 = compare_dense(b.gpu, b.cpu)
-    assert_envelope(rep3, "wave through late observations")
+    assert_envelope(rep3, "wave through late observations", strict=b.only_levels)
     assert rep3["pair_violations"] == 0, rep3
 
 
@@ -192,7 +192,7 @@ def test_occupancy_fusion_logodds_and_positions(hip_lib, oracle_libs, best_oracl
         # sparse random observation is the regime where the reference itself is order-dependent: re-running
         # the reference with the same observations shuffled changes up to 15 of ~5000 finite distances
         # ("parity contract") -> judged against the envelope of those runs.
-        assert_envelope(rep, f"cycle {cycle}")
+        assert_envelope(rep, f"cycle {cycle}", strict=b.only_levels)
         assert rep["pair_violations"] == 0, rep
 
 
@@ -296,16 +296,23 @@ def test_local_sliding_window_mode(hip_lib, oracle_libs, best_oracle_kind):
         # inside the window: the contract of every partially observed map (the far side against the spread of the whole
         # field: what the window newly covers was frozen outside it a step ago)
         spread = rep_in["disagree"] + rep_out["disagree"]
-        assert_envelope(rep_in, f"window step {step}, inside the window", farther_allow=spread)
+        assert_envelope(rep_in, f"window step {step}, inside the window", farther_allow=spread, strict=b.only_levels)
         # Outside the window the reference's field is FROZEN mid-update: an orphan of a delete out there is re-seeded from its
-        # first in-window neighbour, pulls once or twice while its neighbours are still settling, and is never touched again
-        # (:300-321, 345-366, 378) -- the value it keeps is whatever that moment offered.  The engine lets such a voxel pull
-        # from the RELAXED window (k_reseed_outside): never farther than the reference got (beyond its own spread), often
-        # closer -- nearer to the exact transform, never below it (checked above).  Only the far side is bounded here.
-        _log = dict(rep_out)
-        _log["closer"] = 0
-        assert_envelope(_log, f"window step {step}, outside the window (far side)", farther_allow=spread)
-        assert rep_out["closer"] <= 0.02 * rep_out["finite"], rep_out
+        # first in-window neighbour that is valid at that moment of the list walk, pulls once or twice while its neighbours are
+        # still settling, and is never touched again (:300-321, 345-366, 378) -- the value it keeps is whatever that moment
+        # offered, and which orphans get a value at all depends on the order of the dead obstacle's list.
+        if b.only_levels:
+            # the level engine models that rule (level_kernels.hpp: k_level_outside): the same contract as inside, both sides
+            assert_envelope(rep_out, f"window step {step}, outside the window", farther_allow=spread, strict=True)
+            assert rep_out["closer"] <= spread, rep_out
+        else:
+            # the frontier rounds let such a voxel pull from the RELAXED window afterwards (k_reseed_outside): never farther
+            # than the reference got (beyond its own spread), often closer -- nearer to the exact transform, never below it
+            # (checked above).  Only the far side is bounded for that engine.
+            _log = dict(rep_out)
+            _log["closer"] = 0
+            assert_envelope(_log, f"window step {step}, outside the window (far side)", farther_allow=spread)
+            assert rep_out["closer"] <= 0.02 * rep_out["finite"], rep_out
 
 
 def test_window_then_delete_with_dependents_outside_the_window(hip_lib, oracle_libs, best_oracle_kind):
@@ -332,7 +339,7 @@ def test_window_then_delete_with_dependents_outside_the_window(hip_lib, oracle_l
     sg, sc = b.esdf()
     assert sg["deleted"] == sc["deleted"] > 0
     rep = compare_dense(b.gpu, b.cpu)
-    assert_envelope(rep, "delete with orphans outside the window")
+    assert_envelope(rep, "delete with orphans outside the window", strict=b.only_levels)
     # the window moves over the former outside; a second delete and an insert there
     for m in (b.gpu, b.cpu):
         m.SetUpdateRange((1.0, 0.0, 0.0), (n * res, n * res, n * res))
@@ -341,7 +348,7 @@ def test_window_then_delete_with_dependents_outside_the_window(hip_lib, oracle_l
     sg, sc = b.esdf()
     assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
     rep = compare_dense(b.gpu, b.cpu)
-    assert_envelope(rep, "window moved over the former outside")
+    assert_envelope(rep, "window moved over the former outside", strict=b.only_levels)
 
 
 def test_visualisation_exports(hip_lib, oracle_libs, best_oracle_kind):

@@ -98,7 +98,7 @@ def test_random_sequences_partially_observed(hip_lib, oracle_libs, best_oracle_k
             b.fuse()
         b.esdf()
         rep = compare_dense(b.gpu, b.cpu)
-        assert_envelope(rep, f"step {step}")
+        assert_envelope(rep, f"step {step}", strict=b.only_levels)
         assert rep["pair_violations"] == 0, rep
 
 
@@ -137,6 +137,12 @@ def test_random_sequences_hash_map(hip_lib, oracle_libs, best_oracle_kind, seed)
         sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
         assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
         rep = compare_hash(gpu, cpu)
+        # (not strict, whatever the engine: on seed 63, step 4 -- 4 % observed, propagation through channels a voxel wide -- the
+        #  level engine, its CPU model (tests/test_levelsync_model.py: test_hash_fuzz_seed_63_is_a_property_of_the_schedule) and
+        #  the frontier rounds all end 44 voxels CLOSER than seven shuffled runs of the reference that agree with each other,
+        #  by 1-11 in d^2 at distances of 7-14 voxels, both sides above the exact distance: pulls that see the field as the level found it carry another
+        #  obstacle through the channel than pulls that see their predecessors' writes; 0.4 % of the finite voxels, one state
+        #  in 150 of this suite)
         assert_envelope(rep, f"step {step}")
         live = np.concatenate([live, new])
         q = (rng.uniform(-25, 25, (150, 3)) + centre) * res + np.array(origin)

@@ -133,7 +133,7 @@ def test_hash_streaming_window_positions(hip_lib, oracle_libs, best_oracle_kind)
         rep = compare(gpu, cpu)
         # the union of boxes is only partially observed at its rim: the reference's order dependence applies -> judged
         # against the envelope of its own shuffled runs
-        assert_envelope(rep, f"frame {frame}")
+        assert_envelope(rep, f"frame {frame}", strict=gpu.only_levels)
     assert rep["pages"] >= 2
 
 
@@ -177,7 +177,7 @@ def test_hash_wave_reaches_unallocated_space(hip_lib, oracle_libs, best_oracle_k
     cycles(gpu, cpu, np.array([[20, 3, 5]], np.int32), [], 3)
     rep = compare(gpu, cpu)
     assert rep["pages"] == 2, rep
-    assert_envelope(rep, "freshly observed free space next to a field")  # (the order-dependent regime)
+    assert_envelope(rep, "freshly observed free space next to a field", strict=gpu.only_levels)  # (the order-dependent regime)
 
 
 def test_hash_c4_stream_box_observe(hip_lib, oracle_libs, best_oracle_kind):
@@ -209,7 +209,7 @@ def test_hash_c4_stream_box_observe(hip_lib, oracle_libs, best_oracle_kind):
     rep = compare(gpu, cpu)
     # frames 0..2 only observe (3 hits make an obstacle): frame 3 inserts the whole visible surface at once
     assert rep["finite"] > 500000
-    assert_envelope(rep, "C4 frame 3")
+    assert_envelope(rep, "C4 frame 3", strict=gpu.only_levels)
 
 
 def test_hash_visualisation_getters(hip_lib, oracle_libs, best_oracle_kind):

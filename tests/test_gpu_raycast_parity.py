@@ -97,7 +97,7 @@ def test_frames_counts_exact_with_reference_dedup(hip_lib, oracle_libs, best_ora
         rep = compare_dense(gpu, cpu)
         # partially observed map: the reference itself is order-dependent here -> judged against the
         # envelope of its own shuffled runs on these very frames
-        assert_envelope(rep, f"frame {f}")
+        assert_envelope(rep, f"frame {f}", strict=gpu.only_levels)
         assert rep["pair_violations"] == 0, rep
     assert touched_total > 30000
     assert gpu.download_field(("occ",))["occ"].sum() > 500
@@ -218,7 +218,7 @@ def test_hash_map_frames_counts_exact(hip_lib, oracle_libs, best_oracle_kind, si
         sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
         assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
         rep = compare_hash(gpu, cpu)
-        assert_envelope(rep, f"frame {f}")
+        assert_envelope(rep, f"frame {f}", strict=gpu.only_levels)
     assert touched_total > 30000 and rep["pages"] >= 8
     assert gpu.hash_window()[1] == (1 if site.any() else 0) and sg["dropped_observations"] == 0
 
@@ -356,7 +356,7 @@ def test_signed_variant_inverse_map(hip_lib, oracle_libs, best_oracle_kind, mode
     # shuffled runs (a partially observed map)
     if mode == "array":
         rep = compare_dense(gi, ci)
-        assert_envelope(rep, "inverse map")
+        assert_envelope(rep, "inverse map", strict=gi.only_levels)
         assert rep["pair_violations"] == 0, rep
         occ_main, occ_inv = g.download_field(("occ",))["occ"], gi.download_field(("occ",))["occ"]
         assert occ_inv.sum() > occ_main.sum() > 0     # (a grazed voxel can be occupied in both: hit by some rays, crossed by others)

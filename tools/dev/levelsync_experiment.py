@@ -17,7 +17,7 @@ from oracle import pyoracle  # noqa: E402
 from scenarios import (P_DEFAULT, EnvelopeOracle, all_voxels, d2_from_dist, depth_to_points, render_depth,  # noqa: E402
                        yaw_pose)
 
-SCHED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+SCHED = 1  # (argv[1] is kept for old command lines: the experimental schedules are gone, 1 = the level engine's model)
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 KIND = "ref" if pyoracle.available("ref") else "port"
 
