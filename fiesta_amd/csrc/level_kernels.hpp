@@ -244,9 +244,13 @@ struct LvDirs {
   template <class S>
   __device__ inline void init(const S &sp) {
     q = (int)(threadIdx.x & 3u);
+    // (selects between compile-time constants: a table in memory would put a chain of loads in front of every launch)
+    constexpr signed char X[24] = {FIESTA_STENCIL24(FIESTA_LV_DX)}, Y[24] = {FIESTA_STENCIL24(FIESTA_LV_DY)}, Z[24] = {FIESTA_STENCIL24(FIESTA_LV_DZ)};
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      dx[j] = kLvDx[6 * q + j], dy[j] = kLvDy[6 * q + j], dz[j] = kLvDz[6 * q + j];
+      dx[j] = q == 0 ? X[j] : q == 1 ? X[6 + j] : q == 2 ? X[12 + j] : X[18 + j];
+      dy[j] = q == 0 ? Y[j] : q == 1 ? Y[6 + j] : q == 2 ? Y[12 + j] : Y[18 + j];
+      dz[j] = q == 0 ? Z[j] : q == 1 ? Z[6 + j] : q == 2 ? Z[12 + j] : Z[18 + j];
       e2[j] = dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j];
       off[j] = sp.doff(dx[j], dy[j], dz[j]);
     }
@@ -496,13 +500,16 @@ __global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
     *a.ctl_other = LevelCtl{};
     a.counters[C_INSERT] = 0, a.counters[C_DELETE] = 0;  // both queues are drained (the seeds ran before this launch)
   }
-  uint32_t level = ctl->level;
+  // (the host names the level this launch starts at: the counters and the list are then requested together, one memory
+  //  latency in front of the first level instead of three)
+  uint32_t level = a.level;
+  const uint32_t first = (uint32_t)tid < (uint32_t)CAP ? a.list[level & 1u][tid] : 0u;  // (a list holds far more than CAP entries)
   uint32_t n = ctl->n[level % 3u], nwait = ctl->nwait[level % 3u], work = 0;
   bool fits = ctl->overflow == 0;
   if (tid == 0) s_wrote = 0, s_maxd2 = 0;
   bool in_lds = n <= (uint32_t)CAP;  // the current frontier is (also) in s_list
-  if (in_lds)
-    for (uint32_t i = tid; i < n; i += NT) s_list[level & 1u][i] = a.list[level & 1u][i];
+  static_assert(CAP <= NT, "one entry per thread loads the list");
+  if (in_lds && (uint32_t)tid < n) s_list[level & 1u][tid] = first;
   __syncthreads();
   uint32_t wrote = 0, maxd2 = 0;
   // (an update is over after at most a few thousand levels -- the longest chain of voxels the grid holds; the bound on the
@@ -782,6 +789,7 @@ struct LevelEngine {
   // `done` is recorded behind the last kernel of every chain: when run() returns it marks the end of the levels' device work.
   template <class S>
   Outcome run(const S &sp, LevelArgs a, hipStream_t s, hipEvent_t done, bool wide, int64_t *launches) {
+    a.level = 0;
     for (;;) {
       hipLaunchKernelGGL((k_level_run<S, kNT, (int)kSingleCap>), dim3(1), dim3(kNT), 0, s, sp, a);
       FIESTA_HIP_CHECK(hipGetLastError());
@@ -793,6 +801,7 @@ struct LevelEngine {
         if (h_ctl->overflow) return kOverflow;
         const uint32_t l = h_ctl->level, n = h_ctl->n[l % 3u];
         if (n == 0 || n == h_ctl->nwait[l % 3u]) return kDone;
+        a.level = l;
         if (n <= a.single_cap) break;  // small again: back to the one work-group
         if (!wide) return kHandOver;
         // a chain of wide levels; work-groups in proportion to the frontier this chain starts with
