@@ -110,8 +110,14 @@ inline void checkpoint_header(DevFile &f, uint32_t mode, const Geom &g) {
   for (int k = 0; k < 3; ++k) mine.org[k] = g.org[k];
   memcpy(&h, &mine, sizeof(h));
   f.host(&h, sizeof(h));
-  if (!f.writing() && memcmp(&h, &mine, sizeof(h)) != 0)
-    throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: file was written by a map of another mode, geometry or format version");
+  if (!f.writing() && memcmp(&h, &mine, sizeof(h)) != 0) {  // say WHICH part differs
+    if (memcmp(h.magic, mine.magic, 8) != 0) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: not a fiesta_hip checkpoint (bad magic)");
+    if (h.version != mine.version)
+      throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: format version " + std::to_string(h.version) + ", this library reads version " +
+                                              std::to_string(mine.version) + " only (older files cannot be migrated: re-save them with the library that wrote them)");
+    if (h.mode != mine.mode) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: written by a map of the other mode (array / hash)");
+    throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: written by a map of another geometry (grid, shard box, resolution or origin)");
+  }
 }
 
 }  // namespace fiesta

@@ -845,6 +845,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   FIESTA_HIP_CHECK(hipMemsetAsync(tile_epoch_, 0, ntiles_ * sizeof(uint32_t), stream_));
   set_original_range();
   pp_ = ProbParams{0, 0, 0, 0, 0};
+#ifdef FIESTA_HIP_TUNING  // a developer's build (tools/dev): the shipped library reads no environment
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_SPATIAL")) spatial_ = atoi(e);
   if (const char *e = getenv("FIESTA_HIP_LIST_THRESHOLD")) list_threshold_ = std::max(0, atoi(e));
@@ -853,6 +854,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   if (const char *e = getenv("FIESTA_HIP_BLOCKS")) spatial_blocks_ = std::max(8, atoi(e) / 8 * 8);
   if (const char *e = getenv("FIESTA_HIP_BULK_RATIO")) bulk_ratio_ = atof(e);
   if (const char *e = getenv("FIESTA_HIP_FT_S0")) ft_s0_ = atoi(e);
+#endif
   if (ft_s0_ != 16 && ft_s0_ != 32) throw Error(FIESTA_HIP_ERR_INVALID, "FIESTA_HIP_FT_S0 must be 16 or 32");
   for (auto &e : ft_ev_) FIESTA_HIP_CHECK(hipEventCreate(&e));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1263,13 +1265,14 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   ft_spill_.ensure_exact((size_t)spill_blocks * 4 * (spill_stride / sizeof(unsigned long long)), stream_);
   a.rowlist = ft_rowlist_.p;
   a.rowcnt = ft_rowcnt_.p;
-  a.planemask = reinterpret_cast<uint32_t *>(ft_rowcnt_.p + a.nx);
   a.inter = ft_inter_.p;
   // a shard's transform lands in a side buffer first: it only replaces the field once every shard has confirmed that
   // its margin sufficed (bulk_commit); if not, the frontier rounds take over from the untouched field
   // ... unless the margin test cannot fail: a region that reaches the global boundary on every side (a single shard, or
   // margins grown to the whole grid) holds every obstacle there is -- the result is final and goes in place
-  ft_in_place_ = !g.sharded || !open_side;
+  // -- and only in a group of ONE: with several shards the commit waits for every shard's verdict, and an error on another
+  // shard between try and commit (an allocation failing there) must find this shard's field untouched
+  ft_in_place_ = !g.sharded || (!open_side && alone_in_group_);
   if (!ft_in_place_) ft_out_.ensure((size_t)g.n, stream_);
   a.coc = ft_in_place_ ? coc_ : ft_out_.p;
   const bool want_max = track_ || open_side;
@@ -1345,6 +1348,9 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 // The map-local half of the engine choice: may this update be served by the bulk transform at all?
 bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
   const Geom &g = g_;
+  // (a map that held no obstacle before this update has no history left, whatever the checks below say -- ADVICE r3: the
+  //  flag must not outlive an emptied map just because an early return skipped the line that clears it)
+  if (win_dirty_ && !g.sharded && (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd <= 0) win_dirty_ = false;
   if (update_engine_ == 1 || update_engine_ == 3) return false;
   if (!(g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1)) return false;
   const long long owned = (long long)(g.ox1 - g.ox0 + 1) * (g.oy1 - g.oy0 + 1) * (g.oz1 - g.oz0 + 1);
@@ -1376,12 +1382,14 @@ bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
 // delta x (voxels per obstacle) of them.  In voxel units: bulk pays iff  n <= 1.3e8 + 50 x (estimated updated voxels) --
 // on every grid up to 512^3 that is always (measured: 0.80 vs 0.93 ms at a delta of 100), on a 1024^3 shard from a delta of
 // ~2 % of the obstacles.  FIESTA_HIP_BULK_RATIO (a fraction of the occupied voxels) overrides the model.
-bool DenseMap::bulk_pays(double delta, double nocc, double n) const {
-  if (bulk_ratio_ >= 0) return delta >= bulk_ratio_ * std::max(nocc, 1.0);
+bool DenseMap::bulk_pays(double delta, double nocc, double n) const { return bulk_pays_model(delta, nocc, n, ft_last_ms_, bulk_ratio_); }
+// (static: the sharded driver decides from numbers every rank has seen -- the gathered maxima -- never from one rank's own)
+bool DenseMap::bulk_pays_model(double delta, double nocc, double n, double ft_last_ms, double bulk_ratio) {
+  if (bulk_ratio >= 0) return delta >= bulk_ratio * std::max(nocc, 1.0);
   const double updated = std::min(n, delta * n / std::max(nocc, 1.0));
   // a scene of deep deques (surfaces: the transform takes twice the sweep's nominal time) and a handful of voxels: the
   // rounds win by a few percent (measured: 1.38 vs 1.53 ms at a delta of 100, 2.1 vs 1.5 ms at 500)
-  if (delta <= 128 && ft_last_ms_ > 1.25 * n * 6e-9) return false;
+  if (delta <= 128 && ft_last_ms > 1.25 * n * 6e-9) return false;
   return n <= 1.3e8 + 50.0 * updated;
 }
 

@@ -116,7 +116,11 @@ class DenseMap {
   void bulk_commit(fiesta_hip_stats *st);
   int update_engine() const { return update_engine_; }
   void set_update_engine(int e) { update_engine_ = e; }
+  void set_alone_in_group(bool alone) { alone_in_group_ = alone; }
   bool bulk_pays(double delta, double nocc, double n) const;  // is the fixed sweep cheaper than the frontier rounds?
+  static bool bulk_pays_model(double delta, double nocc, double n, double ft_last_ms, double bulk_ratio);
+  double ft_last_ms() const { return ft_last_ms_; }
+  double bulk_ratio() const { return bulk_ratio_; }
   // continue relaxing tiles that are already flagged (after ghost entries were applied)
   void relax_pending(fiesta_hip_stats *st, int64_t *pending);
 
@@ -224,7 +228,7 @@ class DenseMap {
   int update_engine_ = 0;
   LevelEngine *lv_ = nullptr;   // the level engine's lists and control block (level_kernels.hpp), created on first use
   hipEvent_t lv_done_ = nullptr;
-  double bulk_ratio_ = -1;  // >= 0 (FIESTA_HIP_BULK_RATIO): bulk when inserts + deletes exceed this fraction of the occupied voxels
+  double bulk_ratio_ = -1;  // >= 0 (a tuning build's FIESTA_HIP_BULK_RATIO): bulk when inserts + deletes exceed this fraction of the occupied voxels
   // Late observations: a voxel first observed while obstacles exist stays at "no obstacle" until a wave reaches it
   // (the reference never queues it), so the field is no longer the transform of the occupied set and the bulk path is
   // off until a scan finds no such voxel left (k_count_stale) or the map holds no obstacle.
@@ -234,6 +238,7 @@ class DenseMap {
   static constexpr int kFtBlocks = 1024;  // work-groups of a pass (4 waves each): what 256 CUs hold at once with 16-entry rings
   double ft_last_ms_ = 0;      // kernel time of the last bulk update (the engine choice's idea of this scene's sweep)
   bool ft_in_place_ = true;   // the last transform wrote the field itself (no side buffer: its result could not be inexact)
+  bool alone_in_group_ = true;  // a shard: the only one of its group (ShardGroup tells)
   bool ft_counters_clean_ = false;  // reset_stats_counters() ran and no transform has used the spill counters since
   DevBuf<uint32_t> ft_inter_, ft_out_;
   DevBuf<unsigned long long> ft_spill_;  // backing store of the transform's rings (run_bulk)

@@ -34,7 +34,6 @@ struct FtArgs {
   int sx0, sy0, sw0, sny, snzw;
   uint16_t *rowlist;         // [nx][ny]: non-empty rows of plane x, ascending
   int32_t *rowcnt;           // [nx]
-  uint32_t *planemask;       // unused (r02: a bit mask built with atomics, zeroed by a memset per update); pass B reads rowcnt
   uint32_t *inter;           // [nx][ny][nz]: pass A result, y' << 10 | z' (WIDE: << 11), region coordinates
   vox_t *coc;                // output array (the map's voxel words) with extents (., ony, onz); region voxel (x,y,z) is
   int ox0, oy0, oz0;         // output voxel (x - ox0, y - oy0, z - oz0), written iff inside [0,onx) x [0,ony) x [0,onz)

@@ -541,7 +541,9 @@ HashMap::HashMap(const fiesta_hip_config &cfg) {
   g.gx0 = g.gy0 = g.gz0 = -kHalf;  // the window starts centred on map voxel 0 and follows the observations (ensure_window)
   g.wrap = 1;                      // ids are map coordinates modulo 1024, decoded relative to their voxel
   set_original_range();
+#ifdef FIESTA_HIP_TUNING
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
+#endif
   if (cfg.update_engine < 0 || cfg.update_engine > 3) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
   update_engine_ = cfg.update_engine;
 

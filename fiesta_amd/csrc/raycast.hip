@@ -660,6 +660,10 @@ static void ray_cast_rounds(RayState &rc, const RayArgs &ra, int64_t n, int stri
                        // only on rays before it; a valid frame never fails here, however long its dependency chains)
     while (!done) {
       const int64_t first = iters + 1;
+      // (a frame starts with at least kMaxRounds + 16 free tags, ray_stamps; one whose dependency chains need more rounds
+      //  than tags are left must fail loudly: a wrapped tag would collide with older stamps -- ADVICE r3)
+      if (rc.tag <= (uint32_t)batch)
+        throw Error(FIESTA_HIP_ERR_STATE, "raycast de-dup: the frame's dependency chains exhausted the stamp tags (split the cloud into smaller frames)");
       for (int b = 0; b < batch; ++b) {
         const uint32_t tag_next = rc.tag--;
         ++iters;

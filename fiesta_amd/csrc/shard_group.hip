@@ -242,6 +242,7 @@ ShardGroup::ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<in
     }
     L->counts.ensure(kMaxLinks + 2, s);
     FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+    L->map->set_alone_in_group(world_ == 1);
     L->map->bulk_reserve(margin_);  // (the transform's scratch: not inside the first update)
     locals_.push_back(std::move(L));
   }
@@ -360,19 +361,27 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
       locals_[i]->map->bulk_probe(&ni, &nd, &nocc, &el);
       rows[i][0] = el ? 1 : 0, rows[i][1] = (long long)ni, rows[i][2] = (long long)nd, rows[i][3] = nocc;
       rows[i][4] = locals_[i]->map->update_engine();
+      // what the cost model needs, as numbers every rank will see (the decision used to read rank-local state --
+      // the last transform's time, this shard's voxel count -- and two ranks could enter different collectives)
+      rows[i][5] = (long long)locals_[i]->map->total();
+      rows[i][6] = (long long)std::llround(locals_[i]->map->ft_last_ms() * 1e6);   // ns
+      rows[i][7] = locals_[i]->map->bulk_ratio() >= 0 ? (long long)std::llround(locals_[i]->map->bulk_ratio() * 1e9) : -1;
     }
     gather_rows(rows);
     bool all = true, force = true;
-    long long ni = 0, nd = 0, nocc = 0;
+    long long ni = 0, nd = 0, nocc = 0, n_max = 0, ft_ns_max = 0, ratio = -1;
     for (int r = 0; r < world_; ++r) {
       const long long *t = &h_table_[(size_t)r * kRow];
       all = all && t[0] != 0;
       force = force && t[4] == 2;
       ni += t[1], nd += t[2], nocc += t[3];
+      n_max = std::max(n_max, t[5]), ft_ns_max = std::max(ft_ns_max, t[6]), ratio = std::max(ratio, t[7]);
     }
-    // (the cost model per shard: its share of the delta and of the obstacles against its own array)
+    // (the cost model per shard: its share of the delta and of the obstacles against the LARGEST shard's array and the
+    //  SLOWEST shard's last transform -- all from the gathered table, so every rank computes the same answer)
     const bool want = all && (ni + nd) > 0 &&
-                      (force || locals_[0]->map->bulk_pays((double)(ni + nd) / world_, (double)nocc / world_, (double)locals_[0]->map->total()));
+                      (force || DenseMap::bulk_pays_model((double)(ni + nd) / world_, (double)nocc / world_, (double)n_max,
+                                                          (double)ft_ns_max * 1e-6, ratio >= 0 ? (double)ratio * 1e-9 : -1.0));
     for (int m = margin_; want; m *= 2) {
       std::vector<fiesta_hip_stats> ss(locals_.size());
       for (size_t i = 0; i < locals_.size(); ++i) {
