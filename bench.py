@@ -255,6 +255,8 @@ def esdf_summary(stats):
         out["level_kernel_us"] = float(statistics.median([st["prof"][0] for st in lv])) / 1e3
         out["frontier_entries"] = float(statistics.median([st["prof"][6] for st in lv]))
         out["frontier_peak"] = float(statistics.median([st["prof"][7] for st in lv]))
+        # thread 0's view of the one-work-group kernel: fetch + pull, barrier, push, append + barriers (us per update)
+        out["level_phases_us"] = [float(statistics.median([st["prof"][k] for st in lv])) / 1e3 for k in (2, 3, 4, 5)]
     return out
 
 
@@ -290,7 +292,7 @@ def run_c3(args):
         T = yaw_pose(2.0 * f, (0.0, 0.0, 0.0))
         frames.append((T, render_depth(T, rows=480, cols=640, spheres=spheres, intr=intr)))
     lc, rc = origin, tuple(np.add(origin, size))
-    t_ray, t_fuse, t_esdf, t_all, cpu_t, esdf_stats, updated, parity = [], [], [], [], [], [], [], None
+    t_ray, t_fuse, t_esdf, t_all, cpu_t, esdf_stats, updated, parity, traces = [], [], [], [], [], [], [], None, []
     for f, (T, depth) in enumerate(frames):
         checked = cpu is not None and f < cpu_frames
         t0 = time.perf_counter()
@@ -308,6 +310,7 @@ def run_c3(args):
         t1b = time.perf_counter()
         m.UpdateOccupancy(True)
         m.synchronize()
+        t2a = time.perf_counter()
         if not checked:
             m.snapshot_save(0)       # (the benchmark's unit: voxels whose (d^2, obstacle) changes -- outside the timers)
             m.synchronize()
@@ -316,6 +319,8 @@ def run_c3(args):
         t3 = time.perf_counter()
         if not checked and f >= args.warmup:
             updated.append(m.snapshot_count_updated(0))
+            if st.get("levels"):
+                traces.append(m.level_trace()[0])
         if checked:
             c2 = time.perf_counter()
             cpu.UpdateOccupancy(True)
@@ -336,9 +341,9 @@ def run_c3(args):
                                   "(test_config3_640x480_frames_reference_intrinsics) and profiles/r04*_envelope_reports.jsonl"}
         if f >= args.warmup and not checked:
             t_ray.append((t1 - t0) * 1e3)
-            t_fuse.append((t2 - t1b) * 1e3)
+            t_fuse.append((t2a - t1b) * 1e3)
             t_esdf.append((t3 - t2) * 1e3)
-            t_all.append((t1 - t0 + t3 - t1b) * 1e3)
+            t_all.append((t1 - t0 + t2a - t1b + t3 - t2) * 1e3)
             esdf_stats.append(st)
     p50 = statistics.median
     out = {
@@ -351,6 +356,8 @@ def run_c3(args):
         "update_occupancy_p50_ms": p50(t_fuse), "update_esdf_p50_ms": p50(t_esdf),
         "update_esdf": esdf_summary(esdf_stats),
         "updated_voxels_per_frame": (sum(updated) / len(updated)) if updated else None,
+        # one frame's update level by level: (frontier entries, us inside the kernel) -- the frame with the median level count
+        "level_trace_of_a_median_frame": sorted(traces, key=len)[len(traces) // 2] if traces else None,
         # UpdateESDF of a sensor frame: a few thousand voxels change -- latency-bound by construction (levels x memory round
         # trips), reported against the same roofline as the headline for completeness
         "roofline": {"bound": "hbm", "kernel": "k_level_run (level engine, one work-group)" if esdf_stats and all(st_.get("levels") for st_ in esdf_stats) else "k_relax_q",

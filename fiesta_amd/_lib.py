@@ -126,6 +126,7 @@ def load():
         "fiesta_hip_set_update_range": (C.c_int, [vp, vp, vp, C.c_int]),
         "fiesta_hip_set_original_range": (C.c_int, [vp]),
         "fiesta_hip_set_update_engine": (C.c_int, [vp, C.c_int32]),
+        "fiesta_hip_level_trace": (C.c_int, [vp, vp, vp]),
         "fiesta_hip_count_no_obstacle": (C.c_int, [vp, vp]),
         "fiesta_hip_set_occupancy_vox": (C.c_int, [vp, vp, vp, i64, vp]),
         "fiesta_hip_set_occupancy_pos": (C.c_int, [vp, vp, vp, i64, vp]),

@@ -191,6 +191,13 @@ int fiesta_hip_set_update_engine(fiesta_hip_map *m, int32_t engine) {
   });
 }
 
+int fiesta_hip_level_trace(fiesta_hip_map *m, uint32_t out[48], int32_t *n_levels) {
+  return guarded([&] {
+    need(m && out && n_levels, "bad argument");
+    *n_levels = m->dense ? m->dense->level_trace(out) : m->hash->level_trace(out);
+  });
+}
+
 int fiesta_hip_set_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret) {
   return guarded([&] {
     need(m && (n == 0 || (vox && occ)) && n >= 0, "bad argument");

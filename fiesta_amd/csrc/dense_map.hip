@@ -1448,6 +1448,13 @@ void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long l
   *eligible = bulk_eligible(*ni, *nd);
 }
 
+int DenseMap::level_trace(uint32_t *out48) const {
+  memset(out48, 0, 48 * sizeof(uint32_t));
+  if (!lv_ || !lv_->h_ctl) return 0;
+  memcpy(out48, lv_->h_ctl->trace, 48 * sizeof(uint32_t));
+  return (int)lv_->h_ctl->level;
+}
+
 // UpdateESDF by the level engine (level_kernels.hpp).  Seeds: the insert queue, and the orphans the delete scan finds.
 // Returns false if the update did not fit the engine's lists: the field then carries frontier tags and the list of active
 // tiles is set up for the frontier rounds, which the caller runs.

@@ -1078,6 +1078,13 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
   }
 }
 
+int HashMap::level_trace(uint32_t *out48) const {
+  memset(out48, 0, 48 * sizeof(uint32_t));
+  if (!lv_ || !lv_->h_ctl) return 0;
+  memcpy(out48, lv_->h_ctl->trace, 48 * sizeof(uint32_t));
+  return (int)lv_->h_ctl->level;
+}
+
 // UpdateESDF by the level engine (level_kernels.hpp; as DenseMap::run_levels).  false: the update did not fit its lists,
 // the field carries frontier tags and the tile list is set up for the frontier rounds.
 bool HashMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd, bool scan) {

@@ -63,6 +63,7 @@ class HashMap {
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
   void update_esdf(fiesta_hip_stats *st);
   void set_update_engine(int e) { update_engine_ = e; }
+  int level_trace(uint32_t *out48) const;  // fiesta_hip_level_trace
   void get_distance_vox(const int32_t *vox, int64_t n, double *out);
   void get_distance_pos(const double *pos, int64_t n, double *out);
   void get_dist_grad(const double *pos, int64_t n, double *dist, double *grad);

@@ -55,6 +55,7 @@ struct LevelCtl {
   uint32_t phase[4];  // of that, thread 0's view: fetch + pull, barrier, push, append + barriers
   uint32_t items;     // frontier entries processed, summed over the levels (statistics)
   uint32_t peak;      // the largest frontier
+  uint32_t trace[48]; // the first levels of k_level_run: entries << 16 | duration in 10 ns units (statistics)
 };
 
 struct LevelArgs {
@@ -154,11 +155,17 @@ struct PagedSpace {
   }
   __device__ inline bool valid(int x, int y, int z) const { return box.has(x, y, z); }
   __device__ inline int32_t doff(int, int, int) const { return 0; }
-  __device__ inline int32_t page_self(bool live, int x, int y, int z) const { return live ? dir[((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5)] : -1; }
+  __device__ inline int32_t page_self(bool live, int x, int y, int z) const {
+    const int32_t p = dir[live ? ((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5) : 0];  // (the load is unconditional: no branch)
+    return live ? p : -1;
+  }
   __device__ inline uint32_t addr_self(int32_t p, int x, int y, int z) const {
     return (uint32_t)p * (uint32_t)kPageVox + (uint32_t)(((x & 15) * 16 + (y & 15)) * 32 + (z & 31));
   }
-  __device__ inline int32_t page(bool ok, int x, int y, int z) const { return ok ? dir[((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5)] : -1; }
+  __device__ inline int32_t page(bool ok, int x, int y, int z) const {
+    const int32_t p = dir[ok ? ((x >> 4) * kNTY + (y >> 4)) * kNTZ + (z >> 5) : 0];
+    return ok ? p : -1;
+  }
   __device__ inline uint32_t addr(int32_t p, uint32_t, int32_t, int x, int y, int z) const { return addr_self(p, x, y, z); }
   __device__ inline bool resident(uint32_t a) const { return page_tile[a / (uint32_t)kPageVox] >= 0; }
   __device__ inline bool occupied(uint32_t a, int, int, int) const { return (occbits[a >> 5] >> (a & 31)) & 1u; }
@@ -221,6 +228,8 @@ template <class S>
 __device__ inline int32_t lv_inf(const S &) {
   return S::kWrap ? kD2Cap : kD2Inf;
 }
+// has_link (common.hpp) without short circuits: an obstacle, or the stale link of a reset voxel
+__device__ inline bool lv_link(vox_t w) { return ((w & kNoCoc) == 0u) | (((w & kAct) == 0u) & ((w & kIdMask) != 0u)); }
 template <class S>
 __device__ inline int32_t lv_have(const S &sp, int x, int y, int z, vox_t w) {
   return (w & kNoCoc) ? lv_inf(sp) : lv_d2(sp, x, y, z, w & kIdMask);
@@ -238,22 +247,20 @@ __device__ const signed char kLvDy[24] = {FIESTA_STENCIL24(FIESTA_LV_DY)};
 __device__ const signed char kLvDz[24] = {FIESTA_STENCIL24(FIESTA_LV_DZ)};
 struct LvDirs {
   int dx[6], dy[6], dz[6];
-  int e2[6];       // |direction|^2
-  int32_t off[6];  // dense arrays: the direction as an address offset
   int q;           // the lane's quarter: directions 6q .. 6q + 5
   template <class S>
   __device__ inline void init(const S &sp) {
     q = (int)(threadIdx.x & 3u);
-    // (selects between compile-time constants: a table in memory would put a chain of loads in front of every launch)
-    constexpr signed char X[24] = {FIESTA_STENCIL24(FIESTA_LV_DX)}, Y[24] = {FIESTA_STENCIL24(FIESTA_LV_DY)}, Z[24] = {FIESTA_STENCIL24(FIESTA_LV_DZ)};
+    // The lane's six directions, each packed as (dx + 2) | (dy + 2) << 4 | (dz + 2) << 8 in a LITERAL: the quarter selects
+    // between four literals per slot (v_cndmask with immediates).  A constexpr table indexed by 6 q + j became a table in
+    // memory behind a tree of branches -- several hundred instructions and a chain of loads in front of every launch.
+#define FIESTA_LV_PICK(A, B, C_, D) (q == 0 ? (A) : q == 1 ? (B) : q == 2 ? (C_) : (D))
+    const int pk[6] = {FIESTA_LV_PICK(545, 529, 561, 544), FIESTA_LV_PICK(547, 563, 531, 548), FIESTA_LV_PICK(530, 274, 786, 514),
+                       FIESTA_LV_PICK(562, 818, 306, 578), FIESTA_LV_PICK(290, 289, 291, 34), FIESTA_LV_PICK(802, 803, 801, 1058)};
+#undef FIESTA_LV_PICK
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      dx[j] = q == 0 ? X[j] : q == 1 ? X[6 + j] : q == 2 ? X[12 + j] : X[18 + j];
-      dy[j] = q == 0 ? Y[j] : q == 1 ? Y[6 + j] : q == 2 ? Y[12 + j] : Y[18 + j];
-      dz[j] = q == 0 ? Z[j] : q == 1 ? Z[6 + j] : q == 2 ? Z[12 + j] : Z[18 + j];
-      e2[j] = dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j];
-      off[j] = sp.doff(dx[j], dy[j], dz[j]);
-    }
+    for (int j = 0; j < 6; ++j) dx[j] = (pk[j] & 15) - 2, dy[j] = ((pk[j] >> 4) & 15) - 2, dz[j] = (pk[j] >> 8) - 2;
+    (void)sp;
   }
 };
 
@@ -266,7 +273,9 @@ struct LvItem {
   vox_t nb[6];      // their words when phase A read them; kUnobserved: no such voxel / outside the window / never observed
 };
 
-// Loads a lane's share of an entry's stencil: the directory entries as one batch, then the words as one batch.
+// Loads a lane's share of an entry's stencil: the directory entries as one batch, then the words as one batch.  No load
+// sits behind a branch (a lane without that neighbour reads word 0 and drops the value): a conditional load costs an
+// exec-mask region of five scalar instructions per direction, and the whole level is a few hundred instructions.
 template <class S, bool COHERENT>
 __device__ inline void lv_fetch(const S &sp, const vox_t *coc, uint32_t e, bool live, const LvDirs &dr, LvItem &it) {
   sp.decode(e, it.x, it.y, it.z);
@@ -275,17 +284,18 @@ __device__ inline void lv_fetch(const S &sp, const vox_t *coc, uint32_t e, bool 
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int ux = it.x + dr.dx[j], uy = it.y + dr.dy[j], uz = it.z + dr.dz[j];
-    pg[j] = sp.page(live && sp.valid(ux, uy, uz), ux, uy, uz);
+    pg[j] = sp.page(live & sp.valid(ux, uy, uz), ux, uy, uz);
   }
   it.self = pself >= 0 ? sp.addr_self(pself, it.x, it.y, it.z) : 0u;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    it.an[j] = pg[j] >= 0 ? sp.addr(pg[j], it.self, dr.off[j], it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j]) : 0u;
-    it.nb[j] = kUnobserved;
-    if (pg[j] >= 0) it.nb[j] = lv_load<COHERENT>(coc + it.an[j]);
+    const uint32_t at = sp.addr(pg[j], it.self, sp.doff(dr.dx[j], dr.dy[j], dr.dz[j]), it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j]);
+    it.an[j] = pg[j] >= 0 ? at : 0u;
+    const vox_t w = lv_load<COHERENT>(coc + it.an[j]);
+    it.nb[j] = pg[j] >= 0 ? w : kUnobserved;
   }
-  it.w = kUnobserved;
-  if (pself >= 0) it.w = lv_load<COHERENT>(coc + it.self);
+  const vox_t w = lv_load<COHERENT>(coc + it.self);
+  it.w = pself >= 0 ? w : kUnobserved;
 }
 
 // ---- phase A for one frontier entry (the four lanes of its quad call this together; all four return the verdict) ---------
@@ -304,13 +314,14 @@ __device__ inline uint32_t lv_pull(const S &sp, vox_t *coc, const LvItem &it, co
   int32_t best = lv_have(sp, it.x, it.y, it.z, w);
   vox_t bid = kNoCoc;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < 6; ++j) {  // (selects, no branches)
     const vox_t wn = it.nb[j];
-    if (has_link(wn)) {  // an obstacle, or the stale link of a voxel the local-map rule reset (:353 tests the id only)
-      const vox_t id = wn & kIdMask;
-      const int32_t d = lv_d2(sp, it.x, it.y, it.z, id);
-      if (d < best) best = d, bid = id;
-    }
+    const vox_t id = wn & kIdMask;
+    const int32_t d = lv_d2(sp, it.x, it.y, it.z, id);
+    // a candidate: an obstacle, or the stale link of a voxel the local-map rule reset (:353 tests the id only)
+    const bool take = lv_link(wn) & (d < best);
+    best = take ? d : best;
+    bid = take ? id : bid;
   }
   // the best of the four quarters; the lower quarter wins a tie (= the first in the reference's direction order)
 #pragma unroll
@@ -366,13 +377,16 @@ __device__ inline uint32_t lv_push(const S &sp, vox_t *coc, uint32_t e, const Lv
   auto settled = [](vox_t w) { return (w & kNoCoc) ? ((w & kAct) ? kInf : w) : (w & ~kAct); };
   const vox_t expect = settled(it.w);
   if (improved) got_self = lv_cas<ONE>(coc + it.self, expect, id | kAct);
-  int32_t dn[6];
+  auto dnb = [&](const int j) {  // the obstacle's squared distance from neighbour j
+    return dv + 2 * (dr.dx[j] * ux + dr.dy[j] * uy + dr.dz[j] * uz) + (dr.dx[j] * dr.dx[j] + dr.dy[j] * dr.dy[j] + dr.dz[j] * dr.dz[j]);
+  };
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     got[j] = 0;
-    dn[j] = dv + 2 * (dr.dx[j] * ux + dr.dy[j] * uy + dr.dz[j] * uz) + dr.e2[j];
-    if (pushes && it.nb[j] != kUnobserved && (!S::kWrap || dn[j] < kD2Cap) &&
-        dn[j] < lv_have(sp, it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j], it.nb[j])) {
+    const int32_t dn = dnb(j);
+    const int32_t hv = lv_have(sp, it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j], it.nb[j]);
+    const bool want = pushes & (it.nb[j] != kUnobserved) & (!S::kWrap | (dn < kD2Cap)) & (dn < hv);  // (no short circuits)
+    if (want) {
       tried |= 1u << j;
       got[j] = lv_cas<ONE>(coc + it.an[j], settled(it.nb[j]), id | kAct);
     }
@@ -388,32 +402,41 @@ __device__ inline uint32_t lv_push(const S &sp, vox_t *coc, uint32_t e, const Lv
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     if (tried & (1u << j)) {
+      const int32_t dn = dnb(j);
       const int r = got[j] == settled(it.nb[j])
                         ? 1
-                        : lv_min<S, ONE>(sp, coc, it.an[j], it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j], id, dn[j], got[j]);
-      if (r) ++wrote, maxd2 = max(maxd2, (uint32_t)dn[j]);
+                        : lv_min<S, ONE>(sp, coc, it.an[j], it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j], id, dn, got[j]);
+      if (r) ++wrote, maxd2 = max(maxd2, (uint32_t)dn);
       if (r == 1) queue |= 1u << j;
     }
   }
   if (waits) queue |= 1u << 6, atomicAdd(n_wait, 1u);
-  // -- append: one vote per kind of entry (own voxel, direction 0..5), positions from the votes, ONE atomic per wave
+  // -- append: one vote per kind of entry (own voxel, direction 0..5); the votes and their running totals are wave-uniform
+  //    (scalar registers), a lane's position is a vote's total so far + the lanes below it in that vote; ONE atomic per wave
   const int lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t mine[7], total = 0;
+  unsigned long long vote[7];
+  uint32_t total = 0;
 #pragma unroll
   for (int b = 0; b < 7; ++b) {
-    const unsigned long long m = __ballot((queue >> b) & 1u);
-    mine[b] = total + (uint32_t)__popcll(m & below);
-    total += (uint32_t)__popcll(m);
+    vote[b] = __ballot((queue >> b) & 1u);
+    total += (uint32_t)__popcll(vote[b]);
   }
   if (total) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(n_next, total);
     base = (uint32_t)__shfl((int)base, 0);
-    if (queue & (1u << 6)) put(base + mine[6], e);
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-      if (queue & (1u << j)) put(base + mine[j], lv_pack(it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j]));
+    for (int b = 0; b < 7; ++b) {
+      if (queue & (1u << b)) {
+        const uint32_t at = base + (uint32_t)__popcll(vote[b] & below);
+        if (b == 6)
+          put(at, e);
+        else
+          put(at, lv_pack(it.x + dr.dx[b], it.y + dr.dy[b], it.z + dr.dz[b]));
+      }
+      base += (uint32_t)__popcll(vote[b]);
+    }
   }
   return wrote;
 }
@@ -491,8 +514,9 @@ __global__ void k_level_outside(S sp, LevelArgs a) {
 template <class S, int NT, int CAP>
 __global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
   __shared__ uint32_t s_list[2][CAP];
-  __shared__ uint32_t s_res[CAP];
-  __shared__ uint32_t s_next, s_nextwait, s_wrote, s_maxd2;
+  __shared__ vox_t s_nb[14][NT];     // a level of more than NT / 4 entries: the two entries of every quad between the phases
+  __shared__ uint32_t s_an[14][NT];  // (per entry: the lane's six neighbour words / addresses, then the own word / address)
+  __shared__ uint32_t s_next, s_nextwait, s_wrote, s_maxd2, s_trace_n;
   LevelCtl *ctl = a.ctl;
   const int tid = threadIdx.x;
   const unsigned long long t_in = wall_clock64();
@@ -528,7 +552,7 @@ __global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
       else if (at < a.cap)
         gout[at] = e;
     };
-    if (tid == 0) ctl->items += n, ctl->peak = max(ctl->peak, n);
+    if (tid == 0) ctl->items += n, ctl->peak = max(ctl->peak, n), s_trace_n = n;
     const unsigned long long p0 = wall_clock64();
     unsigned long long p1 = p0, p2 = p0, p3 = p0;
     if (n <= QT) {
@@ -548,23 +572,43 @@ __global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
       if (__ballot(live && verdict != kLvNone)) wrote += lv_push<S, true>(sp, a.coc, e, it, dr, live ? verdict : kLvNone, &s_next, &s_nextwait, maxd2, put);
       p3 = wall_clock64();
     } else {
-      const uint32_t n_up = (n + 15u) / 16u * 16u;  // whole waves (16 entries each) walk the loops together
-      for (uint32_t i = (uint32_t)tid >> 2; i < n_up; i += QT) {
-        LvItem it;
-        const bool live = i < n;
-        lv_fetch<S, true>(sp, a.coc, live ? in[i] : 0u, live, dr, it);
-        const uint32_t verdict = lv_pull<S, true>(sp, a.coc, it, dr);
-        if (live && dr.q == 0) s_res[i] = verdict;
+      // QT < n <= CAP = 2 QT: every quad has TWO entries.  Both stencils are requested together (one memory latency for the
+      // level's pulls, as above); the first stays in registers across the barrier, the second waits in LDS.
+      static_assert(CAP == 2 * (int)QT, "two entries per quad");
+      const uint32_t i0 = (uint32_t)tid >> 2, i1 = i0 + QT;
+      const bool live1 = i1 < n;
+      const uint32_t e0 = in[i0], e1 = live1 ? in[i1] : 0u;
+      uint32_t v0, v1;
+      {
+        LvItem it0, it1;
+        lv_fetch<S, true>(sp, a.coc, e0, true, dr, it0);
+        lv_fetch<S, true>(sp, a.coc, e1, live1, dr, it1);
+        auto park = [&](const LvItem &it, const int k) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) s_nb[7 * k + j][tid] = it.nb[j], s_an[7 * k + j][tid] = it.an[j];
+          s_nb[7 * k + 6][tid] = it.w, s_an[7 * k + 6][tid] = it.self;
+        };
+        v0 = lv_pull<S, true>(sp, a.coc, it0, dr);
+        park(it0, 0);
+        v1 = lv_pull<S, true>(sp, a.coc, it1, dr);
+        park(it1, 1);
       }
-      __syncthreads();
-      for (uint32_t i = (uint32_t)tid >> 2; i < n_up; i += QT) {
-        const bool live = i < n;
-        const uint32_t verdict = live ? s_res[i] : kLvNone;
-        if (!__ballot(verdict != kLvNone)) continue;
+      __syncthreads();  // every pull has read the field
+      auto unpark = [&](LvItem &it, const uint32_t e, const int k) {
+        sp.decode(e, it.x, it.y, it.z);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) it.nb[j] = s_nb[7 * k + j][tid], it.an[j] = s_an[7 * k + j][tid];
+        it.w = s_nb[7 * k + 6][tid], it.self = s_an[7 * k + 6][tid];
+      };
+      {
         LvItem it;
-        const uint32_t e = live ? in[i] : 0u;
-        lv_fetch<S, true>(sp, a.coc, e, live && verdict != kLvNone && verdict != kLvWait, dr, it);
-        wrote += lv_push<S, true>(sp, a.coc, e, it, dr, verdict, &s_next, &s_nextwait, maxd2, put);
+        unpark(it, e0, 0);
+        wrote += lv_push<S, true>(sp, a.coc, e0, it, dr, v0, &s_next, &s_nextwait, maxd2, put);
+      }
+      if (__ballot(live1 && v1 != kLvNone)) {
+        LvItem it;
+        unpark(it, e1, 1);
+        wrote += lv_push<S, true>(sp, a.coc, e1, it, dr, live1 ? v1 : kLvNone, &s_next, &s_nextwait, maxd2, put);
       }
     }
     __syncthreads();
@@ -575,6 +619,7 @@ __global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
     if (tid == 0) {
       const unsigned long long p4 = wall_clock64();
       ctl->phase[0] += (uint32_t)(p1 - p0), ctl->phase[1] += (uint32_t)(p2 - p1), ctl->phase[2] += (uint32_t)(p3 - p2), ctl->phase[3] += (uint32_t)(p4 - p3);
+      if (level <= 48u) ctl->trace[level - 1u] = (s_trace_n << 16) | (uint32_t)min((unsigned long long)0xFFFFu, p4 - p0);
     }
   }
   // hand the state back: the next launch (or the host) goes on from here
@@ -745,7 +790,7 @@ struct LevelEngine {
   LevelCtl *h_ctl = nullptr;  // pinned
   uint32_t serial = 0;
   uint32_t cap = 0;
-  static constexpr uint32_t kSingleCap = 1024;  // frontier one work-group keeps to itself (one CU: ~25 ns per entry)
+  static constexpr uint32_t kSingleCap = 512;  // frontier one work-group keeps to itself: two entries per quad of lanes
   enum Outcome { kDone = 0, kOverflow = 1, kHandOver = 2 };
   static constexpr int kNT = 1024;
   ~LevelEngine() {

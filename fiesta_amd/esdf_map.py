@@ -150,6 +150,14 @@ class ESDFMap:
             self.served["bulk" if d["bulk"] else "levels" if d["levels"] else "rounds"] += 1
         return d
 
+    def level_trace(self):
+        """The last level-engine update, level by level: [(frontier entries, microseconds inside the kernel), ...] for its
+        first 48 levels, and the number of levels it ran (fiesta_hip_level_trace)."""
+        out = (C.c_uint32 * 48)()
+        n = C.c_int32(0)
+        check(self._lib.fiesta_hip_level_trace(self._h, out, C.byref(n)))
+        return [(int(w) >> 16, (int(w) & 0xFFFF) / 100.0) for w in list(out)[: min(n.value, 48)]], n.value
+
     @property
     def only_levels(self) -> bool:
         """Every UpdateESDF of this map so far that had work ran the level engine from start to end (fiesta_hip_stats.levels):

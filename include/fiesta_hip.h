@@ -130,6 +130,11 @@ int fiesta_hip_set_original_range(fiesta_hip_map *m);
 /* fiesta_hip_config.update_engine, changed on a live map (takes effect with the next UpdateESDF; array maps only, a
  * hash-block map has one engine).  No reference counterpart: the reference has one engine. */
 int fiesta_hip_set_update_engine(fiesta_hip_map *m, int32_t engine);
+/* Diagnostics of the last UpdateESDF the level engine served (fiesta_hip_stats.levels): for each of its first 48 levels
+ * (= layers of the reference's FIFO, src/ESDFMap.cpp:339-392) the number of frontier entries (high 16 bits) and the time
+ * the level took inside the one-work-group kernel in units of 10 ns (low 16 bits).  *n_levels = levels of that update
+ * (may exceed 48).  No reference counterpart. */
+int fiesta_hip_level_trace(fiesta_hip_map *m, uint32_t out[48], int32_t *n_levels);
 
 /* ---- occupancy ingest: ESDFMap::SetOccupancy x2 (src/ESDFMap.cpp:401-437), batched ----
  * Observations are applied as if SetOccupancy had been called once per entry; hit/total counters are
