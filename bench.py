@@ -831,7 +831,7 @@ def main():
                     f"({G}^3 owned per GPU + 2-voxel ghost layer; RCCL ghost exchange + transition all-gather, "
                     f"{statistics.mean(s_['sweeps'] for s_ in timed):.1f} ghost sweeps per update)"),
                 "update_engine": args.engine, "unobserved_block_fraction": args.unobserved,
-                "protocol": None if sharded_map is None else ("native C++ shard group over RCCL (shard_group.hip)" if getattr(sharded_map, "_group", None) else "python protocol over torch.distributed (debugging back end)"),
+                "protocol": None if sharded_map is None else sharded_map.protocol,
             },
             "update_esdf_p50_ms": statistics.median(s["host_ms"] for s in timed),
             "update_esdf_device_p50_ms": statistics.median(s["device_ms"] for s in timed),

@@ -117,6 +117,7 @@ def load():
         "fiesta_hip_rccl_unique_id": (C.c_int, [vp]),
         "fiesta_hip_shard_box": (C.c_int, [vp, C.c_int32, C.c_int32, vp, vp]),
         "fiesta_hip_shard_group_create": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),
+        "fiesta_hip_shard_group_create_hosted": (C.c_int, [vp, C.c_int32, C.c_int32, vp, vp]),
         "fiesta_hip_shard_group_precheck": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32]),
         "fiesta_hip_shard_group_comm_info": (C.c_int, [vp, vp, vp]),
         "fiesta_hip_shard_group_destroy": (C.c_int, [vp]),

@@ -600,6 +600,23 @@ int fiesta_hip_shard_group_create(fiesta_hip_map *const *shards, const int32_t *
     *out = h;
   });
 }
+int fiesta_hip_shard_group_create_hosted(fiesta_hip_map *shard, int32_t rank, int32_t world, const fiesta_hip_shard_transport *t,
+                                         fiesta_hip_shard_group **out) {
+  return guarded([&] {
+    need(shard && out && t && t->all_gather && t->exchange, "null argument");
+    *out = nullptr;
+    std::vector<DenseMap *> maps{&dense(shard, "shard_group_create_hosted")};
+    std::vector<int> rk{rank};
+    auto *h = new fiesta_hip_shard_group;
+    try {
+      h->g = new fiesta::ShardGroup(maps, rk, world, nullptr, t);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+  });
+}
 int fiesta_hip_shard_group_precheck(fiesta_hip_map *const *shards, const int32_t *ranks, int32_t n_local, int32_t world, int32_t use_rccl) {
   return guarded([&] {
     need(shards && ranks && n_local > 0, "null argument");

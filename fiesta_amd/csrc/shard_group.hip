@@ -138,6 +138,7 @@ static void local_array(const int gg[3], int world, int rank, int org[3], int di
   }
 }
 
+static thread_local bool g_precheck_skips_rccl = false;  // (the hosted constructor: one shard per process, no librccl)
 void ShardGroup::precheck(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, bool rccl) {
   if (maps.empty() || maps.size() != ranks.size()) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: bad shard list");
   const Geom &g0 = maps[0]->geom();
@@ -145,8 +146,8 @@ void ShardGroup::precheck(const std::vector<DenseMap *> &maps, const std::vector
   const int gg[3] = {g0.GX, g0.GY, g0.GZ};
   int l[3];
   layout_of(world, l);
-  if (rccl && maps.size() != 1) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: one shard per process under RCCL");
-  if (!rccl && (int)maps.size() != world) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: without RCCL every shard must be local");
+  if (rccl && maps.size() != 1) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: one shard per process under RCCL / a hosted transport");
+  if (!rccl && (int)maps.size() != world) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: without a transport every shard must be local");
   for (size_t i = 0; i < maps.size(); ++i) {
     if (ranks[i] < 0 || ranks[i] >= world) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: rank out of range");
     const Geom &g = maps[i]->geom();
@@ -156,7 +157,7 @@ void ShardGroup::precheck(const std::vector<DenseMap *> &maps, const std::vector
         dims[0] != g.nx || dims[1] != g.ny || dims[2] != g.nz)
       throw Error(FIESTA_HIP_ERR_INVALID, "shard group: a shard's box does not match the regular cut of the global grid");
   }
-  if (rccl) (void)Rccl::get();  // (throws when librccl cannot be loaded)
+  if (rccl && !g_precheck_skips_rccl) (void)Rccl::get();  // (throws when librccl cannot be loaded)
 }
 
 void ShardGroup::comm_info(int *nranks, int *rank) const {
@@ -169,9 +170,21 @@ void ShardGroup::comm_info(int *nranks, int *rank) const {
   if (rank) *rank = r;
 }
 
-ShardGroup::ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id)
+ShardGroup::ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id,
+                       const fiesta_hip_shard_transport *hosted)
     : world_(world) {
-  precheck(maps, ranks, world, rccl_id != nullptr);
+  if (hosted && rccl_id) throw Error(FIESTA_HIP_ERR_INVALID, "shard group: RCCL or a hosted transport, not both");
+  if (hosted) {
+    host_ = *hosted, hosted_ = true;
+    g_precheck_skips_rccl = true;
+  }
+  try {
+    precheck(maps, ranks, world, rccl_id != nullptr || hosted_);
+  } catch (...) {
+    g_precheck_skips_rccl = false;
+    throw;
+  }
+  g_precheck_skips_rccl = false;
   const Geom &g0 = maps[0]->geom();
   gg_[0] = g0.GX, gg_[1] = g0.GY, gg_[2] = g0.GZ;
   int l[3];
@@ -279,10 +292,18 @@ void ShardGroup::gather_rows(const std::vector<std::vector<long long>> &rows) {
     FIESTA_RCCL_CHECK(Rccl::get().AllGather(d_row_, d_table_, kRow, ncclInt64, (ncclComm_t)comm_, s));
     FIESTA_HIP_CHECK(hipMemcpyAsync(h_table_, d_table_, (size_t)world_ * kRow * sizeof(long long), hipMemcpyDeviceToHost, s));
     FIESTA_HIP_CHECK(hipStreamSynchronize(s));
+  } else if (hosted_) {
+    std::vector<long long> all((size_t)world_ * kRow);
+    host_all_gather(rows[0].data(), all.data(), kRow * (int64_t)sizeof(long long));
+    memcpy(h_table_, all.data(), all.size() * sizeof(long long));
   } else {
     for (size_t i = 0; i < locals_.size(); ++i)
       memcpy(&h_table_[(size_t)locals_[i]->rank * kRow], rows[i].data(), kRow * sizeof(long long));
   }
+}
+
+void ShardGroup::host_all_gather(const void *send, void *recv, int64_t bytes) {
+  if (host_.all_gather(host_.ctx, send, recv, bytes) != 0) throw Error(FIESTA_HIP_ERR_DEVICE, "shard group: the hosted transport's all_gather failed");
 }
 
 ShardGroup::Local *ShardGroup::find_local(int rank) {
@@ -293,7 +314,7 @@ ShardGroup::Local *ShardGroup::find_local(int rank) {
 
 bool ShardGroup::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
   // 1. local fusion; 2. every shard's transitions to every shard
-  if (world_ == 1 && !comm_) {  // nobody to tell: the shard's own fusion already keeps its replica of the global bitmap
+  if (world_ == 1 && !remote()) {  // nobody to tell: the shard's own fusion already keeps its replica of the global bitmap
     int64_t ni = 0, nd = 0;
     const bool any = locals_[0]->map->update_occupancy(global_map, &ni, &nd);
     if (n_ins) *n_ins = ni;
@@ -326,6 +347,18 @@ bool ShardGroup::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_de
       FIESTA_RCCL_CHECK(Rccl::get().AllGather(L.trans.p, gathered_.p, (size_t)2 * max_n, ncclUint32, (ncclComm_t)comm_, s));
       for (int r = 0; r < world_; ++r)
         L.map->apply_transitions(gathered_.p + (size_t)2 * max_n * r, h_table_[(size_t)r * kRow]);
+    } else if (hosted_) {  // the same all-gather, through host buffers and the caller's transport
+      Local &L = *locals_[0];
+      hipStream_t s = L.map->stream();
+      const size_t words = (size_t)2 * max_n;
+      h_words_.assign(words, 0u);
+      const long long mine = h_table_[(size_t)L.rank * kRow];
+      if (mine) L.map->copy_to_host(h_words_.data(), L.trans.p, (size_t)2 * mine * sizeof(uint32_t));
+      h_gathered_.resize(words * world_);
+      host_all_gather(h_words_.data(), h_gathered_.data(), (int64_t)(words * sizeof(uint32_t)));
+      gathered_.ensure(words * world_, s);
+      L.map->copy_to_device(gathered_.p, h_gathered_.data(), words * world_ * sizeof(uint32_t));
+      for (int r = 0; r < world_; ++r) L.map->apply_transitions(gathered_.p + words * r, h_table_[(size_t)r * kRow]);
     } else {
       for (auto &src : locals_) src->map->synchronize();
       for (auto &dst : locals_)
@@ -498,6 +531,32 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
       for (size_t k = 0; k < L.links.size(); ++k) {
         Link &ln = L.links[k];
         L.map->halo_apply_sparse(ln.recv.p, h_table_[(size_t)ln.peer * kRow + ln.slot], &L.counts.p[kMaxLinks]);
+      }
+    } else if (hosted_) {  // the same messages, staged through host memory and handed to the caller's transport
+      Local &L = *locals_[0];
+      const size_t nl = L.links.size();
+      std::vector<std::vector<uint32_t>> out(nl), in(nl);
+      std::vector<int32_t> peers(nl);
+      std::vector<const void *> sp(nl);
+      std::vector<void *> rp(nl);
+      std::vector<int64_t> sb(nl), rb(nl);
+      for (size_t k = 0; k < nl; ++k) {
+        Link &ln = L.links[k];
+        const long long ns = h_table_[(size_t)L.rank * kRow + k], nr = h_table_[(size_t)ln.peer * kRow + ln.slot];
+        out[k].resize((size_t)2 * ns), in[k].resize((size_t)2 * nr);
+        if (ns) L.map->copy_to_host(out[k].data(), ln.send.p, (size_t)2 * ns * sizeof(uint32_t));
+        peers[k] = ln.peer, sp[k] = out[k].data(), rp[k] = in[k].data();
+        sb[k] = (int64_t)(2 * ns * sizeof(uint32_t)), rb[k] = (int64_t)(2 * nr * sizeof(uint32_t));
+        sent_total += ns;
+      }
+      if (host_.exchange(host_.ctx, (int32_t)nl, peers.data(), sp.data(), sb.data(), rp.data(), rb.data()) != 0)
+        throw Error(FIESTA_HIP_ERR_DEVICE, "shard group: the hosted transport's exchange failed");
+      for (size_t k = 0; k < nl; ++k) {
+        Link &ln = L.links[k];
+        const long long nr = h_table_[(size_t)ln.peer * kRow + ln.slot];
+        if (!nr) continue;
+        L.map->copy_to_device(ln.recv.p, in[k].data(), (size_t)2 * nr * sizeof(uint32_t));
+        L.map->halo_apply_sparse(ln.recv.p, nr, &L.counts.p[kMaxLinks]);
       }
     } else {
       for (auto &Lp : locals_) Lp->map->synchronize();  // (every send buffer is complete before anybody copies from it)

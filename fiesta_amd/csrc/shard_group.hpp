@@ -18,7 +18,12 @@ class ShardGroup {
  public:
   // maps[i] is the shard of global rank ranks[i].  rccl_id != nullptr: one shard per process, `world` ranks over RCCL.
   // rccl_id == nullptr: all `world` shards live in this process (tests, N shards multiplexed on one GPU).
-  ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id);
+  // hosted != nullptr (and rccl_id == nullptr): one shard per process, messages handed to the CALLER's functions through
+  // host buffers (fiesta_hip_shard_transport: an all-gather and a neighbour exchange) -- the same sweep loop, sparse
+  // diff / apply and convergence test as over RCCL, across process boundaries that RCCL refuses on one GPU (two ranks on
+  // one device) or that have no RCCL at all; what the multi-process tests bind to torch.distributed / gloo.
+  ShardGroup(const std::vector<DenseMap *> &maps, const std::vector<int> &ranks, int world, const uint8_t *rccl_id,
+             const fiesta_hip_shard_transport *hosted = nullptr);
   ~ShardGroup();
   // Everything the constructor checks LOCALLY (shard boxes against the regular cut, set-up rules, librccl loadable when
   // `rccl`), without the collective ncclCommInitRank: ranks agree on the outcome of this first, so that one rank's local
@@ -40,6 +45,11 @@ class ShardGroup {
   int gg_[3] = {0, 0, 0};
   std::vector<std::unique_ptr<Local>> locals_;
   void *comm_ = nullptr;  // ncclComm_t
+  bool hosted_ = false;   // messages go through host_ (the caller's transport)
+  fiesta_hip_shard_transport host_{};
+  bool remote() const { return comm_ != nullptr || hosted_; }  // peers live in other processes
+  void host_all_gather(const void *send, void *recv, int64_t bytes);
+  std::vector<uint32_t> h_words_, h_gathered_;
   long long *h_table_ = nullptr, *d_row_ = nullptr, *d_table_ = nullptr;
   DevBuf<uint32_t> gathered_;
 };

@@ -238,16 +238,26 @@ class ShardedESDFMap:
         # The Python loop below is the same protocol spelled out over torch.distributed -- what the CPU (gloo) tests drive
         # with a numpy stand-in shard, and a cross-check for the native engine.
         self._group = None
+        self.protocol = "python protocol over the transport (dense slabs; tests and debugging)"
         n_here = len(self.shards)
         can = default_shards and (n_here == n_shards or (n_here == 1 and getattr(self.transport, "on_gpu", False)))
         auto = native is None
-        if auto:
+        if native == "hosted":
+            # the C++ protocol of shard_group.hip with THIS transport's torch.distributed group carrying its messages through
+            # host buffers (fiesta_hip_shard_transport): one shard per rank, any back end -- gloo between processes that
+            # share one GPU, where RCCL refuses to form a communicator
+            if not (default_shards and n_here == 1 and n_shards > 1 and hasattr(self.transport, "dist")):
+                raise ValueError("hosted shard group: needs one HIP shard per rank and a torch.distributed transport")
+            self._open_hosted_group()
+            native = False
+        elif auto:
             native = can
         if native:
             if not can:
                 raise ValueError("native shard group: needs HIP shards, all local or one per rank on the RCCL transport")
             try:
                 self._open_native_group()
+                self.protocol = "native C++ shard group, " + ("RCCL" if (n_here == 1 and n_shards > 1) or self._rccl_group_of_one else "all shards in this process")
                 failed = 0
             except Exception as e:  # noqa: BLE001  (e.g. the RCCL communicator could not be formed)
                 if not auto:
@@ -259,6 +269,65 @@ class ShardedESDFMap:
             if auto and n_here == 1 and n_shards > 1 and self.transport.allreduce_sum(failed) and self._group is not None:
                 self._glib.fiesta_hip_shard_group_destroy(self._group)
                 self._group = None
+
+    def _open_hosted_group(self):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        torch, dist, world = self.transport.torch, self.transport.dist, self.n_shards
+        (rank,) = sorted(self.shards)
+
+        def view(ptr, nbytes):
+            return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)) if nbytes else np.empty(0, np.uint8)
+
+        AG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+        EX = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                         C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+
+        def all_gather(_ctx, send, recv, nbytes):
+            try:
+                t = torch.from_numpy(view(send, nbytes).copy())
+                out = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(out, t)
+                view(recv, nbytes * world)[:] = np.concatenate([o.numpy() for o in out])
+                return 0
+            except Exception:  # noqa: BLE001  (nothing may propagate through the C frames)
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def exchange(_ctx, n, peers, send, sbytes, recv, rbytes):
+            try:
+                ops, landed, keep = [], [], []
+                for k in range(n):
+                    if sbytes[k]:
+                        t = torch.from_numpy(view(send[k], sbytes[k]).copy())
+                        keep.append(t)
+                        ops.append(dist.P2POp(dist.isend, t, int(peers[k])))
+                    if rbytes[k]:
+                        r = torch.empty(int(rbytes[k]), dtype=torch.uint8)
+                        landed.append((k, r))
+                        ops.append(dist.P2POp(dist.irecv, r, int(peers[k])))
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                for k, r in landed:
+                    view(recv[k], rbytes[k])[:] = r.numpy()
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        class Transport(C.Structure):
+            _fields_ = [("ctx", C.c_void_p), ("all_gather", AG), ("exchange", EX)]
+
+        self._hosted_cbs = (AG(all_gather), EX(exchange))     # (kept alive as long as the group)
+        self._hosted_struct = Transport(None, *self._hosted_cbs)
+        g = C.c_void_p()
+        _lib.check(lib.fiesta_hip_shard_group_create_hosted(self.shards[rank]._h, rank, world, C.byref(self._hosted_struct), C.byref(g)))
+        self._group, self._glib, self._check = g, lib, _lib.check
+        self.protocol = "native C++ shard group over a hosted transport (torch.distributed through host buffers)"
 
     def _open_native_group(self):
         import ctypes as C

@@ -347,6 +347,23 @@ int fiesta_hip_shard_group_create(fiesta_hip_map *const *local_shards, const int
 /* The LOCAL half of _create's checks (shard boxes against the regular cut, set-up rules, librccl loadable when
  * use_rccl) without the collective communicator set-up: ranks exchange the outcome of this first (out of band), so that
  * one rank's local failure cannot leave the others blocked inside ncclCommInitRank. */
+/* A third transport for the same protocol: the caller's own messaging, through HOST buffers.  One shard per process (like
+ * RCCL); the library stages what it sends and receives through host memory and calls
+ *   all_gather(ctx, send, recv, bytes)      every rank contributes `bytes` bytes; recv = world x bytes, in rank order
+ *   exchange(ctx, n, peers, send, send_bytes, recv, recv_bytes)   for k < n: send_bytes[k] bytes from send[k] go to rank
+ *                                           peers[k], recv_bytes[k] bytes from that rank arrive in recv[k] (either may be 0;
+ *                                           a pair of ranks exchanges at most one message each way per call)
+ * Both are collective over the group's ranks and return 0 on success.  Slower than RCCL by the staging copies; it exists
+ * so that the C++ sweep loop, sparse diff / apply and convergence test can run ACROSS PROCESSES where RCCL cannot (two ranks
+ * on one GPU) -- the multi-process tests bind it to torch.distributed over gloo -- or over a fabric RCCL does not know. */
+typedef struct fiesta_hip_shard_transport {
+  void *ctx;
+  int32_t (*all_gather)(void *ctx, const void *send, void *recv, int64_t bytes);
+  int32_t (*exchange)(void *ctx, int32_t n, const int32_t *peers, const void *const *send, const int64_t *send_bytes,
+                      void *const *recv, const int64_t *recv_bytes);
+} fiesta_hip_shard_transport;
+int fiesta_hip_shard_group_create_hosted(fiesta_hip_map *local_shard, int32_t local_rank, int32_t world,
+                                         const fiesta_hip_shard_transport *transport, fiesta_hip_shard_group **out);
 int fiesta_hip_shard_group_precheck(fiesta_hip_map *const *local_shards, const int32_t *local_ranks, int32_t n_local,
                                     int32_t world, int32_t use_rccl);
 /* What the RCCL communicator itself reports: *nranks = ncclCommCount (0: local transport, no communicator),

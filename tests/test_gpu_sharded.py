@@ -273,6 +273,103 @@ def test_dist_transport_with_hip_shards_two_ranks_one_gpu(hip_lib):
     assert all(r[1] == "ok" for r in results), [r for r in results if r[1] != "ok"]
 
 
+def _hosted_worker(rank, world, port, gs, q):
+    try:
+        import torch  # noqa: F401  (before the HIP library: one HIP runtime per process)
+        import torch.distributed as dist
+        import os
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, here)
+        sys.path.insert(0, os.path.dirname(here))
+        from fiesta_amd.sharded import DistTransport, ShardedESDFMap
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sm = ShardedESDFMap((0, 0, 0), 0.1, gs, world, transport=DistTransport(), devices=(0,), native="hosted")
+        assert sm._group is not None and "hosted" in sm.protocol
+        (mine,) = sm.shards.values()
+        sm.SetParameters(*P_DEFAULT)
+        sm.SetOriginalRange()
+        sm.SetOccupancyBox((0, 0, 0), tuple(np.array(gs) - 1), 0)
+        sm.UpdateOccupancy(True)
+        sm.UpdateESDF()
+        rng = np.random.RandomState(11)
+        S = np.unique((rng.rand(160, 3) * gs).astype(np.int32), axis=0)
+        S[:30, 0] = gs[0] // 2 - 2 + rng.randint(0, 4, 30)        # a cluster on the x cut
+        S[30:50, 1] = gs[1] // 2 - 2 + rng.randint(0, 4, 20)      # ... and on the y cut (4 shards)
+        S = np.unique(S, axis=0)
+
+        def check(obstacles, tag):
+            ix = np.indices(gs).reshape(3, -1).T
+            want = ((ix[:, None, :] - obstacles[None, :, :]) ** 2).sum(-1).min(1).reshape(gs)
+            for lo, size, crop in sm.download_owned(("d2",)).values():
+                sl = tuple(slice(int(a), int(a + s)) for a, s in zip(lo, size))
+                assert np.array_equal(crop["d2"].astype(np.int64), want[sl]), (tag, rank)
+        # 1. the bulk path of the shard group (every shard eligible, fully observed): decided from the gathered table
+        for _ in range(3):
+            sm.SetOccupancy(S, 1)
+            sm.UpdateOccupancy(True)
+        assert sm.last_insert == len(S)
+        st = sm.UpdateESDF()
+        check(S, "insert / bulk")
+        # 2. the frontier rounds with ghost sweeps: deletes and inserts next to the cuts, engine switched on the live maps
+        mine.set_update_engine("rounds")
+        gone = S[:60]
+        new = np.array([[gs[0] // 2, 3, 3], [gs[0] // 2 - 1, gs[1] // 2, 5], [1, 1, 1], [gs[0] - 2, gs[1] - 2, gs[2] - 2]], np.int32)
+        for _ in range(6):
+            sm.SetOccupancy(gone, 0)
+            sm.SetOccupancy(new, 1)
+            sm.UpdateOccupancy(True)
+        assert sm.last_delete == len(gone)
+        sm.UpdateESDF()
+        sweeps = sm.last_sweeps
+        live = np.concatenate([S[60:], new])
+        check(live, "mixed / rounds")
+        # 3. back to the library's choice, a small delta at the cut
+        mine.set_update_engine("auto")
+        more = np.array([[gs[0] // 2 - 1, 7, 7], [gs[0] // 2, gs[1] - 3, 9]], np.int32)
+        for _ in range(3):
+            sm.SetOccupancy(more, 1)
+            sm.UpdateOccupancy(True)
+        sm.UpdateESDF()
+        check(np.concatenate([live, more]), "small delta / auto")
+        q.put((rank, "ok", (int(bool(st.get("bulk"))), sweeps, sm.last_entries_sent)))
+        dist.barrier()
+        sm.close()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cpp_protocol_across_processes_on_a_hosted_transport(hip_lib, world):
+    """the C++ sweep loop, sparse diff / apply and convergence test of shard_group.hip -- the code
+    `bench.py --gpus N` runs over RCCL -- ACROSS PROCESSES: 2 and 4 processes share the one visible GPU (where RCCL refuses
+    a communicator), each owns one shard, the group's all-gathers and neighbour exchanges travel through
+    fiesta_hip_shard_transport bound to torch.distributed / gloo.  The sharded bulk path (decided from the gathered table),
+    the frontier rounds with ghost sweeps at the cuts (2 x 1 x 1 and 2 x 2 x 1) and a small delta under the library's own
+    engine choice, each against brute force on every owned voxel."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    gs = (48, 40, 32)
+    procs = [ctx.Process(target=_hosted_worker, args=(r, world, port, gs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), [r for r in results if r[1] != "ok"]
+    assert all(r[2][0] == 1 for r in results), "the first update must have gone through the sharded bulk path"
+    assert all(r[2][1] >= 1 for r in results), "the rounds update must have needed ghost sweeps"
+
+
 def _brute_d2(vox, obs):
     out = np.empty(len(vox), np.int64)
     for s in range(0, len(vox), 4096):
