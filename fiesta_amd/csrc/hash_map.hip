@@ -372,15 +372,39 @@ __global__ __launch_bounds__(256) void k_h_invalidate(Geom g, const int32_t *dir
 }
 
 // ---- queries (src/ESDFMap.cpp:452-540); an unallocated voxel reads like a freshly allocated one ----
-__device__ inline double h_distance(const Geom &g, const int32_t *dir, const vox_t *coc, int x, int y, int z) {
-  if (!in_win(x, y, z)) return (double)FIESTA_HIP_INFINITY;
-  const int64_t a = vaddr(dir, x, y, z);
+// The reference's hash map answers for ANY voxel it ever allocated (:732-765).  Inside the window a lookup is one load of
+// the dense directory; outside it -- pages that are parked -- a query goes through the MAP-WIDE page table: every page's
+// tile in map coordinates as a sorted 64-bit key (a few thousand entries: a binary search), so that a planner may ask for
+// a goal far from the sensor.  A parked page answers with the field it held when the window left it.
+__host__ __device__ inline unsigned long long tile_key(int tx, int ty, int tz) {
+  return ((unsigned long long)(uint32_t)(tx + (1 << 20)) << 42) | ((unsigned long long)(uint32_t)(ty + (1 << 20)) << 21) |
+         (unsigned long long)(uint32_t)(tz + (1 << 20));
+}
+// pool address of WINDOW voxel (x, y, z), which may lie outside the window; -1: no page anywhere holds it
+__device__ inline int64_t h_lookup(const Geom &g, const int32_t *dir, const PageTable &tab, int x, int y, int z) {
+  if (in_win(x, y, z)) return vaddr(dir, x, y, z);
+  const int vx = x + g.gx0, vy = y + g.gy0, vz = z + g.gz0;  // map voxel; the window origin is a whole number of tiles
+  const unsigned long long key = tile_key(vx >> 4, vy >> 4, vz >> 5);
+  int lo = 0, hi = tab.n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const unsigned long long k = tab.keys[mid];
+    if (k == key) return (int64_t)tab.pages[mid] * kPageVox + (((vx & 15) * 16 + (vy & 15)) * 32 + (vz & 31));
+    if (k < key)
+      lo = mid + 1;
+    else
+      hi = mid - 1;
+  }
+  return -1;
+}
+__device__ inline double h_distance(const Geom &g, const int32_t *dir, const PageTable &tab, const vox_t *coc, int x, int y, int z) {
+  const int64_t a = h_lookup(g, dir, tab, x, y, z);
   if (a < 0) return (double)FIESTA_HIP_INFINITY;
   const vox_t w = coc[a] & ~kAct;
   if (w & kNoCoc) return (double)FIESTA_HIP_INFINITY;
   return sqrt((double)h_dist2(g, x, y, z, w)) * g.res;
 }
-__global__ void k_h_query_dist(Geom g, const int32_t *dir, const vox_t *coc, const int32_t *vox, const double *pos,
+__global__ void k_h_query_dist(Geom g, const int32_t *dir, PageTable tab, const vox_t *coc, const int32_t *vox, const double *pos,
                                int64_t n, double *out) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -392,9 +416,9 @@ __global__ void k_h_query_dist(Geom g, const int32_t *dir, const vox_t *coc, con
     y = (int)floor((pos[3 * i + 1] - g.org[1]) / g.res) - g.gy0;
     z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) - g.gz0;
   }
-  out[i] = h_distance(g, dir, coc, x, y, z);
+  out[i] = h_distance(g, dir, tab, coc, x, y, z);
 }
-__global__ void k_h_query_occ(Geom g, const int32_t *dir, const uint32_t *occbits, const int32_t *vox, const double *pos,
+__global__ void k_h_query_occ(Geom g, const int32_t *dir, PageTable tab, const uint32_t *occbits, const int32_t *vox, const double *pos,
                               int64_t n, int32_t *out) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -406,11 +430,11 @@ __global__ void k_h_query_occ(Geom g, const int32_t *dir, const uint32_t *occbit
     y = (int)floor((pos[3 * i + 1] - g.org[1]) / g.res) - g.gy0;
     z = (int)floor((pos[3 * i + 2] - g.org[2]) / g.res) - g.gz0;
   }
-  const int64_t a = in_win(x, y, z) ? vaddr(dir, x, y, z) : -1;
+  const int64_t a = h_lookup(g, dir, tab, x, y, z);
   out[i] = a < 0 ? 0 : (int)hbit(occbits, a);
 }
 // GetDistWithGradTrilinear (src/ESDFMap.cpp:481-540), f64 in the reference's operation order
-__global__ void k_h_query_trilinear(Geom g, const int32_t *dir, const vox_t *coc, const double *pos, int64_t n, double *dist,
+__global__ void k_h_query_trilinear(Geom g, const int32_t *dir, PageTable tab, const vox_t *coc, const double *pos, int64_t n, double *dist,
                                     double *grad) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -426,7 +450,7 @@ __global__ void k_h_query_trilinear(Geom g, const int32_t *dir, const vox_t *coc
   double v[2][2][2];
   for (int ix = 0; ix < 2; ++ix)
     for (int iy = 0; iy < 2; ++iy)
-      for (int iz = 0; iz < 2; ++iz) v[ix][iy][iz] = h_distance(g, dir, coc, b[0] + ix - g.gx0, b[1] + iy - g.gy0, b[2] + iz - g.gz0);
+      for (int iz = 0; iz < 2; ++iz) v[ix][iy][iz] = h_distance(g, dir, tab, coc, b[0] + ix - g.gx0, b[1] + iy - g.gy0, b[2] + iz - g.gz0);
   const double v00 = (1 - f[0]) * v[0][0][0] + f[0] * v[1][0][0];
   const double v01 = (1 - f[0]) * v[0][0][1] + f[0] * v[1][0][1];
   const double v10 = (1 - f[0]) * v[0][1][0] + f[0] * v[1][1][0];
@@ -1229,13 +1253,40 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
 }
 
 // ---- queries ----
+// The map-wide page table of the query kernels (PageTable): sorted on the host whenever pages were added since it was built
+// (a few thousand keys at most; pages are never freed and a page's map tile never changes).
+PageTable HashMap::page_table() {
+  if (ptab_pages_built_ != npages_) {
+    std::vector<int32_t> gt((size_t)npages_ * 3);
+    if (npages_) {
+      FIESTA_HIP_CHECK(hipMemcpyAsync(gt.data(), page_gtile_.p, gt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    }
+    std::vector<std::pair<unsigned long long, int32_t>> e((size_t)npages_);
+    for (int64_t p = 0; p < npages_; ++p) e[p] = {tile_key(gt[3 * p], gt[3 * p + 1], gt[3 * p + 2]), (int32_t)p};
+    std::sort(e.begin(), e.end());
+    std::vector<unsigned long long> keys(e.size());
+    std::vector<int32_t> pages(e.size());
+    for (size_t i = 0; i < e.size(); ++i) keys[i] = e[i].first, pages[i] = e[i].second;
+    ptab_keys_.ensure(std::max<size_t>(1, keys.size()), stream_);
+    ptab_pages_.ensure(std::max<size_t>(1, pages.size()), stream_);
+    if (!keys.empty()) {
+      FIESTA_HIP_CHECK(hipMemcpyAsync(ptab_keys_.p, keys.data(), keys.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream_));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(ptab_pages_.p, pages.data(), pages.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));  // (the host vectors go out of scope)
+    }
+    ptab_pages_built_ = npages_;
+  }
+  return PageTable{ptab_keys_.p, ptab_pages_.p, (int)ptab_pages_built_};
+}
+
 void HashMap::get_distance_vox(const int32_t *vox, int64_t n, double *out) {
   use_device();
   if (n <= 0) return;
   stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
   stage_c_.ensure(n * sizeof(double), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-  hipLaunchKernelGGL(k_h_query_dist, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, (const vox_t *)coc_.p,
+  hipLaunchKernelGGL(k_h_query_dist, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, page_table(), (const vox_t *)coc_.p,
                      (const int32_t *)stage_a_.p, (const double *)nullptr, n, (double *)stage_c_.p);
   FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1246,7 +1297,7 @@ void HashMap::get_distance_pos(const double *pos, int64_t n, double *out) {
   stage_a_.ensure(n * 3 * sizeof(double), stream_);
   stage_c_.ensure(n * sizeof(double), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
-  hipLaunchKernelGGL(k_h_query_dist, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, (const vox_t *)coc_.p,
+  hipLaunchKernelGGL(k_h_query_dist, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, page_table(), (const vox_t *)coc_.p,
                      (const int32_t *)nullptr, (const double *)stage_a_.p, n, (double *)stage_c_.p);
   FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1258,7 +1309,7 @@ void HashMap::get_dist_grad(const double *pos, int64_t n, double *dist, double *
   stage_b_.ensure(n * 3 * sizeof(double), stream_);
   stage_c_.ensure(n * sizeof(double), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
-  hipLaunchKernelGGL(k_h_query_trilinear, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, (const vox_t *)coc_.p,
+  hipLaunchKernelGGL(k_h_query_trilinear, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, page_table(), (const vox_t *)coc_.p,
                      (const double *)stage_a_.p, n, (double *)stage_c_.p, (double *)stage_b_.p);
   FIESTA_HIP_CHECK(hipMemcpyAsync(dist, stage_c_.p, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   if (grad) FIESTA_HIP_CHECK(hipMemcpyAsync(grad, stage_b_.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -1270,7 +1321,7 @@ void HashMap::get_occupancy_vox(const int32_t *vox, int64_t n, int32_t *out) {
   stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
   stage_c_.ensure(n * sizeof(int32_t), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-  hipLaunchKernelGGL(k_h_query_occ, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, (const uint32_t *)occbits_.p,
+  hipLaunchKernelGGL(k_h_query_occ, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, page_table(), (const uint32_t *)occbits_.p,
                      (const int32_t *)stage_a_.p, (const double *)nullptr, n, (int32_t *)stage_c_.p);
   FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1281,7 +1332,7 @@ void HashMap::get_occupancy_pos(const double *pos, int64_t n, int32_t *out) {
   stage_a_.ensure(n * 3 * sizeof(double), stream_);
   stage_c_.ensure(n * sizeof(int32_t), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
-  hipLaunchKernelGGL(k_h_query_occ, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, (const uint32_t *)occbits_.p,
+  hipLaunchKernelGGL(k_h_query_occ, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const int32_t *)dir_, page_table(), (const uint32_t *)occbits_.p,
                      (const int32_t *)nullptr, (const double *)stage_a_.p, n, (int32_t *)stage_c_.p);
   FIESTA_HIP_CHECK(hipMemcpyAsync(out, stage_c_.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));

@@ -25,6 +25,13 @@
 
 namespace fiesta {
 
+// every page's tile in MAP coordinates, sorted: what a query outside the window searches (hash_map.hip: h_lookup)
+struct PageTable {
+  const unsigned long long *keys;  // (tx + 2^20) << 42 | (ty + 2^20) << 21 | (tz + 2^20)
+  const int32_t *pages;
+  int n;
+};
+
 class HashMap {
  public:
   static constexpr int kWin = 1024, kHalf = 512;   // window, voxels per axis / half of it (initial offset of map voxel 0)
@@ -91,6 +98,10 @@ class HashMap {
   void zero_counters(int first, int n);
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count);
   bool run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd, bool scan);  // false: the rounds finish
+  PageTable page_table();  // the map-wide page table of the query kernels (hash_map.hip)
+  DevBuf<unsigned long long> ptab_keys_;
+  DevBuf<int32_t> ptab_pages_;
+  int64_t ptab_pages_built_ = -1;
   void free_raycast_state();
   struct RaycastState;
   RaycastState *rc_ = nullptr;

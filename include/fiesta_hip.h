@@ -111,9 +111,11 @@ int fiesta_hip_voxel_key(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32
  * part of it that queries, observations and UpdateESDF work on is a WINDOW of 1024^3 voxels that starts centred on map
  * voxel (0,0,0) and FOLLOWS THE OBSERVATIONS: a SetOccupancy batch or ray-cast frame whose bounding box does not fit
  * the window recentres it on that box (per axis, in whole tiles of 16 x 16 x 32 voxels).  Pages that leave the window
- * are parked -- kept, listed by fiesta_hip_download_hash, not queried (they read "never observed") -- and rejoin, with
- * their distance field rebuilt at the next UpdateESDF, when the window returns.  Inside the window the field is the
- * ESDF of the obstacles inside the window (reach of a closest-obstacle id: 512 voxels).
+ * are parked -- kept, listed by fiesta_hip_download_hash, still ANSWERING every query (GetDistance, GetOccupancy,
+ * GetDistWithGradTrilinear go through a map-wide page table outside the window: a planner may ask about a goal far from
+ * the sensor) with the field they held when the window left, but taking no part in observations or UpdateESDF -- and
+ * rejoin, with their distance field rebuilt at the next UpdateESDF, when the window returns.  Inside the window the field
+ * is the ESDF of the obstacles inside the window (reach of a closest-obstacle id: 512 voxels).
  *   fiesta_hip_hash_window    origin = map voxel of the window's lowest corner; moves (nullable) = moves so far
  *   fiesta_hip_hash_recentre  move the window so that `centre` is at its middle (e.g. to query around a goal pose) */
 int fiesta_hip_hash_window(fiesta_hip_map *m, int32_t origin[3], int64_t *moves);
