@@ -13,7 +13,8 @@
 // The map itself is UNBOUNDED like the reference's (any int voxel coordinate): the window MOVES.  It starts centred on
 // the map origin; an observation batch (or ray-cast frame) whose bounding box does not fit the current window recentres
 // it, per axis, on that box (ensure_window).  Pages whose tile leaves the window are PARKED: they keep their content and
-// their place in the pool and in download(), but take no part in queries, observations or UpdateESDF while parked; when
+// their place in the pool and in download() and still ANSWER queries (through the map-wide page table, PageTable below),
+// but take no part in observations or UpdateESDF while parked; when
 // the window comes back over them they are re-attached and their distance field is rebuilt from the obstacles in and
 // around them at the next UpdateESDF (like voxels behind a deleted obstacle).  Inside the window the field is the ESDF
 // of the obstacles INSIDE THE WINDOW.  Closest-obstacle ids are map coordinates modulo 1024 decoded relative to their
