@@ -1568,7 +1568,9 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   // (level_kernels.hpp) takes every update of a few thousand voxels -- a sensor frame -- that the transform does not, and,
   // if asked for (update_engine 3), every update its lists can hold; one that outgrows them is finished by the rounds.
   bool levels_fell_back = false;
-  const bool try_levels = !seed_only && !g_.sharded && !g_.wrap && update_engine_ != 1 && (update_engine_ == 3 || ni + nd <= (unsigned long long)small_update_);
+  // (the inserts ARE level 0: more of them than one work-group carries and the level engine would only hand the update on)
+  const bool try_levels = !seed_only && !g_.sharded && !g_.wrap && update_engine_ != 1 &&
+                          (update_engine_ == 3 || (ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kSingleCap));
   const bool try_bulk = !seed_only && !g_.sharded && bulk_eligible(ni, nd) &&
                         (update_engine_ == 2 || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
   bool counters_reset = false;

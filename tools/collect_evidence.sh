@@ -8,12 +8,18 @@ R=gpurun_out/$TAG
 mkdir -p "$R"
 export TMPDIR=/tmp
 # FIESTA_REV=<commit> in the environment is recorded in the traffic summary (the GPU box has no .git)
+# the parity suite with one JSON line per envelope comparison (the numbers DESIGN.md 3c quotes)
+export FIESTA_ENVELOPE_LOG=$PWD/$R/envelope_reports.jsonl
+rm -f "$FIESTA_ENVELOPE_LOG"
+python -m pytest tests -q -m gpu --junitxml="$R/pytest_gpu.xml" > "$R/pytest_gpu.log" 2>&1
+grep -aE "^(FAILED|ERROR)|[0-9]+ (passed|failed)" "$R/pytest_gpu.log" > "$R/pytest_gpu.txt"
+unset FIESTA_ENVELOPE_LOG
 # C2 headline as the driver runs it (the JSON line carries roofline + cpu_baseline incl. the full-size CPU leg, ~4 min) ...
 python bench.py > "$R/bench_default.log" 2>&1
-grep metric "$R/bench_default.log" > "$R/bench_default.json"
+grep '^{"metric' "$R/bench_default.log" > "$R/bench_default.json"
 # ... and the same GPU work under the kernel trace (without the 4-minute CPU leg)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -o bench -- python bench.py --no-cpu-full > "$R/bench_default_profiled.log" 2>&1
-grep metric "$R/bench_default_profiled.log" > "$R/bench_default_profiled.json"
+grep '^{"metric' "$R/bench_default_profiled.log" > "$R/bench_default_profiled.json"
 # HBM traffic of UpdateESDF's kernels: two PMC passes, calibrated inside the same runs (tools/pmc_traffic.py)
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/pmc_$C" -o bench -- \
@@ -26,18 +32,33 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SA
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
   --output-format csv -d "$R/pmc_LDS" -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$R/pmc_LDS.log" 2>&1
 # the other scene, the other engine, the other configurations
-python bench.py --scene surfaces --no-cpu-baseline 2>&1 | grep metric > "$R/bench_c2_surfaces.json"
-python bench.py --engine rounds --no-cpu-baseline 2>&1 | grep metric > "$R/bench_c2_rounds.json"
-python bench.py --engine rounds --scene surfaces --no-cpu-baseline 2>&1 | grep metric > "$R/bench_c2_surfaces_rounds.json"
-python bench.py --workload c3 --steps 20 --warmup 4 2>&1 | grep metric > "$R/bench_c3.json"
-python bench.py --workload c4 --steps 40 --warmup 5 2>&1 | grep metric > "$R/bench_c4.json"
-python bench.py --gpus 1 --force-sharded --no-cpu-baseline 2>&1 | grep metric > "$R/bench_sharded_1rank.json"
+python bench.py --scene surfaces --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c2_surfaces.json"
+python bench.py --engine rounds --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c2_rounds.json"
+python bench.py --engine rounds --scene surfaces --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c2_surfaces_rounds.json"
+python bench.py --engine levels --no-cpu-baseline --steps 3 --warmup 1 2>&1 | grep '^{"metric' > "$R/bench_c2_levels.json"
+# C2-partial: 27 % of the map (32^3 blocks) never observed -> the transform's gate is shut, the frontier rounds serve the 50k delta
+python bench.py --unobserved 0.27 --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c2_partial.json"
+python bench.py --workload c3 --steps 20 --warmup 4 2>&1 | grep '^{"metric' > "$R/bench_c3.json"
+python bench.py --workload c3 --steps 20 --warmup 4 --engine rounds --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c3_rounds.json"
+python bench.py --workload c4 --steps 40 --warmup 5 2>&1 | grep '^{"metric' > "$R/bench_c4.json"
+python bench.py --workload c4 --steps 40 --warmup 5 --engine rounds --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c4_rounds.json"
+python tools/dev/floor_latency.py > "$R/floor_latency.txt" 2>&1
+# kernel stats of the sensor-rate configurations (level engine: k_level_run; hand-over: k_relax_q)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats_c3" -o c3 -- python bench.py --workload c3 --steps 20 --warmup 4 --no-cpu-baseline > "$R/c3_profiled.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats_c4" -o c4 -- python bench.py --workload c4 --steps 40 --warmup 5 --no-cpu-baseline > "$R/c4_profiled.log" 2>&1
+python bench.py --gpus 1 --force-sharded --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_sharded_1rank.json"
 python bench.py --delta-sweep --no-cpu-baseline 2>&1 | grep -E "^\{" > "$R/delta_sweep.json"
 # copy what is to be judged into profiles/ (gpurun_out/ is scratch)
 cp "$R/stats/bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats_default.csv"
-for f in bench_default bench_default_profiled delta_sweep bench_c2_surfaces bench_c2_rounds bench_c2_surfaces_rounds bench_c3 bench_c4 bench_sharded_1rank pmc_traffic_ft; do
+for f in bench_default bench_default_profiled delta_sweep bench_c2_surfaces bench_c2_rounds bench_c2_surfaces_rounds bench_c2_levels bench_c2_partial \
+         bench_c3 bench_c3_rounds bench_c4 bench_c4_rounds bench_sharded_1rank pmc_traffic_ft; do
   cp "$R/$f.json" "profiles/${TAG}_$f.json"
 done
+cp "$R/floor_latency.txt" "profiles/${TAG}_floor_latency.txt"
+cp "$R/pytest_gpu.txt" "profiles/${TAG}_pytest_gpu.txt"
+cp "$R/envelope_reports.jsonl" "profiles/${TAG}_envelope_reports.jsonl"
+cp "$R/stats_c3/c3_kernel_stats.csv" "profiles/${TAG}_c3_kernel_stats.csv"
+cp "$R/stats_c4/c4_kernel_stats.csv" "profiles/${TAG}_c4_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE SQ LDS; do
   cp "$R/pmc_$C/bench_counter_collection.csv" "profiles/${TAG}_pmc_${C}_counter_collection.csv"
 done
