@@ -33,7 +33,7 @@ class Stats(C.Structure):
                 ("relax_ms", C.c_double), ("relax_launches", C.c_int64), ("prof", C.c_int64 * 8),
                 ("bulk", C.c_int64), ("ft_rows_ms", C.c_double), ("ft_plane_ms", C.c_double), ("ft_x_ms", C.c_double),
                 ("ft_overflow", C.c_int64 * 6), ("observed_voxels", C.c_int64), ("occupied_voxels", C.c_int64),
-                ("ft_max_d2", C.c_int64), ("dropped_observations", C.c_int64), ("levels", C.c_int64)]
+                ("ft_max_d2", C.c_int64), ("dropped_observations", C.c_int64), ("levels", C.c_int64), ("grid_levels", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -128,6 +128,7 @@ def load():
         "fiesta_hip_set_original_range": (C.c_int, [vp]),
         "fiesta_hip_set_update_engine": (C.c_int, [vp, C.c_int32]),
         "fiesta_hip_level_trace": (C.c_int, [vp, vp, vp]),
+        "fiesta_hip_level_tuning": (C.c_int, [vp, C.c_int32, C.c_int64]),
         "fiesta_hip_count_no_obstacle": (C.c_int, [vp, vp]),
         "fiesta_hip_set_occupancy_vox": (C.c_int, [vp, vp, vp, i64, vp]),
         "fiesta_hip_set_occupancy_pos": (C.c_int, [vp, vp, vp, i64, vp]),

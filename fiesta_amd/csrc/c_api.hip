@@ -198,6 +198,18 @@ int fiesta_hip_level_trace(fiesta_hip_map *m, uint32_t out[48], int32_t *n_level
   });
 }
 
+int fiesta_hip_level_tuning(fiesta_hip_map *m, int32_t grid_groups, int64_t spin_limit) {
+  return guarded([&] {
+    need(m != nullptr, "null map handle");
+    need(grid_groups <= 32, "at most 32 work-groups (the CUs of one XCD)");
+    need(spin_limit <= 0xFFFFFFFFll, "spin_limit does not fit 32 bits");
+    if (m->dense)
+      m->dense->level_tuning(grid_groups, spin_limit);
+    else
+      m->hash->level_tuning(grid_groups, spin_limit);
+  });
+}
+
 int fiesta_hip_set_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, const int32_t *occ, int64_t n, int32_t *ret) {
   return guarded([&] {
     need(m && (n == 0 || (vox && occ)) && n >= 0, "bad argument");

@@ -1448,6 +1448,12 @@ void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long l
   *eligible = bulk_eligible(*ni, *nd);
 }
 
+void DenseMap::level_tuning(int grid_groups, long long spin_limit) {
+  if (!lv_) lv_ = new LevelEngine;
+  if (grid_groups >= 0) lv_->grid_groups = grid_groups;
+  if (spin_limit >= 0) lv_->spin_limit = (uint32_t)spin_limit;
+}
+
 int DenseMap::level_trace(uint32_t *out48) const {
   memset(out48, 0, 48 * sizeof(uint32_t));
   if (!lv_ || !lv_->h_ctl) return 0;
@@ -1491,7 +1497,7 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
   }
   host_counts_[0] = host_counts_[1] = 0;  // (k_level_run clears the device's queue counters)
   int64_t launches = 0;
-  const LevelEngine::Outcome how = lv_->run(sp, a, stream_, lv_done_, update_engine_ == 3, &launches);
+  const LevelEngine::Outcome how = lv_->run(sp, a, stream_, lv_done_, update_engine_ == 3, ni + nd <= (unsigned long long)LevelEngine::kTiny, &launches);
   const LevelCtl &c = *lv_->h_ctl;
   if (how == LevelEngine::kDone) {
     h_counters_fresh_ = false;
@@ -1505,6 +1511,7 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
       st->voxel_writes = (int64_t)c.writes;
       st->invalidated = (int64_t)c.invalidated;
       st->levels = 1;
+      st->grid_levels = (int64_t)c.grid_levels;
       st->prof[0] = (int64_t)c.ticks * 10, st->prof[1] = (int64_t)c.level;  // ns inside k_level_run, levels
       for (int k = 0; k < 4; ++k) st->prof[2 + k] = (int64_t)c.phase[k] * 10;
       st->prof[6] = (int64_t)c.items, st->prof[7] = (int64_t)c.peak;
@@ -1512,13 +1519,15 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
     return true;
   }
   if (st) st->prof[1] = (int64_t)c.level, st->prof[6] = (int64_t)c.items, st->prof[7] = (int64_t)c.peak;  // (how far the levels got)
-  if (how == LevelEngine::kHandOver) {  // the frontier grew beyond one work-group's reach: its entries become active tiles
+  if (how == LevelEngine::kAbort)  // k_level_grid gave up between two phases: both repairs below, the list's first
+    FIESTA_HIP_CHECK(hipMemsetAsync(&lv_->ctl->overflow, 0, sizeof(uint32_t), stream_));  // (k_level_pull skips a given-up update)
+  if (how == LevelEngine::kHandOver || how == LevelEngine::kAbort) {  // the frontier grew beyond the level engine's reach: its entries become active tiles
     a.level = c.level;  // (phase A of the level the engine stopped in front of: see k_level_list_to_tiles)
     hipLaunchKernelGGL((k_level_pull<DenseSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
     hipLaunchKernelGGL((k_level_list_to_tiles<DenseSpace>), dim3(16), dim3(256), 0, stream_, sp, a, tg, tile_flag_[0], tile_list_[0],
                        &counters_[C_LIST0]);
     FIESTA_HIP_CHECK(hipGetLastError());
-    return false;
+    if (how == LevelEngine::kHandOver) return false;
   }
   // Overflow.  What the level engine left behind: frontier tags on queued voxels, reset orphans that still carry their
   // dead id, and -- if the scan's own lists overflowed -- orphans outside the window that nobody touched.  The ordinary scan

@@ -117,6 +117,7 @@ class DenseMap {
   int update_engine() const { return update_engine_; }
   void set_update_engine(int e) { update_engine_ = e; }
   int level_trace(uint32_t *out48) const;  // fiesta_hip_level_trace
+  void level_tuning(int grid_groups, long long spin_limit);  // fiesta_hip_level_tuning
   void set_alone_in_group(bool alone) { alone_in_group_ = alone; }
   bool bulk_pays(double delta, double nocc, double n) const;  // is the fixed sweep cheaper than the frontier rounds?
   static bool bulk_pays_model(double delta, double nocc, double n, double ft_last_ms, double bulk_ratio);

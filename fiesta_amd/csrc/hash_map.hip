@@ -1102,6 +1102,12 @@ void HashMap::run_rounds(fiesta_hip_stats *st, uint32_t first_count) {
   }
 }
 
+void HashMap::level_tuning(int grid_groups, long long spin_limit) {
+  if (!lv_) lv_ = new LevelEngine;
+  if (grid_groups >= 0) lv_->grid_groups = grid_groups;
+  if (spin_limit >= 0) lv_->spin_limit = (uint32_t)spin_limit;
+}
+
 int HashMap::level_trace(uint32_t *out48) const {
   memset(out48, 0, 48 * sizeof(uint32_t));
   if (!lv_ || !lv_->h_ctl) return 0;
@@ -1142,7 +1148,7 @@ bool HashMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned l
   }
   host_ni_ = host_nd_ = 0;  // (k_level_run clears the device's queue counters)
   int64_t launches = 0;
-  const LevelEngine::Outcome how = lv_->run(sp, a, stream_, lv_done_, update_engine_ == 3, &launches);
+  const LevelEngine::Outcome how = lv_->run(sp, a, stream_, lv_done_, update_engine_ == 3, ni + nd <= (unsigned long long)LevelEngine::kTiny, &launches);
   const LevelCtl &c = *lv_->h_ctl;
   if (how == LevelEngine::kDone) {
     if (st) {
@@ -1154,19 +1160,22 @@ bool HashMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned l
       st->voxel_writes = (int64_t)c.writes;
       st->invalidated = (int64_t)c.invalidated;
       st->levels = 1;
+      st->grid_levels = (int64_t)c.grid_levels;
       st->prof[0] = (int64_t)c.ticks * 10, st->prof[1] = (int64_t)c.level;  // ns inside k_level_run, levels
       for (int k = 0; k < 4; ++k) st->prof[2 + k] = (int64_t)c.phase[k] * 10;
       st->prof[6] = (int64_t)c.items, st->prof[7] = (int64_t)c.peak;
     }
     return true;
   }
-  if (how == LevelEngine::kHandOver) {  // (see DenseMap::run_levels)
+  if (how == LevelEngine::kAbort)  // (see DenseMap::run_levels)
+    FIESTA_HIP_CHECK(hipMemsetAsync(&lv_->ctl->overflow, 0, sizeof(uint32_t), stream_));
+  if (how == LevelEngine::kHandOver || how == LevelEngine::kAbort) {
     a.level = c.level;  // (phase A of the level the engine stopped in front of: see k_level_list_to_tiles)
     hipLaunchKernelGGL((k_level_pull<PagedSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
     hipLaunchKernelGGL((k_level_list_to_tiles<PagedSpace>), dim3(16), dim3(256), 0, stream_, sp, a, tg, tile_flag_[0], tile_list_[0],
                        &counters_[C_LIST0]);
     FIESTA_HIP_CHECK(hipGetLastError());
-    return false;
+    if (how == LevelEngine::kHandOver) return false;
   }
   if (nd) {  // (see DenseMap::run_levels)
     hipLaunchKernelGGL(k_h_invalidate<false>, dim3(grid_for(nvox / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, (const int32_t *)dir_,

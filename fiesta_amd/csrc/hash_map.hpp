@@ -72,6 +72,7 @@ class HashMap {
   void update_esdf(fiesta_hip_stats *st);
   void set_update_engine(int e) { update_engine_ = e; }
   int level_trace(uint32_t *out48) const;  // fiesta_hip_level_trace
+  void level_tuning(int grid_groups, long long spin_limit);  // fiesta_hip_level_tuning
   void get_distance_vox(const int32_t *vox, int64_t n, double *out);
   void get_distance_pos(const double *pos, int64_t n, double *out);
   void get_dist_grad(const double *pos, int64_t n, double *dist, double *grad);

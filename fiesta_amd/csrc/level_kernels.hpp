@@ -55,7 +55,12 @@ struct LevelCtl {
   uint32_t phase[4];  // of that, thread 0's view: fetch + pull, barrier, push, append + barriers
   uint32_t items;     // frontier entries processed, summed over the levels (statistics)
   uint32_t peak;      // the largest frontier
-  uint32_t trace[48]; // the first levels of k_level_run: entries << 16 | duration in 10 ns units (statistics)
+  uint32_t trace[48]; // the first levels of the update: entries << 16 | duration in 10 ns units (statistics)
+  // k_level_grid (one slot per launch of it within an update):
+  uint32_t bar[8];    // arrivals at its barriers (monotonic: barrier k is over when the count reaches k x work-groups)
+  uint32_t xccs[8];   // bit x: a participating work-group ran on XCD x (more than one bit: the launch leaves the field alone)
+  uint32_t grid_refused;  // ... and says so here
+  uint32_t grid_levels;   // levels k_level_grid ran (statistics)
 };
 
 struct LevelArgs {
@@ -67,7 +72,13 @@ struct LevelArgs {
   LevelCtl *ctl_other; // the NEXT update's control block: k_level_run clears it (no memset on the next update's path)
   uint32_t cap;        // entries a list holds
   uint32_t single_cap; // k_level_run leaves a frontier larger than this to the multi-work-group kernels
-  uint32_t level;      // k_level_pull / k_level_push: which level this launch is (host-side count; the device checks)
+  uint32_t level;      // which level this launch starts at / is (host-side count; the device checks); kLvAny: ask the device
+  uint32_t grid_min;   // k_level_grid leaves a frontier of at most this many entries to k_level_run again
+  uint32_t grid_max;   // ... and one of more than this many to the frontier rounds (an update that large is cheaper there)
+  uint32_t bar;        // k_level_grid: its slot in LevelCtl::bar / xccs
+  uint32_t *flags;     // k_level_grid: one word per participating work-group (its latest barrier number), one 128-byte line
+  uint32_t bar_base;   // k_level_grid: barrier numbers of this launch start above this (never reused: the flags are never reset)
+  uint32_t spin_limit; // k_level_grid: polls a barrier waits before it gives the update up (0: at once -- tests of the recovery)
   unsigned long long *counters;
   int track;           // maintain counters[C_MAXD2]
 };
@@ -75,6 +86,7 @@ struct LevelArgs {
 // phase A's verdict, one word per frontier entry
 constexpr uint32_t kLvNone = 0xFFFFFFFFu;   // nothing to do (no obstacle yet, inside the window: a push will find it)
 constexpr uint32_t kLvWait = 0xFFFFFFFEu;   // no obstacle yet, OUTSIDE the window: ask again next level
+constexpr uint32_t kLvAny = 0xFFFFFFFFu;    // LevelArgs::level: "whatever level the control block says"
 constexpr uint32_t kLvPush = 0x40000000u;   // | id: did not improve, offers this obstacle to its neighbours
                                             // otherwise: the id it improved to
 
@@ -527,9 +539,12 @@ __global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
   // (the host names the level this launch starts at: the counters and the list are then requested together, one memory
   //  latency in front of the first level instead of three)
   uint32_t level = a.level;
+  if (level == kLvAny) level = ctl->level;  // (a launch behind k_level_grid: the host does not know how far that got)
   const uint32_t first = (uint32_t)tid < (uint32_t)CAP ? a.list[level & 1u][tid] : 0u;  // (a list holds far more than CAP entries)
   uint32_t n = ctl->n[level % 3u], nwait = ctl->nwait[level % 3u], work = 0;
-  bool fits = ctl->overflow == 0;
+  const uint32_t found_overflow = ctl->overflow;
+  if (found_overflow) return;  // (the update was given up ahead of this launch: the host picks up the pieces)
+  bool fits = true;
   if (tid == 0) s_wrote = 0, s_maxd2 = 0;
   bool in_lds = n <= (uint32_t)CAP;  // the current frontier is (also) in s_list
   static_assert(CAP <= NT, "one entry per thread loads the list");
@@ -633,12 +648,214 @@ __global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
     ctl->n[level % 3u] = min(n, a.cap), ctl->nwait[level % 3u] = nwait;
     ctl->n[(level + 1u) % 3u] = 0, ctl->nwait[(level + 1u) % 3u] = 0;
     ctl->n[(level + 2u) % 3u] = 0, ctl->nwait[(level + 2u) % 3u] = 0;
-    if (!fits || work >= 65536u) ctl->overflow = 1;
+    if (!found_overflow && (!fits || work >= 65536u)) ctl->overflow = 1;
     ctl->writes += s_wrote;
     ctl->work += work;
     if (s_maxd2 > ctl->maxd2) ctl->maxd2 = s_maxd2;
     if (a.track && s_maxd2) atomicMax(&a.counters[C_MAXD2], (unsigned long long)s_maxd2);
     ctl->ticks += (uint32_t)(wall_clock64() - t_in);
+  }
+}
+
+// ---- wide levels: one launch, many work-groups, barriers between them --------------------------------------------------
+// k_level_run is one work-group on one CU: a level of n entries costs it ~2.5 us + n x 40 ns of instruction issue.  Here
+// the same two phases run on up to 32 CUs, with a counter barrier where k_level_run has __syncthreads.  What makes that
+// affordable is that all participating work-groups share ONE L2: the XCDs' L2s are not coherent with each other, so a
+// barrier across XCDs would need an agent-scope release + acquire on every CU per phase (~3.5 us each, twice a level);
+// inside one XCD the field is coherent through the L2 for the loads that bypass the L1 (lv_load<true>) and the
+// read-modify-writes the phases already use.  Placement is not promised by HIP, so it is CHECKED: the launch has 8 x G
+// work-groups, those with blockIdx % 8 == 0 take part (observed: they share an XCD), each records the XCD it runs on
+// (HW_REG_XCC_ID) before the first barrier -- through read-modify-writes, which are coherent anywhere -- and if more than
+// one XCD shows up every work-group leaves before touching the field: k_level_run (launched behind this kernel anyway)
+// goes on alone and the host stops asking for the grid.  A different placement changes the speed, never the result.
+// Every wait is bounded: a barrier that is not complete after `spin_limit` polls sets overflow = 2, all work-groups
+// leave, and the host rebuilds the frontier-round engine's state from the tags in the field (LevelEngine::kAbort).
+struct LvGridSync {
+  uint32_t *count;     // LevelCtl::bar[slot]: arrivals at the FIRST barrier (read-modify-writes: coherent on any placement)
+  uint32_t *overflow;  // LevelCtl::overflow
+  uint32_t *flags;     // all later barriers: work-group g stores the barrier's number into flags[g], wave 0 of everybody reads
+  uint32_t base;       //   the 32 words with one load per poll.  Plain stores stay in the XCD's L2 and loads that bypass the L1
+  uint32_t g, groups, limit, done;  // are served from it: ~0.7 us a barrier where a counter of atomics costs ~2.5 (an atomic
+  uint32_t *s_ok;      //   drops its line from the L2, so every poll behind one goes to memory).  Same-XCD only -- checked first.
+  __device__ inline bool give_up() {
+    (void)__hip_atomic_fetch_max(overflow, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  // Every memory operation of the calling work-group is complete when its arrival is published (__syncthreads waits for
+  // each wave's outstanding loads, stores and atomics).  Both forms return false if the update is being given up.
+  __device__ inline bool first() {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      (void)__hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t polls = 0;
+      bool ok = true;
+      while (__hip_atomic_fetch_add(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups) {
+        if (polls++ >= limit || __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          ok = give_up();
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      *s_ok = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    return *s_ok != 0u;
+  }
+  __device__ inline bool operator()() {
+    __syncthreads();
+    const uint32_t target = base + ++done;
+    if (threadIdx.x < 64u) {
+      const uint32_t lane = threadIdx.x;
+      if (lane == 0) __hip_atomic_store(flags + g, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      uint32_t polls = 0;
+      bool ok = true;
+      for (;;) {
+        // lanes 0 .. groups-1: the flags; lane 32: has somebody given up?
+        const uint32_t *p = lane < groups ? flags + lane : overflow;
+        const uint32_t f = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__any(lane == 32u && f != 0u) || polls++ >= limit) {
+          ok = give_up();
+          break;
+        }
+        if (__all(lane >= groups || (int32_t)(f - target) >= 0)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (lane == 0) *s_ok = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    return *s_ok != 0u;
+  }
+};
+
+template <class S, int NT>
+__global__ __launch_bounds__(NT) void k_level_grid(S sp, LevelArgs a) {
+  if (blockIdx.x & 7u) return;
+  __shared__ uint32_t s_ok, s_wrote, s_maxd2;
+  LevelCtl *ctl = a.ctl;
+  const int tid = threadIdx.x;
+  const uint32_t g = blockIdx.x >> 3, G = gridDim.x >> 3;
+  // the state the previous launch left (every work-group reads the same words: they all take the same way)
+  uint32_t level = ctl->level;
+  if (ctl->overflow || ctl->grid_refused) return;
+  uint32_t n = ctl->n[level % 3u], nwait = ctl->nwait[level % 3u];
+  if (n == 0 || n == nwait || n <= a.grid_min || n > a.grid_max) return;
+  const unsigned long long t_in = wall_clock64();
+  LvGridSync sync{&ctl->bar[a.bar], &ctl->overflow, a.flags, a.bar_base, g, G, a.spin_limit, 0u, &s_ok};
+  if (tid == 0) {
+    s_wrote = 0, s_maxd2 = 0;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // hwreg(HW_REG_XCC_ID, 0, 4)
+    (void)__hip_atomic_fetch_or(&ctl->xccs[a.bar], 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!sync.first()) return;
+  {  // (a read-modify-write reads the word where the other XCDs' read-modify-writes went)
+    const uint32_t seen = __hip_atomic_fetch_or(&ctl->xccs[a.bar], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__popc(seen) != 1) {
+      if (g == 0 && tid == 0) ctl->grid_refused = 1;
+      return;
+    }
+  }
+  LvDirs dr;
+  dr.init(sp);
+  constexpr uint32_t QT = NT / 4;  // entries a pass of one work-group covers
+  uint32_t wrote = 0, maxd2 = 0, work = 0;
+  bool fits = true;
+  for (;;) {
+    const uint32_t *in = a.list[level & 1u];
+    uint32_t *out = a.list[(level + 1u) & 1u];
+    uint32_t *n_next = &ctl->n[(level + 1u) % 3u], *w_next = &ctl->nwait[(level + 1u) % 3u];
+    auto put = [&](uint32_t at, uint32_t e) {
+      if (at < a.cap) out[at] = e;
+    };
+    auto clear_slot = [&]() {  // the counters read last a level ago and appended to next level (written where the appends will go)
+      if (g == 0 && tid == 0) {
+        __hip_atomic_store(&ctl->n[(level + 2u) % 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->nwait[(level + 2u) % 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
+    const unsigned long long p0 = wall_clock64();
+    unsigned long long p1 = p0, p2 = p0, p3 = p0;
+    // this work-group's share: whole waves (16 entries), the same for everybody
+    const uint32_t per = ((n + G - 1u) / G + 15u) & ~15u;
+    const uint32_t lo = min(n, g * per), hi = min(n, lo + per);
+    bool ok;
+    if (per <= QT) {  // one pass: the stencil stays in registers between the phases
+      LvItem it;
+      const uint32_t i = lo + ((uint32_t)tid >> 2);
+      const bool live = i < hi;
+      const uint32_t e = live ? lv_load<true>(in + i) : 0u;
+      uint32_t verdict = kLvNone;
+      if (__ballot(live)) {
+        lv_fetch<S, true>(sp, a.coc, e, live, dr, it);
+        verdict = lv_pull<S, false>(sp, a.coc, it, dr);
+      }
+      if (verdict == 0x12345678u) ++wrote;  // (keeps the verdict -- and the loads behind it -- ahead of the clock read)
+      p1 = wall_clock64();
+      ok = sync();  // every pull has read the field
+      p2 = wall_clock64();
+      if (ok) {
+        clear_slot();
+        if (__ballot(live && verdict != kLvNone)) wrote += lv_push<S, false>(sp, a.coc, e, it, dr, live ? verdict : kLvNone, n_next, w_next, maxd2, put);
+      }
+      p3 = wall_clock64();
+    } else {  // several passes: the verdicts wait in memory, the stencil is fetched again (as k_level_pull / k_level_push do)
+      for (uint32_t i = lo + ((uint32_t)tid >> 2); i < lo + per; i += QT) {
+        LvItem it;
+        const bool live = i < hi;
+        if (!__ballot(live)) continue;
+        lv_fetch<S, true>(sp, a.coc, live ? lv_load<true>(in + i) : 0u, live, dr, it);
+        const uint32_t verdict = lv_pull<S, false>(sp, a.coc, it, dr);
+        if (live && dr.q == 0) a.res[i] = verdict;
+      }
+      ok = sync();
+      if (ok) {
+        clear_slot();
+        for (uint32_t i = lo + ((uint32_t)tid >> 2); i < lo + per; i += QT) {
+          const bool live = i < hi;
+          const uint32_t verdict = live ? lv_load<true>(a.res + i) : kLvNone;
+          if (!__ballot(verdict != kLvNone)) continue;
+          LvItem it;
+          const uint32_t e = live ? lv_load<true>(in + i) : 0u;
+          lv_fetch<S, true>(sp, a.coc, e, live && verdict != kLvNone && verdict != kLvWait, dr, it);
+          wrote += lv_push<S, false>(sp, a.coc, e, it, dr, verdict, n_next, w_next, maxd2, put);
+        }
+      }
+    }
+    if (ok) ok = sync();  // every push has landed, every append is counted
+    if (!ok) {
+      fits = false;
+      break;
+    }
+    const uint32_t n_was = n;
+    n = __hip_atomic_load(n_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nwait = __hip_atomic_load(w_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ++level, ++work;
+    if (g == 0 && tid == 0) {  // the control block follows level by level: a launch that is given up leaves a consistent count
+      ctl->level = level;
+      ctl->items += n_was, ctl->peak = max(ctl->peak, n_was);
+      const unsigned long long p4 = wall_clock64();  // (work-group 0's view, like k_level_run's: pull, barrier, push, barrier + counts)
+      ctl->phase[0] += (uint32_t)(p1 - p0), ctl->phase[1] += (uint32_t)(p2 - p1), ctl->phase[2] += (uint32_t)(p3 - p2), ctl->phase[3] += (uint32_t)(p4 - p3);
+      if (level <= 48u) ctl->trace[level - 1u] = (min(n_was, 0xFFFFu) << 16) | (uint32_t)min((unsigned long long)0xFFFFu, wall_clock64() - p0);
+    }
+    if (n > a.cap) {  // the list is full: the frontier-round engine has to finish (all work-groups read the same count)
+      if (g == 0 && tid == 0) ctl->n[level % 3u] = a.cap, (void)__hip_atomic_fetch_max(&ctl->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    if (n == 0 || n == nwait || n <= a.grid_min || n > a.grid_max || work >= 65536u) break;
+  }
+  (void)fits;
+  if (wrote) atomicAdd(&s_wrote, wrote);
+  if (maxd2) atomicMax(&s_maxd2, maxd2);
+  __syncthreads();
+  if (tid == 0) {
+    if (s_wrote) atomicAdd(&ctl->writes, s_wrote);
+    if (s_maxd2) {
+      atomicMax(&ctl->maxd2, s_maxd2);
+      if (a.track) atomicMax(&a.counters[C_MAXD2], (unsigned long long)s_maxd2);
+    }
+    if (g == 0) {
+      ctl->work += work, ctl->grid_levels += work;
+      ctl->ticks += (uint32_t)(wall_clock64() - t_in);
+    }
   }
 }
 
@@ -784,15 +1001,24 @@ __global__ void k_level_list_to_tiles(S sp, LevelArgs a, TileGrid tg, uint32_t *
 
 // ---- host side: buffers and the launch sequence, shared by both map classes ------------------------------------------
 struct LevelEngine {
-  DevBuf<uint32_t> list[2], res, outside;
+  DevBuf<uint32_t> list[2], res, outside, flags;
+  uint32_t grid_launches = 0;
   LevelCtl *ctl2 = nullptr;   // device: two blocks, alternating between updates (the idle one is cleared by k_level_run)
   LevelCtl *ctl = nullptr;    // the current update's
   LevelCtl *h_ctl = nullptr;  // pinned
   uint32_t serial = 0;
   uint32_t cap = 0;
   static constexpr uint32_t kSingleCap = 512;  // frontier one work-group keeps to itself: two entries per quad of lanes
-  enum Outcome { kDone = 0, kOverflow = 1, kHandOver = 2 };
+  static constexpr uint32_t kGridEnter = 192;  // ... and what it keeps while k_level_grid stands behind it (7-10 us a level there)
+  static constexpr uint32_t kGridMin = 64;     // frontier k_level_grid gives back to the one work-group
+  static constexpr uint32_t kGridMax = 4096;   // frontier beyond which an update goes to the frontier rounds (pinned to this engine:
+                                               // on as pairs of launches over all CUs, which beat one XCD from ~10 k entries)
+  static constexpr uint32_t kTiny = 8;         // inserts + deletes of an update that is launched without the grid behind it
+  enum Outcome { kDone = 0, kOverflow = 1, kHandOver = 2, kAbort = 3 };
   static constexpr int kNT = 1024;
+  int grid_groups = 32;          // work-groups of k_level_grid that take part (one XCD has 32 CUs); 0: never launch it
+  uint32_t spin_limit = 1u << 18;  // polls one of its barriers waits (~0.2 s) before the update is given up
+  bool grid_ok = true;           // until a launch found its work-groups on more than one XCD
   ~LevelEngine() {
     if (ctl2) (void)hipFree(ctl2);
     if (h_ctl) (void)hipHostFree(h_ctl);
@@ -803,6 +1029,8 @@ struct LevelEngine {
       FIESTA_HIP_CHECK(hipMemsetAsync(ctl2, 0, 2 * sizeof(LevelCtl), s));
       FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_ctl, sizeof(LevelCtl)));
       ctl = ctl2;
+      flags.ensure_exact(64, s);
+      FIESTA_HIP_CHECK(hipMemsetAsync(flags.p, 0, 64 * sizeof(uint32_t), s));
     }
     if (want <= cap) return;
     for (auto &l : list) l.ensure_exact(want, s);
@@ -821,33 +1049,57 @@ struct LevelEngine {
     a.cap = cap;
     a.single_cap = kSingleCap;
     a.level = 0;
+    a.grid_min = kGridMin;
+    a.grid_max = kGridMax;
+    a.bar = 0;
+    a.flags = flags.p;
+    a.bar_base = 0;
+    a.spin_limit = spin_limit;
     a.counters = counters;
     a.track = track ? 1 : 0;
     return a;
   }
   // a new update: the block the previous update's k_level_run cleared
   void begin() { ctl = ctl2 + (++serial & 1u); }
-  // Runs the levels.  kDone: the update is finished.  kOverflow: a list overflowed, the caller rebuilds the rounds' state by
-  // a scan (k_level_to_tiles).  kHandOver (only if !wide): a level outgrew the one work-group; the current frontier is in
-  // the list, the caller passes it to the rounds (k_level_list_to_tiles).  wide: such levels go on as launches over many
-  // work-groups instead.  One host round trip per chain; a sensor frame's update is one launch and one round trip.
+  // Runs the levels.  One chain of launches = k_level_run (narrow levels) -> k_level_grid (wide ones, one XCD's CUs) ->
+  // k_level_run (the tail), each of which finds out on the device whether there is anything for it; one host round trip per
+  // chain, and a sensor frame's update is one chain.  `tiny`: a handful of seeds -- the first chain is k_level_run alone.
+  // kDone: the update is finished.  kOverflow: a list overflowed, the caller rebuilds the rounds' state by a scan
+  // (k_level_to_tiles).  kAbort: k_level_grid gave up at a barrier; the caller does both of the following.  kHandOver (only
+  // if !wide, and only without the grid): a level outgrew the one work-group; the current frontier is in the list, the
+  // caller passes it to the rounds (k_level_list_to_tiles).  wide, without the grid: such levels go on as pairs of launches.
   // `done` is recorded behind the last kernel of every chain: when run() returns it marks the end of the levels' device work.
   template <class S>
-  Outcome run(const S &sp, LevelArgs a, hipStream_t s, hipEvent_t done, bool wide, int64_t *launches) {
-    a.level = 0;
+  Outcome run(const S &sp, LevelArgs a, hipStream_t s, hipEvent_t done, bool wide, bool tiny, int64_t *launches) {
+    uint32_t slot = 0;
+    bool first = true;
     for (;;) {
+      const bool grid = grid_ok && grid_groups > 0 && slot < 8u && !(first && tiny);
+      a.level = first ? 0u : kLvAny;
+      a.single_cap = grid ? kGridEnter : kSingleCap;
       hipLaunchKernelGGL((k_level_run<S, kNT, (int)kSingleCap>), dim3(1), dim3(kNT), 0, s, sp, a);
-      FIESTA_HIP_CHECK(hipGetLastError());
       ++*launches;
+      if (grid) {
+        a.level = kLvAny, a.bar = slot++;
+        a.bar_base = (++grid_launches) << 18;  // (2^18 barriers a launch: 65536 levels is the bound of one update)
+        hipLaunchKernelGGL((k_level_grid<S, kNT>), dim3(8 * grid_groups), dim3(kNT), 0, s, sp, a);
+        a.single_cap = kSingleCap;
+        hipLaunchKernelGGL((k_level_run<S, kNT, (int)kSingleCap>), dim3(1), dim3(kNT), 0, s, sp, a);
+        *launches += 2;
+      }
+      first = false;
+      FIESTA_HIP_CHECK(hipGetLastError());
       FIESTA_HIP_CHECK(hipEventRecord(done, s));
       FIESTA_HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(LevelCtl), hipMemcpyDeviceToHost, s));
       FIESTA_HIP_CHECK(hipStreamSynchronize(s));
       for (;;) {
+        if (h_ctl->overflow == 2u) return kAbort;
         if (h_ctl->overflow) return kOverflow;
+        if (h_ctl->grid_refused) grid_ok = false;
         const uint32_t l = h_ctl->level, n = h_ctl->n[l % 3u];
         if (n == 0 || n == h_ctl->nwait[l % 3u]) return kDone;
         a.level = l;
-        if (n <= a.single_cap) break;  // small again: back to the one work-group
+        if (n <= kSingleCap || (grid_ok && grid_groups > 0 && slot < 8u && n <= a.grid_max)) break;  // another chain
         if (!wide) return kHandOver;
         // a chain of wide levels; work-groups in proportion to the frontier this chain starts with
         const int blocks = (int)std::min<uint32_t>((n + 63u) / 64u * 2u, 16384u), chain = 8;  // (64 entries per work-group pass)

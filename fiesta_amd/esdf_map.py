@@ -158,6 +158,11 @@ class ESDFMap:
         check(self._lib.fiesta_hip_level_trace(self._h, out, C.byref(n)))
         return [(int(w) >> 16, (int(w) & 0xFFFF) / 100.0) for w in list(out)[: min(n.value, 48)]], n.value
 
+    def level_tuning(self, grid_groups=-1, spin_limit=-1):
+        """Diagnostics of the level engine's wide levels (fiesta_hip_level_tuning): work-groups that take part (0: off), polls
+        a barrier among them waits before the update is given up (0: at once)."""
+        check(self._lib.fiesta_hip_level_tuning(self._h, int(grid_groups), int(spin_limit)))
+
     @property
     def only_levels(self) -> bool:
         """Every UpdateESDF of this map so far that had work ran the level engine from start to end (fiesta_hip_stats.levels):

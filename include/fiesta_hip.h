@@ -85,6 +85,7 @@ typedef struct fiesta_hip_stats {
   int64_t levels;        /* 1: this update ran the level engine from start to end (rounds = its levels, one per layer of the
                             reference's FIFO); 0 with bulk == 0: the frontier rounds ran (possibly after the level engine's
                             lists overflowed) */
+  int64_t grid_levels;   /* of `rounds` with levels == 1: levels that ran on many CUs (k_level_grid) rather than one */
 } fiesta_hip_stats;
 
 const char *fiesta_hip_last_error(void);
@@ -137,6 +138,11 @@ int fiesta_hip_set_update_engine(fiesta_hip_map *m, int32_t engine);
  * the level took inside the one-work-group kernel in units of 10 ns (low 16 bits).  *n_levels = levels of that update
  * (may exceed 48).  No reference counterpart. */
 int fiesta_hip_level_trace(fiesta_hip_map *m, uint32_t out[48], int32_t *n_levels);
+/* Diagnostics of the level engine's wide levels (k_level_grid): `grid_groups` work-groups of one XCD take part
+ * (0..32; 0: never launched -- wide frontiers go to the frontier rounds as before); a barrier among them waits `spin_limit`
+ * polls (~1 us each) before the update is given up and repaired by the frontier rounds (0: gives up at its first barrier --
+ * how the tests reach that path).  Negative values leave a setting as it is.  Defaults: 32, 262144. */
+int fiesta_hip_level_tuning(fiesta_hip_map *m, int32_t grid_groups, int64_t spin_limit);
 
 /* ---- occupancy ingest: ESDFMap::SetOccupancy x2 (src/ESDFMap.cpp:401-437), batched ----
  * Observations are applied as if SetOccupancy had been called once per entry; hit/total counters are

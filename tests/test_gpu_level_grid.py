@@ -1,0 +1,114 @@
+"""The level engine's wide levels (fiesta_amd/csrc/level_kernels.hpp: k_level_grid): many work-groups of one XCD behind
+counter / flag barriers.  Three ways through the same update must agree: with the grid, without it (wide levels as pairs
+of launches: the kernel boundary is the barrier), and with a grid that gives up at its first barrier (the frontier rounds
+repair the update).  The reference (src/ESDFMap.cpp:273-398) is the judge of all three."""
+import numpy as np
+import pytest
+
+from scenarios import P_DEFAULT, all_voxels, assert_envelope, assert_exact, compare_dense, Both, EnvelopeOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(oracle_libs, kind, n, engine, envelope=0, grid_groups=-1, spin_limit=-1):
+    import fiesta_amd
+    res = 0.1
+    size = tuple(np.asarray(n) * res)
+    gpu = fiesta_amd.ESDFMap((0, 0, 0), res, size, update_engine=engine)
+    gpu.level_tuning(grid_groups, spin_limit)
+    mk = lambda: oracle_libs.OracleMap((0, 0, 0), res, size, kind=kind)   # noqa: E731
+    cpu = EnvelopeOracle(mk, k=envelope) if envelope else mk()
+    b = Both(gpu, cpu)
+    b.params()
+    gpu.SetOriginalRange()
+    cpu.SetOriginalRange()
+    return b
+
+
+def _wide_update(b, seed, partial):
+    """A delta whose frontier grows to thousands of entries: 400 obstacles into an empty observed map, then half of them
+    deleted and 200 new ones in ONE update."""
+    rng = np.random.RandomState(seed)
+    gs = np.array(b.gpu.grid_size)
+    g = all_voxels(b.gpu.grid_size)
+    if partial:
+        blocks = rng.rand(*(gs // 4 + 1)) > 0.25
+        keep = blocks[g[:, 0] // 4, g[:, 1] // 4, g[:, 2] // 4]
+        g = g[keep]
+    b.observe(g, 0)
+    b.fuse()
+    b.esdf()
+    S = g[rng.choice(len(g), 400, replace=False)]
+    b.make_occupied(S)
+    st1, _ = b.esdf()
+    T = g[rng.choice(len(g), 200, replace=False)]
+    b.mixed(T, S[:200])
+    st2, _ = b.esdf()
+    return st1, st2
+
+
+@pytest.mark.parametrize("partial", [False, True], ids=["observed", "partial"])
+def test_grid_levels_match_the_reference(hip_lib, oracle_libs, best_oracle_kind, partial):
+    b = _pair(oracle_libs, best_oracle_kind, (64, 64, 48), "levels", envelope=4 if partial else 0)
+    st1, st2 = _wide_update(b, 5, partial)
+    assert st1["levels"] == 1 and st2["levels"] == 1
+    assert st1["grid_levels"] > 0 and st2["grid_levels"] > 0, (st1, st2)   # the grid took part (one XCD found)
+    rep = compare_dense(b.gpu, b.cpu)
+    if partial:
+        assert_envelope(rep, "wide levels on the grid", strict=True)
+        assert rep["pair_violations"] == 0, rep
+    else:
+        assert_exact(rep)
+
+
+def test_grid_and_launch_pairs_run_the_same_schedule(hip_lib, oracle_libs, best_oracle_kind):
+    """A wide level is the same two phases on 32 work-groups, on 8 (several passes each: the verdicts wait in memory) and as
+    a pair of launches (0: no grid).  Inside a level the order of the pushes is free: equal candidates may tie differently
+    from run to run (as in the reference), so the three fields are compared up to a handful of voxels -- and the first
+    with the reference's order spread (this delta, inserts and deletes in one update of a fragmentary map, is one the
+    level schedule does NOT follow strictly: the reference drains its whole insert queue ahead of the delete queue)."""
+    fields = []
+    for groups in (32, 8, 0):
+        b = _pair(oracle_libs, best_oracle_kind, (64, 64, 48), "levels", envelope=4 if groups == 32 else 0, grid_groups=groups)
+        st1, st2 = _wide_update(b, 9, True)
+        assert st2["levels"] == 1
+        assert (st2["grid_levels"] > 0) == (groups > 0)
+        if groups == 32:
+            rep = compare_dense(b.gpu, b.cpu)
+            assert_envelope(rep, "wide levels, inserts and deletes in one update")
+            assert rep["pair_violations"] == 0, rep
+        fields.append(b.gpu.download_field(("d2",))["d2"])
+    finite = int((fields[0] >= 0).sum())
+    for f in fields[1:]:
+        differ = int((f != fields[0]).sum())
+        assert differ <= finite // 1000, (differ, finite)
+
+
+@pytest.mark.parametrize("partial", [False, True], ids=["observed", "partial"])
+def test_a_grid_that_gives_up_is_repaired_by_the_rounds(hip_lib, oracle_libs, best_oracle_kind, partial):
+    """spin_limit = 0: the first work-group that does not find everybody at the first barrier gives the update up.  The
+    frontier is still in the list; the frontier rounds finish -- same contract as any update they serve."""
+    b = _pair(oracle_libs, best_oracle_kind, (64, 64, 48), "levels", envelope=4 if partial else 0, spin_limit=0)
+    st1, st2 = _wide_update(b, 5, partial)
+    assert st1["levels"] == 0 and st1["rounds"] > 0, st1    # the level engine did not finish this one
+    rep = compare_dense(b.gpu, b.cpu)
+    if partial:
+        assert_envelope(rep, "grid gave up, rounds finished")
+        assert rep["pair_violations"] == 0, rep
+        spread = rep["envelope"]["disagree"]
+    else:
+        assert_exact(rep)
+    # ... and the engine goes on as before once the waits are long enough again
+    b.gpu.level_tuning(-1, 1 << 18)
+    rng = np.random.RandomState(77)
+    b.make_occupied(rng.randint(0, 48, (300, 3)).astype(np.int32))
+    st3, _ = b.esdf()
+    assert st3["levels"] == 1
+    rep = compare_dense(b.gpu, b.cpu)
+    if partial:
+        # (voxels the first two updates left inside that state's allowance and this one did not touch are still where they
+        #  were, while the runs' disagreement is counted anew: every engine shows ~45 such voxels here -- tools/dev/abort_experiment.py)
+        assert_envelope(rep, "after the repair", farther_allow=spread)
+        assert rep["pair_violations"] == 0, rep
+    else:
+        assert_exact(rep)
