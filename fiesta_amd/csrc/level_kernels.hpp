@@ -75,6 +75,7 @@ struct LevelArgs {
   uint32_t level;      // which level this launch starts at / is (host-side count; the device checks); kLvAny: ask the device
   uint32_t grid_min;   // k_level_grid leaves a frontier of at most this many entries to k_level_run again
   uint32_t grid_max;   // ... and one of more than this many to the frontier rounds (an update that large is cheaper there)
+  uint32_t items_max;  // ... as is an update that has processed more than this many frontier entries altogether
   uint32_t bar;        // k_level_grid: its slot in LevelCtl::bar / xccs
   uint32_t *flags;     // k_level_grid: one word per participating work-group (its latest barrier number), one 128-byte line
   uint32_t bar_base;   // k_level_grid: barrier numbers of this launch start above this (never reused: the flags are never reset)
@@ -739,6 +740,8 @@ __global__ __launch_bounds__(NT) void k_level_grid(S sp, LevelArgs a) {
   if (ctl->overflow || ctl->grid_refused) return;
   uint32_t n = ctl->n[level % 3u], nwait = ctl->nwait[level % 3u];
   if (n == 0 || n == nwait || n <= a.grid_min || n > a.grid_max) return;
+  uint32_t items = ctl->items;  // (entries processed so far: only work-group 0 writes it, at the end of a level)
+  if (items > a.items_max) return;
   const unsigned long long t_in = wall_clock64();
   LvGridSync sync{&ctl->bar[a.bar], &ctl->overflow, a.flags, a.bar_base, g, G, a.spin_limit, 0u, &s_ok};
   if (tid == 0) {
@@ -829,6 +832,7 @@ __global__ __launch_bounds__(NT) void k_level_grid(S sp, LevelArgs a) {
     n = __hip_atomic_load(n_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     nwait = __hip_atomic_load(w_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ++level, ++work;
+    items += n_was;
     if (g == 0 && tid == 0) {  // the control block follows level by level: a launch that is given up leaves a consistent count
       ctl->level = level;
       ctl->items += n_was, ctl->peak = max(ctl->peak, n_was);
@@ -840,7 +844,7 @@ __global__ __launch_bounds__(NT) void k_level_grid(S sp, LevelArgs a) {
       if (g == 0 && tid == 0) ctl->n[level % 3u] = a.cap, (void)__hip_atomic_fetch_max(&ctl->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
-    if (n == 0 || n == nwait || n <= a.grid_min || n > a.grid_max || work >= 65536u) break;
+    if (n == 0 || n == nwait || n <= a.grid_min || n > a.grid_max || items > a.items_max || work >= 65536u) break;
   }
   (void)fits;
   if (wrote) atomicAdd(&s_wrote, wrote);
@@ -1013,6 +1017,7 @@ struct LevelEngine {
   static constexpr uint32_t kGridMin = 64;     // frontier k_level_grid gives back to the one work-group
   static constexpr uint32_t kGridMax = 4096;   // frontier beyond which an update goes to the frontier rounds (pinned to this engine:
                                                // on as pairs of launches over all CUs, which beat one XCD from ~10 k entries)
+  static constexpr uint32_t kItemsMax = 16384; // frontier entries altogether beyond which an update goes to the frontier rounds (unless pinned)
   static constexpr uint32_t kTiny = 8;         // inserts + deletes of an update that is launched without the grid behind it
   enum Outcome { kDone = 0, kOverflow = 1, kHandOver = 2, kAbort = 3 };
   static constexpr int kNT = 1024;
@@ -1051,6 +1056,7 @@ struct LevelEngine {
     a.level = 0;
     a.grid_min = kGridMin;
     a.grid_max = kGridMax;
+    a.items_max = 0xFFFFFFFFu;
     a.bar = 0;
     a.flags = flags.p;
     a.bar_base = 0;
@@ -1073,6 +1079,7 @@ struct LevelEngine {
   Outcome run(const S &sp, LevelArgs a, hipStream_t s, hipEvent_t done, bool wide, bool tiny, int64_t *launches) {
     uint32_t slot = 0;
     bool first = true;
+    a.items_max = wide ? 0xFFFFFFFFu : kItemsMax;
     for (;;) {
       const bool grid = grid_ok && grid_groups > 0 && slot < 8u && !(first && tiny);
       a.level = first ? 0u : kLvAny;
@@ -1099,6 +1106,7 @@ struct LevelEngine {
         const uint32_t l = h_ctl->level, n = h_ctl->n[l % 3u];
         if (n == 0 || n == h_ctl->nwait[l % 3u]) return kDone;
         a.level = l;
+        if (h_ctl->items > a.items_max && n > kGridMin) return kHandOver;  // (a large update after all: cheaper on the frontier rounds)
         if (n <= kSingleCap || (grid_ok && grid_groups > 0 && slot < 8u && n <= a.grid_max)) break;  // another chain
         if (!wide) return kHandOver;
         // a chain of wide levels; work-groups in proportion to the frontier this chain starts with
