@@ -448,17 +448,20 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
         }
         if (LEVELS) {
           if (__ballot(rmask != 0)) {
-            bool fits = true;
+            uint32_t inside = 0, outside = 0;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
               const bool dead = (rmask >> k) & 1u;
               const bool inw = win_all || g.in_window(x, y, z8 + k);
               if (dead && inw) coc[base + z8 + k] = kReset | (w[r][k] & kIdMask);
-              fits &= lv_append(dead && inw, lv_pack(x, y, z8 + k), lv.list[0], &lv.ctl->n[0], lv.cap);
-              if (!win_all) fits &= lv_append(dead && !inw, lv_pack(x, y, z8 + k), lv.outside, &lv.ctl->nout, lv.cap);
+              inside |= (dead && inw) ? 1u << k : 0u;
+              outside |= (dead && !inw) ? 1u << k : 0u;
             }
+            auto entry = [&](int k) { return lv_pack(x, y, z8 + k); };
+            bool fits = lv_append_many<V>(inside, entry, lv.list[0], &lv.ctl->n[0], lv.cap);
+            if (!win_all) fits &= lv_append_many<V>(outside, entry, lv.outside, &lv.ctl->nout, lv.cap);
             if (!fits) lv.ctl->overflow = 1;
-            if (const uint32_t c = (uint32_t)__popc(rmask)) atomicAdd(&lv.ctl->invalidated, c);
+            local += __popc(rmask);
           }
           continue;
         }
@@ -494,7 +497,12 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
   if (lane == 0 && local) atomicAdd(&blk_local, local);
   __syncthreads();
-  if (threadIdx.x == 0 && blk_local) atomicAdd(&counters[C_INVALIDATED], blk_local);
+  if (threadIdx.x == 0 && blk_local) {
+    if (LEVELS)
+      atomicAdd(&lv.ctl->invalidated, (uint32_t)blk_local);  // (the level engine keeps its statistics in its control block)
+    else
+      atomicAdd(&counters[C_INVALIDATED], blk_local);
+  }
 }
 
 // =====================================================================================================
@@ -1523,9 +1531,11 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
     FIESTA_HIP_CHECK(hipMemsetAsync(&lv_->ctl->overflow, 0, sizeof(uint32_t), stream_));  // (k_level_pull skips a given-up update)
   if (how == LevelEngine::kHandOver || how == LevelEngine::kAbort) {  // the frontier grew beyond the level engine's reach: its entries become active tiles
     a.level = c.level;  // (phase A of the level the engine stopped in front of: see k_level_list_to_tiles)
-    hipLaunchKernelGGL((k_level_pull<DenseSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
-    hipLaunchKernelGGL((k_level_list_to_tiles<DenseSpace>), dim3(16), dim3(256), 0, stream_, sp, a, tg, tile_flag_[0], tile_list_[0],
-                       &counters_[C_LIST0]);
+    // (work-groups in proportion to the frontier: a delete on a surface orphans 10^5 voxels and level 0 is handed over whole)
+    const uint32_t n_over = std::min(c.n[c.level % 3u], lv_->cap);
+    hipLaunchKernelGGL((k_level_pull<DenseSpace>), dim3(std::min(std::max(n_over / 64u, 64u), 8192u)), dim3(256), 0, stream_, sp, a);
+    hipLaunchKernelGGL((k_level_list_to_tiles<DenseSpace>), dim3(std::min(std::max(n_over / 256u, 16u), 4096u)), dim3(256), 0, stream_, sp, a, tg,
+                       tile_flag_[0], tile_list_[0], &counters_[C_LIST0]);
     FIESTA_HIP_CHECK(hipGetLastError());
     if (how == LevelEngine::kHandOver) return false;
   }
@@ -1577,11 +1587,14 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   // (level_kernels.hpp) takes every update of a few thousand voxels -- a sensor frame -- that the transform does not, and,
   // if asked for (update_engine 3), every update its lists can hold; one that outgrows them is finished by the rounds.
   bool levels_fell_back = false;
+  // On a map the transform's gate is open for -- every voxel observed, no history of partial windows -- the reference's
+  // field is the exact transform whatever the order (section 3c): the level engine has nothing to add there, and a delete on
+  // such a map orphans a whole Voronoi cell (10^5 voxels behind a surface), which is the rounds' or the transform's work.
+  const bool gate_open = !seed_only && !g_.sharded && bulk_eligible(ni, nd);
   // (the inserts ARE level 0: more of them than one work-group carries and the level engine would only hand the update on)
   const bool try_levels = !seed_only && !g_.sharded && !g_.wrap && update_engine_ != 1 &&
-                          (update_engine_ == 3 || (ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kSingleCap));
-  const bool try_bulk = !seed_only && !g_.sharded && bulk_eligible(ni, nd) &&
-                        (update_engine_ == 2 || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
+                          (update_engine_ == 3 || (!gate_open && ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kSingleCap));
+  const bool try_bulk = gate_open && (update_engine_ == 2 || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
   bool counters_reset = false;
   if (try_bulk) {
     reset_stats_counters(/*lists=*/true);
@@ -1608,11 +1621,11 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
                        tile_list_[0], &counters_[C_LIST0]);
     FIESTA_HIP_CHECK(hipGetLastError());
   }
-  if (nd || remote_del) {
+  if ((nd || remote_del) && !levels_fell_back) {  // (a fall-back: the level engine's scan reset the orphans, run_levels set up their tiles)
     // the scan is bounded by (delete queue's box) + (largest stored distance) where that bound is tracked
     // (enable_distance_tracking)
     const int bounded = (track_ && nd) ? 1 : 0;
-    if (bounded && !levels_fell_back) {
+    if (bounded) {
       hipLaunchKernelGGL(k_del_bbox, dim3(1), dim3(1024), 0, stream_, g_, (const uint32_t *)del_.p, (int64_t)nd, counters_);
       FIESTA_HIP_CHECK(hipGetLastError());
     }

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_h_invalidate(Geom g, const int32_t *dir
         bool fits = lv_append(reset, entry, lv.list[0], &lv.ctl->n[0], lv.cap);
         if (!win_all) fits &= lv_append(outside, entry, lv.outside, &lv.ctl->nout, lv.cap);
         if (!fits) lv.ctl->overflow = 1;
-        if (lane == 0) atomicAdd(&lv.ctl->invalidated, (uint32_t)__popcll(mm));
+        if (lane == 0) local += __popcll(mm);
       }
       continue;
     }
@@ -368,7 +368,12 @@ __global__ __launch_bounds__(256) void k_h_invalidate(Geom g, const int32_t *dir
   __syncthreads();
   if (lane == 0 && local) atomicAdd(&blk_local, local);
   __syncthreads();
-  if (threadIdx.x == 0 && blk_local) atomicAdd(&counters[C_INVALIDATED], blk_local);
+  if (threadIdx.x == 0 && blk_local) {
+    if (LEVELS)
+      atomicAdd(&lv.ctl->invalidated, (uint32_t)blk_local);
+    else
+      atomicAdd(&counters[C_INVALIDATED], blk_local);
+  }
 }
 
 // ---- queries (src/ESDFMap.cpp:452-540); an unallocated voxel reads like a freshly allocated one ----
@@ -1171,9 +1176,11 @@ bool HashMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned l
     FIESTA_HIP_CHECK(hipMemsetAsync(&lv_->ctl->overflow, 0, sizeof(uint32_t), stream_));
   if (how == LevelEngine::kHandOver || how == LevelEngine::kAbort) {
     a.level = c.level;  // (phase A of the level the engine stopped in front of: see k_level_list_to_tiles)
-    hipLaunchKernelGGL((k_level_pull<PagedSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
-    hipLaunchKernelGGL((k_level_list_to_tiles<PagedSpace>), dim3(16), dim3(256), 0, stream_, sp, a, tg, tile_flag_[0], tile_list_[0],
-                       &counters_[C_LIST0]);
+    // (work-groups in proportion to the frontier: a delete on a surface orphans 10^5 voxels and level 0 is handed over whole)
+    const uint32_t n_over = std::min(c.n[c.level % 3u], lv_->cap);
+    hipLaunchKernelGGL((k_level_pull<PagedSpace>), dim3(std::min(std::max(n_over / 64u, 64u), 8192u)), dim3(256), 0, stream_, sp, a);
+    hipLaunchKernelGGL((k_level_list_to_tiles<PagedSpace>), dim3(std::min(std::max(n_over / 256u, 16u), 4096u)), dim3(256), 0, stream_, sp, a, tg,
+                       tile_flag_[0], tile_list_[0], &counters_[C_LIST0]);
     FIESTA_HIP_CHECK(hipGetLastError());
     if (how == LevelEngine::kHandOver) return false;
   }

@@ -232,6 +232,32 @@ __device__ inline bool lv_append(bool pred, uint32_t value, uint32_t *list, uint
   if (pred && at < cap) list[at] = value;
   return base + (uint32_t)__popcll(m) <= cap;
 }
+// The same for up to NBITS values per lane: bit k of `mask` set = the lane appends value(k).  ONE atomic per wave (a scan that
+// finds 10^5 orphans behind a deleted surface otherwise spends its time on that one hot counter).
+template <int NBITS, class Value>
+__device__ inline bool lv_append_many(uint32_t mask, Value value, uint32_t *list, uint32_t *count, uint32_t cap) {
+  const uint32_t mine = (uint32_t)__popc(mask);
+  if (!__ballot(mine != 0u)) return true;
+  const int lane = threadIdx.x & 63;
+  uint32_t incl = mine;  // inclusive prefix sum over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+    if (lane >= off) incl += up;
+  }
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+  uint32_t base = 0;
+  if (lane == 63) base = atomicAdd(count, total);
+  base = (uint32_t)__shfl((int)base, 63);
+  uint32_t at = base + incl - mine;
+#pragma unroll
+  for (int k = 0; k < NBITS; ++k) {
+    const bool on = (mask >> k) & 1u;
+    if (on && at < cap) list[at] = value(k);
+    at += on ? 1u : 0u;
+  }
+  return base + total <= cap;
+}
 template <class S>
 __device__ inline int32_t lv_d2(const S &sp, int x, int y, int z, vox_t id) {
   return dist2(S::kWrap, x + sp.g.gx0, y + sp.g.gy0, z + sp.g.gz0, id);
