@@ -12,11 +12,13 @@
 //                             neighbour's word (d^2 is recomputed from the ids, exact int32); a neighbour that improves joins
 //                             the next frontier -- once: bit 30 of the word (kAct) is the "already queued" mark, set by
 //                             whoever improves the voxel first and cleared when the voxel is processed.
-// The next frontier is compacted with a wave ballot + prefix count and ONE atomic per wave.  Two grid-wide barriers per
-// level.  For the frontiers of a sensor frame (a few hundred voxels) the whole update is ONE launch of ONE work-group
-// (k_level_run: the barriers are __syncthreads, ~2 memory latencies per level); a level that outgrows one work-group goes
-// on as a pair of launches per level over any number of work-groups (k_level_pull / k_level_push: the kernel boundary is
-// the barrier), chained without host round trips.
+// The next frontier is compacted with a wave ballot + prefix count and ONE atomic per wave.  Two barriers per level.
+// For the frontiers of a sensor frame (a few hundred voxels) the whole update is ONE launch of ONE work-group
+// (k_level_run: the barriers are __syncthreads, ~2 memory latencies per level); wider levels run on the 32 CUs of one XCD
+// behind flag barriers (k_level_grid, below: why one XCD, how the placement is checked, how every wait is bounded); a
+// frontier beyond that is handed to the frontier rounds, or -- engine pinned -- goes on as a pair of launches per level over
+// any number of work-groups (k_level_pull / k_level_push: the kernel boundary is the barrier).  The launches of an update
+// are chained without host round trips: each finds out on the device whether there is anything for it.
 //
 // Deletes (:292-337).  The reference walks the vanished obstacle's list and re-seeds every member from its first valid
 // neighbour; those re-seeded voxels then pull and push like everybody else.  Here the orphans are found by the scan of

@@ -112,3 +112,38 @@ def test_a_grid_that_gives_up_is_repaired_by_the_rounds(hip_lib, oracle_libs, be
         assert rep["pair_violations"] == 0, rep
     else:
         assert_exact(rep)
+
+
+def test_auto_asks_the_level_engine_only_where_the_order_matters(hip_lib, oracle_libs, best_oracle_kind):
+    """`auto`: a fully observed map is the transform's or the rounds' (the reference's field is the exact
+    transform there whatever the order); a sensor-sized delta on a partially observed map is the level engine's; more than
+    512 inserts are the rounds'."""
+    rng = np.random.RandomState(21)
+    # fully observed: the gate of the bulk transform is open
+    b = _pair(oracle_libs, best_oracle_kind, (48, 48, 48), "auto")
+    g = all_voxels(b.gpu.grid_size)
+    b.observe(g, 0)
+    b.fuse()
+    b.esdf()
+    b.make_occupied(g[rng.choice(len(g), 20, replace=False)])
+    st, _ = b.esdf()
+    assert st["levels"] == 0 and (st["bulk"] == 1 or st["rounds"] > 0), st
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    # partially observed: a sensor-sized delta, then a large one
+    b = _pair(oracle_libs, best_oracle_kind, (48, 48, 48), "auto", envelope=4)
+    keep = (rng.rand(13, 13, 13) > 0.25)[g[:, 0] // 4, g[:, 1] // 4, g[:, 2] // 4]
+    b.observe(g[keep], 0)
+    b.fuse()
+    b.esdf()
+    b.make_occupied(g[keep][rng.choice(int(keep.sum()), 600, replace=False)])
+    st, _ = b.esdf()
+    assert st["levels"] == 0 and st["rounds"] > 0, st    # more than 512 inserts
+    rep = compare_dense(b.gpu, b.cpu)
+    assert_envelope(rep, "600 inserts, auto")
+    assert rep["pair_violations"] == 0, rep
+    b.make_occupied(g[keep][rng.choice(int(keep.sum()), 15, replace=False)])
+    st, _ = b.esdf()
+    assert st["levels"] == 1 and st["bulk"] == 0, st     # a sensor-sized delta among existing obstacles
+    rep = compare_dense(b.gpu, b.cpu)
+    assert_envelope(rep, "sensor-sized delta, auto")
+    assert rep["pair_violations"] == 0, rep
