@@ -390,8 +390,41 @@ struct Port {
         }
       }
       for (int o : orphans) coc[o] = kNone, dist[o] = kInf;
-      for (int o : orphans)
-        if (in_window(vox_of(o)) || may_wait[o]) add(F, o);
+      if (schedule == 2) {
+        // EXPERIMENT (schedule 2): the reference's list walk re-seeds an orphan from its first valid neighbour AT THAT MOMENT,
+        // and orphans walked earlier are valid -- the dead cell fills from its rim inwards during the delete drain, and every
+        // filled orphan is queued in layer 0 (:300-331).  Modelled as rounds: in round k every still-empty orphan with a valid
+        // neighbour (as round k-1 left the field) adopts the FIRST such neighbour's obstacle, in the reference's direction order.
+        std::vector<int> empty;
+        for (int o : orphans)
+          if (in_window(vox_of(o))) empty.push_back(o);
+        for (;;) {
+          std::vector<std::pair<int, I3>> got;
+          std::vector<int> still;
+          for (int o : empty) {
+            const I3 ov = vox_of(o);
+            bool found = false;
+            for (const I3 &dir : kDirs) {
+              const I3 nv = ov + dir;
+              if (!in_window(nv)) continue;
+              const int ns = slot(nv);
+              if (!defined(coc[ns]) || dist[ns] < 0 || !occupied(slot(coc[ns]))) continue;
+              got.push_back({o, coc[ns]});
+              found = true;
+              break;
+            }
+            if (!found) still.push_back(o);
+          }
+          if (got.empty()) break;
+          for (auto &g : got) coc[g.first] = g.second, dist[g.first] = metric(vox_of(g.first), g.second), add(F, g.first);
+          empty.swap(still);
+        }
+        for (int o : orphans)
+          if (!in_window(vox_of(o)) && may_wait[o]) add(F, o);
+      } else {
+        for (int o : orphans)
+          if (in_window(vox_of(o)) || may_wait[o]) add(F, o);
+      }
     }
     int64_t expanded = 0, changes = 0;
     std::vector<std::pair<int, I3>> better, pushers;
@@ -445,6 +478,116 @@ struct Port {
         for (int s : waiting) add(Fn, s);
       waiting.clear();
       F.swap(Fn);
+    }
+    if (st) st->expanded = expanded, st->change_num = changes;
+  }
+
+  // EXPERIMENT (schedule 3): two lineages.  The reference's queue holds the inserted voxels AHEAD of the re-seeded orphans
+  // (:278-337), and a FIFO keeps that order through every layer: in each layer the descendants of the inserts are processed
+  // before the descendants of the orphans, and an entry whose voxel was improved since it was queued is skipped (:345).
+  // Here: every level has an I part and an O part, each a Jacobi step (pull from the field as the part found it, then push),
+  // the O part after the I part, entries carrying the distance they were queued with.
+  void relax_lineages(oracle_esdf_stats *st) {
+    struct Ent { int s; double d; };
+    std::vector<Ent> FI, FO, NI, NO;
+    while (!q_ins.empty()) {
+      const Item e = q_ins.front();
+      q_ins.pop_front();
+      const int s = slot(e.p);
+      if (!occupied(s)) continue;
+      coc[s] = e.p;
+      dist[s] = 0.0;
+      FI.push_back({s, 0.0});
+    }
+    bool any_del = false;
+    while (!q_del.empty()) {
+      const Item e = q_del.front();
+      q_del.pop_front();
+      if (!occupied(slot(e.p))) any_del = true;
+    }
+    if (any_del) {
+      std::vector<int> orphans;
+      const int n0 = nslots();
+      for (int s = (mode == 1 ? 1 : 0); s < n0; ++s)
+        if (defined(coc[s]) && dist[s] >= 0 && !occupied(slot(coc[s]))) orphans.push_back(s);
+      for (int o : orphans) coc[o] = kNone, dist[o] = kInf;
+      std::vector<int> empty;
+      for (int o : orphans)
+        if (in_window(vox_of(o))) empty.push_back(o);
+      for (;;) {  // the rim-inward fill of schedule 2
+        std::vector<std::pair<int, I3>> got;
+        std::vector<int> still;
+        for (int o : empty) {
+          const I3 ov = vox_of(o);
+          bool found = false;
+          for (const I3 &dir : kDirs) {
+            const I3 nv = ov + dir;
+            if (!in_window(nv)) continue;
+            const int ns = slot(nv);
+            if (!defined(coc[ns]) || dist[ns] < 0 || !occupied(slot(coc[ns]))) continue;
+            got.push_back({o, coc[ns]});
+            found = true;
+            break;
+          }
+          if (!found) still.push_back(o);
+        }
+        if (got.empty()) break;
+        for (auto &g : got) coc[g.first] = g.second, dist[g.first] = metric(vox_of(g.first), g.second), FO.push_back({g.first, dist[g.first]});
+        empty.swap(still);
+      }
+    }
+    int64_t expanded = 0, changes = 0;
+    auto part = [&](std::vector<Ent> &F, std::vector<Ent> &N) {
+      std::vector<std::pair<int, I3>> better, pushers;
+      for (const Ent &e : F) {
+        const int s = e.s;
+        if (e.d != dist[s]) continue;  // stale (:345)
+        const I3 v = vox_of(s);
+        double best = dist[s];
+        I3 bc = kNone;
+        for (int i = 0; i < 24; ++i) {
+          const I3 nv = v + kDirs[i];
+          if (!in_window(nv)) continue;
+          const int ns = slot(nv);
+          if (!defined(coc[ns])) continue;
+          const double t = metric(v, coc[ns]);
+          if (best > t) best = t, bc = coc[ns];
+        }
+        ++expanded;
+        if (defined(bc))
+          better.push_back({s, bc});
+        else if (defined(coc[s]))
+          pushers.push_back({s, coc[s]});
+      }
+      for (auto &b : better) {
+        const double t = metric(vox_of(b.first), b.second);
+        if (dist[b.first] > t) {
+          coc[b.first] = b.second, dist[b.first] = t;
+          N.push_back({b.first, t});
+          ++changes;
+        }
+      }
+      for (auto &p : pushers) {
+        const I3 v = vox_of(p.first);
+        for (const I3 &dir : kDirs) {
+          const I3 nv = v + dir;
+          if (!in_window(nv)) continue;
+          const int ns = slot(nv);
+          const double t = metric(nv, p.second);
+          if (dist[ns] > t) {
+            dist[ns] = t;
+            coc[ns] = p.second;
+            N.push_back({ns, t});
+          }
+        }
+      }
+    };
+    while (!FI.empty() || !FO.empty()) {
+      ++levels_run;
+      NI.clear(), NO.clear();
+      part(FI, NI);
+      part(FO, NO);
+      FI.swap(NI), FO.swap(NO);
     }
     if (st) st->expanded = expanded, st->change_num = changes;
   }
@@ -630,7 +773,9 @@ void oracle_update_esdf(oracle_map *m, oracle_esdf_stats *st) {
   st->inserted = (int64_t)m->p.q_ins.size();
   st->deleted = (int64_t)m->p.q_del.size();
   auto t0 = std::chrono::steady_clock::now();
-  if (m->p.schedule)
+  if (m->p.schedule == 3)
+    m->p.relax_lineages(st);
+  else if (m->p.schedule)
     m->p.relax_levels(st);
   else
     m->p.relax(st);
@@ -705,7 +850,9 @@ int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc
   return n;
 }
 int oracle_check_consistency(oracle_map *m) { return m->p.lists_consistent(); }
-// port only: the schedule UpdateESDF runs (0 = the reference's FIFO; 1 = the model of the GPU's level engine, relax_levels)
+// port only: the schedule UpdateESDF runs (0 = the reference's FIFO; 1 = the model of the GPU's level engine, relax_levels;
+// 2, 3 = two experiments on that model kept for tools/dev/schedule_experiment.py -- the dead cell filled from its rim inwards
+// ahead of level 0, and the inserts' descendants ahead of the orphans' in every level: DESIGN.md section 3c says what they showed)
 void oracle_set_schedule(oracle_map *m, int schedule) { m->p.schedule = schedule; }
 int64_t oracle_levels_run(oracle_map *m) { return m->p.levels_run; }
 

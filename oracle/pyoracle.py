@@ -246,7 +246,8 @@ class OracleMap:
         return {"vox": vox, "dist": dist, "coc": coc, "occ": occ}
 
     def set_schedule(self, schedule):
-        """port only: 0 = the reference's FIFO, 1 = the CPU model of the GPU's level engine (esdf_port.cpp: relax_levels)."""
+        """port only: 0 = the reference's FIFO, 1 = the CPU model of the GPU's level engine (esdf_port.cpp: relax_levels);
+        2 / 3 = experiments on that model (tools/dev/schedule_experiment.py)."""
         self.lib.oracle_set_schedule(self.h, int(schedule))
 
     @property
