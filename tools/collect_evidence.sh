@@ -48,10 +48,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats_c3" -o c3 -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats_c4" -o c4 -- python bench.py --workload c4 --steps 40 --warmup 5 --no-cpu-baseline > "$R/c4_profiled.log" 2>&1
 python bench.py --gpus 1 --force-sharded --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_sharded_1rank.json"
 python bench.py --delta-sweep --no-cpu-baseline 2>&1 | grep -E "^\{" > "$R/delta_sweep.json"
+# config-5-sized pieces on one GPU: one 1024^3 shard through the native group, two of them multiplexed (2048 x 1024 x 1024)
+python bench.py --gpus 1 --force-sharded --grid 1024 --steps 5 --warmup 1 --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_1024_one_shard.json"
+python tools/c5_smoke.py > "$R/c5_two_shards_bulk.json" 2> "$R/c5_smoke.err"
+# the parity suite twice more (ties inside a level fall differently from run to run: is any test at its margin?)
+for k in 2 3; do python -m pytest tests -q -m gpu 2>&1 | grep -aE "^(FAILED|ERROR)|[0-9]+ (passed|failed)" >> "$R/pytest_gpu.txt"; done
 # copy what is to be judged into profiles/ (gpurun_out/ is scratch)
 cp "$R/stats/bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats_default.csv"
 for f in bench_default bench_default_profiled delta_sweep bench_c2_surfaces bench_c2_rounds bench_c2_surfaces_rounds bench_c2_levels bench_c2_partial \
-         bench_c3 bench_c3_rounds bench_c4 bench_c4_rounds bench_sharded_1rank pmc_traffic_ft; do
+         bench_c3 bench_c3_rounds bench_c4 bench_c4_rounds bench_sharded_1rank bench_1024_one_shard c5_two_shards_bulk pmc_traffic_ft; do
   cp "$R/$f.json" "profiles/${TAG}_$f.json"
 done
 cp "$R/floor_latency.txt" "profiles/${TAG}_floor_latency.txt"
