@@ -66,7 +66,7 @@ def test_grid_and_launch_pairs_run_the_same_schedule(hip_lib, oracle_libs, best_
     a pair of launches (0: no grid).  Inside a level the order of the pushes is free: equal candidates may tie differently
     from run to run (as in the reference), so the three fields are compared up to a handful of voxels -- and the first
     with the reference's order spread (this delta, inserts and deletes in one update of a fragmentary map, is one the
-    level schedule does NOT follow strictly: the reference drains its whole insert queue ahead of the delete queue)."""
+    level schedule does NOT follow strictly: the reference floods a dead cell during its list walk)."""
     fields = []
     for groups in (32, 8, 0):
         b = _pair(oracle_libs, best_oracle_kind, (64, 64, 48), "levels", envelope=4 if groups == 32 else 0, grid_groups=groups)
