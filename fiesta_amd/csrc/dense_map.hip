@@ -1473,7 +1473,13 @@ int DenseMap::level_trace(uint32_t *out48) const {
 // Returns false if the update did not fit the engine's lists: the field then carries frontier tags and the list of active
 // tiles is set up for the frontier rounds, which the caller runs.
 bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd) {
-  if (!lv_) lv_ = new LevelEngine;
+  if (!lv_) {
+    lv_ = new LevelEngine;
+#ifdef FIESTA_HIP_TUNING
+    if (const char *e = getenv("FIESTA_HIP_GRID_ENTER")) lv_->grid_enter = (uint32_t)atoi(e);
+    if (const char *e = getenv("FIESTA_HIP_GRID_MIN")) lv_->grid_min = (uint32_t)atoi(e);
+#endif
+  }
   if (!lv_done_) FIESTA_HIP_CHECK(hipEventCreate(&lv_done_));
   // list capacity: what a frame needs is a few thousand entries; a forced level engine gets room for a large update
   const uint32_t want = update_engine_ == 3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(g_.n / 4, 1 << 20), 1 << 26) : (1u << 20);

@@ -1049,6 +1049,7 @@ struct LevelEngine {
   static constexpr uint32_t kTiny = 8;         // inserts + deletes of an update that is launched without the grid behind it
   enum Outcome { kDone = 0, kOverflow = 1, kHandOver = 2, kAbort = 3 };
   static constexpr int kNT = 1024;
+  uint32_t grid_enter = kGridEnter, grid_min = kGridMin;  // (members so that a tuning build can sweep them)
   int grid_groups = 32;          // work-groups of k_level_grid that take part (one XCD has 32 CUs); 0: never launch it
   uint32_t spin_limit = 1u << 18;  // polls one of its barriers waits (~0.2 s) before the update is given up
   bool grid_ok = true;           // until a launch found its work-groups on more than one XCD
@@ -1082,7 +1083,7 @@ struct LevelEngine {
     a.cap = cap;
     a.single_cap = kSingleCap;
     a.level = 0;
-    a.grid_min = kGridMin;
+    a.grid_min = grid_min;
     a.grid_max = kGridMax;
     a.items_max = 0xFFFFFFFFu;
     a.bar = 0;
@@ -1111,7 +1112,7 @@ struct LevelEngine {
     for (;;) {
       const bool grid = grid_ok && grid_groups > 0 && slot < 8u && !(first && tiny);
       a.level = first ? 0u : kLvAny;
-      a.single_cap = grid ? kGridEnter : kSingleCap;
+      a.single_cap = grid ? grid_enter : kSingleCap;
       hipLaunchKernelGGL((k_level_run<S, kNT, (int)kSingleCap>), dim3(1), dim3(kNT), 0, s, sp, a);
       ++*launches;
       if (grid) {
@@ -1134,7 +1135,7 @@ struct LevelEngine {
         const uint32_t l = h_ctl->level, n = h_ctl->n[l % 3u];
         if (n == 0 || n == h_ctl->nwait[l % 3u]) return kDone;
         a.level = l;
-        if (h_ctl->items > a.items_max && n > kGridMin) return kHandOver;  // (a large update after all: cheaper on the frontier rounds)
+        if (h_ctl->items > a.items_max && n > grid_min) return kHandOver;  // (a large update after all: cheaper on the frontier rounds)
         if (n <= kSingleCap || (grid_ok && grid_groups > 0 && slot < 8u && n <= a.grid_max)) break;  // another chain
         if (!wide) return kHandOver;
         // a chain of wide levels; work-groups in proportion to the frontier this chain starts with
