@@ -64,6 +64,9 @@ def parse():
                          "B's checkerboard); the bulk transform's gate stays shut, the line measures the general engine")
     ap.add_argument("--scene", default="scatter", choices=["scatter", "surfaces"],
                     help="C2 obstacle distribution: uniform scatter (headline) or depth-sensor-like shells (scene C)")
+    ap.add_argument("--pin-depth", action="store_true",
+                    help="C3: the host depth images live in pinned memory (what a node that owns its image buffers can do: "
+                         "the upload inside the timed region becomes one DMA instead of the runtime's staging copy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=224)
     ap.add_argument("--no-cpu-full", action="store_true",
@@ -287,10 +290,16 @@ def run_c3(args):
     spheres = [((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7), ((0.5, -2.0, -0.5), 0.4), ((-2.0, -1.0, 0.5), 0.6),
                ((2.2, -1.8, 0.2), 0.3)]
     nframes = args.warmup + args.steps
-    frames = []
+    frames, pins = [], []
     for f in range(nframes):
         T = yaw_pose(2.0 * f, (0.0, 0.0, 0.0))
-        frames.append((T, render_depth(T, rows=480, cols=640, spheres=spheres, intr=intr)))
+        depth = render_depth(T, rows=480, cols=640, spheres=spheres, intr=intr)
+        if args.pin_depth:
+            import torch
+            pinned = torch.from_numpy(np.ascontiguousarray(depth)).pin_memory()
+            pins.append(pinned)            # (keeps the pinned storage alive)
+            depth = pinned.numpy()
+        frames.append((T, depth))
     lc, rc = origin, tuple(np.add(origin, size))
     t_ray, t_fuse, t_esdf, t_all, cpu_t, esdf_stats, updated, parity, traces = [], [], [], [], [], [], [], None, []
     for f, (T, depth) in enumerate(frames):
@@ -351,7 +360,9 @@ def run_c3(args):
         "warmup": args.warmup, "ms_per_step": p50(t_all), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 ray arithmetic, u32 voxel words", "data": "synthetic",
         "config": {"workload": f"C3: {G}^3 @0.1 m, 640x480 depth frames (307200 rays), yaw 2 deg/frame, dedup=1; host "
-                               "uint16 image uploaded inside the timed ray cast (PCIe-inclusive)"},
+                               "uint16 image uploaded inside the timed ray cast (PCIe-inclusive)"
+                               + (", from PINNED host memory" if args.pin_depth else ", from pageable host memory"),
+                   "update_engine": args.engine},
         "raycast_p50_ms": p50(t_ray), "rays_per_sec": 307200 / (p50(t_ray) * 1e-3),
         "update_occupancy_p50_ms": p50(t_fuse), "update_esdf_p50_ms": p50(t_esdf),
         "update_esdf": esdf_summary(esdf_stats),
