@@ -687,8 +687,9 @@ __global__ __launch_bounds__(NT) void k_level_run(S sp, LevelArgs a) {
 }
 
 // ---- wide levels: one launch, many work-groups, barriers between them --------------------------------------------------
-// k_level_run is one work-group on one CU: a level of n entries costs it ~2.5 us + n x 40 ns of instruction issue.  Here
-// the same two phases run on up to 32 CUs, with a counter barrier where k_level_run has __syncthreads.  What makes that
+// k_level_run is one work-group on one CU: a level of n entries costs it ~2.5 us + n x 40 ns (every lane's neighbour word
+// is a memory request of its own, and they all leave through one CU).  Here the same two phases run on up to 32 CUs,
+// with a barrier among the work-groups where k_level_run has __syncthreads.  What makes that
 // affordable is that all participating work-groups share ONE L2: the XCDs' L2s are not coherent with each other, so a
 // barrier across XCDs would need an agent-scope release + acquire on every CU per phase (~3.5 us each, twice a level);
 // inside one XCD the field is coherent through the L2 for the loads that bypass the L1 (lv_load<true>) and the
