@@ -6,7 +6,7 @@
 // what the processing of layer L enqueued.  The order INSIDE a layer is an accident of the queue history and cannot be
 // reproduced by a parallel machine; the layers can.  One level here = one layer:
 //   phase A (pull, :349-367)  every frontier voxel looks at its 24 stencil neighbours IN THE FIELD AS THE LEVEL FOUND IT
-//                             (nothing but frontier tags is written during this phase) and remembers the best obstacle;
+//                             (nothing but the entries' own frontier tags is written during this phase, by plain stores) and remembers the best obstacle;
 //   phase B (:369-391)        a voxel that improved stores its new obstacle and stays in the frontier (re-queued, :371);
 //                             one that did not offers ITS obstacle to the 24 neighbours: a compare-and-swap minimum on the
 //                             neighbour's word (d^2 is recomputed from the ids, exact int32); a neighbour that improves joins
@@ -344,12 +344,12 @@ template <class S, bool ONE>
 __device__ inline uint32_t lv_pull(const S &sp, vox_t *coc, const LvItem &it, const LvDirs &dr) {
   const vox_t w = it.w;
   // the entry is being processed: its "queued" mark goes (and with it whatever a reset word still carried)
+  // (a plain store: during phase A nobody else writes this word -- a voxel is in the frontier once, the pushes wait behind
+  //  the barrier -- and readers of this phase take it with or without the mark; one atomic less per entry on the lines
+  //  the whole frontier hammers)
   if (dr.q == 0 && w != kUnobserved) {
-    if (w & kNoCoc) {
-      if (w != kInf) lv_and<ONE>(coc + it.self, kNoCoc);
-    } else if (w & kAct) {
-      lv_and<ONE>(coc + it.self, ~kAct);
-    }
+    const vox_t plain = (w & kNoCoc) ? kInf : (w & ~kAct);
+    if (plain != w) __hip_atomic_store(coc + it.self, plain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   const bool have = !(w & kNoCoc);
   int32_t best = lv_have(sp, it.x, it.y, it.z, w);
