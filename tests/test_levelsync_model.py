@@ -256,3 +256,30 @@ def test_hash_fuzz_seed_63_is_a_property_of_the_schedule(oracle_libs, best_oracl
         live = np.concatenate([live, new])
         rng.uniform(-25, 25, (150, 3))
     assert outside[:4] == [(0, 0, 0)] * 4 and outside[4] == (44, 0, 0), outside
+
+
+def test_wide_mixed_delta_seed_9_is_a_property_of_the_schedule(oracle_libs, best_oracle_kind):
+    """tests/test_gpu_level_grid.py: test_grid_and_launch_pairs_run_the_same_schedule -- 400 obstacles into a map with a
+    quarter of its 4^3 blocks unobserved, then 200 of them deleted and 200 new ones in ONE update.  The second state is the
+    other place of the GPU suite where the level engine is outside the strict contract (42 closer, 4 farther where the
+    reference's runs disagree on 13): the model gives exactly those numbers -- the schedule, not the device."""
+    n, res = (64, 64, 48), 0.1
+    p = Pair(oracle_libs, best_oracle_kind, (0, 0, 0), res, size_of(n, res), k=4)
+    rng = np.random.RandomState(9)
+    gs = np.array(p.eng.grid_size)
+    g = all_voxels(p.eng.grid_size)
+    blocks = rng.rand(*(gs // 4 + 1)) > 0.25
+    g = g[blocks[g[:, 0] // 4, g[:, 1] // 4, g[:, 2] // 4]]
+    p.observe(g, 0)
+    p.fuse()
+    p.esdf()
+    S = g[rng.choice(len(g), 400, replace=False)]
+    p.cycles(S, [], 3)
+    p.esdf()
+    e = p.judge()
+    assert_envelope(e, "400 inserts", strict=True)
+    T = g[rng.choice(len(g), 200, replace=False)]
+    p.cycles(T, S[:200], 6)
+    p.esdf()
+    e = p.judge()
+    assert (e["closer"], e["farther"], e["disagree"]) == (42, 4, 13), e
