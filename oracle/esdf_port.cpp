@@ -19,6 +19,7 @@
 #include <deque>
 #include <unordered_map>
 #include <unordered_set>
+#include <algorithm>
 #include <vector>
 
 #include "oracle_api.h"
@@ -389,8 +390,75 @@ struct Port {
           }
         }
       }
+      std::vector<I3> was(schedule >= 4 ? orphans.size() : 0);
+      if (schedule >= 4)
+        for (size_t k = 0; k < orphans.size(); ++k) was[k] = coc[orphans[k]];
+      const std::vector<I3> &was5 = was;
       for (int o : orphans) coc[o] = kNone, dist[o] = kInf;
-      if (schedule == 2) {
+      if (schedule == 4) {
+        // EXPERIMENT (schedule 4): the list walk itself, without the lists.  A vanished obstacle's list is push-front in
+        // adoption order, i.e. (roughly) walked from the voxels farthest from it to the nearest; every orphan takes the
+        // first valid neighbour AT THAT MOMENT -- orphans walked earlier included (:300-321).  Here: per vanished obstacle,
+        // its orphans by decreasing distance from it, one after the other.
+        std::vector<size_t> order(orphans.size());
+        for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+        auto key = [&](size_t k) { return ((long long)was[k].x * 2048 + was[k].y) * 2048 + was[k].z; };
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+          if (key(a) != key(b)) return key(a) < key(b);
+          return metric(vox_of(orphans[a]), was[a]) > metric(vox_of(orphans[b]), was[b]);
+        });
+        for (size_t k : order) {
+          const int o = orphans[k];
+          const I3 ov = vox_of(o);
+          if (!in_window(ov)) continue;
+          for (const I3 &dir : kDirs) {
+            const I3 nv = ov + dir;
+            if (!in_window(nv)) continue;
+            const int ns = slot(nv);
+            if (!defined(coc[ns]) || dist[ns] < 0 || !occupied(slot(coc[ns]))) continue;
+            coc[o] = coc[ns], dist[o] = metric(ov, coc[ns]);
+            add(F, o);
+            break;
+          }
+        }
+        for (int o : orphans)
+          if (!in_window(vox_of(o)) && may_wait[o]) add(F, o);
+      } else if (schedule == 5 || schedule == 6) {
+        // EXPERIMENT (schedules 5, 6): the same, shaped for a parallel machine -- all vanished obstacles at once, their orphans
+        // in SHELLS of decreasing distance from their own obstacle (5: one shell per squared distance; 6: per whole voxel
+        // of distance), every shell one Jacobi step: an orphan takes its first neighbour that was valid when the shell began.
+        std::vector<std::pair<long long, int>> byd;
+        for (size_t k = 0; k < orphans.size(); ++k) {
+          const int o = orphans[k];
+          if (!in_window(vox_of(o))) continue;
+          const double m = metric(vox_of(o), was5[k]);
+          const long long d2 = (long long)std::llround(m * m * res_inv * res_inv);
+          const long long shell = schedule == 5 ? d2 : (long long)std::floor(std::sqrt((double)d2));
+          byd.push_back({-shell, o});
+        }
+        std::stable_sort(byd.begin(), byd.end());
+        for (size_t b = 0; b < byd.size();) {
+          size_t e = b;
+          while (e < byd.size() && byd[e].first == byd[b].first) ++e;
+          std::vector<std::pair<int, I3>> got;
+          for (size_t k = b; k < e; ++k) {
+            const int o = byd[k].second;
+            const I3 ov = vox_of(o);
+            for (const I3 &dir : kDirs) {
+              const I3 nv = ov + dir;
+              if (!in_window(nv)) continue;
+              const int ns = slot(nv);
+              if (!defined(coc[ns]) || dist[ns] < 0 || !occupied(slot(coc[ns]))) continue;
+              got.push_back({o, coc[ns]});
+              break;
+            }
+          }
+          for (auto &g : got) coc[g.first] = g.second, dist[g.first] = metric(vox_of(g.first), g.second), add(F, g.first);
+          b = e;
+        }
+        for (int o : orphans)
+          if (!in_window(vox_of(o)) && may_wait[o]) add(F, o);
+      } else if (schedule == 2) {
         // EXPERIMENT (schedule 2): the reference's list walk re-seeds an orphan from its first valid neighbour AT THAT MOMENT,
         // and orphans walked earlier are valid -- the dead cell fills from its rim inwards during the delete drain, and every
         // filled orphan is queued in layer 0 (:300-331).  Modelled as rounds: in round k every still-empty orphan with a valid
@@ -851,8 +919,10 @@ int64_t oracle_dump_hash(oracle_map *m, int32_t *vox, double *dist, int32_t *coc
 }
 int oracle_check_consistency(oracle_map *m) { return m->p.lists_consistent(); }
 // port only: the schedule UpdateESDF runs (0 = the reference's FIFO; 1 = the model of the GPU's level engine, relax_levels;
-// 2, 3 = two experiments on that model kept for tools/dev/schedule_experiment.py -- the dead cell filled from its rim inwards
-// ahead of level 0, and the inserts' descendants ahead of the orphans' in every level: DESIGN.md section 3c says what they showed)
+// 2 .. 6 = experiments on that model kept for tools/dev/schedule_experiment.py: 2 the dead cell filled from its rim inwards
+// ahead of level 0, 3 also the inserts' descendants ahead of the orphans' in every level, 4 the reference's list walk emulated
+// (per vanished obstacle, orphans by decreasing distance from it, one after the other), 5 / 6 the same in parallel shells of
+// equal squared / whole-voxel distance.  DESIGN.md section 3c says what they showed.)
 void oracle_set_schedule(oracle_map *m, int schedule) { m->p.schedule = schedule; }
 int64_t oracle_levels_run(oracle_map *m) { return m->p.levels_run; }
 

@@ -247,7 +247,7 @@ class OracleMap:
 
     def set_schedule(self, schedule):
         """port only: 0 = the reference's FIFO, 1 = the CPU model of the GPU's level engine (esdf_port.cpp: relax_levels);
-        2 / 3 = experiments on that model (tools/dev/schedule_experiment.py)."""
+        2 .. 6 = experiments on that model (tools/dev/schedule_experiment.py)."""
         self.lib.oracle_set_schedule(self.h, int(schedule))
 
     @property

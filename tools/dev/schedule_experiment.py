@@ -63,5 +63,5 @@ if __name__ == "__main__":
     import contextlib, io
     for name, f in [("dense wide seed 9", lambda s: dense_wide(9, s)), ("dense wide seed 5", lambda s: dense_wide(5, s)), ("dense wide seed 3", lambda s: dense_wide(3, s)),
                     ("hash fuzz 63", lambda s: hash_fuzz(63, s)), ("hash fuzz 62", lambda s: hash_fuzz(62, s)), ("hash fuzz 61", lambda s: hash_fuzz(61, s))]:
-        for sched in (1, 2, 3):
+        for sched in (1, 2, 3, 4, 5, 6):
             print(name, "schedule", sched, "(closer, farther, disagree) per state:", f(sched), flush=True)

@@ -7,7 +7,7 @@ import pyoracle
 import test_levelsync_model as T
 from scenarios import depth_to_points, render_depth, yaw_pose
 kind = "ref" if pyoracle.available("ref", "array") else "port"
-for sched in (1, 2, 3):
+for sched in (1, 2, 3, 4, 5, 6):
     origin, size, res = (-6.4, -6.4, -3.2), (12.75, 12.75, 6.35), 0.1
     p = T.Pair(pyoracle, kind, origin, res, size, k=4)
     p.eng.set_schedule(sched)
