@@ -1508,6 +1508,13 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
       hipLaunchKernelGGL((k_level_outside<DenseSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
       FIESTA_HIP_CHECK(hipGetLastError());
     }
+    // the delete drain's list walk: the dead cells fill from their rims inwards before level 0 (level_kernels.hpp).  Whole-map
+    // updates only: under a partial window the orphans outside it keep asking their in-window neighbours (k_level_outside), and
+    // that proxy was fitted to neighbours that wait for their first pull (test_local_sliding_window_mode).
+    if (win_all) {
+      hipLaunchKernelGGL((k_level_fill<DenseSpace, 1024>), dim3(1), dim3(1024), 0, stream_, sp, a);
+      FIESTA_HIP_CHECK(hipGetLastError());
+    }
   }
   host_counts_[0] = host_counts_[1] = 0;  // (k_level_run clears the device's queue counters)
   int64_t launches = 0;

@@ -1150,6 +1150,10 @@ bool HashMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned l
       hipLaunchKernelGGL((k_level_outside<PagedSpace>), dim3(64), dim3(256), 0, stream_, sp, a);
       FIESTA_HIP_CHECK(hipGetLastError());
     }
+    if (win_all) {  // (see DenseMap::run_levels)
+      hipLaunchKernelGGL((k_level_fill<PagedSpace, 1024>), dim3(1), dim3(1024), 0, stream_, sp, a);
+      FIESTA_HIP_CHECK(hipGetLastError());
+    }
   }
   host_ni_ = host_nd_ = 0;  // (k_level_run clears the device's queue counters)
   int64_t launches = 0;

@@ -547,6 +547,125 @@ __global__ void k_level_outside(S sp, LevelArgs a) {
   }
 }
 
+// ---- the list walk of the delete drain, without the lists ---------------------------------------------------------------
+// The reference re-seeds the orphans of a vanished obstacle while it walks that obstacle's list (:300-331): every orphan
+// takes the obstacle of its FIRST neighbour (stencil order) that is valid at that moment -- and orphans walked earlier are
+// valid again.  A list is push-front in adoption order, so it is walked from the voxels farthest from the obstacle to the
+// nearest: the dead cell fills from its rim inwards before any propagation starts, and every re-seeded orphan is queued in
+// layer 0 with the value it got.  Here (schedule 6 of the CPU model oracle/esdf_port.cpp): the orphans of
+// ALL vanished obstacles at once, in shells of decreasing whole-voxel distance from their own obstacle, one shell after the
+// other; inside a shell every orphan looks at the field as the shell (or its pass of 256 orphans) found it.  After the
+// delete scan "valid" is simply "holds an obstacle": every voxel whose obstacle vanished has been reset.  Orphans that find
+// nobody keep "no obstacle" and leave level 0 (a push will find them, :378).  ONE work-group, level 0 of at most kFillCap
+// entries; a larger one keeps the orphans as pull-only entries of level 0 (the schedule of rounds 1-3 of this engine).
+constexpr uint32_t kFillCap = 8192;
+template <class S, int NT>
+__global__ __launch_bounds__(NT) void k_level_fill(S sp, LevelArgs a) {
+  __shared__ uint8_t s_shell[kFillCap];    // shell of entry i (255: not an orphan to fill)
+  __shared__ uint16_t s_order[kFillCap];   // the orphans, sorted by shell (far shells first)
+  __shared__ uint8_t s_keep[kFillCap];     // does entry i stay in level 0?
+  __shared__ uint32_t s_count[64], s_start[64], s_fill[64], s_n;
+  LevelCtl *ctl = a.ctl;
+  const int tid = threadIdx.x;
+  const uint32_t n = ctl->n[0];
+  if (n == 0 || n > kFillCap || n > a.cap || ctl->overflow) return;
+  uint32_t *list = a.list[0];
+  if (tid < 64) s_count[tid] = 0, s_fill[tid] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += NT) {
+    int x, y, z;
+    sp.decode(list[i], x, y, z);
+    uint32_t shell = 255;
+    const int32_t pg = sp.page_self(sp.valid(x, y, z), x, y, z);
+    if (pg >= 0) {
+      const vox_t w = a.coc[sp.addr_self(pg, x, y, z)];
+      if ((w & kNoCoc) && (w & kAct) && (w & kIdMask) != 0u && w != kUnobserved) {  // kReset | the vanished obstacle's id
+        const int32_t d2 = lv_d2(sp, x, y, z, w & kIdMask);
+        int r = (int)sqrtf((float)d2);
+        r += ((r + 1) * (r + 1) <= d2) ? 1 : 0, r -= (r * r > d2) ? 1 : 0;  // floor(sqrt(d2)), exactly
+        shell = (uint32_t)min(r, 63);
+        atomicAdd(&s_count[shell], 1u);
+      }
+    }
+    s_shell[i] = (uint8_t)shell;
+    s_keep[i] = shell == 255 ? 1 : 0;  // (seeds and waiting orphans outside the window stay; orphans: if they find somebody)
+  }
+  __syncthreads();
+  if (tid == 0) {  // far shells first
+    uint32_t at = 0;
+    for (int sh = 63; sh >= 0; --sh) s_start[sh] = at, at += s_count[sh];
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += NT) {
+    const uint32_t sh = s_shell[i];
+    if (sh != 255) s_order[s_start[sh] + atomicAdd(&s_fill[sh], 1u)] = (uint16_t)i;
+  }
+  __syncthreads();
+  LvDirs dr;
+  dr.init(sp);
+  constexpr uint32_t QT = NT / 4;
+  const int lane = tid & 63;
+  for (int sh = 63; sh >= 0; --sh) {
+    const uint32_t cnt = s_count[sh], first = s_start[sh];
+    for (uint32_t base = 0; base < cnt; base += QT) {  // (wave-uniform bounds: the barriers below are reached by everybody)
+      const uint32_t k = base + ((uint32_t)tid >> 2);
+      const bool live = k < cnt;
+      const uint32_t idx = live ? s_order[first + k] : 0u;
+      LvItem it;
+      uint32_t key = 99;   // the lane's first valid direction: 6 q + j
+      vox_t got = kNoCoc;
+      if (__ballot(live)) {
+        lv_fetch<S, true>(sp, a.coc, live ? list[idx] : 0u, live, dr, it);
+#pragma unroll
+        for (int j = 5; j >= 0; --j) {
+          const vox_t wn = it.nb[j];
+          bool ok = wn != kUnobserved && !(wn & kNoCoc);
+          // (the stale link of a voxel the local-map rule reset names an obstacle that may still stand, :308)
+          if (wn != kUnobserved && (wn & kNoCoc) && !(wn & kAct) && (wn & kIdMask) != 0u)
+            ok = sp.alive(it.x + dr.dx[j], it.y + dr.dy[j], it.z + dr.dz[j], wn & kIdMask);
+          if (ok) key = (uint32_t)(6 * dr.q + j), got = wn & kIdMask;
+        }
+      }
+      // the first valid direction of the quad (the reference's stencil order), and the obstacle behind it
+      uint32_t best = key;
+      best = min(best, (uint32_t)__shfl_xor((int)best, 1));
+      best = min(best, (uint32_t)__shfl_xor((int)best, 2));
+      const vox_t id = (vox_t)__shfl((int)got, (lane & ~3) | (int)min(best / 6u, 3u));
+      __syncthreads();  // every orphan of this pass has looked
+      if (live && dr.q == 0) {
+        if (best != 99u) {
+          __hip_atomic_store(a.coc + it.self, id | kAct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          s_keep[idx] = 1;
+        }
+      }
+      __syncthreads();  // ... and every re-seeded one is in the field before the next pass looks
+    }
+  }
+  // orphans that found nobody: plain "no obstacle", out of level 0; the others move up
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += NT) {  // (order inside level 0 does not matter: wave votes, as everywhere)
+    const uint32_t i = base + tid;
+    const bool in = i < n;
+    const uint32_t e = in ? list[i] : 0u;
+    const bool keep = in && s_keep[i];
+    if (in && !keep) {
+      int x, y, z;
+      sp.decode(e, x, y, z);
+      const int32_t pg = sp.page_self(true, x, y, z);
+      if (pg >= 0) __hip_atomic_store(a.coc + sp.addr_self(pg, x, y, z), kInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();  // (every entry of this stretch has been read before any is overwritten)
+    const unsigned long long m = __ballot(keep);
+    uint32_t at = 0;
+    if (lane == 0 && m) at = atomicAdd(&s_n, (uint32_t)__popcll(m));
+    at = (uint32_t)__shfl((int)at, 0) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (keep) list[at] = e;  // (at < base + NT: a kept entry never lands on one that is still to be read -- see the barrier above)
+  }
+  __syncthreads();
+  if (tid == 0) ctl->n[0] = s_n;
+}
+
 // ---- the levels -------------------------------------------------------------------------------------------------------
 // ONE work-group runs levels until the frontier is empty (or only waits), outgrows `single_cap`, or a list overflows.
 // The frontier lives in LDS (entries beyond the LDS lists' size go to the global list at the same position: the launch

@@ -433,7 +433,7 @@ struct Port {
           if (!in_window(vox_of(o))) continue;
           const double m = metric(vox_of(o), was5[k]);
           const long long d2 = (long long)std::llround(m * m * res_inv * res_inv);
-          const long long shell = schedule == 5 ? d2 : (long long)std::floor(std::sqrt((double)d2));
+          const long long shell = schedule == 5 ? d2 : std::min<long long>(63, (long long)std::floor(std::sqrt((double)d2)));  // (6: the GPU's 64 bins)
           byd.push_back({-shell, o});
         }
         std::stable_sort(byd.begin(), byd.end());

@@ -138,11 +138,12 @@ def test_random_sequences_hash_map(hip_lib, oracle_libs, best_oracle_kind, seed)
         assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
         rep = compare_hash(gpu, cpu)
         # (not strict, whatever the engine: on seed 63, step 4 -- 4 % observed, propagation through channels a voxel wide -- the
-        #  level engine, its CPU model (tests/test_levelsync_model.py: test_hash_fuzz_seed_63_is_a_property_of_the_schedule) and
-        #  the frontier rounds all end 44 voxels CLOSER than seven shuffled runs of the reference that agree with each other,
-        #  by 1-11 in d^2 at distances of 7-14 voxels, both sides above the exact distance: pulls that see the field as the level found it carry another
-        #  obstacle through the channel than pulls that see their predecessors' writes; 0.4 % of the finite voxels, one state
-        #  in 150 of this suite)
+        #  frontier rounds, and the level engine as long as its orphans waited in level 0 for their first pull, end 44 voxels
+        #  CLOSER than seven shuffled runs of the reference that agree with each other, by 1-11 in d^2 at distances of 7-14
+        #  voxels, both sides above the exact distance: the reference floods the dead cells during its list walk, a layered
+        #  schedule lets another obstacle through the channel first.  With the list walk ahead of level 0 (k_level_fill) the
+        #  pinned level engine is at 0 here; `auto` and the rounds serve this 59-delete update with the frontier rounds and stay
+        #  at 44.  tests/test_levelsync_model.py pins both numbers on the CPU model.)
         assert_envelope(rep, f"step {step}")
         live = np.concatenate([live, new])
         q = (rng.uniform(-25, 25, (150, 3)) + centre) * res + np.array(origin)

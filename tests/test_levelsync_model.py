@@ -21,9 +21,11 @@ from scenarios import (P_DEFAULT, EnvelopeOracle, all_voxels, assert_envelope, d
 class Pair:
     """The level-schedule model and the envelope of the reference, driven by identical calls."""
 
-    def __init__(self, oracle_libs, kind, origin, res, size, k):
+    def __init__(self, oracle_libs, kind, origin, res, size, k, schedule=6):
+        # schedule 6: levels + the delete drain's list walk in shells (what the GPU runs on whole-map updates whose level 0
+        # holds at most 8192 entries, level_kernels.hpp: k_level_fill); schedule 1: levels only (larger level 0, partial windows)
         self.eng = oracle_libs.OracleMap(origin, res, size, kind="port")
-        self.eng.set_schedule(1)
+        self.eng.set_schedule(schedule)
         self.env = EnvelopeOracle(lambda: oracle_libs.OracleMap(origin, res, size, kind=kind), k=k)
         self.res = res
         for m in (self.eng, self.env):
@@ -203,18 +205,21 @@ def test_fully_observed_equals_the_reference(oracle_libs, best_oracle_kind, seed
         live = np.array(sorted(keep), np.int32).reshape(-1, 3)
 
 
-def test_hash_fuzz_seed_63_is_a_property_of_the_schedule(oracle_libs, best_oracle_kind):
+@pytest.mark.parametrize("schedule, last", [(1, (44, 0, 0)), (6, (0, 0, 0))], ids=["levels-only", "with-the-list-walk"])
+def test_hash_fuzz_seed_63_is_a_property_of_the_schedule(oracle_libs, best_oracle_kind, schedule, last):
     """tests/test_gpu_fuzz.py: test_random_sequences_hash_map[63], on the hash-block flavour of the model and the reference.
-    The one state of the GPU suite where the level engine leaves the envelope although the reference's shuffled runs all
-    agree: the model leaves it on exactly the same number of voxels (44, all closer, all above the exact distance) -- it is
-    what a layered schedule does there, not an accident of the device.  Pinned so that a change of either shows."""
+    The one state of the GPU suite where the level engine of round 4's first half left the envelope although the reference's
+    shuffled runs all agree: the model of that schedule (1: orphans wait in level 0 for their first pull) leaves it on exactly
+    the same 44 voxels (all closer, all above the exact distance) -- the schedule, not the device.  With the delete drain's
+    list walk ahead of level 0 (6: the dead cells fill from their rims inwards; k_level_fill on the GPU) they
+    are gone.  Both pinned so that a change of either shows."""
     from scenarios import D2_INF, hash_key
     kind = best_oracle_kind if oracle_libs.available(best_oracle_kind, "hash") else "port"
     rng = np.random.RandomState(63)
     origin, res = tuple(float(v) for v in rng.uniform(-1, 1, 3)), float(rng.choice([0.05, 0.1]))
     rng.choice([0, 1000, 50000])
     eng = oracle_libs.OracleMap(origin, res, reserve_size=1000, mode="hash", kind="port")
-    eng.set_schedule(1)
+    eng.set_schedule(schedule)
     cpu = EnvelopeOracle(lambda: oracle_libs.OracleMap(origin, res, reserve_size=1000, mode="hash", kind=kind), k=6)
     for m in (eng, cpu):
         m.SetParameters(*P_DEFAULT)
@@ -255,16 +260,18 @@ def test_hash_fuzz_seed_63_is_a_property_of_the_schedule(oracle_libs, best_oracl
             assert np.all(d2[o][bad] >= exact) and np.all(D.min(0)[bad] - d2[o][bad] <= 16)   # (by at most ~0.6 voxel in distance)
         live = np.concatenate([live, new])
         rng.uniform(-25, 25, (150, 3))
-    assert outside[:4] == [(0, 0, 0)] * 4 and outside[4] == (44, 0, 0), outside
+    assert outside[:4] == [(0, 0, 0)] * 4 and outside[4] == last, outside
 
 
 def test_wide_mixed_delta_seed_9_is_a_property_of_the_schedule(oracle_libs, best_oracle_kind):
     """tests/test_gpu_level_grid.py: test_grid_and_launch_pairs_run_the_same_schedule -- 400 obstacles into a map with a
     quarter of its 4^3 blocks unobserved, then 200 of them deleted and 200 new ones in ONE update.  The second state is the
     other place of the GPU suite where the level engine is outside the strict contract (42 closer, 4 farther where the
-    reference's runs disagree on 13): the model gives exactly those numbers -- the schedule, not the device."""
+    reference's runs disagree on 13): the model gives exactly those numbers -- the schedule, not the device.
+    (Level 0 of that update holds far more than 8192 entries: the GPU runs it without the list walk, schedule 1; with it the
+    model says 43 / 0 / 13 -- the far side goes, the near side has another cause.)"""
     n, res = (64, 64, 48), 0.1
-    p = Pair(oracle_libs, best_oracle_kind, (0, 0, 0), res, size_of(n, res), k=4)
+    p = Pair(oracle_libs, best_oracle_kind, (0, 0, 0), res, size_of(n, res), k=4, schedule=1)
     rng = np.random.RandomState(9)
     gs = np.array(p.eng.grid_size)
     g = all_voxels(p.eng.grid_size)
