@@ -1356,9 +1356,10 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 // The map-local half of the engine choice: may this update be served by the bulk transform at all?
 bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
   const Geom &g = g_;
-  // (a map that held no obstacle before this update has no history left, whatever the checks below say -- ADVICE r3: the
-  //  flag must not outlive an emptied map just because an early return skipped the line that clears it)
-  if (win_dirty_ && !g.sharded && (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd <= 0) win_dirty_ = false;
+  // (a map that held no obstacle before this update has no history left: update_esdf clears the flag ahead of recording
+  //  this update's own window; here only when the window is the whole array -- the sharded driver's probe comes this way)
+  const bool full_win = g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1;
+  if (win_dirty_ && full_win && !g.sharded && (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd <= 0) win_dirty_ = false;
   if (update_engine_ == 1 || update_engine_ == 3) return false;
   if (!(g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1)) return false;
   const long long owned = (long long)(g.ox1 - g.ox0 + 1) * (g.oy1 - g.oy0 + 1) * (g.oz1 - g.oz0 + 1);
@@ -1594,6 +1595,9 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
   const bool full_window = g_.wx0 <= 0 && g_.wy0 <= 0 && g_.wz0 <= 0 && g_.wx1 >= g_.nx - 1 && g_.wy1 >= g_.ny - 1 && g_.wz1 >= g_.nz - 1;
+  // (a map that held no obstacle before this update has no history: cleared BEFORE this update's own window is recorded --
+  //  the first obstacles inserted under a partial window on an empty map must leave the flag set)
+  if (win_dirty_ && !g_.sharded && (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd <= 0) win_dirty_ = false;
   if (!full_window) win_dirty_ = true;  // (see bulk_eligible)
   // Engine choice.  The bulk transform costs one fixed sweep over the grid; the frontier rounds cost in proportion to
   // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).  The level engine

@@ -731,6 +731,7 @@ void HashMap::checkpoint(const char *path, bool write) {
   moves_ = meta[1];
   dropped_host_ = meta[2];
   force_scan_ = meta[3] != 0;
+  ptab_pages_built_ = -1;  // (page_gtile_ was replaced: the map-wide page table of the parked pages is rebuilt on demand)
   touched_upper_ = (int64_t)nt;
   host_queues_valid_ = false;
   shadow_vox_ = -1;
@@ -1188,7 +1189,7 @@ bool HashMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned l
     FIESTA_HIP_CHECK(hipGetLastError());
     if (how == LevelEngine::kHandOver) return false;
   }
-  if (nd) {  // (see DenseMap::run_levels)
+  if (scan) {  // (see DenseMap::run_levels; `scan`, not nd: the first scan also ran for a window move)
     hipLaunchKernelGGL(k_h_invalidate<false>, dim3(grid_for(nvox / 16 + 1, 256, 16384)), dim3(256), 0, stream_, g_, (const int32_t *)dir_,
                        (const int32_t *)page_tile_.p, (const uint32_t *)page_fresh_.p, nvox, coc_.p, (const uint32_t *)occbits_.p,
                        tile_flag_[0], tile_list_[0], &counters_[C_LIST0], counters_, LevelArgs{});

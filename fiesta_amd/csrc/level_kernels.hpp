@@ -564,11 +564,13 @@ __global__ __launch_bounds__(NT) void k_level_fill(S sp, LevelArgs a) {
   __shared__ uint8_t s_shell[kFillCap];    // shell of entry i (255: not an orphan to fill)
   __shared__ uint16_t s_order[kFillCap];   // the orphans, sorted by shell (far shells first)
   __shared__ uint8_t s_keep[kFillCap];     // does entry i stay in level 0?
-  __shared__ uint32_t s_count[64], s_start[64], s_fill[64], s_n;
+  __shared__ uint32_t s_count[64], s_start[64], s_fill[64], s_n, s_fmax;
   LevelCtl *ctl = a.ctl;
   const int tid = threadIdx.x;
   const uint32_t n = ctl->n[0];
   if (n == 0 || n > kFillCap || n > a.cap || ctl->overflow) return;
+  if (tid == 0) s_fmax = 0;
+  uint32_t fill_max = 0;  // largest d^2 an orphan adopted here: it may never improve in a level and so never be counted there
   uint32_t *list = a.list[0];
   if (tid < 64) s_count[tid] = 0, s_fill[tid] = 0;
   __syncthreads();
@@ -636,6 +638,7 @@ __global__ __launch_bounds__(NT) void k_level_fill(S sp, LevelArgs a) {
         if (best != 99u) {
           __hip_atomic_store(a.coc + it.self, id | kAct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           s_keep[idx] = 1;
+          fill_max = max(fill_max, (uint32_t)lv_d2(sp, it.x, it.y, it.z, id));
         }
       }
       __syncthreads();  // ... and every re-seeded one is in the field before the next pass looks
@@ -662,8 +665,15 @@ __global__ __launch_bounds__(NT) void k_level_fill(S sp, LevelArgs a) {
     at = (uint32_t)__shfl((int)at, 0) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (keep) list[at] = e;  // (at < base + NT: a kept entry never lands on one that is still to be read -- see the barrier above)
   }
+  if (fill_max) atomicMax(&s_fmax, fill_max);
   __syncthreads();
-  if (tid == 0) ctl->n[0] = s_n;
+  if (tid == 0) {
+    ctl->n[0] = s_n;
+    // (the bounded delete scan reaches ceil(sqrt(C_MAXD2)) + 1 voxels; a filled orphan that only pushes from
+    //  here on must be inside that bound, or a later delete of its obstacle leaves it with a stale link)
+    if (s_fmax > ctl->maxd2) ctl->maxd2 = s_fmax;
+    if (a.track && s_fmax) atomicMax(&a.counters[C_MAXD2], (unsigned long long)s_fmax);
+  }
 }
 
 // ---- the levels -------------------------------------------------------------------------------------------------------
@@ -1142,8 +1152,11 @@ __global__ void k_level_list_to_tiles(S sp, LevelArgs a, TileGrid tg, uint32_t *
       a.coc[at] = kReset;
       continue;  // (outside the window: the rounds never stage it)
     }
-    if (verdict != kLvNone && !(verdict & kLvPush))
-      (void)lv_min<S, false>(sp, a.coc, at, x, y, z, verdict & kIdMask, lv_d2(sp, x, y, z, verdict & kIdMask), a.coc[at]);
+    if (verdict != kLvNone && !(verdict & kLvPush)) {
+      const int32_t dv = lv_d2(sp, x, y, z, verdict & kIdMask);
+      (void)lv_min<S, false>(sp, a.coc, at, x, y, z, verdict & kIdMask, dv, a.coc[at]);
+      if (a.track) atomicMax(&a.counters[C_MAXD2], (unsigned long long)dv);  // (the rounds that take over only see later writes)
+    }
     if (!(a.coc[at] & kNoCoc)) atomicOr(a.coc + at, kAct);
     if (!sp.valid(x, y, z)) continue;
     const uint32_t t = sp.tile_of(tg, at, x, y, z);

@@ -130,8 +130,9 @@ int fiesta_hip_set_prob_params(fiesta_hip_map *m, double p_hit, double p_miss, d
 int fiesta_hip_set_update_range(fiesta_hip_map *m, const double min_pos[3], const double max_pos[3],
                                 int new_vec);
 int fiesta_hip_set_original_range(fiesta_hip_map *m);
-/* fiesta_hip_config.update_engine, changed on a live map (takes effect with the next UpdateESDF; array maps only, a
- * hash-block map has one engine).  No reference counterpart: the reference has one engine. */
+/* fiesta_hip_config.update_engine, changed on a live map (takes effect with the next UpdateESDF).  Array maps take 0-4;
+ * hash-block maps take 0, 1 and 3 (2 and 4 behave as 0 there: the transforms need a dense array).  No reference
+ * counterpart: the reference has one engine. */
 int fiesta_hip_set_update_engine(fiesta_hip_map *m, int32_t engine);
 /* Diagnostics of the last UpdateESDF the level engine served (fiesta_hip_stats.levels): for each of its first 48 levels
  * (= layers of the reference's FIFO, src/ESDFMap.cpp:339-392) the number of frontier entries (high 16 bits) and the time
@@ -352,9 +353,6 @@ int fiesta_hip_rccl_unique_id(uint8_t id[128]);
 int fiesta_hip_shard_box(const int32_t global_grid[3], int32_t world, int32_t rank, int32_t lo[3], int32_t size[3]);
 int fiesta_hip_shard_group_create(fiesta_hip_map *const *local_shards, const int32_t *local_ranks, int32_t n_local,
                                   int32_t world, const uint8_t *rccl_id, fiesta_hip_shard_group **out);
-/* The LOCAL half of _create's checks (shard boxes against the regular cut, set-up rules, librccl loadable when
- * use_rccl) without the collective communicator set-up: ranks exchange the outcome of this first (out of band), so that
- * one rank's local failure cannot leave the others blocked inside ncclCommInitRank. */
 /* A third transport for the same protocol: the caller's own messaging, through HOST buffers.  One shard per process (like
  * RCCL); the library stages what it sends and receives through host memory and calls
  *   all_gather(ctx, send, recv, bytes)      every rank contributes `bytes` bytes; recv = world x bytes, in rank order
@@ -372,6 +370,9 @@ typedef struct fiesta_hip_shard_transport {
 } fiesta_hip_shard_transport;
 int fiesta_hip_shard_group_create_hosted(fiesta_hip_map *local_shard, int32_t local_rank, int32_t world,
                                          const fiesta_hip_shard_transport *transport, fiesta_hip_shard_group **out);
+/* The LOCAL half of _create's checks (shard boxes against the regular cut, set-up rules, librccl loadable when
+ * use_rccl) without the collective communicator set-up: ranks exchange the outcome of this first (out of band), so that
+ * one rank's local failure cannot leave the others blocked inside ncclCommInitRank. */
 int fiesta_hip_shard_group_precheck(fiesta_hip_map *const *local_shards, const int32_t *local_ranks, int32_t n_local,
                                     int32_t world, int32_t use_rccl);
 /* What the RCCL communicator itself reports: *nranks = ncclCommCount (0: local transport, no communicator),

@@ -97,12 +97,17 @@ def test_window_narrowed_then_widened_keeps_the_transform_off(hip_lib, oracle_li
         # (the two planes of voxels just beyond the narrowed window, x = 19 and 20, held orphans of the deletes that ran under
         #  it: which of those the reference re-seeded follows its list order, which the engines approximate -- level_kernels.hpp:
         #  k_level_outside, dense_map.hip: k_reseed_outside; the allowance is 0.5 % of that shell, nothing anywhere else)
+        # ... and only for a map the level engine served: the rounds-only map keeps the contract it always met
+        by_levels = m.served["levels"] > 0
         shell = 2 * n * n
-        assert_envelope(rep, "after the window widened", farther_allow=max(rep["envelope"]["disagree"], shell // 200))
+        if by_levels:
+            assert_envelope(rep, "after the window widened", farther_allow=max(rep["envelope"]["disagree"], shell // 200))
+        else:
+            assert_envelope(rep, "after the window widened")
         # a fixed point of the reference's operator everywhere -- except, possibly, on that shell: a voxel the narrowed window
         # froze (as the reference freezes its own, :378) keeps its value until a wave passes again
         mi = np.asarray(rep["mismatch_idx"])
-        frozen = rep["d2_mismatch"] <= len(mi) and np.all(np.isin(mi // (n * n), (19, 20)))
+        frozen = by_levels and rep["d2_mismatch"] <= len(mi) and np.all(np.isin(mi // (n * n), (19, 20)))
         assert rep["pair_violations"] == 0 or frozen, rep
     # everything deleted, one update without obstacles: the history is gone, the gate may open again
     occ = np.argwhere(maps[0].download_field(("occ",))["occ"].reshape((n,) * 3) == 1).astype(np.int32)
