@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import statistics
 import sys
@@ -56,7 +57,7 @@ def parse():
                          "2048^3 as 2x2x2 shards at N = 8 = config 5)")
     ap.add_argument("--obstacles", type=int, default=None,
                     help="live obstacle voxels per rank (default: config 2's density, 50000 per 512^3)")
-    ap.add_argument("--engine", default="auto", choices=["auto", "rounds", "bulk", "levels"],
+    ap.add_argument("--engine", default="auto", choices=["auto", "rounds", "bulk", "levels", "envelope", "cells"],
                     help="UpdateESDF engine: chosen per update (default), frontier rounds only, or the bulk feature "
                          "transform whenever the map state allows it")
     ap.add_argument("--unobserved", type=float, default=0.0,
@@ -804,7 +805,18 @@ def main():
         call_p50_ms = statistics.median(s["host_ms"] for s in timed)
         call_achieved = my_updated / args.steps * ALGO_BYTES_PER_UPDATED_VOXEL / (call_p50_ms * 1e-3) / 1e9
         n_bulk = sum(int(s.get("bulk", 0)) for s in timed)
-        if n_bulk == len(timed):
+        n_cells = sum(int(s.get("cells", 0)) for s in timed)
+        if n_bulk == len(timed) and n_cells == len(timed):
+            kernel = "k_nn_cells + k_nn_lists + k_nn_fill (cell transform: every kernel of UpdateESDF)"
+            phases = {k: statistics.median(s[k] for s in timed) for k in ("nn_cells_ms", "nn_lists_ms", "nn_fill_ms")}
+            # the dominant kernel on ITS OWN bytes: k_nn_fill writes 4 B per voxel of the grid and reads only the cells' lists
+            own = float(G) ** 3 * 4.0
+            dominant = {"kernel": "k_nn_fill", "ms": phases["nn_fill_ms"], "own_bytes": own, "own_bytes_what": "4 B written per grid voxel",
+                        "achieved_GBs": own / (phases["nn_fill_ms"] * 1e-3) / 1e9,
+                        "frac": own / (phases["nn_fill_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "list_entries_per_cell": statistics.mean(s["nn_entries"] for s in timed) / (math.ceil(G / 8) ** 3)}
+            overflow = None
+        elif n_bulk == len(timed):
             kernel = "k_ft_rows + k_ft_plane + k_ft_x (bulk feature transform: every kernel of UpdateESDF)"
             phases = {k: statistics.median(s[k] for s in timed) for k in ("ft_rows_ms", "ft_plane_ms", "ft_x_ms")}
             # the dominant kernel on ITS OWN bytes: pass B reads 4 B and writes 4 B per voxel of the grid

@@ -33,7 +33,9 @@ class Stats(C.Structure):
                 ("relax_ms", C.c_double), ("relax_launches", C.c_int64), ("prof", C.c_int64 * 8),
                 ("bulk", C.c_int64), ("ft_rows_ms", C.c_double), ("ft_plane_ms", C.c_double), ("ft_x_ms", C.c_double),
                 ("ft_overflow", C.c_int64 * 6), ("observed_voxels", C.c_int64), ("occupied_voxels", C.c_int64),
-                ("ft_max_d2", C.c_int64), ("dropped_observations", C.c_int64), ("levels", C.c_int64), ("grid_levels", C.c_int64)]
+                ("ft_max_d2", C.c_int64), ("dropped_observations", C.c_int64), ("levels", C.c_int64), ("grid_levels", C.c_int64),
+                ("cells", C.c_int64), ("nn_cells_ms", C.c_double), ("nn_lists_ms", C.c_double), ("nn_fill_ms", C.c_double),
+                ("nn_entries", C.c_int64), ("nn_failed", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

@@ -25,6 +25,7 @@
 #include "dense_map.hpp"
 #include "checkpoint.hpp"
 #include "ft_kernels.hpp"
+#include "nn_kernels.hpp"
 #include "level_kernels.hpp"
 #include "relax_kernels.hpp"
 
@@ -809,7 +810,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   g.oz1 = glo[2] + gs[2] - 1;
   nbitwords_ = (int64_t)g.nx * g.ny * g.nzw;
 
-  if (cfg.update_engine < 0 || cfg.update_engine > 3) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
+  if (cfg.update_engine < 0 || cfg.update_engine > 5) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
   update_engine_ = cfg.update_engine;
   ntx_ = (g.nx + tx_ - 1) / tx_;
   nty_ = (g.ny + ty_ - 1) / ty_;
@@ -1353,6 +1354,78 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   return true;
 }
 
+// ---- the cell transform (nn_core.hpp / nn_kernels.hpp): the same fixed point for a sparse obstacle set ----------------------
+// Applies to one unsharded map with plain ids (at most 1024 voxels per axis, region = the whole array).  Whether it is
+// worth trying: the obstacle density must be in the range where every cell finds an obstacle within its search window and
+// lists stay short (measured on scatter scenes, tests/test_nn_model.py: 1.2e-4 ... 2.5e-3 of the voxels; config 2's scene is
+// 3.7e-4), it must not have failed at about this obstacle count, and it must not have been slower than the envelope passes.
+bool DenseMap::cells_wanted() const {
+  const Geom &g = g_;
+  if (update_engine_ == 4 || g.sharded || g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024) return false;
+  if (update_engine_ == 5) return true;
+  const long long nocc = (long long)h_counters_[C_NOCC];
+  if (nocc * 8192 < g.n || nocc * 400 > g.n) return false;
+  if (nn_fail_nocc_ >= 0 && std::llabs(nocc - nn_fail_nocc_) * 4 <= nn_fail_nocc_) return false;
+  if (nn_last_ms_ > 0 && ft_last_ms_ > 0 && nn_last_ms_ > ft_last_ms_ && std::llabs(nocc - nn_last_nocc_) * 4 <= nn_last_nocc_) return false;
+  return true;
+}
+
+bool DenseMap::run_cells(fiesta_hip_stats *st) {
+  const Geom &g = g_;
+  if (g.sharded || g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024 || (g.gx0 | g.gy0 | g.gz0) != 0) return false;
+  NnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = nn::Geom{g.nx, g.ny, g.nz, (g.nx + nn::kB - 1) / nn::kB, (g.ny + nn::kB - 1) / nn::kB, (g.nz + nn::kB - 1) / nn::kB};
+  const int64_t nrows = (int64_t)a.g.ncx * a.g.ncy, ncells = nrows * a.g.ncz;
+  const size_t sites_cap = (size_t)std::max<long long>((long long)h_counters_[C_NOCC], 0) + 64;  // (k_fuse keeps the count exact)
+  nn_ctab_.ensure_exact((size_t)nrows * (a.g.ncz + 1), stream_);
+  nn_sites_.ensure(sites_cap, stream_);
+  nn_lists_.ensure_exact((size_t)ncells * nn::kStride + kListPad, stream_);
+  a.occ = occbits_, a.nzw = g.nzw;
+  a.ctab = nn_ctab_.p, a.sites = nn_sites_.p, a.sites_cap = (uint32_t)std::min<size_t>(nn_sites_.cap, 0xFFFFFFFFu);
+  a.lists = nn_lists_.p;
+  a.cursor = &counters_[C_NN_CURSOR], a.failed = &counters_[C_NN_FAILED], a.entries = &counters_[C_NN_ENTRIES];
+  a.maxd2 = track_ ? &counters_[C_FT_MAXD2] : nullptr;
+  a.coc = coc_;
+  if (!ft_counters_clean_)
+    FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
+  ft_counters_clean_ = false;
+  FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[0], stream_));
+  hipLaunchKernelGGL(k_nn_cells, dim3((unsigned)((nrows + 15) / 16)), dim3(1024), 0, stream_, a);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[1], stream_));
+  hipLaunchKernelGGL(k_nn_lists, dim3((a.g.ncz + 63) / 64, (a.g.ncy + 3) / 4, a.g.ncx), dim3(1024), 0, stream_, a);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[2], stream_));
+  const int64_t nq = nrows * ((a.g.ncz + 3) / 4);
+  unsigned fill_blocks = (unsigned)std::min<int64_t>(nq, kFillBlocks);
+  // the unpredicated variant: whole cells everywhere and runs of an even number of quads (k_nn_fill: FULL)
+  bool full = g.nx % nn::kB == 0 && g.ny % nn::kB == 0 && g.nz % (4 * nn::kB) == 0;
+  if (full) {
+    unsigned b = fill_blocks;
+    while (b >= 256 && nq % (2 * (int64_t)b) != 0) --b;
+    if (b >= 256) fill_blocks = b; else full = false;
+  }
+  const dim3 cell_grid((a.g.ncz + 3) / 4, a.g.ncy, a.g.ncx);
+  if (track_) {
+    if (full) hipLaunchKernelGGL((k_nn_fill_full<true>), dim3(fill_blocks), dim3(256), 0, stream_, a);
+    else hipLaunchKernelGGL((k_nn_fill<true>), cell_grid, dim3(256), 0, stream_, a);
+  } else {
+    if (full) hipLaunchKernelGGL((k_nn_fill_full<false>), dim3(fill_blocks), dim3(256), 0, stream_, a);
+    else hipLaunchKernelGGL((k_nn_fill<false>), cell_grid, dim3(256), 0, stream_, a);
+  }
+  FIESTA_HIP_CHECK(hipGetLastError());
+  FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[3], stream_));
+  if (track_)  // (a failed transform leaves 0 here; the envelope passes that follow it set the bound themselves)
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&counters_[C_MAXD2], &counters_[C_FT_MAXD2], sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
+  if (st) {
+    st->bulk = 1;
+    st->cells = 1;
+    st->relax_launches = 3;
+  }
+  return true;
+}
+
 // The map-local half of the engine choice: may this update be served by the bulk transform at all?
 bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
   const Geom &g = g_;
@@ -1403,7 +1476,7 @@ bool DenseMap::bulk_pays_model(double delta, double nocc, double n, double ft_la
 }
 
 // After a successful bulk transform: the queues are consumed, timings and counters reported.
-void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
+void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells) {
   static_assert(C_DELETE == C_INSERT + 1, "counter layout");
   zero_counters(C_INSERT, 2);  // both queues are drained
   host_counts_[0] = host_counts_[1] = 0;
@@ -1411,23 +1484,30 @@ void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
   collect_stats(nullptr);
   FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  float m1 = 0, m2 = 0, m3 = 0;
+  const bool timed = hipEventElapsedTime(&m1, ft_ev_[0], ft_ev_[1]) == hipSuccess && hipEventElapsedTime(&m2, ft_ev_[1], ft_ev_[2]) == hipSuccess &&
+                     hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]) == hipSuccess;
   if (st) {
-    float ms = 0, m1 = 0, m2 = 0, m3 = 0;
+    float ms = 0;
     FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
-    FIESTA_HIP_CHECK(hipEventElapsedTime(&m1, ft_ev_[0], ft_ev_[1]));
-    FIESTA_HIP_CHECK(hipEventElapsedTime(&m2, ft_ev_[1], ft_ev_[2]));
-    FIESTA_HIP_CHECK(hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]));
     st->device_ms = ms;
-    st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
+    if (cells) {
+      st->nn_cells_ms = m1, st->nn_lists_ms = m2, st->nn_fill_ms = m3;
+      st->nn_entries = (int64_t)h_counters_[C_NN_ENTRIES];
+      st->nn_failed = (int64_t)h_counters_[C_NN_FAILED];
+    } else {
+      st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
+      st->ft_overflow[0] = (int64_t)h_counters_[C_FT_OVF0], st->ft_overflow[3] = (int64_t)h_counters_[C_FT_OVF0 + 3];
+    }
     st->relax_ms = (double)m1 + m2 + m3;
-    for (int k = 0; k < 6; ++k) st->ft_overflow[k] = (int64_t)h_counters_[C_FT_OVF0 + k];
     st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
   }
-  {
-    float m1 = 0, m2 = 0, m3 = 0;
-    if (hipEventElapsedTime(&m1, ft_ev_[0], ft_ev_[1]) == hipSuccess && hipEventElapsedTime(&m2, ft_ev_[1], ft_ev_[2]) == hipSuccess &&
-        hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]) == hipSuccess)
+  if (timed) {
+    if (cells) {
+      if (h_counters_[C_NN_FAILED] == 0) nn_last_ms_ = (double)m1 + m2 + m3, nn_last_nocc_ = (long long)h_counters_[C_NOCC];
+    } else {
       ft_last_ms_ = (double)m1 + m2 + m3;
+    }
   }
 }
 
@@ -1611,11 +1691,29 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   // (the inserts ARE level 0: more of them than one work-group carries and the level engine would only hand the update on)
   const bool try_levels = !seed_only && !g_.sharded && !g_.wrap && update_engine_ != 1 &&
                           (update_engine_ == 3 || (!gate_open && ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kSingleCap));
-  const bool try_bulk = gate_open && (update_engine_ == 2 || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
+  const bool try_bulk = gate_open && (bulk_pinned() || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
   bool counters_reset = false;
   if (try_bulk) {
     reset_stats_counters(/*lists=*/true);
     counters_reset = true;
+    // a sparse obstacle set: the cell transform first (nn_kernels.hpp).  A cell without a list fails it -- k_nn_fill then
+    // wrote nothing -- and the envelope passes below serve the update; the obstacle count is remembered and not retried.
+    if (cells_wanted() && run_cells(st)) {
+      const long long nocc_now = (long long)h_counters_[C_NOCC];
+      bulk_finish(st, h0, /*cells=*/true);
+      if (h_counters_[C_NN_FAILED] == 0) {
+        nn_fail_nocc_ = -1;
+        return;
+      }
+      nn_fail_nocc_ = nocc_now;
+      const int64_t failed = (int64_t)h_counters_[C_NN_FAILED];
+      if (st) {
+        memset(&st->cells, 0, sizeof(st->cells));
+        st->nn_failed = failed;
+      }
+      FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+      reset_stats_counters(/*lists=*/true);
+    }
     bool exact = true;
     if (run_bulk(st, 0, &exact)) {
       bulk_finish(st, h0);

@@ -70,6 +70,9 @@ enum Counter {
   C_REMOTE_DEL,  // sharded maps: some shard reported an occupied->free transition since the last UpdateESDF
   C_FT_OVF0,     // bulk path: column groups that went through spill mode in pass A ([0]) and pass B ([3]); the others unused
   C_FT_OVF5 = C_FT_OVF0 + 5,
+  C_NN_CURSOR = C_FT_OVF0 + 1,   // cell transform (nn_kernels.hpp), in the slots the envelope passes leave unused: sites handed out,
+  C_NN_FAILED = C_FT_OVF0 + 2,   //   cells that got no list (non-zero: the update is served by the envelope passes instead),
+  C_NN_ENTRIES = C_FT_OVF0 + 4,  //   list entries in total
   C_FT_MAXD2,    // bulk path: largest d^2 written (2^30: a voxel found no obstacle in its region)
   C_PROF0,  // 8 profiling slots (FIESTA_HIP_PROF=1): cycles in stage / propagate / write-back, queue items, ...
   C_COUNT = C_PROF0 + 8
@@ -116,6 +119,8 @@ class DenseMap {
   void bulk_commit(fiesta_hip_stats *st);
   int update_engine() const { return update_engine_; }
   void set_update_engine(int e) { update_engine_ = e; }
+  // 2, 4, 5: a transform whenever the map's state allows one (4: the envelope passes only, 5: the cell transform first)
+  bool bulk_pinned() const { return update_engine_ == 2 || update_engine_ == 4 || update_engine_ == 5; }
   int level_trace(uint32_t *out48) const;  // fiesta_hip_level_trace
   void level_tuning(int grid_groups, long long spin_limit);  // fiesta_hip_level_tuning
   void set_alone_in_group(bool alone) { alone_in_group_ = alone; }
@@ -198,7 +203,9 @@ class DenseMap {
   bool run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd);  // false: the rounds have to finish
   bool bulk_eligible(unsigned long long ni, unsigned long long nd);
   bool run_bulk(fiesta_hip_stats *st, int margin, bool *exact);
-  void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0);
+  bool cells_wanted() const;            // should this update try the cell transform (nn_kernels.hpp) before the envelope passes?
+  bool run_cells(fiesta_hip_stats *st);  // false: not applicable to this map (nothing launched)
+  void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells = false);
   void reset_stats_counters(bool lists = false);
   void enable_distance_tracking();
   void collect_stats(fiesta_hip_stats *st);
@@ -226,7 +233,8 @@ class DenseMap {
   int ntx_ = 0, nty_ = 0, ntz_ = 0, ntiles_ = 0;
   uint32_t *tile_epoch_ = nullptr;
   // UpdateESDF engine (fiesta_hip_config.update_engine): 0 = choose per update, 1 = frontier rounds only,
-  // 2 = bulk feature transform whenever the map state allows it, 3 = level engine for every update it can hold
+  // 2 = bulk feature transform whenever the map state allows it, 3 = level engine for every update it can hold,
+  // 4 = as 2 with the envelope passes only, 5 = as 2 with the cell transform wherever it applies
   int update_engine_ = 0;
   LevelEngine *lv_ = nullptr;   // the level engine's lists and control block (level_kernels.hpp), created on first use
   hipEvent_t lv_done_ = nullptr;
@@ -243,6 +251,11 @@ class DenseMap {
   bool alone_in_group_ = true;  // a shard: the only one of its group (ShardGroup tells)
   bool ft_counters_clean_ = false;  // reset_stats_counters() ran and no transform has used the spill counters since
   DevBuf<uint32_t> ft_inter_, ft_out_;
+  // cell transform (nn_kernels.hpp): first site per cell, the sites, one record (list) per cell
+  DevBuf<uint32_t> nn_ctab_, nn_sites_, nn_lists_;
+  double nn_last_ms_ = 0;        // kernel time of the last cell transform that succeeded ...
+  long long nn_last_nocc_ = -1;  // ... and the obstacle count it ran on
+  long long nn_fail_nocc_ = -1;  // obstacle count of the last one that failed (a cell without a list): not retried near it
   DevBuf<unsigned long long> ft_spill_;  // backing store of the transform's rings (run_bulk)
   DevBuf<uint16_t> ft_rowlist_;
   DevBuf<int32_t> ft_rowcnt_;

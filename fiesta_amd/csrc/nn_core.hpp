@@ -1,0 +1,206 @@
+// fiesta_amd/csrc/nn_core.hpp -- the CELL transform: UpdateESDF's fixed point on a fully observed map (the exact Euclidean
+// feature transform of the occupied set) computed the way a SPARSE obstacle set wants it: every 8^3 cell
+// of voxels gets the short list of obstacles that can be the nearest one of any of its voxels, and its 512 voxels take
+// the minimum over that list.  No pass over the grid reads anything but the 1-bit occupancy map; the only per-voxel
+// traffic is the 4-byte store of the result (src/ESDFMap.cpp:273-398 is what this replaces, as the envelope passes of
+// ft_core.hpp do; which of the two transforms serves an update is dense_map.hip's choice).
+//
+// This header is the arithmetic both sides share: the gfx950 kernels (nn_kernels.hpp) and the host model the CPU tests
+// drive (tests/cpp/nn_model.cpp against brute force / scipy).  Plain pointers, no HIP types.
+//
+//   cell          8 x 8 x 8 voxels, origin O = 8 (cx, cy, cz); voxel v = O + (x, y, z), 0 <= x, y, z <= 7
+//   site          an occupied voxel s; p = s - O its offset from the cell origin
+//   competitor t  the site nearest to the cell centre found in the 5^3 cells around the cell (any site would do: it
+//                 only has to be SOME obstacle; the nearest one prunes best)
+//   keep rule     s is dropped iff t is at least as near as s for EVERY voxel of the cell:
+//                     |p - v|^2 >= |q - v|^2  for all v   <=>   |p|^2 - |q|^2 >= 14 * sum_a max(0, p_a - q_a)     (q = t - O)
+//                 (the half-space test of the bisector of s and t against the cell's box; ties go to t, which carries
+//                 the same distance -- ids are tie-equivalent).  Whatever survives is a superset of the
+//                 cell's true winners.
+//   search window every site that survives lies within R = |t - c| + 2 h of the centre c = O + 3.5 (h = the box's half
+//                 diagonal, 3.5 sqrt 3): rows of cells whose nearest point is farther are never read.  In DOUBLED
+//                 coordinates (e = 2 p - 7: integers) that is |e|^2 <= rad2.
+//   key           for voxel v and list entry i:  ((|p|^2 - 2 v.p + 147) << 9) | i << 4  -- |v - s|^2 minus the voxel's own
+//                 |v|^2 (the same for every entry), biased to stay non-negative (|v|^2 <= 147); the minimum over the
+//                 list names the nearest site, smallest list index on ties.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FIESTA_NN_HD __host__ __device__
+#else
+#define FIESTA_NN_HD
+#include <math.h>
+#endif
+
+namespace fiesta {
+namespace nn {
+
+constexpr int kB = 8;               // cell edge
+constexpr int kCap = 30;            // entries a cell's list holds; a cell that needs more fails the transform
+constexpr int kSH = 9;              // a key's distance part starts at this bit; bits 4..8: the list index (so key & 0x1F0 is the
+                                    // byte offset of the winner's entry), bits 0..3: zero
+constexpr int kBias = 3 * 7 * 7;    // |v|^2 of the voxel farthest from the cell origin
+constexpr int kKmax = 5;            // the search window reaches this many cells (p stays inside a signed byte when doubled)
+constexpr int kStride = 128;        // dwords of a cell's record: [0] the number of entries, [4 + 4 i ..] entry i = (b, K, m, W)
+constexpr uint32_t kPadK = 0xFFFFFFFFu;  // K of a padding entry (b = m = 0): never the minimum
+constexpr int kNone = 0x7FFFFFFF;
+
+struct Geom {
+  int nx, ny, nz;     // voxels
+  int ncx, ncy, ncz;  // cells = ceil(n / 8)
+};
+
+// entry of a kept site (offsets p from the cell origin, each within [-8 kKmax, 8 kKmax + 7]), 16 bytes:
+//   b  bytes (-2 py, -2 pz, 0, 0): what v_dot4_i32_i8 multiplies with the lane's (y, z, 0, 0)
+//   K  ((|p|^2 + kBias) << kSH) | index << 4
+//   m  (-2 px) << kSH: the step of a key from one x-slab of the cell to the next
+//   W  the site's packed coordinates: the word a voxel stores (common.hpp: pack_coc of a plain-id map)
+FIESTA_NN_HD inline uint32_t entry_b(int py, int pz) { return ((uint32_t)(-2 * py) & 255u) | (((uint32_t)(-2 * pz) & 255u) << 8); }
+FIESTA_NN_HD inline uint32_t entry_k(int px, int py, int pz, int idx) {
+  return ((uint32_t)(px * px + py * py + pz * pz + kBias) << kSH) | ((uint32_t)idx << 4);
+}
+FIESTA_NN_HD inline uint32_t entry_m(int px) { return (uint32_t)(-2 * px * (1 << kSH)); }
+// the key of voxel (x, y, z) of the cell against an entry, as the kernel computes it
+FIESTA_NN_HD inline uint32_t key_of(uint32_t b, uint32_t K, uint32_t m, int x, int y, int z) {
+  const int m2y = (int)(int8_t)(b & 255u), m2z = (int)(int8_t)((b >> 8) & 255u);
+  const int t = y * m2y + z * m2z;                           // -2 (y py + z pz)
+  return (uint32_t)(t * (1 << kSH)) + K + (uint32_t)x * m;  // (two's complement: the sum is the non-negative key)
+}
+
+FIESTA_NN_HD inline void unpack_site(uint32_t w, int &x, int &y, int &z) {
+  x = (int)((w >> 20) & 1023u), y = (int)((w >> 10) & 1023u), z = (int)(w & 1023u);
+}
+
+// |2 (s - c)|^2 of a site at offset p: the doubled offset from the cell centre is 2 p - 7 per axis
+FIESTA_NN_HD inline int e2_of(int px, int py, int pz) {
+  const int ex = 2 * px - 7, ey = 2 * py - 7, ez = 2 * pz - 7;
+  return ex * ex + ey * ey + ez * ez;
+}
+// (2 R)^2 rounded up: 2 R = |e_t| + 4 h, 4 h = 14 sqrt 3 = 24.2487
+FIESTA_NN_HD inline int rad2_of(int e2) {
+  const float r = sqrtf((float)e2) + 24.26f;
+  return (int)(r * r) + 1;
+}
+// cells the window reaches along an axis: a site of the ball has 16 |d| - 7 <= 2 R
+FIESTA_NN_HD inline int reach_of(int rad2) { return (int)((sqrtf((float)rad2) + 7.01f) * 0.0625f); }
+// doubled gap between the centre and a cell d cells away along one axis
+FIESTA_NN_HD inline int gap_of(int d) { return d ? 16 * (d < 0 ? -d : d) - 7 : 0; }
+
+// Where the lists come from: the first-site table and the site array, through an accessor.  bounds(): the index range of
+// the sites of cells z0..z1 of cell row (X, Y); site(): the packed site behind an index of such a range.  PlainSrc reads
+// the two arrays as they lie in memory (the host model; the kernel's path for rows it has not staged); k_nn_lists wraps it
+// with a copy of its work-group's neighbourhood in LDS (nn_kernels.hpp: StagedSrc).
+struct PlainSrc {
+  const uint32_t *ctab, *sites;
+  int ncy, ncz;
+  FIESTA_NN_HD inline void bounds(int X, int Y, int z0, int z1, uint32_t &i0, uint32_t &i1) const {
+    const uint32_t *row = ctab + ((int64_t)X * ncy + Y) * (ncz + 1);
+    i0 = row[z0], i1 = row[z1 + 1];
+  }
+  FIESTA_NN_HD inline uint32_t site(uint32_t i) const { return sites[i]; }
+};
+
+// Who builds a list: ONE lane on the host model, a TEAM of four adjacent lanes in k_nn_lists (the rows of the search window
+// dealt out among them: four times the waves in flight for the same work -- the sweeps are chains of dependent reads).
+//   lanes, rank   size of the team, this lane's place in it
+//   nearest()     the team's minimum of (e2, w) pairs, smaller e2 first, then smaller w (called by every lane, outside loops)
+//   slot()        the next free entry of the list (any lane, inside loops)
+//   count()       entries handed out (called by every lane once all have finished their rows)
+struct Solo {
+  static constexpr int lanes = 1;
+  int rank = 0, n = 0;
+  FIESTA_NN_HD inline void nearest(int &, uint32_t &) const {}
+  FIESTA_NN_HD inline int slot() { return n++; }
+  FIESTA_NN_HD inline int count() const { return n; }
+};
+
+// nearest site to the centre of cell (cx, cy, cz) among this lane's rows of the cells within +-K: doubled squared
+// distance and word (ties: the smaller word, so that a team agrees whatever the split)
+template <class Src, class Team>
+FIESTA_NN_HD inline void scan_nearest(const Geom &g, const Src &src, const Team &team, int cx, int cy, int cz, int K, int &best_e2, uint32_t &best_w) {
+  const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
+  const int z0 = cz - K < 0 ? 0 : cz - K, z1 = cz + K > g.ncz - 1 ? g.ncz - 1 : cz + K;
+  const int side = 2 * K + 1;
+  for (int r = team.rank; r < side * side; r += Team::lanes) {
+    const int X = cx + r / side - K, Y = cy + r % side - K;
+    if ((unsigned)X >= (unsigned)g.ncx || (unsigned)Y >= (unsigned)g.ncy) continue;
+    uint32_t i, i1;
+    src.bounds(X, Y, z0, z1, i, i1);
+    for (; i < i1; ++i) {
+      const uint32_t w = src.site(i);
+      int sx, sy, sz;
+      unpack_site(w, sx, sy, sz);
+      const int e2 = e2_of(sx - ox, sy - oy, sz - oz);
+      if (e2 < best_e2 || (e2 == best_e2 && w < best_w)) best_e2 = e2, best_w = w;
+    }
+  }
+}
+
+// The record of cell (cx, cy, cz) into out[kStride].  Returns the number of entries, or 0 when the cell cannot be served:
+// no site within the search window's reach, a competitor so far away that the window would exceed kKmax cells, more than
+// kCap survivors.  (Every lane of a team returns the same value; lane 0 writes the count.)
+template <class Src, class Team>
+FIESTA_NN_HD inline int build_list(const Geom &g, const Src &src, Team &team, int cx, int cy, int cz, uint32_t *out) {
+  int te2 = kNone;
+  uint32_t tw = 0xFFFFFFFFu;
+  for (int K = 2; K <= kKmax && te2 == kNone; ++K) {
+    scan_nearest(g, src, team, cx, cy, cz, K, te2, tw);
+    team.nearest(te2, tw);
+  }
+  int n = 0;
+  if (te2 != kNone) {
+    const int rad2 = rad2_of(te2);
+    const int Kw = reach_of(rad2);
+    if (Kw <= kKmax) {
+      const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
+      int qx, qy, qz;
+      unpack_site(tw, qx, qy, qz);
+      qx -= ox, qy -= oy, qz -= oz;
+      const int q2 = qx * qx + qy * qy + qz * qz;
+      const int side = 2 * Kw + 1;
+      for (int r = team.rank; r < side * side; r += Team::lanes) {
+        const int dx = r / side - Kw, dy = r % side - Kw;
+        const int X = cx + dx, Y = cy + dy;
+        if ((unsigned)X >= (unsigned)g.ncx || (unsigned)Y >= (unsigned)g.ncy) continue;
+        const int gx = gap_of(dx), gy = gap_of(dy);
+        const int rem = rad2 - gx * gx - gy * gy;
+        if (rem < 0) continue;  // the whole row of cells lies outside the ball
+        int m = (int)((sqrtf((float)rem) + 7.01f) * 0.0625f);  // cells along z the ball still touches
+        m = m > Kw ? Kw : m;
+        const int z0 = cz - m < 0 ? 0 : cz - m, z1 = cz + m > g.ncz - 1 ? g.ncz - 1 : cz + m;
+        uint32_t i, i1;
+        src.bounds(X, Y, z0, z1, i, i1);
+        for (; i < i1; ++i) {
+          const uint32_t w = src.site(i);
+          int px, py, pz;
+          unpack_site(w, px, py, pz);
+          px -= ox, py -= oy, pz -= oz;
+          const int lhs = px * px + py * py + pz * pz - q2;
+          const int ax = px - qx, ay = py - qy, az = pz - qz;
+          const int rhs = 14 * ((ax > 0 ? ax : 0) + (ay > 0 ? ay : 0) + (az > 0 ? az : 0));
+          if (w == tw || lhs < rhs) {
+            const int k = team.slot();
+            if (k < kCap) {
+              uint32_t *e = out + 4 + 4 * k;
+              e[0] = entry_b(py, pz), e[1] = entry_k(px, py, pz, k), e[2] = entry_m(px), e[3] = w;
+            }
+          }
+        }
+      }
+      n = team.count();
+      if (n > kCap) n = 0;
+    }
+  }
+  if (team.rank == 0) {
+    out[0] = (uint32_t)n;
+    if (n & 1) {  // (the kernel takes two entries per step)
+      uint32_t *e = out + 4 + 4 * n;
+      e[0] = 0u, e[1] = kPadK, e[2] = 0u, e[3] = 0u;
+    }
+  }
+  return n;
+}
+
+}  // namespace nn
+}  // namespace fiesta

@@ -1,0 +1,420 @@
+// fiesta_amd/csrc/nn_kernels.hpp -- gfx950 kernels of the CELL transform (nn_core.hpp): UpdateESDF on a fully observed map
+// with a sparse obstacle set, as three launches that never read a per-voxel array:
+//
+//   k_nn_cells   occupancy bitmap -> the obstacles ("sites") ordered by cell row, and per cell the index of its first
+//                site.  A wave per row of cells (cx, cy): lane c reads byte c of each of the row's 64 voxel rows -- one
+//                coalesced 64-byte segment per load.                                            reads 1 bit / voxel
+//   k_nn_lists   FOUR LANES per cell: the competitor (nearest site to the cell centre), then every site of the search window
+//                that the competitor does not dominate over the whole cell -> the cell's list.  A row of window cells is
+//                ONE contiguous range of the site array (that is what the ordering is for).  The work-group first copies
+//                its neighbourhood -- the table rows and sites within 3 cells of its 64 x 4 cells -- into LDS: a lane's
+//                ~150 dependent reads then cost LDS latency, not L2 latency (the first version, straight from memory,
+//                spent 130 us on config 2 waiting).                                              reads sites (L2-resident)
+//   k_nn_fill    a WAVE per cell, a lane per (y, z) column of the cell, eight x-slabs in registers: per list entry one
+//                v_dot4_i32_i8 + one v_lshl_add_u32 give the lane's key at x = 0, one add per slab moves it along x,
+//                v_min3_u32 keeps the best of two entries; the winner's word is fetched from the list by ds_bpermute and
+//                stored.  Waves are persistent (32 cells each on config 2) and fetch the NEXT cell's list while they
+//                work on this one: a wave per cell spent its life waiting for six dependent loads.   writes 4 B / voxel
+//
+// A cell without a list (nothing within the window's reach, more candidates than a list holds) fails the whole
+// transform: k_nn_lists counts it, k_nn_fill then leaves the field alone and the host runs the envelope passes instead
+// (dense_map.hip: run_cells).
+#pragma once
+#include "common.hpp"
+#include "nn_core.hpp"
+
+namespace fiesta {
+
+struct NnArgs {
+  nn::Geom g;
+  const uint32_t *occ;  // occupancy bitmap: row (x, y) at ((x * ny) + y) * nzw words, bit z
+  int nzw;
+  uint32_t *ctab;       // [ncx * ncy][ncz + 1]: first site of the cell; entry ncz: end of the row
+  uint32_t *sites;      // packed x << 20 | y << 10 | z
+  uint32_t sites_cap;
+  uint32_t *lists;      // [cells][nn::kStride]: the cells' records (nn_core.hpp), dword 0 = entries (0: the cell has no list)
+  unsigned long long *cursor;   // sites handed out so far
+  unsigned long long *failed;   // cells without a list (+ 1 if the site array overflowed)
+  unsigned long long *entries;  // list entries in total (statistics, and what the engine choice learns from)
+  unsigned long long *maxd2;    // TRACK: atomicMax of every d^2 written
+  vox_t *coc;
+};
+
+// ---- sites by cell row ---------------------------------------------------------------------------------------------------
+// One batch of loads per wave: the 64 voxel rows of the cell row, a byte per lane and row (two on a 1024-voxel axis), kept
+// in registers for both halves -- counting, and after the wave's range of the site array is known, writing the sites.
+__global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell rows per work-group, one per wave
+  __shared__ uint32_t s_tot[16], s_start[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 16 + wave;
+  const nn::Geom &g = a.g;
+  const bool rlive = row < g.ncx * g.ncy;  // (wave-uniform)
+  const int cx = rlive ? row / g.ncy : 0, cy = rlive ? row % g.ncy : 0;
+  const int nchunk = (g.ncz + 63) >> 6;  // cells of the row per lane
+  uint32_t pk[2][16];  // pk[k][r / 4] byte r % 4: the 8 z-bits of voxel row r (x = r / 8, y = r % 8) in cell lane + 64 k
+  uint32_t cnt[2] = {0, 0};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = lane + 64 * k;
+    const bool has = rlive && k < nchunk && c < g.ncz;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pk[k][q] = 0;
+    if (k < nchunk) {
+#pragma unroll
+      for (int r = 0; r < 64; ++r) {
+        const int x = nn::kB * cx + (r >> 3), y = nn::kB * cy + (r & 7);
+        const bool in = x < g.nx && y < g.ny;  // (wave-uniform)
+        const uint8_t *bytes = reinterpret_cast<const uint8_t *>(a.occ + ((int64_t)(in ? x : 0) * g.ny + (in ? y : 0)) * a.nzw);
+        const uint32_t m = (in && has) ? (uint32_t)bytes[has ? c : 0] : 0u;
+        pk[k][r >> 2] |= m << (8 * (r & 3));
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cnt[k] += (uint32_t)__popc(pk[k][q]);
+    }
+  }
+  uint32_t first[2];
+  uint32_t base = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    uint32_t incl = cnt[k];
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= off) incl += up;
+    }
+    first[k] = base + incl - cnt[k];
+    base += (uint32_t)__shfl((int)incl, 63);
+  }
+  const uint32_t total = base;
+  // the work-group's range of the site array: ONE atomic on the cursor (4096 of them, one per row, serialised for 60 us:
+  // device-scope atomics on one address cross the XCDs)
+  if (lane == 0) s_tot[wave] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t sum = 0;
+    for (int w = 0; w < 16; ++w) s_start[w] = sum, sum += s_tot[w];
+    const uint32_t at = sum ? (uint32_t)atomicAdd(a.cursor, (unsigned long long)sum) : 0u;
+    if ((unsigned long long)at + sum > a.sites_cap) atomicAdd(a.failed, 1ull);
+    for (int w = 0; w < 16; ++w) s_start[w] += at;
+  }
+  __syncthreads();
+  if (!rlive) return;
+  const uint32_t start = s_start[wave];
+  uint32_t *tab = a.ctab + (int64_t)row * (g.ncz + 1);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = lane + 64 * k;
+    if (k < nchunk && c < g.ncz) tab[c] = start + first[k];
+  }
+  if (lane == 0) tab[g.ncz] = start + total;
+  if (total == 0) return;  // (wave-uniform)
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (cnt[k] == 0) continue;
+    const int c = lane + 64 * k;
+    uint32_t at = start + first[k];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      uint32_t m = pk[k][q];
+      while (m) {  // in a cell: x-major, then y, then z
+        const int bit = __ffs((int)m) - 1;
+        m &= m - 1;
+        const int r = 4 * q + (bit >> 3);
+        if (at < a.sites_cap)
+          a.sites[at] = ((uint32_t)(nn::kB * cx + (r >> 3)) << 20) | ((uint32_t)(nn::kB * cy + (r & 7)) << 10) | (uint32_t)(nn::kB * c + (bit & 7));
+        ++at;
+      }
+    }
+  }
+}
+
+// ---- one list per cell ------------------------------------------------------------------------------------------------------
+// The neighbourhood of a work-group's 64 (z) x 4 (y) cells in LDS: table rows and sites of the cells within kStageK of it.
+// A window that reaches farther (a cell whose nearest obstacle is more than ~16 voxels away) reads those rows from memory.
+constexpr int kStageK = 3;
+constexpr int kStageNX = 1 + 2 * kStageK, kStageNY = 4 + 2 * kStageK, kStageNR = kStageNX * kStageNY;  // 7 x 10 rows of cells
+constexpr int kStageNZ = 64 + 2 * kStageK + 1;                                                          // table entries per row
+constexpr int kStageSites = 3072;
+struct StagedSrc {
+  nn::PlainSrc plain;
+  const uint32_t *tab;     // [kStageNR][kStageNZ]: entry e of a row = the first site of cell Zf + e (clamped into the row)
+  const uint32_t *delta;   // [kStageNR]: LDS index of a staged site = its index in the site array + delta[row]
+  const uint32_t *lsites;
+  int X0, Y0, Zf;
+  bool staged;
+  __device__ __forceinline__ void bounds(int X, int Y, int z0, int z1, uint32_t &i0, uint32_t &i1) const {
+    const int rx = X - X0, ry = Y - Y0, e0 = z0 - Zf, e1 = z1 + 1 - Zf;
+    if (staged && (unsigned)rx < (unsigned)kStageNX && (unsigned)ry < (unsigned)kStageNY && e0 >= 0 && e1 < kStageNZ) {
+      const int row = rx * kStageNY + ry;
+      const uint32_t d = delta[row];
+      i0 = (tab[row * kStageNZ + e0] + d) | 0x80000000u, i1 = (tab[row * kStageNZ + e1] + d) | 0x80000000u;
+    } else {
+      plain.bounds(X, Y, z0, z1, i0, i1);
+    }
+  }
+  __device__ __forceinline__ uint32_t site(uint32_t i) const { return (i & 0x80000000u) ? lsites[i & 0x7FFFFFFFu] : plain.sites[i]; }
+};
+
+// A team of four adjacent lanes builds one list (nn_core.hpp: Team): the rows of the window dealt out among them.
+struct QuadTeam {
+  static constexpr int lanes = 4;
+  int rank;
+  uint32_t *counter;  // LDS: entries handed out so far (the lanes of a quad run in lock step: slots are deterministic)
+  __device__ __forceinline__ void nearest(int &e2, uint32_t &w) const {
+#pragma unroll
+    for (int off = 1; off <= 2; off <<= 1) {
+      const int oe = __shfl_xor(e2, off);
+      const uint32_t ow = (uint32_t)__shfl_xor((int)w, off);
+      if (oe < e2 || (oe == e2 && ow < w)) e2 = oe, w = ow;
+    }
+  }
+  __device__ __forceinline__ int slot() { return (int)atomicAdd(counter, 1u); }
+  __device__ __forceinline__ int count() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the quad's lanes have left their loops: same wave, program order)
+    return (int)*(volatile uint32_t *)counter;
+  }
+};
+
+__global__ __launch_bounds__(1024) void k_nn_lists(NnArgs a) {  // 64 (z) x 4 (y) cells, four lanes each
+  __shared__ uint32_t s_tab[kStageNR * kStageNZ];
+  __shared__ uint32_t s_delta[kStageNR], s_cnt[kStageNR];
+  __shared__ uint32_t s_sites[kStageSites];
+  __shared__ uint32_t s_slots[256];
+  __shared__ uint32_t s_total, s_bad, s_sum;
+  const nn::Geom &g = a.g;
+  const int tid = (int)threadIdx.x;
+  const int cz0 = (int)blockIdx.x * 64, cy0 = (int)blockIdx.y * 4, cx = (int)blockIdx.z;
+  const int X0 = cx - kStageK, Y0 = cy0 - kStageK, Zf = cz0 - kStageK;
+  const int64_t rowlen = g.ncz + 1;
+  if (tid < 256) s_slots[tid] = 0;
+  if (tid == 0) s_bad = 0, s_sum = 0;
+  for (int idx = tid; idx < kStageNR * kStageNZ; idx += 1024) {
+    const int row = idx / kStageNZ, e = idx - row * kStageNZ;
+    const int X = X0 + row / kStageNY, Y = Y0 + row % kStageNY;
+    uint32_t v = 0;
+    if ((unsigned)X < (unsigned)g.ncx && (unsigned)Y < (unsigned)g.ncy) {
+      const int cz = min(max(Zf + e, 0), g.ncz);
+      v = a.ctab[((int64_t)X * g.ncy + Y) * rowlen + cz];
+    }
+    s_tab[idx] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {  // LDS offsets of the rows' sites: a scan over kStageNR <= 128 counts
+    uint32_t c0 = tid < kStageNR ? s_tab[tid * kStageNZ + kStageNZ - 1] - s_tab[tid * kStageNZ] : 0u;
+    uint32_t c1 = tid + 64 < kStageNR ? s_tab[(tid + 64) * kStageNZ + kStageNZ - 1] - s_tab[(tid + 64) * kStageNZ] : 0u;
+    uint32_t i0 = c0, i1 = c1;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u0 = (uint32_t)__shfl_up((int)i0, off), u1 = (uint32_t)__shfl_up((int)i1, off);
+      if (tid >= off) i0 += u0, i1 += u1;
+    }
+    const uint32_t t0 = (uint32_t)__shfl((int)i0, 63);
+    if (tid < kStageNR) s_delta[tid] = (i0 - c0) - s_tab[tid * kStageNZ], s_cnt[tid] = c0;
+    if (tid + 64 < kStageNR) s_delta[tid + 64] = (t0 + i1 - c1) - s_tab[(tid + 64) * kStageNZ], s_cnt[tid + 64] = c1;
+    if (tid == 63) s_total = t0 + i1;
+  }
+  __syncthreads();
+  const bool staged = s_total <= (uint32_t)kStageSites;
+  if (staged) {
+    for (int idx = tid; idx < kStageNR * 16; idx += 1024) {
+      const int row = idx >> 4;
+      const uint32_t cnt = s_cnt[row], first = s_tab[row * kStageNZ], d = s_delta[row];
+      for (uint32_t j = (uint32_t)(idx & 15); j < cnt; j += 16) s_sites[first + j + d] = a.sites[first + j];
+    }
+  }
+  __syncthreads();
+  const int ci = tid >> 2;  // cell of the work-group: 16 per wave, consecutive in z
+  const int cz = cz0 + (ci & 63), cy = cy0 + (ci >> 6);
+  int n = 0;
+  const bool live = cz < g.ncz && cy < g.ncy;  // (the same for the four lanes of a team)
+  QuadTeam team{tid & 3, &s_slots[ci]};
+  if (live) {
+    const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
+    StagedSrc src{nn::PlainSrc{a.ctab, a.sites, g.ncy, g.ncz}, s_tab, s_delta, s_sites, X0, Y0, Zf, staged};
+    n = nn::build_list(g, src, team, cx, cy, cz, a.lists + cell * nn::kStride);
+  }
+  // statistics: failures and entries, one atomic each per work-group
+  if (live && team.rank == 0) {
+    if (n == 0) atomicAdd(&s_bad, 1u);
+    else atomicAdd(&s_sum, (uint32_t)n);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (s_bad) atomicAdd(a.failed, (unsigned long long)s_bad);
+    if (s_sum) atomicAdd(a.entries, (unsigned long long)s_sum);
+  }
+}
+
+// ---- every voxel's minimum over its cell's list -------------------------------------------------------------------------------
+// Sums of the four signed byte products of a with b0 and with b1 (v_dot4_i32_i8, VOP3P).  Written as ONE asm statement that
+// ends in s_nop 2: on gfx940+ a VALU instruction must not read a DOT result within three wait states of the DOT, hipcc's
+// hazard recognizer pads its own DOTs but cannot look into inline asm, and without the padding the sums read back wrong
+// (tools/dev/serve_probe.hip reproduces it: the same loop is right with the nops, and with __builtin_amdgcn_sdot4 -- which
+// costs a mov + v_dot4c per product, two instructions more per pair of entries).  Early-clobber outputs: a DOT must not be
+// allocated onto its own sources either.
+__device__ __forceinline__ void nn_dot4_pair(uint32_t a, uint32_t b0, uint32_t b1, int &d0, int &d1) {
+  asm("v_dot4_i32_i8 %0, %2, %3, 0\n\tv_dot4_i32_i8 %1, %2, %4, 0\n\ts_nop 2" : "=&v"(d0), "=&v"(d1) : "v"(a), "v"(b0), "v"(b1));
+}
+
+constexpr int kFillBlocks = 2048;  // persistent work-groups of four waves: 8 per CU, 32 cells per wave on a 512^3 map
+constexpr int kListPad = 64;       // dwords the list array is over-allocated by
+
+// A QUAD is four cells adjacent in z, one per wave of the work-group: their stores complete 128-byte lines.  The quads of
+// the map in row-major order are dealt out in contiguous runs, one run per work-group.
+//
+// Memory choreography of one wave (the k_ft_x recipe, ft_kernels.hpp): the next cell's record -- 512 bytes: the count, then
+// 16 bytes (b, K, m, W) per entry -- is fetched by LDS-DMA (global_load_lds_dword: lane i's dword lands at m0 + 4 i, no
+// register is in flight) into the other of two landing zones BEFORE this cell's arithmetic, issued and waited for by hand:
+// hipcc never sees a load, so it never drains vmcnt for one, and this cell's stores stay in flight behind the fetch
+// (gfx9 retires the loads and stores of a wave in issue order).  An entry is read back as ONE ds_read_b128 from a
+// wave-uniform address (a broadcast): b, K and m arrive in VGPRs holding the same value in every lane -- no scalar loads,
+// no readlane.  FULL maps only: every extent a multiple of the cell edge, rows a multiple of four cells long, runs of an
+// even number of quads -- no predicate anywhere, so the number of stores between a fetch and its wait is the same on every
+// path.  Other maps take the simple predicated variant below.
+template <bool TRACK>
+__global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
+  constexpr int kTileRow = 40;  // dwords between two rows of the tile: 32 + padding that spreads the rows over the banks
+  __shared__ __attribute__((aligned(16))) uint32_t land[4][2][nn::kStride];  // per wave, two zones of one record each
+  __shared__ __attribute__((aligned(16))) uint32_t tile[nn::kB * nn::kB * kTileRow];
+  const nn::Geom &g = a.g;
+  if (*a.failed) return;  // some cell has no list: the envelope passes serve this update (dense_map.hip)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int quads = g.ncz >> 2;
+  const uint32_t nq = (uint32_t)(g.ncx * g.ncy) * (uint32_t)quads;
+  const uint32_t per = nq / gridDim.x;  // (even, and gridDim.x * per == nq: the host's choice)
+  const uint32_t q0 = blockIdx.x * per, q1 = q0 + per;
+  const int row0 = (int)(q0 / (uint32_t)quads);
+  const int y = lane >> 3, z = lane & 7;
+  const uint32_t ayz = (uint32_t)y | ((uint32_t)z << 8);
+  const int64_t plane = (int64_t)g.ny * g.nz;
+  const int loff4 = y * g.nz + 4 * z;  // the lane's 16 bytes of a stored slab: row y, voxels 4 z .. 4 z + 3 of the quad's 32
+  uint32_t dmax = 0;
+  const uint32_t zone0 = (uint32_t)(size_t)&land[wave][0][0];  // LDS byte offsets: the low half of the generic address
+  struct At { int cx, cy, q; };  // a quad: cell row (cx, cy), quad q of it
+  auto fetch = [&](const At &c, const int zone) {
+    const int64_t cell = ((int64_t)c.cx * g.ncy + c.cy) * g.ncz + 4 * c.q + wave;
+    const uint32_t *lp = a.lists + cell * nn::kStride + lane, *hp = lp + 64;
+    const uint32_t at = zone0 + (uint32_t)zone * (uint32_t)(nn::kStride * 4);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off\n\t"
+                 "s_mov_b32 m0, %2\n\tglobal_load_lds_dword %3, off"
+                 : : "s"(at), "v"(lp), "s"(at + 256u), "v"(hp) : "memory", "m0");
+  };
+  auto advance = [&](At &c) {
+    if (++c.q == quads) {
+      c.q = 0;
+      if (++c.cy == g.ncy) c.cy = 0, ++c.cx;
+    }
+  };
+  auto serve = [&](const At &c, const int zone) {
+    const uint32_t *lz = &land[wave][zone][0];
+    const int cnt = __builtin_amdgcn_readfirstlane((int)lz[0]);
+    uint32_t best[nn::kB];
+#pragma unroll
+    for (int x = 0; x < nn::kB; ++x) best[x] = 0xFFFFFFFFu;
+    for (int i = 0; i < cnt; i += 2) {  // two entries per step (an odd list ends with a padding entry)
+      const uint4 e0 = *reinterpret_cast<const uint4 *>(lz + 4 + 4 * i), e1 = *reinterpret_cast<const uint4 *>(lz + 8 + 4 * i);
+      int d0, d1;
+      nn_dot4_pair(ayz, e0.x, e1.x, d0, d1);
+      uint32_t k0 = ((uint32_t)d0 << nn::kSH) + e0.y, k1 = ((uint32_t)d1 << nn::kSH) + e1.y;
+      best[0] = min(best[0], min(k0, k1));
+#pragma unroll
+      for (int x = 1; x < nn::kB; ++x) {
+        k0 += e0.z, k1 += e1.z;
+        best[x] = min(best[x], min(k0, k1));
+      }
+    }
+    uint32_t ww[nn::kB];
+#pragma unroll
+    for (int x = 0; x < nn::kB; ++x) {
+      ww[x] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lz + 7) + (best[x] & 0x1F0u));
+      if (TRACK) dmax = max(dmax, (best[x] >> nn::kSH) - (uint32_t)nn::kBias + (uint32_t)(x * x + y * y + z * z));
+    }
+    // Full lines out: a cell's z-rows are 32 bytes, and stored as such (eight 32-byte pieces per store instruction, the
+    // other three quarters of each 128-byte line coming from the other waves at their own pace) the same bytes took 270 us
+    // instead of 120.  The quad's four waves exchange through an LDS tile [x][y][32 z] and each stores two x-slabs of it:
+    // 16 bytes per lane, eight whole 128-byte lines per instruction.
+    asm volatile("s_barrier" ::: "memory");  // the tile's readers of the quad before are done
+#pragma unroll
+    for (int x = 0; x < nn::kB; ++x) tile[(x * nn::kB + y) * kTileRow + nn::kB * wave + z] = ww[x];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    vox_t *slab = a.coc + ((int64_t)(nn::kB * c.cx + 2 * wave) * g.ny + nn::kB * c.cy) * g.nz + 4 * nn::kB * c.q;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(&tile[((2 * wave + j) * nn::kB + y) * kTileRow + 4 * z]);
+      *reinterpret_cast<uint4 *>(slab + loff4) = v;  // lane (y, z): row y of the slab, z-voxels 4 z .. 4 z + 3 of the quad
+      slab += plane;
+    }
+  };
+  // Zones 0 and 1 alternate between "being fetched" and "being served".  The wave's VMEM operations in issue order, per
+  // round:  F1 (2 loads) | S0 (2 stores) | F0' (2 loads) | S1 (2 stores);  a fetch is needed one serve after it was issued.
+  At ca{row0 / g.ncy, row0 % g.ncy, (int)(q0 % (uint32_t)quads)}, cb;
+  fetch(ca, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (uint32_t q = q0; q < q1; q += 2) {
+    cb = ca;
+    advance(cb);
+    fetch(cb, 1);  // (zone 1 was last read by the serve at the end of the round before: lgkmcnt(0) stands behind it)
+    serve(ca, 0);  // (zone 0 has landed: the wait before the loop / at the end of the round before)
+    ca = cb;
+    if (q + 2 < q1) advance(ca);  // (the run's last fetch re-reads its last cell: no branch around a load)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zone 0's LDS reads are done before the DMA may overwrite it
+    fetch(ca, 0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // zone 1 has landed: behind F1 only S0's two stores and F0''s two loads
+    serve(cb, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(2)" ::: "memory");  // zone 0 has landed: behind F0' only S1's two stores
+  }
+  if (TRACK) {
+    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
+    if (lane == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
+  }
+}
+
+// The predicated variant for maps with cells cut by the array's faces: one wave per cell, the record through the scalar cache.
+typedef __attribute__((address_space(4))) const uint32_t nn_cu32;  // constant address space: wave-uniform reads become s_load
+typedef uint32_t nn_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const nn_u32x4 nn_cu32x4;
+template <bool TRACK>
+__global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
+  const nn::Geom &g = a.g;
+  if (*a.failed) return;
+  // grid (ceil(ncz / 4), ncy, ncx)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cz = (int)blockIdx.x * 4 + wave, cy = (int)blockIdx.y, cx = (int)blockIdx.z;
+  if (cz >= g.ncz) return;
+  const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
+  const uint32_t *rec = a.lists + cell * nn::kStride;
+  nn_cu32 *lp = reinterpret_cast<nn_cu32 *>(reinterpret_cast<uintptr_t>(rec));
+  const int cnt = (int)lp[0];
+  const int y = lane >> 3, z = lane & 7;
+  const uint32_t ayz = (uint32_t)y | ((uint32_t)z << 8);
+  uint32_t best[nn::kB];
+#pragma unroll
+  for (int x = 0; x < nn::kB; ++x) best[x] = 0xFFFFFFFFu;
+  for (int i = 0; i < cnt; ++i) {
+    const nn_u32x4 e = *reinterpret_cast<nn_cu32x4 *>(lp + 4 + 4 * i);
+    uint32_t k = ((uint32_t)__builtin_amdgcn_sdot4((int)ayz, (int)e.x, 0, false) << nn::kSH) + e.y;
+    best[0] = min(best[0], k);
+#pragma unroll
+    for (int x = 1; x < nn::kB; ++x) {
+      k += e.z;
+      best[x] = min(best[x], k);
+    }
+  }
+  const int X0 = nn::kB * cx, Y = nn::kB * cy + y, Z = nn::kB * cz + z;
+  const bool inyz = Y < g.ny && Z < g.nz;
+  vox_t *out = a.coc + ((int64_t)X0 * g.ny + Y) * g.nz + Z;
+  const int64_t plane = (int64_t)g.ny * g.nz;
+  uint32_t dmax = 0;
+#pragma unroll
+  for (int x = 0; x < nn::kB; ++x) {
+    const uint32_t ww = rec[7 + ((best[x] & 0x1F0u) >> 2)];
+    if (inyz && X0 + x < g.nx) {
+      out[x * plane] = ww;
+      if (TRACK) dmax = max(dmax, (best[x] >> nn::kSH) - (uint32_t)nn::kBias + (uint32_t)(x * x + y * y + z * z));
+    }
+  }
+  if (TRACK) {
+    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
+    if (lane == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
+  }
+}
+
+}  // namespace fiesta

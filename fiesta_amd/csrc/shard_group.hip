@@ -393,7 +393,7 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
       bool el = false;
       locals_[i]->map->bulk_probe(&ni, &nd, &nocc, &el);
       rows[i][0] = el ? 1 : 0, rows[i][1] = (long long)ni, rows[i][2] = (long long)nd, rows[i][3] = nocc;
-      rows[i][4] = locals_[i]->map->update_engine();
+      rows[i][4] = locals_[i]->map->bulk_pinned() ? 2 : locals_[i]->map->update_engine();
       // what the cost model needs, as numbers every rank will see (the decision used to read rank-local state --
       // the last transform's time, this shard's voxel count -- and two ranks could enter different collectives)
       rows[i][5] = (long long)locals_[i]->map->total();

@@ -34,6 +34,9 @@ def _d3(v):
     return np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(3))
 
 
+ENGINES = {"auto": 0, "rounds": 1, "bulk": 2, "levels": 3, "envelope": 4, "cells": 5}
+
+
 class ESDFMap:
     """Drop-in for ``fiesta::ESDFMap``; array mode by default, hash-block mode with ``mode="hash"``."""
 
@@ -49,7 +52,7 @@ class ESDFMap:
         cfg.reserve_size = int(reserve_size)
         if update_engine is None or update_engine == 0 or update_engine == "auto":
             update_engine = DEFAULT_UPDATE_ENGINE
-        cfg.update_engine = {"auto": 0, "rounds": 1, "bulk": 2, "levels": 3}.get(update_engine, update_engine)
+        cfg.update_engine = ENGINES.get(update_engine, update_engine)
         if shard_lo is not None:
             cfg.shard_lo[:] = [int(v) for v in shard_lo]
             cfg.global_grid[:] = [int(v) for v in global_grid]
@@ -100,7 +103,7 @@ class ESDFMap:
 
     def set_update_engine(self, update_engine):
         """"auto" / "rounds" / "bulk" / "levels" (0 / 1 / 2 / 3) from the next UpdateESDF on."""
-        check(self._lib.fiesta_hip_set_update_engine(self._h, {"auto": 0, "rounds": 1, "bulk": 2, "levels": 3}.get(update_engine, update_engine)))
+        check(self._lib.fiesta_hip_set_update_engine(self._h, ENGINES.get(update_engine, update_engine)))
 
     # -- occupancy ingest ----------------------------------------------------------------------------
     def SetOccupancy(self, where, occ, want_ret=True):

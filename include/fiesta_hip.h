@@ -50,8 +50,9 @@ typedef struct fiesta_hip_config {
   int32_t reserve_size; /* hash mode: initial voxel reserve (src/ESDFMap.cpp:141-145) */
   int32_t update_engine; /* UpdateESDF engine: 0 = chosen per update (default), 1 = frontier rounds only, 2 = bulk
                             feature transform whenever the map is fully observed, 3 = level engine for
-                            every update its lists can hold (DESIGN.md 3a'); on fully observed maps the distances do not
-                            depend on it */
+                            every update its lists can hold, 4 = as 2 with the envelope passes only, 5 = as 2
+                            with the cell transform wherever it applies (2 chooses between the two); on
+                            fully observed maps the distances do not depend on it */
   /* Spatial sharding. A map may be one shard of a larger global grid: it owns the global
    * voxel box [shard_lo, shard_lo + grid) and stores closest-obstacle ids in GLOBAL coordinates. For an
    * unsharded map leave these zero. */
@@ -86,6 +87,12 @@ typedef struct fiesta_hip_stats {
                             reference's FIFO); 0 with bulk == 0: the frontier rounds ran (possibly after the level engine's
                             lists overflowed) */
   int64_t grid_levels;   /* of `rounds` with levels == 1: levels that ran on many CUs (k_level_grid) rather than one */
+  int64_t cells;         /* with bulk == 1: the transform was the cell transform (nn_kernels.hpp: per-cell obstacle lists), not
+                            the envelope passes */
+  double nn_cells_ms, nn_lists_ms, nn_fill_ms; /* cell transform: HIP-event time of k_nn_cells / k_nn_lists / k_nn_fill */
+  int64_t nn_entries;    /* cell transform: list entries over all cells */
+  int64_t nn_failed;     /* cells that got no list when the cell transform was tried (> 0: the envelope passes served the
+                            update instead, cells == 0) */
 } fiesta_hip_stats;
 
 const char *fiesta_hip_last_error(void);

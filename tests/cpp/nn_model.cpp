@@ -1,0 +1,77 @@
+// tests/cpp/nn_model.cpp -- TEST INFRASTRUCTURE: host model of the cell transform's kernels (fiesta_amd/csrc/nn_kernels.hpp).
+//
+// Compiles fiesta_amd/csrc/nn_core.hpp -- the list rule, the search window, the keys -- with g++ and drives it the way the
+// three kernels do: sites ordered by cell row out of the occupancy bitmap (k_nn_cells), one list per cell (k_nn_lists),
+// every voxel's minimum key over its cell's list (k_nn_fill).  tests/test_nn_model.py checks the result against scipy's
+// exact transform on a machine without a GPU.  Not part of the product: libfiesta_hip.so never links this file.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../fiesta_amd/csrc/nn_core.hpp"
+
+using namespace fiesta::nn;
+
+extern "C" {
+// occ: [nx][ny][nz] bytes (0 / 1).  out: [nx][ny][nz] words (the packed site; 0x80000000 where the cell had no list).
+// stats: [0] cells without a list (the kernels would hand the update to the envelope passes), [1] list entries in total,
+// [2] longest list, [3] sites.  Returns 0.
+int nn_model_run(const uint8_t *occ, int nx, int ny, int nz, uint32_t *out, int64_t *stats) {
+  Geom g{nx, ny, nz, (nx + kB - 1) / kB, (ny + kB - 1) / kB, (nz + kB - 1) / kB};
+  const int64_t nrows = (int64_t)g.ncx * g.ncy;
+  std::vector<uint32_t> ctab((size_t)nrows * (g.ncz + 1));
+  std::vector<uint32_t> sites;
+  // k_nn_cells: per cell row (cx, cy), cells in z order, inside a cell x-major then y then z
+  for (int cx = 0; cx < g.ncx; ++cx)
+    for (int cy = 0; cy < g.ncy; ++cy) {
+      uint32_t *row = ctab.data() + ((int64_t)cx * g.ncy + cy) * (g.ncz + 1);
+      for (int cz = 0; cz < g.ncz; ++cz) {
+        row[cz] = (uint32_t)sites.size();
+        for (int x = kB * cx; x < kB * cx + kB && x < nx; ++x)
+          for (int y = kB * cy; y < kB * cy + kB && y < ny; ++y)
+            for (int z = kB * cz; z < kB * cz + kB && z < nz; ++z)
+              if (occ[((int64_t)x * ny + y) * nz + z]) sites.push_back(((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)z);
+      }
+      row[g.ncz] = (uint32_t)sites.size();
+    }
+  int64_t failed = 0, entries = 0, longest = 0;
+  std::vector<uint32_t> list(kStride);
+  for (int cx = 0; cx < g.ncx; ++cx)
+    for (int cy = 0; cy < g.ncy; ++cy)
+      for (int cz = 0; cz < g.ncz; ++cz) {
+        const PlainSrc src{ctab.data(), sites.data(), g.ncy, g.ncz};
+        Solo solo;
+        const int n = build_list(g, src, solo, cx, cy, cz, list.data());
+        if ((int)list[0] != n) return 2;
+        if (n == 0) ++failed;
+        entries += n;
+        if (n > longest) longest = n;
+        const int npad = (n + 1) & ~1;
+        // k_nn_fill: lane (y, z), eight x-slabs
+        for (int x = 0; x < kB; ++x)
+          for (int y = 0; y < kB; ++y)
+            for (int z = 0; z < kB; ++z) {
+              const int X = kB * cx + x, Y = kB * cy + y, Z = kB * cz + z;
+              if (X >= nx || Y >= ny || Z >= nz) continue;
+              uint32_t best = 0xFFFFFFFFu;
+              for (int i = 0; i < npad; ++i) {
+                const uint32_t k = key_of(list[4 + 4 * i], list[5 + 4 * i], list[6 + 4 * i], x, y, z);
+                if (k < best) best = k;
+              }
+              uint32_t w = 0x80000000u;
+              if (n) {
+                w = list[4 + ((best & 0x1F0u) >> 2) + 3];
+                // the key's distance part is the true squared distance minus |v|^2, biased
+                int sx, sy, sz;
+                unpack_site(w, sx, sy, sz);
+                const int d2 = (sx - X) * (sx - X) + (sy - Y) * (sy - Y) + (sz - Z) * (sz - Z);
+                if ((int)(best >> kSH) - kBias + x * x + y * y + z * z != d2) return 1;
+              }
+              out[((int64_t)X * ny + Y) * nz + Z] = w;
+            }
+      }
+  stats[0] = failed, stats[1] = entries, stats[2] = longest, stats[3] = (int64_t)sites.size();
+  return 0;
+}
+}

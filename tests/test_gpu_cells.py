@@ -1,0 +1,197 @@
+"""The cell transform (fiesta_amd/csrc/nn_kernels.hpp) on the GPU: UpdateESDF on fully observed maps with a
+sparse obstacle set, served by per-cell obstacle lists instead of the envelope passes.  Same bar as every fully observed
+test: squared distances equal to the reference's / the exact transform's on every voxel, ids tie-equivalent (occupied, at
+exactly that distance).  Also: which transform the library picks, that a scene the cell transform cannot serve (a cell
+with no obstacle in reach, a wall) is handed to the envelope passes within the same call, and that the tracked distance
+bound is maintained.  The CPU model of the same arithmetic is tests/test_nn_model.py."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from scenarios import P_DEFAULT, Both, all_voxels, assert_exact, compare_dense
+
+pytestmark = pytest.mark.gpu
+
+
+def make_map(shape, engine, res=0.1):
+    import fiesta_amd
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, tuple((s - 0.5) * res for s in shape), update_engine=engine)   # (ceil(size / res) voxels)
+    assert tuple(m.grid_size) == tuple(shape)
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    m.SetOccupancyBox((0, 0, 0), tuple(s - 1 for s in shape), 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    return m
+
+
+def occupy(m, vox, cycles=3):
+    for _ in range(cycles):
+        m.SetOccupancy(np.ascontiguousarray(vox, np.int32), 1, want_ret=False)
+        m.UpdateOccupancy(True)
+
+
+def free(m, vox, cycles=6):
+    for _ in range(cycles):
+        m.SetOccupancy(np.ascontiguousarray(vox, np.int32), 0, want_ret=False)
+        m.UpdateOccupancy(True)
+
+
+def check_exact(m, shape):
+    f = m.download_field(("d2", "coc", "occ"))
+    occ = f["occ"].reshape(shape)
+    d2 = f["d2"].reshape(shape).astype(np.int64)
+    assert occ.any()
+    idx = ndimage.distance_transform_edt(occ == 0, return_distances=False, return_indices=True)
+    gx, gy, gz = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    want = (idx[0] - gx) ** 2 + (idx[1] - gy) ** 2 + (idx[2] - gz) ** 2
+    bad = int((d2 != want).sum())
+    assert bad == 0, f"{bad} voxels differ from the exact transform"
+    c = f["coc"].reshape(shape + (3,)).astype(np.int64)
+    assert np.all(occ[c[..., 0], c[..., 1], c[..., 2]] == 1), "a closest obstacle is not occupied"
+    own = (c[..., 0] - gx) ** 2 + (c[..., 1] - gy) ** 2 + (c[..., 2] - gz) ** 2
+    assert np.array_equal(own, want), "an id is not at the stored distance"
+
+
+SCENES = [((64, 64, 64), 200, 1), ((96, 72, 80), 300, 2), ((61, 45, 83), 230, 3), ((128, 128, 128), 1000, 12345),
+          ((33, 17, 130), 140, 5), ((24, 100, 9), 60, 7)]
+
+
+@pytest.mark.parametrize("shape,k,seed", SCENES)
+def test_cell_transform_is_the_exact_transform(hip_lib, shape, k, seed):
+    """scatter scenes, ragged extents (cells cut by the array's faces), insert then a mixed insert + delete update"""
+    m = make_map(shape, "cells")
+    rng = np.random.RandomState(seed)
+    S = (rng.randint(0, 1 << 20, (k, 3)) % np.array(shape)).astype(np.int32)
+    occupy(m, S)
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 1 and st["nn_failed"] == 0, st
+    assert st["nn_entries"] > 0
+    check_exact(m, shape)
+    new = (rng.randint(0, 1 << 20, (k // 2, 3)) % np.array(shape)).astype(np.int32)
+    for _ in range(6):
+        m.SetOccupancy(new, 1, want_ret=False)
+        m.SetOccupancy(S[: k // 2], 0, want_ret=False)
+        m.UpdateOccupancy(True)
+    st = m.UpdateESDF()
+    assert st["deleted"] > 0 and st["inserted"] > 0
+    assert st["bulk"] == 1 and st["cells"] == 1, st
+    check_exact(m, shape)
+    m.close()
+
+
+def test_cells_against_the_reference_with_queries(hip_lib, oracle_libs, best_oracle_kind):
+    """the same flow against the verbatim reference (ids tie-equivalent, log-odds, queues) -- config 1's size and scene"""
+    import fiesta_amd
+    n, res = 128, 0.1
+    gpu = fiesta_amd.ESDFMap((0, 0, 0), res, (n * res,) * 3, update_engine="cells")
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, (n * res,) * 3, kind=best_oracle_kind)
+    b = Both(gpu, cpu)
+    b.params()
+    gpu.SetOriginalRange()
+    cpu.SetOriginalRange()
+    b.observe(all_voxels(n), 0)
+    b.fuse()
+    b.esdf()
+    S = np.random.RandomState(12345).randint(0, n, (1000, 3)).astype(np.int32)
+    b.make_occupied(S)
+    sg, _ = b.esdf()
+    assert sg["cells"] == 1
+    assert_exact(compare_dense(gpu, cpu))
+    b.make_free(S[:500])
+    sg, _ = b.esdf()
+    assert sg["cells"] == 1
+    assert_exact(compare_dense(gpu, cpu))
+    pos = np.random.RandomState(3).uniform(0.2, n * res - 0.2, (2000, 3))
+    dg, gg = gpu.GetDistWithGradTrilinear(pos)
+    dc, gc = cpu.GetDistWithGradTrilinear(pos)
+    assert np.array_equal(dg, dc) and np.array_equal(gg, gc)
+    gpu.close()
+    cpu.close()
+
+
+def test_scenes_the_cell_transform_cannot_serve_go_to_the_envelope_passes(hip_lib):
+    """one obstacle in a 96^3 map (cells with nothing in reach) and a wall (more candidates than a list holds): the cell
+    transform reports failed cells, the SAME UpdateESDF call finishes on the envelope passes, the result is exact; the
+    library does not try again at that obstacle count unless pinned"""
+    shape = (96, 96, 96)
+    m = make_map(shape, "cells")
+    occupy(m, np.array([[3, 4, 5]], np.int32))
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 0 and st["nn_failed"] > 0, st
+    check_exact(m, shape)
+    m.close()
+    shape = (48, 48, 48)
+    m = make_map(shape, "bulk")
+    wall = np.array([(x, y, 20) for x in range(48) for y in range(48)], np.int32)[::23]  # 101 voxels of a plane: density in range
+    occupy(m, wall)
+    st = m.UpdateESDF()
+    check_exact(m, shape)
+    first_cells = st["cells"]
+    occupy(m, np.array([(x, y, 20) for x in range(48) for y in range(48)], np.int32))
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1
+    check_exact(m, shape)
+    m.set_update_engine("cells")
+    free(m, np.array([[0, 0, 20]], np.int32))
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 0 and st["nn_failed"] > 0, (st, first_cells)
+    check_exact(m, shape)
+    m.close()
+
+
+def test_which_transform_the_library_picks(hip_lib):
+    """density inside the cell transform's range -> cells; outside (a handful of obstacles, or one in forty voxels) -> the
+    envelope passes; engine "envelope" never runs the cell transform; all three fields identical"""
+    shape = (80, 80, 80)
+    rng = np.random.RandomState(9)
+    S = rng.randint(0, 80, (300, 3)).astype(np.int32)   # 5.9e-4 of the voxels
+    fields = []
+    for engine, want_cells in (("bulk", 1), ("envelope", 0), ("cells", 1), ("auto", 1)):
+        m = make_map(shape, engine)
+        occupy(m, S)
+        st = m.UpdateESDF()
+        assert st["bulk"] == 1 and st["cells"] == want_cells, (engine, st)
+        fields.append(m.download_field(("d2",))["d2"].copy())
+        m.close()
+    for f in fields[1:]:
+        assert np.array_equal(f, fields[0])
+    m = make_map(shape, "bulk")
+    occupy(m, S[:5])                                   # 1e-5: nothing within a cell's reach almost everywhere
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 0 and st["nn_failed"] == 0, st   # (not even tried)
+    check_exact(m, shape)
+    dense = rng.randint(0, 80, (20000, 3)).astype(np.int32)  # 3.8e-2
+    occupy(m, dense)
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 0 and st["nn_failed"] == 0, st
+    check_exact(m, shape)
+    m.close()
+
+
+def test_cell_transform_keeps_the_tracked_distance_bound(hip_lib):
+    """a map that has seen a ray-cast frame tracks the largest stored distance (the delete scan of the other engines is
+    bounded by it): after a cell transform the bound must cover the field, or a later small delete misses orphans"""
+    import fiesta_amd
+    shape = (64, 64, 64)
+    m = make_map(shape, "cells")
+    # one ray-cast frame far from everything switches the tracking on (raycast.hip: enable_distance_tracking)
+    T = np.eye(4)
+    T[:3, 3] = (3.2, 3.2, 3.2)
+    pts = np.array([[0.3, 0.0, 0.0]], np.float32)
+    m.RaycastFrame(pts, T, (3.2, 3.2, 3.2), 0.05, 5.0, (-100.0,) * 3, (100.0,) * 3)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    rng = np.random.RandomState(4)
+    S = rng.randint(0, 64, (200, 3)).astype(np.int32)
+    occupy(m, S)
+    st = m.UpdateESDF()
+    assert st["cells"] == 1, st
+    check_exact(m, shape)
+    # a small delete on the rounds / level engine: its scan must reach every voxel that pointed at the deleted obstacles
+    m.set_update_engine("rounds")
+    free(m, S[:3])
+    st = m.UpdateESDF()
+    assert st["bulk"] == 0
+    check_exact(m, shape)
+    m.close()

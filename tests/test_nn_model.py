@@ -1,0 +1,127 @@
+"""The cell transform's arithmetic (fiesta_amd/csrc/nn_core.hpp: which obstacles a cell's list must hold, the search window
+that finds them, the keys a voxel minimises) checked on the CPU: tests/cpp/nn_model.cpp drives the very header the HIP
+kernels of nn_kernels.hpp are built on, and wherever every cell got its list the result must be the exact Euclidean
+feature transform (squared distances equal to scipy's EDT; every closest site occupied).  Cells that cannot be served --
+no obstacle within reach, too many candidates -- must say so (the GPU path then runs the envelope passes instead).
+No GPU, no oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "cpp", "nn_model.cpp")
+LIB = os.path.join(HERE, "cpp", "libnn_model.so")
+CORE = os.path.join(os.path.dirname(HERE), "fiesta_amd", "csrc", "nn_core.hpp")
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(CORE)):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", LIB, SRC], check=True)
+    lib = C.CDLL(LIB)
+    lib.nn_model_run.restype = C.c_int
+    lib.nn_model_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def run(lib, occ):
+    nx, ny, nz = occ.shape
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    out = np.full(occ.shape, 0xDEADBEEF, np.uint32)
+    stats = np.zeros(4, np.int64)
+    rc = lib.nn_model_run(occ.ctypes.data, nx, ny, nz, out.ctypes.data, stats.ctypes.data)
+    assert rc == 0, "a key's distance part disagrees with the site it names (1) / the record's count with the return value (2)"
+    return out, dict(failed=int(stats[0]), entries=int(stats[1]), longest=int(stats[2]), sites=int(stats[3]))
+
+
+def check_exact(occ, out, served=None):
+    nx, ny, nz = occ.shape
+    idx = ndimage.distance_transform_edt(occ == 0, return_distances=False, return_indices=True)
+    gx, gy, gz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    want = (idx[0] - gx) ** 2 + (idx[1] - gy) ** 2 + (idx[2] - gz) ** 2
+    sel = np.ones(occ.shape, bool) if served is None else served
+    o = out[sel]
+    assert np.all(o < 0x40000000)
+    cx, cy, cz = (o >> 20).astype(np.int64), ((o >> 10) & 1023).astype(np.int64), (o & 1023).astype(np.int64)
+    assert cx.max() < nx and cy.max() < ny and cz.max() < nz
+    assert np.all(occ[cx, cy, cz] == 1), "closest site is not occupied"
+    got = (cx - gx[sel]) ** 2 + (cy - gy[sel]) ** 2 + (cz - gz[sel]) ** 2
+    bad = np.flatnonzero(got != want[sel])
+    assert len(bad) == 0, f"{len(bad)} voxels differ from the exact transform"
+
+
+def scatter(shape, density, seed):
+    rng = np.random.RandomState(seed)
+    return (rng.rand(*shape) < density).astype(np.uint8)
+
+
+# (shape, density, seed): ragged extents, the benchmark's density (3.7e-4), denser and sparser neighbours of it
+CASES = [((64, 64, 64), 3.7e-4, 1), ((96, 72, 80), 3.7e-4, 2), ((61, 45, 83), 1e-3, 3), ((40, 40, 40), 5e-3, 4),
+         ((33, 17, 130), 2e-3, 5), ((128, 128, 128), 3.7e-4, 6), ((24, 100, 9), 3e-3, 7), ((70, 70, 70), 2e-2, 8)]
+
+
+@pytest.mark.parametrize("shape,density,seed", CASES)
+def test_cell_lists_give_the_exact_transform(model, shape, density, seed):
+    occ = scatter(shape, density, seed)
+    if not occ.any():
+        occ[tuple(s // 2 for s in shape)] = 1
+    out, st = run(model, occ)
+    assert st["sites"] == int(occ.sum())
+    ncell = np.prod([(s + 7) // 8 for s in shape])
+    if st["failed"] == 0:
+        check_exact(occ, out)
+    else:  # the served cells are still exact; the others say "no list"
+        served = out != 0x80000000
+        assert (~served).sum() > 0
+        check_exact(occ, out, served)
+    print(shape, density, "cells", ncell, st, "mean list", st["entries"] / max(1, ncell - st["failed"]))
+
+
+def test_benchmark_density_needs_no_fallback(model):
+    """config 2's scene at a size the model runs in seconds: every cell must be served, lists short"""
+    rng = np.random.RandomState(12345)
+    n = 160
+    occ = np.zeros((n, n, n), np.uint8)
+    v = rng.randint(0, n, (int(50000 * (n / 512.0) ** 3), 3))
+    occ[v[:, 0], v[:, 1], v[:, 2]] = 1
+    out, st = run(model, occ)
+    assert st["failed"] == 0, st
+    assert st["longest"] <= 30 and st["entries"] / (n // 8) ** 3 < 9.0, st
+    check_exact(occ, out)
+
+
+def test_cells_that_cannot_be_served_say_so(model):
+    """one obstacle in a 96^3 map: cells farther than the window's reach have no list; a wall: more candidates than a list
+    holds.  Both must be reported, never answered wrongly."""
+    occ = np.zeros((96, 96, 96), np.uint8)
+    occ[3, 4, 5] = 1
+    out, st = run(model, occ)
+    assert st["failed"] > 0
+    served = out != 0x80000000
+    assert served.sum() > 0
+    check_exact(occ, out, served)
+    wall = np.zeros((48, 48, 48), np.uint8)
+    wall[:, :, 20] = 1
+    out, st = run(model, wall)
+    assert st["failed"] > 0
+    served = out != 0x80000000
+    if served.any():
+        check_exact(wall, out, served)
+
+
+def test_ties_and_clusters(model):
+    """obstacles on a regular lattice (every voxel between them ties) and a dense cluster inside an empty region"""
+    occ = np.zeros((64, 64, 64), np.uint8)
+    occ[4::12, 4::12, 4::12] = 1
+    out, st = run(model, occ)
+    assert st["failed"] == 0
+    check_exact(occ, out)
+    occ = scatter((64, 64, 64), 4e-4, 21)
+    occ[28:33, 30:34, 29:31] = 1
+    out, st = run(model, occ)
+    served = out != 0x80000000
+    check_exact(occ, out, served)
