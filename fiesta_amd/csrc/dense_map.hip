@@ -1399,12 +1399,12 @@ bool DenseMap::run_cells(fiesta_hip_stats *st) {
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[2], stream_));
   const int64_t nq = nrows * ((a.g.ncz + 3) / 4);
   unsigned fill_blocks = (unsigned)std::min<int64_t>(nq, kFillBlocks);
-  // the unpredicated variant: whole cells everywhere and runs of an even number of quads (k_nn_fill: FULL)
+  // the unpredicated variant: whole cells everywhere and the same number of quads for every wave (k_nn_fill_full)
   bool full = g.nx % nn::kB == 0 && g.ny % nn::kB == 0 && g.nz % (4 * nn::kB) == 0;
   if (full) {
-    unsigned b = fill_blocks;
-    while (b >= 256 && nq % (2 * (int64_t)b) != 0) --b;
-    if (b >= 256) fill_blocks = b; else full = false;
+    unsigned b = (unsigned)std::min<int64_t>(nq / 4, kFillBlocks);
+    while (b >= 64 && nq % (4 * (int64_t)b) != 0) --b;
+    if (b >= 64) fill_blocks = b; else full = false;
   }
   const dim3 cell_grid((a.g.ncz + 3) / 4, a.g.ncy, a.g.ncx);
   if (track_) {

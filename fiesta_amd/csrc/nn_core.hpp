@@ -41,8 +41,11 @@ constexpr int kCap = 30;            // entries a cell's list holds; a cell that 
 constexpr int kSH = 9;              // a key's distance part starts at this bit; bits 4..8: the list index (so key & 0x1F0 is the
                                     // byte offset of the winner's entry), bits 0..3: zero
 constexpr int kBias = 3 * 7 * 7;    // |v|^2 of the voxel farthest from the cell origin
+constexpr int kKfirst = 1;           // cells around the cell the competitor is first looked for in (any site will do: the nearest prunes best)
 constexpr int kKmax = 5;            // the search window reaches this many cells (p stays inside a signed byte when doubled)
 constexpr int kStride = 128;        // dwords of a cell's record: [0] the number of entries, [4 + 4 i ..] entry i = (b, K, m, W)
+constexpr int kRaw = 32;            // candidates a team's scratch holds between the sweep and the record
+constexpr int kThin = 16;           // lists longer than this are thinned pairwise
 constexpr uint32_t kPadK = 0xFFFFFFFFu;  // K of a padding entry (b = m = 0): never the minimum
 constexpr int kNone = 0x7FFFFFFF;
 
@@ -87,16 +90,31 @@ FIESTA_NN_HD inline int reach_of(int rad2) { return (int)((sqrtf((float)rad2) + 
 // doubled gap between the centre and a cell d cells away along one axis
 FIESTA_NN_HD inline int gap_of(int d) { return d ? 16 * (d < 0 ? -d : d) - 7 : 0; }
 
+// is the site at offset p dominated by the one at q over the whole cell (q2 = |q|^2)?  Ties go to q.
+FIESTA_NN_HD inline bool dominated(int px, int py, int pz, int qx, int qy, int qz, int q2) {
+  const int ax = px - qx, ay = py - qy, az = pz - qz;
+  return px * px + py * py + pz * pz - q2 >= 14 * ((ax > 0 ? ax : 0) + (ay > 0 ? ay : 0) + (az > 0 ? az : 0));
+}
+// a candidate between sweep and record: three signed bytes
+FIESTA_NN_HD inline uint32_t pack_p(int px, int py, int pz) { return ((uint32_t)px & 255u) | (((uint32_t)py & 255u) << 8) | (((uint32_t)pz & 255u) << 16); }
+FIESTA_NN_HD inline void unpack_p(uint32_t v, int &px, int &py, int &pz) {
+  px = (int)(int8_t)(v & 255u), py = (int)(int8_t)((v >> 8) & 255u), pz = (int)(int8_t)((v >> 16) & 255u);
+}
+
 // Where the lists come from: the first-site table and the site array, through an accessor.  bounds(): the index range of
-// the sites of cells z0..z1 of cell row (X, Y); site(): the packed site behind an index of such a range.  PlainSrc reads
-// the two arrays as they lie in memory (the host model; the kernel's path for rows it has not staged); k_nn_lists wraps it
-// with a copy of its work-group's neighbourhood in LDS (nn_kernels.hpp: StagedSrc).
+// the sites of cells z0..z1 of cell row (X, Y) -- empty for a row outside the map, z clamped into the row; site(): the
+// packed site behind an index of such a range.  PlainSrc reads the two arrays as they lie in memory (the host model; the
+// kernel's path for the rare cell whose window leaves the staged neighbourhood); k_nn_lists stages its work-group's
+// neighbourhood in LDS and reads that (nn_kernels.hpp: StagedSrc, reach = 3 cells).
 struct PlainSrc {
+  static constexpr int reach = 1 << 20;  // cells from the asking cell this source can serve
   const uint32_t *ctab, *sites;
-  int ncy, ncz;
+  int ncx, ncy, ncz;
   FIESTA_NN_HD inline void bounds(int X, int Y, int z0, int z1, uint32_t &i0, uint32_t &i1) const {
+    i0 = i1 = 0;
+    if ((unsigned)X >= (unsigned)ncx || (unsigned)Y >= (unsigned)ncy) return;
     const uint32_t *row = ctab + ((int64_t)X * ncy + Y) * (ncz + 1);
-    i0 = row[z0], i1 = row[z1 + 1];
+    i0 = row[z0 < 0 ? 0 : z0], i1 = row[(z1 > ncz - 1 ? ncz - 1 : z1) + 1];
   }
   FIESTA_NN_HD inline uint32_t site(uint32_t i) const { return sites[i]; }
 };
@@ -105,28 +123,44 @@ struct PlainSrc {
 // dealt out among them: four times the waves in flight for the same work -- the sweeps are chains of dependent reads).
 //   lanes, rank   size of the team, this lane's place in it
 //   nearest()     the team's minimum of (e2, w) pairs, smaller e2 first, then smaller w (called by every lane, outside loops)
-//   slot()        the next free entry of the list (any lane, inside loops)
-//   count()       entries handed out (called by every lane once all have finished their rows)
+//   restart()     forget the slots handed out (every lane, outside loops)
+//   slot()        the next free slot (any lane, inside loops)
+//   count()       slots handed out (called by every lane once all have finished their loops)
+//   put(), get()  the team's scratch of kRaw words: the candidates between the sweep and the record
 struct Solo {
   static constexpr int lanes = 1;
   int rank = 0, n = 0;
+  uint32_t raw[32];
   FIESTA_NN_HD inline void nearest(int &, uint32_t &) const {}
+  FIESTA_NN_HD inline void restart() { n = 0; }
   FIESTA_NN_HD inline int slot() { return n++; }
   FIESTA_NN_HD inline int count() const { return n; }
+  FIESTA_NN_HD inline void put(int k, uint32_t v) { raw[k] = v; }
+  FIESTA_NN_HD inline uint32_t get(int k) const { return raw[k]; }
+};
+
+// the rows (dx, dy) of a (2 K + 1)^2 window in row-major order, every Team::lanes-th of them for this lane
+struct RowWalk {
+  int dx, dy, K, step;
+  FIESTA_NN_HD inline RowWalk(int K_, int rank, int lanes) : dx(-K_), dy(-K_ + rank), K(K_), step(lanes) { wrap(); }
+  FIESTA_NN_HD inline void wrap() {
+    while (dy > K) dy -= 2 * K + 1, ++dx;
+  }
+  FIESTA_NN_HD inline bool done() const { return dx > K; }
+  FIESTA_NN_HD inline void next() {
+    dy += step;
+    wrap();
+  }
 };
 
 // nearest site to the centre of cell (cx, cy, cz) among this lane's rows of the cells within +-K: doubled squared
 // distance and word (ties: the smaller word, so that a team agrees whatever the split)
 template <class Src, class Team>
-FIESTA_NN_HD inline void scan_nearest(const Geom &g, const Src &src, const Team &team, int cx, int cy, int cz, int K, int &best_e2, uint32_t &best_w) {
+FIESTA_NN_HD inline void scan_nearest(const Src &src, const Team &team, int cx, int cy, int cz, int K, int &best_e2, uint32_t &best_w) {
   const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
-  const int z0 = cz - K < 0 ? 0 : cz - K, z1 = cz + K > g.ncz - 1 ? g.ncz - 1 : cz + K;
-  const int side = 2 * K + 1;
-  for (int r = team.rank; r < side * side; r += Team::lanes) {
-    const int X = cx + r / side - K, Y = cy + r % side - K;
-    if ((unsigned)X >= (unsigned)g.ncx || (unsigned)Y >= (unsigned)g.ncy) continue;
+  for (RowWalk rw(K, team.rank, Team::lanes); !rw.done(); rw.next()) {
     uint32_t i, i1;
-    src.bounds(X, Y, z0, z1, i, i1);
+    src.bounds(cx + rw.dx, cy + rw.dy, cz - K, cz + K, i, i1);
     for (; i < i1; ++i) {
       const uint32_t w = src.site(i);
       int sx, sy, sz;
@@ -137,61 +171,102 @@ FIESTA_NN_HD inline void scan_nearest(const Geom &g, const Src &src, const Team 
   }
 }
 
-// The record of cell (cx, cy, cz) into out[kStride].  Returns the number of entries, or 0 when the cell cannot be served:
-// no site within the search window's reach, a competitor so far away that the window would exceed kKmax cells, more than
-// kCap survivors.  (Every lane of a team returns the same value; lane 0 writes the count.)
+// The record of cell (cx, cy, cz) into out[kStride].  Returns the number of entries; 0 when the cell cannot be served: no
+// site within the search window's reach, a competitor so far away that the window would exceed kKmax cells, more than
+// kCap survivors; -1 (nothing written) when the window would leave what this source can serve (Src::reach cells): the
+// caller asks again with a source that reaches farther.  (Every lane of a team returns the same value; lane 0 writes the
+// count.)
 template <class Src, class Team>
-FIESTA_NN_HD inline int build_list(const Geom &g, const Src &src, Team &team, int cx, int cy, int cz, uint32_t *out) {
-  int te2 = kNone;
-  uint32_t tw = 0xFFFFFFFFu;
-  for (int K = 2; K <= kKmax && te2 == kNone; ++K) {
-    scan_nearest(g, src, team, cx, cy, cz, K, te2, tw);
-    team.nearest(te2, tw);
-  }
-  int n = 0;
-  if (te2 != kNone) {
+FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, int cz, uint32_t *out) {
+  constexpr int kmax = Src::reach < kKmax ? Src::reach : kKmax;
+  const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
+  int raw = 0;
+  // Second try: more candidates than the scratch holds are collected again against the NEAREST site of the 5^3 cells (the
+  // first competitor came from the 3^3 cells and may be a poor one).
+  for (int kfirst = kKfirst; kfirst <= 2; kfirst = 2 + (raw <= kRaw)) {
+    int te2 = kNone;
+    uint32_t tw = 0xFFFFFFFFu;
+    for (int K = kfirst; K <= kmax && te2 == kNone; ++K) {
+      scan_nearest(src, team, cx, cy, cz, K, te2, tw);
+      team.nearest(te2, tw);
+    }
+    raw = 0;
+    if (te2 == kNone) {
+      if (kmax < kKmax) return -1;
+      break;
+    }
     const int rad2 = rad2_of(te2);
     const int Kw = reach_of(rad2);
-    if (Kw <= kKmax) {
-      const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
-      int qx, qy, qz;
-      unpack_site(tw, qx, qy, qz);
-      qx -= ox, qy -= oy, qz -= oz;
-      const int q2 = qx * qx + qy * qy + qz * qz;
-      const int side = 2 * Kw + 1;
-      for (int r = team.rank; r < side * side; r += Team::lanes) {
-        const int dx = r / side - Kw, dy = r % side - Kw;
-        const int X = cx + dx, Y = cy + dy;
-        if ((unsigned)X >= (unsigned)g.ncx || (unsigned)Y >= (unsigned)g.ncy) continue;
-        const int gx = gap_of(dx), gy = gap_of(dy);
-        const int rem = rad2 - gx * gx - gy * gy;
-        if (rem < 0) continue;  // the whole row of cells lies outside the ball
-        int m = (int)((sqrtf((float)rem) + 7.01f) * 0.0625f);  // cells along z the ball still touches
-        m = m > Kw ? Kw : m;
-        const int z0 = cz - m < 0 ? 0 : cz - m, z1 = cz + m > g.ncz - 1 ? g.ncz - 1 : cz + m;
-        uint32_t i, i1;
-        src.bounds(X, Y, z0, z1, i, i1);
-        for (; i < i1; ++i) {
-          const uint32_t w = src.site(i);
-          int px, py, pz;
-          unpack_site(w, px, py, pz);
-          px -= ox, py -= oy, pz -= oz;
-          const int lhs = px * px + py * py + pz * pz - q2;
-          const int ax = px - qx, ay = py - qy, az = pz - qz;
-          const int rhs = 14 * ((ax > 0 ? ax : 0) + (ay > 0 ? ay : 0) + (az > 0 ? az : 0));
-          if (w == tw || lhs < rhs) {
-            const int k = team.slot();
-            if (k < kCap) {
-              uint32_t *e = out + 4 + 4 * k;
-              e[0] = entry_b(py, pz), e[1] = entry_k(px, py, pz, k), e[2] = entry_m(px), e[3] = w;
-            }
-          }
+    if (Kw > kmax) {
+      if (kfirst < 2) {  // (a poor competitor widens the window: look for the nearest one before giving up)
+        raw = kRaw + 1;
+        continue;
+      }
+      if (kmax < kKmax) return -1;
+      raw = 0;
+      break;
+    }
+    int qx, qy, qz;
+    unpack_site(tw, qx, qy, qz);
+    qx -= ox, qy -= oy, qz -= oz;
+    const int q2 = qx * qx + qy * qy + qz * qz;
+    team.restart();
+    for (RowWalk rw(Kw, team.rank, Team::lanes); !rw.done(); rw.next()) {
+      const int gx = gap_of(rw.dx), gy = gap_of(rw.dy);
+      const int rem = rad2 - gx * gx - gy * gy;
+      if (rem < 0) continue;  // the whole row of cells lies outside the ball
+      int m = (int)((sqrtf((float)rem) + 7.01f) * 0.0625f);  // cells along z the ball still touches
+      m = m > Kw ? Kw : m;
+      uint32_t i, i1;
+      src.bounds(cx + rw.dx, cy + rw.dy, cz - m, cz + m, i, i1);
+      for (; i < i1; ++i) {
+        const uint32_t w = src.site(i);
+        int px, py, pz;
+        unpack_site(w, px, py, pz);
+        px -= ox, py -= oy, pz -= oz;
+        if (w == tw || !dominated(px, py, pz, qx, qy, qz, q2)) {
+          const int k = team.slot();
+          if (k < kRaw) team.put(k, pack_p(px, py, pz));
         }
       }
-      n = team.count();
-      if (n > kCap) n = 0;
     }
+    raw = team.count();
+    if (kfirst >= 2) break;
   }
+  int n = 0;
+  if (raw > 0 && raw <= kRaw) {
+    // A long list is thinned pairwise: a candidate any OTHER candidate dominates goes (dominance is transitive, so testing
+    // against dropped ones is as good) -- 25 -> 13 entries at most on config 2's scene; short lists (the mean is 6) skip it.
+    if (raw > kThin) {
+      for (int k = team.rank; k < raw; k += Team::lanes) {
+        const uint32_t pk = team.get(k);
+        int px, py, pz;
+        unpack_p(pk, px, py, pz);
+        bool dead = false;
+        for (int j = 0; j < raw && !dead; ++j) {
+          int qx, qy, qz;
+          unpack_p(team.get(j) & 0xFFFFFFu, qx, qy, qz);
+          dead = j != k && dominated(px, py, pz, qx, qy, qz, qx * qx + qy * qy + qz * qz);
+        }
+        if (dead) team.put(k, pk | 0x80000000u);  // (the low 24 bits stay: others still test against it)
+      }
+    }
+    team.restart();
+    for (int k = team.rank; k < raw; k += Team::lanes) {
+      const uint32_t pk = team.get(k);
+      if (pk & 0x80000000u) continue;
+      int px, py, pz;
+      unpack_p(pk, px, py, pz);
+      const int i = team.slot();
+      if (i < kCap) {
+        uint32_t *e = out + 4 + 4 * i;
+        e[0] = entry_b(py, pz), e[1] = entry_k(px, py, pz, i), e[2] = entry_m(px);
+        e[3] = ((uint32_t)(px + ox) << 20) | ((uint32_t)(py + oy) << 10) | (uint32_t)(pz + oz);
+      }
+    }
+    n = team.count();
+  }
+  if (n > kCap) n = 0;
   if (team.rank == 0) {
     out[0] = (uint32_t)n;
     if (n & 1) {  // (the kernel takes two entries per step)

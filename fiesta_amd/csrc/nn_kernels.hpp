@@ -130,35 +130,51 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
 // ---- one list per cell ------------------------------------------------------------------------------------------------------
 // The neighbourhood of a work-group's 64 (z) x 4 (y) cells in LDS: table rows and sites of the cells within kStageK of it.
 // A window that reaches farther (a cell whose nearest obstacle is more than ~16 voxels away) reads those rows from memory.
-constexpr int kStageK = 3;
+constexpr int kStageK = 4;
 constexpr int kStageNX = 1 + 2 * kStageK, kStageNY = 4 + 2 * kStageK, kStageNR = kStageNX * kStageNY;  // 7 x 10 rows of cells
 constexpr int kStageNZ = 64 + 2 * kStageK + 1;                                                          // table entries per row
 constexpr int kStageSites = 3072;
-struct StagedSrc {
-  nn::PlainSrc plain;
-  const uint32_t *tab;     // [kStageNR][kStageNZ]: entry e of a row = the first site of cell Zf + e (clamped into the row)
+struct StagedSrc {  // the staged neighbourhood only: no range checks (rows outside the map are staged empty, entries are
+  static constexpr int reach = kStageK;  // clamped into their row), no second path -- a window that needs more is served by
+  const uint32_t *tab;     // nn::PlainSrc in a second attempt.  [kStageNR][kStageNZ]: entry e of a row = first site of cell Zf + e
   const uint32_t *delta;   // [kStageNR]: LDS index of a staged site = its index in the site array + delta[row]
   const uint32_t *lsites;
-  int X0, Y0, Zf;
-  bool staged;
+  int rbase, ebase;        // row index of (cx, cy) and entry index of cz for this lane's cell
   __device__ __forceinline__ void bounds(int X, int Y, int z0, int z1, uint32_t &i0, uint32_t &i1) const {
-    const int rx = X - X0, ry = Y - Y0, e0 = z0 - Zf, e1 = z1 + 1 - Zf;
-    if (staged && (unsigned)rx < (unsigned)kStageNX && (unsigned)ry < (unsigned)kStageNY && e0 >= 0 && e1 < kStageNZ) {
-      const int row = rx * kStageNY + ry;
-      const uint32_t d = delta[row];
-      i0 = (tab[row * kStageNZ + e0] + d) | 0x80000000u, i1 = (tab[row * kStageNZ + e1] + d) | 0x80000000u;
+    const int row = X * kStageNY + Y + rbase;  // (X, Y arrive as cx + dx, cy + dy: rbase takes the origin out)
+    const uint32_t d = delta[row];
+    const uint32_t *t = tab + row * kStageNZ + ebase;
+    i0 = t[z0] + d, i1 = t[z1 + 1] + d;
+  }
+  __device__ __forceinline__ uint32_t site(uint32_t i) const { return lsites[i]; }
+};
+
+// The second attempt's source for a cell whose window leaves the staged neighbourhood (its nearest obstacle is more than ~16
+// voxels away: one cell in a thousand on config 2's scene): staged rows from LDS, the others from memory.  (Everything from
+// memory is a chain of ~60 dependent L2 round trips per lane, and one such team holds its whole work-group back.)
+struct HybridSrc {
+  static constexpr int reach = 1 << 20;
+  StagedSrc st;
+  nn::PlainSrc plain;
+  int X0, Y0, Zf;
+  __device__ __forceinline__ void bounds(int X, int Y, int z0, int z1, uint32_t &i0, uint32_t &i1) const {
+    const int rx = X - X0, ry = Y - Y0;
+    if (st.tab && (unsigned)rx < (unsigned)kStageNX && (unsigned)ry < (unsigned)kStageNY && z0 >= Zf && z1 + 1 - Zf < kStageNZ) {
+      st.bounds(X, Y, z0, z1, i0, i1);
+      i0 |= 0x80000000u, i1 |= 0x80000000u;
     } else {
       plain.bounds(X, Y, z0, z1, i0, i1);
     }
   }
-  __device__ __forceinline__ uint32_t site(uint32_t i) const { return (i & 0x80000000u) ? lsites[i & 0x7FFFFFFFu] : plain.sites[i]; }
+  __device__ __forceinline__ uint32_t site(uint32_t i) const { return (i & 0x80000000u) ? st.lsites[i & 0x7FFFFFFFu] : plain.sites[i]; }
 };
 
 // A team of four adjacent lanes builds one list (nn_core.hpp: Team): the rows of the window dealt out among them.
 struct QuadTeam {
   static constexpr int lanes = 4;
   int rank;
-  uint32_t *counter;  // LDS: entries handed out so far (the lanes of a quad run in lock step: slots are deterministic)
+  uint32_t *counter;  // LDS: slots handed out so far (the lanes of a quad run in lock step: slots are deterministic)
+  uint32_t *raw;      // LDS: the team's scratch, nn::kRaw words
   __device__ __forceinline__ void nearest(int &e2, uint32_t &w) const {
 #pragma unroll
     for (int off = 1; off <= 2; off <<= 1) {
@@ -167,7 +183,14 @@ struct QuadTeam {
       if (oe < e2 || (oe == e2 && ow < w)) e2 = oe, w = ow;
     }
   }
+  __device__ __forceinline__ void restart() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (rank == 0) *(volatile uint32_t *)counter = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
   __device__ __forceinline__ int slot() { return (int)atomicAdd(counter, 1u); }
+  __device__ __forceinline__ void put(int k, uint32_t v) { *(volatile uint32_t *)(raw + k) = v; }
+  __device__ __forceinline__ uint32_t get(int k) const { return *(volatile uint32_t *)(raw + k); }
   __device__ __forceinline__ int count() const {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the quad's lanes have left their loops: same wave, program order)
     return (int)*(volatile uint32_t *)counter;
@@ -179,14 +202,15 @@ __global__ __launch_bounds__(1024) void k_nn_lists(NnArgs a) {  // 64 (z) x 4 (y
   __shared__ uint32_t s_delta[kStageNR], s_cnt[kStageNR];
   __shared__ uint32_t s_sites[kStageSites];
   __shared__ uint32_t s_slots[256];
-  __shared__ uint32_t s_total, s_bad, s_sum;
+  __shared__ uint32_t s_raw[256 * (nn::kRaw + 1)];  // (+ 1: the sixteen teams of a wave on different banks)
+  __shared__ uint32_t s_total, s_bad, s_sum, s_done;
   const nn::Geom &g = a.g;
   const int tid = (int)threadIdx.x;
   const int cz0 = (int)blockIdx.x * 64, cy0 = (int)blockIdx.y * 4, cx = (int)blockIdx.z;
   const int X0 = cx - kStageK, Y0 = cy0 - kStageK, Zf = cz0 - kStageK;
   const int64_t rowlen = g.ncz + 1;
   if (tid < 256) s_slots[tid] = 0;
-  if (tid == 0) s_bad = 0, s_sum = 0;
+  if (tid == 0) s_bad = 0, s_sum = 0, s_done = 0;
   for (int idx = tid; idx < kStageNR * kStageNZ; idx += 1024) {
     const int row = idx / kStageNZ, e = idx - row * kStageNZ;
     const int X = X0 + row / kStageNY, Y = Y0 + row % kStageNY;
@@ -225,21 +249,32 @@ __global__ __launch_bounds__(1024) void k_nn_lists(NnArgs a) {  // 64 (z) x 4 (y
   const int cz = cz0 + (ci & 63), cy = cy0 + (ci >> 6);
   int n = 0;
   const bool live = cz < g.ncz && cy < g.ncy;  // (the same for the four lanes of a team)
-  QuadTeam team{tid & 3, &s_slots[ci]};
+  QuadTeam team{tid & 3, &s_slots[ci], &s_raw[ci * (nn::kRaw + 1)]};
   if (live) {
     const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
-    StagedSrc src{nn::PlainSrc{a.ctab, a.sites, g.ncy, g.ncz}, s_tab, s_delta, s_sites, X0, Y0, Zf, staged};
-    n = nn::build_list(g, src, team, cx, cy, cz, a.lists + cell * nn::kStride);
+    uint32_t *rec = a.lists + cell * nn::kStride;
+    n = -1;
+    const StagedSrc ssrc{staged ? s_tab : nullptr, s_delta, s_sites, -(X0 * kStageNY + Y0), -Zf};
+    if (staged) n = nn::build_list(ssrc, team, cx, cy, cz, rec);
+    if (n < 0) {  // (a team decides together: the window needs more than the staged three cells -- or nothing was staged)
+      const HybridSrc src{ssrc, nn::PlainSrc{a.ctab, a.sites, g.ncx, g.ncy, g.ncz}, X0, Y0, Zf};
+      n = nn::build_list(src, team, cx, cy, cz, rec);
+    }
   }
-  // statistics: failures and entries, one atomic each per work-group
-  if (live && team.rank == 0) {
-    if (n == 0) atomicAdd(&s_bad, 1u);
-    else atomicAdd(&s_sum, (uint32_t)n);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    if (s_bad) atomicAdd(a.failed, (unsigned long long)s_bad);
-    if (s_sum) atomicAdd(a.entries, (unsigned long long)s_sum);
+  // statistics: failures and entries, one atomic each per work-group -- by the LAST wave to get here, not behind a barrier
+  // (a wave that waits for its work-group's slowest team keeps its registers from the next work-group)
+  const unsigned long long bad = __ballot(live && team.rank == 0 && n == 0);
+  int sum = (live && team.rank == 0) ? n : 0;
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if ((tid & 63) == 0) {
+    if (bad) atomicAdd(&s_bad, (uint32_t)__popcll(bad));
+    if (sum) atomicAdd(&s_sum, (uint32_t)sum);
+    __threadfence_block();
+    if (atomicAdd(&s_done, 1u) == 15u) {
+      const uint32_t b = atomicAdd(&s_bad, 0u), t = atomicAdd(&s_sum, 0u);
+      if (b) atomicAdd(a.failed, (unsigned long long)b);
+      if (t) atomicAdd(a.entries, (unsigned long long)t);
+    }
   }
 }
 
@@ -254,33 +289,37 @@ __device__ __forceinline__ void nn_dot4_pair(uint32_t a, uint32_t b0, uint32_t b
   asm("v_dot4_i32_i8 %0, %2, %3, 0\n\tv_dot4_i32_i8 %1, %2, %4, 0\n\ts_nop 2" : "=&v"(d0), "=&v"(d1) : "v"(a), "v"(b0), "v"(b1));
 }
 
-constexpr int kFillBlocks = 2048;  // persistent work-groups of four waves: 8 per CU, 32 cells per wave on a 512^3 map
+constexpr int kFillBlocks = 2048;  // persistent work-groups of four waves: 8 per CU, 8 quads (32 cells) per wave on a 512^3 map
 constexpr int kListPad = 64;       // dwords the list array is over-allocated by
 
-// A QUAD is four cells adjacent in z, one per wave of the work-group: their stores complete 128-byte lines.  The quads of
-// the map in row-major order are dealt out in contiguous runs, one run per work-group.
+// A QUAD is four cells adjacent in z: 32 voxels, one 128-byte line per (x, y) row.  ONE WAVE serves a quad -- its four cells
+// one after the other, the 4 x 8 winners' words kept in registers -- and then stores it slab by slab through a 1.25 KB LDS
+// tile of its own: 16 bytes per lane, eight whole lines per store instruction.  (Stored cell by cell, eight 32-byte pieces
+// per instruction, the same bytes took 270 us instead of 120; exchanged between the four waves of a work-group behind two
+// barriers per cell, 170 us: a wave stalled on its fetch stalled the other three.)  The quads of the map in row-major
+// order are dealt out in contiguous runs, one run per wave.
 //
 // Memory choreography of one wave (the k_ft_x recipe, ft_kernels.hpp): the next cell's record -- 512 bytes: the count, then
 // 16 bytes (b, K, m, W) per entry -- is fetched by LDS-DMA (global_load_lds_dword: lane i's dword lands at m0 + 4 i, no
 // register is in flight) into the other of two landing zones BEFORE this cell's arithmetic, issued and waited for by hand:
-// hipcc never sees a load, so it never drains vmcnt for one, and this cell's stores stay in flight behind the fetch
+// hipcc never sees a load, so it never drains vmcnt for one, and a quad's stores stay in flight behind the next fetch
 // (gfx9 retires the loads and stores of a wave in issue order).  An entry is read back as ONE ds_read_b128 from a
 // wave-uniform address (a broadcast): b, K and m arrive in VGPRs holding the same value in every lane -- no scalar loads,
-// no readlane.  FULL maps only: every extent a multiple of the cell edge, rows a multiple of four cells long, runs of an
-// even number of quads -- no predicate anywhere, so the number of stores between a fetch and its wait is the same on every
-// path.  Other maps take the simple predicated variant below.
+// no readlane.  FULL maps only: every extent a multiple of the cell edge, rows a multiple of four cells long, the same
+// number of quads for every wave -- no predicate anywhere, so the number of memory operations between a fetch and its wait
+// is the same on every path.  Other maps take the simple predicated variant below.
 template <bool TRACK>
 __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
   constexpr int kTileRow = 40;  // dwords between two rows of the tile: 32 + padding that spreads the rows over the banks
   __shared__ __attribute__((aligned(16))) uint32_t land[4][2][nn::kStride];  // per wave, two zones of one record each
-  __shared__ __attribute__((aligned(16))) uint32_t tile[nn::kB * nn::kB * kTileRow];
+  __shared__ __attribute__((aligned(16))) uint32_t tile[4][nn::kB * kTileRow];  // per wave, one x-slab of a quad: [y][32 z]
   const nn::Geom &g = a.g;
   if (*a.failed) return;  // some cell has no list: the envelope passes serve this update (dense_map.hip)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int quads = g.ncz >> 2;
   const uint32_t nq = (uint32_t)(g.ncx * g.ncy) * (uint32_t)quads;
-  const uint32_t per = nq / gridDim.x;  // (even, and gridDim.x * per == nq: the host's choice)
-  const uint32_t q0 = blockIdx.x * per, q1 = q0 + per;
+  const uint32_t per = nq / (gridDim.x * 4u);  // (gridDim.x * 4 * per == nq: the host's choice)
+  const uint32_t q0 = (blockIdx.x * 4u + (uint32_t)wave) * per, q1 = q0 + per;
   const int row0 = (int)(q0 / (uint32_t)quads);
   const int y = lane >> 3, z = lane & 7;
   const uint32_t ayz = (uint32_t)y | ((uint32_t)z << 8);
@@ -288,9 +327,10 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
   const int loff4 = y * g.nz + 4 * z;  // the lane's 16 bytes of a stored slab: row y, voxels 4 z .. 4 z + 3 of the quad's 32
   uint32_t dmax = 0;
   const uint32_t zone0 = (uint32_t)(size_t)&land[wave][0][0];  // LDS byte offsets: the low half of the generic address
+  uint32_t *const mytile = &tile[wave][0];
   struct At { int cx, cy, q; };  // a quad: cell row (cx, cy), quad q of it
-  auto fetch = [&](const At &c, const int zone) {
-    const int64_t cell = ((int64_t)c.cx * g.ncy + c.cy) * g.ncz + 4 * c.q + wave;
+  auto fetch = [&](const At &c, const int cell_of_quad, const int zone) {
+    const int64_t cell = ((int64_t)c.cx * g.ncy + c.cy) * g.ncz + 4 * c.q + cell_of_quad;
     const uint32_t *lp = a.lists + cell * nn::kStride + lane, *hp = lp + 64;
     const uint32_t at = zone0 + (uint32_t)zone * (uint32_t)(nn::kStride * 4);
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off\n\t"
@@ -303,7 +343,8 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
       if (++c.cy == g.ncy) c.cy = 0, ++c.cx;
     }
   };
-  auto serve = [&](const At &c, const int zone) {
+  // one cell: every voxel's minimum key over the record in `zone`, the winners' words into ww[0..7]
+  auto serve = [&](const int zone, uint32_t *ww) {
     const uint32_t *lz = &land[wave][zone][0];
     const int cnt = __builtin_amdgcn_readfirstlane((int)lz[0]);
     uint32_t best[nn::kB];
@@ -321,45 +362,41 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
         best[x] = min(best[x], min(k0, k1));
       }
     }
-    uint32_t ww[nn::kB];
 #pragma unroll
     for (int x = 0; x < nn::kB; ++x) {
       ww[x] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lz + 7) + (best[x] & 0x1F0u));
       if (TRACK) dmax = max(dmax, (best[x] >> nn::kSH) - (uint32_t)nn::kBias + (uint32_t)(x * x + y * y + z * z));
     }
-    // Full lines out: a cell's z-rows are 32 bytes, and stored as such (eight 32-byte pieces per store instruction, the
-    // other three quarters of each 128-byte line coming from the other waves at their own pace) the same bytes took 270 us
-    // instead of 120.  The quad's four waves exchange through an LDS tile [x][y][32 z] and each stores two x-slabs of it:
-    // 16 bytes per lane, eight whole 128-byte lines per instruction.
-    asm volatile("s_barrier" ::: "memory");  // the tile's readers of the quad before are done
+  };
+  // The wave's VMEM operations in issue order, per quad:  F1 | F2 | F3 | F0' | S x 8   (F: the two loads of a cell's fetch,
+  // issued as the cell before it begins; F0': the next quad's first cell; S: the quad's stores).  A fetch is needed one cell
+  // after it was issued: behind it then lie the next fetch, and -- for a quad's first cell -- the eight stores of the quad before.
+  At c{row0 / g.ncy, row0 % g.ncy, (int)(q0 % (uint32_t)quads)};
+  fetch(c, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (uint32_t q = q0; q < q1; ++q) {
+    uint32_t ww[4][nn::kB];
+    At nxt = c;
+    if (q + 1 < q1) advance(nxt);  // (the run's last fetch re-reads its last quad's first cell: no branch around a load)
 #pragma unroll
-    for (int x = 0; x < nn::kB; ++x) tile[(x * nn::kB + y) * kTileRow + nn::kB * wave + z] = ww[x];
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    vox_t *slab = a.coc + ((int64_t)(nn::kB * c.cx + 2 * wave) * g.ny + nn::kB * c.cy) * g.nz + 4 * nn::kB * c.q;
+    for (int k = 0; k < 4; ++k) {
+      // zone (k + 1) & 1 was last read by the cell before: its LDS reads are done (lgkmcnt(0) below)
+      if (k < 3) fetch(c, k + 1, (k + 1) & 1); else fetch(nxt, 0, 0);
+      if (k == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // behind this cell's fetch: the quad before's 8 stores + the fetch just issued
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           // ... only the fetch just issued
+      serve(k & 1, ww[k]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    vox_t *slab = a.coc + ((int64_t)(nn::kB * c.cx) * g.ny + nn::kB * c.cy) * g.nz + 4 * nn::kB * c.q;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(&tile[((2 * wave + j) * nn::kB + y) * kTileRow + 4 * z]);
+    for (int x = 0; x < nn::kB; ++x) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mytile[y * kTileRow + nn::kB * k + z] = ww[k][x];
+      const uint4 v = *reinterpret_cast<const uint4 *>(&mytile[y * kTileRow + 4 * z]);  // (LDS is in order within a wave)
       *reinterpret_cast<uint4 *>(slab + loff4) = v;  // lane (y, z): row y of the slab, z-voxels 4 z .. 4 z + 3 of the quad
       slab += plane;
     }
-  };
-  // Zones 0 and 1 alternate between "being fetched" and "being served".  The wave's VMEM operations in issue order, per
-  // round:  F1 (2 loads) | S0 (2 stores) | F0' (2 loads) | S1 (2 stores);  a fetch is needed one serve after it was issued.
-  At ca{row0 / g.ncy, row0 % g.ncy, (int)(q0 % (uint32_t)quads)}, cb;
-  fetch(ca, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (uint32_t q = q0; q < q1; q += 2) {
-    cb = ca;
-    advance(cb);
-    fetch(cb, 1);  // (zone 1 was last read by the serve at the end of the round before: lgkmcnt(0) stands behind it)
-    serve(ca, 0);  // (zone 0 has landed: the wait before the loop / at the end of the round before)
-    ca = cb;
-    if (q + 2 < q1) advance(ca);  // (the run's last fetch re-reads its last cell: no branch around a load)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zone 0's LDS reads are done before the DMA may overwrite it
-    fetch(ca, 0);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // zone 1 has landed: behind F1 only S0's two stores and F0''s two loads
-    serve(cb, 1);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(2)" ::: "memory");  // zone 0 has landed: behind F0' only S1's two stores
+    c = nxt;
   }
   if (TRACK) {
     for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));

@@ -40,9 +40,9 @@ int nn_model_run(const uint8_t *occ, int nx, int ny, int nz, uint32_t *out, int6
   for (int cx = 0; cx < g.ncx; ++cx)
     for (int cy = 0; cy < g.ncy; ++cy)
       for (int cz = 0; cz < g.ncz; ++cz) {
-        const PlainSrc src{ctab.data(), sites.data(), g.ncy, g.ncz};
+        const PlainSrc src{ctab.data(), sites.data(), g.ncx, g.ncy, g.ncz};
         Solo solo;
-        const int n = build_list(g, src, solo, cx, cy, cz, list.data());
+        const int n = build_list(src, solo, cx, cy, cz, list.data());
         if ((int)list[0] != n) return 2;
         if (n == 0) ++failed;
         entries += n;
