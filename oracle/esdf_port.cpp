@@ -71,6 +71,11 @@ struct Port {
   double l_hit = 0, l_miss = 0, l_min = 0, l_max = 0, l_occ = 0;
   // update window
   I3 wmin, wmax, wmin_prev, wmax_prev;
+  // fifo probe (relax(): intra-layer dependency depth of the update queue; measurement only)
+  struct FifoLayer { int64_t entries, dependent, depth; };
+  bool fifo_probe = false;
+  std::vector<FifoLayer> fifo_layers;
+  std::vector<int> fifo_wlayer, fifo_wdepth;
   // raycast front-end state (include/Fiesta.h:107-110,287)
   std::vector<int> stamp_free, stamp_occ;
   std::unordered_set<int> hstamp_free, hstamp_occ;
@@ -279,18 +284,53 @@ struct Port {
       head[s] = kUndef;
     }
     // --- phase 3: FIFO relaxation, pull then push over the 24-stencil (:339-392)
+    // MEASUREMENT (fifo_probe, off by default; tools/dev/fifo_depth.py): the queue is processed in LAYERS (layer L + 1 = what
+    // layer L enqueued).  How far is the order INSIDE a layer from being irrelevant?  Every processed entry gets a depth:
+    // 1 + the largest depth of an EARLIER entry of the SAME layer that wrote a word this entry reads (its own voxel's state,
+    // the 24 neighbours' obstacle in the pull, their distance in the push).  A layer of depth 1 can be processed in any order
+    // -- or all at once; depth k needs k ordered sub-steps.  The probe only watches; the order and the result are untouched.
     int64_t expanded = 0, changes = 0;
+    size_t layer_left = q_upd.size();
+    int layer_id = 1, layer_depth = 0;
+    int64_t layer_entries = 0, layer_dependent = 0;
+    auto close_layer = [&]() {
+      if (fifo_probe && layer_entries) fifo_layers.push_back({layer_entries, layer_dependent, (int64_t)layer_depth});
+      ++layer_id, layer_depth = 0, layer_entries = 0, layer_dependent = 0;
+    };
+    if (fifo_probe) {
+      fifo_wlayer.assign(dist.size(), 0);
+      fifo_wdepth.assign(dist.size(), 0);
+    }
     while (!q_upd.empty()) {
+      if (layer_left == 0) {
+        close_layer();
+        layer_left = q_upd.size();
+      }
+      --layer_left;
       const Item e = q_upd.front();
       q_upd.pop_front();
       const int s = slot(e.p);
-      if (e.d != dist[s]) continue;  // stale entry
+      int depth = 1;
+      auto reads = [&](int x) {
+        if (fifo_probe && fifo_wlayer[x] == layer_id && fifo_wdepth[x] + 1 > depth) depth = fifo_wdepth[x] + 1;
+      };
+      auto writes = [&](int x) {
+        if (!fifo_probe) return;
+        if (fifo_wlayer[x] != layer_id) fifo_wlayer[x] = layer_id, fifo_wdepth[x] = 0;
+        if (depth > fifo_wdepth[x]) fifo_wdepth[x] = depth;
+      };
+      reads(s);
+      if (e.d != dist[s]) {  // stale entry (made stale by an earlier entry of this layer, if reads(s) raised the depth)
+        if (fifo_probe && depth > 1) ++layer_entries, ++layer_dependent, layer_depth = std::max(layer_depth, depth);
+        continue;
+      }
       ++expanded;
       bool improved = false;
       for (int i = 0; i < 24; ++i) {  // pull
         const I3 nv = e.p + kDirs[i];
         if (!in_window(nv)) continue;
         const int ns = slot(nv);
+        reads(ns);
         if (!defined(coc[ns])) continue;
         const double t = metric(e.p, coc[ns]);
         if (dist[s] > t) {
@@ -301,8 +341,10 @@ struct Port {
           coc[s] = coc[ns];
         }
       }
+      if (fifo_probe) ++layer_entries, layer_dependent += depth > 1, layer_depth = std::max(layer_depth, depth);
       if (improved) {
         ++changes;
+        writes(s);
         q_upd.push_back({e.p, dist[s]});
         continue;
       }
@@ -317,10 +359,12 @@ struct Port {
           unlink(slot(coc[ns]), ns);
           link_front(owner, ns);
           coc[ns] = coc[s];
+          writes(ns);
           q_upd.push_back({nv, t});
         }
       }
     }
+    close_layer();
     if (st) {
       st->expanded = expanded;
       st->change_num = changes;
@@ -924,6 +968,19 @@ int oracle_check_consistency(oracle_map *m) { return m->p.lists_consistent(); }
 // (per vanished obstacle, orphans by decreasing distance from it, one after the other), 5 / 6 the same in parallel shells of
 // equal squared / whole-voxel distance.  DESIGN.md section 3c says what they showed.)
 void oracle_set_schedule(oracle_map *m, int schedule) { m->p.schedule = schedule; }
+// port only: the probe of relax() -- per layer of the update queue (entries processed, entries that read a word an earlier
+// entry of the same layer wrote, longest such chain).  enable: 1 on / 0 off (clears).  oracle_fifo_layers copies up to cap
+// rows of 3 int64 and returns the number of layers recorded since the probe was switched on.
+void oracle_fifo_probe(oracle_map *m, int enable) {
+  m->p.fifo_probe = enable != 0;
+  m->p.fifo_layers.clear();
+}
+int64_t oracle_fifo_layers(oracle_map *m, int64_t *out, int64_t cap) {
+  const int64_t n = (int64_t)m->p.fifo_layers.size();
+  for (int64_t i = 0; i < n && i < cap; ++i)
+    out[3 * i] = m->p.fifo_layers[i].entries, out[3 * i + 1] = m->p.fifo_layers[i].dependent, out[3 * i + 2] = m->p.fifo_layers[i].depth;
+  return n;
+}
 int64_t oracle_levels_run(oracle_map *m) { return m->p.levels_run; }
 
 // GetPointCloud (src/ESDFMap.cpp:544-582), restated: occupied voxels inside the update range (hash flavour: x and y

@@ -99,6 +99,8 @@ def _load(kind: str, mode: str):
     if kind == "port":   # the model of the GPU's level-synchronous schedule lives in the restatement only
         sig["oracle_set_schedule"] = (None, [vp, i32])
         sig["oracle_levels_run"] = (i64, [vp])
+        sig["oracle_fifo_probe"] = (None, [vp, i32])
+        sig["oracle_fifo_layers"] = (i64, [vp, vp, i64])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -249,6 +251,17 @@ class OracleMap:
         """port only: 0 = the reference's FIFO, 1 = the CPU model of the GPU's level engine (esdf_port.cpp: relax_levels);
         2 .. 6 = experiments on that model (tools/dev/schedule_experiment.py)."""
         self.lib.oracle_set_schedule(self.h, int(schedule))
+
+    def fifo_probe(self, enable=True):
+        """port only: watch the update queue's layers (esdf_port.cpp: relax, fifo_probe) from now on"""
+        self.lib.oracle_fifo_probe(self.h, int(bool(enable)))
+
+    def fifo_layers(self):
+        """rows (entries, entries depending on an earlier entry of the same layer, longest chain) per layer since fifo_probe()"""
+        n = int(self.lib.oracle_fifo_layers(self.h, None, 0))
+        out = np.zeros((max(n, 1), 3), np.int64)
+        self.lib.oracle_fifo_layers(self.h, _p(out), n)
+        return out[:n]
 
     @property
     def levels_run(self):
