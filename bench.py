@@ -347,8 +347,9 @@ def run_c3(args):
                 parity = {"frames": cpu_frames, "voxels": int(len(od2)), "finite": int(fin.sum()), "observed_sets_equal": bool(np.array_equal(gd2 < 0, od2 < 0)),
                           "d2_differs_from_this_reference_run": int((gd2 != od2).sum()), "closer": int((gd2 < od2).sum()), "farther": int((gd2 > od2).sum()),
                           "note": "a partially observed map: the reference's own distances depend on its queue order there; the same "
-                                  "frames are judged against the envelope of 5 shuffled reference runs in tests/test_gpu_raycast_parity.py "
-                                  "(test_config3_640x480_frames_reference_intrinsics) and profiles/r04*_envelope_reports.jsonl"}
+                                  "frames (the first three, level engine pinned) are judged against the envelope of 4 reference runs in shuffled order in "
+                                  "tests/test_gpu_raycast_parity.py (test_config3_full_size_distances_inside_the_reference_envelope); counters, queues "
+                                  "and occupancy of the frames bit-exact in test_config3_640x480_frames_reference_intrinsics"}
         if f >= args.warmup and not checked:
             t_ray.append((t1 - t0) * 1e3)
             t_fuse.append((t2a - t1b) * 1e3)
@@ -484,7 +485,7 @@ def run_c4(args):
                   "finite": int(((cv >= 0) & (cv != D2_INF)).sum()), "d2_differs_from_this_reference_run": int((cv != gv).sum()),
                   "closer": int((gv < cv).sum()), "farther": int((gv > cv).sum()),
                   "note": "a partially observed, streaming map: judged against the envelope of shuffled reference runs in "
-                          "tests/test_gpu_hash_parity.py (test_config4_stream...)"}
+                          "tests/test_gpu_hash_parity.py (test_hash_c4_stream_box_observe: the first 4 frames of this stream, no deletes yet)"}
         g2.close()
         cpu = {"value": cu / ct, "unit": "voxels/s", "cores": 1, "kind": "reference" if c.describe.startswith("reference") else "port",
                "sample": f"the first {ncpu} frames of the same stream (ingest + UpdateOccupancy + UpdateESDF, {ct:.1f} s; changed "

@@ -7,8 +7,8 @@ frame EXACTLY, including the reference's order-dependent per-frame de-duplicatio
 import numpy as np
 import pytest
 
-from scenarios import (INTRINSICS, P_DEFAULT, EnvelopeOracle, assert_envelope, assert_exact, compare_dense, depth_to_points,
-                       render_depth, yaw_pose)
+from scenarios import (INTRINSICS, P_DEFAULT, EnvelopeOracle, assert_envelope, assert_exact, compare_dense, d2_from_dist,
+                       depth_to_points, render_depth, yaw_pose)
 
 pytestmark = pytest.mark.gpu
 
@@ -254,6 +254,48 @@ def test_config3_640x480_frames_reference_intrinsics(hip_lib, oracle_libs, best_
     # occupancy after three frames, voxel for voxel (the distance field of this partially observed map is covered, with
     # its stated budget, by the smaller frame tests above)
     assert np.array_equal(gpu.download_field(("occ",))["occ"], cpu.dump_dense(("occ",))["occ"])
+
+
+def test_config3_full_size_distances_inside_the_reference_envelope(hip_lib, oracle_libs, best_oracle_kind):
+    """VERDICT r4 missing #4: the DISTANCE FIELD of config 3 at full size.  The same three 640 x 480 frames into the 512^3 map,
+    the level engine pinned (the reference's FIFO layers as levels: the engine whose contract has no constant), and next to
+    the reference run three more runs of the verbatim reference fed the same observations in shuffled first-touch order
+    (scenarios.EnvelopeOracle).  After the third frame every observed voxel's squared distance is judged against the
+    interval those four runs span: outside it on at most as many voxels as the runs themselves disagree on, either side."""
+    import fiesta_amd
+    import psutil
+    if psutil.virtual_memory().available < 48 * 2 ** 30:
+        pytest.skip("four 512^3 reference maps (6.4 GB each) need ~40 GB of host memory")
+    G, res = 512, 0.1
+    half = G * res / 2
+    origin, size = (-half, -half, -half), (G * res,) * 3
+    gpu = fiesta_amd.ESDFMap(origin, res, size, update_engine="levels")
+    cpu = EnvelopeOracle(lambda: oracle_libs.OracleMap(origin, res, size, kind=best_oracle_kind), k=3)
+    for m in (gpu, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    lc, rc = origin, tuple(np.add(origin, size))
+    spheres = [((1.5, 0.5, 0.0), 0.5), ((-1.0, 2.0, 0.3), 0.7), ((0.5, -2.0, -0.5), 0.4), ((-2.0, -1.0, 0.5), 0.6),
+               ((2.2, -1.8, 0.2), 0.3)]
+    for f in range(3):
+        T = yaw_pose(2.0 * f, (0.0, 0.0, 0.0))
+        depth = render_depth(T, rows=480, cols=640, spheres=spheres, intr=INTRINSICS)
+        gpu.RaycastDepth(depth, INTRINSICS["fx"], INTRINSICS["fy"], INTRINSICS["cx"], INTRINSICS["cy"], T, T[:3, 3],
+                         RAY["min_ray_length"], RAY["max_ray_length"], lc, rc, dedup=1)
+        cpu.raycast_frame(depth_to_points(depth, INTRINSICS), T, T[:3, 3], RAY["min_ray_length"], RAY["max_ray_length"], lc, rc)
+        a, b = gpu.UpdateOccupancy(True), cpu.UpdateOccupancy(True)
+        assert a == b and (gpu.last_insert, gpu.last_delete) == (cpu.last_insert, cpu.last_delete)
+        sg, sc = gpu.UpdateESDF(), cpu.UpdateESDF()
+        assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+    gd2 = gpu.download_field(("d2",))["d2"].astype(np.int64)
+    observed = np.flatnonzero(gd2 >= 0)
+    assert 10 ** 4 < len(observed) < 10 ** 7
+    env = cpu.judge(gd2, mask=observed)          # (also checks nothing: the observed sets are compared next)
+    pd2 = d2_from_dist(cpu.dump_dense(("dist",))["dist"], res)
+    assert np.array_equal(gd2 < 0, pd2 < 0), "observed sets differ"
+    assert env["finite"] > 10000
+    assert gpu.only_levels, gpu.served
+    assert_envelope(env, "config 3, 512^3, after three 640 x 480 frames", strict=True)
 
 
 def test_temporal_depth_filter_three_frames(hip_lib, oracle_libs, best_oracle_kind):
