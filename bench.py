@@ -79,7 +79,7 @@ def parse():
                     help="engine crossover table instead of the headline: UpdateESDF p50 for deltas 100 ... 50k on every engine")
     ap.add_argument("--verify-samples", type=int, default=20000,
                     help="owned voxels per rank checked after the timed region against a k-d tree over the GLOBAL obstacle list")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "queries"],
                     help="c2 = the headline metric; c3 = depth-frame pipeline; c4 = hash-block map, streaming window")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded driver even with one rank (smoke test)")
@@ -513,6 +513,110 @@ def run_c4(args):
     m.close()
 
 
+def run_queries(args):
+    """`--workload queries`: the consumer side of the path (src/ESDFMap.cpp:467-540).  Config 2's map
+    (512^3, 50 000 scattered obstacles, fully observed), then
+      batch   N device-resident positions through fiesta_hip_get_dist_grad_dev (GetDistWithGradTrilinear: 8 corner words, f64
+              value + gradient), queries/s and the fraction of the HBM roofline at SURVEY.md 8d's 64 B per query;
+      scalar  ONE position per call through the drop-in C++ class (examples/query_latency.cpp, compiled here): a random walk,
+              uniformly random positions, the first call after an update -- the host-side brick cache;
+      cpu     the verbatim reference's GetDistWithGradTrilinear in a loop on one host core, a bounded sample (256^3 map of the
+              same obstacle density, 2 M positions)."""
+    import subprocess
+    import tempfile
+    import torch
+    import fiesta_amd
+    G, res = args.grid, 0.1
+    dev = torch.device("cuda", 0)
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, (G * res,) * 3, update_engine=args.engine)
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    m.SetOccupancyBox((0, 0, 0), (G - 1,) * 3, 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    w = Workload(G, args.obstacles, seed=12345)
+    for _ in range(3):
+        m.SetOccupancy(w.initial(), 1, want_ret=False)
+        m.UpdateOccupancy(True)
+    st = m.UpdateESDF()
+    N = 8_000_000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    pos = (torch.rand((N, 3), generator=gen, device=dev, dtype=torch.float64) * (G * res - 0.6) + 0.3).contiguous()
+    dist = torch.empty(N, device=dev, dtype=torch.float64)
+    grad = torch.empty((N, 3), device=dev, dtype=torch.float64)
+    for _ in range(args.warmup):
+        m.GetDistWithGradTrilinearDevice(pos.data_ptr(), N, dist.data_ptr(), grad.data_ptr())
+    m.synchronize()
+    ts = []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        m.GetDistWithGradTrilinearDevice(pos.data_ptr(), N, dist.data_ptr(), grad.data_ptr())
+        m.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t = statistics.median(ts)
+    # check a sample against the exact transform (k-d tree) -- trilinear of exact corner distances, recomputed in numpy f64
+    from scipy.spatial import cKDTree
+    occ = np.ascontiguousarray(m.GetOccupiedVoxels(), dtype=np.int64)
+    tree = cKDTree(occ)
+    ps = pos[:20000].cpu().numpy()
+    b = np.floor((ps - 0.5 * res) / res).astype(np.int64)
+    f = (ps - (b + 0.5) * res) / res
+    corner = np.stack([b + np.array(o) for o in [(i, j, k) for i in (0, 1) for j in (0, 1) for k in (0, 1)]], 1)   # n x 8 x 3
+    dcorner = tree.query(corner.reshape(-1, 3))[0].reshape(-1, 8) * res
+    wts = np.stack([(f[:, 0] if i else 1 - f[:, 0]) * (f[:, 1] if j else 1 - f[:, 1]) * (f[:, 2] if k else 1 - f[:, 2])
+                    for i in (0, 1) for j in (0, 1) for k in (0, 1)], 1)
+    want = (wts * dcorner).sum(1)
+    err = float(np.abs(dist[:20000].cpu().numpy() - want).max())
+    # scalar calls through the C++ class
+    scalar = None
+    try:
+        exe = os.path.join(tempfile.mkdtemp(), "query_latency")
+        subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "query_latency.cpp"),
+                        "-L" + os.path.join(ROOT, "fiesta_amd"), "-lfiesta_hip", "-Wl,-rpath," + os.path.join(ROOT, "fiesta_amd"), "-o", exe], check=True)
+        scalar = json.loads(subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    except Exception as e:   # (no host compiler on the box: the batch line stands on its own)
+        scalar = {"error": str(e)}
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        pyoracle.build("port")
+        kind = "ref" if pyoracle.available("ref", "array") else "port"
+        g2 = 256
+        c = pyoracle.OracleMap((0, 0, 0), res, (g2 * res,) * 3, kind=kind)
+        c.SetParameters(*P_DEFAULT)
+        c.SetOriginalRange()
+        c.SetOccupancyVox(np.ascontiguousarray(np.stack(np.meshgrid(*[np.arange(g2, dtype=np.int32)] * 3, indexing="ij"), -1).reshape(-1, 3)), 0)
+        c.UpdateOccupancy(True)
+        c.UpdateESDF()
+        w2 = Workload(g2, int(round(50000 * (g2 / 512.0) ** 3)), seed=12345)
+        for _ in range(3):
+            c.SetOccupancyVox(w2.initial(), 1)
+            c.UpdateOccupancy(True)
+        c.UpdateESDF()
+        pc = np.random.RandomState(7).rand(2_000_000, 3) * (g2 * res - 0.6) + 0.3
+        t0 = time.perf_counter()
+        c.GetDistWithGradTrilinear(pc)
+        tc = time.perf_counter() - t0
+        cpu = {"value": len(pc) / tc, "unit": "queries/s", "cores": 1, "kind": "reference" if c.describe.startswith("reference") else "port",
+               "sample": f"2 000 000 uniformly random GetDistWithGradTrilinear calls on a {g2}^3 map of the same obstacle density "
+                         f"({tc:.2f} s; cpu: {cpu_model()}, {os.cpu_count()} cores, 1 used)"}
+        c.close()
+    bytes_q = 64.0
+    out = {"metric": "esdf_trilinear_queries_per_sec", "value": N / t, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": t * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"queries: {N} device-resident uniformly random GetDistWithGradTrilinear positions per step on config 2's map "
+                                  f"({G}^3 @0.1 m, {args.obstacles} scattered obstacles, fully observed)", "grid": [G, G, G]},
+           "roofline": {"bound": "hbm", "kernel": "k_query_trilinear", "achieved": N * bytes_q / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": N * bytes_q / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac_definition": "64 B per query (SURVEY.md 8d: 8 corner keys x 8 B) x queries / p50 of the call / 8 TB/s; the engine reads 8 x 4 B "
+                                           "words and moves 24 B of position in and 32 B of value + gradient out per query"},
+           "verify": {"sampled": 20000, "max_abs_error_m_vs_trilinear_of_exact_corner_distances": err},
+           "scalar_calls_through_the_cpp_class": scalar, "cpu_baseline": cpu, "map_update": esdf_summary([st])}
+    print(json.dumps(out), flush=True)
+    m.close()
+
+
 def run_delta_sweep(args):
     """`--delta-sweep`: where do the two UpdateESDF engines cross?  C2's map (512^3, 50k obstacles, fully observed), both
     scenes; per step `delta` voxels are replaced (delta/2 inserts + delta/2 deletes in one UpdateESDF); every delta on
@@ -593,6 +697,9 @@ def main():
         return run_c3(args)
     if args.workload == "c4":
         return run_c4(args)
+    if args.workload == "queries":
+        import torch  # noqa: F401
+        return run_queries(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -149,6 +149,7 @@ def load():
         "fiesta_hip_get_distance_pos": (C.c_int, [vp, vp, i64, vp]),
         "fiesta_hip_get_dist_grad": (C.c_int, [vp, vp, i64, vp, vp]),
         "fiesta_hip_get_dist_grad_dev": (C.c_int, [vp, vp, i64, vp, vp]),
+        "fiesta_hip_host_cache_fetches": (C.c_int, [vp, vp]),
         "fiesta_hip_get_occupancy_vox": (C.c_int, [vp, vp, i64, vp]),
         "fiesta_hip_get_occupancy_pos": (C.c_int, [vp, vp, i64, vp]),
         "fiesta_hip_download_field": (C.c_int, [vp, vp, vp, vp, vp]),

@@ -365,6 +365,12 @@ int fiesta_hip_get_dist_grad_dev(fiesta_hip_map *m, const double *pos_dev, int64
     dense(m, "get_dist_grad_dev").get_dist_grad(pos_dev, n, dist_dev, grad_dev, true);
   });
 }
+int fiesta_hip_host_cache_fetches(fiesta_hip_map *m, int64_t *fetches) {
+  return guarded([&] {
+    need(m && fetches, "bad argument");
+    *fetches = m->dense ? m->dense->host_brick_fetches() : 0;
+  });
+}
 int fiesta_hip_get_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32_t *out) {
   return guarded([&] {
     need(m && (n == 0 || (vox && out)) && n >= 0, "bad argument");

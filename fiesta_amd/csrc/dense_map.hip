@@ -509,47 +509,41 @@ __global__ __launch_bounds__(256) void k_invalidate(Geom g, TileGrid tg, vox_t *
 // =====================================================================================================
 // queries
 // =====================================================================================================
-__device__ inline double word_distance(const Geom &g, vox_t w, int x, int y, int z) {
+// The arithmetic of the queries is written once, over any SOURCE of voxel words: the batch kernels read the field in HBM, the
+// scalar host calls of the drop-in class (one position per call: fiesta::ESDFMap::GetDistance & co., include/fiesta/ESDFMap.h)
+// read a host-side cache of 16^3-voxel bricks (DenseMap::HostBricks below) -- same code, same -ffp-contract=off, same bits.
+__host__ __device__ inline double word_distance(const Geom &g, vox_t w, int x, int y, int z) {
   // GetDistance(Vector3i) (src/ESDFMap.cpp:477-479): unobserved (-10000) reads as +10000
   if (w & kNoCoc) return (double)FIESTA_HIP_INFINITY;
   const int32_t d2 = dist2(g.wrap, x + g.gx0, y + g.gy0, z + g.gz0, w);
   return sqrt((double)d2) * g.res;  // Dist (:122-124)
 }
-__device__ inline double vox_distance(const Geom &g, const vox_t *coc, int x, int y, int z) {
+struct FieldWords {  // the field itself
+  const Geom &g;
+  const vox_t *coc;
+  __device__ inline vox_t operator()(int x, int y, int z) const { return coc[g.idx(x, y, z)]; }
+};
+template <class Words>
+__host__ __device__ inline double vox_distance(const Geom &g, Words &wd, int x, int y, int z) {
   if (!g.in_grid(x, y, z)) return (double)FIESTA_HIP_INFINITY;  // the reference reads out of bounds here
-  return word_distance(g, coc[g.idx(x, y, z)] & ~kAct, x, y, z);
+  return word_distance(g, wd(x, y, z) & ~kAct, x, y, z);
 }
-__device__ inline bool pos_in_map(const Geom &g, double px, double py, double pz) {  // PosInMap (:46-61)
+__host__ __device__ inline bool pos_in_map(const Geom &g, double px, double py, double pz) {  // PosInMap (:46-61)
   return !(px < g.lo[0] || py < g.lo[1] || pz < g.lo[2] || px > g.hi[0] || py > g.hi[1] || pz > g.hi[2]);
 }
-
-__global__ void k_query_dist_vox(Geom g, const vox_t *coc, const int32_t *vox, int64_t n, double *out) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  out[i] = vox_distance(g, coc, vox[3 * i] - g.gx0, vox[3 * i + 1] - g.gy0, vox[3 * i + 2] - g.gz0);
+template <class Words>
+__host__ __device__ inline double query_dist_pos(const Geom &g, Words &wd, double px, double py, double pz) {  // (:467-475)
+  if (!pos_in_map(g, px, py, pz)) return (double)FIESTA_HIP_UNDEFINED;
+  return vox_distance(g, wd, (int)floor((px - g.org[0]) / g.res) - g.gx0, (int)floor((py - g.org[1]) / g.res) - g.gy0,
+                      (int)floor((pz - g.org[2]) / g.res) - g.gz0);
 }
-__global__ void k_query_dist_pos(Geom g, const vox_t *coc, const double *pos, int64_t n, double *out) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
-  if (!pos_in_map(g, px, py, pz)) {
-    out[i] = (double)FIESTA_HIP_UNDEFINED;
-    return;
-  }
-  out[i] = vox_distance(g, coc, (int)floor((px - g.org[0]) / g.res) - g.gx0,
-                        (int)floor((py - g.org[1]) / g.res) - g.gy0, (int)floor((pz - g.org[2]) / g.res) - g.gz0);
-}
-// GetDistWithGradTrilinear (src/ESDFMap.cpp:481-540), same operation order in f64 (compiled with
-// -ffp-contract=off so no FMA contraction changes the last bit).
-__global__ void k_query_trilinear(Geom g, const vox_t *coc, const double *pos, int64_t n, double *dist,
-                                  double *grad) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+// GetDistWithGradTrilinear (src/ESDFMap.cpp:481-540), same operation order in f64 (compiled with -ffp-contract=off so no
+// FMA contraction changes the last bit).  grad: three doubles or null.
+template <class Words>
+__host__ __device__ inline double query_trilinear(const Geom &g, Words &wd, const double *p, double *grad) {
   if (!pos_in_map(g, p[0], p[1], p[2])) {
-    dist[i] = -1;
-    if (grad) grad[3 * i] = grad[3 * i + 1] = grad[3 * i + 2] = 0;
-    return;
+    if (grad) grad[0] = grad[1] = grad[2] = 0;
+    return -1;
   }
   int b[3];
   double f[3];
@@ -563,23 +557,46 @@ __global__ void k_query_trilinear(Geom g, const vox_t *coc, const double *pos, i
   for (int ix = 0; ix < 2; ++ix)
     for (int iy = 0; iy < 2; ++iy)
       for (int iz = 0; iz < 2; ++iz)
-        v[ix][iy][iz] = vox_distance(g, coc, b[0] + ix - g.gx0, b[1] + iy - g.gy0, b[2] + iz - g.gz0);
+        v[ix][iy][iz] = vox_distance(g, wd, b[0] + ix - g.gx0, b[1] + iy - g.gy0, b[2] + iz - g.gz0);
   const double v00 = (1 - f[0]) * v[0][0][0] + f[0] * v[1][0][0];
   const double v01 = (1 - f[0]) * v[0][0][1] + f[0] * v[1][0][1];
   const double v10 = (1 - f[0]) * v[0][1][0] + f[0] * v[1][1][0];
   const double v11 = (1 - f[0]) * v[0][1][1] + f[0] * v[1][1][1];
   const double v0 = (1 - f[1]) * v00 + f[1] * v10;
   const double v1 = (1 - f[1]) * v01 + f[1] * v11;
-  dist[i] = (1 - f[2]) * v0 + f[2] * v1;
   if (grad) {
-    grad[3 * i + 2] = (v1 - v0) * g.res_inv;
-    grad[3 * i + 1] = ((1 - f[2]) * (v10 - v00) + f[2] * (v11 - v01)) * g.res_inv;
+    grad[2] = (v1 - v0) * g.res_inv;
+    grad[1] = ((1 - f[2]) * (v10 - v00) + f[2] * (v11 - v01)) * g.res_inv;
     double gx = (1 - f[2]) * (1 - f[1]) * (v[1][0][0] - v[0][0][0]);
     gx += (1 - f[2]) * f[1] * (v[1][1][0] - v[0][1][0]);
     gx += f[2] * (1 - f[1]) * (v[1][0][1] - v[0][0][1]);
     gx += f[2] * f[1] * (v[1][1][1] - v[0][1][1]);
-    grad[3 * i] = gx * g.res_inv;
+    grad[0] = gx * g.res_inv;
   }
+  return (1 - f[2]) * v0 + f[2] * v1;
+}
+
+__global__ void k_query_dist_vox(Geom g, const vox_t *coc, const int32_t *vox, int64_t n, double *out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  FieldWords wd{g, coc};
+  out[i] = vox_distance(g, wd, vox[3 * i] - g.gx0, vox[3 * i + 1] - g.gy0, vox[3 * i + 2] - g.gz0);
+}
+__global__ void k_query_dist_pos(Geom g, const vox_t *coc, const double *pos, int64_t n, double *out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  FieldWords wd{g, coc};
+  out[i] = query_dist_pos(g, wd, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+}
+__global__ void k_query_trilinear(Geom g, const vox_t *coc, const double *pos, int64_t n, double *dist,
+                                  double *grad) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  FieldWords wd{g, coc};
+  double gr[3];
+  dist[i] = query_trilinear(g, wd, p, grad ? gr : nullptr);
+  if (grad) grad[3 * i] = gr[0], grad[3 * i + 1] = gr[1], grad[3 * i + 2] = gr[2];
 }
 // GetOccupancy x2 (src/ESDFMap.cpp:452-465)
 __global__ void k_query_occ_vox(Geom g, const uint32_t *occbits, const int32_t *vox, int64_t n, int32_t *out) {
@@ -599,6 +616,65 @@ __global__ void k_query_occ_pos(Geom g, const uint32_t *occbits, const double *p
   const int x = (int)floor((px - g.org[0]) / g.res) - g.gx0, y = (int)floor((py - g.org[1]) / g.res) - g.gy0,
             z = (int)floor((pz - g.org[2]) / g.res) - g.gz0;
   out[i] = g.in_grid(x, y, z) ? (int)occ_test(occbits, g, x, y, z) : 0;
+}
+
+// ---- host-side brick cache of the scalar queries (DenseMap::HostBricks) ------------------------------------------------------
+// The reference's GetDistance is an array read (src/ESDFMap.cpp:467-479); a planner calls it 10^4-10^6 times a second, one
+// position per call.  Through copy-in / launch / copy-out / synchronise such a call cost tens of microseconds (VERDICT r4
+// weak #10).  Now: the field is cached on the host in bricks of 16^3 voxels, fetched on first touch -- ONE small kernel that
+// writes the brick's 4096 words and 4096 occupancy bits straight into pinned host memory, one synchronisation -- and every
+// further scalar query into that brick is a host read.  Whatever can change the field bumps an epoch that invalidates
+// every brick (UpdateOccupancy, UpdateESDF, restore / load, ghost exchange).
+__global__ __launch_bounds__(256) void k_fetch_brick(Geom g, const vox_t *coc, const uint32_t *occbits, int bx, int by, int bz, uint32_t *dst) {
+  const int t = threadIdx.x, x = 16 * bx + (t >> 4), y = 16 * by + (t & 15), z0 = 16 * bz;
+  uint32_t bits = 0;
+  for (int k = 0; k < 16; ++k) {
+    const bool in = g.in_grid(x, y, z0 + k);
+    dst[t * 16 + k] = in ? coc[g.idx(x, y, z0 + k)] : kUnobserved;
+    if (in && occ_test(occbits, g, x, y, z0 + k)) bits |= 1u << k;
+  }
+  reinterpret_cast<uint16_t *>(dst + 4096)[t] = (uint16_t)bits;
+}
+struct DenseMap::HostBricks {
+  static constexpr int kSlots = 2048, kWords = 4096 + 128;  // direct-mapped: brick id modulo kSlots (35 MB of pinned memory)
+  uint32_t *pool = nullptr;
+  std::vector<int64_t> tag;
+  std::vector<uint64_t> stamp;
+  int64_t fetches = 0;
+  ~HostBricks() {
+    if (pool) (void)hipHostFree(pool);
+  }
+};
+const uint32_t *DenseMap::host_brick(int x, int y, int z) {
+  if (!bricks_) {
+    bricks_ = new HostBricks;
+    FIESTA_HIP_CHECK(hipHostMalloc((void **)&bricks_->pool, (size_t)HostBricks::kSlots * HostBricks::kWords * sizeof(uint32_t)));
+    bricks_->tag.assign(HostBricks::kSlots, -1);
+    bricks_->stamp.assign(HostBricks::kSlots, 0);
+  }
+  const int bx = x >> 4, by = y >> 4, bz = z >> 4;
+  const int64_t id = ((int64_t)bx * ((g_.ny + 15) >> 4) + by) * ((g_.nz + 15) >> 4) + bz;
+  const int slot = (int)(id % HostBricks::kSlots);
+  uint32_t *b = bricks_->pool + (size_t)slot * HostBricks::kWords;
+  if (bricks_->tag[slot] != id || bricks_->stamp[slot] != field_epoch_) {
+    use_device();
+    hipLaunchKernelGGL(k_fetch_brick, dim3(1), dim3(256), 0, stream_, g_, (const vox_t *)coc_, (const uint32_t *)occbits_, bx, by, bz, b);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    bricks_->tag[slot] = id, bricks_->stamp[slot] = field_epoch_;
+    ++bricks_->fetches;
+  }
+  return b;
+}
+struct DenseMap::HostWords {  // a source of voxel words for the query templates
+  DenseMap *m;
+  vox_t operator()(int x, int y, int z) { return m->host_brick(x, y, z)[((x & 15) << 8) | ((y & 15) << 4) | (z & 15)]; }
+};
+int64_t DenseMap::host_brick_fetches() const { return bricks_ ? bricks_->fetches : 0; }
+int DenseMap::host_occ(int x, int y, int z) {
+  const uint32_t *b = host_brick(x, y, z);
+  const int row = ((x & 15) << 4) | (y & 15);
+  return (int)((b[4096 + (row >> 1)] >> (16 * (row & 1) + (z & 15))) & 1u);
 }
 
 // ---- whole-field export ----
@@ -648,7 +724,8 @@ __global__ void k_slice(Geom g, const vox_t *coc, int z, double *out) {
   const int64_t n = (int64_t)g.nx * g.ny;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int y = (int)(i % g.ny), x = (int)(i / g.ny);
-    out[i] = vox_distance(g, coc, x, y, z);
+    FieldWords wd{g, coc};
+    out[i] = vox_distance(g, wd, x, y, z);
   }
 }
 
@@ -688,7 +765,8 @@ __global__ void k_slice_marker(Geom g, const vox_t *coc, int z, double max_dist,
     const int y = g.wy0 + (int)(i % ey), x = g.wx0 + (int)(i / ey);
     const vox_t w = coc[g.idx(x, y, z)];
     if (w == kUnobserved || (w & kNoCoc)) continue;  // distance -10000 / +10000
-    const double d = vox_distance(g, coc, x, y, z);
+    FieldWords wd{g, coc};
+    const double d = vox_distance(g, wd, x, y, z);
     const unsigned long long k = atomicAdd(count, 1ull);
     if (k >= cap) continue;
     xyz[3 * k] = (x + g.gx0 + 0.5) * g.res + g.org[0];
@@ -879,6 +957,7 @@ DenseMap::~DenseMap() {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
+  delete bricks_;
   delete lv_;
   if (lv_done_) (void)hipEventDestroy(lv_done_);
   for (hipEvent_t e : evpool_) (void)hipEventDestroy(e);
@@ -1024,6 +1103,7 @@ bool DenseMap::check_update() {  // CheckUpdate (src/ESDFMap.cpp:227-233)
 }
 
 bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   // ONE host synchronisation per call (none when nothing was observed): the host keeps the queue sizes / map totals of
   // its last read and an upper bound of the touched list, so the fusion kernel is launched without asking the device
@@ -1513,6 +1593,7 @@ void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time
 
 // The sharded driver's bulk step (shard_group.hip): transform with `margin`, report exactness; commit consumes the queues.
 bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   ++epoch_;
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
@@ -1521,6 +1602,7 @@ bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
   return run_bulk(st, margin, exact);
 }
 void DenseMap::bulk_commit(fiesta_hip_stats *st) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   if (!ft_in_place_) FIESTA_HIP_CHECK(hipMemcpyAsync(coc_, ft_out_.p, (size_t)g_.n * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
   bulk_finish(st, std::chrono::steady_clock::now());
@@ -1648,7 +1730,8 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
   return false;
 }
 
-void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
+void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const auto h0 = std::chrono::steady_clock::now();
   if (host_counts_valid_) {  // (what UpdateOccupancy read last: nothing else changes these four)
@@ -1791,6 +1874,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
 }
 
 void DenseMap::relax_pending(fiesta_hip_stats *st, int64_t *pending) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   if (st) memset(st, 0, sizeof(*st));
   reset_stats_counters();
@@ -1811,8 +1895,13 @@ void DenseMap::relax_pending(fiesta_hip_stats *st, int64_t *pending) {
 
 // ---- queries ----
 void DenseMap::get_distance_vox(const int32_t *vox, int64_t n, double *out) {
-  use_device();
   if (n <= 0) return;
+  if (n <= kHostQueries) {  // a scalar call of the drop-in class: the host-side brick cache
+    HostWords wd{this};
+    for (int64_t i = 0; i < n; ++i) out[i] = vox_distance(g_, wd, vox[3 * i] - g_.gx0, vox[3 * i + 1] - g_.gy0, vox[3 * i + 2] - g_.gz0);
+    return;
+  }
+  use_device();
   stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
   stage_c_.ensure(n * sizeof(double), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
@@ -1822,8 +1911,13 @@ void DenseMap::get_distance_vox(const int32_t *vox, int64_t n, double *out) {
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void DenseMap::get_distance_pos(const double *pos, int64_t n, double *out) {
-  use_device();
   if (n <= 0) return;
+  if (n <= kHostQueries) {
+    HostWords wd{this};
+    for (int64_t i = 0; i < n; ++i) out[i] = query_dist_pos(g_, wd, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+    return;
+  }
+  use_device();
   stage_a_.ensure(n * 3 * sizeof(double), stream_);
   stage_c_.ensure(n * sizeof(double), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -1833,8 +1927,13 @@ void DenseMap::get_distance_pos(const double *pos, int64_t n, double *out) {
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void DenseMap::get_dist_grad(const double *pos, int64_t n, double *dist, double *grad, bool dev) {
-  use_device();
   if (n <= 0) return;
+  if (!dev && n <= kHostQueries) {
+    HostWords wd{this};
+    for (int64_t i = 0; i < n; ++i) dist[i] = query_trilinear(g_, wd, pos + 3 * i, grad ? grad + 3 * i : nullptr);
+    return;
+  }
+  use_device();
   if (dev) {
     hipLaunchKernelGGL(k_query_trilinear, dim3(grid_for(n)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, pos, n,
                        dist, grad);
@@ -1852,8 +1951,15 @@ void DenseMap::get_dist_grad(const double *pos, int64_t n, double *dist, double 
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void DenseMap::get_occupancy_vox(const int32_t *vox, int64_t n, int32_t *out) {
-  use_device();
   if (n <= 0) return;
+  if (n <= kHostQueries) {
+    for (int64_t i = 0; i < n; ++i) {
+      const int x = vox[3 * i] - g_.gx0, y = vox[3 * i + 1] - g_.gy0, z = vox[3 * i + 2] - g_.gz0;
+      out[i] = g_.in_grid(x, y, z) ? host_occ(x, y, z) : 0;
+    }
+    return;
+  }
+  use_device();
   stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
   stage_c_.ensure(n * sizeof(int32_t), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, vox, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
@@ -1863,8 +1969,21 @@ void DenseMap::get_occupancy_vox(const int32_t *vox, int64_t n, int32_t *out) {
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void DenseMap::get_occupancy_pos(const double *pos, int64_t n, int32_t *out) {
-  use_device();
   if (n <= 0) return;
+  if (n <= kHostQueries) {
+    for (int64_t i = 0; i < n; ++i) {
+      const double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+      if (!pos_in_map(g_, px, py, pz)) {
+        out[i] = FIESTA_HIP_UNDEFINED;
+        continue;
+      }
+      const int x = (int)floor((px - g_.org[0]) / g_.res) - g_.gx0, y = (int)floor((py - g_.org[1]) / g_.res) - g_.gy0,
+                z = (int)floor((pz - g_.org[2]) / g_.res) - g_.gz0;
+      out[i] = g_.in_grid(x, y, z) ? host_occ(x, y, z) : 0;
+    }
+    return;
+  }
+  use_device();
   stage_a_.ensure(n * 3 * sizeof(double), stream_);
   stage_c_.ensure(n * sizeof(int32_t), stream_);
   FIESTA_HIP_CHECK(hipMemcpyAsync(stage_a_.p, pos, n * 3 * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -2041,6 +2160,7 @@ void DenseMap::snapshot_save(int slot) {
 }
 
 void DenseMap::snapshot_restore(int slot) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   if (slot < 0 || slot >= 4 || !snaps_[slot].valid) throw Error(FIESTA_HIP_ERR_STATE, "no such snapshot");
   Snapshot &s = snaps_[slot];
@@ -2083,6 +2203,7 @@ void DenseMap::snapshot_restore(int slot) {
 
 // Raw dump (write) / load of the whole map state: one routine for both directions (checkpoint.hpp).
 void DenseMap::checkpoint(const char *path, bool write) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   DevFile f(path, write, stream_);
@@ -2295,6 +2416,7 @@ void DenseMap::halo_pack(const int32_t *lo, const int32_t *hi, uint32_t *out_dev
 }
 
 int64_t DenseMap::halo_apply(const int32_t *lo, const int32_t *hi, const uint32_t *in_dev) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   check_box(g_, lo, hi);
   const int ex = hi[0] - lo[0] + 1, ey = hi[1] - lo[1] + 1, ez = hi[2] - lo[2] + 1;
@@ -2325,6 +2447,7 @@ int64_t DenseMap::export_transitions(uint32_t *out_dev, int64_t cap) {
 }
 
 void DenseMap::apply_transitions(const uint32_t *ent_dev, int64_t n) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   if (!g_.sharded) throw Error(FIESTA_HIP_ERR_STATE, "apply_transitions: not a sharded map");
   if (n <= 0) return;
@@ -2346,6 +2469,7 @@ void DenseMap::halo_diff(const int32_t *lo, const int32_t *hi, uint32_t *shadow_
 }
 
 void DenseMap::halo_apply_sparse(const uint32_t *entries_dev, int64_t n, unsigned long long *changed_dev) {
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   if (n <= 0) return;
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};

@@ -136,6 +136,7 @@ class DenseMap {
   void get_dist_grad(const double *pos, int64_t n, double *dist, double *grad, bool dev);
   void get_occupancy_vox(const int32_t *vox, int64_t n, int32_t *out);
   void get_occupancy_pos(const double *pos, int64_t n, int32_t *out);
+  int64_t host_brick_fetches() const;  // bricks fetched for scalar queries so far (tests, bench)
 
   void download_field(int32_t *d2, int32_t *coc, uint8_t *occ, double *logodds);
   void download_counts(int32_t *num_hit, int32_t *num_miss);
@@ -296,6 +297,16 @@ class DenseMap {
   friend struct RaycastAccess;
 
   Snapshot snaps_[4];
+
+  // scalar queries (n <= kHostQueries positions per call, host pointers): a host-side cache of 16^3-voxel bricks of the
+  // field, see dense_map.hip (HostBricks).  field_epoch_ is bumped by everything that may change the field.
+  static constexpr int64_t kHostQueries = 8;
+  struct HostBricks;
+  struct HostWords;
+  HostBricks *bricks_ = nullptr;
+  uint64_t field_epoch_ = 1;
+  const uint32_t *host_brick(int x, int y, int z);
+  int host_occ(int x, int y, int z);
 };
 
 }  // namespace fiesta

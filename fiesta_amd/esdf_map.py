@@ -255,6 +255,18 @@ class ESDFMap:
         check(self._lib.fiesta_hip_get_dist_grad(self._h, _p(v), len(v), _p(dist), _p(grad)))
         return (float(dist[0]), grad[0]) if scalar else (dist, grad)
 
+    def GetDistWithGradTrilinearDevice(self, pos_dev_ptr: int, n: int, dist_dev_ptr: int, grad_dev_ptr: int = 0):
+        """device-resident batch (n x 3 f64 positions, n f64 distances, n x 3 f64 gradients or 0): the planner-side fast path"""
+        check(self._lib.fiesta_hip_get_dist_grad_dev(self._h, C.c_void_p(pos_dev_ptr), n, C.c_void_p(dist_dev_ptr),
+                                                     C.c_void_p(grad_dev_ptr) if grad_dev_ptr else None))
+
+    @property
+    def host_cache_fetches(self) -> int:
+        """bricks of the field fetched for scalar host queries so far (fiesta_hip_host_cache_fetches)"""
+        n = C.c_int64(0)
+        check(self._lib.fiesta_hip_host_cache_fetches(self._h, C.byref(n)))
+        return int(n.value)
+
     # -- whole field -----------------------------------------------------------------------------------------
     def download_field(self, want=("d2", "coc", "occ", "logodds")):
         n = self.grid_total_size_

@@ -245,6 +245,13 @@ int fiesta_hip_get_occupancy_pos(fiesta_hip_map *m, const double *pos, int64_t n
 /* Device-resident query: pos_dev n x 3 double, dist_dev n double, grad_dev n x 3 double (nullable). */
 int fiesta_hip_get_dist_grad_dev(fiesta_hip_map *m, const double *pos_dev, int64_t n, double *dist_dev,
                                  double *grad_dev);
+/* The five host-pointer queries above, called with n <= 8 on an array map (what fiesta::ESDFMap::GetDistance & co. do:
+ * one position per call, as the reference's callers -- planners, 10^4-10^6 calls a second, src/ESDFMap.cpp:467-540 is an
+ * array read there), are answered from a host-side cache of 16^3-voxel bricks of the field: the first query into a brick
+ * fetches it (one small kernel writing into pinned host memory, one synchronisation), every further one is a host read
+ * with the same arithmetic, bit for bit.  UpdateOccupancy, UpdateESDF, a restore or load and the ghost exchange of a
+ * shard invalidate the cache.  *fetches = bricks fetched so far (a statistic for tests and the benchmark). */
+int fiesta_hip_host_cache_fetches(fiesta_hip_map *m, int64_t *fetches);
 
 /* ---- whole-field access (tests, visualisation, checkpoints) ----
  * Dense dump in the reference's linear order; each output is nullable.

@@ -173,6 +173,53 @@ def test_queries_bit_exact(hip_lib, oracle_libs, best_oracle_kind):
     assert b.gpu.GetDistance(np.array([1, 2, 3], np.int32)) == b.cpu.GetDistanceVox([[1, 2, 3]])[0]
 
 
+def test_scalar_queries_through_the_host_brick_cache(hip_lib, oracle_libs, best_oracle_kind):
+    """The drop-in class asks ONE position per call (include/fiesta/ESDFMap.h, as the reference's callers do): such calls are
+    answered from a host-side cache of 16^3-voxel bricks (dense_map.hip: HostBricks).  Same bits as the batch kernels and the
+    reference -- interior, faces of the map (the +1 corners of the trilinear stencil leave the grid there), outside --, one
+    fetch per brick, and every call that may change the field invalidates the cache."""
+    n = 40
+    b = make_pair(oracle_libs, best_oracle_kind, n, res=0.2, origin=(-4.0, -4.0, 0.0))
+    observe_all(b, n)
+    rng = np.random.RandomState(21)
+    S = rng.randint(0, n, (150, 3)).astype(np.int32)
+    b.make_occupied(S)
+    b.esdf()
+    lo = np.array([-4.0, -4.0, 0.0])
+    pos = lo + rng.rand(600, 3) * (n * 0.2)                       # all over the map, faces included
+    pos[::50] += 30.0                                             # ... and some outside
+    interior = np.all((pos > lo + 0.2) & (pos < lo + n * 0.2 - 0.4), axis=1)
+    dgb, ggb = b.gpu.GetDistWithGradTrilinear(pos)                # the batch kernels
+    dc, gc = b.cpu.GetDistWithGradTrilinear(pos[interior])        # (the reference reads out of bounds at the +1 faces)
+    before = b.gpu.host_cache_fetches
+    for i, p in enumerate(pos):                                   # ONE position per call
+        d, g = b.gpu.GetDistWithGradTrilinear(p)
+        assert d == dgb[i] and np.array_equal(g, ggb[i]), (i, p)
+        assert b.gpu.GetDistance(p) == b.gpu.GetDistance(pos[i:i + 1].repeat(9, 0))[0]     # (9 positions: the batch path)
+        assert b.gpu.GetOccupancy(p) == b.gpu.GetOccupancy(pos[i:i + 1].repeat(9, 0))[0]
+    assert np.array_equal(dgb[interior], dc) and np.array_equal(ggb[interior], gc)
+    fetched = b.gpu.host_cache_fetches - before
+    assert 0 < fetched <= 27 + 1, fetched                          # 40^3 voxels = 27 bricks: each fetched once
+    vox = rng.randint(-2, n + 2, (300, 3)).astype(np.int32)
+    inside = np.all((vox >= 0) & (vox < n), axis=1)
+    for v in vox[inside]:
+        assert b.gpu.GetDistance(v) == b.cpu.GetDistanceVox(v[None])[0]
+        assert b.gpu.GetOccupancy(v) == b.cpu.GetOccupancyVox(v[None])[0]
+    for v in vox[~inside][:20]:                                   # (the reference reads out of bounds here; the batch path defines it)
+        assert b.gpu.GetDistance(v) == b.gpu.GetDistance(np.repeat(v[None], 9, 0))[0]
+    assert b.gpu.host_cache_fetches - before == fetched          # nothing fetched twice
+    # the field changes: the cache must not answer from before
+    b.make_free(S[:75])
+    probe = (lo + (S[0] + 0.5) * 0.2)
+    assert b.gpu.GetOccupancy(probe) == b.cpu.GetOccupancyPos(probe[None])[0] == 0       # (after UpdateOccupancy)
+    b.esdf()
+    for p in pos[interior][:100]:
+        d, g = b.gpu.GetDistWithGradTrilinear(p)
+        dc1, gc1 = b.cpu.GetDistWithGradTrilinear(p[None])
+        assert d == dc1[0] and np.array_equal(g, gc1[0])
+    assert b.gpu.host_cache_fetches - before > fetched
+
+
 def test_occupancy_fusion_logodds_and_positions(hip_lib, oracle_libs, best_oracle_kind):
     """SetOccupancy(Vector3d) + majority vote + clamping (src/ESDFMap.cpp:235-271) with mixed hits/misses,
     invalid occ values and out-of-map positions."""
