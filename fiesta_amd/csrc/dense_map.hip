@@ -1773,7 +1773,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
   const bool gate_open = !seed_only && !g_.sharded && bulk_eligible(ni, nd);
   // (the inserts ARE level 0: more of them than one work-group carries and the level engine would only hand the update on)
   const bool try_levels = !seed_only && !g_.sharded && !g_.wrap && update_engine_ != 1 &&
-                          (update_engine_ == 3 || (!gate_open && ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kSingleCap));
+                          (update_engine_ == 3 || (!gate_open && ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kInsertCap));
   const bool try_bulk = gate_open && (bulk_pinned() || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
   bool counters_reset = false;
   if (try_bulk) {

@@ -1223,7 +1223,7 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
     const auto d00 = std::chrono::steady_clock::now();
     bool levels_fell_back = false;
     // (the inserts ARE level 0: more of them than one work-group carries and the level engine would only hand the update on)
-    if (update_engine_ != 1 && (update_engine_ == 3 || (ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kSingleCap))) {
+    if (update_engine_ != 1 && (update_engine_ == 3 || (ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kInsertCap))) {
       // (the level engine keeps its statistics in its own control block: no counter reset, no read-back of counters --
       //  dropped observations are reported from the last value the host saw plus what it clipped itself)
       if (run_levels(st, ni, nd, nd || force_scan_)) {

@@ -1174,6 +1174,9 @@ struct LevelEngine {
   uint32_t serial = 0;
   uint32_t cap = 0;
   static constexpr uint32_t kSingleCap = 512;  // frontier one work-group keeps to itself: two entries per quad of lanes
+  static constexpr uint32_t kInsertCap = 512;  // inserts of an update `auto` still gives to this engine.  (r05 tried 2048 so that config 4's
+                                               // 648-insert frames would keep the FIFO layers: every one of them -- ~90 k voxel writes each -- outgrew
+                                               // kItemsMax and was handed to the rounds anyway, 0.35 ms per update instead of 0.25.)
   static constexpr uint32_t kGridEnter = 192;  // ... and what it keeps while k_level_grid stands behind it (7-10 us a level there)
   static constexpr uint32_t kGridMin = 64;     // frontier k_level_grid gives back to the one work-group
   static constexpr uint32_t kGridMax = 4096;   // frontier beyond which an update goes to the frontier rounds (pinned to this engine:
