@@ -56,20 +56,50 @@ __device__ inline bool obstacle_alive(const Geom &g, const uint32_t *occbits, co
   return g.in_grid(x, y, z) && occ_test(occbits, g, x, y, z);
 }
 
+// Appends `value` to list[] for every thread of the WORK-GROUP whose `pred` holds with ONE atomicAdd on the counter (every
+// thread of the group must call it, in uniform control flow): a returning atomic on one hot address costs ~10-50 ns and they
+// serialise -- 780 of them (one per wave of a 50 k-voxel batch) were most of k_observe_vox's 12 us and of k_fuse's 29 us.
+// s: two words of LDS per wave + one.  Returns the number appended by the group.
+__device__ inline uint32_t block_append(bool pred, uint32_t value, uint32_t *list, unsigned long long *counter, uint32_t *s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+  const unsigned long long m = __ballot(pred);
+  if (lane == 0) s[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t sum = 0;
+    for (int w = 0; w < nwave; ++w) {
+      const uint32_t c = s[w];
+      s[w] = sum, sum += c;
+    }
+    s[nwave] = sum;
+    s[nwave + 1] = sum ? (uint32_t)atomicAdd(counter, (unsigned long long)sum) : 0u;
+  }
+  __syncthreads();
+  const uint32_t total = s[nwave];
+  if (pred) list[s[nwave + 1] + s[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+  __syncthreads();  // (s is free again)
+  return total;
+}
+
 // ---- SetOccupancy(Vector3i,int), PROBABILISTIC branch (src/ESDFMap.cpp:417-437) ----
 // vox are map (global) voxel coordinates. No validation of occ here: the reference's Vector3i overload
 // does none either.
-__global__ void k_observe_vox(Geom g, const int32_t *vox, const int32_t *occ, int64_t n,
-                              unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
+__global__ __launch_bounds__(256) void k_observe_vox(Geom g, const int32_t *vox, const int32_t *occ, int64_t n,
+                                                      unsigned long long *cnt, uint32_t *touched, unsigned long long *counters) {
+  __shared__ uint32_t s_app[18];
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int x = vox[3 * i] - g.gx0, y = vox[3 * i + 1] - g.gy0, z = vox[3 * i + 2] - g.gz0;
-  if (!g.in_grid(x, y, z) || !g.in_window(x, y, z) || !g.owned(x, y, z)) return;  // VoxInRange (:420)
-  const int64_t idx = g.idx(x, y, z);
-  const unsigned long long add = ((unsigned long long)(uint32_t)occ[i] << 32) | 1ull;
-  const unsigned long long old = atomicAdd(&cnt[idx], add);
-  // num_miss_ became 1: first touch since the last fusion -> occupancy_queue_ (:426)
-  wave_append((uint32_t)old == 0, (uint32_t)idx, touched, &counters[C_TOUCHED]);
+  bool first = false;
+  int64_t idx = 0;
+  if (i < n) {
+    const int x = vox[3 * i] - g.gx0, y = vox[3 * i + 1] - g.gy0, z = vox[3 * i + 2] - g.gz0;
+    if (g.in_grid(x, y, z) && g.in_window(x, y, z) && g.owned(x, y, z)) {  // VoxInRange (:420)
+      idx = g.idx(x, y, z);
+      const unsigned long long add = ((unsigned long long)(uint32_t)occ[i] << 32) | 1ull;
+      const unsigned long long old = atomicAdd(&cnt[idx], add);
+      first = (uint32_t)old == 0;  // num_miss_ became 1: first touch since the last fusion -> occupancy_queue_ (:426)
+    }
+  }
+  block_append(first, (uint32_t)idx, touched, &counters[C_TOUCHED], s_app);
 }
 
 // SetOccupancy(Vector3i, occ) for EVERY voxel of a box (map coordinates, inclusive), e.g. "observe the whole
@@ -171,38 +201,47 @@ __device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_
 }
 
 // ---- UpdateOccupancy (src/ESDFMap.cpp:235-271): one lane per touched voxel ----
-__global__ void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *touched, int64_t n,
-                       unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *gocc,
-                       uint32_t *ins, uint32_t *del, unsigned long long *counters) {
+// `result` (nullable, pinned host memory the device can write): the LAST work-group to finish copies the four counters the
+// host wants after a fusion -- insert / delete queue lengths, observed and occupied voxels -- there and clears the touched
+// list's counter: UpdateOccupancy is then two launches and one synchronisation (r04: + a counter-reset kernel + a copy).
+__global__ __launch_bounds__(256) void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *touched, int64_t n,
+                                              unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *gocc,
+                                              uint32_t *ins, uint32_t *del, unsigned long long *counters, unsigned long long *result) {
+  __shared__ uint32_t s_app[18];
+  __shared__ uint32_t s_obs;
   if (n < 0) n = (int64_t)counters[C_TOUCHED];  // the host only knows an upper bound (it sized the grid with it)
-  const int lane = threadIdx.x & 63;
-  // (whole waves stride over the list: the ballots below need every lane of a wave in the same iteration)
-  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = i0 + lane;
+  if (threadIdx.x == 0) s_obs = 0;
+  long long nocc = 0;  // (thread 0's: inserts - deletes of the group)
+  // whole work-groups stride over the list (the appends below need every thread of the group in the same iteration)
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i0 + threadIdx.x;
     bool to_ins = false, to_del = false, first_obs = false;
     uint32_t idx = 0;
     if (i < n) {
       idx = touched[i];
       fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, to_ins, to_del, first_obs);
     }
-    // queue appends: ONE atomic per wave and queue (tens of thousands of transitions would otherwise serialise on
-    // the two counters)
-    const unsigned long long mi = __ballot(to_ins), md = __ballot(to_del), mo = __ballot(first_obs);
+    // queue appends: ONE atomic per work-group, pass and queue (block_append)
+    const uint32_t ni = block_append(to_ins, idx, ins, &counters[C_INSERT], s_app);
+    const uint32_t nd = block_append(to_del, idx, del, &counters[C_DELETE], s_app);
+    nocc += (long long)ni - (long long)nd;
     // bookkeeping for the choice of the UpdateESDF engine: observed voxels and occupied voxels of the map
-    if (lane == 0 && mo) atomicAdd(&counters[C_OBSERVED], (unsigned long long)__popcll(mo));
-    if (lane == 0 && (mi | md))
-      atomicAdd(&counters[C_NOCC], (unsigned long long)((long long)__popcll(mi) - (long long)__popcll(md)));
-    if (mi) {
-      uint32_t base = 0;  // (queues hold < 2^32 entries: voxel indices are 32-bit)
-      if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_INSERT], (unsigned long long)__popcll(mi));
-      base = __shfl(base, 0);
-      if (to_ins) ins[base + __popcll(mi & ((1ull << lane) - 1ull))] = idx;
-    }
-    if (md) {
-      uint32_t base = 0;
-      if (lane == 0) base = (uint32_t)atomicAdd(&counters[C_DELETE], (unsigned long long)__popcll(md));
-      base = __shfl(base, 0);
-      if (to_del) del[base + __popcll(md & ((1ull << lane) - 1ull))] = idx;
+    const unsigned long long mo = __ballot(first_obs);
+    if ((threadIdx.x & 63) == 0 && mo) atomicAdd(&s_obs, (uint32_t)__popcll(mo));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_obs) atomicAdd(&counters[C_OBSERVED], (unsigned long long)s_obs);
+    if (nocc) atomicAdd(&counters[C_NOCC], (unsigned long long)nocc);
+    if (result) {
+      __threadfence();
+      if (atomicAdd(&counters[C_FUSE_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull) {  // everybody else is done
+        __threadfence();
+        for (int k = 0; k < 4; ++k) result[k] = atomicAdd(&counters[C_INSERT + k], 0ull);
+        counters[C_TOUCHED] = 0;
+        counters[C_FUSE_TICKET] = 0;
+        __threadfence_system();
+      }
     }
   }
 }
@@ -1045,7 +1084,7 @@ void DenseMap::observe_vox(const int32_t *vox, const int32_t *occ, int64_t n, in
     docc_in = (const int32_t *)stage_b_.p;
   }
   ensure_touched_capacity(n);
-  hipLaunchKernelGGL(k_observe_vox, dim3(grid_for(n)), dim3(256), 0, stream_, g, dv, docc_in, n, cnt_, touched_.p,
+  hipLaunchKernelGGL(k_observe_vox, dim3(grid_for(n, 256)), dim3(256), 0, stream_, g, dv, docc_in, n, cnt_, touched_.p,
                      counters_);
   FIESTA_HIP_CHECK(hipGetLastError());
   if (ret && !dev) {  // what each SetOccupancy(Vector3i,int) call returns: Vox2Idx(vox) (:418,421,437)
@@ -1124,12 +1163,9 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
     del_.ensure(nd + nt, stream_, nd);
     hipLaunchKernelGGL(k_fuse, dim3(grid_for((int64_t)nt, 256, 8192)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
                        (const uint32_t *)touched_.p, (int64_t)-1, cnt_, logodds_, coc_, occbits_, gocc_, ins_.p,
-                       del_.p, counters_);
+                       del_.p, counters_, &h_counters_[C_INSERT]);  // (its last work-group writes the four results into h_counters_)
     FIESTA_HIP_CHECK(hipGetLastError());
-    zero_counter(C_TOUCHED);
     touched_upper_ = 0;
-    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
     for (int k = 0; k < 4; ++k) host_counts_[k] = h_counters_[C_INSERT + k];
     ni = host_counts_[0];

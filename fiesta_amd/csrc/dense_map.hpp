@@ -73,6 +73,7 @@ enum Counter {
   C_NN_CURSOR = C_FT_OVF0 + 1,   // cell transform (nn_kernels.hpp), in the slots the envelope passes leave unused: sites handed out,
   C_NN_FAILED = C_FT_OVF0 + 2,   //   cells that got no list (non-zero: the update is served by the envelope passes instead),
   C_NN_ENTRIES = C_FT_OVF0 + 4,  //   list entries in total
+  C_FUSE_TICKET = C_FT_OVF0 + 5,  // k_fuse: work-groups that have finished (the last one reports and clears it: zero between launches)
   C_FT_MAXD2,    // bulk path: largest d^2 written (2^30: a voxel found no obstacle in its region)
   C_PROF0,  // 8 profiling slots (FIESTA_HIP_PROF=1): cycles in stage / propagate / write-back, queue items, ...
   C_COUNT = C_PROF0 + 8
