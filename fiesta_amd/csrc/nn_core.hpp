@@ -195,8 +195,19 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
       if (kmax < kKmax) return -1;
       break;
     }
+    int qx, qy, qz;
+    unpack_site(tw, qx, qy, qz);
+    qx -= ox, qy -= oy, qz -= oz;
+    const int q2 = qx * qx + qy * qy + qz * qz;
     const int rad2 = rad2_of(te2);
-    const int Kw = reach_of(rad2);
+    // Two bounds on where a winner can lie, both from the competitor t: the ball above (|s - c| <= |t - c| + 2 h), and a cube
+    // -- a site s that is nearest to some voxel v of the cell has |s_a - v_a| <= |s - v| <= |t - v| <= M on every axis, M the
+    // distance from t to the cell's farthest corner, so p_a lies in [-M, 7 + M]: (M + 7) / 8 cells either way.  The cube is
+    // the tighter one along the axes (M <= |t - c| + h), the ball cuts its corners: the window is their intersection.
+    const int fx = qx > 7 - qx ? qx : 7 - qx, fy = qy > 7 - qy ? qy : 7 - qy, fz = qz > 7 - qz ? qz : 7 - qz;
+    const int Kc = ((int)(sqrtf((float)(fx * fx + fy * fy + fz * fz)) + 0.01f) + 7) >> 3;
+    const int Kb = reach_of(rad2);
+    const int Kw = Kb < Kc ? Kb : Kc;
     if (Kw > kmax) {
       if (kfirst < 2) {  // (a poor competitor widens the window: look for the nearest one before giving up)
         raw = kRaw + 1;
@@ -206,10 +217,6 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
       raw = 0;
       break;
     }
-    int qx, qy, qz;
-    unpack_site(tw, qx, qy, qz);
-    qx -= ox, qy -= oy, qz -= oz;
-    const int q2 = qx * qx + qy * qy + qz * qz;
     team.restart();
     for (RowWalk rw(Kw, team.rank, Team::lanes); !rw.done(); rw.next()) {
       const int gx = gap_of(rw.dx), gy = gap_of(rw.dy);
