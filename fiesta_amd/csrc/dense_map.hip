@@ -1190,10 +1190,16 @@ void DenseMap::enable_distance_tracking() {
 }
 
 // ONE memset: the statistics, the transform's spill counters and -- at the start of an update (lists) -- the tile-list counters
-void DenseMap::reset_stats_counters(bool lists) {
+void DenseMap::reset_stats_counters(bool lists, bool queues) {
   static_assert(C_LIST2 == C_LIST0 + 2 && C_INVALIDATED == C_LIST2 + 1 && C_FT_MAXD2 < C_COUNT, "counter layout");
   const int first = lists ? C_LIST0 : C_INVALIDATED;
-  zero_counters(first, C_COUNT - first);
+  if (queues) {  // ... and the two queue lengths in the same launch (a transform drains both queues whatever happens)
+    static_assert(C_DELETE == C_INSERT + 1, "counter layout");
+    hipLaunchKernelGGL(k_zero_words2, dim3(1), dim3(64), 0, stream_, &counters_[first], C_COUNT - first, &counters_[C_INSERT], 2);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  } else {
+    zero_counters(first, C_COUNT - first);
+  }
   ft_counters_clean_ = true;
 }
 
@@ -1594,7 +1600,8 @@ bool DenseMap::bulk_pays_model(double delta, double nocc, double n, double ft_la
 // After a successful bulk transform: the queues are consumed, timings and counters reported.
 void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells) {
   static_assert(C_DELETE == C_INSERT + 1, "counter layout");
-  zero_counters(C_INSERT, 2);  // both queues are drained
+  if (!queues_zeroed_) zero_counters(C_INSERT, 2);  // both queues are drained
+  queues_zeroed_ = false;
   host_counts_[0] = host_counts_[1] = 0;
   if (g_.sharded) zero_counter(C_REMOTE_DEL);
   FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
@@ -1813,7 +1820,10 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
   const bool try_bulk = gate_open && (bulk_pinned() || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
   bool counters_reset = false;
   if (try_bulk) {
-    reset_stats_counters(/*lists=*/true);
+    // (an unsharded map's transform cannot fail to serve the update -- the envelope passes stand behind the cell transform --
+    //  so the two queue lengths go in the same launch as the statistics)
+    queues_zeroed_ = !g_.sharded && g_.nx <= 2048 && g_.ny <= 2048 && g_.nz <= 2048;
+    reset_stats_counters(/*lists=*/true, queues_zeroed_);
     counters_reset = true;
     // a sparse obstacle set: the cell transform first (nn_kernels.hpp).  A cell without a list fails it -- k_nn_fill then
     // wrote nothing -- and the envelope passes below serve the update; the obstacle count is remembered and not retried.
@@ -1837,6 +1847,11 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
     if (run_bulk(st, 0, &exact)) {
       bulk_finish(st, h0);
       return;
+    }
+    if (queues_zeroed_) {  // (cannot happen: see above -- but the engines below read the queue lengths on the device)
+      h_counters_[C_INSERT] = ni, h_counters_[C_DELETE] = nd;
+      FIESTA_HIP_CHECK(hipMemcpyAsync(&counters_[C_INSERT], &h_counters_[C_INSERT], 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, stream_));
+      queues_zeroed_ = false;
     }
   }
   if (try_levels) {  // (the level engine keeps its statistics in its own control block: no counter reset on its path)

@@ -208,7 +208,7 @@ class DenseMap {
   bool cells_wanted() const;            // should this update try the cell transform (nn_kernels.hpp) before the envelope passes?
   bool run_cells(fiesta_hip_stats *st);  // false: not applicable to this map (nothing launched)
   void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells = false);
-  void reset_stats_counters(bool lists = false);
+  void reset_stats_counters(bool lists = false, bool queues = false);
   void enable_distance_tracking();
   void collect_stats(fiesta_hip_stats *st);
 
@@ -251,6 +251,7 @@ class DenseMap {
   double ft_last_ms_ = 0;      // kernel time of the last bulk update (the engine choice's idea of this scene's sweep)
   bool ft_in_place_ = true;   // the last transform wrote the field itself (no side buffer: its result could not be inexact)
   bool alone_in_group_ = true;  // a shard: the only one of its group (ShardGroup tells)
+  bool queues_zeroed_ = false;      // this update's reset already cleared C_INSERT / C_DELETE (bulk_finish need not)
   bool ft_counters_clean_ = false;  // reset_stats_counters() ran and no transform has used the spill counters since
   DevBuf<uint32_t> ft_inter_, ft_out_;
   // cell transform (nn_kernels.hpp): first site per cell, the sites, one record (list) per cell

@@ -17,6 +17,10 @@ namespace {  // (this header is included by two translation units)
 __global__ void k_zero_words(unsigned long long *p, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
+__global__ void k_zero_words2(unsigned long long *p, int n, unsigned long long *q, int m) {  // two ranges, one launch
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+  for (int i = threadIdx.x; i < m; i += blockDim.x) q[i] = 0;
+}
 }  // namespace
 
 struct TileGrid {

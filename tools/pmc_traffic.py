@@ -47,7 +47,8 @@ def main():
     names = sorted(k for k in F if kern in k)
     if not names:
         raise KeyError(kern)
-    n_updates = max(1, len(F[[k for k in names if "k_ft_rows" in k][0]]) if any("k_ft_rows" in k for k in names) else len(F[names[0]]))
+    first = [k for k in names if "k_ft_rows" in k or "k_nn_cells" in k]   # one launch of these per UpdateESDF
+    n_updates = max(1, len(F[first[0]]) if first else len(F[names[0]]))
     fr_sum = sum(sum(F[k]) for k in names)
     wr_sum = sum(sum(W[k]) for k in names if k in W)
     kname = " + ".join(names)
