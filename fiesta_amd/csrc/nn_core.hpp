@@ -130,7 +130,7 @@ struct PlainSrc {
 struct Solo {
   static constexpr int lanes = 1;
   int rank = 0, n = 0;
-  uint32_t raw[32];
+  uint32_t raw[kRaw];
   FIESTA_NN_HD inline void nearest(int &, uint32_t &) const {}
   FIESTA_NN_HD inline void restart() { n = 0; }
   FIESTA_NN_HD inline int slot() { return n++; }
@@ -171,25 +171,46 @@ FIESTA_NN_HD inline void scan_nearest(const Src &src, const Team &team, int cx, 
   }
 }
 
+// The competitor of cell (cx, cy, cz): the nearest site to its centre among the 3^3 cells around it, or the first ring beyond
+// that holds one (up to the source's reach).  te2 stays kNone if there is none.
+template <class Src, class Team>
+FIESTA_NN_HD inline void first_competitor(const Src &src, Team &team, int cx, int cy, int cz, int kfirst, int &te2, uint32_t &tw) {
+  constexpr int kmax = Src::reach < kKmax ? Src::reach : kKmax;
+  te2 = kNone, tw = 0xFFFFFFFFu;
+  for (int K = kfirst; K <= kmax && te2 == kNone; ++K) {
+    scan_nearest(src, team, cx, cy, cz, K, te2, tw);
+    team.nearest(te2, tw);
+  }
+}
+// cells the search window of a cell with competitor (te2, tw) reaches (what the sweep costs: k_nn_lists sorts its cells by it)
+FIESTA_NN_HD inline int window_reach(int te2, uint32_t tw, int cx, int cy, int cz) {
+  if (te2 == kNone) return kKmax + 1;
+  int qx, qy, qz;
+  unpack_site(tw, qx, qy, qz);
+  qx -= kB * cx, qy -= kB * cy, qz -= kB * cz;
+  const int fx = qx > 7 - qx ? qx : 7 - qx, fy = qy > 7 - qy ? qy : 7 - qy, fz = qz > 7 - qz ? qz : 7 - qz;
+  const int Kc = ((int)(sqrtf((float)(fx * fx + fy * fy + fz * fz)) + 0.01f) + 7) >> 3;
+  const int Kb = reach_of(rad2_of(te2));
+  return Kb < Kc ? Kb : Kc;
+}
+
 // The record of cell (cx, cy, cz) into out[kStride].  Returns the number of entries; 0 when the cell cannot be served: no
 // site within the search window's reach, a competitor so far away that the window would exceed kKmax cells, more than
 // kCap survivors; -1 (nothing written) when the window would leave what this source can serve (Src::reach cells): the
 // caller asks again with a source that reaches farther.  (Every lane of a team returns the same value; lane 0 writes the
-// count.)
+// count.)  have: the competitor (te2_in, tw_in) was found already (first_competitor with kKfirst).
 template <class Src, class Team>
-FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, int cz, uint32_t *out) {
+FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, int cz, uint32_t *out, bool have = false, int te2_in = kNone,
+                                   uint32_t tw_in = 0xFFFFFFFFu) {
   constexpr int kmax = Src::reach < kKmax ? Src::reach : kKmax;
   const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
   int raw = 0;
   // Second try: more candidates than the scratch holds are collected again against the NEAREST site of the 5^3 cells (the
   // first competitor came from the 3^3 cells and may be a poor one).
   for (int kfirst = kKfirst; kfirst <= 2; kfirst = 2 + (raw <= kRaw)) {
-    int te2 = kNone;
-    uint32_t tw = 0xFFFFFFFFu;
-    for (int K = kfirst; K <= kmax && te2 == kNone; ++K) {
-      scan_nearest(src, team, cx, cy, cz, K, te2, tw);
-      team.nearest(te2, tw);
-    }
+    int te2 = te2_in;
+    uint32_t tw = tw_in;
+    if (!have || kfirst != kKfirst) first_competitor(src, team, cx, cy, cz, kfirst, te2, tw);
     raw = 0;
     if (te2 == kNone) {
       if (kmax < kKmax) return -1;
@@ -200,14 +221,11 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
     qx -= ox, qy -= oy, qz -= oz;
     const int q2 = qx * qx + qy * qy + qz * qz;
     const int rad2 = rad2_of(te2);
-    // Two bounds on where a winner can lie, both from the competitor t: the ball above (|s - c| <= |t - c| + 2 h), and a cube
-    // -- a site s that is nearest to some voxel v of the cell has |s_a - v_a| <= |s - v| <= |t - v| <= M on every axis, M the
+    // Two bounds on where a winner can lie, both from the competitor t: the ball (|s - c| <= |t - c| + 2 h), and a cube -- a
+    // site s that is nearest to some voxel v of the cell has |s_a - v_a| <= |s - v| <= |t - v| <= M on every axis, M the
     // distance from t to the cell's farthest corner, so p_a lies in [-M, 7 + M]: (M + 7) / 8 cells either way.  The cube is
     // the tighter one along the axes (M <= |t - c| + h), the ball cuts its corners: the window is their intersection.
-    const int fx = qx > 7 - qx ? qx : 7 - qx, fy = qy > 7 - qy ? qy : 7 - qy, fz = qz > 7 - qz ? qz : 7 - qz;
-    const int Kc = ((int)(sqrtf((float)(fx * fx + fy * fy + fz * fz)) + 0.01f) + 7) >> 3;
-    const int Kb = reach_of(rad2);
-    const int Kw = Kb < Kc ? Kb : Kc;
+    const int Kw = window_reach(te2, tw, cx, cy, cz);
     if (Kw > kmax) {
       if (kfirst < 2) {  // (a poor competitor widens the window: look for the nearest one before giving up)
         raw = kRaw + 1;

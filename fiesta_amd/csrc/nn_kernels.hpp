@@ -136,14 +136,14 @@ constexpr int kStageNZ = 64 + 2 * kStageK + 1;                                  
 constexpr int kStageSites = 3072;
 struct StagedSrc {  // the staged neighbourhood only: no range checks (rows outside the map are staged empty, entries are
   static constexpr int reach = kStageK;  // clamped into their row), no second path -- a window that needs more is served by
-  const uint32_t *tab;     // nn::PlainSrc in a second attempt.  [kStageNR][kStageNZ]: entry e of a row = first site of cell Zf + e
-  const uint32_t *delta;   // [kStageNR]: LDS index of a staged site = its index in the site array + delta[row]
+  const uint16_t *tab;     // HybridSrc in a second attempt.  [kStageNR][kStageNZ]: entry e of a row = sites of the row before cell Zf + e
+  const uint32_t *soff;    // [kStageNR]: LDS index of the row's first staged site
   const uint32_t *lsites;
   int rbase, ebase;        // row index of (cx, cy) and entry index of cz for this lane's cell
   __device__ __forceinline__ void bounds(int X, int Y, int z0, int z1, uint32_t &i0, uint32_t &i1) const {
     const int row = X * kStageNY + Y + rbase;  // (X, Y arrive as cx + dx, cy + dy: rbase takes the origin out)
-    const uint32_t d = delta[row];
-    const uint32_t *t = tab + row * kStageNZ + ebase;
+    const uint32_t d = soff[row];
+    const uint16_t *t = tab + row * kStageNZ + ebase;
     i0 = t[z0] + d, i1 = t[z1 + 1] + d;
   }
   __device__ __forceinline__ uint32_t site(uint32_t i) const { return lsites[i]; }
@@ -197,13 +197,16 @@ struct QuadTeam {
   }
 };
 
-__global__ __launch_bounds__(1024) void k_nn_lists(NnArgs a) {  // 64 (z) x 4 (y) cells, four lanes each
-  __shared__ uint32_t s_tab[kStageNR * kStageNZ];
-  __shared__ uint32_t s_delta[kStageNR], s_cnt[kStageNR];
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_nn_lists(NnArgs a) {  // (two work-groups per CU: 64 VGPRs, < 80 KB of LDS)  // 64 (z) x 4 (y) cells, four lanes each
+  __shared__ uint16_t s_tab[kStageNR * kStageNZ];
+  __shared__ uint32_t s_first[kStageNR], s_soff[kStageNR], s_cnt[kStageNR];
   __shared__ uint32_t s_sites[kStageSites];
   __shared__ uint32_t s_slots[256];
   __shared__ uint32_t s_raw[256 * (nn::kRaw + 1)];  // (+ 1: the sixteen teams of a wave on different banks)
   __shared__ uint32_t s_total, s_bad, s_sum, s_done;
+  __shared__ uint32_t s_te2[256], s_tw[256], s_bin[8];
+  __shared__ uint16_t s_order[256];
+  __shared__ uint8_t s_key[256];
   const nn::Geom &g = a.g;
   const int tid = (int)threadIdx.x;
   const int cz0 = (int)blockIdx.x * 64, cy0 = (int)blockIdx.y * 4, cx = (int)blockIdx.z;
@@ -211,52 +214,91 @@ __global__ __launch_bounds__(1024) void k_nn_lists(NnArgs a) {  // 64 (z) x 4 (y
   const int64_t rowlen = g.ncz + 1;
   if (tid < 256) s_slots[tid] = 0;
   if (tid == 0) s_bad = 0, s_sum = 0, s_done = 0;
-  for (int idx = tid; idx < kStageNR * kStageNZ; idx += 1024) {
-    const int row = idx / kStageNZ, e = idx - row * kStageNZ;
-    const int X = X0 + row / kStageNY, Y = Y0 + row % kStageNY;
-    uint32_t v = 0;
+  if (tid < 8) s_bin[tid] = 0;
+  // staging, step 1: per row of cells its range of the site array inside the neighbourhood's z-extent
+  if (tid < kStageNR) {
+    const int X = X0 + tid / kStageNY, Y = Y0 + tid % kStageNY;
+    uint32_t f = 0, l = 0;
     if ((unsigned)X < (unsigned)g.ncx && (unsigned)Y < (unsigned)g.ncy) {
-      const int cz = min(max(Zf + e, 0), g.ncz);
-      v = a.ctab[((int64_t)X * g.ncy + Y) * rowlen + cz];
+      const uint32_t *row = a.ctab + ((int64_t)X * g.ncy + Y) * rowlen;
+      f = row[min(max(Zf, 0), g.ncz)], l = row[min(max(Zf + kStageNZ - 1, 0), g.ncz)];
     }
-    s_tab[idx] = v;
+    s_first[tid] = f, s_cnt[tid] = l - f;
   }
   __syncthreads();
   if (tid < 64) {  // LDS offsets of the rows' sites: a scan over kStageNR <= 128 counts
-    uint32_t c0 = tid < kStageNR ? s_tab[tid * kStageNZ + kStageNZ - 1] - s_tab[tid * kStageNZ] : 0u;
-    uint32_t c1 = tid + 64 < kStageNR ? s_tab[(tid + 64) * kStageNZ + kStageNZ - 1] - s_tab[(tid + 64) * kStageNZ] : 0u;
+    const uint32_t c0 = tid < kStageNR ? s_cnt[tid] : 0u, c1 = tid + 64 < kStageNR ? s_cnt[tid + 64] : 0u;
     uint32_t i0 = c0, i1 = c1;
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t u0 = (uint32_t)__shfl_up((int)i0, off), u1 = (uint32_t)__shfl_up((int)i1, off);
       if (tid >= off) i0 += u0, i1 += u1;
     }
     const uint32_t t0 = (uint32_t)__shfl((int)i0, 63);
-    if (tid < kStageNR) s_delta[tid] = (i0 - c0) - s_tab[tid * kStageNZ], s_cnt[tid] = c0;
-    if (tid + 64 < kStageNR) s_delta[tid + 64] = (t0 + i1 - c1) - s_tab[(tid + 64) * kStageNZ], s_cnt[tid + 64] = c1;
+    if (tid < kStageNR) s_soff[tid] = i0 - c0;
+    if (tid + 64 < kStageNR) s_soff[tid + 64] = t0 + i1 - c1;
     if (tid == 63) s_total = t0 + i1;
   }
   __syncthreads();
   const bool staged = s_total <= (uint32_t)kStageSites;
-  if (staged) {
+  if (staged) {  // step 2: the table (16-bit, relative to the row's first staged site) and the sites
+    for (int idx = tid; idx < kStageNR * kStageNZ; idx += 1024) {
+      const int row = idx / kStageNZ, e = idx - row * kStageNZ;
+      const int X = X0 + row / kStageNY, Y = Y0 + row % kStageNY;
+      uint32_t v = 0;
+      if ((unsigned)X < (unsigned)g.ncx && (unsigned)Y < (unsigned)g.ncy)
+        v = a.ctab[((int64_t)X * g.ncy + Y) * rowlen + min(max(Zf + e, 0), g.ncz)] - s_first[row];
+      s_tab[idx] = (uint16_t)v;
+    }
     for (int idx = tid; idx < kStageNR * 16; idx += 1024) {
       const int row = idx >> 4;
-      const uint32_t cnt = s_cnt[row], first = s_tab[row * kStageNZ], d = s_delta[row];
-      for (uint32_t j = (uint32_t)(idx & 15); j < cnt; j += 16) s_sites[first + j + d] = a.sites[first + j];
+      const uint32_t cnt = s_cnt[row], first = s_first[row], at = s_soff[row];
+      for (uint32_t j = (uint32_t)(idx & 15); j < cnt; j += 16) s_sites[at + j] = a.sites[first + j];
     }
   }
   __syncthreads();
-  const int ci = tid >> 2;  // cell of the work-group: 16 per wave, consecutive in z
+  // Phase A: team i finds the competitor of cell i of the work-group (16 cells per wave, consecutive in z) and how far its
+  // search window reaches.  Then the work-group's cells are SORTED by that reach, and in phase B team i builds the list of the
+  // i-th cell in that order: the lanes of a wave walk their windows in lock step, so a wave costs what its widest window
+  // costs -- 13 row steps if one of its sixteen cells needs the 7 x 7 rows, 7 if all get by with 5 x 5 (four cells in five
+  // do).  Sorted, thirteen waves of sixteen take the short walk.
+  const int team_i = tid >> 2;
+  QuadTeam team{tid & 3, &s_slots[team_i], &s_raw[team_i * (nn::kRaw + 1)]};
+  const StagedSrc ssrc{staged ? s_tab : nullptr, s_soff, s_sites, -(X0 * kStageNY + Y0), -Zf};
+  {
+    const int cz = cz0 + (team_i & 63), cy = cy0 + (team_i >> 6);
+    const bool live = cz < g.ncz && cy < g.ncy;
+    int te2 = nn::kNone, key = 7;  // (7: not a cell of the map)
+    uint32_t tw = 0xFFFFFFFFu;
+    if (live) {
+      if (staged) nn::first_competitor(ssrc, team, cx, cy, cz, nn::kKfirst, te2, tw);
+      key = min(nn::window_reach(te2, tw, cx, cy, cz), 6);
+    }
+    if (team.rank == 0) {
+      s_te2[team_i] = (uint32_t)te2, s_tw[team_i] = tw, s_key[team_i] = (uint8_t)key;
+      atomicAdd(&s_bin[key], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t at = 0;
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t c = s_bin[k];
+      s_bin[k] = at, at += c;
+    }
+  }
+  __syncthreads();
+  if (tid < 256) s_order[atomicAdd(&s_bin[s_key[tid]], 1u)] = (uint16_t)tid;  // (which team gets which cell does not change any list)
+  __syncthreads();
+  const int ci = s_order[team_i];
   const int cz = cz0 + (ci & 63), cy = cy0 + (ci >> 6);
   int n = 0;
   const bool live = cz < g.ncz && cy < g.ncy;  // (the same for the four lanes of a team)
-  QuadTeam team{tid & 3, &s_slots[ci], &s_raw[ci * (nn::kRaw + 1)]};
   if (live) {
     const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
     uint32_t *rec = a.lists + cell * nn::kStride;
     n = -1;
-    const StagedSrc ssrc{staged ? s_tab : nullptr, s_delta, s_sites, -(X0 * kStageNY + Y0), -Zf};
-    if (staged) n = nn::build_list(ssrc, team, cx, cy, cz, rec);
-    if (n < 0) {  // (a team decides together: the window needs more than the staged three cells -- or nothing was staged)
+    if (staged) n = nn::build_list(ssrc, team, cx, cy, cz, rec, true, (int)s_te2[ci], s_tw[ci]);
+    if (n < 0) {  // (a team decides together: the window needs more than the staged cells -- or nothing was staged)
       const HybridSrc src{ssrc, nn::PlainSrc{a.ctab, a.sites, g.ncx, g.ncy, g.ncz}, X0, Y0, Zf};
       n = nn::build_list(src, team, cx, cy, cz, rec);
     }
