@@ -1481,13 +1481,19 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 // worth trying: the obstacle density must be in the range where every cell finds an obstacle within its search window and
 // lists stay short (measured on scatter scenes, tests/test_nn_model.py: 1.2e-4 ... 2.5e-3 of the voxels; config 2's scene is
 // 3.7e-4), it must not have failed at about this obstacle count, and it must not have been slower than the envelope passes.
-bool DenseMap::cells_wanted() const {
+bool DenseMap::cells_wanted() {
   const Geom &g = g_;
   if (update_engine_ == 4 || g.sharded || g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024) return false;
   if (update_engine_ == 5) return true;
   const long long nocc = (long long)h_counters_[C_NOCC];
   if (nocc * 8192 < g.n || nocc * 400 > g.n) return false;
-  if (nn_fail_nocc_ >= 0 && std::llabs(nocc - nn_fail_nocc_) * 4 <= nn_fail_nocc_) return false;
+  // a failed attempt (a cell without a list: ~0.2 ms lost before the envelope passes take over) is not repeated at once: the
+  // next 8, 16, ... 256 eligible updates go straight to the envelope passes, then it is tried again -- a scene that cannot be
+  // served costs 1 % in the long run, one unlucky cell in a scene that can does not switch the transform off for good
+  if (nn_skip_ > 0) {
+    --nn_skip_;
+    return false;
+  }
   if (nn_last_ms_ > 0 && ft_last_ms_ > 0 && nn_last_ms_ > ft_last_ms_ && std::llabs(nocc - nn_last_nocc_) * 4 <= nn_last_nocc_) return false;
   return true;
 }
@@ -1828,13 +1834,13 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
     // a sparse obstacle set: the cell transform first (nn_kernels.hpp).  A cell without a list fails it -- k_nn_fill then
     // wrote nothing -- and the envelope passes below serve the update; the obstacle count is remembered and not retried.
     if (cells_wanted() && run_cells(st)) {
-      const long long nocc_now = (long long)h_counters_[C_NOCC];
       bulk_finish(st, h0, /*cells=*/true);
       if (h_counters_[C_NN_FAILED] == 0) {
-        nn_fail_nocc_ = -1;
+        nn_fail_streak_ = 0;
         return;
       }
-      nn_fail_nocc_ = nocc_now;
+      nn_fail_streak_ = std::min(nn_fail_streak_ + 1, 6);
+      nn_skip_ = 4 << nn_fail_streak_;
       const int64_t failed = (int64_t)h_counters_[C_NN_FAILED];
       if (st) {
         memset(&st->cells, 0, sizeof(st->cells));
