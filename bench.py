@@ -915,19 +915,30 @@ def main():
         call_achieved = my_updated / args.steps * ALGO_BYTES_PER_UPDATED_VOXEL / (call_p50_ms * 1e-3) / 1e9
         n_bulk = sum(int(s.get("bulk", 0)) for s in timed)
         n_cells = sum(int(s.get("cells", 0)) for s in timed)
-        if n_bulk == len(timed) and n_cells == len(timed):
+        engine_steps = {"cells": n_cells, "envelope": n_bulk - n_cells, "levels": sum(int(s.get("levels", 0)) for s in timed),
+                        "cell_transform_attempts_that_failed": sum(1 for s in timed if int(s.get("nn_failed", 0)) > 0)}
+        engine_steps["rounds"] = len(timed) - n_bulk - engine_steps["levels"]
+        if n_bulk == len(timed) and 0 < n_cells < len(timed):
+            # a mix of the two transforms (a cell transform that met a cell it could not serve hands that update -- and the next
+            # few eligible ones -- to the envelope passes): the phases below describe the majority, the counts say so
+            major = [s for s in timed if bool(s.get("cells")) == (2 * n_cells >= len(timed))]
+            n_cells = len(major) if major[0].get("cells") else 0
+            phase_src = major
+        else:
+            phase_src = timed
+        if n_bulk == len(timed) and n_cells == len(phase_src) and n_cells > 0:
             kernel = "k_nn_cells + k_nn_lists + k_nn_fill (cell transform: every kernel of UpdateESDF)"
-            phases = {k: statistics.median(s[k] for s in timed) for k in ("nn_cells_ms", "nn_lists_ms", "nn_fill_ms")}
+            phases = {k: statistics.median(s[k] for s in phase_src) for k in ("nn_cells_ms", "nn_lists_ms", "nn_fill_ms")}
             # the dominant kernel on ITS OWN bytes: k_nn_fill writes 4 B per voxel of the grid and reads only the cells' lists
             own = float(G) ** 3 * 4.0
             dominant = {"kernel": "k_nn_fill", "ms": phases["nn_fill_ms"], "own_bytes": own, "own_bytes_what": "4 B written per grid voxel",
                         "achieved_GBs": own / (phases["nn_fill_ms"] * 1e-3) / 1e9,
                         "frac": own / (phases["nn_fill_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "list_entries_per_cell": statistics.mean(s["nn_entries"] for s in timed) / (math.ceil(G / 8) ** 3)}
+                        "list_entries_per_cell": statistics.mean(s["nn_entries"] for s in phase_src) / (math.ceil(G / 8) ** 3)}
             overflow = None
         elif n_bulk == len(timed):
             kernel = "k_ft_rows + k_ft_plane + k_ft_x (bulk feature transform: every kernel of UpdateESDF)"
-            phases = {k: statistics.median(s[k] for s in timed) for k in ("ft_rows_ms", "ft_plane_ms", "ft_x_ms")}
+            phases = {k: statistics.median(s[k] for s in phase_src) for k in ("ft_rows_ms", "ft_plane_ms", "ft_x_ms")}
             # the dominant kernel on ITS OWN bytes: pass B reads 4 B and writes 4 B per voxel of the grid
             own = float(G) ** 3 * 8.0
             dominant = {"kernel": "k_ft_x", "ms": phases["ft_x_ms"], "own_bytes": own, "own_bytes_what": "4 B read + 4 B written per grid voxel",
@@ -988,7 +999,7 @@ def main():
                 "launches": launches, "avg_launch_us": relax_ms * 1e3 / max(1, launches),
                 "algorithmic_bytes_per_launch": my_updated * ALGO_BYTES_PER_UPDATED_VOXEL / max(1, launches),
                 "frac_of_measured_copy_6.29TBs": call_achieved / 6290.0,
-                "phases_p50_ms": phases, "dominant_kernel": dominant, "ring_overflows": overflow,
+                "phases_p50_ms": phases, "dominant_kernel": dominant, "ring_overflows": overflow, "engine_steps": engine_steps,
             },
             "verify": verify,
             "parity": parity_summary(args, G, world) if args.unobserved <= 0 else {

@@ -32,6 +32,16 @@
 #define FIESTA_NN_HD
 #include <math.h>
 #endif
+// Small-integer products and the square roots of the window bounds.  On the device: 24-bit multiplies (v_mul_i32_i24 is full
+// rate, v_mul_lo_u32 a quarter: every operand here is below 2^12) and the bare v_sqrt_f32 (1 ulp; the bounds carry margins
+// of 0.01 and more, and only have to err on the wide side).  On the host: the plain operators.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FIESTA_NN_MUL(a, b) __mul24((a), (b))
+#define FIESTA_NN_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define FIESTA_NN_MUL(a, b) ((a) * (b))
+#define FIESTA_NN_SQRT(x) sqrtf(x)
+#endif
 
 namespace fiesta {
 namespace nn {
@@ -78,22 +88,23 @@ FIESTA_NN_HD inline void unpack_site(uint32_t w, int &x, int &y, int &z) {
 // |2 (s - c)|^2 of a site at offset p: the doubled offset from the cell centre is 2 p - 7 per axis
 FIESTA_NN_HD inline int e2_of(int px, int py, int pz) {
   const int ex = 2 * px - 7, ey = 2 * py - 7, ez = 2 * pz - 7;
-  return ex * ex + ey * ey + ez * ez;
+  return FIESTA_NN_MUL(ex, ex) + FIESTA_NN_MUL(ey, ey) + FIESTA_NN_MUL(ez, ez);
 }
 // (2 R)^2 rounded up: 2 R = |e_t| + 4 h, 4 h = 14 sqrt 3 = 24.2487
 FIESTA_NN_HD inline int rad2_of(int e2) {
-  const float r = sqrtf((float)e2) + 24.26f;
+  const float r = FIESTA_NN_SQRT((float)e2) + 24.27f;
   return (int)(r * r) + 1;
 }
 // cells the window reaches along an axis: a site of the ball has 16 |d| - 7 <= 2 R
-FIESTA_NN_HD inline int reach_of(int rad2) { return (int)((sqrtf((float)rad2) + 7.01f) * 0.0625f); }
+FIESTA_NN_HD inline int reach_of(int rad2) { return (int)((FIESTA_NN_SQRT((float)rad2) + 7.02f) * 0.0625f); }
 // doubled gap between the centre and a cell d cells away along one axis
 FIESTA_NN_HD inline int gap_of(int d) { return d ? 16 * (d < 0 ? -d : d) - 7 : 0; }
 
 // is the site at offset p dominated by the one at q over the whole cell (q2 = |q|^2)?  Ties go to q.
 FIESTA_NN_HD inline bool dominated(int px, int py, int pz, int qx, int qy, int qz, int q2) {
   const int ax = px - qx, ay = py - qy, az = pz - qz;
-  return px * px + py * py + pz * pz - q2 >= 14 * ((ax > 0 ? ax : 0) + (ay > 0 ? ay : 0) + (az > 0 ? az : 0));
+  return FIESTA_NN_MUL(px, px) + FIESTA_NN_MUL(py, py) + FIESTA_NN_MUL(pz, pz) - q2 >=
+         FIESTA_NN_MUL(14, (ax > 0 ? ax : 0) + (ay > 0 ? ay : 0) + (az > 0 ? az : 0));
 }
 // a candidate between sweep and record: three signed bytes
 FIESTA_NN_HD inline uint32_t pack_p(int px, int py, int pz) { return ((uint32_t)px & 255u) | (((uint32_t)py & 255u) << 8) | (((uint32_t)pz & 255u) << 16); }
@@ -126,6 +137,7 @@ struct PlainSrc {
 //   restart()     forget the slots handed out (every lane, outside loops)
 //   slot()        the next free slot (any lane, inside loops)
 //   count()       slots handed out (called by every lane once all have finished their loops)
+//   count_now()   slots handed out so far, as this lane sees them (inside loops; entries below it may still be on their way)
 //   put(), get()  the team's scratch of kRaw words: the candidates between the sweep and the record
 struct Solo {
   static constexpr int lanes = 1;
@@ -135,6 +147,7 @@ struct Solo {
   FIESTA_NN_HD inline void restart() { n = 0; }
   FIESTA_NN_HD inline int slot() { return n++; }
   FIESTA_NN_HD inline int count() const { return n; }
+  FIESTA_NN_HD inline int count_now() const { return n; }
   FIESTA_NN_HD inline void put(int k, uint32_t v) { raw[k] = v; }
   FIESTA_NN_HD inline uint32_t get(int k) const { return raw[k]; }
 };
@@ -189,7 +202,7 @@ FIESTA_NN_HD inline int window_reach(int te2, uint32_t tw, int cx, int cy, int c
   unpack_site(tw, qx, qy, qz);
   qx -= kB * cx, qy -= kB * cy, qz -= kB * cz;
   const int fx = qx > 7 - qx ? qx : 7 - qx, fy = qy > 7 - qy ? qy : 7 - qy, fz = qz > 7 - qz ? qz : 7 - qz;
-  const int Kc = ((int)(sqrtf((float)(fx * fx + fy * fy + fz * fz)) + 0.01f) + 7) >> 3;
+  const int Kc = ((int)(FIESTA_NN_SQRT((float)(FIESTA_NN_MUL(fx, fx) + FIESTA_NN_MUL(fy, fy) + FIESTA_NN_MUL(fz, fz))) + 0.02f) + 7) >> 3;
   const int Kb = reach_of(rad2_of(te2));
   return Kb < Kc ? Kb : Kc;
 }
@@ -219,7 +232,7 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
     int qx, qy, qz;
     unpack_site(tw, qx, qy, qz);
     qx -= ox, qy -= oy, qz -= oz;
-    const int q2 = qx * qx + qy * qy + qz * qz;
+    const int q2 = FIESTA_NN_MUL(qx, qx) + FIESTA_NN_MUL(qy, qy) + FIESTA_NN_MUL(qz, qz);
     const int rad2 = rad2_of(te2);
     // Two bounds on where a winner can lie, both from the competitor t: the ball (|s - c| <= |t - c| + 2 h), and a cube -- a
     // site s that is nearest to some voxel v of the cell has |s_a - v_a| <= |s - v| <= |t - v| <= M on every axis, M the
@@ -238,9 +251,9 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
     team.restart();
     for (RowWalk rw(Kw, team.rank, Team::lanes); !rw.done(); rw.next()) {
       const int gx = gap_of(rw.dx), gy = gap_of(rw.dy);
-      const int rem = rad2 - gx * gx - gy * gy;
+      const int rem = rad2 - FIESTA_NN_MUL(gx, gx) - FIESTA_NN_MUL(gy, gy);
       if (rem < 0) continue;  // the whole row of cells lies outside the ball
-      int m = (int)((sqrtf((float)rem) + 7.01f) * 0.0625f);  // cells along z the ball still touches
+      int m = (int)((FIESTA_NN_SQRT((float)rem) + 7.02f) * 0.0625f);  // cells along z the ball still touches
       m = m > Kw ? Kw : m;
       uint32_t i, i1;
       src.bounds(cx + rw.dx, cy + rw.dy, cz - m, cz + m, i, i1);
@@ -249,7 +262,19 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
         int px, py, pz;
         unpack_site(w, px, py, pz);
         px -= ox, py -= oy, pz -= oz;
-        if (w == tw || !dominated(px, py, pz, qx, qy, qz, q2)) {
+        bool keep = w == tw || !dominated(px, py, pz, qx, qy, qz, q2);
+        if (keep && kfirst >= 2 && w != tw) {
+          // the second try also asks the candidates already collected (dominance is transitive: whoever drops s here, or
+          // whoever later drops that one, stands in for s) -- a list that overflowed against t alone comes out thinned
+          const int have_n = team.count_now();
+          for (int j = 0; j < have_n && j < kRaw && keep; ++j) {
+            int ux, uy, uz;
+            unpack_p(team.get(j), ux, uy, uz);
+            keep = !dominated(px, py, pz, ux, uy, uz, FIESTA_NN_MUL(ux, ux) + FIESTA_NN_MUL(uy, uy) + FIESTA_NN_MUL(uz, uz)) ||
+                   (ux == px && uy == py && uz == pz);
+          }
+        }
+        if (keep) {
           const int k = team.slot();
           if (k < kRaw) team.put(k, pack_p(px, py, pz));
         }
