@@ -185,20 +185,20 @@ struct QuadTeam {
   }
   __device__ __forceinline__ void restart() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (rank == 0) *(volatile uint32_t *)counter = 0u;
+    if (rank == 0) (void)atomicExch(counter, 0u);  // (LDS atomics rather than volatile accesses: those go out as flat, system-scope)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   __device__ __forceinline__ int slot() { return (int)atomicAdd(counter, 1u); }
   // a team's lanes are lanes of one wave in lock step: a slot handed out by an earlier instruction has been put by the time
   // a later one reads it -- except the three other lanes' puts of the SAME step, which a lane may miss (harmless: it then
   // keeps a candidate it could have dropped)
-  __device__ __forceinline__ int count_now() const { return (int)min(*(volatile uint32_t *)counter, (uint32_t)nn::kRaw); }
+  __device__ __forceinline__ int count_now() const { return (int)min(atomicAdd(counter, 0u), (uint32_t)nn::kRaw); }
   // (plain LDS accesses: what one lane of a team put is read by the others behind count()'s fence, or as count_now() says)
   __device__ __forceinline__ void put(int k, uint32_t v) { raw[k] = v; }
   __device__ __forceinline__ uint32_t get(int k) const { return raw[k]; }
   __device__ __forceinline__ int count() const {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the quad's lanes have left their loops: same wave, program order)
-    return (int)*(volatile uint32_t *)counter;
+    return (int)atomicAdd(counter, 0u);
   }
 };
 
