@@ -210,6 +210,10 @@ __global__ __launch_bounds__(256) void k_fuse(Geom g, ProbParams pp, int global_
   __shared__ uint32_t s_app[18];
   __shared__ uint32_t s_obs;
   if (n < 0) n = (int64_t)counters[C_TOUCHED];  // the host only knows an upper bound (it sized the grid with it)
+  // work-groups beyond the list leave at once and take no ticket (a depth frame's upper bound is millions of voxels, its list
+  // tens of thousands: 8192 idle groups queueing for the ticket cost 0.16 ms)
+  const unsigned long long nwork = (unsigned long long)max((int64_t)1, min((int64_t)gridDim.x, (n + blockDim.x - 1) / blockDim.x));
+  if (blockIdx.x >= nwork) return;
   if (threadIdx.x == 0) s_obs = 0;
   long long nocc = 0;  // (thread 0's: inserts - deletes of the group)
   // whole work-groups stride over the list (the appends below need every thread of the group in the same iteration)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256) void k_fuse(Geom g, ProbParams pp, int global_
     if (nocc) atomicAdd(&counters[C_NOCC], (unsigned long long)nocc);
     if (result) {
       __threadfence();
-      if (atomicAdd(&counters[C_FUSE_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull) {  // everybody else is done
+      if (atomicAdd(&counters[C_FUSE_TICKET], 1ull) == nwork - 1ull) {  // everybody else is done
         __threadfence();
         for (int k = 0; k < 4; ++k) result[k] = atomicAdd(&counters[C_INSERT + k], 0ull);
         counters[C_TOUCHED] = 0;
