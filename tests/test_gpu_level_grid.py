@@ -147,3 +147,63 @@ def test_auto_asks_the_level_engine_only_where_the_order_matters(hip_lib, oracle
     rep = compare_dense(b.gpu, b.cpu)
     assert_envelope(rep, "sensor-sized delta, auto")
     assert rep["pair_violations"] == 0, rep
+
+
+def test_filled_orphans_keep_the_tracked_distance_bound(hip_lib):
+    """A map that has seen a ray-cast frame tracks the largest stored d^2, and the delete scan of its later updates only
+    looks that far.  The level engine's orphan fill (k_level_fill: an orphan takes the obstacle of its first valid
+    neighbour) can store a d^2 above everything stored before without that orphan ever improving -- the bound must follow,
+    or the NEXT delete misses the voxel and leaves it pointing at a dead obstacle.  Fully observed map, whole-map window,
+    level engine pinned: after every update the field must be the exact transform of what is occupied.  (A guard for the
+    scenario, not a reproducer: with the fill's own bookkeeping switched off this scene still passes -- the levels that
+    follow the fill raise the bound on their way.)"""
+    import fiesta_amd
+    from scipy import ndimage
+    n, res = 64, 0.1
+    m = fiesta_amd.ESDFMap((0, 0, 0), res, (n * res,) * 3, update_engine="auto")
+    m.SetParameters(*P_DEFAULT)
+    m.SetOriginalRange()
+    m.SetOccupancyBox((0, 0, 0), (n - 1,) * 3, 0)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    T = np.eye(4)
+    T[:3, 3] = (0.45, 0.45, 0.45)   # (a short ray in a corner, far from the scene below)
+    m.RaycastFrame(np.array([[0.3, 0.0, 0.0]], np.float32), T, (0.45, 0.45, 0.45), 0.05, 5.0, (-100.0,) * 3, (100.0,) * 3)
+    m.UpdateOccupancy(True)
+    m.UpdateESDF()   # (distance tracking is on from here)
+    # a lattice of obstacles (spacing 8) with a void of radius 18 around the centre that holds two obstacles A and B, 20 apart:
+    # the largest stored d^2 is 194.  Deleting A orphans its 3827 voxels; the fill hands most of them B's id directly, up to
+    # d^2 = 242, and they never improve.  Deleting B next: 31 of its dependents lie beyond a scan bounded by the OLD maximum
+    # ((ceil(sqrt(194)) + 1)^2 = 225).  (numbers from scipy's transform of the same scene)
+    L = np.array([(4 + 8 * i, 4 + 8 * j, 4 + 8 * k) for i in range(8) for j in range(8) for k in range(8)], np.int32)
+    L = L[((L - 32) ** 2).sum(1) > 18 * 18]
+    A, B = np.array([[22, 32, 32]], np.int32), np.array([[42, 32, 32]], np.int32)
+    S = np.concatenate([L, A, B])
+    for _ in range(3):
+        m.SetOccupancy(S, 1, want_ret=False)
+        m.UpdateOccupancy(True)
+    m.UpdateESDF()
+    m.set_update_engine("levels")
+    gx, gy, gz = np.meshgrid(*[np.arange(n)] * 3, indexing="ij")
+
+    def exact():
+        f = m.download_field(("d2", "coc", "occ"))
+        occ = f["occ"].reshape(n, n, n)
+        idx = ndimage.distance_transform_edt(occ == 0, return_distances=False, return_indices=True)
+        want = (idx[0] - gx) ** 2 + (idx[1] - gy) ** 2 + (idx[2] - gz) ** 2
+        d2 = f["d2"].reshape(n, n, n).astype(np.int64)
+        c = f["coc"].reshape(n, n, n, 3).astype(np.int64)
+        assert np.all(occ[c[..., 0], c[..., 1], c[..., 2]] == 1), "a voxel points at a dead obstacle"
+        assert int((d2 != want).sum()) == 0, f"{int((d2 != want).sum())} voxels differ from the exact transform"
+        return int(d2.max())
+
+    assert exact() == 194
+    for gone, dmax in ((A, 242), (B, None)):
+        for _ in range(6):
+            m.SetOccupancy(gone, 0, want_ret=False)
+            m.UpdateOccupancy(True)
+        st = m.UpdateESDF()
+        assert st["deleted"] == 1 and st["levels"] == 1, st
+        got = exact()
+        assert dmax is None or got >= dmax
+    m.close()
