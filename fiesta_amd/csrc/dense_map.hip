@@ -1481,13 +1481,14 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 }
 
 // ---- the cell transform (nn_core.hpp / nn_kernels.hpp): the same fixed point for a sparse obstacle set ----------------------
-// Applies to one unsharded map with plain ids (at most 1024 voxels per axis, region = the whole array).  Whether it is
+// Applies to maps with plain ids (no global extent beyond 1024 voxels) whose region -- the array, a shard's array plus
+// margin -- has at most 1024 voxels per axis.  Whether it is
 // worth trying: the obstacle density must be in the range where every cell finds an obstacle within its search window and
 // lists stay short (measured on scatter scenes, tests/test_nn_model.py: 1.2e-4 ... 2.5e-3 of the voxels; config 2's scene is
 // 3.7e-4), it must not have failed at about this obstacle count, and it must not have been slower than the envelope passes.
 bool DenseMap::cells_wanted() {
   const Geom &g = g_;
-  if (update_engine_ == 4 || g.sharded || g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024) return false;
+  if (update_engine_ == 4 || g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024) return false;
   if (update_engine_ == 5) return true;
   const long long nocc = (long long)h_counters_[C_NOCC];
   if (nocc * 8192 < g.n || nocc * 400 > g.n) return false;
@@ -1502,23 +1503,50 @@ bool DenseMap::cells_wanted() {
   return true;
 }
 
-bool DenseMap::run_cells(fiesta_hip_stats *st) {
+// The cell transform of this map's array.  Unsharded: the region is the array, the bitmap the map's own.  Sharded: the
+// region is the array grown by `margin` (+ what a search window adds to a distance: a cell's window reaches
+// |competitor - centre| + 14 voxels) towards the neighbour shards, cut out of the replica of the GLOBAL bitmap
+// (nn_core.hpp: region_geom) -- no communication, like run_bulk.  Exactness is decided cell by cell on the device: a cell
+// whose window touches an open face of the region fails, and a failed cell fails the transform (the caller reads
+// C_NN_FAILED and takes the envelope passes).  Returns false (nothing launched) if the transform does not apply to this map.
+bool DenseMap::run_cells(fiesta_hip_stats *st, int margin) {
   const Geom &g = g_;
-  if (g.sharded || g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024 || (g.gx0 | g.gy0 | g.gz0) != 0) return false;
+  if (g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024) return false;
   NnArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = nn::Geom{g.nx, g.ny, g.nz, (g.nx + nn::kB - 1) / nn::kB, (g.ny + nn::kB - 1) / nn::kB, (g.nz + nn::kB - 1) / nn::kB};
+  int rlo[3] = {0, 0, 0};
+  bool open_side = false;
+  if (g.sharded) {
+    const int G[3] = {g.GX, g.GY, g.GZ}, l0[3] = {g.gx0, g.gy0, g.gz0}, ln[3] = {g.nx, g.ny, g.nz};
+    const int mc = (margin + 24 + nn::kB - 1) / nn::kB * nn::kB;
+    if (!nn::region_geom(G, l0, ln, mc, a.g, rlo)) return false;
+    open_side = a.g.open != 0;
+    a.occ = gocc_, a.sx0 = rlo[0], a.sy0 = rlo[1], a.szb = rlo[2] / 8, a.sny = g.GY, a.snzw = g.GZW;
+  } else {
+    if ((g.gx0 | g.gy0 | g.gz0) != 0) return false;
+    a.g = nn::whole_geom(g.nx, g.ny, g.nz);
+    a.occ = occbits_, a.sny = g.ny, a.snzw = g.nzw;
+  }
   const int64_t nrows = (int64_t)a.g.ncx * a.g.ncy, ncells = nrows * a.g.ncz;
-  const size_t sites_cap = (size_t)std::max<long long>((long long)h_counters_[C_NOCC], 0) + 64;  // (k_fuse keeps the count exact)
+  // sites: the obstacles of the region -- an unsharded map knows the count (k_fuse keeps it exact); a shard's region also
+  // holds obstacles of its neighbours: room for the region's share of a scene at the densest the transform is tried at,
+  // and k_nn_cells fails the transform if that does not suffice
+  const size_t sites_cap = g.sharded ? (size_t)std::max<long long>(4 * (long long)h_counters_[C_NOCC] + 4096,
+                                                                   (long long)a.g.nx * a.g.ny * a.g.nz / 256)
+                                     : (size_t)std::max<long long>((long long)h_counters_[C_NOCC], 0) + 64;
   nn_ctab_.ensure_exact((size_t)nrows * (a.g.ncz + 1), stream_);
   nn_sites_.ensure(sites_cap, stream_);
   nn_lists_.ensure_exact((size_t)ncells * nn::kStride + kListPad, stream_);
-  a.occ = occbits_, a.nzw = g.nzw;
   a.ctab = nn_ctab_.p, a.sites = nn_sites_.p, a.sites_cap = (uint32_t)std::min<size_t>(nn_sites_.cap, 0xFFFFFFFFu);
   a.lists = nn_lists_.p;
   a.cursor = &counters_[C_NN_CURSOR], a.failed = &counters_[C_NN_FAILED], a.entries = &counters_[C_NN_ENTRIES];
-  a.maxd2 = track_ ? &counters_[C_FT_MAXD2] : nullptr;
-  a.coc = coc_;
+  // (the largest distance written: maps that track it, and shards -- the group sizes the next margin from it)
+  const bool want_max = track_ || open_side;
+  a.maxd2 = want_max ? &counters_[C_FT_MAXD2] : nullptr;
+  // a shard's transform lands in a side buffer unless nobody else has a say (run_bulk)
+  ft_in_place_ = !g.sharded || (!open_side && alone_in_group_);
+  if (!ft_in_place_) ft_out_.ensure((size_t)g.n, stream_);
+  a.coc = ft_in_place_ ? coc_ : ft_out_.p;
   if (!ft_counters_clean_)
     FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
   ft_counters_clean_ = false;
@@ -1526,20 +1554,23 @@ bool DenseMap::run_cells(fiesta_hip_stats *st) {
   hipLaunchKernelGGL(k_nn_cells, dim3((unsigned)((nrows + 15) / 16)), dim3(1024), 0, stream_, a);
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[1], stream_));
-  hipLaunchKernelGGL(k_nn_lists, dim3((a.g.ncz + 63) / 64, (a.g.ncy + 3) / 4, a.g.ncx), dim3(1024), 0, stream_, a);
+  const int lcx = a.g.lx1 - a.g.lx0, lcy = a.g.ly1 - a.g.ly0, lcz = a.g.lz1 - a.g.lz0;  // the cells that get a list
+  hipLaunchKernelGGL(k_nn_lists, dim3((lcz + 63) / 64, (lcy + 3) / 4, lcx), dim3(1024), 0, stream_, a);
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[2], stream_));
+  // the unpredicated variant: the region IS the array, whole cells everywhere and the same number of quads for every wave
+  // (k_nn_fill_full)
   const int64_t nq = nrows * ((a.g.ncz + 3) / 4);
-  unsigned fill_blocks = (unsigned)std::min<int64_t>(nq, kFillBlocks);
-  // the unpredicated variant: whole cells everywhere and the same number of quads for every wave (k_nn_fill_full)
-  bool full = g.nx % nn::kB == 0 && g.ny % nn::kB == 0 && g.nz % (4 * nn::kB) == 0;
+  unsigned fill_blocks = 0;
+  bool full = (a.g.fx | a.g.fy | a.g.fz) == 0 && a.g.nx == g.nx && a.g.ny == g.ny && a.g.nz == g.nz && g.nx % nn::kB == 0 &&
+              g.ny % nn::kB == 0 && g.nz % (4 * nn::kB) == 0;
   if (full) {
     unsigned b = (unsigned)std::min<int64_t>(nq / 4, kFillBlocks);
     while (b >= 64 && nq % (4 * (int64_t)b) != 0) --b;
     if (b >= 64) fill_blocks = b; else full = false;
   }
-  const dim3 cell_grid((a.g.ncz + 3) / 4, a.g.ncy, a.g.ncx);
-  if (track_) {
+  const dim3 cell_grid((lcz + 3) / 4, lcy, lcx);
+  if (want_max) {
     if (full) hipLaunchKernelGGL((k_nn_fill_full<true>), dim3(fill_blocks), dim3(256), 0, stream_, a);
     else hipLaunchKernelGGL((k_nn_fill<true>), cell_grid, dim3(256), 0, stream_, a);
   } else {
@@ -1652,13 +1683,36 @@ bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
   reset_stats_counters();
   if (st) memset(st, 0, sizeof(*st));
+  // a sparse obstacle set: the cell transform first, as on an unsharded map (update_esdf).  Its cells decide exactness
+  // themselves -- a search window that touches an open face of the region fails its cell -- so a transform without a failed
+  // cell is exact whatever the margin; one with failed cells wrote nothing and the envelope passes serve this try.
+  tried_cells_ = false;
+  if (cells_wanted() && run_cells(st, margin)) {
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_FT_OVF0], &counters_[C_FT_OVF0], 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));  // (C_NN_CURSOR ... C_NN_ENTRIES and C_FT_MAXD2 lie in this block)
+    if (h_counters_[C_NN_FAILED] == 0) {
+      nn_fail_streak_ = 0;
+      tried_cells_ = true;
+      if (exact) *exact = true;
+      if (st) st->ft_max_d2 = (int64_t)h_counters_[C_FT_MAXD2];
+      return true;
+    }
+    nn_fail_streak_ = std::min(nn_fail_streak_ + 1, 6);
+    nn_skip_ = 4 << nn_fail_streak_;
+    const int64_t failed = (int64_t)h_counters_[C_NN_FAILED];
+    reset_stats_counters();
+    if (st) {
+      memset(st, 0, sizeof(*st));
+      st->nn_failed = failed;
+    }
+  }
   return run_bulk(st, margin, exact);
 }
 void DenseMap::bulk_commit(fiesta_hip_stats *st) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   if (!ft_in_place_) FIESTA_HIP_CHECK(hipMemcpyAsync(coc_, ft_out_.p, (size_t)g_.n * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
-  bulk_finish(st, std::chrono::steady_clock::now());
+  bulk_finish(st, std::chrono::steady_clock::now(), tried_cells_);
 }
 void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long long *nocc, bool *eligible) {
   use_device();
@@ -1837,7 +1891,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
     counters_reset = true;
     // a sparse obstacle set: the cell transform first (nn_kernels.hpp).  A cell without a list fails it -- k_nn_fill then
     // wrote nothing -- and the envelope passes below serve the update; the obstacle count is remembered and not retried.
-    if (cells_wanted() && run_cells(st)) {
+    if (cells_wanted() && run_cells(st, 0)) {
       bulk_finish(st, h0, /*cells=*/true);
       if (h_counters_[C_NN_FAILED] == 0) {
         nn_fail_streak_ = 0;

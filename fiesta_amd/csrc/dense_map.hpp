@@ -206,7 +206,7 @@ class DenseMap {
   bool bulk_eligible(unsigned long long ni, unsigned long long nd);
   bool run_bulk(fiesta_hip_stats *st, int margin, bool *exact);
   bool cells_wanted();                  // should this update try the cell transform (nn_kernels.hpp) before the envelope passes?
-  bool run_cells(fiesta_hip_stats *st);  // false: not applicable to this map (nothing launched)
+  bool run_cells(fiesta_hip_stats *st, int margin);  // false: not applicable to this map (nothing launched)
   void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells = false);
   void reset_stats_counters(bool lists = false, bool queues = false);
   void enable_distance_tracking();
@@ -258,6 +258,7 @@ class DenseMap {
   DevBuf<uint32_t> nn_ctab_, nn_sites_, nn_lists_;
   double nn_last_ms_ = 0;        // kernel time of the last cell transform that succeeded ...
   long long nn_last_nocc_ = -1;  // ... and the obstacle count it ran on
+  bool tried_cells_ = false;     // bulk_try: the transform waiting for bulk_commit is the cell transform's
   int nn_fail_streak_ = 0, nn_skip_ = 0;  // failed attempts in a row; eligible updates still to be left to the envelope passes
   DevBuf<unsigned long long> ft_spill_;  // backing store of the transform's rings (run_bulk)
   DevBuf<uint16_t> ft_rowlist_;

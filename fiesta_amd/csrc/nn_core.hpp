@@ -59,10 +59,63 @@ constexpr int kThin = 16;           // lists longer than this are thinned pairwi
 constexpr uint32_t kPadK = 0xFFFFFFFFu;  // K of a padding entry (b = m = 0): never the minimum
 constexpr int kNone = 0x7FFFFFFF;
 
+// The REGION the transform works on: the occupancy bits it reads, in its own coordinates (sites, cells).  An unsharded map:
+// the array itself.  A shard: its array grown by a margin towards the neighbour shards, cut out of the replica of the global
+// bitmap on global multiples of 8 -- the array then lies somewhere inside the region (f*: the region coordinates of its
+// voxel (0, 0, 0); a*: its extents), only the cells that hold a voxel of it get a list (l*), and a face of the region
+// beyond which the global grid goes on is OPEN: a cell whose search window touches it cannot be served.
 struct Geom {
-  int nx, ny, nz;     // voxels
+  int nx, ny, nz;     // voxels of the region
   int ncx, ncy, ncz;  // cells = ceil(n / 8)
+  int wx, wy, wz;     // region -> the coordinates a voxel word stores (the region's origin in the global grid)
+  int open;           // open faces: 1 x-lo, 2 x-hi, 4 y-lo, 8 y-hi, 16 z-lo, 32 z-hi
+  int lx0, lx1, ly0, ly1, lz0, lz1;  // cells that get a list (half-open ranges)
+  int fx, fy, fz;     // region coordinates of the array's voxel (0, 0, 0)
+  int ax, ay, az;     // the array's extents
 };
+// a region that IS the array
+FIESTA_NN_HD inline Geom whole_geom(int nx, int ny, int nz) {
+  Geom g{};
+  g.nx = nx, g.ny = ny, g.nz = nz;
+  g.ncx = (nx + kB - 1) / kB, g.ncy = (ny + kB - 1) / kB, g.ncz = (nz + kB - 1) / kB;
+  g.lx1 = g.ncx, g.ly1 = g.ncy, g.lz1 = g.ncz;
+  g.ax = nx, g.ay = ny, g.az = nz;
+  return g;
+}
+// The region of an array at l0[] (extents ln[]) of a global grid G[], grown by mc voxels towards the rest of the grid: cut
+// on global multiples of 8, clipped to the grid; a face that does not reach the grid's is open.  rlo[]: its origin in the
+// grid.  false: more than 1024 voxels along an axis (a site's coordinate has ten bits).
+FIESTA_NN_HD inline bool region_geom(const int *G, const int *l0, const int *ln, int mc, Geom &g, int *rlo) {
+  int n[3], f[3], c0[3], c1[3], open = 0;
+  for (int k = 0; k < 3; ++k) {
+    int lo = l0[k] - mc;
+    lo = (lo < 0 ? 0 : lo) & ~(kB - 1);
+    int hi = (l0[k] + ln[k] + mc + kB - 1) & ~(kB - 1);  // (exclusive)
+    if (hi > G[k]) hi = G[k];
+    rlo[k] = lo, n[k] = hi - lo, f[k] = l0[k] - lo;
+    if (lo > 0) open |= 1 << (2 * k);
+    if (hi < G[k]) open |= 2 << (2 * k);
+    c0[k] = f[k] / kB, c1[k] = (f[k] + ln[k] - 1) / kB + 1;
+    if (n[k] > 1024 || hi > 1024) return false;
+  }
+  g = whole_geom(n[0], n[1], n[2]);
+  g.wx = rlo[0], g.wy = rlo[1], g.wz = rlo[2];
+  g.open = open;
+  g.lx0 = c0[0], g.lx1 = c1[0], g.ly0 = c0[1], g.ly1 = c1[1], g.lz0 = c0[2], g.lz1 = c1[2];
+  g.fx = f[0], g.fy = f[1], g.fz = f[2];
+  g.ax = ln[0], g.ay = ln[1], g.az = ln[2];
+  return true;
+}
+// what build_list needs of it
+struct Frame {
+  int wx = 0, wy = 0, wz = 0, open = 0, ncx = 0, ncy = 0, ncz = 0;
+};
+FIESTA_NN_HD inline Frame frame_of(const Geom &g) { return Frame{g.wx, g.wy, g.wz, g.open, g.ncx, g.ncy, g.ncz}; }
+// does the window of +-K cells around cell (cx, cy, cz) touch an open face?
+FIESTA_NN_HD inline bool leaves_region(const Frame &f, int cx, int cy, int cz, int K) {
+  return ((f.open & 1) && cx - K < 0) || ((f.open & 2) && cx + K >= f.ncx) || ((f.open & 4) && cy - K < 0) ||
+         ((f.open & 8) && cy + K >= f.ncy) || ((f.open & 16) && cz - K < 0) || ((f.open & 32) && cz + K >= f.ncz);
+}
 
 // entry of a kept site (offsets p from the cell origin, each within [-8 kKmax, 8 kKmax + 7]), 16 bytes:
 //   b  bytes (-2 py, -2 pz, 0, 0): what v_dot4_i32_i8 multiplies with the lane's (y, z, 0, 0)
@@ -211,10 +264,11 @@ FIESTA_NN_HD inline int window_reach(int te2, uint32_t tw, int cx, int cy, int c
 // site within the search window's reach, a competitor so far away that the window would exceed kKmax cells, more than
 // kCap survivors; -1 (nothing written) when the window would leave what this source can serve (Src::reach cells): the
 // caller asks again with a source that reaches farther.  (Every lane of a team returns the same value; lane 0 writes the
-// count.)  have: the competitor (te2_in, tw_in) was found already (first_competitor with kKfirst).
+// count.)  have: the competitor (te2_in, tw_in) was found already (first_competitor with kKfirst).  fr: a shard's region
+// (open faces fail the cells whose window touches them; the entries' words are in global coordinates).
 template <class Src, class Team>
 FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, int cz, uint32_t *out, bool have = false, int te2_in = kNone,
-                                   uint32_t tw_in = 0xFFFFFFFFu) {
+                                   uint32_t tw_in = 0xFFFFFFFFu, const Frame fr = Frame{}) {
   constexpr int kmax = Src::reach < kKmax ? Src::reach : kKmax;
   const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
   int raw = 0;
@@ -245,6 +299,14 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
         continue;
       }
       if (kmax < kKmax) return -1;
+      raw = 0;
+      break;
+    }
+    if (fr.open && leaves_region(fr, cx, cy, cz, Kw)) {  // a shard: obstacles beyond the region could win in this cell
+      if (kfirst < 2) {
+        raw = kRaw + 1;
+        continue;
+      }
       raw = 0;
       break;
     }
@@ -311,7 +373,7 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
       if (i < kCap) {
         uint32_t *e = out + 4 + 4 * i;
         e[0] = entry_b(py, pz), e[1] = entry_k(px, py, pz, i), e[2] = entry_m(px);
-        e[3] = ((uint32_t)(px + ox) << 20) | ((uint32_t)(py + oy) << 10) | (uint32_t)(pz + oz);
+        e[3] = ((uint32_t)(px + ox + fr.wx) << 20) | ((uint32_t)(py + oy + fr.wy) << 10) | (uint32_t)(pz + oz + fr.wz);
       }
     }
     n = team.count();

@@ -27,8 +27,9 @@ namespace fiesta {
 
 struct NnArgs {
   nn::Geom g;
-  const uint32_t *occ;  // occupancy bitmap: row (x, y) at ((x * ny) + y) * nzw words, bit z
-  int nzw;
+  const uint32_t *occ;  // the occupancy bitmap the region is cut out of: row (X, Y) at (X * sny + Y) * snzw words, bit Z;
+  int sx0, sy0, szb;    // region voxel (x, y, z) is bit z % 8 of byte szb + z / 8 of row (sx0 + x, sy0 + y)
+  int sny, snzw;        // (an unsharded map: its own bitmap, offsets 0; a shard: its replica of the global one)
   uint32_t *ctab;       // [ncx * ncy][ncz + 1]: first site of the cell; entry ncz: end of the row
   uint32_t *sites;      // packed x << 20 | y << 10 | z
   uint32_t sites_cap;
@@ -57,15 +58,21 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
   for (int k = 0; k < 2; ++k) {
     const int c = lane + 64 * k;
     const bool has = rlive && k < nchunk && c < g.ncz;
+    // (the bits of a row's last byte beyond the region: beyond the grid they are zero anyway, inside a shard's replica they
+    //  belong to voxels the region does not hold)
+    const uint32_t zmask = (nn::kB * c + nn::kB <= g.nz) ? 0xFFu : (0xFFu >> (nn::kB * c + nn::kB - g.nz));
 #pragma unroll
     for (int q = 0; q < 16; ++q) pk[k][q] = 0;
     if (k < nchunk) {
+      // the row of the cell row's voxel (0, 0); row r lies (r / 8) x-strides and (r % 8) y-strides farther
+      const int64_t ystride = (int64_t)a.snzw * 4, xstride = ystride * a.sny;
+      const uint8_t *row0 = reinterpret_cast<const uint8_t *>(a.occ) + (int64_t)(a.sx0 + nn::kB * cx) * xstride +
+                            (int64_t)(a.sy0 + nn::kB * cy) * ystride + a.szb + (has ? c : 0);
+      const int xin = g.nx - nn::kB * cx, yin = g.ny - nn::kB * cy;  // rows of the cell row inside the region (wave-uniform)
 #pragma unroll
       for (int r = 0; r < 64; ++r) {
-        const int x = nn::kB * cx + (r >> 3), y = nn::kB * cy + (r & 7);
-        const bool in = x < g.nx && y < g.ny;  // (wave-uniform)
-        const uint8_t *bytes = reinterpret_cast<const uint8_t *>(a.occ + ((int64_t)(in ? x : 0) * g.ny + (in ? y : 0)) * a.nzw);
-        const uint32_t m = (in && has) ? (uint32_t)bytes[has ? c : 0] : 0u;
+        const bool in = (r >> 3) < xin && (r & 7) < yin;
+        const uint32_t m = (in && has) ? ((uint32_t)row0[in ? (r >> 3) * xstride + (r & 7) * ystride : 0] & zmask) : 0u;
         pk[k][r >> 2] |= m << (8 * (r & 3));
       }
 #pragma unroll
@@ -214,8 +221,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   __shared__ uint8_t s_key[256];
   const nn::Geom &g = a.g;
   const int tid = (int)threadIdx.x;
-  const int cz0 = (int)blockIdx.x * 64, cy0 = (int)blockIdx.y * 4, cx = (int)blockIdx.z;
+  const int cz0 = g.lz0 + (int)blockIdx.x * 64, cy0 = g.ly0 + (int)blockIdx.y * 4, cx = g.lx0 + (int)blockIdx.z;  // (the cells that get a list)
   const int X0 = cx - kStageK, Y0 = cy0 - kStageK, Zf = cz0 - kStageK;
+  const nn::Frame fr = nn::frame_of(g);
   const int64_t rowlen = g.ncz + 1;
   if (tid < 256) s_slots[tid] = 0;
   if (tid == 0) s_bad = 0, s_sum = 0, s_done = 0;
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   const StagedSrc ssrc{staged ? s_tab : nullptr, s_soff, s_sites, -(X0 * kStageNY + Y0), -Zf};
   {
     const int cz = cz0 + (team_i & 63), cy = cy0 + (team_i >> 6);
-    const bool live = cz < g.ncz && cy < g.ncy;
+    const bool live = cz < g.lz1 && cy < g.ly1;
     int te2 = nn::kNone, key = 7;  // (7: not a cell of the map)
     uint32_t tw = 0xFFFFFFFFu;
     if (live) {
@@ -297,15 +305,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   const int ci = s_order[team_i];
   const int cz = cz0 + (ci & 63), cy = cy0 + (ci >> 6);
   int n = 0;
-  const bool live = cz < g.ncz && cy < g.ncy;  // (the same for the four lanes of a team)
+  const bool live = cz < g.lz1 && cy < g.ly1;  // (the same for the four lanes of a team)
   if (live) {
     const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
     uint32_t *rec = a.lists + cell * nn::kStride;
     n = -1;
-    if (staged) n = nn::build_list(ssrc, team, cx, cy, cz, rec, true, (int)s_te2[ci], s_tw[ci]);
+    if (staged) n = nn::build_list(ssrc, team, cx, cy, cz, rec, true, (int)s_te2[ci], s_tw[ci], fr);
     if (n < 0) {  // (a team decides together: the window needs more than the staged cells -- or nothing was staged)
       const HybridSrc src{ssrc, nn::PlainSrc{a.ctab, a.sites, g.ncx, g.ncy, g.ncz}, X0, Y0, Zf};
-      n = nn::build_list(src, team, cx, cy, cz, rec);
+      n = nn::build_list(src, team, cx, cy, cz, rec, false, nn::kNone, 0xFFFFFFFFu, fr);
     }
   }
   // statistics: failures and entries, one atomic each per work-group -- by the LAST wave to get here, not behind a barrier
@@ -459,10 +467,10 @@ template <bool TRACK>
 __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
   const nn::Geom &g = a.g;
   if (*a.failed) return;
-  // grid (ceil(ncz / 4), ncy, ncx)
+  // grid: the cells that got a list, (ceil((lz1 - lz0) / 4), ly1 - ly0, lx1 - lx0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int cz = (int)blockIdx.x * 4 + wave, cy = (int)blockIdx.y, cx = (int)blockIdx.z;
-  if (cz >= g.ncz) return;
+  const int cz = g.lz0 + (int)blockIdx.x * 4 + wave, cy = g.ly0 + (int)blockIdx.y, cx = g.lx0 + (int)blockIdx.z;
+  if (cz >= g.lz1) return;
   const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
   const uint32_t *rec = a.lists + cell * nn::kStride;
   nn_cu32 *lp = reinterpret_cast<nn_cu32 *>(reinterpret_cast<uintptr_t>(rec));
@@ -482,15 +490,16 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
       best[x] = min(best[x], k);
     }
   }
-  const int X0 = nn::kB * cx, Y = nn::kB * cy + y, Z = nn::kB * cz + z;
-  const bool inyz = Y < g.ny && Z < g.nz;
-  vox_t *out = a.coc + ((int64_t)X0 * g.ny + Y) * g.nz + Z;
-  const int64_t plane = (int64_t)g.ny * g.nz;
+  // the voxel in the ARRAY's coordinates (a shard's array lies somewhere inside the region)
+  const int X0 = nn::kB * cx - g.fx, Y = nn::kB * cy + y - g.fy, Z = nn::kB * cz + z - g.fz;
+  const bool inyz = (unsigned)Y < (unsigned)g.ay && (unsigned)Z < (unsigned)g.az;
+  vox_t *out = a.coc + ((int64_t)X0 * g.ay + Y) * g.az + Z;
+  const int64_t plane = (int64_t)g.ay * g.az;
   uint32_t dmax = 0;
 #pragma unroll
   for (int x = 0; x < nn::kB; ++x) {
     const uint32_t ww = rec[7 + ((best[x] & 0x1F0u) >> 2)];
-    if (inyz && X0 + x < g.nx) {
+    if (inyz && (unsigned)(X0 + x) < (unsigned)g.ax) {
       out[x * plane] = ww;
       if (TRACK) dmax = max(dmax, (best[x] >> nn::kSH) - (uint32_t)nn::kBias + (uint32_t)(x * x + y * y + z * z));
     }

@@ -433,6 +433,7 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
       }
       if (!ok) break;  // a region outgrew the transform's 1024-voxel limit: the frontier rounds below take over
       if (!exact) continue;
+      size_t cells_shards = 0;  // shards of this process whose transform was the cell transform (nn_kernels.hpp)
       for (size_t i = 0; i < locals_.size(); ++i) {
         locals_[i]->map->bulk_commit(&ss[i]);
         // The transform rewrote owned AND ghost cells on every shard behind the exchange's back: what was "last sent" no
@@ -448,11 +449,17 @@ void ShardGroup::update_esdf(fiesta_hip_stats *st, int32_t *sweeps_out, int64_t 
         total.ft_rows_ms = std::max(total.ft_rows_ms, ss[i].ft_rows_ms);
         total.ft_plane_ms = std::max(total.ft_plane_ms, ss[i].ft_plane_ms);
         total.ft_x_ms = std::max(total.ft_x_ms, ss[i].ft_x_ms);
+        total.nn_cells_ms = std::max(total.nn_cells_ms, ss[i].nn_cells_ms);
+        total.nn_lists_ms = std::max(total.nn_lists_ms, ss[i].nn_lists_ms);
+        total.nn_fill_ms = std::max(total.nn_fill_ms, ss[i].nn_fill_ms);
+        total.nn_entries += ss[i].nn_entries, total.nn_failed += ss[i].nn_failed;
+        cells_shards += ss[i].cells ? 1 : 0;
         for (int k = 0; k < 6; ++k) total.ft_overflow[k] += ss[i].ft_overflow[k];
         total.relax_launches += ss[i].relax_launches;
       }
       total.inserted = ni, total.deleted = nd;
       total.bulk = 1;
+      total.cells = cells_shards == locals_.size() ? 1 : 0;
       total.ft_max_d2 = dmax2;
       // next time start from what this scene needed (+ slack), in steps of 16 voxels
       const int need = (int)std::ceil(std::sqrt((double)dmax2)) + 8;

@@ -17,8 +17,27 @@ extern "C" {
 // occ: [nx][ny][nz] bytes (0 / 1).  out: [nx][ny][nz] words (the packed site; 0x80000000 where the cell had no list).
 // stats: [0] cells without a list (the kernels would hand the update to the envelope passes), [1] list entries in total,
 // [2] longest list, [3] sites.  Returns 0.
+static int run_region(const uint8_t *occG, const int *G, const Geom &g, const int *rlo, uint32_t *out, int64_t *stats);
+
 int nn_model_run(const uint8_t *occ, int nx, int ny, int nz, uint32_t *out, int64_t *stats) {
-  Geom g{nx, ny, nz, (nx + kB - 1) / kB, (ny + kB - 1) / kB, (nz + kB - 1) / kB};
+  const int G[3] = {nx, ny, nz}, zero[3] = {0, 0, 0};
+  return run_region(occ, G, whole_geom(nx, ny, nz), zero, out, stats);
+}
+
+// A SHARD: the array at l0[] (extents ln[]) of the global grid G[], its region grown by mc voxels (nn_core.hpp: region_geom).
+// occ: the GLOBAL occupancy [GX][GY][GZ]; out: the array's words [ln0][ln1][ln2] (global coordinates of the nearest site).
+// Returns 3 if the region does not fit the site packing.
+int nn_model_run_shard(const uint8_t *occ, const int *G, const int *l0, const int *ln, int mc, uint32_t *out, int64_t *stats) {
+  Geom g;
+  int rlo[3];
+  if (!region_geom(G, l0, ln, mc, g, rlo)) return 3;
+  return run_region(occ, G, g, rlo, out, stats);
+}
+}
+
+static int run_region(const uint8_t *occG, const int *G, const Geom &g, const int *rlo, uint32_t *out, int64_t *stats) {
+  const int nx = g.nx, ny = g.ny, nz = g.nz;
+  auto occ_at = [&](int x, int y, int z) { return occG[((int64_t)(x + rlo[0]) * G[1] + (y + rlo[1])) * G[2] + (z + rlo[2])]; };
   const int64_t nrows = (int64_t)g.ncx * g.ncy;
   std::vector<uint32_t> ctab((size_t)nrows * (g.ncz + 1));
   std::vector<uint32_t> sites;
@@ -31,18 +50,18 @@ int nn_model_run(const uint8_t *occ, int nx, int ny, int nz, uint32_t *out, int6
         for (int x = kB * cx; x < kB * cx + kB && x < nx; ++x)
           for (int y = kB * cy; y < kB * cy + kB && y < ny; ++y)
             for (int z = kB * cz; z < kB * cz + kB && z < nz; ++z)
-              if (occ[((int64_t)x * ny + y) * nz + z]) sites.push_back(((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)z);
+              if (occ_at(x, y, z)) sites.push_back(((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)z);
       }
       row[g.ncz] = (uint32_t)sites.size();
     }
   int64_t failed = 0, entries = 0, longest = 0;
   std::vector<uint32_t> list(kStride);
-  for (int cx = 0; cx < g.ncx; ++cx)
-    for (int cy = 0; cy < g.ncy; ++cy)
-      for (int cz = 0; cz < g.ncz; ++cz) {
+  for (int cx = g.lx0; cx < g.lx1; ++cx)
+    for (int cy = g.ly0; cy < g.ly1; ++cy)
+      for (int cz = g.lz0; cz < g.lz1; ++cz) {
         const PlainSrc src{ctab.data(), sites.data(), g.ncx, g.ncy, g.ncz};
         Solo solo;
-        const int n = build_list(src, solo, cx, cy, cz, list.data());
+        const int n = build_list(src, solo, cx, cy, cz, list.data(), false, kNone, 0xFFFFFFFFu, frame_of(g));
         if ((int)list[0] != n) return 2;
         if (n == 0) ++failed;
         entries += n;
@@ -52,8 +71,8 @@ int nn_model_run(const uint8_t *occ, int nx, int ny, int nz, uint32_t *out, int6
         for (int x = 0; x < kB; ++x)
           for (int y = 0; y < kB; ++y)
             for (int z = 0; z < kB; ++z) {
-              const int X = kB * cx + x, Y = kB * cy + y, Z = kB * cz + z;
-              if (X >= nx || Y >= ny || Z >= nz) continue;
+              const int X = kB * cx + x - g.fx, Y = kB * cy + y - g.fy, Z = kB * cz + z - g.fz;  // (the array's coordinates)
+              if ((unsigned)X >= (unsigned)g.ax || (unsigned)Y >= (unsigned)g.ay || (unsigned)Z >= (unsigned)g.az) continue;
               uint32_t best = 0xFFFFFFFFu;
               for (int i = 0; i < npad; ++i) {
                 const uint32_t k = key_of(list[4 + 4 * i], list[5 + 4 * i], list[6 + 4 * i], x, y, z);
@@ -65,13 +84,13 @@ int nn_model_run(const uint8_t *occ, int nx, int ny, int nz, uint32_t *out, int6
                 // the key's distance part is the true squared distance minus |v|^2, biased
                 int sx, sy, sz;
                 unpack_site(w, sx, sy, sz);
-                const int d2 = (sx - X) * (sx - X) + (sy - Y) * (sy - Y) + (sz - Z) * (sz - Z);
+                const int GX = X + g.fx + g.wx, GY = Y + g.fy + g.wy, GZ = Z + g.fz + g.wz;  // (the voxel in the words' coordinates)
+                const int d2 = (sx - GX) * (sx - GX) + (sy - GY) * (sy - GY) + (sz - GZ) * (sz - GZ);
                 if ((int)(best >> kSH) - kBias + x * x + y * y + z * z != d2) return 1;
               }
-              out[((int64_t)X * ny + Y) * nz + Z] = w;
+              out[((int64_t)X * g.ay + Y) * g.az + Z] = w;
             }
       }
   stats[0] = failed, stats[1] = entries, stats[2] = longest, stats[3] = (int64_t)sites.size();
   return 0;
-}
 }

@@ -195,3 +195,39 @@ def test_cell_transform_keeps_the_tracked_distance_bound(hip_lib):
     assert st["bulk"] == 0
     check_exact(m, shape)
     m.close()
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 4, 8])
+def test_cell_transform_on_shards(hip_lib, oracle_libs, best_oracle_kind, n_shards):
+    """One grid cut into shards (multiplexed on the one GPU): every shard runs the cell transform on its own array -- owned
+    box + ghost layers, at odd offsets of the global grid -- reading the replica of the global bitmap, its region grown by the
+    group's margin; no exchange.  Obstacles hug the cuts, so nearest obstacles lie across them.  Same bar as unsharded: the
+    assembled field equals the reference's on every voxel; and the shards did run the cell transform."""
+    from fiesta_amd.sharded import ShardedESDFMap
+    from test_gpu_sharded import compare, drive
+    gs, res = (136, 128, 144), 0.1
+    sm = ShardedESDFMap((0, 0, 0), res, gs, n_shards, native=True, update_engine="cells")
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res), kind=best_oracle_kind)
+    assert cpu.grid_size == gs
+    for m in (sm, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    allv = all_voxels(gs)
+    rng = np.random.RandomState(31)
+    S = (rng.rand(2400, 3) * gs).astype(np.int32)
+    S[:200, 0] = rng.randint(66, 70, 200)   # shard faces at 68 / 64 / 72
+    S[200:400, 1] = rng.randint(62, 66, 200)
+    S[400:600, 2] = rng.randint(70, 74, 200)
+    drive(sm, cpu, [([], allv, 1)])
+    for occ, free, cycles in ((S, [], 3), ((rng.rand(700, 3) * gs).astype(np.int32), S[:1200], 6)):
+        for _ in range(cycles):
+            for v, o in ((occ, 1), (free, 0)):
+                if len(v):
+                    sm.SetOccupancy(v, o)
+                    cpu.SetOccupancyVox(v, o)
+            assert sm.UpdateOccupancy(True) == cpu.UpdateOccupancy(True)
+        sg, sc = sm.UpdateESDF(), cpu.UpdateESDF()
+        assert (sg["inserted"], sg["deleted"]) == (sc["inserted"], sc["deleted"])
+        assert sg["bulk"] == 1 and sg["cells"] == 1 and sg["nn_failed"] == 0, sg
+        compare(sm, cpu, gs)
+    sm.close()

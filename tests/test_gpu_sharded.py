@@ -76,6 +76,8 @@ def test_group_of_one_runs_its_protocol_over_an_rccl_communicator(hip_lib, oracl
     ncclCommInitRank with one rank) uses it -- the per-sweep row all-gather, the transition all-gather, the (empty)
     send/receive group -- instead of the shortcuts of a group on the local transport.  Same fields as the oracle, and the
     communicator itself reports one rank."""
+    import torch  # noqa: F401  (first: the library then finds torch's librccl loaded instead of opening ROCm's own -- a later
+    #                            `import torch` in this process would bring a SECOND copy, and the two abort at exit)
     from fiesta_amd.sharded import ShardedESDFMap
     gs, res = (72, 64, 80), 0.1
     sm = ShardedESDFMap((0, 0, 0), res, gs, 1, native=True, rccl_group_of_one=True, update_engine=engine)

@@ -125,3 +125,66 @@ def test_ties_and_clusters(model):
     out, st = run(model, occ)
     served = out != 0x80000000
     check_exact(occ, out, served)
+
+
+# ---- a shard's region: the array somewhere inside a larger grid, lists from the global bitmap ------------------------------
+def run_shard(lib, occ, l0, ln, mc):
+    lib.nn_model_run_shard.restype = C.c_int
+    lib.nn_model_run_shard.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p]
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    G = np.array(occ.shape, np.int32)
+    l0, ln = np.array(l0, np.int32), np.array(ln, np.int32)
+    out = np.full(tuple(ln), 0xDEADBEEF, np.uint32)
+    stats = np.zeros(4, np.int64)
+    rc = lib.nn_model_run_shard(occ.ctypes.data, G.ctypes.data, l0.ctypes.data, ln.ctypes.data, int(mc), out.ctypes.data, stats.ctypes.data)
+    assert rc == 0, rc
+    return out, dict(failed=int(stats[0]), entries=int(stats[1]), longest=int(stats[2]), sites=int(stats[3]))
+
+
+def check_shard_exact(occ, out, l0, ln):
+    """the array's words against the exact transform of the WHOLE grid's obstacles"""
+    idx = ndimage.distance_transform_edt(occ == 0, return_distances=False, return_indices=True)
+    sl = tuple(slice(a, a + n) for a, n in zip(l0, ln))
+    g = np.meshgrid(*[np.arange(a, a + n) for a, n in zip(l0, ln)], indexing="ij")
+    want = sum((idx[k][sl] - g[k]) ** 2 for k in range(3))
+    assert np.all(out < 0x40000000)
+    c = [(out >> 20).astype(np.int64), ((out >> 10) & 1023).astype(np.int64), (out & 1023).astype(np.int64)]
+    assert np.all(occ[c[0], c[1], c[2]] == 1), "closest site is not occupied"
+    got = sum((c[k] - g[k]) ** 2 for k in range(3))
+    assert int((got != want).sum()) == 0, f"{int((got != want).sum())} voxels differ from the exact transform of the global grid"
+
+
+@pytest.mark.parametrize("l0,ln", [((0, 0, 0), (66, 66, 66)), ((62, 62, 62), (66, 66, 66)), ((62, 0, 30), (66, 64, 50)),
+                                   ((0, 62, 0), (128, 66, 128)), ((29, 35, 41), (37, 30, 51))])
+def test_a_shard_inside_a_larger_grid_is_exact_when_the_margin_suffices(model, l0, ln):
+    """arrays with ghost layers at odd offsets of a 128^3 grid; obstacles on both sides of every face; a margin that holds
+    every search window: no failed cell, and the array equals the transform of the global obstacle set"""
+    occ = scatter((128, 128, 128), 1.2e-3, 17)
+    out, st = run_shard(model, occ, l0, ln, 40)
+    assert st["failed"] == 0, st
+    check_shard_exact(occ, out, l0, ln)
+
+
+def test_a_margin_too_small_fails_cells_instead_of_answering_wrong(model):
+    """with 8 voxels of margin the windows of the cells at the open faces leave the region: they must fail (the shard then
+    takes the envelope passes, which test their own margin) -- and a face that lies on the grid's own boundary is not open"""
+    occ = scatter((128, 128, 128), 1.2e-3, 17)
+    out, st = run_shard(model, occ, (62, 62, 62), (66, 66, 66), 8)
+    assert st["failed"] > 0
+    out, st = run_shard(model, occ, (0, 0, 0), (128, 128, 128), 0)   # the whole grid as ONE shard: nothing is open
+    assert st["failed"] == 0
+    check_shard_exact(occ, out, (0, 0, 0), (128, 128, 128))
+
+
+def test_the_nearest_obstacle_beyond_an_open_face(model):
+    """an empty half: every obstacle of the array's voxels lies across the face, farther than the margin -> cells fail; with
+    the margin grown past them the array is exact"""
+    occ = np.zeros((128, 64, 64), np.uint8)
+    occ[100:, :, :] = scatter((28, 64, 64), 2e-3, 3)
+    l0, ln = (0, 0, 0), (66, 64, 64)
+    out, st = run_shard(model, occ, l0, ln, 16)
+    assert st["failed"] > 0
+    occ[70:, :, :] = scatter((58, 64, 64), 2e-3, 4)
+    out, st = run_shard(model, occ, l0, ln, 48)
+    if st["failed"] == 0:
+        check_shard_exact(occ, out, l0, ln)
