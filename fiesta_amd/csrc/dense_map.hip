@@ -1408,7 +1408,7 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   // -- and only in a group of ONE: with several shards the commit waits for every shard's verdict, and an error on another
   // shard between try and commit (an allocation failing there) must find this shard's field untouched
   ft_in_place_ = !g.sharded || (!open_side && alone_in_group_);
-  if (!ft_in_place_) ft_out_.ensure((size_t)g.n, stream_);
+  if (!ft_in_place_) ft_out_.ensure_exact((size_t)g.n, stream_);
   a.coc = ft_in_place_ ? coc_ : ft_out_.p;
   const bool want_max = track_ || open_side;
   a.maxd2 = want_max ? &counters_[C_FT_MAXD2] : nullptr;
@@ -1545,7 +1545,7 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin) {
   a.maxd2 = want_max ? &counters_[C_FT_MAXD2] : nullptr;
   // a shard's transform lands in a side buffer unless nobody else has a say (run_bulk)
   ft_in_place_ = !g.sharded || (!open_side && alone_in_group_);
-  if (!ft_in_place_) ft_out_.ensure((size_t)g.n, stream_);
+  if (!ft_in_place_) ft_out_.ensure_exact((size_t)g.n, stream_);
   a.coc = ft_in_place_ ? coc_ : ft_out_.p;
   if (!ft_counters_clean_)
     FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
@@ -1711,7 +1711,9 @@ bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
 void DenseMap::bulk_commit(fiesta_hip_stats *st) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
-  if (!ft_in_place_) FIESTA_HIP_CHECK(hipMemcpyAsync(coc_, ft_out_.p, (size_t)g_.n * sizeof(vox_t), hipMemcpyDeviceToDevice, stream_));
+  // the side buffer BECOMES the field (both hold exactly n words; every user of the field takes the pointer at call time,
+  // in stream order behind the transform): a copy would move 4 B per voxel once more
+  if (!ft_in_place_) std::swap(coc_, ft_out_.p);
   bulk_finish(st, std::chrono::steady_clock::now(), tried_cells_);
 }
 void DenseMap::bulk_probe(unsigned long long *ni, unsigned long long *nd, long long *nocc, bool *eligible) {
@@ -2613,7 +2615,7 @@ void DenseMap::bulk_reserve(int margin) {
   ft_rowlist_.ensure((size_t)(ext[0] * ext[1]), stream_);
   ft_rowcnt_.ensure((size_t)ext[0] + 64, stream_);
   ft_spill_.ensure_exact((size_t)std::min<int64_t>((std::max(ext[0], ext[1]) * nzc + 3) / 4, kFtBlocks) * 4 * ((size_t)std::max(ext[0], ext[1]) + 2) * (512u / sizeof(unsigned long long)), stream_);
-  if (open_side) ft_out_.ensure((size_t)g.n, stream_);
+  if (open_side) ft_out_.ensure_exact((size_t)g.n, stream_);
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
