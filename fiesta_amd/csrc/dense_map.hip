@@ -1488,7 +1488,8 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 // 3.7e-4), it must not have failed at about this obstacle count, and it must not have been slower than the envelope passes.
 bool DenseMap::cells_wanted() {
   const Geom &g = g_;
-  if (update_engine_ == 4 || g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024) return false;
+  if (update_engine_ == 4 || g.nx > nn::kRegionMax || g.ny > nn::kRegionMax || g.nz > nn::kRegionMax) return false;
+  if (!g.sharded && (g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024)) return false;
   if (update_engine_ == 5) return true;
   const long long nocc = (long long)h_counters_[C_NOCC];
   if (nocc * 8192 < g.n || nocc * 400 > g.n) return false;
@@ -1511,7 +1512,7 @@ bool DenseMap::cells_wanted() {
 // C_NN_FAILED and takes the envelope passes).  Returns false (nothing launched) if the transform does not apply to this map.
 bool DenseMap::run_cells(fiesta_hip_stats *st, int margin) {
   const Geom &g = g_;
-  if (g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024) return false;
+  if (!g.sharded && (g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024)) return false;
   NnArgs a;
   memset(&a, 0, sizeof(a));
   int rlo[3] = {0, 0, 0};
@@ -1555,7 +1556,8 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin) {
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[1], stream_));
   const int lcx = a.g.lx1 - a.g.lx0, lcy = a.g.ly1 - a.g.ly0, lcz = a.g.lz1 - a.g.lz0;  // the cells that get a list
-  hipLaunchKernelGGL(k_nn_lists, dim3((lcz + 63) / 64, (lcy + 3) / 4, lcx), dim3(1024), 0, stream_, a);
+  if (a.g.big()) hipLaunchKernelGGL(k_nn_lists<true>, dim3((lcz + 63) / 64, (lcy + 3) / 4, lcx), dim3(1024), 0, stream_, a);
+  else hipLaunchKernelGGL(k_nn_lists<false>, dim3((lcz + 63) / 64, (lcy + 3) / 4, lcx), dim3(1024), 0, stream_, a);
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[2], stream_));
   // the unpredicated variant: the region IS the array, whole cells everywhere and the same number of quads for every wave

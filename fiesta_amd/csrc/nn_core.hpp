@@ -72,6 +72,7 @@ struct Geom {
   int lx0, lx1, ly0, ly1, lz0, lz1;  // cells that get a list (half-open ranges)
   int fx, fy, fz;     // region coordinates of the array's voxel (0, 0, 0)
   int ax, ay, az;     // the array's extents
+  FIESTA_NN_HD inline bool big() const { return nx > 1024 || ny > 1024 || nz > 1024; }  // sites modulo 1024 (site_offset)
 };
 // a region that IS the array
 FIESTA_NN_HD inline Geom whole_geom(int nx, int ny, int nz) {
@@ -84,7 +85,9 @@ FIESTA_NN_HD inline Geom whole_geom(int nx, int ny, int nz) {
 }
 // The region of an array at l0[] (extents ln[]) of a global grid G[], grown by mc voxels towards the rest of the grid: cut
 // on global multiples of 8, clipped to the grid; a face that does not reach the grid's is open.  rlo[]: its origin in the
-// grid.  false: more than 1024 voxels along an axis (a site's coordinate has ten bits).
+// grid.  false: more than kRegionMax voxels along an axis.  (A region of more than 1024 voxels stores its sites modulo 1024:
+// Geom::big; the words of its entries are global coordinates modulo 1024 either way.)
+constexpr int kRegionMax = 1536;  // voxels of a region along an axis (sites modulo 1024: k_nn_cells carries 192 cells of a row)
 FIESTA_NN_HD inline bool region_geom(const int *G, const int *l0, const int *ln, int mc, Geom &g, int *rlo) {
   int n[3], f[3], c0[3], c1[3], open = 0;
   for (int k = 0; k < 3; ++k) {
@@ -96,7 +99,7 @@ FIESTA_NN_HD inline bool region_geom(const int *G, const int *l0, const int *ln,
     if (lo > 0) open |= 1 << (2 * k);
     if (hi < G[k]) open |= 2 << (2 * k);
     c0[k] = f[k] / kB, c1[k] = (f[k] + ln[k] - 1) / kB + 1;
-    if (n[k] > 1024 || hi > 1024) return false;
+    if (n[k] > kRegionMax) return false;
   }
   g = whole_geom(n[0], n[1], n[2]);
   g.wx = rlo[0], g.wy = rlo[1], g.wz = rlo[2];
@@ -137,6 +140,16 @@ FIESTA_NN_HD inline uint32_t key_of(uint32_t b, uint32_t K, uint32_t m, int x, i
 FIESTA_NN_HD inline void unpack_site(uint32_t w, int &x, int &y, int &z) {
   x = (int)((w >> 20) & 1023u), y = (int)((w >> 10) & 1023u), z = (int)(w & 1023u);
 }
+// A site's offset from a cell origin (ox, oy, oz).  A region of more than 1024 voxels along an axis (a config-5 shard: 1024
+// owned + ghost layers + margin) stores its sites MODULO 1024 -- a site is only ever looked at from a cell within a search
+// window of it (< 512 voxels), so the offset is the one residue in [-512, 512), exactly as the wrap maps' voxel words are
+// decoded (common.hpp: coc_offset).
+template <bool WRAP>
+FIESTA_NN_HD inline void site_offset(uint32_t w, int ox, int oy, int oz, int &px, int &py, int &pz) {
+  unpack_site(w, px, py, pz);
+  px -= ox, py -= oy, pz -= oz;
+  if (WRAP) px = ((px + 512) & 1023) - 512, py = ((py + 512) & 1023) - 512, pz = ((pz + 512) & 1023) - 512;
+}
 
 // |2 (s - c)|^2 of a site at offset p: the doubled offset from the cell centre is 2 p - 7 per axis
 FIESTA_NN_HD inline int e2_of(int px, int py, int pz) {
@@ -170,7 +183,9 @@ FIESTA_NN_HD inline void unpack_p(uint32_t v, int &px, int &py, int &pz) {
 // packed site behind an index of such a range.  PlainSrc reads the two arrays as they lie in memory (the host model; the
 // kernel's path for the rare cell whose window leaves the staged neighbourhood); k_nn_lists stages its work-group's
 // neighbourhood in LDS and reads that (nn_kernels.hpp: StagedSrc, reach = 3 cells).
-struct PlainSrc {
+template <bool WRAP>
+struct PlainSrcT {
+  static constexpr bool wrap = WRAP;     // sites are stored modulo 1024 (site_offset)
   static constexpr int reach = 1 << 20;  // cells from the asking cell this source can serve
   const uint32_t *ctab, *sites;
   int ncx, ncy, ncz;
@@ -182,6 +197,7 @@ struct PlainSrc {
   }
   FIESTA_NN_HD inline uint32_t site(uint32_t i) const { return sites[i]; }
 };
+typedef PlainSrcT<false> PlainSrc;
 
 // Who builds a list: ONE lane on the host model, a TEAM of four adjacent lanes in k_nn_lists (the rows of the search window
 // dealt out among them: four times the waves in flight for the same work -- the sweeps are chains of dependent reads).
@@ -229,9 +245,9 @@ FIESTA_NN_HD inline void scan_nearest(const Src &src, const Team &team, int cx, 
     src.bounds(cx + rw.dx, cy + rw.dy, cz - K, cz + K, i, i1);
     for (; i < i1; ++i) {
       const uint32_t w = src.site(i);
-      int sx, sy, sz;
-      unpack_site(w, sx, sy, sz);
-      const int e2 = e2_of(sx - ox, sy - oy, sz - oz);
+      int px, py, pz;
+      site_offset<Src::wrap>(w, ox, oy, oz, px, py, pz);
+      const int e2 = e2_of(px, py, pz);
       if (e2 < best_e2 || (e2 == best_e2 && w < best_w)) best_e2 = e2, best_w = w;
     }
   }
@@ -249,11 +265,11 @@ FIESTA_NN_HD inline void first_competitor(const Src &src, Team &team, int cx, in
   }
 }
 // cells the search window of a cell with competitor (te2, tw) reaches (what the sweep costs: k_nn_lists sorts its cells by it)
+template <bool WRAP = false>
 FIESTA_NN_HD inline int window_reach(int te2, uint32_t tw, int cx, int cy, int cz) {
   if (te2 == kNone) return kKmax + 1;
   int qx, qy, qz;
-  unpack_site(tw, qx, qy, qz);
-  qx -= kB * cx, qy -= kB * cy, qz -= kB * cz;
+  site_offset<WRAP>(tw, kB * cx, kB * cy, kB * cz, qx, qy, qz);
   const int fx = qx > 7 - qx ? qx : 7 - qx, fy = qy > 7 - qy ? qy : 7 - qy, fz = qz > 7 - qz ? qz : 7 - qz;
   const int Kc = ((int)(FIESTA_NN_SQRT((float)(FIESTA_NN_MUL(fx, fx) + FIESTA_NN_MUL(fy, fy) + FIESTA_NN_MUL(fz, fz))) + 0.02f) + 7) >> 3;
   const int Kb = reach_of(rad2_of(te2));
@@ -284,15 +300,14 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
       break;
     }
     int qx, qy, qz;
-    unpack_site(tw, qx, qy, qz);
-    qx -= ox, qy -= oy, qz -= oz;
+    site_offset<Src::wrap>(tw, ox, oy, oz, qx, qy, qz);
     const int q2 = FIESTA_NN_MUL(qx, qx) + FIESTA_NN_MUL(qy, qy) + FIESTA_NN_MUL(qz, qz);
     const int rad2 = rad2_of(te2);
     // Two bounds on where a winner can lie, both from the competitor t: the ball (|s - c| <= |t - c| + 2 h), and a cube -- a
     // site s that is nearest to some voxel v of the cell has |s_a - v_a| <= |s - v| <= |t - v| <= M on every axis, M the
     // distance from t to the cell's farthest corner, so p_a lies in [-M, 7 + M]: (M + 7) / 8 cells either way.  The cube is
     // the tighter one along the axes (M <= |t - c| + h), the ball cuts its corners: the window is their intersection.
-    const int Kw = window_reach(te2, tw, cx, cy, cz);
+    const int Kw = window_reach<Src::wrap>(te2, tw, cx, cy, cz);
     if (Kw > kmax) {
       if (kfirst < 2) {  // (a poor competitor widens the window: look for the nearest one before giving up)
         raw = kRaw + 1;
@@ -322,8 +337,7 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
       for (; i < i1; ++i) {
         const uint32_t w = src.site(i);
         int px, py, pz;
-        unpack_site(w, px, py, pz);
-        px -= ox, py -= oy, pz -= oz;
+        site_offset<Src::wrap>(w, ox, oy, oz, px, py, pz);
         bool keep = w == tw || !dominated(px, py, pz, qx, qy, qz, q2);
         if (keep && kfirst >= 2 && w != tw) {
           // the second try also asks the candidates already collected (dominance is transitive: whoever drops s here, or
@@ -373,7 +387,8 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
       if (i < kCap) {
         uint32_t *e = out + 4 + 4 * i;
         e[0] = entry_b(py, pz), e[1] = entry_k(px, py, pz, i), e[2] = entry_m(px);
-        e[3] = ((uint32_t)(px + ox + fr.wx) << 20) | ((uint32_t)(py + oy + fr.wy) << 10) | (uint32_t)(pz + oz + fr.wz);
+        // (the word a voxel stores: global coordinates, modulo 1024 on grids beyond that -- common.hpp: pack_coc)
+        e[3] = (((uint32_t)(px + ox + fr.wx) & 1023u) << 20) | (((uint32_t)(py + oy + fr.wy) & 1023u) << 10) | ((uint32_t)(pz + oz + fr.wz) & 1023u);
       }
     }
     n = team.count();

@@ -44,6 +44,7 @@ struct NnArgs {
 // ---- sites by cell row ---------------------------------------------------------------------------------------------------
 // One batch of loads per wave: the 64 voxel rows of the cell row, a byte per lane and row (two on a 1024-voxel axis), kept
 // in registers for both halves -- counting, and after the wave's range of the site array is known, writing the sites.
+constexpr int kCellChunks = (nn::kRegionMax / nn::kB + 63) / 64;  // 64-cell chunks of the longest row of cells
 __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell rows per work-group, one per wave
   __shared__ uint32_t s_tot[16], s_start[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -51,11 +52,11 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
   const nn::Geom &g = a.g;
   const bool rlive = row < g.ncx * g.ncy;  // (wave-uniform)
   const int cx = rlive ? row / g.ncy : 0, cy = rlive ? row % g.ncy : 0;
-  const int nchunk = (g.ncz + 63) >> 6;  // cells of the row per lane
-  uint32_t pk[2][16];  // pk[k][r / 4] byte r % 4: the 8 z-bits of voxel row r (x = r / 8, y = r % 8) in cell lane + 64 k
-  uint32_t cnt[2] = {0, 0};
+  const int nchunk = (g.ncz + 63) >> 6;  // cells of the row per lane (<= kCellChunks: a region has at most nn::kRegionMax voxels along z)
+  uint32_t pk[kCellChunks][16];  // pk[k][r / 4] byte r % 4: the 8 z-bits of voxel row r (x = r / 8, y = r % 8) in cell lane + 64 k
+  uint32_t cnt[kCellChunks] = {};
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < kCellChunks; ++k) {
     const int c = lane + 64 * k;
     const bool has = rlive && k < nchunk && c < g.ncz;
     // (the bits of a row's last byte beyond the region: beyond the grid they are zero anyway, inside a shard's replica they
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
       for (int q = 0; q < 16; ++q) cnt[k] += (uint32_t)__popc(pk[k][q]);
     }
   }
-  uint32_t first[2];
+  uint32_t first[kCellChunks];
   uint32_t base = 0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < kCellChunks; ++k) {
     uint32_t incl = cnt[k];
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
@@ -108,14 +109,14 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
   const uint32_t start = s_start[wave];
   uint32_t *tab = a.ctab + (int64_t)row * (g.ncz + 1);
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < kCellChunks; ++k) {
     const int c = lane + 64 * k;
     if (k < nchunk && c < g.ncz) tab[c] = start + first[k];
   }
   if (lane == 0) tab[g.ncz] = start + total;
   if (total == 0) return;  // (wave-uniform)
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < kCellChunks; ++k) {
     if (cnt[k] == 0) continue;
     const int c = lane + 64 * k;
     uint32_t at = start + first[k];
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
         m &= m - 1;
         const int r = 4 * q + (bit >> 3);
         if (at < a.sites_cap)
-          a.sites[at] = ((uint32_t)(nn::kB * cx + (r >> 3)) << 20) | ((uint32_t)(nn::kB * cy + (r & 7)) << 10) | (uint32_t)(nn::kB * c + (bit & 7));
+          a.sites[at] = (((uint32_t)(nn::kB * cx + (r >> 3)) & 1023u) << 20) | (((uint32_t)(nn::kB * cy + (r & 7)) & 1023u) << 10) |
+                        ((uint32_t)(nn::kB * c + (bit & 7)) & 1023u);  // (region coordinates; modulo 1024 in a region beyond that)
         ++at;
       }
     }
@@ -141,7 +143,9 @@ constexpr int kStageK = 4;
 constexpr int kStageNX = 1 + 2 * kStageK, kStageNY = 4 + 2 * kStageK, kStageNR = kStageNX * kStageNY;  // 7 x 10 rows of cells
 constexpr int kStageNZ = 64 + 2 * kStageK + 1;                                                          // table entries per row
 constexpr int kStageSites = 3072;
-struct StagedSrc {  // the staged neighbourhood only: no range checks (rows outside the map are staged empty, entries are
+template <bool WRAP>
+struct StagedSrcT {  // the staged neighbourhood only: no range checks (rows outside the map are staged empty, entries are
+  static constexpr bool wrap = WRAP;
   static constexpr int reach = kStageK;  // clamped into their row), no second path -- a window that needs more is served by
   const uint16_t *tab;     // HybridSrc in a second attempt.  [kStageNR][kStageNZ]: entry e of a row = sites of the row before cell Zf + e
   const uint32_t *soff;    // [kStageNR]: LDS index of the row's first staged site
@@ -159,10 +163,12 @@ struct StagedSrc {  // the staged neighbourhood only: no range checks (rows outs
 // The second attempt's source for a cell whose window leaves the staged neighbourhood (its nearest obstacle is more than ~16
 // voxels away: one cell in a thousand on config 2's scene): staged rows from LDS, the others from memory.  (Everything from
 // memory is a chain of ~60 dependent L2 round trips per lane, and one such team holds its whole work-group back.)
-struct HybridSrc {
+template <bool WRAP>
+struct HybridSrcT {
+  static constexpr bool wrap = WRAP;
   static constexpr int reach = 1 << 20;
-  StagedSrc st;
-  nn::PlainSrc plain;
+  StagedSrcT<WRAP> st;
+  nn::PlainSrcT<WRAP> plain;
   int X0, Y0, Zf;
   __device__ __forceinline__ void bounds(int X, int Y, int z0, int z1, uint32_t &i0, uint32_t &i1) const {
     const int rx = X - X0, ry = Y - Y0;
@@ -209,6 +215,8 @@ struct QuadTeam {
   }
 };
 
+// WRAP: a region of more than 1024 voxels along an axis, its sites stored modulo 1024 (nn_core.hpp: site_offset)
+template <bool WRAP>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_nn_lists(NnArgs a) {  // (two work-groups per CU: 64 VGPRs, < 80 KB of LDS)  // 64 (z) x 4 (y) cells, four lanes each
   __shared__ uint16_t s_tab[kStageNR * kStageNZ];
   __shared__ uint32_t s_first[kStageNR], s_soff[kStageNR], s_cnt[kStageNR];
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   // do).  Sorted, thirteen waves of sixteen take the short walk.
   const int team_i = tid >> 2;
   QuadTeam team{tid & 3, &s_slots[team_i], &s_raw[team_i * (nn::kRaw + 1)]};
-  const StagedSrc ssrc{staged ? s_tab : nullptr, s_soff, s_sites, -(X0 * kStageNY + Y0), -Zf};
+  const StagedSrcT<WRAP> ssrc{staged ? s_tab : nullptr, s_soff, s_sites, -(X0 * kStageNY + Y0), -Zf};
   {
     const int cz = cz0 + (team_i & 63), cy = cy0 + (team_i >> 6);
     const bool live = cz < g.lz1 && cy < g.ly1;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     uint32_t tw = 0xFFFFFFFFu;
     if (live) {
       if (staged) nn::first_competitor(ssrc, team, cx, cy, cz, nn::kKfirst, te2, tw);
-      key = min(nn::window_reach(te2, tw, cx, cy, cz), 6);
+      key = min(nn::window_reach<WRAP>(te2, tw, cx, cy, cz), 6);
     }
     if (team.rank == 0) {
       s_te2[team_i] = (uint32_t)te2, s_tw[team_i] = tw, s_key[team_i] = (uint8_t)key;
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     n = -1;
     if (staged) n = nn::build_list(ssrc, team, cx, cy, cz, rec, true, (int)s_te2[ci], s_tw[ci], fr);
     if (n < 0) {  // (a team decides together: the window needs more than the staged cells -- or nothing was staged)
-      const HybridSrc src{ssrc, nn::PlainSrc{a.ctab, a.sites, g.ncx, g.ncy, g.ncz}, X0, Y0, Zf};
+      const HybridSrcT<WRAP> src{ssrc, nn::PlainSrcT<WRAP>{a.ctab, a.sites, g.ncx, g.ncy, g.ncz}, X0, Y0, Zf};
       n = nn::build_list(src, team, cx, cy, cz, rec, false, nn::kNone, 0xFFFFFFFFu, fr);
     }
   }

@@ -50,7 +50,7 @@ static int run_region(const uint8_t *occG, const int *G, const Geom &g, const in
         for (int x = kB * cx; x < kB * cx + kB && x < nx; ++x)
           for (int y = kB * cy; y < kB * cy + kB && y < ny; ++y)
             for (int z = kB * cz; z < kB * cz + kB && z < nz; ++z)
-              if (occ_at(x, y, z)) sites.push_back(((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)z);
+              if (occ_at(x, y, z)) sites.push_back((((uint32_t)x & 1023u) << 20) | (((uint32_t)y & 1023u) << 10) | ((uint32_t)z & 1023u));
       }
       row[g.ncz] = (uint32_t)sites.size();
     }
@@ -59,9 +59,15 @@ static int run_region(const uint8_t *occG, const int *G, const Geom &g, const in
   for (int cx = g.lx0; cx < g.lx1; ++cx)
     for (int cy = g.ly0; cy < g.ly1; ++cy)
       for (int cz = g.lz0; cz < g.lz1; ++cz) {
-        const PlainSrc src{ctab.data(), sites.data(), g.ncx, g.ncy, g.ncz};
         Solo solo;
-        const int n = build_list(src, solo, cx, cy, cz, list.data(), false, kNone, 0xFFFFFFFFu, frame_of(g));
+        int n;
+        if (g.big()) {  // (sites modulo 1024: the kernel's WRAP instance)
+          const PlainSrcT<true> src{ctab.data(), sites.data(), g.ncx, g.ncy, g.ncz};
+          n = build_list(src, solo, cx, cy, cz, list.data(), false, kNone, 0xFFFFFFFFu, frame_of(g));
+        } else {
+          const PlainSrc src{ctab.data(), sites.data(), g.ncx, g.ncy, g.ncz};
+          n = build_list(src, solo, cx, cy, cz, list.data(), false, kNone, 0xFFFFFFFFu, frame_of(g));
+        }
         if ((int)list[0] != n) return 2;
         if (n == 0) ++failed;
         entries += n;
@@ -82,10 +88,10 @@ static int run_region(const uint8_t *occG, const int *G, const Geom &g, const in
               if (n) {
                 w = list[4 + ((best & 0x1F0u) >> 2) + 3];
                 // the key's distance part is the true squared distance minus |v|^2, biased
-                int sx, sy, sz;
-                unpack_site(w, sx, sy, sz);
                 const int GX = X + g.fx + g.wx, GY = Y + g.fy + g.wy, GZ = Z + g.fz + g.wz;  // (the voxel in the words' coordinates)
-                const int d2 = (sx - GX) * (sx - GX) + (sy - GY) * (sy - GY) + (sz - GZ) * (sz - GZ);
+                int dx, dy, dz;  // the word is decoded relative to its voxel (exact on any grid: the site is < 512 away)
+                site_offset<true>(w, GX, GY, GZ, dx, dy, dz);
+                const int d2 = dx * dx + dy * dy + dz * dz;
                 if ((int)(best >> kSH) - kBias + x * x + y * y + z * z != d2) return 1;
               }
               out[((int64_t)X * g.ay + Y) * g.az + Z] = w;

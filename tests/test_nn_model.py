@@ -148,9 +148,14 @@ def check_shard_exact(occ, out, l0, ln):
     g = np.meshgrid(*[np.arange(a, a + n) for a, n in zip(l0, ln)], indexing="ij")
     want = sum((idx[k][sl] - g[k]) ** 2 for k in range(3))
     assert np.all(out < 0x40000000)
-    c = [(out >> 20).astype(np.int64), ((out >> 10) & 1023).astype(np.int64), (out & 1023).astype(np.int64)]
+    # the word names the site modulo 1024 per axis; it is decoded relative to the voxel that holds it (fiesta_amd/csrc/common.hpp:
+    # coc_offset) -- the plain coordinate on a grid of at most 1024 voxels
+    w = [(out >> 20).astype(np.int64), ((out >> 10) & 1023).astype(np.int64), (out & 1023).astype(np.int64)]
+    d = [((g[k] - w[k] + 512) & 1023) - 512 for k in range(3)]
+    c = [g[k] - d[k] for k in range(3)]
+    assert all((c[k] >= 0).all() and (c[k] < occ.shape[k]).all() for k in range(3))
     assert np.all(occ[c[0], c[1], c[2]] == 1), "closest site is not occupied"
-    got = sum((c[k] - g[k]) ** 2 for k in range(3))
+    got = sum(d[k] ** 2 for k in range(3))
     assert int((got != want).sum()) == 0, f"{int((got != want).sum())} voxels differ from the exact transform of the global grid"
 
 
@@ -187,4 +192,14 @@ def test_the_nearest_obstacle_beyond_an_open_face(model):
     occ[70:, :, :] = scatter((58, 64, 64), 2e-3, 4)
     out, st = run_shard(model, occ, l0, ln, 48)
     if st["failed"] == 0:
+        check_shard_exact(occ, out, l0, ln)
+
+
+def test_a_region_of_more_than_1024_voxels_stores_its_sites_modulo_1024(model):
+    """a config-5-shaped shard along x: 1026 voxels of a 2048-long grid from an odd offset, margin on the open side -> a region
+    of 1072 voxels; sites and words modulo 1024, decoded relative to the cell / the voxel"""
+    occ = scatter((2048, 24, 40), 1.0e-3, 23)
+    for l0, ln in (((1022, 0, 0), (1026, 24, 40)), ((0, 0, 0), (1026, 24, 40)), ((500, 0, 0), (1100, 24, 40))):
+        out, st = run_shard(model, occ, l0, ln, 40)
+        assert st["failed"] == 0, (l0, st)
         check_shard_exact(occ, out, l0, ln)

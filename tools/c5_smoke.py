@@ -71,6 +71,8 @@ def main():
                       "ft_max_d2": st1.get("ft_max_d2")},
            "step": {"inserted": ni, "deleted": nd, "bulk": st2["bulk"], "rounds": st2["rounds"], "sweeps": st2.get("sweeps"),
                     "wall_ms": t_step * 1e3, "halo_entries_sent": st2.get("halo_entries_sent"),
+                    "cells": st2.get("cells"),   # 1: every shard ran the cell transform (nn_kernels.hpp), else the envelope passes
+                    "nn_ms_max_over_shards": [st2.get("nn_cells_ms"), st2.get("nn_lists_ms"), st2.get("nn_fill_ms")],
                     "ft_ms_max_over_shards": [st2.get("ft_rows_ms"), st2.get("ft_plane_ms"), st2.get("ft_x_ms")]},
            "sample": {"voxels": len(q), "mismatch_vs_kdtree": bad}}
     print(json.dumps(out))
