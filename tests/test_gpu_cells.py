@@ -231,3 +231,54 @@ def test_cell_transform_on_shards(hip_lib, oracle_libs, best_oracle_kind, n_shar
         assert sg["bulk"] == 1 and sg["cells"] == 1 and sg["nn_failed"] == 0, sg
         compare(sm, cpu, gs)
     sm.close()
+
+
+def test_cell_transform_on_config5_shaped_shards(hip_lib):
+    """a 2048-long grid cut into two shards of 1024 (+ ghost layers): ids modulo 1024 in the voxel words (common.hpp: pack_coc),
+    and a REGION of more than 1024 voxels (array + margin), whose sites the cell transform stores modulo 1024 too
+    (nn_core.hpp: site_offset).  Obstacles along the whole length, around the cut / the wrap of the ids at x = 1024 and at both
+    ends; insert, then a mixed update -- squared distances and decoded obstacles of 60 000 voxels against brute force."""
+    from fiesta_amd.sharded import ShardedESDFMap
+    from test_gpu_sharded import _brute_d2
+    gs, res = (2048, 40, 48), 0.1
+    sm = ShardedESDFMap((0, 0, 0), res, gs, 2, native=True, update_engine="cells")
+    sm.SetParameters(*P_DEFAULT)
+    sm.SetOriginalRange()
+    sm.SetOccupancyBox((0, 0, 0), tuple(np.array(gs) - 1), 0)
+    sm.UpdateOccupancy(True)
+    sm.UpdateESDF()
+    rng = np.random.RandomState(19)
+    S = (rng.rand(3000, 3) * gs).astype(np.int32)
+    S[:200, 0] = rng.randint(1010, 1040, 200)
+    S[200:240, 0] = rng.randint(0, 6, 40)
+    S[240:280, 0] = rng.randint(2042, 2048, 40)
+    S = np.unique(S, axis=0)
+
+    def check(obs):
+        f = sm.assemble()
+        assert int(f["occ"].sum()) == len(obs)
+        idx = np.random.RandomState(2).randint(0, gs[0] * gs[1] * gs[2], 60000).astype(np.int64)
+        idx = np.concatenate([idx, (np.arange(1000, 1048)[:, None] * gs[1] * gs[2] + np.arange(0, gs[1] * gs[2], 37)[None, :]).reshape(-1)])
+        V = np.stack([idx // (gs[1] * gs[2]), (idx // gs[2]) % gs[1], idx % gs[2]], -1)
+        want = _brute_d2(V, obs.astype(np.int64))
+        got = f["d2"][idx].astype(np.int64)
+        assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+        c = f["coc"][idx].astype(np.int64)
+        assert np.array_equal(((V - c) ** 2).sum(-1), want)
+        assert np.all(f["occ"][(c[:, 0] * gs[1] + c[:, 1]) * gs[2] + c[:, 2]] == 1)
+
+    for _ in range(3):
+        sm.SetOccupancy(S, 1)
+        sm.UpdateOccupancy(True)
+    st = sm.UpdateESDF()
+    assert st["inserted"] == len(S) and st["bulk"] == 1 and st["cells"] == 1 and st["nn_failed"] == 0, st
+    check(S)
+    gone, new = S[::2], (rng.rand(800, 3) * gs).astype(np.int32)
+    for _ in range(6):
+        sm.SetOccupancy(new, 1)
+        sm.SetOccupancy(gone, 0)
+        sm.UpdateOccupancy(True)
+    st = sm.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 1, st
+    check(np.unique(np.concatenate([S[1::2], new]), axis=0))
+    sm.close()
