@@ -1572,11 +1572,16 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin) {
     if (b >= 64) fill_blocks = b; else full = false;
   }
   const dim3 cell_grid((lcz + 3) / 4, lcy, lcx);
+  // arrays at an offset of their region, pairs of voxels aligned: quads of cells, 8-byte stores (k_nn_fill_quads)
+  const bool pairs = !full && (a.g.az % 2) == 0 && (a.g.fz % 2) == 0;
+  const dim3 quad_grid(((lcz + 3) / 4 + 3) / 4, lcy, lcx);
   if (want_max) {
     if (full) hipLaunchKernelGGL((k_nn_fill_full<true>), dim3(fill_blocks), dim3(256), 0, stream_, a);
+    else if (pairs) hipLaunchKernelGGL((k_nn_fill_quads<true>), quad_grid, dim3(256), 0, stream_, a);
     else hipLaunchKernelGGL((k_nn_fill<true>), cell_grid, dim3(256), 0, stream_, a);
   } else {
     if (full) hipLaunchKernelGGL((k_nn_fill_full<false>), dim3(fill_blocks), dim3(256), 0, stream_, a);
+    else if (pairs) hipLaunchKernelGGL((k_nn_fill_quads<false>), quad_grid, dim3(256), 0, stream_, a);
     else hipLaunchKernelGGL((k_nn_fill<false>), cell_grid, dim3(256), 0, stream_, a);
   }
   FIESTA_HIP_CHECK(hipGetLastError());
