@@ -344,13 +344,14 @@ def _hosted_worker(rank, world, port, gs, q):
         q.put((rank, "fail", traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_cpp_protocol_across_processes_on_a_hosted_transport(hip_lib, world):
     """the C++ sweep loop, sparse diff / apply and convergence test of shard_group.hip -- the code
-    `bench.py --gpus N` runs over RCCL -- ACROSS PROCESSES: 2 and 4 processes share the one visible GPU (where RCCL refuses
+    `bench.py --gpus N` runs over RCCL -- ACROSS PROCESSES: 2, 4 and 8 processes share the one visible GPU (where RCCL refuses
     a communicator), each owns one shard, the group's all-gathers and neighbour exchanges travel through
     fiesta_hip_shard_transport bound to torch.distributed / gloo.  The sharded bulk path (decided from the gathered table),
-    the frontier rounds with ghost sweeps at the cuts (2 x 1 x 1 and 2 x 2 x 1) and a small delta under the library's own
+    the frontier rounds with ghost sweeps at the cuts (2 x 1 x 1, 2 x 2 x 1 and config 5's 2 x 2 x 2: faces, edges and the corner
+    where eight shards meet) and a small delta under the library's own
     engine choice, each against brute force on every owned voxel."""
     import socket
     import torch.multiprocessing as mp
