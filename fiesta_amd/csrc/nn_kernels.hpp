@@ -228,6 +228,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   __shared__ uint16_t s_order[256];
   __shared__ uint8_t s_key[256];
   const nn::Geom &g = a.g;
+  if (*a.failed) return;  // k_nn_cells ran out of room for the sites (a shard's region: its table points past the array)
   const int tid = (int)threadIdx.x;
   const int cz0 = g.lz0 + (int)blockIdx.x * 64, cy0 = g.ly0 + (int)blockIdx.y * 4, cx = g.lx0 + (int)blockIdx.z;  // (the cells that get a list)
   const int X0 = cx - kStageK, Y0 = cy0 - kStageK, Zf = cz0 - kStageK;

@@ -282,3 +282,30 @@ def test_cell_transform_on_config5_shaped_shards(hip_lib):
     assert st["bulk"] == 1 and st["cells"] == 1, st
     check(np.unique(np.concatenate([S[1::2], new]), axis=0))
     sm.close()
+
+
+def test_a_shard_whose_cells_fail_takes_the_envelope_passes(hip_lib, oracle_libs, best_oracle_kind):
+    """two shards, every obstacle in the far half of ONE of them: the other shard's nearest obstacles lie across the cut, farther
+    than its region's margin -- its cells find nothing in reach or a window that touches the open face, the cell transform
+    fails there (nn_failed), that shard runs the envelope passes (which grow their margin until it suffices), the other one
+    may keep the cell transform; the assembled field equals the reference's"""
+    from fiesta_amd.sharded import ShardedESDFMap
+    from test_gpu_sharded import compare, drive
+    gs, res = (256, 48, 56), 0.1
+    sm = ShardedESDFMap((0, 0, 0), res, gs, 2, native=True, update_engine="cells")
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, tuple((np.array(gs) - 0.5) * res), kind=best_oracle_kind)
+    for m in (sm, cpu):
+        m.SetParameters(*P_DEFAULT)
+        m.SetOriginalRange()
+    rng = np.random.RandomState(8)
+    S = (rng.rand(900, 3) * gs).astype(np.int32)
+    S[:, 0] = 200 + S[:, 0] % 56            # x in [200, 256): the left shard (x < 128) is empty, 72+ voxels from the first obstacle
+    drive(sm, cpu, [([], all_voxels(gs), 1)])
+    for _ in range(3):
+        sm.SetOccupancy(S, 1)
+        cpu.SetOccupancyVox(S, 1)
+        assert sm.UpdateOccupancy(True) == cpu.UpdateOccupancy(True)
+    sg, sc = sm.UpdateESDF(), cpu.UpdateESDF()
+    assert sg["inserted"] == sc["inserted"] and sg["bulk"] == 1 and sg["cells"] == 0, sg   # (not EVERY shard ran the cell transform)
+    compare(sm, cpu, gs)
+    sm.close()
