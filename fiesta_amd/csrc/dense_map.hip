@@ -1481,9 +1481,9 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 }
 
 // ---- the cell transform (nn_core.hpp / nn_kernels.hpp): the same fixed point for a sparse obstacle set ----------------------
-// Applies to maps with plain ids (no global extent beyond 1024 voxels) whose region -- the array, a shard's array plus
-// margin -- has at most 1024 voxels per axis.  Whether it is
-// worth trying: the obstacle density must be in the range where every cell finds an obstacle within its search window and
+// Applies to unsharded maps with plain ids (at most 1024 voxels per axis) and to the shards of any grid whose region -- the
+// array plus margin -- stays within nn::kRegionMax voxels per axis (beyond 1024 the sites are stored modulo 1024).  Whether
+// it is worth trying: the obstacle density must be in the range where every cell finds an obstacle within its search window and
 // lists stay short (measured on scatter scenes, tests/test_nn_model.py: 1.2e-4 ... 2.5e-3 of the voxels; config 2's scene is
 // 3.7e-4), it must not have failed at about this obstacle count, and it must not have been slower than the envelope passes.
 bool DenseMap::cells_wanted() {
