@@ -29,6 +29,9 @@ def best_oracle_kind(oracle_libs):
 @pytest.fixture(scope="session")
 def hip_lib():
     """The product library; GPU tests must run on it and nothing else."""
+    # torch first: a shard group over RCCL opens librccl at run time and finds torch's copy if it is loaded; opened before
+    # torch (a sub-run that starts with the RCCL test), ROCm's own copy AND torch's end up in one process and abort at exit
+    import torch  # noqa: F401
     import fiesta_amd
     lib = fiesta_amd.load()
     if fiesta_amd.device_count() < 1:
