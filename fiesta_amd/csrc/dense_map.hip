@@ -1510,7 +1510,7 @@ bool DenseMap::cells_wanted() {
 // (nn_core.hpp: region_geom) -- no communication, like run_bulk.  Exactness is decided cell by cell on the device: a cell
 // whose window touches an open face of the region fails, and a failed cell fails the transform (the caller reads
 // C_NN_FAILED and takes the envelope passes).  Returns false (nothing launched) if the transform does not apply to this map.
-bool DenseMap::run_cells(fiesta_hip_stats *st, int margin) {
+bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   const Geom &g = g_;
   if (!g.sharded && (g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024)) return false;
   NnArgs a;
@@ -1548,6 +1548,11 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin) {
   ft_in_place_ = !g.sharded || (!open_side && alone_in_group_);
   if (!ft_in_place_) ft_out_.ensure_exact((size_t)g.n, stream_);
   a.coc = ft_in_place_ ? coc_ : ft_out_.p;
+  if (publish) {  // a last one-thread launch reports into h_counters_ and cleans up (nn_kernels.hpp: k_nn_close)
+    a.pub = h_counters_, a.queues = &counters_[C_INSERT], a.track_dst = track_ ? &counters_[C_MAXD2] : nullptr;
+    a.tag = ++nn_tag_;
+    a.pub_failed = C_NN_FAILED, a.pub_entries = C_NN_ENTRIES, a.pub_maxd2 = C_FT_MAXD2, a.pub_tag = C_NN_CURSOR;
+  }
   if (!ft_counters_clean_)
     FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
   ft_counters_clean_ = false;
@@ -1586,7 +1591,11 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin) {
   }
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[3], stream_));
-  if (track_)  // (a failed transform leaves 0 here; the envelope passes that follow it set the bound themselves)
+  if (publish) {
+    hipLaunchKernelGGL(k_nn_close, dim3(1), dim3(1), 0, stream_, a);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  if (track_ && !publish)  // (a failed transform leaves 0 here; the envelope passes that follow it set the bound themselves)
     FIESTA_HIP_CHECK(hipMemcpyAsync(&counters_[C_MAXD2], &counters_[C_FT_MAXD2], sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
   if (st) {
     st->bulk = 1;
@@ -1646,15 +1655,33 @@ bool DenseMap::bulk_pays_model(double delta, double nocc, double n, double ft_la
 }
 
 // After a successful bulk transform: the queues are consumed, timings and counters reported.
-void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells) {
+void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells, bool published) {
   static_assert(C_DELETE == C_INSERT + 1, "counter layout");
-  if (!queues_zeroed_) zero_counters(C_INSERT, 2);  // both queues are drained
-  queues_zeroed_ = false;
-  host_counts_[0] = host_counts_[1] = 0;
-  if (g_.sharded) zero_counter(C_REMOTE_DEL);
-  FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
-  collect_stats(nullptr);
-  FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  nn_clean_ = false;
+  if (published) {
+    // a cell transform that reports for itself (k_nn_close): ONE synchronisation -- results in h_counters_, the transform's
+    // counters clean for the next update, and unless a cell failed the queue lengths too
+    FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
+    FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+    published = h_counters_[C_NN_CURSOR] == nn_tag_;  // (always, unless a launch failed)
+    if (published) {
+      h_counters_fresh_ = false;
+      if (h_counters_[C_NN_FAILED] == 0) {  // ... and the queue lengths are cleared too
+        queues_zeroed_ = false;
+        host_counts_[0] = host_counts_[1] = 0;
+        nn_clean_ = true;
+      }
+    }
+  }
+  if (!published) {
+    if (!queues_zeroed_) zero_counters(C_INSERT, 2);  // both queues are drained
+    queues_zeroed_ = false;
+    host_counts_[0] = host_counts_[1] = 0;
+    if (g_.sharded) zero_counter(C_REMOTE_DEL);
+    FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
+    collect_stats(nullptr);
+    FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  }
   float m1 = 0, m2 = 0, m3 = 0;
   const bool timed = hipEventElapsedTime(&m1, ft_ev_[0], ft_ev_[1]) == hipSuccess && hipEventElapsedTime(&m2, ft_ev_[1], ft_ev_[2]) == hipSuccess &&
                      hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]) == hipSuccess;
@@ -1686,6 +1713,7 @@ void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time
 bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
+  nn_clean_ = false;
   ++epoch_;
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
   reset_stats_counters();
@@ -1694,7 +1722,7 @@ bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
   // themselves -- a search window that touches an open face of the region fails its cell -- so a transform without a failed
   // cell is exact whatever the margin; one with failed cells wrote nothing and the envelope passes serve this try.
   tried_cells_ = false;
-  if (cells_wanted() && run_cells(st, margin)) {
+  if (cells_wanted() && run_cells(st, margin, /*publish=*/false)) {
     FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_FT_OVF0], &counters_[C_FT_OVF0], 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));  // (C_NN_CURSOR ... C_NN_ENTRIES and C_FT_MAXD2 lie in this block)
     if (h_counters_[C_NN_FAILED] == 0) {
@@ -1849,6 +1877,8 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
 void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
+  const bool nn_was_clean = nn_clean_;  // (only a cell transform that reports for itself sets it again: bulk_finish)
+  nn_clean_ = false;
   const auto h0 = std::chrono::steady_clock::now();
   if (host_counts_valid_) {  // (what UpdateOccupancy read last: nothing else changes these four)
     for (int k = 0; k < 4; ++k) h_counters_[C_INSERT + k] = host_counts_[k];
@@ -1895,13 +1925,22 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
   if (try_bulk) {
     // (an unsharded map's transform cannot fail to serve the update -- the envelope passes stand behind the cell transform --
     //  so the two queue lengths go in the same launch as the statistics)
-    queues_zeroed_ = !g_.sharded && g_.nx <= 2048 && g_.ny <= 2048 && g_.nz <= 2048;
-    reset_stats_counters(/*lists=*/true, queues_zeroed_);
-    counters_reset = true;
     // a sparse obstacle set: the cell transform first (nn_kernels.hpp).  A cell without a list fails it -- k_nn_fill then
     // wrote nothing -- and the envelope passes below serve the update; the obstacle count is remembered and not retried.
-    if (cells_wanted() && run_cells(st, 0)) {
-      bulk_finish(st, h0, /*cells=*/true);
+    const bool want_cells = cells_wanted();
+    // (the last update was a cell transform that cleaned up behind itself and nothing has touched the counters since: no
+    //  reset launch ahead of this one -- its fill will clear the queue lengths at its end)
+    const bool lean = want_cells && nn_was_clean;
+    if (lean) {
+      queues_zeroed_ = false;
+      ft_counters_clean_ = true;
+    } else {
+      queues_zeroed_ = !g_.sharded && g_.nx <= 2048 && g_.ny <= 2048 && g_.nz <= 2048;
+      reset_stats_counters(/*lists=*/true, queues_zeroed_);
+    }
+    counters_reset = true;
+    if (want_cells && run_cells(st, 0, /*publish=*/true)) {
+      bulk_finish(st, h0, /*cells=*/true, /*published=*/true);
       if (h_counters_[C_NN_FAILED] == 0) {
         nn_fail_streak_ = 0;
         return;
@@ -2285,6 +2324,7 @@ void DenseMap::snapshot_save(int slot) {
 
 void DenseMap::snapshot_restore(int slot) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
+  nn_clean_ = false;  // (the counters come back as they were saved)
   use_device();
   if (slot < 0 || slot >= 4 || !snaps_[slot].valid) throw Error(FIESTA_HIP_ERR_STATE, "no such snapshot");
   Snapshot &s = snaps_[slot];
@@ -2328,6 +2368,7 @@ void DenseMap::snapshot_restore(int slot) {
 // Raw dump (write) / load of the whole map state: one routine for both directions (checkpoint.hpp).
 void DenseMap::checkpoint(const char *path, bool write) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
+  nn_clean_ = false;  // (the counters come back as they were saved)
   use_device();
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   DevFile f(path, write, stream_);

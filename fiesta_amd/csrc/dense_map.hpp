@@ -206,8 +206,8 @@ class DenseMap {
   bool bulk_eligible(unsigned long long ni, unsigned long long nd);
   bool run_bulk(fiesta_hip_stats *st, int margin, bool *exact);
   bool cells_wanted();                  // should this update try the cell transform (nn_kernels.hpp) before the envelope passes?
-  bool run_cells(fiesta_hip_stats *st, int margin);  // false: not applicable to this map (nothing launched)
-  void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells = false);
+  bool run_cells(fiesta_hip_stats *st, int margin, bool publish);  // false: not applicable to this map (nothing launched)
+  void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells = false, bool published = false);
   void reset_stats_counters(bool lists = false, bool queues = false);
   void enable_distance_tracking();
   void collect_stats(fiesta_hip_stats *st);
@@ -258,6 +258,8 @@ class DenseMap {
   DevBuf<uint32_t> nn_ctab_, nn_sites_, nn_lists_;
   double nn_last_ms_ = 0;        // kernel time of the last cell transform that succeeded ...
   long long nn_last_nocc_ = -1;  // ... and the obstacle count it ran on
+  bool nn_clean_ = false;        // the last update was a cell transform whose fill cleaned the counters up behind itself (nn_fill_done)
+  unsigned long long nn_tag_ = 1ull << 40;  // serial number of the cell transforms that report for themselves
   bool tried_cells_ = false;     // bulk_try: the transform waiting for bulk_commit is the cell transform's
   int nn_fail_streak_ = 0, nn_skip_ = 0;  // failed attempts in a row; eligible updates still to be left to the envelope passes
   DevBuf<unsigned long long> ft_spill_;  // backing store of the transform's rings (run_bulk)

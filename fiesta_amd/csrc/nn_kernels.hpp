@@ -39,7 +39,31 @@ struct NnArgs {
   unsigned long long *entries;  // list entries in total (statistics, and what the engine choice learns from)
   unsigned long long *maxd2;    // TRACK: atomicMax of every d^2 written
   vox_t *coc;
+  // k_nn_close (one thread, behind the fill): copies the results the host wants into pinned host memory `pub` (indexed like
+  // the counter array), `tag` last; leaves the transform's counters -- and, if no cell failed, the two drained queue lengths
+  // `queues` -- at zero for the next update; hands the distance bound to `track_dst`.
+  unsigned long long *pub, *queues, *track_dst;
+  unsigned long long tag;
+  int pub_failed, pub_entries, pub_maxd2, pub_tag;  // slots of pub
 };
+
+
+// ---- the transform's last launch: one thread reports and cleans up ------------------------------------------------------------
+// One host synchronisation then ends the update: no copy of the counters, no reset launch ahead of the next transform.  (The
+// same work done by the fill's last work-group -- a ticket every work-group takes at its end -- doubled the fill's time: 2048
+// returning atomics on one address, all at the same moment.)
+__global__ void k_nn_close(NnArgs a) {
+  const unsigned long long failed = *a.failed, entries = *a.entries, md = a.maxd2 ? *a.maxd2 : 0ull;
+  volatile unsigned long long *h = a.pub;
+  h[a.pub_failed] = failed, h[a.pub_entries] = entries, h[a.pub_maxd2] = md;
+  if (a.track_dst && failed == 0) *a.track_dst = md;
+  *a.cursor = 0, *a.failed = 0, *a.entries = 0;
+  if (a.maxd2) *a.maxd2 = 0;
+  if (failed == 0) a.queues[0] = 0, a.queues[1] = 0;
+  __threadfence_system();
+  h[a.pub_tag] = a.tag;  // (last: the host trusts the other three once it sees this update's tag)
+  __threadfence_system();
+}
 
 // ---- sites by cell row ---------------------------------------------------------------------------------------------------
 // One batch of loads per wave: the 64 voxel rows of the cell row, a byte per lane and row (two on a 1024-voxel axis), kept
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
   // grid: the cells that got a list, (ceil((lz1 - lz0) / 4), ly1 - ly0, lx1 - lx0)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int cz = g.lz0 + (int)blockIdx.x * 4 + wave, cy = g.ly0 + (int)blockIdx.y, cx = g.lx0 + (int)blockIdx.z;
-  if (cz >= g.lz1) return;
+  if (cz < g.lz1) {  // (a wave beyond the range only goes to the closing barrier)
   const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
   const uint32_t *rec = a.lists + cell * nn::kStride;
   nn_cu32 *lp = reinterpret_cast<nn_cu32 *>(reinterpret_cast<uintptr_t>(rec));
@@ -517,6 +541,7 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
     for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
     if (lane == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
   }
+  }
 }
 
 // The predicated variant for arrays that lie at an offset inside their region (a shard: owned box + ghost layers, cut by
@@ -534,7 +559,7 @@ __global__ __launch_bounds__(256) void k_nn_fill_quads(NnArgs a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q = (int)blockIdx.x * 4 + wave, cy = g.ly0 + (int)blockIdx.y, cx = g.lx0 + (int)blockIdx.z;
   const int cz0 = g.lz0 + 4 * q;
-  if (cz0 >= g.lz1) return;
+  if (cz0 < g.lz1) {  // (a wave beyond the range only goes to the closing barrier)
   const int y = lane >> 3, z = lane & 7;
   const uint32_t ayz = (uint32_t)y | ((uint32_t)z << 8);
   uint32_t *const mytile = &tile[wave][0];
@@ -592,6 +617,7 @@ __global__ __launch_bounds__(256) void k_nn_fill_quads(NnArgs a) {
   if (TRACK) {
     for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
     if (lane == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
+  }
   }
 }
 
