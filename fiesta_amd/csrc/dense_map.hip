@@ -1481,15 +1481,14 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 }
 
 // ---- the cell transform (nn_core.hpp / nn_kernels.hpp): the same fixed point for a sparse obstacle set ----------------------
-// Applies to unsharded maps with plain ids (at most 1024 voxels per axis) and to the shards of any grid whose region -- the
-// array plus margin -- stays within nn::kRegionMax voxels per axis (beyond 1024 the sites are stored modulo 1024).  Whether
+// Applies to maps, and to the shards of any grid, whose region -- the array, a shard's array plus margin -- stays within
+// nn::kRegionMax voxels per axis (beyond 1024 the sites are stored modulo 1024, as the voxel words of such grids are).  Whether
 // it is worth trying: the obstacle density must be in the range where every cell finds an obstacle within its search window and
 // lists stay short (measured on scatter scenes, tests/test_nn_model.py: 1.2e-4 ... 2.5e-3 of the voxels; config 2's scene is
 // 3.7e-4), it must not have failed at about this obstacle count, and it must not have been slower than the envelope passes.
 bool DenseMap::cells_wanted() {
   const Geom &g = g_;
   if (update_engine_ == 4 || g.nx > nn::kRegionMax || g.ny > nn::kRegionMax || g.nz > nn::kRegionMax) return false;
-  if (!g.sharded && (g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024)) return false;
   if (update_engine_ == 5) return true;
   const long long nocc = (long long)h_counters_[C_NOCC];
   if (nocc * 8192 < g.n || nocc * 400 > g.n) return false;
@@ -1512,7 +1511,7 @@ bool DenseMap::cells_wanted() {
 // C_NN_FAILED and takes the envelope passes).  Returns false (nothing launched) if the transform does not apply to this map.
 bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   const Geom &g = g_;
-  if (!g.sharded && (g.wrap || g.nx > 1024 || g.ny > 1024 || g.nz > 1024)) return false;
+  if (g.nx > nn::kRegionMax || g.ny > nn::kRegionMax || g.nz > nn::kRegionMax) return false;
   NnArgs a;
   memset(&a, 0, sizeof(a));
   int rlo[3] = {0, 0, 0};

@@ -309,3 +309,26 @@ def test_a_shard_whose_cells_fail_takes_the_envelope_passes(hip_lib, oracle_libs
     assert sg["inserted"] == sc["inserted"] and sg["bulk"] == 1 and sg["cells"] == 0, sg   # (not EVERY shard ran the cell transform)
     compare(sm, cpu, gs)
     sm.close()
+
+
+def test_cell_transform_on_an_unsharded_map_beyond_1024_voxels(hip_lib):
+    """one map of 1400 x 40 x 48 voxels: ids modulo 1024, decoded relative to the voxel (common.hpp), and the cell transform's
+    sites likewise relative to the asking cell -- every voxel against scipy's exact transform, insert and mixed update"""
+    shape = (1400, 40, 48)
+    m = make_map(shape, "cells")
+    rng = np.random.RandomState(41)
+    S = (rng.randint(0, 1 << 20, (2600, 3)) % np.array(shape)).astype(np.int32)
+    S[:150, 0] = rng.randint(1000, 1050, 150)    # around the wrap of the ids
+    occupy(m, S)
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 1 and st["nn_failed"] == 0, st
+    check_exact(m, shape)
+    new = (rng.randint(0, 1 << 20, (900, 3)) % np.array(shape)).astype(np.int32)
+    for _ in range(6):
+        m.SetOccupancy(new, 1, want_ret=False)
+        m.SetOccupancy(S[:1300], 0, want_ret=False)
+        m.UpdateOccupancy(True)
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 1, st
+    check_exact(m, shape)
+    m.close()
