@@ -332,3 +332,27 @@ def test_cell_transform_on_an_unsharded_map_beyond_1024_voxels(hip_lib):
     assert st["bulk"] == 1 and st["cells"] == 1, st
     check_exact(m, shape)
     m.close()
+
+
+def test_a_scene_the_cell_transform_cannot_serve_is_not_retried_at_once(hip_lib):
+    """the library's own choice (`bulk`: a transform whenever the gate is open): 216 obstacles in one corner of a 96^3 map are in
+    the density range of the cell transform, but most cells have nothing within reach -- the first update tries it, counts
+    the failed cells and finishes on the envelope passes; the next 8 eligible updates do not try (no failed cell reported,
+    no time lost), the one after them does again"""
+    shape = (96, 96, 96)
+    m = make_map(shape, "bulk")
+    cube = np.array([(x, y, z) for x in range(6) for y in range(6) for z in range(6)], np.int32) + 3
+    occupy(m, cube)
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 0 and st["nn_failed"] > 0, st
+    check_exact(m, shape)
+    flip = np.array([[80, 80, 80]], np.int32)
+    tried = []
+    for i in range(10):
+        (occupy if i % 2 == 0 else free)(m, flip, 6)
+        st = m.UpdateESDF()
+        assert st["bulk"] == 1 and st["cells"] == 0 and st["inserted"] + st["deleted"] == 1, st
+        tried.append(st["nn_failed"] > 0)
+    assert tried == [False] * 8 + [True] + [False], tried
+    check_exact(m, shape)
+    m.close()
