@@ -1484,14 +1484,14 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
 // Applies to maps, and to the shards of any grid, whose region -- the array, a shard's array plus margin -- stays within
 // nn::kRegionMax voxels per axis (beyond 1024 the sites are stored modulo 1024, as the voxel words of such grids are).  Whether
 // it is worth trying: the obstacle density must be in the range where every cell finds an obstacle within its search window and
-// lists stay short (measured on scatter scenes, tests/test_nn_model.py: 1.2e-4 ... 2.5e-3 of the voxels; config 2's scene is
-// 3.7e-4), it must not have failed at about this obstacle count, and it must not have been slower than the envelope passes.
+// lists stay short (measured on scatter scenes, profiles/r05h_density_range.json: 8e-5 ... 2.5e-3 of the voxels; config 2's
+// scene is 3.7e-4), it must not have failed at about this obstacle count, and it must not have been slower than the envelope passes.
 bool DenseMap::cells_wanted() {
   const Geom &g = g_;
   if (update_engine_ == 4 || g.nx > nn::kRegionMax || g.ny > nn::kRegionMax || g.nz > nn::kRegionMax) return false;
   if (update_engine_ == 5) return true;
   const long long nocc = (long long)h_counters_[C_NOCC];
-  if (nocc * 8192 < g.n || nocc * 400 > g.n) return false;
+  if (nocc * 12288 < g.n || nocc * 400 > g.n) return false;
   // a failed attempt (a cell without a list: ~0.2 ms lost before the envelope passes take over) is not repeated at once: the
   // next 8, 16, ... 256 eligible updates go straight to the envelope passes, then it is tried again -- a scene that cannot be
   // served costs 1 % in the long run, one unlucky cell in a scene that can does not switch the transform off for good

@@ -52,7 +52,7 @@ constexpr int kSH = 9;              // a key's distance part starts at this bit;
                                     // byte offset of the winner's entry), bits 0..3: zero
 constexpr int kBias = 3 * 7 * 7;    // |v|^2 of the voxel farthest from the cell origin
 constexpr int kKfirst = 1;           // cells around the cell the competitor is first looked for in (any site will do: the nearest prunes best)
-constexpr int kKmax = 5;            // the search window reaches this many cells (p stays inside a signed byte when doubled)
+constexpr int kKmax = 7;            // the search window reaches this many cells (p in [-56, 63]: -2 p stays inside a signed byte)
 constexpr int kStride = 128;        // dwords of a cell's record: [0] the number of entries, [4 + 4 i ..] entry i = (b, K, m, W)
 constexpr int kRaw = 32;            // candidates a team's scratch holds between the sweep and the record
 constexpr int kThin = 16;           // lists longer than this are thinned pairwise
