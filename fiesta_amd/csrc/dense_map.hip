@@ -1539,6 +1539,7 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   nn_lists_.ensure_exact((size_t)ncells * nn::kStride + kListPad, stream_);
   a.ctab = nn_ctab_.p, a.sites = nn_sites_.p, a.sites_cap = (uint32_t)std::min<size_t>(nn_sites_.cap, 0xFFFFFFFFu);
   a.lists = nn_lists_.p;
+  a.dump = nn_lists_.p + (size_t)ncells * nn::kStride + (kListPad - 128);
   a.cursor = &counters_[C_NN_CURSOR], a.failed = &counters_[C_NN_FAILED], a.entries = &counters_[C_NN_ENTRIES];
   // (the largest distance written: maps that track it, and shards -- the group sizes the next margin from it)
   const bool want_max = track_ || open_side;
@@ -1578,14 +1579,16 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   const dim3 cell_grid((lcz + 3) / 4, lcy, lcx);
   // arrays at an offset of their region, pairs of voxels aligned: quads of cells, 8-byte stores (k_nn_fill_quads)
   const bool pairs = !full && (a.g.az % 2) == 0 && (a.g.fz % 2) == 0;
-  const dim3 quad_grid(((lcz + 3) / 4 + 3) / 4, lcy, lcx);
+  // (persistent waves there too: runs of at least four quads where the map has them)
+  const int64_t nq_off = (int64_t)lcx * lcy * ((lcz + 3) / 4);
+  const unsigned off_blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(kFillBlocks, (nq_off + 15) / 16));
   if (want_max) {
     if (full) hipLaunchKernelGGL((k_nn_fill_full<true>), dim3(fill_blocks), dim3(256), 0, stream_, a);
-    else if (pairs) hipLaunchKernelGGL((k_nn_fill_quads<true>), quad_grid, dim3(256), 0, stream_, a);
+    else if (pairs) hipLaunchKernelGGL((k_nn_fill_full<true, true>), dim3(off_blocks), dim3(256), 0, stream_, a);
     else hipLaunchKernelGGL((k_nn_fill<true>), cell_grid, dim3(256), 0, stream_, a);
   } else {
     if (full) hipLaunchKernelGGL((k_nn_fill_full<false>), dim3(fill_blocks), dim3(256), 0, stream_, a);
-    else if (pairs) hipLaunchKernelGGL((k_nn_fill_quads<false>), quad_grid, dim3(256), 0, stream_, a);
+    else if (pairs) hipLaunchKernelGGL((k_nn_fill_full<false, true>), dim3(off_blocks), dim3(256), 0, stream_, a);
     else hipLaunchKernelGGL((k_nn_fill<false>), cell_grid, dim3(256), 0, stream_, a);
   }
   FIESTA_HIP_CHECK(hipGetLastError());

@@ -42,6 +42,7 @@ struct NnArgs {
   // k_nn_close (one thread, behind the fill): copies the results the host wants into pinned host memory `pub` (indexed like
   // the counter array), `tag` last; leaves the transform's counters -- and, if no cell failed, the two drained queue lengths
   // `queues` -- at zero for the next update; hands the distance bound to `track_dst`.
+  uint32_t *dump;  // 128 dwords nobody reads: lanes outside the array store here, so that every wave issues the same stores
   unsigned long long *pub, *queues, *track_dst;
   unsigned long long tag;
   int pub_failed, pub_entries, pub_maxd2, pub_tag;  // slots of pub
@@ -378,7 +379,7 @@ __device__ __forceinline__ void nn_dot4_pair(uint32_t a, uint32_t b0, uint32_t b
 }
 
 constexpr int kFillBlocks = 2048;  // persistent work-groups of four waves: 8 per CU, 8 quads (32 cells) per wave on a 512^3 map
-constexpr int kListPad = 64;       // dwords the list array is over-allocated by
+constexpr int kListPad = 256;      // dwords the list array is over-allocated by (the last 128: where masked lanes of the offset fill store)
 
 // A QUAD is four cells adjacent in z: 32 voxels, one 128-byte line per (x, y) row.  ONE WAVE serves a quad -- its four cells
 // one after the other, the 4 x 8 winners' words kept in registers -- and then stores it slab by slab through a 1.25 KB LDS
@@ -396,7 +397,12 @@ constexpr int kListPad = 64;       // dwords the list array is over-allocated by
 // no readlane.  FULL maps only: every extent a multiple of the cell edge, rows a multiple of four cells long, the same
 // number of quads for every wave -- no predicate anywhere, so the number of memory operations between a fetch and its wait
 // is the same on every path.  Other maps take the simple predicated variant below.
-template <bool TRACK>
+// OFFSET: the array lies at an offset inside its region (a shard: owned box + ghost layers), cut by cells on every side, but
+// pairs of voxels stay aligned (even row length, even z-offset).  The same wave-per-quad choreography over the cells that
+// hold a voxel of the array, 8-byte stores (16 lanes per 32-voxel row piece, two store instructions per slab), and -- since
+// the counted waits need the same number of memory operations on every path -- NO predicated store: a lane whose pair lies
+// outside the array stores into a dump area instead.  Runs may differ in length by one quad (each wave counts its own).
+template <bool TRACK, bool OFFSET = false>
 __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
   constexpr int kTileRow = 40;  // dwords between two rows of the tile: 32 + padding that spreads the rows over the banks
   __shared__ __attribute__((aligned(16))) uint32_t land[4][2][nn::kStride];  // per wave, two zones of one record each
@@ -404,10 +410,14 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
   const nn::Geom &g = a.g;
   if (*a.failed) return;  // some cell has no list: the envelope passes serve this update (dense_map.hip)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int quads = g.ncz >> 2;
-  const uint32_t nq = (uint32_t)(g.ncx * g.ncy) * (uint32_t)quads;
-  const uint32_t per = nq / (gridDim.x * 4u);  // (gridDim.x * 4 * per == nq: the host's choice)
-  const uint32_t q0 = (blockIdx.x * 4u + (uint32_t)wave) * per, q1 = q0 + per;
+  // the quads: of the whole map, or (OFFSET) of the cells that got a list -- lx0.., coordinates relative to that range
+  const int quads = OFFSET ? (g.lz1 - g.lz0 + 3) >> 2 : g.ncz >> 2;
+  const int rows_y = OFFSET ? g.ly1 - g.ly0 : g.ncy;
+  const uint32_t nq = (uint32_t)((OFFSET ? g.lx1 - g.lx0 : g.ncx) * rows_y) * (uint32_t)quads;
+  // (full maps: gridDim.x * 4 * per == nq, the host's choice; OFFSET: the last waves' runs are shorter or empty)
+  const uint32_t per = OFFSET ? (nq + gridDim.x * 4u - 1u) / (gridDim.x * 4u) : nq / (gridDim.x * 4u);
+  const uint32_t q0 = (blockIdx.x * 4u + (uint32_t)wave) * per, q1 = OFFSET ? min(q0 + per, nq) : q0 + per;
+  if (OFFSET && q0 >= q1) return;
   const int row0 = (int)(q0 / (uint32_t)quads);
   const int y = lane >> 3, z = lane & 7;
   const uint32_t ayz = (uint32_t)y | ((uint32_t)z << 8);
@@ -418,7 +428,9 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
   uint32_t *const mytile = &tile[wave][0];
   struct At { int cx, cy, q; };  // a quad: cell row (cx, cy), quad q of it
   auto fetch = [&](const At &c, const int cell_of_quad, const int zone) {
-    const int64_t cell = ((int64_t)c.cx * g.ncy + c.cy) * g.ncz + 4 * c.q + cell_of_quad;
+    // (OFFSET: a quad cut by the end of the range fetches its last cell again -- never stored: no branch around a load)
+    const int64_t cell = OFFSET ? ((int64_t)(g.lx0 + c.cx) * g.ncy + (g.ly0 + c.cy)) * g.ncz + min(g.lz0 + 4 * c.q + cell_of_quad, g.lz1 - 1)
+                                : ((int64_t)c.cx * g.ncy + c.cy) * g.ncz + 4 * c.q + cell_of_quad;
     const uint32_t *lp = a.lists + cell * nn::kStride + lane, *hp = lp + 64;
     const uint32_t at = zone0 + (uint32_t)zone * (uint32_t)(nn::kStride * 4);
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off\n\t"
@@ -428,11 +440,11 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
   auto advance = [&](At &c) {
     if (++c.q == quads) {
       c.q = 0;
-      if (++c.cy == g.ncy) c.cy = 0, ++c.cx;
+      if (++c.cy == rows_y) c.cy = 0, ++c.cx;
     }
   };
   // one cell: every voxel's minimum key over the record in `zone`, the winners' words into ww[0..7]
-  auto serve = [&](const int zone, uint32_t *ww) {
+  auto serve = [&](const int zone, uint32_t *ww, const bool col_in, const int xin_lo, const int xin_hi) {
     const uint32_t *lz = &land[wave][zone][0];
     const int cnt = __builtin_amdgcn_readfirstlane((int)lz[0]);
     uint32_t best[nn::kB];
@@ -453,13 +465,15 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
 #pragma unroll
     for (int x = 0; x < nn::kB; ++x) {
       ww[x] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lz + 7) + (best[x] & 0x1F0u));
-      if (TRACK) dmax = max(dmax, (best[x] >> nn::kSH) - (uint32_t)nn::kBias + (uint32_t)(x * x + y * y + z * z));
+      // (OFFSET: only voxels of the array count for the distance bound)
+      if (TRACK && (!OFFSET || (col_in && x >= xin_lo && x < xin_hi)))
+        dmax = max(dmax, (best[x] >> nn::kSH) - (uint32_t)nn::kBias + (uint32_t)(x * x + y * y + z * z));
     }
   };
   // The wave's VMEM operations in issue order, per quad:  F1 | F2 | F3 | F0' | S x 8   (F: the two loads of a cell's fetch,
   // issued as the cell before it begins; F0': the next quad's first cell; S: the quad's stores).  A fetch is needed one cell
   // after it was issued: behind it then lie the next fetch, and -- for a quad's first cell -- the eight stores of the quad before.
-  At c{row0 / g.ncy, row0 % g.ncy, (int)(q0 % (uint32_t)quads)};
+  At c{row0 / rows_y, row0 % rows_y, (int)(q0 % (uint32_t)quads)};
   fetch(c, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (uint32_t q = q0; q < q1; ++q) {
@@ -470,19 +484,56 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
     for (int k = 0; k < 4; ++k) {
       // zone (k + 1) & 1 was last read by the cell before: its LDS reads are done (lgkmcnt(0) below)
       if (k < 3) fetch(c, k + 1, (k + 1) & 1); else fetch(nxt, 0, 0);
-      if (k == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // behind this cell's fetch: the quad before's 8 stores + the fetch just issued
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           // ... only the fetch just issued
-      serve(k & 1, ww[k]);
+      // behind this cell's fetch: the fetch just issued, and for a quad's first cell the stores of the quad before (8; OFFSET: 16)
+      if (k == 0) {
+        if (OFFSET) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      }
+      bool col_in = true;
+      int xin_lo = 0, xin_hi = nn::kB;
+      if (OFFSET && TRACK) {  // which of this lane's voxels of the cell lie in the array
+        const int cz = g.lz0 + 4 * c.q + k;
+        const int Y = nn::kB * (g.ly0 + c.cy) + y - g.fy, Z = nn::kB * cz + z - g.fz, X0 = nn::kB * (g.lx0 + c.cx) - g.fx;
+        col_in = cz < g.lz1 && (unsigned)Y < (unsigned)g.ay && (unsigned)Z < (unsigned)g.az;
+        xin_lo = max(0, -X0), xin_hi = min(nn::kB, g.ax - X0);
+      }
+      serve(k & 1, ww[k], col_in, xin_lo, xin_hi);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    vox_t *slab = a.coc + ((int64_t)(nn::kB * c.cx) * g.ny + nn::kB * c.cy) * g.nz + 4 * nn::kB * c.q;
+    if (!OFFSET) {
+      vox_t *slab = a.coc + ((int64_t)(nn::kB * c.cx) * g.ny + nn::kB * c.cy) * g.nz + 4 * nn::kB * c.q;
 #pragma unroll
-    for (int x = 0; x < nn::kB; ++x) {
+      for (int x = 0; x < nn::kB; ++x) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) mytile[y * kTileRow + nn::kB * k + z] = ww[k][x];
-      const uint4 v = *reinterpret_cast<const uint4 *>(&mytile[y * kTileRow + 4 * z]);  // (LDS is in order within a wave)
-      *reinterpret_cast<uint4 *>(slab + loff4) = v;  // lane (y, z): row y of the slab, z-voxels 4 z .. 4 z + 3 of the quad
-      slab += plane;
+        for (int k = 0; k < 4; ++k) mytile[y * kTileRow + nn::kB * k + z] = ww[k][x];
+        const uint4 v = *reinterpret_cast<const uint4 *>(&mytile[y * kTileRow + 4 * z]);  // (LDS is in order within a wave)
+        *reinterpret_cast<uint4 *>(slab + loff4) = v;  // lane (y, z): row y of the slab, z-voxels 4 z .. 4 z + 3 of the quad
+        slab += plane;
+      }
+    } else {
+      // lane -> row (lane / 16) + 4 h of the slab, voxels 2 (lane % 16), + 1 of the quad's 32; the array's coordinates
+      const int srow = lane >> 4, spair = lane & 15;
+      const int X0 = nn::kB * (g.lx0 + c.cx) - g.fx, Y0 = nn::kB * (g.ly0 + c.cy) - g.fy;
+      const int Zq = nn::kB * (g.lz0 + 4 * c.q) + 2 * spair;  // region z of the pair (even; fz is even too)
+      const bool zin = (unsigned)(Zq - g.fz) < (unsigned)g.az && Zq < nn::kB * g.lz1;
+      const int64_t aplane = (int64_t)g.ay * g.az;
+      uint32_t *const mydump = a.dump + 2 * lane;
+#pragma unroll
+      for (int x = 0; x < nn::kB; ++x) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mytile[y * kTileRow + nn::kB * k + z] = ww[k][x];
+        const bool xin = (unsigned)(X0 + x) < (unsigned)g.ax;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = srow + 4 * h;
+          const uint2 v = *reinterpret_cast<const uint2 *>(&mytile[r * kTileRow + 2 * spair]);  // (LDS is in order within a wave)
+          const bool in = xin && zin && (unsigned)(Y0 + r) < (unsigned)g.ay;
+          uint32_t *dst = in ? a.coc + (int64_t)(X0 + x) * aplane + (int64_t)(Y0 + r) * g.az + (Zq - g.fz) : mydump;
+          *reinterpret_cast<uint2 *>(dst) = v;  // (always issued: the waits above count it)
+        }
+      }
     }
     c = nxt;
   }
