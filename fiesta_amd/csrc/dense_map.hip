@@ -1577,7 +1577,7 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
     if (b >= 64) fill_blocks = b; else full = false;
   }
   const dim3 cell_grid((lcz + 3) / 4, lcy, lcx);
-  // arrays at an offset of their region, pairs of voxels aligned: quads of cells, 8-byte stores (k_nn_fill_quads)
+  // arrays at an offset of their region, pairs of voxels aligned: the persistent fill with 8-byte stores (k_nn_fill_full<., true>)
   const bool pairs = !full && (a.g.az % 2) == 0 && (a.g.fz % 2) == 0;
   // (persistent waves there too: runs of at least four quads where the map has them)
   const int64_t nq_off = (int64_t)lcx * lcy * ((lcz + 3) / 4);

@@ -595,81 +595,4 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
   }
 }
 
-// The predicated variant for arrays that lie at an offset inside their region (a shard: owned box + ghost layers, cut by
-// cells on every side) but keep pairs of voxels aligned: an even number of voxels per row and an even z-offset.  A WAVE per
-// quad of cells as in k_nn_fill_full -- the four cells' winners in registers, then slab by slab through a 1.25 KB LDS tile --
-// with the records through the scalar cache as in k_nn_fill, and 8-byte stores: 16 lanes per 32-voxel row piece, four rows
-// per instruction (k_nn_fill's 4-byte stores put 32 bytes per row piece and instruction into memory: 1.45 x the time of the
-// full kernel on the same map).  grid: (ceil(quads / 4), ly1 - ly0, lx1 - lx0), quads = ceil((lz1 - lz0) / 4).
-template <bool TRACK>
-__global__ __launch_bounds__(256) void k_nn_fill_quads(NnArgs a) {
-  constexpr int kTileRow = 40;
-  __shared__ __attribute__((aligned(16))) uint32_t tile[4][nn::kB * kTileRow];
-  const nn::Geom &g = a.g;
-  if (*a.failed) return;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int q = (int)blockIdx.x * 4 + wave, cy = g.ly0 + (int)blockIdx.y, cx = g.lx0 + (int)blockIdx.z;
-  const int cz0 = g.lz0 + 4 * q;
-  if (cz0 < g.lz1) {  // (a wave beyond the range only goes to the closing barrier)
-  const int y = lane >> 3, z = lane & 7;
-  const uint32_t ayz = (uint32_t)y | ((uint32_t)z << 8);
-  uint32_t *const mytile = &tile[wave][0];
-  uint32_t ww[4][nn::kB];
-  uint32_t dmax = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int cz = min(cz0 + k, g.lz1 - 1);  // (a quad cut by the end of the range repeats its last cell: never stored)
-    const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
-    const uint32_t *rec = a.lists + cell * nn::kStride;
-    nn_cu32 *lp = reinterpret_cast<nn_cu32 *>(reinterpret_cast<uintptr_t>(rec));
-    const int cnt = (int)lp[0];
-    uint32_t best[nn::kB];
-#pragma unroll
-    for (int x = 0; x < nn::kB; ++x) best[x] = 0xFFFFFFFFu;
-    for (int i = 0; i < cnt; ++i) {
-      const nn_u32x4 e = *reinterpret_cast<nn_cu32x4 *>(lp + 4 + 4 * i);
-      uint32_t key = ((uint32_t)__builtin_amdgcn_sdot4((int)ayz, (int)e.x, 0, false) << nn::kSH) + e.y;
-      best[0] = min(best[0], key);
-#pragma unroll
-      for (int x = 1; x < nn::kB; ++x) {
-        key += e.z;
-        best[x] = min(best[x], key);
-      }
-    }
-    // is this lane's column of the cell inside the array?  (only those count for the distance bound)
-    const int Y = nn::kB * cy + y - g.fy, Z = nn::kB * cz + z - g.fz;
-    const bool inyz = cz0 + k < g.lz1 && (unsigned)Y < (unsigned)g.ay && (unsigned)Z < (unsigned)g.az;
-#pragma unroll
-    for (int x = 0; x < nn::kB; ++x) {
-      ww[k][x] = rec[7 + ((best[x] & 0x1F0u) >> 2)];
-      if (TRACK && inyz && (unsigned)(nn::kB * cx + x - g.fx) < (unsigned)g.ax)
-        dmax = max(dmax, (best[x] >> nn::kSH) - (uint32_t)nn::kBias + (uint32_t)(x * x + y * y + z * z));
-    }
-  }
-  // stores: lane -> row (lane / 16) + 4 h of the slab, voxels 2 (lane % 16), + 1 of the quad's 32
-  const int srow = lane >> 4, spair = lane & 15;
-  const int Zs = nn::kB * cz0 + 2 * spair - g.fz;  // (even: fz is)
-  const bool zin = (unsigned)Zs < (unsigned)g.az && nn::kB * cz0 + 2 * spair < nn::kB * g.lz1;
-  const int X0 = nn::kB * cx - g.fx, Y0 = nn::kB * cy - g.fy;
-  const int64_t plane = (int64_t)g.ay * g.az;
-#pragma unroll
-  for (int x = 0; x < nn::kB; ++x) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) mytile[y * kTileRow + nn::kB * k + z] = ww[k][x];
-    const bool xin = (unsigned)(X0 + x) < (unsigned)g.ax;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = srow + 4 * h;
-      const uint2 v = *reinterpret_cast<const uint2 *>(&mytile[r * kTileRow + 2 * spair]);  // (LDS is in order within a wave)
-      if (xin && zin && (unsigned)(Y0 + r) < (unsigned)g.ay)
-        *reinterpret_cast<uint2 *>(a.coc + (int64_t)(X0 + x) * plane + (int64_t)(Y0 + r) * g.az + Zs) = v;
-    }
-  }
-  if (TRACK) {
-    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
-    if (lane == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
-  }
-  }
-}
-
 }  // namespace fiesta
