@@ -69,9 +69,16 @@ __global__ void k_nn_close(NnArgs a) {
 // ---- sites by cell row ---------------------------------------------------------------------------------------------------
 // One batch of loads per wave: the 64 voxel rows of the cell row, a byte per lane and row (two on a 1024-voxel axis), kept
 // in registers for both halves -- counting, and after the wave's range of the site array is known, writing the sites.
+// ROWS (maps whose voxel rows are whole 16-byte pieces: nz a multiple of 128, the map's own bitmap): the same bytes arrive as
+// FOUR 16-byte loads per lane -- lane r takes voxel row r's 64 bytes of the chunk -- and are turned round in LDS (lane c then
+// reads byte c of each row: 64 ds_read_u8 from consecutive addresses) instead of 64 one-byte loads per lane, each a load
+// instruction of its own through the texture addresser.
 constexpr int kCellChunks = (nn::kRegionMax / nn::kB + 63) / 64;  // 64-cell chunks of the longest row of cells
+constexpr int kCellTileRow = 80;  // bytes between two voxel rows of a wave's tile (16-byte aligned, and 20 r spreads over the banks)
+template <bool ROWS>
 __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell rows per work-group, one per wave
   __shared__ uint32_t s_tot[16], s_start[16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tile[ROWS ? 16 * 64 * kCellTileRow : 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 16 + wave;
   const nn::Geom &g = a.g;
@@ -95,6 +102,25 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
       const uint8_t *row0 = reinterpret_cast<const uint8_t *>(a.occ) + (int64_t)(a.sx0 + nn::kB * cx) * xstride +
                             (int64_t)(a.sy0 + nn::kB * cy) * ystride + a.szb + (has ? c : 0);
       const int xin = g.nx - nn::kB * cx, yin = g.ny - nn::kB * cy;  // rows of the cell row inside the region (wave-uniform)
+      if constexpr (ROWS) {
+        const int rbytes = g.nz >> 3;  // bytes of a voxel row (a multiple of 16)
+        const bool rin = rlive && (lane >> 3) < xin && (lane & 7) < yin;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(a.occ) + (int64_t)(nn::kB * cx + (rin ? lane >> 3 : 0)) * xstride +
+                             (int64_t)(nn::kB * cy + (rin ? lane & 7 : 0)) * ystride + 64 * k;
+        uint8_t *t = s_tile + wave * (64 * kCellTileRow);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool pin = rin && 64 * k + 16 * j < rbytes;
+          const uint4 v = pin ? *reinterpret_cast<const uint4 *>(src + (pin ? 16 * j : 0)) : uint4{0u, 0u, 0u, 0u};
+          *reinterpret_cast<uint4 *>(t + lane * kCellTileRow + 16 * j) = v;
+        }
+        // (LDS is in order within a wave: the reads below see the writes above, the next chunk's writes come after these reads)
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+          const uint32_t m = has ? (uint32_t)t[r * kCellTileRow + lane] : 0u;
+          pk[k][r >> 2] |= m << (8 * (r & 3));
+        }
+      } else
 #pragma unroll
       for (int r = 0; r < 64; ++r) {
         const bool in = (r >> 3) < xin && (r & 7) < yin;
