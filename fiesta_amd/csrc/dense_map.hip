@@ -1557,8 +1557,8 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
     FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
   ft_counters_clean_ = false;
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[0], stream_));
-  // (whole 16-byte pieces of the map's own voxel rows: four wide loads per lane and a turn in LDS instead of 64 byte loads)
-  if (!g.sharded && g.nz % 128 == 0) hipLaunchKernelGGL(k_nn_cells<true>, dim3((unsigned)((nrows + 15) / 16)), dim3(1024), 0, stream_, a);
+  // (the region's rows start dword-aligned: four wide loads per lane and a turn in LDS instead of 64 byte loads)
+  if (a.szb % 4 == 0) hipLaunchKernelGGL(k_nn_cells<true>, dim3((unsigned)((nrows + 15) / 16)), dim3(1024), 0, stream_, a);
   else hipLaunchKernelGGL(k_nn_cells<false>, dim3((unsigned)((nrows + 15) / 16)), dim3(1024), 0, stream_, a);
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[1], stream_));

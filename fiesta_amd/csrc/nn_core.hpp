@@ -92,7 +92,7 @@ FIESTA_NN_HD inline bool region_geom(const int *G, const int *l0, const int *ln,
   int n[3], f[3], c0[3], c1[3], open = 0;
   for (int k = 0; k < 3; ++k) {
     int lo = l0[k] - mc;
-    lo = (lo < 0 ? 0 : lo) & ~(kB - 1);
+    lo = (lo < 0 ? 0 : lo) & ~((k == 2 ? 32 : kB) - 1);  // (z: whole 32-bit words of the bitmap's rows, so that wide loads stay dword-aligned)
     int hi = (l0[k] + ln[k] + mc + kB - 1) & ~(kB - 1);  // (exclusive)
     if (hi > G[k]) hi = G[k];
     rlo[k] = lo, n[k] = hi - lo, f[k] = l0[k] - lo;

@@ -69,8 +69,8 @@ __global__ void k_nn_close(NnArgs a) {
 // ---- sites by cell row ---------------------------------------------------------------------------------------------------
 // One batch of loads per wave: the 64 voxel rows of the cell row, a byte per lane and row (two on a 1024-voxel axis), kept
 // in registers for both halves -- counting, and after the wave's range of the site array is known, writing the sites.
-// ROWS (maps whose voxel rows are whole 16-byte pieces: nz a multiple of 128, the map's own bitmap): the same bytes arrive as
-// FOUR 16-byte loads per lane -- lane r takes voxel row r's 64 bytes of the chunk -- and are turned round in LDS (lane c then
+// ROWS (the region's first byte of a row dword-aligned: any unsharded map; a shard's region starts on whole bitmap words along
+// z): the same bytes arrive as FOUR 16-byte loads per lane -- lane r takes voxel row r's 64 bytes of the chunk -- and are turned round in LDS (lane c then
 // reads byte c of each row: 64 ds_read_u8 from consecutive addresses) instead of 64 one-byte loads per lane, each a load
 // instruction of its own through the texture addresser.
 constexpr int kCellChunks = (nn::kRegionMax / nn::kB + 63) / 64;  // 64-cell chunks of the longest row of cells
@@ -103,21 +103,33 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
                             (int64_t)(a.sy0 + nn::kB * cy) * ystride + a.szb + (has ? c : 0);
       const int xin = g.nx - nn::kB * cx, yin = g.ny - nn::kB * cy;  // rows of the cell row inside the region (wave-uniform)
       if constexpr (ROWS) {
-        const int rbytes = g.nz >> 3;  // bytes of a voxel row (a multiple of 16)
+        const int rbytes = (int)ystride - a.szb;  // bytes of the bitmap's row from the region's first byte on (loads stay inside the row)
         const bool rin = rlive && (lane >> 3) < xin && (lane & 7) < yin;
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(a.occ) + (int64_t)(nn::kB * cx + (rin ? lane >> 3 : 0)) * xstride +
-                             (int64_t)(nn::kB * cy + (rin ? lane & 7 : 0)) * ystride + 64 * k;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(a.occ) + (int64_t)(a.sx0 + nn::kB * cx + (rin ? lane >> 3 : 0)) * xstride +
+                             (int64_t)(a.sy0 + nn::kB * cy + (rin ? lane & 7 : 0)) * ystride + a.szb + 64 * k;
         uint8_t *t = s_tile + wave * (64 * kCellTileRow);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const bool pin = rin && 64 * k + 16 * j < rbytes;
-          const uint4 v = pin ? *reinterpret_cast<const uint4 *>(src + (pin ? 16 * j : 0)) : uint4{0u, 0u, 0u, 0u};
+          // (a piece that would leave the row is read dword by dword as far as the row goes: rows are whole dwords)
+          uint4 v{0u, 0u, 0u, 0u};
+          const int left = rin ? rbytes - (64 * k + 16 * j) : 0;
+          if (left >= 16 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+            v = *reinterpret_cast<const uint4 *>(src + 16 * j);  // (an unsharded map whose rows are whole 16-byte pieces)
+          } else if (left >= 16) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + 16 * j);  // dword-aligned: szb is a multiple of 4
+            v = uint4{p[0], p[1], p[2], p[3]};
+          } else if (left > 0) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + 16 * j);
+            v.x = p[0];
+            if (left > 4) v.y = p[1];
+            if (left > 8) v.z = p[2];
+          }
           *reinterpret_cast<uint4 *>(t + lane * kCellTileRow + 16 * j) = v;
         }
         // (LDS is in order within a wave: the reads below see the writes above, the next chunk's writes come after these reads)
 #pragma unroll
         for (int r = 0; r < 64; ++r) {
-          const uint32_t m = has ? (uint32_t)t[r * kCellTileRow + lane] : 0u;
+          const uint32_t m = has ? ((uint32_t)t[r * kCellTileRow + lane] & zmask) : 0u;
           pk[k][r >> 2] |= m << (8 * (r & 3));
         }
       } else
