@@ -203,3 +203,23 @@ def test_a_region_of_more_than_1024_voxels_stores_its_sites_modulo_1024(model):
         out, st = run_shard(model, occ, l0, ln, 40)
         assert st["failed"] == 0, (l0, st)
         check_shard_exact(occ, out, l0, ln)
+
+
+def test_sparse_scenes_within_seven_cells_of_reach(model):
+    """search windows reach 7 cells (nn_core.hpp: kKmax): scenes down to ~6e-5 of the voxels are served without a failed
+    cell -- the nearest obstacle of a cell's centre may be 50 voxels away -- and are exact"""
+    for dens, seed in ((6e-5, 7), (9e-5, 8), (1.3e-4, 9)):
+        occ = scatter((160, 152, 168), dens, seed)
+        out, st = run(model, occ)
+        assert st["failed"] == 0, (dens, st)
+        check_exact(occ, out)
+
+
+def test_a_shards_region_starts_on_whole_bitmap_words_along_z(model):
+    """the region's z-origin is a multiple of 32 (k_nn_cells reads the rows of the replica with dword-aligned wide loads), its
+    x / y origins multiples of 8; the array -- here at z = 45 -- is exact all the same"""
+    occ = scatter((96, 96, 200), 1.0e-3, 31)
+    l0, ln = (30, 22, 45), (40, 50, 90)
+    out, st = run_shard(model, occ, l0, ln, 40)
+    assert st["failed"] == 0, st
+    check_shard_exact(occ, out, l0, ln)
