@@ -206,13 +206,18 @@ def test_a_region_of_more_than_1024_voxels_stores_its_sites_modulo_1024(model):
 
 
 def test_sparse_scenes_within_seven_cells_of_reach(model):
-    """search windows reach 7 cells (nn_core.hpp: kKmax): scenes down to ~6e-5 of the voxels are served without a failed
-    cell -- the nearest obstacle of a cell's centre may be 50 voxels away -- and are exact"""
-    for dens, seed in ((6e-5, 7), (9e-5, 8), (1.3e-4, 9)):
+    """search windows reach 7 cells (nn_core.hpp: kKmax): scenes down to ~8e-5 of the voxels (where dense_map.hip starts to try
+    the transform) are served without a failed cell -- the nearest obstacle of a cell's centre may be 50 voxels away -- and
+    are exact; at 6e-5 the first cells fail (the GPU path then takes the envelope passes), every served voxel still exact"""
+    for dens, seed in ((9e-5, 8), (1.3e-4, 9)):
         occ = scatter((160, 152, 168), dens, seed)
         out, st = run(model, occ)
         assert st["failed"] == 0, (dens, st)
         check_exact(occ, out)
+    occ = scatter((160, 152, 168), 6e-5, 7)
+    out, st = run(model, occ)
+    assert 0 < st["failed"] < 20, st
+    check_exact(occ, out, served=out != 0x80000000)
 
 
 def test_a_shards_region_starts_on_whole_bitmap_words_along_z(model):
