@@ -57,7 +57,7 @@ def parse():
                          "2048^3 as 2x2x2 shards at N = 8 = config 5)")
     ap.add_argument("--obstacles", type=int, default=None,
                     help="live obstacle voxels per rank (default: config 2's density, 50000 per 512^3)")
-    ap.add_argument("--engine", default="auto", choices=["auto", "rounds", "bulk", "levels", "envelope", "cells"],
+    ap.add_argument("--engine", default="auto", choices=["auto", "rounds", "bulk", "levels", "envelope", "cells", "masked"],
                     help="UpdateESDF engine: chosen per update (default), frontier rounds only, or the bulk feature "
                          "transform whenever the map state allows it")
     ap.add_argument("--unobserved", type=float, default=0.0,
@@ -963,7 +963,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"{('C2' if G == 512 else 'C2 shape at another size') if world == 1 else 'C5 shape (per rank)'}: {G}^3 dense-array grid @0.1 m fully observed, {args.obstacles} "
+                "workload": f"{('C2' if G == 512 else 'C2 shape at another size') if world == 1 else 'C5 shape (per rank)'}: {G}^3 dense-array grid @0.1 m {'fully observed' if args.unobserved <= 0 else f'PARTIALLY observed ({args.unobserved:.0%} of its 32^3-voxel blocks never observed)'}, {args.obstacles} "
                             f"{'scattered' if args.scene == 'scatter' else 'surface (3 planes + 20 spheres)'} obstacle voxels, "
                             f"per step a {args.obstacles}-voxel delta = {args.obstacles // 2} inserts + {args.obstacles // 2} deletes "
                             "landing in one UpdateESDF (ingest: 3 SetOccupancy+UpdateOccupancy cycles, inputs resident in HBM)",

@@ -183,11 +183,11 @@ int fiesta_hip_set_original_range(fiesta_hip_map *m) {
 int fiesta_hip_set_update_engine(fiesta_hip_map *m, int32_t engine) {
   return guarded([&] {
     need(m != nullptr, "null map handle");
-    need(engine >= 0 && engine <= 5, "unknown update_engine");
+    need(engine >= 0 && engine <= 6, "unknown update_engine");
     if (m->dense)
       m->dense->set_update_engine(engine);
     else
-      m->hash->set_update_engine(engine > 3 ? 0 : engine);  // (no transform on a hash-block map: 2, 4 and 5 mean 0 there)
+      m->hash->set_update_engine(engine > 3 ? 0 : engine);  // (no transform on a hash-block map: 2, 4, 5 and 6 mean 0 there)
   });
 }
 

@@ -101,7 +101,7 @@ inline void checkpoint_header(DevFile &f, uint32_t mode, const Geom &g) {
   CheckpointHeader h, mine;
   memset(&mine, 0, sizeof(mine));
   memcpy(mine.magic, "FIESTAHP", 8);
-  mine.version = 4;  // 4: three list counters (dense_map.hpp, C_LIST2)
+  mine.version = 5;  // 5: the late-observation marks and their counter (dense_map.hpp, C_LATE); 4: three list counters
   mine.mode = mode;
   mine.grid[0] = g.nx, mine.grid[1] = g.ny, mine.grid[2] = g.nz;
   if (mode == FIESTA_HIP_MODE_ARRAY) mine.shard_lo[0] = g.gx0, mine.shard_lo[1] = g.gy0, mine.shard_lo[2] = g.gz0;

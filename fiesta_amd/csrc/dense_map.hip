@@ -26,6 +26,7 @@
 #include "checkpoint.hpp"
 #include "ft_kernels.hpp"
 #include "nn_kernels.hpp"
+#include "mask_kernels.hpp"
 #include "level_kernels.hpp"
 #include "relax_kernels.hpp"
 
@@ -168,7 +169,7 @@ __global__ void k_observe_pos(Geom g, const double *pos, const int32_t *occ, int
 // UpdateOccupancy for one touched voxel (src/ESDFMap.cpp:239-267); reports a transition, does not queue it.
 __device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_map, uint32_t idx,
                                      unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits,
-                                     uint32_t *gocc, bool &to_ins, bool &to_del, bool &first_obs) {
+                                     uint32_t *gocc, uint32_t *obsbits, bool &to_ins, bool &to_del, bool &first_obs) {
   const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
   const unsigned long long c = cnt[idx];
   cnt[idx] = 0;  // num_hit_ = num_miss_ = 0 (:245)
@@ -179,6 +180,7 @@ __device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_
   if (coc[idx] == kUnobserved) {  // first observation: -10000 -> +10000 (:246-249)
     coc[idx] = kInf;
     first_obs = true;
+    atomicOr(&obsbits[g.bitword(x, y, z)], 1u << (z & 31));
   }
   if ((step >= 0 && L >= pp.l_max) || (step <= 0 && L <= pp.l_min)) return;  // already clamped (:250-255)
   if (!global_map && !g.in_prev_window(x, y, z)) {  // local-map reset (:256-259): distance = infinity, the link stays
@@ -206,16 +208,19 @@ __device__ inline void fuse_one(const Geom &g, const ProbParams &pp, int global_
 // list's counter: UpdateOccupancy is then two launches and one synchronisation (r04: + a counter-reset kernel + a copy).
 __global__ __launch_bounds__(256) void k_fuse(Geom g, ProbParams pp, int global_map, const uint32_t *touched, int64_t n,
                                               unsigned long long *cnt, double *logodds, vox_t *coc, uint32_t *occbits, uint32_t *gocc,
+                                              uint32_t *obsbits, uint32_t *latebits, int late_matters,
                                               uint32_t *ins, uint32_t *del, unsigned long long *counters, unsigned long long *result) {
   __shared__ uint32_t s_app[18];
   __shared__ uint32_t s_obs;
+  __shared__ int s_late;
   if (n < 0) n = (int64_t)counters[C_TOUCHED];  // the host only knows an upper bound (it sized the grid with it)
   // work-groups beyond the list leave at once and take no ticket (a depth frame's upper bound is millions of voxels, its list
   // tens of thousands: 8192 idle groups queueing for the ticket cost 0.16 ms)
   const unsigned long long nwork = (unsigned long long)max((int64_t)1, min((int64_t)gridDim.x, (n + blockDim.x - 1) / blockDim.x));
   if (blockIdx.x >= nwork) return;
-  if (threadIdx.x == 0) s_obs = 0;
+  if (threadIdx.x == 0) s_obs = 0, s_late = 0;
   long long nocc = 0;  // (thread 0's: inserts - deletes of the group)
+  __syncthreads();
   // whole work-groups stride over the list (the appends below need every thread of the group in the same iteration)
   for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = i0 + threadIdx.x;
@@ -223,7 +228,17 @@ __global__ __launch_bounds__(256) void k_fuse(Geom g, ProbParams pp, int global_
     uint32_t idx = 0;
     if (i < n) {
       idx = touched[i];
-      fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, to_ins, to_del, first_obs);
+      fuse_one(g, pp, global_map, idx, cnt, logodds, coc, occbits, gocc, obsbits, to_ins, to_del, first_obs);
+      // late observations (see C_LATE): marked when first seen while obstacles exist, healed when the voxel becomes one
+      const int z = idx % g.nz, y = (idx / g.nz) % g.ny, x = idx / (g.nz * g.ny);
+      const uint32_t bit = 1u << (z & 31);
+      if (first_obs && late_matters && !to_ins) {
+        atomicOr(&latebits[g.bitword(x, y, z)], bit);
+        atomicAdd(&s_late, 1);
+      } else if (to_ins && !first_obs && (latebits[g.bitword(x, y, z)] & bit)) {
+        atomicAnd(&latebits[g.bitword(x, y, z)], ~bit);
+        atomicAdd(&s_late, -1);
+      }
     }
     // queue appends: ONE atomic per work-group, pass and queue (block_append)
     const uint32_t ni = block_append(to_ins, idx, ins, &counters[C_INSERT], s_app);
@@ -237,11 +252,13 @@ __global__ __launch_bounds__(256) void k_fuse(Geom g, ProbParams pp, int global_
   if (threadIdx.x == 0) {
     if (s_obs) atomicAdd(&counters[C_OBSERVED], (unsigned long long)s_obs);
     if (nocc) atomicAdd(&counters[C_NOCC], (unsigned long long)nocc);
+    if (s_late) atomicAdd(&counters[C_LATE], (unsigned long long)(long long)s_late);
     if (result) {
       __threadfence();
       if (atomicAdd(&counters[C_FUSE_TICKET], 1ull) == nwork - 1ull) {  // everybody else is done
         __threadfence();
         for (int k = 0; k < 4; ++k) result[k] = atomicAdd(&counters[C_INSERT + k], 0ull);
+        result[C_LATE - C_INSERT] = atomicAdd(&counters[C_LATE], 0ull);
         counters[C_TOUCHED] = 0;
         counters[C_FUSE_TICKET] = 0;
         __threadfence_system();
@@ -931,7 +948,7 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   g.oz1 = glo[2] + gs[2] - 1;
   nbitwords_ = (int64_t)g.nx * g.ny * g.nzw;
 
-  if (cfg.update_engine < 0 || cfg.update_engine > 5) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
+  if (cfg.update_engine < 0 || cfg.update_engine > 6) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
   update_engine_ = cfg.update_engine;
   ntx_ = (g.nx + tx_ - 1) / tx_;
   nty_ = (g.ny + ty_ - 1) / ty_;
@@ -946,6 +963,10 @@ DenseMap::DenseMap(const fiesta_hip_config &cfg) {
   FIESTA_HIP_CHECK(hipMalloc((void **)&cnt_, g.n * sizeof(unsigned long long)));
   FIESTA_HIP_CHECK(hipMalloc((void **)&occbits_, nbitwords_ * sizeof(uint32_t)));
   FIESTA_HIP_CHECK(hipMalloc((void **)&rbits_, nbitwords_ * sizeof(uint32_t)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&obsbits_, nbitwords_ * sizeof(uint32_t)));
+  FIESTA_HIP_CHECK(hipMalloc((void **)&latebits_, nbitwords_ * sizeof(uint32_t)));
+  FIESTA_HIP_CHECK(hipMemsetAsync(obsbits_, 0, nbitwords_ * sizeof(uint32_t), stream_));
+  FIESTA_HIP_CHECK(hipMemsetAsync(latebits_, 0, nbitwords_ * sizeof(uint32_t), stream_));
   if (sharded) {
     ngoccwords_ = (int64_t)g.GX * g.GY * g.GZW;
     FIESTA_HIP_CHECK(hipMalloc((void **)&gocc_, ngoccwords_ * sizeof(uint32_t)));
@@ -996,10 +1017,12 @@ DenseMap::~DenseMap() {
   free_raycast_state();
   void *ptrs[] = {coc_,          logodds_,      cnt_,          occbits_,      rbits_,     tile_epoch_,
                   tile_flag_[0], tile_flag_[1], tile_list_[0], tile_list_[1], counters_,  cbits_[0],
-                  cbits_[1],     cstamp_[0],    cstamp_[1],    gocc_};
+                  cbits_[1],     cstamp_[0],    cstamp_[1],    gocc_,         obsbits_,   latebits_,
+                  mask_ctr_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
+  if (h_mask_ctr_) (void)hipHostFree(h_mask_ctr_);
   delete bricks_;
   delete lv_;
   if (lv_done_) (void)hipEventDestroy(lv_done_);
@@ -1166,8 +1189,8 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
     ins_.ensure(ni + nt, stream_, ni);
     del_.ensure(nd + nt, stream_, nd);
     hipLaunchKernelGGL(k_fuse, dim3(grid_for((int64_t)nt, 256, 8192)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
-                       (const uint32_t *)touched_.p, (int64_t)-1, cnt_, logodds_, coc_, occbits_, gocc_, ins_.p,
-                       del_.p, counters_, &h_counters_[C_INSERT]);  // (its last work-group writes the four results into h_counters_)
+                       (const uint32_t *)touched_.p, (int64_t)-1, cnt_, logodds_, coc_, occbits_, gocc_, obsbits_, latebits_,
+                       (nocc_before > 0 || ni > 0 || nd > 0) ? 1 : 0, ins_.p, del_.p, counters_, &h_counters_[C_INSERT]);  // (its last work-group writes the four results into h_counters_)
     FIESTA_HIP_CHECK(hipGetLastError());
     touched_upper_ = 0;
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1383,7 +1406,7 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   if (g.sharded) {
     a.src = gocc_, a.sx0 = rlo[0], a.sy0 = rlo[1], a.sw0 = rlo[2] / 32, a.sny = g.GY, a.snzw = g.GZW;
   } else {
-    a.src = occbits_, a.sx0 = 0, a.sy0 = 0, a.sw0 = 0, a.sny = g.ny, a.snzw = g.nzw;
+    a.src = tr_occ_ ? tr_occ_ : occbits_, a.sx0 = 0, a.sy0 = 0, a.sw0 = 0, a.sny = g.ny, a.snzw = g.nzw;
   }
   a.ox0 = mlo[0], a.oy0 = mlo[1], a.oz0 = mlo[2];
   a.onx = g.nx, a.ony = g.ny, a.onz = g.nz;
@@ -1409,8 +1432,8 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   // shard between try and commit (an allocation failing there) must find this shard's field untouched
   ft_in_place_ = !g.sharded || (!open_side && alone_in_group_);
   if (!ft_in_place_) ft_out_.ensure_exact((size_t)g.n, stream_);
-  a.coc = ft_in_place_ ? coc_ : ft_out_.p;
-  const bool want_max = track_ || open_side;
+  a.coc = tr_out_ ? tr_out_ : ft_in_place_ ? coc_ : ft_out_.p;  // (tr_out_: a masked transform's side buffer, run_masked)
+  const bool want_max = (track_ && !tr_out_) || open_side;
   a.maxd2 = want_max ? &counters_[C_FT_MAXD2] : nullptr;
   if (!ft_counters_clean_)  // (a second run within one update: the spill counters of the first are still there)
     FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
@@ -1460,7 +1483,7 @@ bool DenseMap::run_bulk(fiesta_hip_stats *st, int margin, bool *exact) {
   }
   if (want_max) {
     const unsigned long long dmax2 = read_counter(C_FT_MAXD2);
-    if (track_) {
+    if (track_ && !tr_out_) {
       h_counters_[C_MAXD2] = dmax2;
       FIESTA_HIP_CHECK(hipMemcpyAsync(&counters_[C_MAXD2], &h_counters_[C_MAXD2], sizeof(unsigned long long), hipMemcpyHostToDevice, stream_));
     }
@@ -1525,7 +1548,8 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   } else {
     if ((g.gx0 | g.gy0 | g.gz0) != 0) return false;
     a.g = nn::whole_geom(g.nx, g.ny, g.nz);
-    a.occ = occbits_, a.sny = g.ny, a.snzw = g.nzw;
+    a.occ = tr_occ_ ? tr_occ_ : occbits_, a.sny = g.ny, a.snzw = g.nzw;
+    a.cellobs = tr_cellobs_;  // (a masked transform: cells nobody ever observed get no list)
   }
   const int64_t nrows = (int64_t)a.g.ncx * a.g.ncy, ncells = nrows * a.g.ncz;
   // sites: the obstacles of the region -- an unsharded map knows the count (k_fuse keeps it exact); a shard's region also
@@ -1542,12 +1566,12 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   a.dump = nn_lists_.p + (size_t)ncells * nn::kStride + (kListPad - 128);
   a.cursor = &counters_[C_NN_CURSOR], a.failed = &counters_[C_NN_FAILED], a.entries = &counters_[C_NN_ENTRIES];
   // (the largest distance written: maps that track it, and shards -- the group sizes the next margin from it)
-  const bool want_max = track_ || open_side;
+  const bool want_max = (track_ && !tr_out_) || open_side;
   a.maxd2 = want_max ? &counters_[C_FT_MAXD2] : nullptr;
   // a shard's transform lands in a side buffer unless nobody else has a say (run_bulk)
   ft_in_place_ = !g.sharded || (!open_side && alone_in_group_);
   if (!ft_in_place_) ft_out_.ensure_exact((size_t)g.n, stream_);
-  a.coc = ft_in_place_ ? coc_ : ft_out_.p;
+  a.coc = tr_out_ ? tr_out_ : ft_in_place_ ? coc_ : ft_out_.p;  // (tr_out_: a masked transform's side buffer, run_masked)
   if (publish) {  // a last one-thread launch reports into h_counters_ and cleans up (nn_kernels.hpp: k_nn_close)
     a.pub = h_counters_, a.queues = &counters_[C_INSERT], a.track_dst = track_ ? &counters_[C_MAXD2] : nullptr;
     a.tag = ++nn_tag_;
@@ -1599,7 +1623,7 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
     hipLaunchKernelGGL(k_nn_close, dim3(1), dim3(1), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
   }
-  if (track_ && !publish)  // (a failed transform leaves 0 here; the envelope passes that follow it set the bound themselves)
+  if (track_ && !publish && !tr_out_)  // (a failed transform leaves 0 here; the envelope passes that follow it set the bound themselves)
     FIESTA_HIP_CHECK(hipMemcpyAsync(&counters_[C_MAXD2], &counters_[C_FT_MAXD2], sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
   if (st) {
     st->bulk = 1;
@@ -1639,6 +1663,204 @@ bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
     if (read_counter(C_SCRATCH) == 0 || (!g.sharded && before <= 0)) stale_inf_ = false;
   }
   return !stale_inf_;
+}
+
+// ---- the masked transform (mask_kernels.hpp): large deltas on partially observed maps -------------------------------------------
+// May this update be served by it?  The same history conditions as the transform of a fully observed map (bulk_eligible: whole
+// window, no update under a partial window since the map last held no obstacle) -- and no voxel still waiting for its first
+// wave: a voxel first observed while obstacles existed reads "no obstacle" in the reference until a wave reaches it
+// (src/ESDFMap.cpp:246-249), which no function of (occupied set, observed set) reproduces.  k_fuse marks and counts such voxels
+// (C_LATE, latebits_); the count falls when one of them becomes an obstacle (the insert drain seeds it) and, found by a rescan
+// here, when a wave has given it an obstacle.
+bool DenseMap::masked_eligible(unsigned long long ni, unsigned long long nd) {
+  const Geom &g = g_;
+  if (g.sharded || g.wrap || update_engine_ == 1 || update_engine_ == 3) return false;
+  if (g.nx > nn::kRegionMax || g.ny > nn::kRegionMax || g.nz > nn::kRegionMax) return false;
+  if (!(g.wx0 <= 0 && g.wy0 <= 0 && g.wz0 <= 0 && g.wx1 >= g.nx - 1 && g.wy1 >= g.ny - 1 && g.wz1 >= g.nz - 1)) return false;
+  if (win_dirty_) return false;  // (update_esdf has cleared it if the map held no obstacle before this update)
+  const long long before = (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd;
+  unsigned long long late = h_counters_[C_LATE];
+  if (late != 0 && before <= 0) {
+    // no obstacle before this update: every voxel legitimately reads "no obstacle", nobody waits for anything
+    FIESTA_HIP_CHECK(hipMemsetAsync(latebits_, 0, nbitwords_ * sizeof(uint32_t), stream_));
+    zero_counter(C_LATE);
+    h_counters_[C_LATE] = late = 0;
+  }
+  if (late != 0) {  // has a wave reached them since?
+    hipLaunchKernelGGL(k_late_rescan, dim3(grid_for(nbitwords_, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_,
+                       (const uint32_t *)occbits_, latebits_, nbitwords_, &counters_[C_LATE]);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    h_counters_[C_LATE] = late = read_counter(C_LATE);
+  }
+  return late == 0;
+}
+
+// One UpdateESDF by the masked transform.  Everything is launched behind one another -- summary of the observed bitmap, the
+// sites, the transform into the side buffer, the certificate, a first chain of repair iterations -- and read back ONCE; further
+// chains only if the repair has not settled.  Returns false with the field untouched (the side buffer is simply dropped) if the
+// repair list outgrew its buffer: the caller's frontier rounds then serve the update.
+bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
+  const Geom &g = g_;
+  const int ncx = (g.nx + 7) / 8, ncy = (g.ny + 7) / 8, ncz = (g.nz + 7) / 8;
+  const int64_t ncells = (int64_t)ncx * ncy * ncz;
+  if (!mask_ctr_) {
+    FIESTA_HIP_CHECK(hipMalloc((void **)&mask_ctr_, MC_COUNT * sizeof(unsigned long long)));
+    FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_mask_ctr_, MC_COUNT * sizeof(unsigned long long)));
+  }
+  const size_t ucap = (size_t)std::max<int64_t>(g.n / 8, 1 << 16);
+  effocc_.ensure_exact((size_t)nbitwords_, stream_);
+  cellobs_.ensure_exact((size_t)ncells, stream_);
+  mask_out_.ensure_exact((size_t)g.n, stream_);
+  mask_ulist_.ensure_exact(ucap, stream_);
+  mask_uval_.ensure_exact(ucap, stream_);
+  if (mask_cstamp_.cap < (size_t)ncells) {
+    mask_cstamp_.ensure_exact((size_t)ncells, stream_);
+    FIESTA_HIP_CHECK(hipMemsetAsync(mask_cstamp_.p, 0, (size_t)ncells * sizeof(uint32_t), stream_));
+    mask_serial_ = 0;
+  }
+  if (mask_serial_ > 0xFFFF0000u) {  // (tags never repeat within the stamps' lifetime)
+    FIESTA_HIP_CHECK(hipMemsetAsync(mask_cstamp_.p, 0, (size_t)ncells * sizeof(uint32_t), stream_));
+    mask_serial_ = 0;
+  }
+  MaskArgs ma;
+  memset(&ma, 0, sizeof(ma));
+  ma.g = g, ma.ncx = ncx, ma.ncy = ncy, ma.ncz = ncz;
+  ma.occbits = occbits_, ma.obsbits = obsbits_, ma.effocc = effocc_.p, ma.cellobs = cellobs_.p;
+  ma.old = coc_, ma.out = mask_out_.p;
+  ma.ulist = mask_ulist_.p, ma.uval = mask_uval_.p, ma.ucap = (uint32_t)std::min<size_t>(ucap, 0xFFFFFFFFu);
+  ma.cstamp = mask_cstamp_.p, ma.ctr = mask_ctr_;
+  FIESTA_HIP_CHECK(hipMemsetAsync(mask_ctr_, 0, MC_COUNT * sizeof(unsigned long long), stream_));
+  hipLaunchKernelGGL(k_obs_cells, dim3(grid_for((int64_t)ncx * ncy * g.nzw, 4, 16384)), dim3(256), 0, stream_, g_, ncx, ncy, ncz,
+                     (const uint32_t *)obsbits_, cellobs_.p);
+  hipLaunchKernelGGL(k_eff_occ, dim3(grid_for(nbitwords_, 256, 8192)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
+                     (const uint32_t *)obsbits_, effocc_.p, nbitwords_);
+  FIESTA_HIP_CHECK(hipGetLastError());
+  struct Restore {  // (the transforms read and write the masked transform's buffers only while it runs)
+    DenseMap *m;
+    ~Restore() { m->tr_occ_ = nullptr, m->tr_out_ = nullptr, m->tr_cellobs_ = nullptr; }
+  } restore{this};
+  tr_occ_ = effocc_.p, tr_out_ = mask_out_.p, tr_cellobs_ = cellobs_.p;
+  const int certify_blocks = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)ncx * ncy * g.nzw + 3) / 4, 1), 768);
+  const int repair_blocks = 2048;
+  int iters_done = 0;  // repair iterations of this update launched so far
+  auto launch_chain = [&](const int n, const unsigned long long *failed) {
+    MaskArgs a = ma;
+    a.failed = failed;
+    for (int k = 0; k < n; ++k) {
+      const uint32_t tag = ++mask_serial_;
+      hipLaunchKernelGGL(k_repair_pull, dim3(repair_blocks), dim3(256), 0, stream_, a, k, tag - 1u, iters_done == 0 ? 1 : 0);
+      hipLaunchKernelGGL(k_repair_commit, dim3(repair_blocks), dim3(256), 0, stream_, a, k, tag);
+      ++iters_done;
+    }
+    FIESTA_HIP_CHECK(hipGetLastError());
+  };
+  bool cells = false;
+  hipEvent_t ev_cert = pool_event(0), ev_rep = pool_event(1), ev_end = pool_event(2);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    cells = attempt == 0 && cells_wanted() && run_cells(st, 0, /*publish=*/false);
+    if (!cells) {
+      bool exact = true;
+      if (!run_bulk(st, 0, &exact)) return false;
+    }
+    const unsigned long long *failed = cells ? &counters_[C_NN_FAILED] : nullptr;
+    MaskArgs a = ma;
+    a.failed = failed;
+    FIESTA_HIP_CHECK(hipEventRecord(ev_cert, stream_));
+    hipLaunchKernelGGL(k_mask_certify, dim3(certify_blocks), dim3(256), 0, stream_, a);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    FIESTA_HIP_CHECK(hipEventRecord(ev_rep, stream_));
+    iters_done = 0;
+    launch_chain(std::min(std::max(mask_chain_hint_, 2), kMaskIters), failed);
+    FIESTA_HIP_CHECK(hipEventRecord(ev_end, stream_));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(h_mask_ctr_, mask_ctr_, MC_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    if (cells) FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_FT_OVF0], &counters_[C_FT_OVF0], 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    if (!cells || h_counters_[C_NN_FAILED] == 0) {
+      if (cells) nn_fail_streak_ = 0;
+      break;
+    }
+    // a cell without a list: nothing was written, certified or repaired -- the envelope passes provide T
+    nn_fail_streak_ = std::min(nn_fail_streak_ + 1, 6);
+    nn_skip_ = 4 << nn_fail_streak_;
+    const int64_t nfailed = (int64_t)h_counters_[C_NN_FAILED];
+    reset_stats_counters(/*lists=*/true);
+    if (st) {
+      memset(&st->cells, 0, sizeof(st->cells));
+      st->nn_failed = nfailed;
+    }
+  }
+  float m1 = 0, m2 = 0, m3 = 0, mc = 0, mr = 0;
+  (void)hipEventElapsedTime(&m1, ft_ev_[0], ft_ev_[1]);
+  (void)hipEventElapsedTime(&m2, ft_ev_[1], ft_ev_[2]);
+  (void)hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]);
+  (void)hipEventElapsedTime(&mc, ev_cert, ev_rep);
+  (void)hipEventElapsedTime(&mr, ev_rep, ev_end);
+  const unsigned long long nu = h_mask_ctr_[MC_ULIST];
+  if (nu > ma.ucap) return false;  // (nothing is committed: coc_ still holds the field as it was)
+  // the repair: further chains until an iteration changes nothing
+  int total_iters = 0;
+  {
+    int n = iters_done;
+    for (;;) {
+      int k = 0;
+      while (k < n && h_mask_ctr_[MC_CHANGED0 + k] != 0) ++k;
+      total_iters += k < n ? k + 1 : n;
+      if (k < n || nu == 0) break;
+      // (the chain's last iteration still changed something)
+      FIESTA_HIP_CHECK(hipMemsetAsync(&mask_ctr_[MC_CHANGED0], 0, kMaskIters * sizeof(unsigned long long), stream_));
+      FIESTA_HIP_CHECK(hipEventRecord(ev_rep, stream_));
+      n = 8;
+      {  // a continuation: its first iteration looks at the stamps of the chain before
+        MaskArgs a = ma;
+        for (int j = 0; j < n; ++j) {
+          const uint32_t tag = ++mask_serial_;
+          hipLaunchKernelGGL(k_repair_pull, dim3(repair_blocks), dim3(256), 0, stream_, a, j, tag - 1u, 0);
+          hipLaunchKernelGGL(k_repair_commit, dim3(repair_blocks), dim3(256), 0, stream_, a, j, tag);
+        }
+        FIESTA_HIP_CHECK(hipGetLastError());
+      }
+      FIESTA_HIP_CHECK(hipEventRecord(ev_end, stream_));
+      FIESTA_HIP_CHECK(hipMemcpyAsync(&h_mask_ctr_[MC_CHANGED0], &mask_ctr_[MC_CHANGED0], kMaskIters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+      FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+      float more = 0;
+      (void)hipEventElapsedTime(&more, ev_rep, ev_end);
+      mr += more;
+    }
+  }
+  mask_chain_hint_ = std::min(total_iters + 2, kMaskIters);
+  // commit: the side buffer BECOMES the field (every user of the field takes the pointer at call time, in stream order)
+  std::swap(coc_, mask_out_.p);
+  zero_counters(C_INSERT, 2);  // both queues are drained
+  host_counts_[0] = host_counts_[1] = 0;
+  queues_zeroed_ = false;
+  if (track_) {  // the distance bound of the delete scan: repaired voxels may lie farther than anything the transform wrote
+    zero_counter(C_MAXD2);
+    hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);
+    FIESTA_HIP_CHECK(hipGetLastError());
+  }
+  FIESTA_HIP_CHECK(hipEventRecord(ev1_, stream_));
+  FIESTA_HIP_CHECK(hipEventSynchronize(ev1_));
+  h_counters_fresh_ = false;
+  if (cells) nn_last_ms_ = (double)m1 + m2 + m3, nn_last_nocc_ = (long long)h_counters_[C_NOCC];
+  else ft_last_ms_ = (double)m1 + m2 + m3;
+  if (st) {
+    float ms = 0;
+    FIESTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    st->device_ms = ms;
+    st->bulk = 1, st->cells = cells ? 1 : 0, st->masked = 1;
+    if (cells) {
+      st->nn_cells_ms = m1, st->nn_lists_ms = m2, st->nn_fill_ms = m3;
+      st->nn_entries = (int64_t)h_counters_[C_NN_ENTRIES];
+    } else {
+      st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
+    }
+    st->mask_certify_ms = mc, st->mask_repair_ms = mr;
+    st->mask_uncertified = (int64_t)nu, st->mask_iterations = total_iters, st->mask_walks = (int64_t)h_mask_ctr_[MC_WALKS];
+    st->relax_ms = (double)m1 + m2 + m3 + mc + mr;
+    st->relax_launches = 3 + 1 + 2 * total_iters;
+    st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+  }
+  return true;
 }
 
 // The cost half of the engine choice, from the measured crossover (profiles/r03a_delta_sweep.json: C2's map, both scenes,
@@ -1887,8 +2109,9 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
   if (host_counts_valid_) {  // (what UpdateOccupancy read last: nothing else changes these four)
     for (int k = 0; k < 4; ++k) h_counters_[C_INSERT + k] = host_counts_[k];
   } else {
-    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], 4 * sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, stream_));  // C_INSERT, C_DELETE, C_OBSERVED, C_NOCC
+    static_assert(C_LATE > C_NOCC, "counter layout");
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_INSERT], &counters_[C_INSERT], (C_LATE - C_INSERT + 1) * sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, stream_));  // C_INSERT, C_DELETE, C_OBSERVED, C_NOCC ... C_LATE
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   }
   const unsigned long long ni = h_counters_[C_INSERT], nd = h_counters_[C_DELETE];
@@ -1926,6 +2149,23 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
                           (update_engine_ == 3 || (!gate_open && ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kInsertCap));
   const bool try_bulk = gate_open && (bulk_pinned() || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
   bool counters_reset = false;
+  // A partially observed map (every map a sensor builds): a delta too large for the level engine goes to the masked transform
+  // (mask_kernels.hpp) where the map's history allows it -- a fixed sweep like the other transforms -- instead of the rounds.
+  if (!seed_only && !gate_open && !try_bulk && (long long)h_counters_[C_OBSERVED] < g_.n &&
+      (update_engine_ == 6 || (!try_levels && (update_engine_ == 0 || bulk_pinned()) &&
+                               bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n))) &&
+      masked_eligible(ni, nd)) {
+    reset_stats_counters(/*lists=*/true);
+    counters_reset = true;
+    if (run_masked(st, h0)) return;
+    if (st) {
+      const fiesta_hip_stats keep = *st;
+      memset(st, 0, sizeof(*st));
+      st->inserted = keep.inserted, st->deleted = keep.deleted, st->observed_voxels = keep.observed_voxels, st->occupied_voxels = keep.occupied_voxels;
+    }
+    FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+    reset_stats_counters(/*lists=*/true);
+  }
   if (try_bulk) {
     // (an unsharded map's transform cannot fail to serve the update -- the envelope passes stand behind the cell transform --
     //  so the two queue lengths go in the same launch as the statistics)
@@ -2302,6 +2542,10 @@ void DenseMap::snapshot_save(int slot) {
   FIESTA_HIP_CHECK(hipMemcpyAsync(s.logodds.p, logodds_, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
   FIESTA_HIP_CHECK(hipMemcpyAsync(s.cnt.p, cnt_, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
   FIESTA_HIP_CHECK(hipMemcpyAsync(s.occbits.p, occbits_, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  s.obsbits.ensure(nbitwords_, stream_);
+  s.latebits.ensure(nbitwords_, stream_);
+  FIESTA_HIP_CHECK(hipMemcpyAsync(s.obsbits.p, obsbits_, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(s.latebits.p, latebits_, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
   if (gocc_) {
     s.gocc.ensure(ngoccwords_, stream_);
     FIESTA_HIP_CHECK(hipMemcpyAsync(s.gocc.p, gocc_, ngoccwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
@@ -2337,6 +2581,8 @@ void DenseMap::snapshot_restore(int slot) {
   FIESTA_HIP_CHECK(hipMemcpyAsync(logodds_, s.logodds.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
   FIESTA_HIP_CHECK(hipMemcpyAsync(cnt_, s.cnt.p, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream_));
   FIESTA_HIP_CHECK(hipMemcpyAsync(occbits_, s.occbits.p, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(obsbits_, s.obsbits.p, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+  FIESTA_HIP_CHECK(hipMemcpyAsync(latebits_, s.latebits.p, nbitwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
   if (gocc_) FIESTA_HIP_CHECK(hipMemcpyAsync(gocc_, s.gocc.p, ngoccwords_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
   const size_t nt = s.counters[C_TOUCHED], ni = s.counters[C_INSERT], nd = s.counters[C_DELETE];
   if (nt) {
@@ -2405,9 +2651,9 @@ void DenseMap::checkpoint(const char *path, bool write) {
     for (int k = 0; k < 3; ++k)  // (windows are voxel coordinates of Pos2Vox of clamped positions: a few voxels around the array at most)
       if (wlo[k] < -4 || whi[k] > 4096 + 4 || plo[k] < -4 || phi[k] > 4096 + 4) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: update range of the file is out of bounds");
     if (nt > (size_t)g_.n || ni > (size_t)g_.n || nd > (size_t)g_.n) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: queue lengths of the file exceed the grid");
-    const unsigned long long sections = 7 + (gocc_ ? 1 : 0);
+    const unsigned long long sections = 8 + (gocc_ ? 1 : 0);
     const unsigned long long expect = f.position() + sections * sizeof(unsigned long long) + (unsigned long long)g_.n * (sizeof(vox_t) + sizeof(double) + sizeof(unsigned long long)) +
-                                      (unsigned long long)nbitwords_ * sizeof(uint32_t) + (gocc_ ? (unsigned long long)ngoccwords_ * sizeof(uint32_t) : 0ull) +
+                                      2ull * (unsigned long long)nbitwords_ * sizeof(uint32_t) + (gocc_ ? (unsigned long long)ngoccwords_ * sizeof(uint32_t) : 0ull) +
                                       (unsigned long long)(nt + ni + nd) * sizeof(uint32_t);
     if (f.file_size() != expect) throw Error(FIESTA_HIP_ERR_INVALID, "checkpoint: file size does not match its header (truncated or corrupt)");
     touched_.ensure(nt, stream_);
@@ -2418,6 +2664,7 @@ void DenseMap::checkpoint(const char *path, bool write) {
   f.device(logodds_, (size_t)g_.n * sizeof(double));
   f.device(cnt_, (size_t)g_.n * sizeof(unsigned long long));
   f.device(occbits_, (size_t)nbitwords_ * sizeof(uint32_t));
+  f.device(latebits_, (size_t)nbitwords_ * sizeof(uint32_t));
   if (gocc_) f.device(gocc_, (size_t)ngoccwords_ * sizeof(uint32_t));
   f.device(touched_.p, nt * sizeof(uint32_t));
   f.device(ins_.p, ni * sizeof(uint32_t));
@@ -2434,6 +2681,9 @@ void DenseMap::checkpoint(const char *path, bool write) {
   stale_inf_ = flags[0] != 0;
   win_dirty_ = flags[2] != 0;
   host_counts_valid_ = false;
+  // (the observed bitmap is the field's own: a word other than "never observed")
+  hipLaunchKernelGGL(k_obs_rebuild, dim3(grid_for(nbitwords_, 256, 8192)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, obsbits_, nbitwords_);
+  FIESTA_HIP_CHECK(hipGetLastError());
   if (track_) {
     zero_counter(C_MAXD2);
     hipLaunchKernelGGL(k_maxd2_scan, dim3(grid_for(g_.n, 256, 4096)), dim3(256), 0, stream_, g_, (const vox_t *)coc_, counters_);

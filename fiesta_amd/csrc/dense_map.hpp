@@ -58,6 +58,7 @@ enum Counter {
   C_MAXD2,         // upper bound of every finite d^2 the work-queue engine ever stored (bounds the delete scan)
   C_DBOX0,         // bounding box of the pending delete queue, local voxel coordinates: min x,y,z then max x,y,z
   C_DBOX5 = C_DBOX0 + 5,
+  C_LATE,          // voxels first observed while obstacles existed that no wave has reached yet (k_fuse marks them in latebits_)
   C_LIST0,         // lengths of the active-tile lists: round r of an update reads counter r % 3, appends to (r + 1) % 3
   C_LIST1,         //   and clears (r + 2) % 3 (consumed by round r - 1, needed empty by round r + 1): no memset between rounds.
   C_LIST2,         //   Between updates pending tiles sit in list 0 / C_LIST0 and the other two are zero.
@@ -85,7 +86,7 @@ struct Snapshot {
   DevBuf<vox_t> coc;
   DevBuf<double> logodds;
   DevBuf<unsigned long long> cnt;
-  DevBuf<uint32_t> occbits, gocc;
+  DevBuf<uint32_t> occbits, gocc, obsbits, latebits;
   DevBuf<uint32_t> touched, ins, del;
   unsigned long long counters[C_COUNT];
   Geom g;
@@ -205,6 +206,9 @@ class DenseMap {
   bool run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd);  // false: the rounds have to finish
   bool bulk_eligible(unsigned long long ni, unsigned long long nd);
   bool run_bulk(fiesta_hip_stats *st, int margin, bool *exact);
+  // the masked transform (mask_kernels.hpp): large deltas on partially observed maps
+  bool masked_eligible(unsigned long long ni, unsigned long long nd);
+  bool run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0);  // false: nothing committed, the rounds serve the update
   bool cells_wanted();                  // should this update try the cell transform (nn_kernels.hpp) before the envelope passes?
   bool run_cells(fiesta_hip_stats *st, int margin, bool publish);  // false: not applicable to this map (nothing launched)
   void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells = false, bool published = false);
@@ -226,6 +230,8 @@ class DenseMap {
   unsigned long long *cnt_ = nullptr;  // 8 B/voxel, cold: hits<<32 | observations (num_hit_/num_miss_)
   uint32_t *occbits_ = nullptr;        // 1 bit/voxel: Exist(idx)
   uint32_t *rbits_ = nullptr;          // 1 bit/voxel: voxel joined the frontier during the current update
+  uint32_t *obsbits_ = nullptr;        // 1 bit/voxel: observed at least once (k_fuse; rebuilt from the field after a restore / load)
+  uint32_t *latebits_ = nullptr;       // 1 bit/voxel: first observed while obstacles existed and not reached by a wave since (C_LATE counts them)
   uint32_t *gocc_ = nullptr;           // sharded maps: 1 bit/voxel of the GLOBAL grid, replicated on every shard
   int64_t ngoccwords_ = 0;
   int64_t nbitwords_ = 0;
@@ -236,7 +242,8 @@ class DenseMap {
   uint32_t *tile_epoch_ = nullptr;
   // UpdateESDF engine (fiesta_hip_config.update_engine): 0 = choose per update, 1 = frontier rounds only,
   // 2 = bulk feature transform whenever the map state allows it, 3 = level engine for every update it can hold,
-  // 4 = as 2 with the envelope passes only, 5 = as 2 with the cell transform wherever it applies
+  // 4 = as 2 with the envelope passes only, 5 = as 2 with the cell transform wherever it applies, 6 = as 0, and on partially
+  // observed maps the masked transform for every update the map's history allows
   int update_engine_ = 0;
   LevelEngine *lv_ = nullptr;   // the level engine's lists and control block (level_kernels.hpp), created on first use
   hipEvent_t lv_done_ = nullptr;
@@ -246,6 +253,17 @@ class DenseMap {
   // off until a scan finds no such voxel left (k_count_stale) or the map holds no obstacle.
   bool stale_inf_ = false;
   bool win_dirty_ = false;  // an update ran under a partial window while obstacles existed (see bulk_eligible)
+  // masked transform (mask_kernels.hpp): the sites' bitmap, the side buffer that becomes the field, the repair list with its
+  // values of the iteration under way, per-cell stamps, per-cell summary of obsbits_, its counters (device + pinned host copy)
+  DevBuf<uint32_t> effocc_, mask_out_, mask_ulist_, mask_uval_, mask_cstamp_;
+  DevBuf<uint8_t> cellobs_;
+  unsigned long long *mask_ctr_ = nullptr, *h_mask_ctr_ = nullptr;
+  uint32_t mask_serial_ = 0;   // tags of the repair iterations (stamps are never cleared)
+  int mask_chain_hint_ = 10;   // repair iterations launched before the first read-back (the last update's count + 2)
+  // while a masked transform runs: what the transforms read and write instead of occbits_ / coc_
+  const uint32_t *tr_occ_ = nullptr;
+  vox_t *tr_out_ = nullptr;
+  const uint8_t *tr_cellobs_ = nullptr;
   int ft_s0_ = 16;            // ring entries per lane in LDS (16 or 32; FIESTA_HIP_FT_S0: an experiment's knob)
   static constexpr int kFtBlocks = 1024;  // work-groups of a pass (4 waves each): what 256 CUs hold at once with 16-entry rings
   double ft_last_ms_ = 0;      // kernel time of the last bulk update (the engine choice's idea of this scene's sweep)

@@ -573,8 +573,8 @@ HashMap::HashMap(const fiesta_hip_config &cfg) {
 #ifdef FIESTA_HIP_TUNING
   if (const char *e = getenv("FIESTA_HIP_PROF")) prof_ = atoi(e);
 #endif
-  if (cfg.update_engine < 0 || cfg.update_engine > 5) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
-  update_engine_ = cfg.update_engine > 3 ? 0 : cfg.update_engine;  // (the transforms need a dense array: 2, 4 and 5 mean 0 here)
+  if (cfg.update_engine < 0 || cfg.update_engine > 6) throw Error(FIESTA_HIP_ERR_INVALID, "unknown update_engine");
+  update_engine_ = cfg.update_engine > 3 ? 0 : cfg.update_engine;  // (the transforms need a dense array: 2, 4, 5 and 6 mean 0 here)
 
   FIESTA_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   FIESTA_HIP_CHECK(hipEventCreate(&ev0_));

@@ -27,6 +27,7 @@ namespace fiesta {
 
 struct NnArgs {
   nn::Geom g;
+  const uint8_t *cellobs;  // nullable; a masked transform (mask_kernels.hpp): per cell 0 = no voxel ever observed -> no list wanted
   const uint32_t *occ;  // the occupancy bitmap the region is cut out of: row (X, Y) at (X * sny + Y) * snzw words, bit Z;
   int sx0, sy0, szb;    // region voxel (x, y, z) is bit z % 8 of byte szb + z / 8 of row (sx0 + x, sy0 + y)
   int sny, snzw;        // (an unsharded map: its own bitmap, offsets 0; a shard: its replica of the global one)
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   const StagedSrcT<WRAP> ssrc{staged ? s_tab : nullptr, s_soff, s_sites, -(X0 * kStageNY + Y0), -Zf};
   {
     const int cz = cz0 + (team_i & 63), cy = cy0 + (team_i >> 6);
-    const bool live = cz < g.lz1 && cy < g.ly1;
-    int te2 = nn::kNone, key = 7;  // (7: not a cell of the map)
+    const bool live = cz < g.lz1 && cy < g.ly1 && !(a.cellobs && a.cellobs[((int64_t)cx * g.ncy + cy) * g.ncz + cz] == 0);
+    int te2 = nn::kNone, key = 7;  // (7: not a cell of the map, or one that wants no list)
     uint32_t tw = 0xFFFFFFFFu;
     if (live) {
       if (staged) nn::first_competitor(ssrc, team, cx, cy, cz, nn::kKfirst, te2, tw);
@@ -377,7 +378,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   const int ci = s_order[team_i];
   const int cz = cz0 + (ci & 63), cy = cy0 + (ci >> 6);
   int n = 0;
-  const bool live = cz < g.lz1 && cy < g.ly1;  // (the same for the four lanes of a team)
+  bool live = cz < g.lz1 && cy < g.ly1;  // (the same for the four lanes of a team)
+  if (live && a.cellobs && a.cellobs[((int64_t)cx * g.ncy + cy) * g.ncz + cz] == 0) {  // an empty record: the fill writes words nobody keeps
+    live = false;
+    if (team.rank == 0) a.lists[(((int64_t)cx * g.ncy + cy) * g.ncz + cz) * nn::kStride] = 0u;
+  }
   if (live) {
     const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
     uint32_t *rec = a.lists + cell * nn::kStride;

@@ -34,7 +34,7 @@ def _d3(v):
     return np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(3))
 
 
-ENGINES = {"auto": 0, "rounds": 1, "bulk": 2, "levels": 3, "envelope": 4, "cells": 5}
+ENGINES = {"auto": 0, "rounds": 1, "bulk": 2, "levels": 3, "envelope": 4, "cells": 5, "masked": 6}
 
 
 class ESDFMap:
@@ -102,7 +102,7 @@ class ESDFMap:
         check(self._lib.fiesta_hip_set_original_range(self._h))
 
     def set_update_engine(self, update_engine):
-        """"auto" / "rounds" / "bulk" / "levels" (0 / 1 / 2 / 3) from the next UpdateESDF on."""
+        """"auto" / "rounds" / "bulk" / "levels" / "envelope" / "cells" / "masked" (0 ... 6) from the next UpdateESDF on."""
         check(self._lib.fiesta_hip_set_update_engine(self._h, ENGINES.get(update_engine, update_engine)))
 
     # -- occupancy ingest ----------------------------------------------------------------------------

@@ -51,7 +51,9 @@ typedef struct fiesta_hip_config {
   int32_t update_engine; /* UpdateESDF engine: 0 = chosen per update (default), 1 = frontier rounds only, 2 = bulk
                             feature transform whenever the map is fully observed, 3 = level engine for
                             every update its lists can hold, 4 = as 2 with the envelope passes only, 5 = as 2
-                            with the cell transform wherever it applies (2 chooses between the two); on
+                            with the cell transform wherever it applies (2 chooses between the two), 6 = on
+                            partially observed maps the masked transform for every update the map's history allows it for
+                            (0, 2, 4 and 5 take it for deltas too large for the level engine), else as 0; on
                             fully observed maps the distances do not depend on it */
   /* Spatial sharding. A map may be one shard of a larger global grid: it owns the global
    * voxel box [shard_lo, shard_lo + grid) and stores closest-obstacle ids in GLOBAL coordinates. For an
@@ -93,6 +95,10 @@ typedef struct fiesta_hip_stats {
   int64_t nn_entries;    /* cell transform: list entries over all cells */
   int64_t nn_failed;     /* cells that got no list when the cell transform was tried (> 0: the envelope passes served the
                             update instead, cells == 0) */
+  int64_t masked;        /* with bulk == 1: a PARTIALLY observed map -- the transform ran masked (mask_kernels.hpp): its result kept
+                            on the observed voxels whose segment to their obstacle is observed, the others repaired by pulls */
+  int64_t mask_uncertified, mask_iterations, mask_walks; /* masked: voxels on the repair list, repair iterations, segment walks */
+  double mask_certify_ms, mask_repair_ms;               /* masked: HIP-event time of k_mask_certify / of the repair launches */
 } fiesta_hip_stats;
 
 const char *fiesta_hip_last_error(void);
@@ -137,8 +143,8 @@ int fiesta_hip_set_prob_params(fiesta_hip_map *m, double p_hit, double p_miss, d
 int fiesta_hip_set_update_range(fiesta_hip_map *m, const double min_pos[3], const double max_pos[3],
                                 int new_vec);
 int fiesta_hip_set_original_range(fiesta_hip_map *m);
-/* fiesta_hip_config.update_engine, changed on a live map (takes effect with the next UpdateESDF).  Array maps take 0-4;
- * hash-block maps take 0, 1 and 3 (2 and 4 behave as 0 there: the transforms need a dense array).  No reference
+/* fiesta_hip_config.update_engine, changed on a live map (takes effect with the next UpdateESDF).  Array maps take 0-6;
+ * hash-block maps take 0, 1 and 3 (2, 4, 5 and 6 behave as 0 there: the transforms need a dense array).  No reference
  * counterpart: the reference has one engine. */
 int fiesta_hip_set_update_engine(fiesta_hip_map *m, int32_t engine);
 /* Diagnostics of the last UpdateESDF the level engine served (fiesta_hip_stats.levels): for each of its first 48 levels
