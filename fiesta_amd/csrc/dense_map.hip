@@ -1702,36 +1702,41 @@ bool DenseMap::masked_eligible(unsigned long long ni, unsigned long long nd) {
 bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0) {
   const Geom &g = g_;
   const int ncx = (g.nx + 7) / 8, ncy = (g.ny + 7) / 8, ncz = (g.nz + 7) / 8;
-  const int64_t ncells = (int64_t)ncx * ncy * ncz;
+  const int64_t ncells = (int64_t)ncx * ncy * ncz, nquads = (int64_t)ncx * ncy * g.nzw;
   if (!mask_ctr_) {
     FIESTA_HIP_CHECK(hipMalloc((void **)&mask_ctr_, MC_COUNT * sizeof(unsigned long long)));
     FIESTA_HIP_CHECK(hipHostMalloc((void **)&h_mask_ctr_, MC_COUNT * sizeof(unsigned long long)));
   }
-  const size_t ucap = (size_t)std::max<int64_t>(g.n / 8, 1 << 16);
+  // the walk list: room for a quarter of the voxels (measured on config 2's partially observed scene: 13 % of the observed
+  // voxels need the walk), in kMaskSegs segments that the quads feed in turn
+  const size_t seg_cap = (size_t)std::max<int64_t>(g.n / 4 / kMaskSegs, 8192);
   effocc_.ensure_exact((size_t)nbitwords_, stream_);
+  mask_ubits_.ensure_exact((size_t)nbitwords_, stream_);
   cellobs_.ensure_exact((size_t)ncells, stream_);
+  celldist_.ensure_exact((size_t)ncells, stream_);
+  cellnb_.ensure_exact((size_t)ncells, stream_);
   mask_out_.ensure_exact((size_t)g.n, stream_);
-  mask_ulist_.ensure_exact(ucap, stream_);
-  mask_uval_.ensure_exact(ucap, stream_);
-  if (mask_cstamp_.cap < (size_t)ncells) {
-    mask_cstamp_.ensure_exact((size_t)ncells, stream_);
-    FIESTA_HIP_CHECK(hipMemsetAsync(mask_cstamp_.p, 0, (size_t)ncells * sizeof(uint32_t), stream_));
-    mask_serial_ = 0;
-  }
-  if (mask_serial_ > 0xFFFF0000u) {  // (tags never repeat within the stamps' lifetime)
-    FIESTA_HIP_CHECK(hipMemsetAsync(mask_cstamp_.p, 0, (size_t)ncells * sizeof(uint32_t), stream_));
+  mask_walks_.ensure_exact(seg_cap * kMaskSegs, stream_);
+  mask_uq_.ensure_exact((size_t)ncells, stream_);
+  if (mask_qstamp_.cap < (size_t)(2 * ncells) || mask_serial_ > 0xFFFF0000u) {  // (tags never repeat within the stamps' lifetime)
+    mask_qstamp_.ensure_exact((size_t)(2 * ncells), stream_);
+    FIESTA_HIP_CHECK(hipMemsetAsync(mask_qstamp_.p, 0, (size_t)(2 * ncells) * sizeof(uint32_t), stream_));
     mask_serial_ = 0;
   }
   MaskArgs ma;
   memset(&ma, 0, sizeof(ma));
   ma.g = g, ma.ncx = ncx, ma.ncy = ncy, ma.ncz = ncz;
-  ma.occbits = occbits_, ma.obsbits = obsbits_, ma.effocc = effocc_.p, ma.cellobs = cellobs_.p;
+  ma.occbits = occbits_, ma.obsbits = obsbits_, ma.cellobs = cellobs_.p, ma.celldist = celldist_.p, ma.cellnb = cellnb_.p;
   ma.old = coc_, ma.out = mask_out_.p;
-  ma.ulist = mask_ulist_.p, ma.uval = mask_uval_.p, ma.ucap = (uint32_t)std::min<size_t>(ucap, 0xFFFFFFFFu);
-  ma.cstamp = mask_cstamp_.p, ma.ctr = mask_ctr_;
+  ma.ubits = mask_ubits_.p, ma.walks = reinterpret_cast<uint2 *>(mask_walks_.p), ma.seg_cap = (uint32_t)seg_cap;
+  ma.uq = mask_uq_.p, ma.qstamp[0] = mask_qstamp_.p, ma.qstamp[1] = mask_qstamp_.p + ncells;
+  ma.ctr = mask_ctr_;
   FIESTA_HIP_CHECK(hipMemsetAsync(mask_ctr_, 0, MC_COUNT * sizeof(unsigned long long), stream_));
-  hipLaunchKernelGGL(k_obs_cells, dim3(grid_for((int64_t)ncx * ncy * g.nzw, 4, 16384)), dim3(256), 0, stream_, g_, ncx, ncy, ncz,
+  FIESTA_HIP_CHECK(hipMemsetAsync(mask_ubits_.p, 0, (size_t)nbitwords_ * sizeof(uint32_t), stream_));
+  hipLaunchKernelGGL(k_obs_cells, dim3(grid_for(nquads, 4, 16384)), dim3(256), 0, stream_, g_, ncx, ncy, ncz,
                      (const uint32_t *)obsbits_, cellobs_.p);
+  hipLaunchKernelGGL(k_cell_dist, dim3(grid_for(ncells, 256, 4096)), dim3(256), 0, stream_, ncx, ncy, ncz, (const uint8_t *)cellobs_.p, celldist_.p,
+                     cellnb_.p);
   hipLaunchKernelGGL(k_eff_occ, dim3(grid_for(nbitwords_, 256, 8192)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
                      (const uint32_t *)obsbits_, effocc_.p, nbitwords_);
   FIESTA_HIP_CHECK(hipGetLastError());
@@ -1740,22 +1745,23 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
     ~Restore() { m->tr_occ_ = nullptr, m->tr_out_ = nullptr, m->tr_cellobs_ = nullptr; }
   } restore{this};
   tr_occ_ = effocc_.p, tr_out_ = mask_out_.p, tr_cellobs_ = cellobs_.p;
-  const int certify_blocks = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)ncx * ncy * g.nzw + 3) / 4, 1), 768);
-  const int repair_blocks = 2048;
-  int iters_done = 0;  // repair iterations of this update launched so far
+  const int classify_blocks = (int)std::min<int64_t>(std::max<int64_t>((nquads + 3) / 4, 1), 2048);
+  const int repair_blocks = (int)std::min<int64_t>(std::max<int64_t>((ncells + 3) / 4, 1), 2048);
+  int gi = 0;  // global repair iterations of this update launched so far
   auto launch_chain = [&](const int n, const unsigned long long *failed) {
     MaskArgs a = ma;
     a.failed = failed;
-    for (int k = 0; k < n; ++k) {
+    for (int k = 0; k < n; ++k, ++gi) {
       const uint32_t tag = ++mask_serial_;
-      hipLaunchKernelGGL(k_repair_pull, dim3(repair_blocks), dim3(256), 0, stream_, a, k, tag - 1u, iters_done == 0 ? 1 : 0);
-      hipLaunchKernelGGL(k_repair_commit, dim3(repair_blocks), dim3(256), 0, stream_, a, k, tag);
-      ++iters_done;
+      const int rd = (gi + 1) & 1;
+      hipLaunchKernelGGL(k_repair_cell, dim3(repair_blocks), dim3(256), 0, stream_, a, k, rd, tag - 1u, gi == 0 ? 1 : 0);
+      hipLaunchKernelGGL(k_repair_commit, dim3(repair_blocks), dim3(256), 0, stream_, a, k, rd, tag - 1u, tag, gi == 0 ? 1 : 0);
     }
     FIESTA_HIP_CHECK(hipGetLastError());
   };
   bool cells = false;
   hipEvent_t ev_cert = pool_event(0), ev_rep = pool_event(1), ev_end = pool_event(2);
+  int chain = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     cells = attempt == 0 && cells_wanted() && run_cells(st, 0, /*publish=*/false);
     if (!cells) {
@@ -1766,13 +1772,16 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
     MaskArgs a = ma;
     a.failed = failed;
     FIESTA_HIP_CHECK(hipEventRecord(ev_cert, stream_));
-    hipLaunchKernelGGL(k_mask_certify, dim3(certify_blocks), dim3(256), 0, stream_, a);
+    hipLaunchKernelGGL(k_mask_classify, dim3(classify_blocks), dim3(256), 0, stream_, a);
+    hipLaunchKernelGGL(k_mask_walk, dim3(kMaskSegs * 8), dim3(256), 0, stream_, a);
+    hipLaunchKernelGGL(k_mask_cells, dim3(classify_blocks), dim3(256), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipEventRecord(ev_rep, stream_));
-    iters_done = 0;
-    launch_chain(std::min(std::max(mask_chain_hint_, 2), kMaskIters), failed);
+    gi = 0;
+    chain = std::min(std::max(mask_chain_hint_, 2), kMaskIters);
+    launch_chain(chain, failed);
     FIESTA_HIP_CHECK(hipEventRecord(ev_end, stream_));
-    FIESTA_HIP_CHECK(hipMemcpyAsync(h_mask_ctr_, mask_ctr_, MC_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(h_mask_ctr_, mask_ctr_, MC_SEG0 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     if (cells) FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_FT_OVF0], &counters_[C_FT_OVF0], 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
     if (!cells || h_counters_[C_NN_FAILED] == 0) {
@@ -1795,39 +1804,31 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
   (void)hipEventElapsedTime(&m3, ft_ev_[2], ft_ev_[3]);
   (void)hipEventElapsedTime(&mc, ev_cert, ev_rep);
   (void)hipEventElapsedTime(&mr, ev_rep, ev_end);
-  const unsigned long long nu = h_mask_ctr_[MC_ULIST];
-  if (nu > ma.ucap) return false;  // (nothing is committed: coc_ still holds the field as it was)
+  if (st)  // (diagnostics: voxels changed in the first eight repair iterations)
+    for (int k = 0; k < 8; ++k) st->prof[k] = (int64_t)h_mask_ctr_[MC_CHANGED0 + k];
+  // a segment of the walk list ran out of room: nothing is committed (k_mask_walk and everything behind it returned at once,
+  // the field is as it was) and the frontier rounds serve the update
+  if (h_mask_ctr_[MC_OVERFLOW] != 0) return false;
   // the repair: further chains until an iteration changes nothing
   int total_iters = 0;
-  {
-    int n = iters_done;
-    for (;;) {
-      int k = 0;
-      while (k < n && h_mask_ctr_[MC_CHANGED0 + k] != 0) ++k;
-      total_iters += k < n ? k + 1 : n;
-      if (k < n || nu == 0) break;
-      // (the chain's last iteration still changed something)
-      FIESTA_HIP_CHECK(hipMemsetAsync(&mask_ctr_[MC_CHANGED0], 0, kMaskIters * sizeof(unsigned long long), stream_));
-      FIESTA_HIP_CHECK(hipEventRecord(ev_rep, stream_));
-      n = 8;
-      {  // a continuation: its first iteration looks at the stamps of the chain before
-        MaskArgs a = ma;
-        for (int j = 0; j < n; ++j) {
-          const uint32_t tag = ++mask_serial_;
-          hipLaunchKernelGGL(k_repair_pull, dim3(repair_blocks), dim3(256), 0, stream_, a, j, tag - 1u, 0);
-          hipLaunchKernelGGL(k_repair_commit, dim3(repair_blocks), dim3(256), 0, stream_, a, j, tag);
-        }
-        FIESTA_HIP_CHECK(hipGetLastError());
-      }
-      FIESTA_HIP_CHECK(hipEventRecord(ev_end, stream_));
-      FIESTA_HIP_CHECK(hipMemcpyAsync(&h_mask_ctr_[MC_CHANGED0], &mask_ctr_[MC_CHANGED0], kMaskIters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-      FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
-      float more = 0;
-      (void)hipEventElapsedTime(&more, ev_rep, ev_end);
-      mr += more;
-    }
+  for (int n = chain;;) {
+    int k = 0;
+    while (k < n && h_mask_ctr_[MC_CHANGED0 + k] != 0) ++k;
+    total_iters += k < n ? k + 1 : n;
+    if (k < n || h_mask_ctr_[MC_QUADS] == 0) break;
+    // (the chain's last iteration still changed something)
+    FIESTA_HIP_CHECK(hipMemsetAsync(&mask_ctr_[MC_CHANGED0], 0, kMaskIters * sizeof(unsigned long long), stream_));
+    FIESTA_HIP_CHECK(hipEventRecord(ev_rep, stream_));
+    n = 4;
+    launch_chain(n, nullptr);
+    FIESTA_HIP_CHECK(hipEventRecord(ev_end, stream_));
+    FIESTA_HIP_CHECK(hipMemcpyAsync(&h_mask_ctr_[MC_CHANGED0], &mask_ctr_[MC_CHANGED0], kMaskIters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    float more = 0;
+    (void)hipEventElapsedTime(&more, ev_rep, ev_end);
+    mr += more;
   }
-  mask_chain_hint_ = std::min(total_iters + 2, kMaskIters);
+  mask_chain_hint_ = std::min(total_iters + 1, kMaskIters);
   // commit: the side buffer BECOMES the field (every user of the field takes the pointer at call time, in stream order)
   std::swap(coc_, mask_out_.p);
   zero_counters(C_INSERT, 2);  // both queues are drained
@@ -1855,9 +1856,10 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
       st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
     }
     st->mask_certify_ms = mc, st->mask_repair_ms = mr;
-    st->mask_uncertified = (int64_t)nu, st->mask_iterations = total_iters, st->mask_walks = (int64_t)h_mask_ctr_[MC_WALKS];
+    st->mask_uncertified = (int64_t)h_mask_ctr_[MC_MARKED], st->mask_iterations = total_iters, st->mask_walks = (int64_t)h_mask_ctr_[MC_WALKS];
+    st->mask_quads = (int64_t)h_mask_ctr_[MC_QUADS];
     st->relax_ms = (double)m1 + m2 + m3 + mc + mr;
-    st->relax_launches = 3 + 1 + 2 * total_iters;
+    st->relax_launches = 3 + 3 + 2 * total_iters;
     st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
   }
   return true;

@@ -253,10 +253,12 @@ class DenseMap {
   // off until a scan finds no such voxel left (k_count_stale) or the map holds no obstacle.
   bool stale_inf_ = false;
   bool win_dirty_ = false;  // an update ran under a partial window while obstacles existed (see bulk_eligible)
-  // masked transform (mask_kernels.hpp): the sites' bitmap, the side buffer that becomes the field, the repair list with its
-  // values of the iteration under way, per-cell stamps, per-cell summary of obsbits_, its counters (device + pinned host copy)
-  DevBuf<uint32_t> effocc_, mask_out_, mask_ulist_, mask_uval_, mask_cstamp_;
-  DevBuf<uint8_t> cellobs_;
+  // masked transform (mask_kernels.hpp): the sites' bitmap, the side buffer that becomes the field, the marks of the voxels under
+  // repair, the walk list, the quads under repair with their stamps, per-cell summaries of obsbits_, its counters (device +
+  // pinned host copy)
+  DevBuf<uint32_t> effocc_, mask_out_, mask_ubits_, mask_uq_, mask_qstamp_, cellnb_;
+  DevBuf<unsigned long long> mask_walks_;  // (idx, winner) pairs
+  DevBuf<uint8_t> cellobs_, celldist_;
   unsigned long long *mask_ctr_ = nullptr, *h_mask_ctr_ = nullptr;
   uint32_t mask_serial_ = 0;   // tags of the repair iterations (stamps are never cleared)
   int mask_chain_hint_ = 10;   // repair iterations launched before the first read-back (the last update's count + 2)

@@ -8,33 +8,42 @@
 // make of it.  So a large delta on such a map is served as
 //
 //   k_obs_cells     per 8^3 cell: no voxel observed / all / some                               reads 1 bit / voxel
+//   k_cell_dist     per cell: how far the nearest cell that is not fully observed is, and which of its 26 neighbours are
 //   k_eff_occ       the occupancy bitmap without the obstacles NONE of whose 24 stencil neighbours is observed (they can
 //                   hand their id to nobody, :375-391): the sites of the transform
 //   <transform>     T of those sites into a SIDE buffer (cell transform nn_kernels.hpp, or the envelope passes)
-//   k_mask_certify  per voxel of the side buffer: never observed -> 0xFFFFFFFF; an obstacle -> itself; CERTIFIED (every voxel of
-//                   the discrete segment to the winner observed) -> T stays; every other observed voxel keeps what it held
-//                   before the update if that obstacle still exists, else "no obstacle", and goes on the repair list
+//   k_mask_classify per voxel of the side buffer, streaming: never observed -> 0xFFFFFFFF; an obstacle -> itself; CERTIFIED at once
+//                   where every cell between the voxel and its winner is fully observed; the others are queued for
+//   k_mask_walk     the certificate proper: every voxel of the discrete segment to the winner observed -> T stays; an
+//                   uncertified voxel keeps what it held before the update if that obstacle still exists, else "no obstacle",
+//                   and is marked for repair (ubits)
 //                   (a second certificate through "portals" -- observed stencil neighbours of a winner hidden behind one
-//                   unobserved voxel -- was modelled and dropped: it shrinks the list 4x and was wrong on 70 of 11.8 M voxels)
-//   k_repair_*      Jacobi pulls (:349-367: 24 neighbours in stencil order, strict <) over the repair list until nothing
-//                   changes: synchronous, deterministic, only listed voxels ever change
+//                   unobserved voxel -- was modelled and dropped: it shrinks the repair set 4x and was wrong on 70 of 11.8 M voxels)
+//   k_mask_cells    the cells that hold a marked voxel
+//   k_repair_cell / k_repair_commit   Jacobi pulls (:349-367: 24 neighbours in stencil order, strict <) on the marked voxels:
+//                   a WAVE stages a cell + its 2-voxel halo in LDS and iterates it to local quiescence against the halo as
+//                   the global iteration found it (block Jacobi); results go to a second buffer and are committed by a
+//                   launch of their own -- synchronous, deterministic, only marked voxels ever change
 //
-// and the side buffer becomes the field (pointer swap).  Nothing is committed before the end: a repair list that outgrows
-// its buffer leaves the field untouched and the frontier rounds serve the update.
+// and the side buffer becomes the field (pointer swap).  tools/dev/masked_engine_model.py is the same algorithm in numpy; the
+// GPU field equals it voxel for voxel (tools/dev/masked_gpu_check.py).
 #pragma once
 #include "common.hpp"
 #include "relax_kernels.hpp"
 
 namespace fiesta {
 
-constexpr int kMaskIters = 48;  // repair iterations one chain of launches can hold (their change counters)
+constexpr int kMaskIters = 24;  // repair iterations one chain of launches can hold (their change counters)
+constexpr int kMaskSegs = 256;  // segments of the walk list (one cursor each, 128 bytes apart: appends spread over the L2 channels)
+constexpr int kMaskSub = 6;     // cell-local Jacobi steps per global repair iteration
 enum MaskCounter {
-  MC_ULIST = 0,   // voxels appended to the repair list (may exceed its capacity: then the update is not committed)
-  MC_WALKS,       // segment walks (statistics)
-  MC_SPARE,       // (unused)
-  MC_UNOBS,       // (unused)
+  MC_MARKED = 0,  // voxels marked for repair
+  MC_WALKS,       // segment walks
+  MC_OVERFLOW,    // walk-list segments that ran out of room (non-zero: the update is not committed)
+  MC_QUADS,       // cells on the repair list
   MC_CHANGED0,    // [kMaskIters]: voxels changed in iteration k of the current chain
-  MC_COUNT = MC_CHANGED0 + kMaskIters
+  MC_SEG0 = MC_CHANGED0 + kMaskIters,  // [kMaskSegs * 16]: the segments' cursors (every 16th word)
+  MC_COUNT = MC_SEG0 + kMaskSegs * 16
 };
 
 struct MaskArgs {
@@ -42,14 +51,17 @@ struct MaskArgs {
   int ncx, ncy, ncz;         // 8^3 cells
   const uint32_t *occbits;   // Exist()
   const uint32_t *obsbits;   // observed at least once
-  const uint32_t *effocc;    // k_eff_occ's result
   const uint8_t *cellobs;    // per cell: 0 nothing observed, 1 every voxel (of the grid) observed, 2 mixed
-  const vox_t *old;          // the field before this update
+  const uint8_t *celldist;   // per cell: 0 not fully observed, k = every cell within k - 1 cells (Chebyshev) is (k <= 3)
+  const uint32_t *cellnb;    // per cell: bit (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1) = the neighbour cell (dx, dy, dz) is fully observed
+                             // (cells outside the grid count as observed: nothing to cross there)
+  vox_t *old;                // the field before this update; the repair's second buffer afterwards
   vox_t *out;                // T on entry, the new field on exit
-  uint32_t *ulist;           // repair list: linear voxel indices
-  uint32_t *uval;            // per entry: the value of the iteration under way
-  uint32_t ucap;
-  uint32_t *cstamp;          // per cell: tag of the last iteration that changed a voxel in or next to it
+  uint32_t *ubits;           // 1 bit / voxel: marked for repair
+  uint2 *walks;              // walk list: (linear voxel index, winner), kMaskSegs segments of seg_cap entries
+  uint32_t seg_cap;
+  uint32_t *uq;              // cells that hold a marked voxel
+  uint32_t *qstamp[2];       // per cell: tag of the last iteration (by parity) that changed a voxel in or next to it
   unsigned long long *ctr;   // MaskCounter
   const unsigned long long *failed;  // the cell transform's failure counter (non-zero: T was not written)
 };
@@ -153,100 +165,98 @@ __global__ __launch_bounds__(256) void k_eff_occ(Geom g, const uint32_t *occbits
 
 // ---- the certificate -------------------------------------------------------------------------------------------------------------
 // Samples of the segment v -> s: n = 2 max|d| + 1 steps, sample i at v + round(d i / n) (never a tie: n is odd), i = 1 .. n - 1;
-// every voxel of the discrete line is visited, most of them twice -- only a sample that MOVED is looked up.
+// every voxel of the discrete line is visited, most of them twice -- only a sample that MOVED is looked up.  Walked from the
+// winner's end: more than half of the walks that fail do so next to a winner that sits behind an unobserved voxel.
 __device__ inline bool mask_segment_observed(const MaskArgs &a, int vx, int vy, int vz, int sx, int sy, int sz) {
   const int dx = sx - vx, dy = sy - vy, dz = sz - vz;
   const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
   const int m = max(ax, max(ay, az)), n = 2 * m + 1, n2 = 2 * n;
   const int ix = dx < 0 ? -1 : 1, iy = dy < 0 ? -1 : 1, iz = dz < 0 ? -1 : 1;
-  int ex = n, ey = n, ez = n, px = vx, py = vy, pz = vz;
-  for (int i = 1; i < n; ++i) {
-    ex += 2 * ax, ey += 2 * ay, ez += 2 * az;
+  // sample i: v + sign * floor((2 |d| i + n) / 2n) per axis; start at i = n - 1 and step down
+  int ex = 2 * ax * (n - 1) + n, ey = 2 * ay * (n - 1) + n, ez = 2 * az * (n - 1) + n;
+  int px = vx + ix * (ex / n2), py = vy + iy * (ey / n2), pz = vz + iz * (ez / n2);
+  ex %= n2, ey %= n2, ez %= n2;
+  // the summary of the cell the walk is in stays in a register: a load per cell crossed, not per sample
+  int ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
+  uint32_t cst = a.cellobs[((int64_t)ccx * a.ncy + ccy) * a.ncz + ccz];
+  if (cst == 0u || (cst == 2u && !bit_test(a.obsbits, a.g, px, py, pz))) return false;
+  for (int i = n - 2; i >= 1; --i) {
+    ex -= 2 * ax, ey -= 2 * ay, ez -= 2 * az;
     bool moved = false;
-    if (ex >= n2) ex -= n2, px += ix, moved = true;
-    if (ey >= n2) ey -= n2, py += iy, moved = true;
-    if (ez >= n2) ez -= n2, pz += iz, moved = true;
-    if (moved && !mask_observed(a, px, py, pz)) return false;
+    if (ex < 0) ex += n2, px -= ix, moved = true;
+    if (ey < 0) ey += n2, py -= iy, moved = true;
+    if (ez < 0) ez += n2, pz -= iz, moved = true;
+    if (!moved) continue;
+    if ((px >> 3) != ccx || (py >> 3) != ccy || (pz >> 3) != ccz) {
+      ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
+      cst = a.cellobs[((int64_t)ccx * a.ncy + ccy) * a.ncz + ccz];
+    }
+    if (cst == 0u || (cst == 2u && !bit_test(a.obsbits, a.g, px, py, pz))) return false;
   }
   return true;
 }
-constexpr int kMaskQueue = 1024;   // voxels of a quad waiting for their walk (per wave)
-constexpr int kMaskUBuf = 1024;    // repair-list entries a wave collects before it takes a range of the list
+
+// Chebyshev distance (in cells, capped at 3) from every fully observed cell to the nearest cell that is not, and the 3^3
+// neighbourhood as a bit mask; cells outside the grid do not count (nothing to cross there).
+__global__ __launch_bounds__(256) void k_cell_dist(int ncx, int ncy, int ncz, const uint8_t *cellobs, uint8_t *celldist, uint32_t *cellnb) {
+  const int64_t n = (int64_t)ncx * ncy * ncz;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+    const int cz = (int)(c % ncz), cy = (int)((c / ncz) % ncy), cx = (int)(c / ((int64_t)ncz * ncy));
+    int d = 3;
+    uint32_t nb = 0x7FFFFFFu;
+    for (int dx = -2; dx <= 2; ++dx)
+      for (int dy = -2; dy <= 2; ++dy)
+        for (int dz = -2; dz <= 2; ++dz) {
+          const int ux = cx + dx, uy = cy + dy, uz = cz + dz;
+          if ((unsigned)ux >= (unsigned)ncx || (unsigned)uy >= (unsigned)ncy || (unsigned)uz >= (unsigned)ncz) continue;
+          if (cellobs[((int64_t)ux * ncy + uy) * ncz + uz] != 1u) {
+            const int r = max(max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy), dz < 0 ? -dz : dz);
+            d = min(d, r);
+            if (r <= 1) nb &= ~(1u << ((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)));
+          }
+        }
+    celldist[c] = (uint8_t)d;
+    cellnb[c] = nb;
+  }
+}
+
+constexpr int kMaskQueue = 512;  // walks a wave collects before it takes a range of a segment
 
 // One WAVE per quad (four cells along z: 32 voxels = one 128-byte line per voxel row, one bitmap word per row); lane = (y, four
-// consecutive z); waves are persistent and collect their repair-list entries in LDS (one atomic on the list cursor per ~1000
-// entries: returning atomics on one address serialise at tens of ns each).
-__global__ __launch_bounds__(256) void k_mask_certify(MaskArgs a) {
+// consecutive z); waves are persistent.  Voxels that need the segment walk go to the walk list, through an LDS queue per wave
+// (one atomic on a segment's cursor per flush: returning atomics on one address serialise at tens of ns each).  No load depends
+// on a voxel's word: the cells between a voxel and its winner are judged from the cell's own summaries, held in registers.
+__global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
   __shared__ uint2 s_queue[4][kMaskQueue];
-  __shared__ uint32_t s_ubuf[4][kMaskUBuf];
-  __shared__ uint32_t s_qn[4], s_un[4];
+  __shared__ uint32_t s_qn[4];
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;  // T was never written (a cell without a list): the host takes the envelope passes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint2 *queue = s_queue[wave];
-  uint32_t *ubuf = s_ubuf[wave];
   const int nqz = g.nzw;  // quads along z
   const int64_t nquads = (int64_t)a.ncx * a.ncy * nqz;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t nwaves = (int64_t)gridDim.x * 4, gw = blockIdx.x * 4ll + wave;
   const int64_t per = (nquads + nwaves - 1) / nwaves;
-  const int64_t q0 = (blockIdx.x * 4ll + wave) * per, q1 = min(q0 + per, nquads);
+  const int64_t q0 = gw * per, q1 = min(q0 + per, nquads);
   const int y = lane >> 3, z4 = lane & 7;
   const bool vec = (g.nz & 3) == 0;
-  if (lane == 0) s_qn[wave] = 0, s_un[wave] = 0;
-  unsigned walks = 0;
+  if (lane == 0) s_qn[wave] = 0;
+  unsigned nwalk = 0;
 
-  auto flush_u = [&]() {  // the wave's collected entries -> the list (every lane calls)
-    const uint32_t n = s_un[wave];
+  // (a quad's walks go to segment quad % kMaskSegs: neighbouring quads feed different segments, the segments fill evenly)
+  auto flush = [&](const int seg) {  // the wave's queued walks -> a segment of the list (every lane calls)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t n = s_qn[wave];
     if (n) {
       uint32_t base = 0;
-      if (lane == 0) base = (uint32_t)atomicAdd(&a.ctr[MC_ULIST], (unsigned long long)n);
+      if (lane == 0) {
+        base = (uint32_t)atomicAdd(&a.ctr[MC_SEG0 + 16 * seg], (unsigned long long)n);
+        if (base + n > a.seg_cap) atomicAdd(&a.ctr[MC_OVERFLOW], 1ull);
+      }
       base = (uint32_t)__shfl((int)base, 0);
       for (uint32_t i = (uint32_t)lane; i < n; i += 64u)
-        if (base + i < a.ucap) a.ulist[base + i] = ubuf[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane == 0) s_un[wave] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  };
-  auto drain = [&]() {  // the walks of the queued voxels, 64 at a time (every lane calls)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const uint32_t n = min(s_qn[wave], (uint32_t)kMaskQueue);
-    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      bool uncert = false;
-      uint32_t idx = 0;
-      if (i < n) {
-        const uint2 e = queue[i];
-        idx = e.x;
-        const int vz = (int)(idx % (uint32_t)g.nz), vy = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), vx = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
-        int sx, sy, sz;
-        unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
-        sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
-        ++walks;
-        const bool ok = mask_segment_observed(a, vx, vy, vz, sx, sy, sz);
-        if (!ok) {  // keeps what it held if that obstacle still exists; repaired from its neighbours afterwards
-          vox_t o = a.old[idx] & ~kAct;
-          if (!(o & kNoCoc)) {
-            int ox, oy, oz;
-            unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, o, ox, oy, oz);
-            ox -= g.gx0, oy -= g.gy0, oz -= g.gz0;
-            if (!(g.in_grid(ox, oy, oz) && bit_test(a.occbits, g, ox, oy, oz))) o = kInf;
-          } else {
-            o = kInf;
-          }
-          a.out[idx] = o;
-          uncert = true;
-        }
-      }
-      const unsigned long long mu = __ballot(uncert);
-      if (mu) {
-        const uint32_t at = s_un[wave];
-        if (uncert) ubuf[at + (uint32_t)__popcll(mu & ((1ull << lane) - 1ull))] = idx;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) s_un[wave] = at + (uint32_t)__popcll(mu);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (at + (uint32_t)__popcll(mu) > (uint32_t)(kMaskUBuf - 64)) flush_u();
-      }
+        if (base + i < a.seg_cap) a.walks[(size_t)seg * a.seg_cap + base + i] = queue[i];
+      nwalk += lane == 0 ? n : 0u;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0) s_qn[wave] = 0;
@@ -256,17 +266,19 @@ __global__ __launch_bounds__(256) void k_mask_certify(MaskArgs a) {
   for (int64_t q = q0; q < q1; ++q) {
     const int qz = (int)(q % nqz);
     const int cy = (int)((q / nqz) % a.ncy), cx = (int)(q / ((int64_t)nqz * a.ncy));
-    // the four cells' summaries
-    uint32_t cs[4];
+    uint32_t cd[4], cn[4];
     bool any_obs = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int cz = 4 * qz + k;
-      cs[k] = cz < a.ncz ? (uint32_t)a.cellobs[((int64_t)cx * a.ncy + cy) * a.ncz + cz] : 0u;
-      any_obs |= cs[k] != 0u;
+      const int64_t c = ((int64_t)cx * a.ncy + cy) * a.ncz + cz;
+      any_obs |= cz < a.ncz && a.cellobs[c] != 0u;
+      cd[k] = cz < a.ncz ? (uint32_t)a.celldist[c] : 0u;
+      cn[k] = cz < a.ncz ? a.cellnb[c] : 0u;
     }
     const int Y = 8 * cy + y, Z = 32 * qz + 4 * z4;
     const bool row_in = Y < g.ny && Z < g.nz;
+    const uint32_t mycd = cd[z4 >> 1], mycn = cn[z4 >> 1];  // (the cell of this lane's four voxels)
     for (int x = 0; x < 8; ++x) {
       const int X = 8 * cx + x;
       if (X >= g.nx) break;  // (wave-uniform)
@@ -306,26 +318,28 @@ __global__ __launch_bounds__(256) void k_mask_certify(MaskArgs a) {
         } else if (w[k] & kNoCoc) {
           w[k] = kInf;  // (a map without a site)
         } else {
-          // coarse test: every cell the box of v and its winner touches fully observed -> certified without a walk
           int sx, sy, sz;
           unpack_coc(g.wrap, X + g.gx0, Y + g.gy0, vz + g.gz0, w[k], sx, sy, sz);
           sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
-          const int cx0 = min(X, sx) >> 3, cx1 = max(X, sx) >> 3, cy0 = min(Y, sy) >> 3, cy1 = max(Y, sy) >> 3, cz0 = min(vz, sz) >> 3,
-                    cz1 = max(vz, sz) >> 3;
-          bool full = (cx1 - cx0 + 1) * (cy1 - cy0 + 1) * (cz1 - cz0 + 1) <= 27;
-          for (int ux = cx0; ux <= cx1 && full; ++ux)
-            for (int uy = cy0; uy <= cy1 && full; ++uy)
-              for (int uz = cz0; uz <= cz1 && full; ++uz) full = a.cellobs[((int64_t)ux * a.ncy + uy) * a.ncz + uz] == 1u;
+          const int cx1 = sx >> 3, cy1 = sy >> 3, cz1 = sz >> 3, cz0 = vz >> 3;
+          const int co = max(max(cx1 > cx ? cx1 - cx : cx - cx1, cy1 > cy ? cy1 - cy : cy - cy1), cz1 > cz0 ? cz1 - cz0 : cz0 - cz1);
+          // every cell the box of v and its winner touches fully observed -> certified without a walk: from the cell's distance
+          // to the nearest cell that is not, else (a box within the 3^3 cells around) from the cell's neighbour mask
+          bool full = (uint32_t)co < mycd;
+          if (!full && co == 1) {
+            const uint32_t mx = 2u | (1u << (cx1 - cx + 1)), my = 2u | (1u << (cy1 - cy + 1)), mz = 2u | (1u << (cz1 - cz0 + 1));
+            const uint32_t pm = ((my & 1u) ? mz : 0u) | ((my & 2u) ? mz << 3 : 0u) | ((my & 4u) ? mz << 6 : 0u);
+            const uint32_t need = ((mx & 1u) ? pm : 0u) | ((mx & 2u) ? pm << 9 : 0u) | ((mx & 4u) ? pm << 18 : 0u);
+            full = (mycn & need) == need;
+          }
           want[k] = !full;
         }
       }
-      // changed words go out now (a walk that ends uncertified overwrites its voxel later: same wave, stores in order)
       if (row_in && (w[0] != w0[0] || w[1] != w0[1] || w[2] != w0[2] || w[3] != w0[3])) {
         if (vec) *reinterpret_cast<uint4 *>(a.out + base) = uint4{w[0], w[1], w[2], w[3]};
         else
           for (int k = 0; k < 4 && Z + k < g.nz; ++k) a.out[base + k] = w[k];
       }
-      // queue the voxels that need a walk
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const unsigned long long mq = __ballot(want[k]);
@@ -337,91 +351,235 @@ __global__ __launch_bounds__(256) void k_mask_certify(MaskArgs a) {
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
       }
-      if (s_qn[wave] > (uint32_t)(kMaskQueue - 256)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        drain();
+      if (s_qn[wave] > (uint32_t)(kMaskQueue - 256)) flush((int)(q % kMaskSegs));
+    }
+    flush((int)(q % kMaskSegs));
+  }
+  if (lane == 0 && nwalk) atomicAdd(&a.ctr[MC_WALKS], (unsigned long long)nwalk);
+}
+
+// The certificate proper: one lane per queued voxel.
+__global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
+  __shared__ uint32_t s_marked;
+  const Geom &g = a.g;
+  if (a.failed && *a.failed) return;
+  if (a.ctr[MC_OVERFLOW]) return;
+  if (threadIdx.x == 0) s_marked = 0;
+  __syncthreads();
+  unsigned marked = 0;
+  // work-group b takes segment b % kMaskSegs, its share of it
+  const int seg = (int)(blockIdx.x % kMaskSegs);
+  const uint32_t part = blockIdx.x / kMaskSegs, parts = (gridDim.x + kMaskSegs - 1 - seg) / kMaskSegs;
+  const uint32_t n = (uint32_t)min(a.ctr[MC_SEG0 + 16 * seg], (unsigned long long)a.seg_cap);
+  for (uint32_t i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
+    const uint2 e = a.walks[(size_t)seg * a.seg_cap + i];
+    const uint32_t idx = e.x;
+    const int vz = (int)(idx % (uint32_t)g.nz), vy = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), vx = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
+    int sx, sy, sz;
+    unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
+    sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
+    if (mask_segment_observed(a, vx, vy, vz, sx, sy, sz)) continue;
+    // uncertified: keeps what it held if that obstacle still exists; repaired from its neighbours afterwards
+    vox_t o = a.old[idx] & ~kAct;
+    if (!(o & kNoCoc)) {
+      int ox, oy, oz;
+      unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, o, ox, oy, oz);
+      ox -= g.gx0, oy -= g.gy0, oz -= g.gz0;
+      if (!(g.in_grid(ox, oy, oz) && bit_test(a.occbits, g, ox, oy, oz))) o = kInf;
+    } else {
+      o = kInf;
+    }
+    a.out[idx] = o;
+    atomicOr(&a.ubits[g.bitword(vx, vy, vz)], 1u << (vz & 31));
+    ++marked;
+  }
+  for (int off = 32; off > 0; off >>= 1) marked += (unsigned)__shfl_xor((int)marked, off);
+  if ((threadIdx.x & 63) == 0 && marked) atomicAdd(&s_marked, marked);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_marked) atomicAdd(&a.ctr[MC_MARKED], (unsigned long long)s_marked);
+}
+
+// The CELLS (8^3 voxels) that hold a marked voxel -> the repair list; their marked voxels' words also go into the second buffer
+// (the repair keeps the two buffers equal on marked voxels between iterations).  One wave per quad (four cells along z): lane =
+// voxel row (x = lane / 8, y), one word of marks per row, a byte of it per cell.
+__global__ __launch_bounds__(256) void k_mask_cells(MaskArgs a) {
+  __shared__ uint32_t s_n, s_base, s_list[16];
+  const Geom &g = a.g;
+  if (a.failed && *a.failed) return;
+  if (a.ctr[MC_OVERFLOW]) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nqz = g.nzw;
+  const int64_t nquads = (int64_t)a.ncx * a.ncy * nqz;
+  for (int64_t q0 = blockIdx.x * 4ll; q0 < nquads; q0 += (int64_t)gridDim.x * 4) {
+    const int64_t q = q0 + wave;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (q < nquads) {
+      const int qz = (int)(q % nqz);
+      const int cy = (int)((q / nqz) % a.ncy), cx = (int)(q / ((int64_t)nqz * a.ncy));
+      const int X = 8 * cx + (lane >> 3), Y = 8 * cy + (lane & 7);
+      uint32_t m = (X < g.nx && Y < g.ny) ? a.ubits[((int64_t)X * g.ny + Y) * g.nzw + qz] : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool has = __any((int)(((m >> (8 * k)) & 255u) != 0u));
+        if (has && lane == 0) s_list[atomicAdd(&s_n, 1u)] = (uint32_t)((((int64_t)cx * a.ncy + cy) * a.ncz) + 4 * qz + k);
+      }
+      const int64_t base = ((int64_t)X * g.ny + Y) * g.nz + 32 * qz;
+      while (m) {
+        const int b = __ffs((int)m) - 1;
+        m &= m - 1;
+        a.old[base + b] = a.out[base + b];
       }
     }
-    if (s_qn[wave]) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      drain();
-    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = (uint32_t)atomicAdd(&a.ctr[MC_QUADS], (unsigned long long)s_n);
+    __syncthreads();
+    if (threadIdx.x < s_n) a.uq[s_base + threadIdx.x] = s_list[threadIdx.x];
+    __syncthreads();
   }
-  flush_u();
-  for (int off = 32; off > 0; off >>= 1) {
-    walks += (unsigned)__shfl_xor((int)walks, off);
-  }
-  if (lane == 0 && walks) atomicAdd(&a.ctr[MC_WALKS], (unsigned long long)walks);
 }
 
-// ---- the repair: Jacobi pulls over the list ------------------------------------------------------------------------------------------
-// Iteration `it` of a chain (tag = the stamp of this update's iteration it): pull evaluates the 24 neighbours of every listed
-// voxel in or next to a cell that changed in iteration it - 1 (all of them in the first iteration of an update) and leaves the
-// better obstacle in uval; commit stores the changes, stamps the cells around them and counts them.  A chain is launched
-// whole; an iteration whose predecessor changed nothing returns at once.
-__global__ __launch_bounds__(256) void k_repair_pull(MaskArgs a, int it, uint32_t tag_prev, int first) {
+// ---- the repair: block-Jacobi pulls on the marked voxels ------------------------------------------------------------------------------
+// Global iteration `it` of a chain.  k_repair_cell: ONE WAVE per listed cell that changed, or has a neighbour that changed, in the
+// iteration before (all of them in an update's first) -- no barrier anywhere, a CU keeps sixteen cells in flight: the cell + its
+// 2-voxel halo (12^3 words) from `out` into the wave's LDS tile, its marked voxels compacted into a list (a lane per marked voxel),
+// up to kMaskSub Jacobi steps on them against that halo, the voxels that end different into `old` (the second buffer).
+// k_repair_commit: the same cells' differences old -> out, counted, and the cells around each changed voxel stamped for the next
+// iteration.  Nobody writes `out` while a k_repair_cell launch reads it: the result does not depend on the order the waves run in.
+constexpr int kTileE = 12, kTileN = kTileE * kTileE * kTileE;
+__global__ __launch_bounds__(256) void k_repair_cell(MaskArgs a, int it, int rd, uint32_t tag_prev, int first) {
+  __shared__ vox_t s_tile[4][kTileN];
+  __shared__ uint16_t s_voxl[4][512];  // marked voxels of the cell: x << 6 | y << 3 | z
+  __shared__ vox_t s_newv[4][512];
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;
+  if (a.ctr[MC_OVERFLOW]) return;
   if (it > 0 && a.ctr[MC_CHANGED0 + it - 1] == 0) return;
-  const unsigned long long nu = a.ctr[MC_ULIST];
-  if (nu > a.ucap) return;  // (the list overflowed: the host gives this update to the rounds)
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)nu; i += gridDim.x * blockDim.x) {
-    const uint32_t idx = a.ulist[i];
-    const int z = (int)(idx % (uint32_t)g.nz), y = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), x = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
-    if (!first && a.cstamp[((int64_t)(x >> 3) * a.ncy + (y >> 3)) * a.ncz + (z >> 3)] != tag_prev) {
-      a.uval[i] = kUnobserved;
-      continue;
+  const uint32_t nuq = (uint32_t)a.ctr[MC_QUADS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  vox_t *tile = s_tile[wave];
+  uint16_t *voxl = s_voxl[wave];
+  vox_t *newv = s_newv[wave];
+  const uint32_t *stamp_r = a.qstamp[rd];  // (written by the commit of the iteration before)
+  for (uint32_t ci = blockIdx.x * 4u + (uint32_t)wave; ci < nuq; ci += gridDim.x * 4u) {
+    const uint32_t c = a.uq[ci];
+    if (!first && stamp_r[c] != tag_prev) continue;  // (wave-uniform)
+    const int cz = (int)(c % (uint32_t)a.ncz);
+    const int cy = (int)((c / (uint32_t)a.ncz) % (uint32_t)a.ncy), cx = (int)(c / ((uint32_t)a.ncz * (uint32_t)a.ncy));
+    const int X0 = 8 * cx - 2, Y0 = 8 * cy - 2, Z0 = 8 * cz - 2;
+    // (LDS is in order within a wave: no barrier between the phases below)
+    for (int i = lane; i < kTileN; i += 64) {
+      const int zz = i % kTileE, r = i / kTileE, yy = r % kTileE, xx = r / kTileE;
+      const int X = X0 + xx, Y = Y0 + yy, Z = Z0 + zz;
+      tile[i] = g.in_grid(X, Y, Z) ? (a.out[g.idx(X, Y, Z)] & ~kAct) : kUnobserved;
     }
-    const vox_t cur = a.out[idx];
-    int32_t best = (cur & kNoCoc) ? kD2Inf : dist2(g.wrap, x + g.gx0, y + g.gy0, z + g.gz0, cur);
-    vox_t bw = cur;
-#define FIESTA_PULL(DX, DY, DZ)                                                                      \
-  {                                                                                                  \
-    const int ux = x + (DX), uy = y + (DY), uz = z + (DZ);                                           \
-    if (g.in_grid(ux, uy, uz)) {                                                                     \
-      const vox_t w = a.out[g.idx(ux, uy, uz)];                                                      \
-      if (!(w & kNoCoc)) {                                                                           \
-        int ox, oy, oz;                                                                              \
-        unpack_coc(g.wrap, ux + g.gx0, uy + g.gy0, uz + g.gz0, w & ~kAct, ox, oy, oz);               \
-        const int32_t d = (x + g.gx0 - ox) * (x + g.gx0 - ox) + (y + g.gy0 - oy) * (y + g.gy0 - oy) + (z + g.gz0 - oz) * (z + g.gz0 - oz); \
-        if (d < best && (!g.wrap || d < kD2Cap)) best = d, bw = pack_coc(ox, oy, oz);                 \
-      }                                                                                              \
-    }                                                                                                \
+    // the cell's marks: lane = voxel row (x = lane / 8, y = lane % 8), a byte of the row's word
+    const int X = 8 * cx + (lane >> 3), Y = 8 * cy + (lane & 7);
+    uint32_t m = (X < g.nx && Y < g.ny) ? ((a.ubits[((int64_t)X * g.ny + Y) * g.nzw + (cz >> 2)] >> (8 * (cz & 3))) & 255u) : 0u;
+    uint32_t incl = (uint32_t)__popc(m);
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= off) incl += up;
+    }
+    const uint32_t nm = (uint32_t)__shfl((int)incl, 63);
+    {
+      uint32_t at = incl - (uint32_t)__popc(m);
+      while (m) {
+        const int b = __ffs((int)m) - 1;
+        m &= m - 1;
+        voxl[at++] = (uint16_t)((lane << 3) | b);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int sub = 0; sub < kMaskSub; ++sub) {
+      bool changed = false;
+      for (uint32_t i = (uint32_t)lane; i < nm; i += 64u) {
+        const uint32_t code = voxl[i];
+        const int x = (int)(code >> 6), y = (int)((code >> 3) & 7u), z = (int)(code & 7u);
+        const int vx = 8 * cx + x + g.gx0, vy = 8 * cy + y + g.gy0, vz = 8 * cz + z + g.gz0;
+        const int c0 = ((x + 2) * kTileE + y + 2) * kTileE + z + 2;
+        const vox_t cw = tile[c0];
+        int32_t best = (cw & kNoCoc) ? kD2Inf : dist2(g.wrap, vx, vy, vz, cw);
+        vox_t bw = cw;
+        // (a neighbour's word names the same obstacle for this voxel: ids are global coordinates, modulo 1024 on larger grids)
+#define FIESTA_PULL(DX, DY, DZ)                                                          \
+  {                                                                                      \
+    const vox_t w = tile[c0 + ((DX) * kTileE + (DY)) * kTileE + (DZ)];                   \
+    if (!(w & kNoCoc)) {                                                                 \
+      const int32_t d = dist2(g.wrap, vx, vy, vz, w);                                    \
+      if (d < best && (!g.wrap || d < kD2Cap)) best = d, bw = w;                         \
+    }                                                                                    \
   }
-    FIESTA_STENCIL24(FIESTA_PULL)
+        FIESTA_STENCIL24(FIESTA_PULL)
 #undef FIESTA_PULL
-    a.uval[i] = bw != cur ? bw : kUnobserved;
+        newv[i] = bw;
+        changed |= bw != cw;
+      }
+      if (!__any((int)changed)) break;  // (wave-uniform)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (every pull of this step has read the tile)
+      for (uint32_t i = (uint32_t)lane; i < nm; i += 64u) {
+        const uint32_t code = voxl[i];
+        tile[(((int)(code >> 6) + 2) * kTileE + (int)((code >> 3) & 7u) + 2) * kTileE + (int)(code & 7u) + 2] = newv[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // the voxels that differ from what `out` holds -> the second buffer (the two were equal on every marked voxel)
+    for (uint32_t i = (uint32_t)lane; i < nm; i += 64u) {
+      const uint32_t code = voxl[i];
+      const int x = (int)(code >> 6), y = (int)((code >> 3) & 7u), z = (int)(code & 7u);
+      const vox_t v = tile[((x + 2) * kTileE + y + 2) * kTileE + z + 2];
+      const int64_t idx = g.idx(8 * cx + x, 8 * cy + y, 8 * cz + z);
+      if (v != (a.out[idx] & ~kAct)) a.old[idx] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next cell's staging overwrites the tile)
   }
 }
 
-__global__ __launch_bounds__(256) void k_repair_commit(MaskArgs a, int it, uint32_t tag) {
-  __shared__ uint32_t s_changed;
+__global__ __launch_bounds__(256) void k_repair_commit(MaskArgs a, int it, int rd, uint32_t tag_prev, uint32_t tag, int first) {
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;
+  if (a.ctr[MC_OVERFLOW]) return;
   if (it > 0 && a.ctr[MC_CHANGED0 + it - 1] == 0) return;
-  const unsigned long long nu = a.ctr[MC_ULIST];
-  if (nu > a.ucap) return;
-  if (threadIdx.x == 0) s_changed = 0;
-  __syncthreads();
-  unsigned mine = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)nu; i += gridDim.x * blockDim.x) {
-    const vox_t w = a.uval[i];
-    if (w == kUnobserved) continue;
-    const uint32_t idx = a.ulist[i];
-    a.out[idx] = w;
-    ++mine;
-    const int z = (int)(idx % (uint32_t)g.nz), y = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), x = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
-    // the cells whose voxels have this one in their stencil (radius 2)
-    const int cx0 = max(x - 2, 0) >> 3, cx1 = min(x + 2, g.nx - 1) >> 3, cy0 = max(y - 2, 0) >> 3, cy1 = min(y + 2, g.ny - 1) >> 3,
-              cz0 = max(z - 2, 0) >> 3, cz1 = min(z + 2, g.nz - 1) >> 3;
-    for (int ux = cx0; ux <= cx1; ++ux)
-      for (int uy = cy0; uy <= cy1; ++uy)
-        for (int uz = cz0; uz <= cz1; ++uz) a.cstamp[((int64_t)ux * a.ncy + uy) * a.ncz + uz] = tag;
+  const uint32_t nuq = (uint32_t)a.ctr[MC_QUADS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // one wave per cell: lane = voxel row (x = lane / 8, y), its 8 z
+  const uint32_t *stamp_r = a.qstamp[rd];
+  uint32_t *stamp_w = a.qstamp[rd ^ 1];
+  unsigned total = 0;
+  for (uint32_t ci = blockIdx.x * 4u + (uint32_t)wave; ci < nuq; ci += gridDim.x * 4u) {
+    const uint32_t c = a.uq[ci];
+    if (!first && stamp_r[c] != tag_prev) continue;  // (the cells k_repair_cell worked on)
+    const int cz = (int)(c % (uint32_t)a.ncz);
+    const int cy = (int)((c / (uint32_t)a.ncz) % (uint32_t)a.ncy), cx = (int)(c / ((uint32_t)a.ncz * (uint32_t)a.ncy));
+    const int x = lane >> 3, y = lane & 7;
+    const int X = 8 * cx + x, Y = 8 * cy + y;
+    uint32_t m = (X < g.nx && Y < g.ny) ? ((a.ubits[((int64_t)X * g.ny + Y) * g.nzw + (cz >> 2)] >> (8 * (cz & 3))) & 255u) : 0u;
+    const int64_t base = ((int64_t)X * g.ny + Y) * g.nz + 8 * cz;
+    unsigned mine = 0;
+    uint32_t near = 0;  // bit (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1): a neighbour cell has a changed voxel in its halo
+    while (m) {
+      const int b = __ffs((int)m) - 1;
+      m &= m - 1;
+      const vox_t nv = a.old[base + b];
+      if (nv == a.out[base + b]) continue;
+      a.out[base + b] = nv;
+      ++mine;
+      const int dxl = x < 2 ? -1 : 0, dxh = x > 5 ? 1 : 0, dyl = y < 2 ? -1 : 0, dyh = y > 5 ? 1 : 0, dzl = b < 2 ? -1 : 0, dzh = b > 5 ? 1 : 0;
+      for (int dx = dxl; dx <= dxh; ++dx)
+        for (int dy = dyl; dy <= dyh; ++dy)
+          for (int dz = dzl; dz <= dzh; ++dz) near |= 1u << ((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mine += (unsigned)__shfl_xor((int)mine, off);
+      near |= (uint32_t)__shfl_xor((int)near, off);
+    }
+    if (mine && lane < 27 && ((near >> lane) & 1u)) {
+      const int ux = cx + lane / 9 - 1, uy = cy + (lane / 3) % 3 - 1, uz = cz + lane % 3 - 1;
+      if ((unsigned)ux < (unsigned)a.ncx && (unsigned)uy < (unsigned)a.ncy && (unsigned)uz < (unsigned)a.ncz)
+        stamp_w[((int64_t)ux * a.ncy + uy) * a.ncz + uz] = tag;
+    }
+    total += mine;
   }
-  for (int off = 32; off > 0; off >>= 1) mine += (unsigned)__shfl_xor((int)mine, off);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_changed, mine);
-  __syncthreads();
-  if (threadIdx.x == 0 && s_changed) atomicAdd(&a.ctr[MC_CHANGED0 + it], (unsigned long long)s_changed);
+  if (lane == 0 && total) atomicAdd(&a.ctr[MC_CHANGED0 + it], (unsigned long long)total);
 }
 
 }  // namespace fiesta

@@ -97,7 +97,8 @@ typedef struct fiesta_hip_stats {
                             update instead, cells == 0) */
   int64_t masked;        /* with bulk == 1: a PARTIALLY observed map -- the transform ran masked (mask_kernels.hpp): its result kept
                             on the observed voxels whose segment to their obstacle is observed, the others repaired by pulls */
-  int64_t mask_uncertified, mask_iterations, mask_walks; /* masked: voxels on the repair list, repair iterations, segment walks */
+  int64_t mask_uncertified, mask_iterations, mask_walks, mask_quads; /* masked: voxels under repair, repair iterations, segment
+                                                                        walks, quads (8 x 8 x 32 voxels) under repair */
   double mask_certify_ms, mask_repair_ms;               /* masked: HIP-event time of k_mask_certify / of the repair launches */
 } fiesta_hip_stats;
 

@@ -1,0 +1,107 @@
+"""tests only: numpy model of the MASKED transform (fiesta_amd/csrc/mask_kernels.hpp) -- the engine for large
+deltas on partially observed maps.  Same arithmetic, same schedule: the GPU field equals this model voxel for voxel
+(tests/test_gpu_masked.py), and the model is what was judged against the verbatim reference's order spread on the CPU before
+any kernel was written (tools/dev/masked_engine_model.py).
+
+  1. sites = the obstacles with at least one OBSERVED stencil neighbour (the others can hand their id to nobody,
+     src/ESDFMap.cpp:375-391); T = exact feature transform of the sites;
+  2. an observed voxel keeps T iff every voxel of its discrete segment to the winner is observed (certificate);
+  3. every other observed voxel keeps what it held before the update if that obstacle still exists, else "no obstacle", and is
+     repaired by 24-neighbour pulls (:349-367: stencil order, strict <) -- block Jacobi: per global iteration every 8^3 cell
+     runs up to BLOCK_SUBITERS steps on its own voxels against the other cells as the iteration found them.
+"""
+import numpy as np
+from scipy import ndimage
+
+from scenarios import D2_INF, DIRS24
+
+BLOCK_SUBITERS = 6   # cell-local Jacobi steps per global iteration (mask_kernels.hpp: kMaskSub); 1 = plain Jacobi
+def certificate(obs, V, S):
+    """V, S: (m, 3) voxels and their winners.  True where every sample of the discrete segment is observed: n = 2 max|d| + 1
+    steps, sample i at v + round(d i / n), i = 1 .. n - 1 (mask_kernels.hpp: mask_segment_observed)."""
+    d = (S - V).astype(np.int64)
+    n = 2 * np.abs(d).max(1) + 1
+    cert = np.ones(len(V), bool)
+    for i in range(1, int(n.max())):
+        act = cert & (i < n)
+        if not act.any():
+            break
+        ai = np.flatnonzero(act)
+        na = n[act][:, None]
+        p = V[act] + (2 * d[act] * i + na) // (2 * na)
+        ok = obs[p[:, 0], p[:, 1], p[:, 2]]
+        cert[ai[~ok]] = False
+    return cert
+
+
+def effective_sites(occ, obs):
+    """obstacles with at least one OBSERVED stencil neighbour: the others can never hand their id to anybody"""
+    G = occ.shape
+    P = np.pad(obs, 2)
+    any_n = np.zeros(G, bool)
+    for e in DIRS24:
+        any_n |= P[2 + e[0]:2 + e[0] + G[0], 2 + e[1]:2 + e[1] + G[1], 2 + e[2]:2 + e[2] + G[2]]
+    return occ & any_n
+
+
+def masked_engine(occ, obs, W_old=None, keep_old=True, mask_sites=True, subiters=None):
+    """occ, obs: bool (G, G, G); W_old: the engine's own previous field (winner coordinates, -1 none).
+    Returns d2 (int64; -1 unobserved, D2_INF none), W, stats."""
+    G = occ.shape
+    eff = effective_sites(occ, obs) if mask_sites else occ
+    idx = ndimage.distance_transform_edt(~eff, return_distances=False, return_indices=True)
+    g = np.meshgrid(*[np.arange(k) for k in G], indexing="ij")
+    V = np.argwhere(obs)
+    S = np.stack([idx[k][obs] for k in range(3)], 1)
+    cert = certificate(obs, V, S) if eff.any() else np.zeros(len(V), bool)
+    # field: winner coordinates per voxel; -1 = none
+    W = np.full(G + (3,), -1, np.int64)
+    W[V[cert, 0], V[cert, 1], V[cert, 2]] = S[cert]
+    U = V[~cert]
+    if keep_old and W_old is not None:  # an uncertified voxel keeps what it held if that obstacle is still there
+        o = W_old[U[:, 0], U[:, 1], U[:, 2]]
+        oc = np.where(o >= 0, o, 0)
+        alive = (o[:, 0] >= 0) & occ[oc[:, 0], oc[:, 1], oc[:, 2]]
+        W[U[alive, 0], U[alive, 1], U[alive, 2]] = o[alive]
+    O = np.argwhere(occ)
+    W[O[:, 0], O[:, 1], O[:, 2]] = O  # an obstacle is its own closest obstacle
+    U = U[~occ[U[:, 0], U[:, 1], U[:, 2]]]
+    iters = 0
+    Gs = np.array(G)
+    L = BLOCK_SUBITERS if subiters is None else subiters  # cell-local Jacobi steps per global iteration (1: plain Jacobi); halos frozen at the iteration's start
+    qid = lambda P: ((P[:, 0] >> 3) * 4096 + (P[:, 1] >> 3)) * 4096 + (P[:, 2] >> 3)   # noqa: E731  (the block: a cell of 8^3 voxels)
+    qU = qid(U) if len(U) else None
+    while len(U):
+        iters += 1
+        snap = W.copy() if L > 1 else W
+        any_change = False
+        for sub in range(L):
+            cur = W[U[:, 0], U[:, 1], U[:, 2]]
+            best = np.where(cur[:, 0] >= 0, ((U - cur) ** 2).sum(1), D2_INF)
+            bw = cur.copy()
+            for e in DIRS24:
+                N = U + e
+                ok = np.all((N >= 0) & (N < Gs), axis=1)
+                Nc = np.where(ok[:, None], N, 0)
+                w = W[Nc[:, 0], Nc[:, 1], Nc[:, 2]]
+                if L > 1:
+                    same = qid(Nc) == qU
+                    w = np.where(same[:, None], w, snap[Nc[:, 0], Nc[:, 1], Nc[:, 2]])
+                has = ok & (w[:, 0] >= 0) & obs[Nc[:, 0], Nc[:, 1], Nc[:, 2]]
+                cand = np.where(has, ((U - w) ** 2).sum(1), D2_INF)
+                take = cand < best
+                best = np.where(take, cand, best)
+                bw[take] = w[take]
+            changed = (bw != cur).any(1)
+            if not changed.any():
+                break
+            any_change = True
+            W[U[:, 0], U[:, 1], U[:, 2]] = bw
+        if not any_change:
+            break
+    d2 = np.where(W[..., 0] >= 0, ((np.stack(g, -1) - W) ** 2).sum(-1), D2_INF)
+    d2 = np.where(obs, d2, -1)
+    return d2.astype(np.int64), W, {"observed": int(obs.sum()), "uncertified": int((~cert).sum()), "jacobi_iterations": iters,
+                                    "isolated_obstacles": int((occ & ~eff).sum())}
+
+

@@ -18,7 +18,7 @@ import fiesta_amd  # noqa: E402
 from oracle import pyoracle  # noqa: E402
 from scenarios import Both, EnvelopeOracle, P_DEFAULT, compare_dense  # noqa: E402
 import bench  # noqa: E402
-import masked_engine_model as model  # noqa: E402
+import masked_model as model  # noqa: E402
 
 
 def main():
@@ -50,7 +50,7 @@ def main():
     def judge(what, sg):
         rep = compare_dense(gpu, env, check_logodds=False)
         e = rep["envelope"]
-        out = {"what": what, "engine": {k: sg[k] for k in ("masked", "bulk", "cells", "levels", "rounds", "mask_uncertified", "mask_iterations", "mask_walks", "nn_failed")},
+        out = {"what": what, "engine": {k: sg[k] for k in ("masked", "bulk", "cells", "levels", "rounds", "mask_uncertified", "mask_iterations", "mask_walks", "mask_quads", "nn_failed")}, "changed": sg["prof"],
                "ms": {k: round(sg[k], 4) for k in ("host_ms", "device_ms", "nn_cells_ms", "nn_lists_ms", "nn_fill_ms", "mask_certify_ms", "mask_repair_ms")},
                "finite": e["finite"], "disagree": e["disagree"], "closer": e["closer"], "farther": e["farther"], "vs_primary": e["vs_primary"],
                "pair_violations": rep["pair_violations"], "leave_one_out": e["leave_one_out"]}
