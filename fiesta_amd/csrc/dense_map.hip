@@ -1532,7 +1532,7 @@ bool DenseMap::cells_wanted() {
 // (nn_core.hpp: region_geom) -- no communication, like run_bulk.  Exactness is decided cell by cell on the device: a cell
 // whose window touches an open face of the region fails, and a failed cell fails the transform (the caller reads
 // C_NN_FAILED and takes the envelope passes).  Returns false (nothing launched) if the transform does not apply to this map.
-bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
+bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish, bool incremental, unsigned long long ni, unsigned long long nd) {
   const Geom &g = g_;
   if (g.nx > nn::kRegionMax || g.ny > nn::kRegionMax || g.nz > nn::kRegionMax) return false;
   NnArgs a;
@@ -1564,6 +1564,16 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   a.ctab = nn_ctab_.p, a.sites = nn_sites_.p, a.sites_cap = (uint32_t)std::min<size_t>(nn_sites_.cap, 0xFFFFFFFFu);
   a.lists = nn_lists_.p;
   a.dump = nn_lists_.p + (size_t)ncells * nn::kStride + (kListPad - 128);
+  if (incremental) {
+    if (nn_dirty_flag_.cap < (size_t)ncells) {
+      nn_dirty_flag_.ensure_exact((size_t)ncells, stream_);
+      FIESTA_HIP_CHECK(hipMemsetAsync(nn_dirty_flag_.p, 0, (size_t)ncells * sizeof(uint32_t), stream_));
+    }
+    nn_dirty_list_.ensure_exact((size_t)ncells / 2 + 64, stream_);
+    a.chg[0] = ins_.p, a.chg[1] = del_.p, a.nchg[0] = (uint32_t)ni, a.nchg[1] = (uint32_t)nd;
+    a.dirty_flag = nn_dirty_flag_.p, a.dirty_list = nn_dirty_list_.p, a.dirty_cap = (uint32_t)(ncells / 2);
+  }
+  a.dirty_count = &counters_[C_NN_DIRTY];
   a.cursor = &counters_[C_NN_CURSOR], a.failed = &counters_[C_NN_FAILED], a.entries = &counters_[C_NN_ENTRIES];
   // (the largest distance written: maps that track it, and shards -- the group sizes the next margin from it)
   const bool want_max = (track_ && !tr_out_) || open_side;
@@ -1575,7 +1585,7 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   if (publish) {  // a last one-thread launch reports into h_counters_ and cleans up (nn_kernels.hpp: k_nn_close)
     a.pub = h_counters_, a.queues = &counters_[C_INSERT], a.track_dst = track_ ? &counters_[C_MAXD2] : nullptr;
     a.tag = ++nn_tag_;
-    a.pub_failed = C_NN_FAILED, a.pub_entries = C_NN_ENTRIES, a.pub_maxd2 = C_FT_MAXD2, a.pub_tag = C_NN_CURSOR;
+    a.pub_failed = C_NN_FAILED, a.pub_entries = C_NN_ENTRIES, a.pub_maxd2 = C_FT_MAXD2, a.pub_tag = C_NN_CURSOR, a.pub_dirty = C_NN_DIRTY;
   }
   if (!ft_counters_clean_)
     FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
@@ -1587,6 +1597,29 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish) {
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[1], stream_));
   const int lcx = a.g.lx1 - a.g.lx0, lcy = a.g.ly1 - a.g.ly0, lcz = a.g.lz1 - a.g.lz0;  // the cells that get a list
+  if (incremental) {
+    // which cells a changed voxel can reach, their lists, their fill: three short launches that find their work on the device
+    hipLaunchKernelGGL(k_nn_mark, dim3((unsigned)std::min<unsigned long long>(std::max<unsigned long long>(ni + nd, 1), 4096)), dim3(256), 0, stream_, a);
+    const unsigned est = (unsigned)std::min<unsigned long long>((ni + nd) * 200 + 256, (unsigned long long)ncells / 2);
+    hipLaunchKernelGGL(k_nn_lists_dirty, dim3(std::min(std::max(est / 64u, 64u), 4096u)), dim3(256), 0, stream_, a);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[2], stream_));
+    if (want_max) hipLaunchKernelGGL(k_nn_fill_dirty<true>, dim3(std::min(std::max(est / 4u, 64u), 8192u)), dim3(256), 0, stream_, a);
+    else hipLaunchKernelGGL(k_nn_fill_dirty<false>, dim3(std::min(std::max(est / 4u, 64u), 8192u)), dim3(256), 0, stream_, a);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[3], stream_));
+    if (publish) {
+      hipLaunchKernelGGL(k_nn_close, dim3(1), dim3(1), 0, stream_, a);
+      FIESTA_HIP_CHECK(hipGetLastError());
+    }
+    if (st) {
+      st->bulk = 1;
+      st->cells = 1;
+      st->nn_incremental = 1;
+      st->relax_launches = 4;
+    }
+    return true;
+  }
   if (a.g.big()) hipLaunchKernelGGL(k_nn_lists<true>, dim3((lcz + 63) / 64, (lcy + 3) / 4, lcx), dim3(1024), 0, stream_, a);
   else hipLaunchKernelGGL(k_nn_lists<false>, dim3((lcz + 63) / 64, (lcy + 3) / 4, lcx), dim3(1024), 0, stream_, a);
   FIESTA_HIP_CHECK(hipGetLastError());
@@ -1921,6 +1954,7 @@ void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time
       st->nn_cells_ms = m1, st->nn_lists_ms = m2, st->nn_fill_ms = m3;
       st->nn_entries = (int64_t)h_counters_[C_NN_ENTRIES];
       st->nn_failed = (int64_t)h_counters_[C_NN_FAILED];
+      if (st->nn_incremental) st->nn_dirty_cells = (int64_t)h_counters_[C_NN_DIRTY];
     } else {
       st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
       st->ft_overflow[0] = (int64_t)h_counters_[C_FT_OVF0], st->ft_overflow[3] = (int64_t)h_counters_[C_FT_OVF0 + 3];
@@ -1942,6 +1976,7 @@ bool DenseMap::bulk_try(fiesta_hip_stats *st, int margin, bool *exact) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   nn_clean_ = false;
+  nn_valid_ = false;
   ++epoch_;
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
   reset_stats_counters();
@@ -2107,6 +2142,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
   use_device();
   const bool nn_was_clean = nn_clean_;  // (only a cell transform that reports for itself sets it again: bulk_finish)
   nn_clean_ = false;
+  const bool nn_was_valid = nn_valid_;  // (set again by a cell transform that succeeds on the map's own field)
   const auto h0 = std::chrono::steady_clock::now();
   if (host_counts_valid_) {  // (what UpdateOccupancy read last: nothing else changes these four)
     for (int k = 0; k < 4; ++k) h_counters_[C_INSERT + k] = host_counts_[k];
@@ -2129,6 +2165,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
     if (st) st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     return;
   }
+  nn_valid_ = false;
   ++epoch_;
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
@@ -2185,10 +2222,27 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
       reset_stats_counters(/*lists=*/true, queues_zeroed_);
     }
     counters_reset = true;
+    // the lists of the last update are still valid and little has changed: only the cells a changed voxel can reach are redone
+    // (a voxel dirties the ~(2 x reach + 1)^3 cells around it: worth it while that is a fraction of the map)
+    const int64_t ncells8 = (int64_t)((g_.nx + 7) / 8) * ((g_.ny + 7) / 8) * ((g_.nz + 7) / 8);
+    if (want_cells && nn_was_valid && !g_.wrap && (int64_t)(ni + nd) * 180 <= ncells8 / 3 && run_cells(st, 0, /*publish=*/true, /*incremental=*/true, ni, nd)) {
+      bulk_finish(st, h0, /*cells=*/true, /*published=*/true);
+      if (h_counters_[C_NN_FAILED] == 0) {
+        nn_fail_streak_ = 0;
+        nn_valid_ = true;
+        return;
+      }
+      // more dirty cells than the list holds, or a cell that lost its last obstacle in reach: the full transform, from scratch
+      FIESTA_HIP_CHECK(hipMemsetAsync(nn_dirty_flag_.p, 0, nn_dirty_flag_.cap * sizeof(uint32_t), stream_));
+      if (st) memset(&st->cells, 0, sizeof(st->cells)), st->nn_incremental = 0;
+      FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+      reset_stats_counters(/*lists=*/true);
+    }
     if (want_cells && run_cells(st, 0, /*publish=*/true)) {
       bulk_finish(st, h0, /*cells=*/true, /*published=*/true);
       if (h_counters_[C_NN_FAILED] == 0) {
         nn_fail_streak_ = 0;
+        nn_valid_ = !g_.sharded;
         return;
       }
       nn_fail_streak_ = std::min(nn_fail_streak_ + 1, 6);
@@ -2575,6 +2629,7 @@ void DenseMap::snapshot_save(int slot) {
 void DenseMap::snapshot_restore(int slot) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   nn_clean_ = false;  // (the counters come back as they were saved)
+  nn_valid_ = false;
   use_device();
   if (slot < 0 || slot >= 4 || !snaps_[slot].valid) throw Error(FIESTA_HIP_ERR_STATE, "no such snapshot");
   Snapshot &s = snaps_[slot];
@@ -2621,6 +2676,7 @@ void DenseMap::snapshot_restore(int slot) {
 void DenseMap::checkpoint(const char *path, bool write) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   nn_clean_ = false;  // (the counters come back as they were saved)
+  if (!write) nn_valid_ = false;
   use_device();
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   DevFile f(path, write, stream_);

@@ -73,6 +73,7 @@ enum Counter {
   C_FT_OVF5 = C_FT_OVF0 + 5,
   C_NN_CURSOR = C_FT_OVF0 + 1,   // cell transform (nn_kernels.hpp), in the slots the envelope passes leave unused: sites handed out,
   C_NN_FAILED = C_FT_OVF0 + 2,   //   cells that got no list (non-zero: the update is served by the envelope passes instead),
+  C_NN_DIRTY = C_FT_OVF0 + 3,    //   cells an incremental transform redoes,
   C_NN_ENTRIES = C_FT_OVF0 + 4,  //   list entries in total
   C_FUSE_TICKET = C_FT_OVF0 + 5,  // k_fuse: work-groups that have finished (the last one reports and clears it: zero between launches)
   C_FT_MAXD2,    // bulk path: largest d^2 written (2^30: a voxel found no obstacle in its region)
@@ -210,7 +211,9 @@ class DenseMap {
   bool masked_eligible(unsigned long long ni, unsigned long long nd);
   bool run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0);  // false: nothing committed, the rounds serve the update
   bool cells_wanted();                  // should this update try the cell transform (nn_kernels.hpp) before the envelope passes?
-  bool run_cells(fiesta_hip_stats *st, int margin, bool publish);  // false: not applicable to this map (nothing launched)
+  // false: not applicable to this map (nothing launched).  incremental: only the cells whose search window holds a voxel of the
+  // insert / delete queues get a new list and a new fill (the lists of the last transform must still be valid: nn_valid_)
+  bool run_cells(fiesta_hip_stats *st, int margin, bool publish, bool incremental = false, unsigned long long ni = 0, unsigned long long nd = 0);
   void bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time_point h0, bool cells = false, bool published = false);
   void reset_stats_counters(bool lists = false, bool queues = false);
   void enable_distance_tracking();
@@ -275,7 +278,9 @@ class DenseMap {
   bool ft_counters_clean_ = false;  // reset_stats_counters() ran and no transform has used the spill counters since
   DevBuf<uint32_t> ft_inter_, ft_out_;
   // cell transform (nn_kernels.hpp): first site per cell, the sites, one record (list) per cell
-  DevBuf<uint32_t> nn_ctab_, nn_sites_, nn_lists_;
+  DevBuf<uint32_t> nn_ctab_, nn_sites_, nn_lists_, nn_dirty_flag_, nn_dirty_list_;
+  bool nn_valid_ = false;        // the lists describe the occupancy as of the last UpdateESDF and the field is their transform: the
+                                 // next update may be incremental (cleared by every other engine, restore and load)
   double nn_last_ms_ = 0;        // kernel time of the last cell transform that succeeded ...
   long long nn_last_nocc_ = -1;  // ... and the obstacle count it ran on
   bool nn_clean_ = false;        // the last update was a cell transform whose fill cleaned the counters up behind itself (nn_fill_done)

@@ -53,7 +53,8 @@ constexpr int kSH = 9;              // a key's distance part starts at this bit;
 constexpr int kBias = 3 * 7 * 7;    // |v|^2 of the voxel farthest from the cell origin
 constexpr int kKfirst = 1;           // cells around the cell the competitor is first looked for in (any site will do: the nearest prunes best)
 constexpr int kKmax = 7;            // the search window reaches this many cells (p in [-56, 63]: -2 p stays inside a signed byte)
-constexpr int kStride = 128;        // dwords of a cell's record: [0] the number of entries, [4 + 4 i ..] entry i = (b, K, m, W)
+constexpr int kStride = 128;        // dwords of a cell's record: [0] the number of entries, [1] the reach of the search window the list was
+                                    // built with, in cells (what an incremental update marks dirty cells by), [4 + 4 i ..] entry i = (b, K, m, W)
 constexpr int kRaw = 32;            // candidates a team's scratch holds between the sweep and the record
 constexpr int kThin = 16;           // lists longer than this are thinned pairwise
 constexpr uint32_t kPadK = 0xFFFFFFFFu;  // K of a padding entry (b = m = 0): never the minimum
@@ -288,6 +289,7 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
   constexpr int kmax = Src::reach < kKmax ? Src::reach : kKmax;
   const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
   int raw = 0;
+  int reach = kKmax;  // (a cell that cannot be served: anything that changes within the widest window may help it)
   // Second try: more candidates than the scratch holds are collected again against the NEAREST site of the 5^3 cells (the
   // first competitor came from the 3^3 cells and may be a poor one).
   for (int kfirst = kKfirst; kfirst <= 2; kfirst = 2 + (raw <= kRaw)) {
@@ -325,6 +327,7 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
       raw = 0;
       break;
     }
+    reach = Kw;
     team.restart();
     for (RowWalk rw(Kw, team.rank, Team::lanes); !rw.done(); rw.next()) {
       const int gx = gap_of(rw.dx), gy = gap_of(rw.dy);
@@ -396,6 +399,7 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
   if (n > kCap) n = 0;
   if (team.rank == 0) {
     out[0] = (uint32_t)n;
+    out[1] = (uint32_t)(n ? reach : kKmax);
     if (n & 1) {  // (the kernel takes two entries per step)
       uint32_t *e = out + 4 + 4 * n;
       e[0] = 0u, e[1] = kPadK, e[2] = 0u, e[3] = 0u;

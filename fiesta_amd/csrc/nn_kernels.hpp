@@ -46,7 +46,15 @@ struct NnArgs {
   uint32_t *dump;  // 128 dwords nobody reads: lanes outside the array store here, so that every wave issues the same stores
   unsigned long long *pub, *queues, *track_dst;
   unsigned long long tag;
-  int pub_failed, pub_entries, pub_maxd2, pub_tag;  // slots of pub
+  int pub_failed, pub_entries, pub_maxd2, pub_tag, pub_dirty;  // slots of pub
+  // an INCREMENTAL transform (k_nn_mark, k_nn_lists_dirty, k_nn_fill_dirty): the lists of the last transform are still valid except
+  // in the cells whose search window holds a voxel that changed occupancy since -- only those get a new list and a new fill
+  const uint32_t *chg[2];       // the insert and the delete queue: linear voxel indices of the array
+  uint32_t nchg[2];
+  uint32_t *dirty_flag;         // per cell: on the dirty list
+  uint32_t *dirty_list;         // cells to redo (linear cell index)
+  unsigned long long *dirty_count;
+  uint32_t dirty_cap;           // (more dirty cells than this: the transform fails and the full one runs)
 };
 
 
@@ -58,8 +66,10 @@ __global__ void k_nn_close(NnArgs a) {
   const unsigned long long failed = *a.failed, entries = *a.entries, md = a.maxd2 ? *a.maxd2 : 0ull;
   volatile unsigned long long *h = a.pub;
   h[a.pub_failed] = failed, h[a.pub_entries] = entries, h[a.pub_maxd2] = md;
-  if (a.track_dst && failed == 0) *a.track_dst = md;
+  if (a.dirty_count) h[a.pub_dirty] = *a.dirty_count;
+  if (a.track_dst && failed == 0) *a.track_dst = a.dirty_flag ? max(*a.track_dst, md) : md;  // (incremental: the cells left alone keep theirs)
   *a.cursor = 0, *a.failed = 0, *a.entries = 0;
+  if (a.dirty_count) *a.dirty_count = 0;
   if (a.maxd2) *a.maxd2 = 0;
   if (failed == 0) a.queues[0] = 0, a.queues[1] = 0;
   __threadfence_system();
@@ -590,14 +600,10 @@ __global__ __launch_bounds__(256) void k_nn_fill_full(NnArgs a) {
 typedef __attribute__((address_space(4))) const uint32_t nn_cu32;  // constant address space: wave-uniform reads become s_load
 typedef uint32_t nn_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const nn_u32x4 nn_cu32x4;
+// one cell's fill by ONE wave (lane = the cell's (y, z) column): the record through the scalar cache, predicated stores
 template <bool TRACK>
-__global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
+__device__ __forceinline__ void nn_fill_cell(const NnArgs &a, const int cx, const int cy, const int cz, const int lane, uint32_t &dmax) {
   const nn::Geom &g = a.g;
-  if (*a.failed) return;
-  // grid: the cells that got a list, (ceil((lz1 - lz0) / 4), ly1 - ly0, lx1 - lx0)
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int cz = g.lz0 + (int)blockIdx.x * 4 + wave, cy = g.ly0 + (int)blockIdx.y, cx = g.lx0 + (int)blockIdx.z;
-  if (cz < g.lz1) {  // (a wave beyond the range only goes to the closing barrier)
   const int64_t cell = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
   const uint32_t *rec = a.lists + cell * nn::kStride;
   nn_cu32 *lp = reinterpret_cast<nn_cu32 *>(reinterpret_cast<uintptr_t>(rec));
@@ -622,7 +628,6 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
   const bool inyz = (unsigned)Y < (unsigned)g.ay && (unsigned)Z < (unsigned)g.az;
   vox_t *out = a.coc + ((int64_t)X0 * g.ay + Y) * g.az + Z;
   const int64_t plane = (int64_t)g.ay * g.az;
-  uint32_t dmax = 0;
 #pragma unroll
   for (int x = 0; x < nn::kB; ++x) {
     const uint32_t ww = rec[7 + ((best[x] & 0x1F0u) >> 2)];
@@ -631,10 +636,113 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
       if (TRACK) dmax = max(dmax, (best[x] >> nn::kSH) - (uint32_t)nn::kBias + (uint32_t)(x * x + y * y + z * z));
     }
   }
+}
+
+template <bool TRACK>
+__global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
+  const nn::Geom &g = a.g;
+  if (*a.failed) return;
+  // grid: the cells that got a list, (ceil((lz1 - lz0) / 4), ly1 - ly0, lx1 - lx0)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cz = g.lz0 + (int)blockIdx.x * 4 + wave, cy = g.ly0 + (int)blockIdx.y, cx = g.lx0 + (int)blockIdx.z;
+  if (cz >= g.lz1) return;
+  uint32_t dmax = 0;
+  nn_fill_cell<TRACK>(a, cx, cy, cz, lane, dmax);
   if (TRACK) {
     for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
     if (lane == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
   }
+}
+
+// ---- the incremental transform: only the cells a change can reach ---------------------------------------------------------------------
+// A cell's list depends on the sites inside its search window and on nothing else (nn_core.hpp: build_list), and its record keeps
+// the window's reach: a voxel that changed occupancy dirties exactly the cells within whose reach it lies.  k_nn_mark: a work-group
+// per changed voxel, its threads over the (2 kKmax + 1)^3 cells around it; k_nn_lists_dirty: a team of four lanes per dirty cell,
+// straight from memory (nn::PlainSrc: a few thousand cells do not pay for staging a neighbourhood); k_nn_fill_dirty: a wave per
+// dirty cell.  More dirty cells than the list holds fails the transform (the full one serves the update).
+__global__ __launch_bounds__(256) void k_nn_mark(NnArgs a) {
+  const nn::Geom &g = a.g;
+  const uint32_t total = a.nchg[0] + a.nchg[1];
+  constexpr int E = 2 * nn::kKmax + 1;
+  for (uint32_t v = blockIdx.x; v < total; v += gridDim.x) {
+    const uint32_t idx = v < a.nchg[0] ? a.chg[0][v] : a.chg[1][v - a.nchg[0]];
+    const int z = (int)(idx % (uint32_t)g.nz), y = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), x = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
+    const int sx = x >> 3, sy = y >> 3, sz = z >> 3;
+    for (int o = (int)threadIdx.x; o < E * E * E; o += (int)blockDim.x) {
+      const int dz = o % E - nn::kKmax, dy = (o / E) % E - nn::kKmax, dx = o / (E * E) - nn::kKmax;
+      const int cx = sx + dx, cy = sy + dy, cz = sz + dz;
+      bool add = false;
+      int64_t c = 0;
+      if ((unsigned)cx < (unsigned)g.ncx && (unsigned)cy < (unsigned)g.ncy && (unsigned)cz < (unsigned)g.ncz) {
+        c = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
+        const int r = max(max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy), dz < 0 ? -dz : dz);
+        add = r <= (int)a.lists[c * nn::kStride + 1] && a.dirty_flag[c] == 0u && atomicExch(&a.dirty_flag[c], 1u) == 0u;
+      }
+      // one atomic on the list's cursor per wave
+      const unsigned long long m = __ballot(add);
+      if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(a.dirty_count, (unsigned long long)__popcll(m));
+        base = (unsigned long long)__shfl((long long)base, leader);
+        const unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if (add && at < a.dirty_cap) a.dirty_list[at] = (uint32_t)c;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nn_lists_dirty(NnArgs a) {
+  __shared__ uint32_t s_slots[64];
+  __shared__ uint32_t s_raw[64 * (nn::kRaw + 1)];
+  const nn::Geom &g = a.g;
+  if (*a.failed) return;
+  const unsigned long long nd = *a.dirty_count;
+  if (nd > a.dirty_cap) {  // (too much has changed for the dirty list: this transform fails)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.failed, 1ull);
+    return;
+  }
+  const int tid = (int)threadIdx.x, team_i = tid >> 2;
+  const nn::Frame fr = nn::frame_of(g);
+  const nn::PlainSrcT<false> src{a.ctab, a.sites, g.ncx, g.ncy, g.ncz};
+  unsigned bad = 0, entries = 0;
+  for (unsigned long long i = blockIdx.x * 64ull + (unsigned long long)team_i; i < nd; i += gridDim.x * 64ull) {
+    const uint32_t c = a.dirty_list[i];
+    const int cz = (int)(c % (uint32_t)g.ncz), cy = (int)((c / (uint32_t)g.ncz) % (uint32_t)g.ncy), cx = (int)(c / ((uint32_t)g.ncz * (uint32_t)g.ncy));
+    QuadTeam team{tid & 3, &s_slots[team_i], &s_raw[team_i * (nn::kRaw + 1)]};
+    if (team.rank == 0) s_slots[team_i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int n = nn::build_list(src, team, cx, cy, cz, a.lists + (int64_t)c * nn::kStride, false, nn::kNone, 0xFFFFFFFFu, fr);
+    if (team.rank == 0) {
+      if (n <= 0) ++bad; else entries += (unsigned)n;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    bad += (unsigned)__shfl_xor((int)bad, off);
+    entries += (unsigned)__shfl_xor((int)entries, off);
+  }
+  if ((tid & 63) == 0) {
+    if (bad) atomicAdd(a.failed, (unsigned long long)bad);
+    (void)entries;  // (the statistics of an incremental transform: the lists it rebuilt are not added to the total)
+  }
+}
+
+template <bool TRACK>
+__global__ __launch_bounds__(256) void k_nn_fill_dirty(NnArgs a) {
+  const nn::Geom &g = a.g;
+  if (*a.failed) return;
+  const unsigned long long nd = *a.dirty_count;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t dmax = 0;
+  for (unsigned long long i = blockIdx.x * 4ull + (unsigned long long)wave; i < nd; i += gridDim.x * 4ull) {
+    const uint32_t c = a.dirty_list[i];
+    const int cz = (int)(c % (uint32_t)g.ncz), cy = (int)((c / (uint32_t)g.ncz) % (uint32_t)g.ncy), cx = (int)(c / ((uint32_t)g.ncz * (uint32_t)g.ncy));
+    nn_fill_cell<TRACK>(a, cx, cy, cz, lane, dmax);
+    if (lane == 0) a.dirty_flag[c] = 0u;
+  }
+  if (TRACK) {
+    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
+    if (lane == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
   }
 }
 

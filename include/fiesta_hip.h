@@ -95,6 +95,9 @@ typedef struct fiesta_hip_stats {
   int64_t nn_entries;    /* cell transform: list entries over all cells */
   int64_t nn_failed;     /* cells that got no list when the cell transform was tried (> 0: the envelope passes served the
                             update instead, cells == 0) */
+  int64_t nn_incremental; /* with cells == 1: only the cells whose search window held a changed voxel were redone (the lists of the
+                             last transform were still valid), nn_dirty_cells of them */
+  int64_t nn_dirty_cells;
   int64_t masked;        /* with bulk == 1: a PARTIALLY observed map -- the transform ran masked (mask_kernels.hpp): its result kept
                             on the observed voxels whose segment to their obstacle is observed, the others repaired by pulls */
   int64_t mask_uncertified, mask_iterations, mask_walks, mask_quads; /* masked: voxels under repair, repair iterations, segment

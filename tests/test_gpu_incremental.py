@@ -1,0 +1,103 @@
+"""GPU: the INCREMENTAL cell transform (nn_kernels.hpp: k_nn_mark / k_nn_lists_dirty / k_nn_fill_dirty) -- on a fully observed map
+whose last UpdateESDF was a cell transform, a small delta redoes only the cells whose search window holds a changed voxel
+(the reference's own cost follows the delta's Voronoi cells, src/ESDFMap.cpp:273-337).  Exactness is the transform's: squared
+distances equal to the reference's on every voxel, whatever mix of incremental and full updates produced the field."""
+import numpy as np
+import pytest
+
+from scenarios import P_DEFAULT, Both, all_voxels, assert_exact, compare_dense
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(oracle_libs, kind, n, engine="cells"):
+    import fiesta_amd
+    res = 0.1
+    gpu = fiesta_amd.ESDFMap((0, 0, 0), res, ((n - 0.5) * res,) * 3, update_engine=engine)
+    cpu = oracle_libs.OracleMap((0, 0, 0), res, ((n - 0.5) * res,) * 3, kind=kind)
+    b = Both(gpu, cpu)
+    b.params()
+    b.observe(all_voxels(n), 0)
+    b.fuse()
+    b.esdf()
+    return b
+
+
+def test_incremental_and_full_updates_interleaved_match_the_reference(hip_lib, oracle_libs, best_oracle_kind):
+    n = 96
+    b = _both(oracle_libs, best_oracle_kind, n)
+    rng = np.random.RandomState(7)
+    V = all_voxels(n)
+    live = V[rng.choice(len(V), 400, replace=False)]
+    b.make_occupied(live)
+    sg, _ = b.esdf()
+    assert sg["cells"] == 1 and sg["nn_incremental"] == 0, sg
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    seen_inc = seen_full = 0
+    for step in range(10):
+        k = [2, 5, 1, 40, 3, 8, 1, 200, 4, 2][step]   # small deltas run incrementally, the large ones dirty too much and run in full
+        new = V[rng.choice(len(V), k, replace=False)]
+        old, live = live[:k], np.concatenate([live[k:], new])
+        b.mixed(new, old)
+        sg, _ = b.esdf()
+        assert sg["cells"] == 1 and sg["nn_failed"] == 0, sg
+        seen_inc += int(sg["nn_incremental"])
+        seen_full += int(not sg["nn_incremental"])
+        if sg["nn_incremental"]:
+            assert 0 < sg["nn_dirty_cells"] < (n // 8) ** 3, sg
+        assert_exact(compare_dense(b.gpu, b.cpu))
+    assert seen_inc >= 6 and seen_full >= 1, (seen_inc, seen_full)
+    b.gpu.close()
+    b.cpu.close()
+
+
+def test_incremental_delete_of_the_only_obstacle_in_reach_falls_back(hip_lib, oracle_libs, best_oracle_kind):
+    """Deleting obstacles until some cell finds nothing within its widest window: the incremental attempt fails (a cell without a
+    list), the same call is served in full -- by the envelope passes, since the cell transform cannot serve such a scene either."""
+    n = 128
+    b = _both(oracle_libs, best_oracle_kind, n)
+    rng = np.random.RandomState(3)
+    V = all_voxels(n)
+    S = V[rng.choice(len(V), 500, replace=False)]
+    b.make_occupied(S)
+    sg, _ = b.esdf()
+    assert sg["cells"] == 1, sg
+    far = S[(S[:, 0] > 40)]          # free one side of the map completely
+    for s in range(0, len(far), 60):
+        b.make_free(far[s:s + 60])
+        sg, _ = b.esdf()
+        assert sg["bulk"] == 1, sg
+        assert_exact(compare_dense(b.gpu, b.cpu))
+    b.gpu.close()
+    b.cpu.close()
+
+
+def test_other_engines_invalidate_the_lists(hip_lib, oracle_libs, best_oracle_kind):
+    n = 64
+    b = _both(oracle_libs, best_oracle_kind, n, engine="auto")
+    rng = np.random.RandomState(9)
+    V = all_voxels(n)
+    S = V[rng.choice(len(V), 200, replace=False)]
+    b.make_occupied(S)
+    sg, _ = b.esdf()
+    assert sg["cells"] == 1, sg
+    b.gpu.set_update_engine("rounds")
+    b.mixed(V[rng.choice(len(V), 3, replace=False)], S[:3])
+    sg, _ = b.esdf()
+    assert sg["bulk"] == 0, sg
+    b.gpu.set_update_engine("cells")
+    b.mixed(V[rng.choice(len(V), 3, replace=False)], S[3:6])
+    sg, _ = b.esdf()
+    assert sg["cells"] == 1 and sg["nn_incremental"] == 0, sg   # (the rounds changed the field behind the lists' back)
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    b.mixed(V[rng.choice(len(V), 3, replace=False)], S[6:9])
+    b.gpu.snapshot_save(0)
+    sg, _ = b.esdf()
+    assert sg["cells"] == 1 and sg["nn_incremental"] == 1, sg
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    b.gpu.snapshot_restore(0)
+    sg = b.gpu.UpdateESDF()
+    assert sg["cells"] == 1 and sg["nn_incremental"] == 0, sg   # (a restored map: whatever the lists describe, it is not this field)
+    assert_exact(compare_dense(b.gpu, b.cpu))
+    b.gpu.close()
+    b.cpu.close()
