@@ -24,7 +24,7 @@ def _both(oracle_libs, kind, n, engine="cells"):
 
 
 def test_incremental_and_full_updates_interleaved_match_the_reference(hip_lib, oracle_libs, best_oracle_kind):
-    n = 96
+    n = 160
     b = _both(oracle_libs, best_oracle_kind, n)
     rng = np.random.RandomState(7)
     V = all_voxels(n)
@@ -35,7 +35,7 @@ def test_incremental_and_full_updates_interleaved_match_the_reference(hip_lib, o
     assert_exact(compare_dense(b.gpu, b.cpu))
     seen_inc = seen_full = 0
     for step in range(10):
-        k = [2, 5, 1, 40, 3, 8, 1, 200, 4, 2][step]   # small deltas run incrementally, the large ones dirty too much and run in full
+        k = [2, 5, 1, 40, 3, 7, 1, 200, 4, 2][step]   # small deltas run incrementally, the large ones dirty too much and run in full
         new = V[rng.choice(len(V), k, replace=False)]
         old, live = live[:k], np.concatenate([live[k:], new])
         b.mixed(new, old)
@@ -73,11 +73,11 @@ def test_incremental_delete_of_the_only_obstacle_in_reach_falls_back(hip_lib, or
 
 
 def test_other_engines_invalidate_the_lists(hip_lib, oracle_libs, best_oracle_kind):
-    n = 64
+    n = 128
     b = _both(oracle_libs, best_oracle_kind, n, engine="auto")
     rng = np.random.RandomState(9)
     V = all_voxels(n)
-    S = V[rng.choice(len(V), 200, replace=False)]
+    S = V[rng.choice(len(V), 800, replace=False)]
     b.make_occupied(S)
     sg, _ = b.esdf()
     assert sg["cells"] == 1, sg
