@@ -1599,9 +1599,9 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish, bool in
   const int lcx = a.g.lx1 - a.g.lx0, lcy = a.g.ly1 - a.g.ly0, lcz = a.g.lz1 - a.g.lz0;  // the cells that get a list
   if (incremental) {
     // which cells a changed voxel can reach, their lists, their fill: three short launches that find their work on the device
-    hipLaunchKernelGGL(k_nn_mark, dim3((unsigned)std::min<unsigned long long>(std::max<unsigned long long>(ni + nd, 1), 4096)), dim3(256), 0, stream_, a);
+    hipLaunchKernelGGL(k_nn_mark, dim3((unsigned)std::min<unsigned long long>((ni + nd) * 3375 / 256 + 1, 16384)), dim3(256), 0, stream_, a);
     const unsigned est = (unsigned)std::min<unsigned long long>((ni + nd) * 200 + 256, (unsigned long long)ncells / 2);
-    hipLaunchKernelGGL(k_nn_lists_dirty, dim3(std::min(std::max(est / 64u, 64u), 4096u)), dim3(256), 0, stream_, a);
+    hipLaunchKernelGGL(k_nn_lists_dirty, dim3(std::min(std::max(est / 16u, 64u), 8192u)), dim3(256), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[2], stream_));
     if (want_max) hipLaunchKernelGGL(k_nn_fill_dirty<true>, dim3(std::min(std::max(est / 4u, 64u), 8192u)), dim3(256), 0, stream_, a);
@@ -1742,7 +1742,8 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
   }
   // the walk list: room for a quarter of the voxels (measured on config 2's partially observed scene: 13 % of the observed
   // voxels need the walk), in kMaskSegs segments that the quads feed in turn
-  const size_t seg_cap = (size_t)std::max<int64_t>(g.n / 4 / kMaskSegs, 8192);
+  if (mask_seg_cap_ == 0) mask_seg_cap_ = (size_t)std::max<int64_t>(g.n / 4 / kMaskSegs, 8192);
+  const size_t seg_cap = mask_seg_cap_;
   effocc_.ensure_exact((size_t)nbitwords_, stream_);
   mask_ubits_.ensure_exact((size_t)nbitwords_, stream_);
   cellobs_.ensure_exact((size_t)ncells, stream_);
@@ -1841,7 +1842,13 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
     for (int k = 0; k < 8; ++k) st->prof[k] = (int64_t)h_mask_ctr_[MC_CHANGED0 + k];
   // a segment of the walk list ran out of room: nothing is committed (k_mask_walk and everything behind it returned at once,
   // the field is as it was) and the frontier rounds serve the update
-  if (h_mask_ctr_[MC_OVERFLOW] != 0) return false;
+  if (h_mask_ctr_[MC_OVERFLOW] != 0) {
+    if (mask_seg_cap_ * kMaskSegs >= (size_t)g.n) return false;  // (cannot be: a voxel is walked once)
+    mask_seg_cap_ *= 2;  // a scene with more walks than the list was sized for: once more, with room
+    tr_occ_ = nullptr, tr_out_ = nullptr, tr_cellobs_ = nullptr;
+    reset_stats_counters(/*lists=*/true);
+    return run_masked(st, h0);
+  }
   // the repair: further chains until an iteration changes nothing
   int total_iters = 0;
   for (int n = chain;;) {
@@ -2225,7 +2232,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
     // the lists of the last update are still valid and little has changed: only the cells a changed voxel can reach are redone
     // (a voxel dirties the ~(2 x reach + 1)^3 cells around it: worth it while that is a fraction of the map)
     const int64_t ncells8 = (int64_t)((g_.nx + 7) / 8) * ((g_.ny + 7) / 8) * ((g_.nz + 7) / 8);
-    if (want_cells && nn_was_valid && !g_.wrap && (int64_t)(ni + nd) * 180 <= ncells8 / 3 && run_cells(st, 0, /*publish=*/true, /*incremental=*/true, ni, nd)) {
+    if (want_cells && nn_was_valid && !g_.wrap && (int64_t)(ni + nd) * 180 <= ncells8 / 2 && run_cells(st, 0, /*publish=*/true, /*incremental=*/true, ni, nd)) {
       bulk_finish(st, h0, /*cells=*/true, /*published=*/true);
       if (h_counters_[C_NN_FAILED] == 0) {
         nn_fail_streak_ = 0;

@@ -289,6 +289,36 @@ struct QuadTeam {
   }
 };
 
+// Sixteen adjacent lanes per list (the incremental transform: few cells, each a chain of dependent reads straight from memory --
+// sixteen lanes make the chain a quarter as long as four do).
+struct WideTeam {
+  static constexpr int lanes = 16;
+  int rank;
+  uint32_t *counter;
+  uint32_t *raw;
+  __device__ __forceinline__ void nearest(int &e2, uint32_t &w) const {
+#pragma unroll
+    for (int off = 1; off <= 8; off <<= 1) {
+      const int oe = __shfl_xor(e2, off);
+      const uint32_t ow = (uint32_t)__shfl_xor((int)w, off);
+      if (oe < e2 || (oe == e2 && ow < w)) e2 = oe, w = ow;
+    }
+  }
+  __device__ __forceinline__ void restart() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (rank == 0) (void)atomicExch(counter, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  __device__ __forceinline__ int slot() { return (int)atomicAdd(counter, 1u); }
+  __device__ __forceinline__ int count_now() const { return (int)min(atomicAdd(counter, 0u), (uint32_t)nn::kRaw); }
+  __device__ __forceinline__ void put(int k, uint32_t v) { raw[k] = v; }
+  __device__ __forceinline__ uint32_t get(int k) const { return raw[k]; }
+  __device__ __forceinline__ int count() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return (int)atomicAdd(counter, 0u);
+  }
+};
+
 // WRAP: a region of more than 1024 voxels along an axis, its sites stored modulo 1024 (nn_core.hpp: site_offset)
 template <bool WRAP>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_nn_lists(NnArgs a) {  // (two work-groups per CU: 64 VGPRs, < 80 KB of LDS)  // 64 (z) x 4 (y) cells, four lanes each
@@ -663,17 +693,23 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
 __global__ __launch_bounds__(256) void k_nn_mark(NnArgs a) {
   const nn::Geom &g = a.g;
   const uint32_t total = a.nchg[0] + a.nchg[1];
-  constexpr int E = 2 * nn::kKmax + 1;
-  for (uint32_t v = blockIdx.x; v < total; v += gridDim.x) {
+  constexpr int E = 2 * nn::kKmax + 1, E3 = E * E * E;
+  // a lane per (changed voxel, cell of the (2 kKmax + 1)^3 around it): every record read of the launch in flight at once
+  const unsigned long long pairs = (unsigned long long)total * E3;
+  for (unsigned long long p0 = (unsigned long long)blockIdx.x * blockDim.x; p0 < pairs; p0 += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long p = p0 + threadIdx.x;
+    const bool live = p < pairs;
+    const uint32_t v = live ? (uint32_t)(p / E3) : 0u;
+    const int o = live ? (int)(p % E3) : 0;
     const uint32_t idx = v < a.nchg[0] ? a.chg[0][v] : a.chg[1][v - a.nchg[0]];
     const int z = (int)(idx % (uint32_t)g.nz), y = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), x = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
     const int sx = x >> 3, sy = y >> 3, sz = z >> 3;
-    for (int o = (int)threadIdx.x; o < E * E * E; o += (int)blockDim.x) {
+    {
       const int dz = o % E - nn::kKmax, dy = (o / E) % E - nn::kKmax, dx = o / (E * E) - nn::kKmax;
       const int cx = sx + dx, cy = sy + dy, cz = sz + dz;
       bool add = false;
       int64_t c = 0;
-      if ((unsigned)cx < (unsigned)g.ncx && (unsigned)cy < (unsigned)g.ncy && (unsigned)cz < (unsigned)g.ncz) {
+      if (live && (unsigned)cx < (unsigned)g.ncx && (unsigned)cy < (unsigned)g.ncy && (unsigned)cz < (unsigned)g.ncz) {
         c = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
         const int r = max(max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy), dz < 0 ? -dz : dz);
         add = r <= (int)a.lists[c * nn::kStride + 1] && a.dirty_flag[c] == 0u && atomicExch(&a.dirty_flag[c], 1u) == 0u;
@@ -693,8 +729,8 @@ __global__ __launch_bounds__(256) void k_nn_mark(NnArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_nn_lists_dirty(NnArgs a) {
-  __shared__ uint32_t s_slots[64];
-  __shared__ uint32_t s_raw[64 * (nn::kRaw + 1)];
+  __shared__ uint32_t s_slots[16];
+  __shared__ uint32_t s_raw[16 * (nn::kRaw + 1)];
   const nn::Geom &g = a.g;
   if (*a.failed) return;
   const unsigned long long nd = *a.dirty_count;
@@ -702,14 +738,14 @@ __global__ __launch_bounds__(256) void k_nn_lists_dirty(NnArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.failed, 1ull);
     return;
   }
-  const int tid = (int)threadIdx.x, team_i = tid >> 2;
+  const int tid = (int)threadIdx.x, team_i = tid >> 4;
   const nn::Frame fr = nn::frame_of(g);
   const nn::PlainSrcT<false> src{a.ctab, a.sites, g.ncx, g.ncy, g.ncz};
   unsigned bad = 0, entries = 0;
-  for (unsigned long long i = blockIdx.x * 64ull + (unsigned long long)team_i; i < nd; i += gridDim.x * 64ull) {
+  for (unsigned long long i = blockIdx.x * 16ull + (unsigned long long)team_i; i < nd; i += gridDim.x * 16ull) {
     const uint32_t c = a.dirty_list[i];
     const int cz = (int)(c % (uint32_t)g.ncz), cy = (int)((c / (uint32_t)g.ncz) % (uint32_t)g.ncy), cx = (int)(c / ((uint32_t)g.ncz * (uint32_t)g.ncy));
-    QuadTeam team{tid & 3, &s_slots[team_i], &s_raw[team_i * (nn::kRaw + 1)]};
+    WideTeam team{tid & 15, &s_slots[team_i], &s_raw[team_i * (nn::kRaw + 1)]};
     if (team.rank == 0) s_slots[team_i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int n = nn::build_list(src, team, cx, cy, cz, a.lists + (int64_t)c * nn::kStride, false, nn::kNone, 0xFFFFFFFFu, fr);
