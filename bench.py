@@ -204,6 +204,14 @@ def run_cpu_baseline(args, grid=None):
     }
 
 
+def revision():
+    """the commit the library was built from (__graft_entry__.build() stamps it; the GPU box has no .git)"""
+    try:
+        return open(os.path.join(ROOT, ".fiesta_rev")).read().strip()
+    except OSError:
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -1025,6 +1033,7 @@ def main():
                 "frac_of_measured_copy_6.29TBs": call_achieved / 6290.0,
                 "phases_p50_ms": phases, "dominant_kernel": dominant, "ring_overflows": overflow, "engine_steps": engine_steps,
             },
+            "revision": revision(),
             "verify": verify,
             "parity": parity_summary(args, G, world) if args.unobserved <= 0 else parity_partial(args, G, world, timed),
         }

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void k_fetch_brick(Geom g, const vox_t *coc, c
   reinterpret_cast<uint16_t *>(dst + 4096)[t] = (uint16_t)bits;
 }
 struct DenseMap::HostBricks {
-  static constexpr int kSlots = 2048, kWords = 4096 + 128;  // direct-mapped: brick id modulo kSlots (35 MB of pinned memory)
+  static constexpr int kSlots = 2048, kWords = 4096 + 128;  // direct-mapped by a HASH of the brick's coordinates (35 MB of pinned memory)
   uint32_t *pool = nullptr;
   std::vector<int64_t> tag;
   std::vector<uint64_t> stamp;
@@ -714,7 +714,11 @@ const uint32_t *DenseMap::host_brick(int x, int y, int z) {
   }
   const int bx = x >> 4, by = y >> 4, bz = z >> 4;
   const int64_t id = ((int64_t)bx * ((g_.ny + 15) >> 4) + by) * ((g_.nz + 15) >> 4) + bz;
-  const int slot = (int)(id % HostBricks::kSlots);
+  // (id modulo 2048 put every brick of a planner's path along x on a 512^3 map -- (ny/16)(nz/16) = 1024 bricks per x-slab
+  //  -- into two slots; a multiplicative hash of the three coordinates spreads any axis-aligned run over the table.  The scalar
+  //  queries of one map are single-threaded, like every other call on it: include/fiesta_hip.h.)
+  const uint32_t hsh = ((uint32_t)bx * 0x9E3779B1u) ^ ((uint32_t)by * 0x85EBCA77u) ^ ((uint32_t)bz * 0xC2B2AE3Du);
+  const int slot = (int)((hsh ^ (hsh >> 15)) % (uint32_t)HostBricks::kSlots);
   uint32_t *b = bricks_->pool + (size_t)slot * HostBricks::kWords;
   if (bricks_->tag[slot] != id || bricks_->stamp[slot] != field_epoch_) {
     use_device();
@@ -1169,7 +1173,6 @@ bool DenseMap::check_update() {  // CheckUpdate (src/ESDFMap.cpp:227-233)
 }
 
 bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) {
-  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   use_device();
   // ONE host synchronisation per call (none when nothing was observed): the host keeps the queue sizes / map totals of
   // its last read and an upper bound of the touched list, so the fusion kernel is launched without asking the device
@@ -1186,6 +1189,7 @@ bool DenseMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del)
   const long long nocc_before = (long long)host_counts_[3];
   const unsigned long long nt = (unsigned long long)touched_upper_;
   if (nt) {
+    ++field_epoch_;  // (occupancy and first observations may change: the host-side brick cache of the scalar queries is stale)
     ins_.ensure(ni + nt, stream_, ni);
     del_.ensure(nd + nt, stream_, nd);
     hipLaunchKernelGGL(k_fuse, dim3(grid_for((int64_t)nt, 256, 8192)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
@@ -2144,8 +2148,7 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
   return false;
 }
 
-void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
-  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)  // UpdateESDF (src/ESDFMap.cpp:273-398)
+void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
   const bool nn_was_clean = nn_clean_;  // (only a cell transform that reports for itself sets it again: bulk_finish)
   nn_clean_ = false;
@@ -2173,6 +2176,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {
     return;
   }
   nn_valid_ = false;
+  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on; an update without work leaves it valid)
   ++epoch_;
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
@@ -2681,9 +2685,8 @@ void DenseMap::snapshot_restore(int slot) {
 
 // Raw dump (write) / load of the whole map state: one routine for both directions (checkpoint.hpp).
 void DenseMap::checkpoint(const char *path, bool write) {
-  ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   nn_clean_ = false;  // (the counters come back as they were saved)
-  if (!write) nn_valid_ = false;
+  if (!write) nn_valid_ = false, ++field_epoch_;  // (a loaded field: the host-side brick cache of the scalar queries is stale)
   use_device();
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   DevFile f(path, write, stream_);

@@ -183,7 +183,7 @@ FIESTA_NN_HD inline void unpack_p(uint32_t v, int &px, int &py, int &pz) {
 // the sites of cells z0..z1 of cell row (X, Y) -- empty for a row outside the map, z clamped into the row; site(): the
 // packed site behind an index of such a range.  PlainSrc reads the two arrays as they lie in memory (the host model; the
 // kernel's path for the rare cell whose window leaves the staged neighbourhood); k_nn_lists stages its work-group's
-// neighbourhood in LDS and reads that (nn_kernels.hpp: StagedSrc, reach = 3 cells).
+// neighbourhood in LDS and reads that (nn_kernels.hpp: StagedSrc, reach = kStageK = 4 cells).
 template <bool WRAP>
 struct PlainSrcT {
   static constexpr bool wrap = WRAP;     // sites are stored modulo 1024 (site_offset)

@@ -211,10 +211,11 @@ __global__ __launch_bounds__(1024) void k_nn_cells(NnArgs a) {  // sixteen cell 
 }
 
 // ---- one list per cell ------------------------------------------------------------------------------------------------------
-// The neighbourhood of a work-group's 64 (z) x 4 (y) cells in LDS: table rows and sites of the cells within kStageK of it.
-// A window that reaches farther (a cell whose nearest obstacle is more than ~16 voxels away) reads those rows from memory.
+// The neighbourhood of a work-group's 64 (z) x 4 (y) cells in LDS: table rows and sites of the cells within kStageK = 4 of it
+// (9 x 12 rows of cells).  A window that reaches farther (a cell whose nearest obstacle is more than ~24 voxels away) reads
+// those rows from memory.
 constexpr int kStageK = 4;
-constexpr int kStageNX = 1 + 2 * kStageK, kStageNY = 4 + 2 * kStageK, kStageNR = kStageNX * kStageNY;  // 7 x 10 rows of cells
+constexpr int kStageNX = 1 + 2 * kStageK, kStageNY = 4 + 2 * kStageK, kStageNR = kStageNX * kStageNY;  // 9 x 12 rows of cells
 constexpr int kStageNZ = 64 + 2 * kStageK + 1;                                                          // table entries per row
 constexpr int kStageSites = 3072;
 template <bool WRAP>

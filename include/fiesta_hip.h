@@ -94,7 +94,8 @@ typedef struct fiesta_hip_stats {
   double nn_cells_ms, nn_lists_ms, nn_fill_ms; /* cell transform: HIP-event time of k_nn_cells / k_nn_lists / k_nn_fill */
   int64_t nn_entries;    /* cell transform: list entries over all cells */
   int64_t nn_failed;     /* cells that got no list when the cell transform was tried (> 0: the envelope passes served the
-                            update instead, cells == 0) */
+                            update instead, cells == 0).  Once a cell has failed the launch stops early: nn_failed and
+                            nn_entries are then LOWER BOUNDS (how many work-groups were already running depends on scheduling) */
   int64_t nn_incremental; /* with cells == 1: only the cells whose search window held a changed voxel were redone (the lists of the
                              last transform were still valid), nn_dirty_cells of them */
   int64_t nn_dirty_cells;

@@ -74,3 +74,19 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"(from|import)\s+oracle|oracle_api\.h|pyoracle|libfiesta_port|libfiesta_ref", src):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_hand_scheduled_kernels_do_not_spill():
+    """k_nn_fill_full, k_ft_x and k_ft_plane wait for LDS-DMA fetches with COUNTED s_waitcnt vmcnt(n) around inline asm: a scratch
+    spill (an extra VMEM operation the count does not know) would make them consume stale records silently.  The
+    code objects inside the built library are inspected: no scratch, no spilled registers."""
+    import sys
+    from fiesta_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_kernel_resources
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build_hip()
+    guarded = check_kernel_resources.check(_lib.LIB_PATH)
+    assert any("k_nn_fill_full" in k for k in guarded) and any("k_ft_x" in k for k in guarded)

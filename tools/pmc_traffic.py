@@ -64,7 +64,14 @@ def main():
     }
     out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
     out["command"] = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (two rocprofv3 --pmc passes)"
-    out["commit"] = os.environ.get("FIESTA_REV", "unrecorded")  # the commit whose binary ran (the GPU box has no .git)
+    # the commit whose binary ran: the GPU box has no .git -- __graft_entry__.build() leaves a stamp that travels with the snapshot
+    rev = os.environ.get("FIESTA_REV")
+    if not rev:
+        try:
+            rev = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".fiesta_rev")).read().strip()
+        except OSError:
+            rev = "unrecorded"
+    out["commit"] = rev
     print(json.dumps(out, indent=1))
 
 
