@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("ft_max_d2", C.c_int64), ("dropped_observations", C.c_int64), ("levels", C.c_int64), ("grid_levels", C.c_int64),
                 ("cells", C.c_int64), ("nn_cells_ms", C.c_double), ("nn_lists_ms", C.c_double), ("nn_fill_ms", C.c_double),
                 ("nn_entries", C.c_int64), ("nn_failed", C.c_int64),
-                ("nn_incremental", C.c_int64), ("nn_dirty_cells", C.c_int64), ("masked", C.c_int64), ("mask_uncertified", C.c_int64), ("mask_iterations", C.c_int64), ("mask_walks", C.c_int64), ("mask_quads", C.c_int64),
+                ("nn_incremental", C.c_int64), ("nn_dirty_cells", C.c_int64), ("nn_brute_cells", C.c_int64), ("masked", C.c_int64), ("mask_uncertified", C.c_int64), ("mask_iterations", C.c_int64), ("mask_walks", C.c_int64), ("mask_quads", C.c_int64),
                 ("mask_certify_ms", C.c_double), ("mask_repair_ms", C.c_double)]
 
     def as_dict(self):

@@ -1578,6 +1578,13 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish, bool in
     a.dirty_flag = nn_dirty_flag_.p, a.dirty_list = nn_dirty_list_.p, a.dirty_cap = (uint32_t)(ncells / 2);
   }
   a.dirty_count = &counters_[C_NN_DIRTY];
+  a.ticket = &counters_[C_FUSE_TICKET];
+  if (!g.sharded && !a.g.big()) {  // cells without a list are served one by one (k_nn_close), up to a 64th of the cells
+    a.fail_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(ncells / 64, 16), 4096);
+    nn_fail_list_.ensure((size_t)a.fail_cap, stream_);
+    a.fail_list = nn_fail_list_.p, a.nfail = &counters_[C_NN_BRUTE];
+  }
+  const unsigned close_blocks = nn_last_brute_ > 0 ? (unsigned)std::min<long long>(nn_last_brute_ + 8, 512) : 1u;
   a.cursor = &counters_[C_NN_CURSOR], a.failed = &counters_[C_NN_FAILED], a.entries = &counters_[C_NN_ENTRIES];
   // (the largest distance written: maps that track it, and shards -- the group sizes the next margin from it)
   const bool want_max = (track_ && !tr_out_) || open_side;
@@ -1590,6 +1597,7 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish, bool in
     a.pub = h_counters_, a.queues = &counters_[C_INSERT], a.track_dst = track_ ? &counters_[C_MAXD2] : nullptr;
     a.tag = ++nn_tag_;
     a.pub_failed = C_NN_FAILED, a.pub_entries = C_NN_ENTRIES, a.pub_maxd2 = C_FT_MAXD2, a.pub_tag = C_NN_CURSOR, a.pub_dirty = C_NN_DIRTY;
+    a.pub_brute = C_NN_BRUTE;
   }
   if (!ft_counters_clean_)
     FIESTA_HIP_CHECK(hipMemsetAsync(&counters_[C_FT_OVF0], 0, 7 * sizeof(unsigned long long), stream_));  // + C_FT_MAXD2
@@ -1613,7 +1621,9 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish, bool in
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[3], stream_));
     if (publish) {
-      hipLaunchKernelGGL(k_nn_close, dim3(1), dim3(1), 0, stream_, a);
+      NnArgs c = a;
+      c.nfail = nullptr;  // (an incremental transform fails on a cell without a list: the full one serves it)
+      hipLaunchKernelGGL(k_nn_close, dim3(1), dim3(256), 0, stream_, c);
       FIESTA_HIP_CHECK(hipGetLastError());
     }
     if (st) {
@@ -1656,8 +1666,8 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish, bool in
   }
   FIESTA_HIP_CHECK(hipGetLastError());
   FIESTA_HIP_CHECK(hipEventRecord(ft_ev_[3], stream_));
-  if (publish) {
-    hipLaunchKernelGGL(k_nn_close, dim3(1), dim3(1), 0, stream_, a);
+  if (publish || a.nfail) {  // the cells without a list, and (publish) the report
+    hipLaunchKernelGGL(k_nn_close, dim3(close_blocks), dim3(256), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
   }
   if (track_ && !publish && !tr_out_)  // (a failed transform leaves 0 here; the envelope passes that follow it set the bound themselves)
@@ -1966,6 +1976,7 @@ void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time
       st->nn_entries = (int64_t)h_counters_[C_NN_ENTRIES];
       st->nn_failed = (int64_t)h_counters_[C_NN_FAILED];
       if (st->nn_incremental) st->nn_dirty_cells = (int64_t)h_counters_[C_NN_DIRTY];
+      else st->nn_brute_cells = (int64_t)h_counters_[C_NN_BRUTE];
     } else {
       st->ft_rows_ms = m1, st->ft_plane_ms = m2, st->ft_x_ms = m3;
       st->ft_overflow[0] = (int64_t)h_counters_[C_FT_OVF0], st->ft_overflow[3] = (int64_t)h_counters_[C_FT_OVF0 + 3];
@@ -1973,6 +1984,7 @@ void DenseMap::bulk_finish(fiesta_hip_stats *st, std::chrono::steady_clock::time
     st->relax_ms = (double)m1 + m2 + m3;
     st->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
   }
+  if (cells && published && !(st && st->nn_incremental)) nn_last_brute_ = (long long)h_counters_[C_NN_BRUTE];
   if (timed) {
     if (cells) {
       if (h_counters_[C_NN_FAILED] == 0) nn_last_ms_ = (double)m1 + m2 + m3, nn_last_nocc_ = (long long)h_counters_[C_NOCC];

@@ -73,6 +73,7 @@ enum Counter {
   C_FT_OVF5 = C_FT_OVF0 + 5,
   C_NN_CURSOR = C_FT_OVF0 + 1,   // cell transform (nn_kernels.hpp), in the slots the envelope passes leave unused: sites handed out,
   C_NN_FAILED = C_FT_OVF0 + 2,   //   cells that got no list (non-zero: the update is served by the envelope passes instead),
+  C_NN_BRUTE = C_FT_OVF0 + 0,    //   cells without a list that k_nn_close serves one by one,
   C_NN_DIRTY = C_FT_OVF0 + 3,    //   cells an incremental transform redoes,
   C_NN_ENTRIES = C_FT_OVF0 + 4,  //   list entries in total
   C_FUSE_TICKET = C_FT_OVF0 + 5,  // k_fuse: work-groups that have finished (the last one reports and clears it: zero between launches)
@@ -279,7 +280,8 @@ class DenseMap {
   bool ft_counters_clean_ = false;  // reset_stats_counters() ran and no transform has used the spill counters since
   DevBuf<uint32_t> ft_inter_, ft_out_;
   // cell transform (nn_kernels.hpp): first site per cell, the sites, one record (list) per cell
-  DevBuf<uint32_t> nn_ctab_, nn_sites_, nn_lists_, nn_dirty_flag_, nn_dirty_list_;
+  DevBuf<uint32_t> nn_ctab_, nn_sites_, nn_lists_, nn_dirty_flag_, nn_dirty_list_, nn_fail_list_;
+  long long nn_last_brute_ = 0;  // cells the last cell transform served by brute force (sizes the closing launch of the next)
   bool nn_valid_ = false;        // the lists describe the occupancy as of the last UpdateESDF and the field is their transform: the
                                  // next update may be incremental (cleared by every other engine, restore and load)
   double nn_last_ms_ = 0;        // kernel time of the last cell transform that succeeded ...

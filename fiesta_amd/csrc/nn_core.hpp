@@ -58,6 +58,7 @@ constexpr int kStride = 128;        // dwords of a cell's record: [0] the number
 constexpr int kRaw = 32;            // candidates a team's scratch holds between the sweep and the record
 constexpr int kThin = 16;           // lists longer than this are thinned pairwise
 constexpr uint32_t kPadK = 0xFFFFFFFFu;  // K of a padding entry (b = m = 0): never the minimum
+constexpr int kWhySparse = 1, kWhyDense = 2, kWhyOpen = 3;  // why a cell got no list (record dword 1, bits 8..15; bits 16..: the window's reach)
 constexpr int kNone = 0x7FFFFFFF;
 
 // The REGION the transform works on: the occupancy bits it reads, in its own coordinates (sites, cells).  An unsharded map:
@@ -290,6 +291,7 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
   const int ox = kB * cx, oy = kB * cy, oz = kB * cz;
   int raw = 0;
   int reach = kKmax;  // (a cell that cannot be served: anything that changes within the widest window may help it)
+  int why = kWhySparse;  // should the cell end without a list: nothing within reach / a shard's open face / too many survivors
   // Second try: more candidates than the scratch holds are collected again against the NEAREST site of the 5^3 cells (the
   // first competitor came from the 3^3 cells and may be a poor one).
   for (int kfirst = kKfirst; kfirst <= 2; kfirst = 2 + (raw <= kRaw)) {
@@ -325,9 +327,11 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
         continue;
       }
       raw = 0;
+      why = kWhyOpen;
       break;
     }
     reach = Kw;
+    why = kWhyDense;
     team.restart();
     for (RowWalk rw(Kw, team.rank, Team::lanes); !rw.done(); rw.next()) {
       const int gx = gap_of(rw.dx), gy = gap_of(rw.dy);
@@ -399,7 +403,9 @@ FIESTA_NN_HD inline int build_list(const Src &src, Team &team, int cx, int cy, i
   if (n > kCap) n = 0;
   if (team.rank == 0) {
     out[0] = (uint32_t)n;
-    out[1] = (uint32_t)(n ? reach : kKmax);
+    // the window's reach; a cell without a list: the widest reach (whatever changes around it may help), and why -- k_nn_brute
+    // serves the few cells a scene leaves without a list one by one (sparse: against every site; dense: against its window)
+    out[1] = n ? (uint32_t)reach : ((uint32_t)kKmax | ((uint32_t)why << 8) | ((uint32_t)reach << 16));
     if (n & 1) {  // (the kernel takes two entries per step)
       uint32_t *e = out + 4 + 4 * n;
       e[0] = 0u, e[1] = kPadK, e[2] = 0u, e[3] = 0u;

@@ -46,7 +46,7 @@ struct NnArgs {
   uint32_t *dump;  // 128 dwords nobody reads: lanes outside the array store here, so that every wave issues the same stores
   unsigned long long *pub, *queues, *track_dst;
   unsigned long long tag;
-  int pub_failed, pub_entries, pub_maxd2, pub_tag, pub_dirty;  // slots of pub
+  int pub_failed, pub_entries, pub_maxd2, pub_tag, pub_dirty, pub_brute;  // slots of pub
   // an INCREMENTAL transform (k_nn_mark, k_nn_lists_dirty, k_nn_fill_dirty): the lists of the last transform are still valid except
   // in the cells whose search window holds a voxel that changed occupancy since -- only those get a new list and a new fill
   const uint32_t *chg[2];       // the insert and the delete queue: linear voxel indices of the array
@@ -55,27 +55,14 @@ struct NnArgs {
   uint32_t *dirty_list;         // cells to redo (linear cell index)
   unsigned long long *dirty_count;
   uint32_t dirty_cap;           // (more dirty cells than this: the transform fails and the full one runs)
+  // cells WITHOUT a list (nothing within reach, more survivors than a list holds): up to fail_cap of them are served one by one
+  // (k_nn_brute, behind the fill); more than that -- or any on a shard with an open face -- fails the transform (`failed`)
+  uint32_t *fail_list;          // linear cell index
+  unsigned long long *nfail;
+  uint32_t fail_cap;
+  unsigned long long *ticket;   // k_nn_close: work-groups that have finished (zero between launches)
 };
 
-
-// ---- the transform's last launch: one thread reports and cleans up ------------------------------------------------------------
-// One host synchronisation then ends the update: no copy of the counters, no reset launch ahead of the next transform.  (The
-// same work done by the fill's last work-group -- a ticket every work-group takes at its end -- doubled the fill's time: 2048
-// returning atomics on one address, all at the same moment.)
-__global__ void k_nn_close(NnArgs a) {
-  const unsigned long long failed = *a.failed, entries = *a.entries, md = a.maxd2 ? *a.maxd2 : 0ull;
-  volatile unsigned long long *h = a.pub;
-  h[a.pub_failed] = failed, h[a.pub_entries] = entries, h[a.pub_maxd2] = md;
-  if (a.dirty_count) h[a.pub_dirty] = *a.dirty_count;
-  if (a.track_dst && failed == 0) *a.track_dst = a.dirty_flag ? max(*a.track_dst, md) : md;  // (incremental: the cells left alone keep theirs)
-  *a.cursor = 0, *a.failed = 0, *a.entries = 0;
-  if (a.dirty_count) *a.dirty_count = 0;
-  if (a.maxd2) *a.maxd2 = 0;
-  if (failed == 0) a.queues[0] = 0, a.queues[1] = 0;
-  __threadfence_system();
-  h[a.pub_tag] = a.tag;  // (last: the host trusts the other three once it sees this update's tag)
-  __threadfence_system();
-}
 
 // ---- sites by cell row ---------------------------------------------------------------------------------------------------
 // One batch of loads per wave: the 64 voxel rows of the cell row, a byte per lane and row (two on a 1024-voxel axis), kept
@@ -434,9 +421,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       n = nn::build_list(src, team, cx, cy, cz, rec, false, nn::kNone, 0xFFFFFFFFu, fr);
     }
   }
+  // a cell without a list: on the list of cells k_nn_brute serves one by one, while that has room and the region has no open
+  // face (a plain load first: a scene that leaves EVERY cell without a list must not queue 10^5 atomics on one address)
+  bool hard = live && team.rank == 0 && n == 0;
+  if (hard && a.fail_list && fr.open == 0 && *a.nfail < a.fail_cap) {
+    const unsigned long long at = atomicAdd(a.nfail, 1ull);
+    if (at < a.fail_cap) {
+      a.fail_list[at] = (uint32_t)(((int64_t)cx * g.ncy + cy) * g.ncz + cz);
+      hard = false;
+    }
+  }
   // statistics: failures and entries, one atomic each per work-group -- by the LAST wave to get here, not behind a barrier
   // (a wave that waits for its work-group's slowest team keeps its registers from the next work-group)
-  const unsigned long long bad = __ballot(live && team.rank == 0 && n == 0);
+  const unsigned long long bad = __ballot(hard);
   int sum = (live && team.rank == 0) ? n : 0;
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
   if ((tid & 63) == 0) {
@@ -713,7 +710,7 @@ __global__ __launch_bounds__(256) void k_nn_mark(NnArgs a) {
       if (live && (unsigned)cx < (unsigned)g.ncx && (unsigned)cy < (unsigned)g.ncy && (unsigned)cz < (unsigned)g.ncz) {
         c = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
         const int r = max(max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy), dz < 0 ? -dz : dz);
-        add = r <= (int)a.lists[c * nn::kStride + 1] && a.dirty_flag[c] == 0u && atomicExch(&a.dirty_flag[c], 1u) == 0u;
+        add = r <= (int)(a.lists[c * nn::kStride + 1] & 255u) && a.dirty_flag[c] == 0u && atomicExch(&a.dirty_flag[c], 1u) == 0u;
       }
       // one atomic on the list's cursor per wave
       const unsigned long long m = __ballot(add);
@@ -781,6 +778,121 @@ __global__ __launch_bounds__(256) void k_nn_fill_dirty(NnArgs a) {
     for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
     if (lane == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
   }
+}
+
+// ---- the cells a scene leaves without a list, one by one ---------------------------------------------------------------------------------
+// A work-group per such cell, a thread per two voxels: the nearest site by brute force -- among EVERY site where the cell found
+// nothing within its widest window (a sparse corner of the map), among the sites of its window where it found more survivors
+// than a list holds (a cell over a dense cluster).  Exact like the lists (the window holds every site that can win in the cell).
+// Runs behind the fill, whose words for these cells (their records are empty) it overwrites.  A handful of cells per update at
+// the ends of the density range the cell transform is tried in; a scene that leaves more than fail_cap cells without a list fails
+// the transform as before.
+__device__ __forceinline__ void nn_brute_cells(const NnArgs &a, uint32_t *s_sites) {
+  const nn::Geom &g = a.g;
+  const bool TRACK = a.maxd2 != nullptr;
+  if (*a.failed) return;
+  const uint32_t nf = (uint32_t)min(*a.nfail, (unsigned long long)a.fail_cap);
+  const uint32_t total = (uint32_t)min(*a.cursor, (unsigned long long)a.sites_cap);
+  const int t = (int)threadIdx.x;
+  uint32_t dmax = 0;
+  for (uint32_t fi = blockIdx.x; fi < nf; fi += gridDim.x) {
+    const uint32_t c = a.fail_list[fi];
+    const int cz = (int)(c % (uint32_t)g.ncz), cy = (int)((c / (uint32_t)g.ncz) % (uint32_t)g.ncy), cx = (int)(c / ((uint32_t)g.ncz * (uint32_t)g.ncy));
+    const uint32_t info = a.lists[(int64_t)c * nn::kStride + 1];
+    const bool dense = ((info >> 8) & 255u) == (uint32_t)nn::kWhyDense;
+    const int K = dense ? (int)(info >> 16) : 0;
+    // this thread's two voxels of the cell: (x, y, z) and (x + 4, y, z)
+    const int vx = nn::kB * cx + (t >> 6), vy = nn::kB * cy + ((t >> 3) & 7), vz = nn::kB * cz + (t & 7);
+    uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu, w0 = 0, w1 = 0;
+    auto range = [&](uint32_t i0, const uint32_t i1) {  // the sites [i0, i1) against the cell's voxels (every thread calls)
+      for (; i0 < i1; i0 += 256u) {
+        __syncthreads();
+        if (i0 + (uint32_t)t < i1) s_sites[t] = a.sites[i0 + (uint32_t)t];
+        __syncthreads();
+        const int m = (int)min(256u, i1 - i0);
+        for (int k = 0; k < m; ++k) {
+          const uint32_t w = s_sites[k];
+          int sx, sy, sz;
+          nn::unpack_site(w, sx, sy, sz);
+          const int dy = sy - vy, dz = sz - vz, d0 = sx - vx, d1 = d0 - 4;
+          const uint32_t r = (uint32_t)(dy * dy + dz * dz);
+          const uint32_t e0 = r + (uint32_t)(d0 * d0), e1 = r + (uint32_t)(d1 * d1);
+          if (e0 < b0) b0 = e0, w0 = w;
+          if (e1 < b1) b1 = e1, w1 = w;
+        }
+      }
+    };
+    if (dense) {
+      for (int dx = -K; dx <= K; ++dx)
+        for (int dy = -K; dy <= K; ++dy) {
+          const int X = cx + dx, Y = cy + dy;
+          if ((unsigned)X >= (unsigned)g.ncx || (unsigned)Y >= (unsigned)g.ncy) continue;  // (block-uniform)
+          const uint32_t *row = a.ctab + ((int64_t)X * g.ncy + Y) * (g.ncz + 1);
+          range(row[max(cz - K, 0)], row[min(cz + K, g.ncz - 1) + 1]);
+        }
+    } else {
+      range(0u, total);
+    }
+    // the words a voxel stores: global coordinates (the region's origin added), modulo 1024 -- as an entry's W (nn_core.hpp)
+    auto word = [&](const uint32_t w) {
+      int sx, sy, sz;
+      nn::unpack_site(w, sx, sy, sz);
+      return (((uint32_t)(sx + g.wx) & 1023u) << 20) | (((uint32_t)(sy + g.wy) & 1023u) << 10) | ((uint32_t)(sz + g.wz) & 1023u);
+    };
+    const int Y = vy - g.fy, Z = vz - g.fz, X0 = vx - g.fx;
+    if ((unsigned)Y < (unsigned)g.ay && (unsigned)Z < (unsigned)g.az) {
+      const int64_t plane = (int64_t)g.ay * g.az;
+      vox_t *out = a.coc + ((int64_t)X0 * g.ay + Y) * g.az + Z;
+      if ((unsigned)X0 < (unsigned)g.ax && b0 != 0xFFFFFFFFu) {
+        out[0] = word(w0);
+        if (TRACK) dmax = max(dmax, b0);
+      }
+      if ((unsigned)(X0 + 4) < (unsigned)g.ax && b1 != 0xFFFFFFFFu) {
+        out[4 * plane] = word(w1);
+        if (TRACK) dmax = max(dmax, b1);
+      }
+    }
+  }
+  if (TRACK) {
+    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
+    if ((t & 63) == 0 && (unsigned long long)dmax > *a.maxd2) atomicMax(a.maxd2, (unsigned long long)dmax);
+  }
+}
+
+
+// ---- the transform's last launch: the cells without a list, then one thread reports and cleans up ----------------------------------
+// One host synchronisation then ends the update: no copy of the counters, no reset launch ahead of the next transform.  (The
+// same work done by the fill's last work-group -- a ticket every work-group takes at its end -- doubled the fill's time: 2048
+// returning atomics on one address, all at the same moment.)  The launch has as many work-groups as the LAST transform left cells
+// without a list (one, normally: a scene inside the density range leaves none, and the first few that appear are served by that
+// one group); the last group to finish closes.  pub == nullptr (a shard's try, a masked transform): no report, the host reads
+// the counters itself.
+__global__ __launch_bounds__(256) void k_nn_close(NnArgs a) {
+  __shared__ uint32_t s_sites[256];
+  __shared__ uint32_t s_last;
+  if (a.nfail) nn_brute_cells(a, s_sites);
+  if (!a.pub) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(a.ticket, 1ull) == (unsigned long long)gridDim.x - 1ull;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  __threadfence();
+  const unsigned long long failed = *a.failed, entries = *a.entries, md = a.maxd2 ? atomicMax(a.maxd2, 0ull) : 0ull;
+  volatile unsigned long long *h = a.pub;
+  h[a.pub_failed] = failed, h[a.pub_entries] = entries, h[a.pub_maxd2] = md;
+  if (a.dirty_count) h[a.pub_dirty] = *a.dirty_count;
+  if (a.nfail) h[a.pub_brute] = min(*a.nfail, (unsigned long long)a.fail_cap), *a.nfail = 0;
+  if (a.track_dst && failed == 0) *a.track_dst = a.dirty_flag ? max(*a.track_dst, md) : md;  // (incremental: the cells left alone keep theirs)
+  *a.cursor = 0, *a.failed = 0, *a.entries = 0, *a.ticket = 0;
+  if (a.dirty_count) *a.dirty_count = 0;
+  if (a.maxd2) *a.maxd2 = 0;
+  if (failed == 0) a.queues[0] = 0, a.queues[1] = 0;
+  __threadfence_system();
+  h[a.pub_tag] = a.tag;  // (last: the host trusts the other values once it sees this update's tag)
+  __threadfence_system();
 }
 
 }  // namespace fiesta

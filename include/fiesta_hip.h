@@ -99,6 +99,8 @@ typedef struct fiesta_hip_stats {
   int64_t nn_incremental; /* with cells == 1: only the cells whose search window held a changed voxel were redone (the lists of the
                              last transform were still valid), nn_dirty_cells of them */
   int64_t nn_dirty_cells;
+  int64_t nn_brute_cells; /* with cells == 1: cells that got no list (nothing within reach, more candidates than a list holds) and were
+                             served one by one by brute force instead of failing the transform (r06) */
   int64_t masked;        /* with bulk == 1: a PARTIALLY observed map -- the transform ran masked (mask_kernels.hpp): its result kept
                             on the observed voxels whose segment to their obstacle is observed, the others repaired by pulls */
   int64_t mask_uncertified, mask_iterations, mask_walks, mask_quads; /* masked: voxels under repair, repair iterations, segment

@@ -356,3 +356,32 @@ def test_a_scene_the_cell_transform_cannot_serve_is_not_retried_at_once(hip_lib)
     assert tried == [False] * 8 + [True] + [False], tried
     check_exact(m, shape)
     m.close()
+
+
+def test_a_few_cells_without_a_list_are_served_one_by_one(hip_lib):
+    """r06: a cell that cannot be listed costs THAT cell, not the transform.  A scatter scene with (a) an
+    empty corner -- the corner's cells find nothing within their widest window -- and (b) a solid block of obstacles -- the cells
+    next to it have more survivors than a list holds: the cell transform serves the update, those few cells by brute force
+    (against every site / against their window), and the field is the exact transform on every voxel."""
+    shape = (128, 128, 128)
+    rng = np.random.RandomState(31)
+    S = rng.randint(0, 128, (700, 3)).astype(np.int32)
+    S = S[~np.all(S < 70, axis=1)]                      # (a) nothing within 70 voxels of the corner (0, 0, 0)
+    m = make_map(shape, "cells")
+    occupy(m, S)
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 1 and st["nn_failed"] == 0 and 0 < st["nn_brute_cells"] <= 64, st
+    check_exact(m, shape)
+    sparse_cells = st["nn_brute_cells"]
+    cube = np.array([(x, y, z) for x in range(7) for y in range(7) for z in range(7)], np.int32) + 90   # (b)
+    occupy(m, cube)
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 1 and st["nn_failed"] == 0 and st["nn_brute_cells"] > sparse_cells, st
+    check_exact(m, shape)
+    # a small delta next: the incremental transform meets the cells without a list again -- it fails on them, the same call runs
+    # in full (brute force included), and the one after that is incremental again if nothing of it touches such a cell
+    free(m, S[:1])
+    st = m.UpdateESDF()
+    assert st["bulk"] == 1 and st["cells"] == 1 and st["nn_failed"] == 0, st
+    check_exact(m, shape)
+    m.close()
