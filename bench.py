@@ -946,6 +946,9 @@ def main():
         engine_steps = {"cells": n_cells, "envelope": n_bulk - n_cells, "levels": sum(int(s.get("levels", 0)) for s in timed),
                         "cell_transform_attempts_that_failed": sum(1 for s in timed if int(s.get("nn_failed", 0)) > 0)}
         engine_steps["rounds"] = len(timed) - n_bulk - engine_steps["levels"]
+        engine_steps["masked"] = sum(int(s.get("masked", 0)) for s in timed)
+        engine_steps["cells_incremental"] = sum(int(s.get("nn_incremental", 0)) for s in timed)
+        engine_steps["cells_served_by_brute_force_per_update"] = statistics.mean(int(s.get("nn_brute_cells", 0)) for s in timed)
         if n_bulk == len(timed) and 0 < n_cells < len(timed):
             # a mix of the two transforms (a cell transform that met a cell it could not serve hands that update -- and the next
             # few eligible ones -- to the envelope passes): the phases below describe the majority, the counts say so
