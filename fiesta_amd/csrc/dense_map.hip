@@ -1518,7 +1518,9 @@ bool DenseMap::cells_wanted() {
   if (update_engine_ == 4 || g.nx > nn::kRegionMax || g.ny > nn::kRegionMax || g.nz > nn::kRegionMax) return false;
   if (update_engine_ == 5) return true;
   const long long nocc = (long long)h_counters_[C_NOCC];
-  if (nocc * 12288 < g.n || nocc * 400 > g.n) return false;
+  // (measured with the cells that get no list served one by one, profiles/r06_density_range.json: 7.5e-5 -- 0.36 against 0.57 ms on
+  //  the envelope passes; 5.2e-5 -- two cells scan every site, 0.89 against 0.56; 2.5e-3 -- 0.74 against 0.98; 3.7e-3 -- 1.14 against 1.04)
+  if (nocc * 15000 < g.n || nocc * 400 > g.n) return false;
   // a failed attempt (a cell without a list: ~0.2 ms lost before the envelope passes take over) is not repeated at once: the
   // next 8, 16, ... 256 eligible updates go straight to the envelope passes, then it is tried again -- a scene that cannot be
   // served costs 1 % in the long run, one unlucky cell in a scene that can does not switch the transform off for good
