@@ -563,6 +563,33 @@ def run_queries(args):
         m.synchronize()
         ts.append(time.perf_counter() - t0)
     t = statistics.median(ts)
+    # a PLANNER's batch: trajectories, not white noise -- 8192 smooth paths of 1024 samples each, 0.4 voxels
+    # apart, stored path by path: neighbouring lanes ask about neighbouring positions (the 8 corner words of consecutive
+    # queries share their 128-byte lines)
+    T_, L_ = 8192, N // 8192
+    gen.manual_seed(11)
+    start = torch.rand((T_, 1, 3), generator=gen, device=dev, dtype=torch.float64) * (G * res - 4.0) + 2.0
+    head = torch.randn((T_, 1, 3), generator=gen, device=dev, dtype=torch.float64)
+    turn = torch.randn((T_, L_, 3), generator=gen, device=dev, dtype=torch.float64) * 0.05
+    dirs = head + torch.cumsum(turn, 1)
+    dirs = dirs / dirs.norm(dim=2, keepdim=True)
+    path = start + torch.cumsum(dirs * (0.4 * res), 1)
+    lo_b, span = 0.3, G * res - 0.6
+    path = lo_b + span - (torch.remainder(path - lo_b, 2 * span) - span).abs()   # (reflected at the map's faces)
+    ppos = path.reshape(-1, 3).contiguous()
+    del start, head, turn, dirs, path
+    for _ in range(args.warmup):
+        m.GetDistWithGradTrilinearDevice(ppos.data_ptr(), N, dist.data_ptr(), grad.data_ptr())
+    m.synchronize()
+    tp = []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        m.GetDistWithGradTrilinearDevice(ppos.data_ptr(), N, dist.data_ptr(), grad.data_ptr())
+        m.synchronize()
+        tp.append(time.perf_counter() - t0)
+    tpl = statistics.median(tp)
+    m.GetDistWithGradTrilinearDevice(pos.data_ptr(), N, dist.data_ptr(), grad.data_ptr())   # (the check below reads the random batch's results)
+    m.synchronize()
     # check a sample against the exact transform (k-d tree) -- trilinear of exact corner distances, recomputed in numpy f64
     from scipy.spatial import cKDTree
     occ = np.ascontiguousarray(m.GetOccupiedVoxels(), dtype=np.int64)
@@ -619,6 +646,9 @@ def run_queries(args):
                         "frac": N * bytes_q / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "frac_definition": "64 B per query (SURVEY.md 8d: 8 corner keys x 8 B) x queries / p50 of the call / 8 TB/s; the engine reads 8 x 4 B "
                                            "words and moves 24 B of position in and 32 B of value + gradient out per query"},
+           "planner_batch": {"what": f"{T_} smooth trajectories x {L_} samples 0.4 voxels apart, stored path by path (the same kernel, the same {N} queries per call)",
+                             "queries_per_sec": N / tpl, "ms_per_call": tpl * 1e3, "roofline_frac_at_64B_per_query": N * bytes_q / tpl / 1e9 / HBM_PEAK_GBS,
+                             "io_bytes_actually_moved_per_query": 24 + 32 + 8, "frac_of_peak_on_position_in_plus_result_out_alone": N * 56.0 / tpl / 1e9 / HBM_PEAK_GBS},
            "verify": {"sampled": 20000, "max_abs_error_m_vs_trilinear_of_exact_corner_distances": err},
            "scalar_calls_through_the_cpp_class": scalar, "cpu_baseline": cpu, "map_update": esdf_summary([st])}
     print(json.dumps(out), flush=True)

@@ -44,8 +44,11 @@ python bench.py --scene surfaces --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R
 python bench.py --engine rounds --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c2_rounds.json"
 python bench.py --engine rounds --scene surfaces --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c2_surfaces_rounds.json"
 python bench.py --engine levels --no-cpu-baseline --steps 3 --warmup 1 2>&1 | grep '^{"metric' > "$R/bench_c2_levels.json"
-# C2-partial: 27 % of the map (32^3 blocks) never observed -> the transform's gate is shut, the frontier rounds serve the 50k delta
+# C2-partial: 27 % of the map (32^3 blocks) never observed -> r06: the masked transform (mask_kernels.hpp); the frontier rounds pinned beside it
 python bench.py --unobserved 0.27 --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c2_partial.json"
+python bench.py --unobserved 0.27 --engine rounds --no-cpu-baseline --steps 5 2>&1 | grep '^{"metric' > "$R/bench_c2_partial_rounds.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats_partial" -o partial -- python bench.py --unobserved 0.27 --no-cpu-baseline --steps 10 > "$R/c2_partial_profiled.log" 2>&1
+python tools/density_range.py > "$R/density_range.json" 2> "$R/density_range.err"
 python bench.py --workload c3 --steps 20 --warmup 4 2>&1 | grep '^{"metric' > "$R/bench_c3.json"
 python bench.py --workload c3 --steps 20 --warmup 4 --engine rounds --no-cpu-baseline 2>&1 | grep '^{"metric' > "$R/bench_c3_rounds.json"
 python bench.py --workload c4 --steps 40 --warmup 5 2>&1 | grep '^{"metric' > "$R/bench_c4.json"
@@ -63,7 +66,8 @@ python tools/c5_smoke.py > "$R/c5_two_shards_bulk.json" 2> "$R/c5_smoke.err"
 for k in 2; do python -m pytest tests -q -m gpu 2>&1 | grep -aE "^(FAILED|ERROR)|[0-9]+ (passed|failed)" >> "$R/pytest_gpu.txt"; done
 # copy what is to be judged into profiles/ (gpurun_out/ is scratch)
 cp "$R/stats/bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats_default.csv"
-for f in bench_default bench_default_profiled delta_sweep bench_c2_envelope bench_queries pmc_traffic_cells bench_c2_surfaces bench_c2_rounds bench_c2_surfaces_rounds bench_c2_levels bench_c2_partial \
+cp "$R/stats_partial/partial_kernel_stats.csv" "profiles/${TAG}_c2_partial_kernel_stats.csv"
+for f in bench_default bench_default_profiled delta_sweep bench_c2_envelope bench_queries pmc_traffic_cells bench_c2_surfaces bench_c2_rounds bench_c2_surfaces_rounds bench_c2_levels bench_c2_partial bench_c2_partial_rounds density_range \
          bench_c3 bench_c3_rounds bench_c4 bench_c4_rounds bench_sharded_1rank bench_1024_one_shard c5_two_shards_bulk pmc_traffic_ft; do
   cp "$R/$f.json" "profiles/${TAG}_$f.json"
 done
@@ -75,4 +79,6 @@ cp "$R/stats_c4/c4_kernel_stats.csv" "profiles/${TAG}_c4_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE SQ LDS; do
   cp "$R/pmc_$C/bench_counter_collection.csv" "profiles/${TAG}_pmc_${C}_counter_collection.csv"
 done
-echo "evidence for $TAG written; describe it in profiles/README.md"
+python -c "import __graft_entry__ as g; g.smoke()" > "$R/smoke.txt" 2>&1; echo "smoke rc=$?" >> "$R/smoke.txt"
+find "$R" -name "*.db" -delete 2>/dev/null
+echo "evidence for $TAG written in $R (gpurun merges gpurun_out/ back; tools/copy_evidence.sh $TAG copies the judged files into profiles/)"
