@@ -15,11 +15,11 @@
 //   k_mask_classify per voxel of the side buffer, streaming: never observed -> 0xFFFFFFFF; an obstacle -> itself; CERTIFIED at once
 //                   where every cell between the voxel and its winner is fully observed; the others are queued for
 //   k_mask_walk     the certificate proper: every voxel of the discrete segment to the winner observed -> T stays; an
-//                   uncertified voxel keeps what it held before the update if that obstacle still exists, else "no obstacle",
-//                   and is marked for repair (ubits)
+//                   uncertified voxel is marked for repair (ubits)
 //                   (a second certificate through "portals" -- observed stencil neighbours of a winner hidden behind one
 //                   unobserved voxel -- was modelled and dropped: it shrinks the repair set 4x and was wrong on 70 of 11.8 M voxels)
-//   k_mask_cells    the cells that hold a marked voxel
+//   k_mask_cells    the cells that hold a marked voxel; a marked voxel keeps what it held before the update if that obstacle
+//                   still exists, else "no obstacle"
 //   k_repair_cell / k_repair_commit   Jacobi pulls (:349-367: 24 neighbours in stencil order, strict <) on the marked voxels:
 //                   a WAVE stages a cell + its 2-voxel halo in LDS and iterates it to local quiescence against the halo as
 //                   the global iteration found it (block Jacobi); results go to a second buffer and are committed by a
@@ -279,6 +279,29 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
     const int Y = 8 * cy + y, Z = 32 * qz + 4 * z4;
     const bool row_in = Y < g.ny && Z < g.nz;
     const uint32_t mycd = cd[z4 >> 1], mycn = cn[z4 >> 1];  // (the cell of this lane's four voxels)
+    // the quad's eight slabs: every load of the quad in flight before the first word is looked at (a slab at a time, each wave
+    // went through eight dependent round trips to memory per quad)
+    uint32_t ww[8][4], obx[8], ocx[8];
+    if (any_obs) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int X = 8 * cx + x;
+        const int64_t base = ((int64_t)X * g.ny + Y) * g.nz + Z;
+        ww[x][0] = ww[x][1] = ww[x][2] = ww[x][3] = kUnobserved;
+        obx[x] = ocx[x] = 0;
+        if (row_in && X < g.nx) {
+          if (vec) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.out + base);
+            ww[x][0] = v.x, ww[x][1] = v.y, ww[x][2] = v.z, ww[x][3] = v.w;
+          } else {
+            for (int k = 0; k < 4 && Z + k < g.nz; ++k) ww[x][k] = a.out[base + k];
+          }
+          const int64_t bw = ((int64_t)X * g.ny + Y) * g.nzw + qz;
+          obx[x] = a.obsbits[bw], ocx[x] = a.occbits[bw];
+        }
+      }
+    }
+#pragma unroll
     for (int x = 0; x < 8; ++x) {
       const int X = 8 * cx + x;
       if (X >= g.nx) break;  // (wave-uniform)
@@ -291,18 +314,8 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
         }
         continue;
       }
-      uint32_t w[4] = {kUnobserved, kUnobserved, kUnobserved, kUnobserved}, w0[4];
-      uint32_t ob = 0, oc = 0;
-      if (row_in) {
-        if (vec) {
-          const uint4 v = *reinterpret_cast<const uint4 *>(a.out + base);
-          w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
-        } else {
-          for (int k = 0; k < 4 && Z + k < g.nz; ++k) w[k] = a.out[base + k];
-        }
-        const int64_t bw = ((int64_t)X * g.ny + Y) * g.nzw + qz;
-        ob = (a.obsbits[bw] >> (4 * z4)) & 15u, oc = (a.occbits[bw] >> (4 * z4)) & 15u;
-      }
+      uint32_t w[4] = {ww[x][0], ww[x][1], ww[x][2], ww[x][3]}, w0[4];
+      const uint32_t ob = (obx[x] >> (4 * z4)) & 15u, oc = (ocx[x] >> (4 * z4)) & 15u;
 #pragma unroll
       for (int k = 0; k < 4; ++k) w0[k] = w[k];
       bool want[4];
@@ -379,17 +392,7 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
     unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
     sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
     if (mask_segment_observed(a, vx, vy, vz, sx, sy, sz)) continue;
-    // uncertified: keeps what it held if that obstacle still exists; repaired from its neighbours afterwards
-    vox_t o = a.old[idx] & ~kAct;
-    if (!(o & kNoCoc)) {
-      int ox, oy, oz;
-      unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, o, ox, oy, oz);
-      ox -= g.gx0, oy -= g.gy0, oz -= g.gz0;
-      if (!(g.in_grid(ox, oy, oz) && bit_test(a.occbits, g, ox, oy, oz))) o = kInf;
-    } else {
-      o = kInf;
-    }
-    a.out[idx] = o;
+    // uncertified: marked for repair (k_mask_cells gives it the word it starts from)
     atomicOr(&a.ubits[g.bitword(vx, vy, vz)], 1u << (vz & 31));
     ++marked;
   }
@@ -428,7 +431,19 @@ __global__ __launch_bounds__(256) void k_mask_cells(MaskArgs a) {
       while (m) {
         const int b = __ffs((int)m) - 1;
         m &= m - 1;
-        a.old[base + b] = a.out[base + b];
+        // an uncertified voxel keeps what it held before the update if that obstacle still exists, else "no obstacle" -- the
+        // word the repair starts from, in both buffers
+        vox_t o = a.old[base + b] & ~kAct;
+        if (!(o & kNoCoc)) {
+          int ox, oy, oz;
+          unpack_coc(g.wrap, X + g.gx0, Y + g.gy0, 32 * qz + b + g.gz0, o, ox, oy, oz);
+          ox -= g.gx0, oy -= g.gy0, oz -= g.gz0;
+          if (!(g.in_grid(ox, oy, oz) && bit_test(a.occbits, g, ox, oy, oz))) o = kInf;
+        } else {
+          o = kInf;
+        }
+        a.out[base + b] = o;
+        a.old[base + b] = o;
       }
     }
     __syncthreads();
