@@ -1776,7 +1776,7 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
   MaskArgs ma;
   memset(&ma, 0, sizeof(ma));
   ma.g = g, ma.ncx = ncx, ma.ncy = ncy, ma.ncz = ncz;
-  ma.occbits = occbits_, ma.obsbits = obsbits_, ma.cellobs = cellobs_.p, ma.celldist = celldist_.p, ma.cellnb = cellnb_.p;
+  ma.occbits = occbits_, ma.obsbits = obsbits_, ma.effocc = effocc_.p, ma.cellobs = cellobs_.p, ma.celldist = celldist_.p, ma.cellnb = cellnb_.p;
   ma.old = coc_, ma.out = mask_out_.p;
   ma.ubits = mask_ubits_.p, ma.walks = reinterpret_cast<uint2 *>(mask_walks_.p), ma.seg_cap = (uint32_t)seg_cap;
   ma.uq = mask_uq_.p, ma.qstamp[0] = mask_qstamp_.p, ma.qstamp[1] = mask_qstamp_.p + ncells;
@@ -1789,13 +1789,21 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
                      cellnb_.p);
   hipLaunchKernelGGL(k_eff_occ, dim3(grid_for(nbitwords_, 256, 8192)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
                      (const uint32_t *)obsbits_, effocc_.p, nbitwords_);
+  {  // the hidden sites' portals: a table of at least four slots per obstacle
+    size_t slots = 4096;
+    while (slots < 4 * (size_t)std::max<long long>((long long)h_counters_[C_NOCC], 1)) slots *= 2;
+    mask_ptab_.ensure_exact(slots, stream_);
+    ma.ptab = reinterpret_cast<uint2 *>(mask_ptab_.p), ma.ptab_mask = (uint32_t)(slots - 1);
+    FIESTA_HIP_CHECK(hipMemsetAsync(mask_ptab_.p, 0xFF, slots * sizeof(unsigned long long), stream_));
+    hipLaunchKernelGGL(k_portal_sites, dim3(grid_for(nbitwords_, 256, 8192)), dim3(256), 0, stream_, ma, nbitwords_);
+  }
   FIESTA_HIP_CHECK(hipGetLastError());
   struct Restore {  // (the transforms read and write the masked transform's buffers only while it runs)
     DenseMap *m;
     ~Restore() { m->tr_occ_ = nullptr, m->tr_out_ = nullptr, m->tr_cellobs_ = nullptr; }
   } restore{this};
   tr_occ_ = effocc_.p, tr_out_ = mask_out_.p, tr_cellobs_ = cellobs_.p;
-  const int classify_blocks = (int)std::min<int64_t>(std::max<int64_t>((nquads + 3) / 4, 1), 2048);
+  const int classify_blocks = (int)std::min<int64_t>(std::max<int64_t>((nquads + 3) / 4, 1), 8192);
   const int repair_blocks = (int)std::min<int64_t>(std::max<int64_t>((ncells + 3) / 4, 1), 2048);
   int gi = 0;  // global repair iterations of this update launched so far
   auto launch_chain = [&](const int n, const unsigned long long *failed) {

@@ -16,8 +16,8 @@
 //                   where every cell between the voxel and its winner is fully observed; the others are queued for
 //   k_mask_walk     the certificate proper: every voxel of the discrete segment to the winner observed -> T stays; an
 //                   uncertified voxel is marked for repair (ubits)
-//                   (a second certificate through "portals" -- observed stencil neighbours of a winner hidden behind one
-//                   unobserved voxel -- was modelled and dropped: it shrinks the repair set 4x and was wrong on 70 of 11.8 M voxels)
+//                   -- or, second chance, the winner has a PORTAL (an observed stencil neighbour that can only hold it) the
+//                   voxel's way to is clear (mask_portal_certificate)
 //   k_mask_cells    the cells that hold a marked voxel; a marked voxel keeps what it held before the update if that obstacle
 //                   still exists, else "no obstacle"
 //   k_repair_cell / k_repair_commit   Jacobi pulls (:349-367: 24 neighbours in stencil order, strict <) on the marked voxels:
@@ -51,6 +51,9 @@ struct MaskArgs {
   int ncx, ncy, ncz;         // 8^3 cells
   const uint32_t *occbits;   // Exist()
   const uint32_t *obsbits;   // observed at least once
+  const uint32_t *effocc;    // the sites of the transform (k_eff_occ)
+  uint2 *ptab;               // the portals of the HIDDEN sites (k_portal_sites): open addressing, {site word, 24-bit mask of stencil
+  uint32_t ptab_mask;        //   directions}, 0xFFFFFFFF = empty; slots - 1
   const uint8_t *cellobs;    // per cell: 0 nothing observed, 1 every voxel (of the grid) observed, 2 mixed
   const uint8_t *celldist;   // per cell: 0 not fully observed, k = every cell within k - 1 cells (Chebyshev) is (k <= 3)
   const uint32_t *cellnb;    // per cell: bit (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1) = the neighbour cell (dx, dy, dz) is fully observed
@@ -194,6 +197,164 @@ __device__ inline bool mask_segment_observed(const MaskArgs &a, int vx, int vy, 
     if (cst == 0u || (cst == 2u && !bit_test(a.obsbits, a.g, px, py, pz))) return false;
   }
   return true;
+}
+
+// The second certificate, for a winner s hidden behind an unobserved voxel: s hands its id to an observed stencil neighbour p --
+// a PORTAL -- and through it to everybody whose way to p is clear.  Only a HIDDEN site has portals (a never-observed voxel among its
+// 26 neighbours); they are found once per update (k_portal_sites) and looked up by the walk.  v keeps T(v) = s if for some stencil direction e (in stencil
+// order) p = s + e is inside the grid, observed, free, nearer to v than s, has NO other site within |e| of it (then p can only
+// hold s: s pushes it there itself, src/ESDFMap.cpp:375-391), and every voxel of the discrete segment v -> p is observed, free
+// and has s as its own winner (`out` still holds T for every observed free voxel: nobody writes it between k_mask_classify and
+// k_mask_cells).  On config 2's partially observed scene four fifths of the voxels the straight segment leaves uncertified have
+// such a winner; against the envelope of the reference's runs (tests/golden/c2_partial_256_envelope.npz) this certificate takes
+// the voxels closer than every run from 247 / 180 to 0 / 0 -- the straight segment alone repaired those regions by pulls, whose
+// ties fall differently from the reference's arrivals.
+__device__ inline bool mask_path_in_cell(const MaskArgs &a, int vx, int vy, int vz, int px_, int py_, int pz_, vox_t ws) {
+  const Geom &g = a.g;
+  const int dx = px_ - vx, dy = py_ - vy, dz = pz_ - vz;
+  const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+  const int m = max(ax, max(ay, az)), n = 2 * m + 1, n2 = 2 * n;
+  const int ix = dx < 0 ? -1 : 1, iy = dy < 0 ? -1 : 1, iz = dz < 0 ? -1 : 1;
+  int ex = n, ey = n, ez = n, px = vx, py = vy, pz = vz;
+  for (int i = 1; i < n; ++i) {
+    ex += 2 * ax, ey += 2 * ay, ez += 2 * az;
+    bool moved = false;
+    if (ex >= n2) ex -= n2, px += ix, moved = true;
+    if (ey >= n2) ey -= n2, py += iy, moved = true;
+    if (ez >= n2) ez -= n2, pz += iz, moved = true;
+    if (!moved) continue;
+    // (observed and free follow from the word: a never-observed voxel holds 0xFFFFFFFF, an obstacle itself)
+    if ((a.out[g.idx(px, py, pz)] & ~kAct) != ws) return false;
+  }
+  return true;
+}
+__device__ __forceinline__ uint32_t portal_hash(vox_t w) { return (w * 0x9E3779B1u) ^ (w >> 15); }
+__device__ inline bool mask_portal_certificate(const MaskArgs &a, int vx, int vy, int vz, int sx, int sy, int sz, vox_t ws) {
+  // the winner's portals (none: it is not hidden, or no neighbour qualifies)
+  uint32_t mask = 0;
+  for (uint32_t slot = portal_hash(ws) & a.ptab_mask;; slot = (slot + 1u) & a.ptab_mask) {
+    const uint2 e = a.ptab[slot];
+    if (e.x == ws) {
+      mask = e.y;
+      break;
+    }
+    if (e.x == 0xFFFFFFFFu) break;
+  }
+  if (!mask) return false;
+  const int dvs = (sx - vx) * (sx - vx) + (sy - vy) * (sy - vy) + (sz - vz) * (sz - vz);
+  int bit = 0;
+#define FIESTA_PORTAL(DX, DY, DZ)                                                                                                \
+  {                                                                                                                              \
+    if ((mask >> bit) & 1u) {                                                                                                    \
+      const int ux = sx + (DX), uy = sy + (DY), uz = sz + (DZ);                                                                  \
+      if ((ux - vx) * (ux - vx) + (uy - vy) * (uy - vy) + (uz - vz) * (uz - vz) < dvs &&                                        \
+          mask_path_in_cell(a, vx, vy, vz, ux, uy, uz, ws))                                                                      \
+        return true;                                                                                                             \
+    }                                                                                                                            \
+    ++bit;                                                                                                                       \
+  }
+  FIESTA_STENCIL24(FIESTA_PORTAL)
+#undef FIESTA_PORTAL
+  return false;
+}
+
+// The portals of every HIDDEN site (one with a never-observed voxel among its 26 neighbours inside the grid), once per update: bit k
+// of a site's mask = its k-th stencil neighbour is inside the grid, observed, free, and has no other site within that distance.
+// A WAVE per 64 words of the site bitmap; for each site found, the wave together: the 9 x 9 voxel rows around the site (x, y within
+// 4) as 9-bit windows of the three bitmaps -- one round of independent loads into LDS --, then lane k < 24 judges direction k
+// from those windows with shifts and popcounts (a thread per word with nested probe loops took 0.41 ms: one lane in sixty-four
+// working through ~600 dependent loads per site).
+__global__ __launch_bounds__(256) void k_portal_sites(MaskArgs a, int64_t nwords) {
+  __shared__ uint32_t s_eff[4][81], s_obs[4][81], s_occ[4][81];  // row (dx + 4) * 9 + dy + 4: bits z - 4 .. z + 4 of row (x + dx, y + dy) in bits 0 .. 8
+  const Geom &g = a.g;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *we = s_eff[wave], *wo = s_obs[wave], *wc = s_occ[wave];
+  const int64_t nchunks = (nwords + 63) / 64;
+  for (int64_t ch = blockIdx.x * 4ll + wave; ch < nchunks; ch += (int64_t)gridDim.x * 4) {
+    const int64_t wi = ch * 64 + lane;
+    const uint32_t mine = wi < nwords ? a.effocc[wi] : 0u;
+    unsigned long long todo = __ballot(mine != 0u);
+    while (todo) {  // (wave-uniform: the lanes' words one after the other)
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      uint32_t m = (uint32_t)__shfl((int)mine, src);
+      const int64_t w0 = ch * 64 + src, row = w0 / g.nzw;
+      const int zw = (int)(w0 - row * g.nzw), y = (int)(row % g.ny), x = (int)(row / g.ny);
+      while (m) {
+        const int z = 32 * zw + __ffs((int)m) - 1;
+        m &= m - 1;
+        // the 81 rows' windows: bit j of a window = voxel z - 4 + j (zero outside the grid; obs: ONE outside the grid for the
+        // hidden test below is handled there)
+        for (int r = lane; r < 81; r += 64) {
+          const int X = x + r / 9 - 4, Y = y + r % 9 - 4;
+          uint32_t be = 0, bo = 0, bc = 0;
+          if ((unsigned)X < (unsigned)g.nx && (unsigned)Y < (unsigned)g.ny) {
+            const int64_t rb = ((int64_t)X * g.ny + Y) * g.nzw;
+            const int z0 = z - 4;  // window start (may be negative)
+            const int wlo = (z0 < 0 ? 0 : z0) >> 5, whi = min(z + 4, g.nz - 1) >> 5;
+            unsigned long long e2 = a.effocc[rb + wlo], o2 = a.obsbits[rb + wlo], c2 = a.occbits[rb + wlo];
+            if (whi != wlo) {
+              e2 |= (unsigned long long)a.effocc[rb + whi] << 32, o2 |= (unsigned long long)a.obsbits[rb + whi] << 32;
+              c2 |= (unsigned long long)a.occbits[rb + whi] << 32;
+            }
+            const int sh = z0 - 32 * wlo;  // bit of the pair that is window bit 0 (negative: the window starts before the grid)
+            if (sh >= 0) be = (uint32_t)(e2 >> sh) & 511u, bo = (uint32_t)(o2 >> sh) & 511u, bc = (uint32_t)(c2 >> sh) & 511u;
+            else be = (uint32_t)(e2 << -sh) & 511u, bo = (uint32_t)(o2 << -sh) & 511u, bc = (uint32_t)(c2 << -sh) & 511u;
+            // (bits beyond the grid's last voxel are zero in the bitmaps: rows are padded with zeros)
+          }
+          we[r] = be, wo[r] = bo, wc[r] = bc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // hidden: a never-observed voxel among the 26 neighbours inside the grid (lane = neighbour)
+        bool unobs = false;
+        if (lane < 27) {
+          const int dx = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dz = lane % 3 - 1;
+          unobs = g.in_grid(x + dx, y + dy, z + dz) && !((wo[(dx + 4) * 9 + dy + 4] >> (dz + 4)) & 1u);
+        }
+        const bool hidden = __any((int)unobs);
+        uint32_t mask = 0;
+        if (hidden) {
+          bool good = false;
+          if (lane < 24) {
+            int ex = 0, ey = 0, ez = 0, k = 0;
+#define FIESTA_PDIR(DX, DY, DZ) \
+  if (k++ == lane) ex = (DX), ey = (DY), ez = (DZ);
+            FIESTA_STENCIL24(FIESTA_PDIR)
+#undef FIESTA_PDIR
+            const int ux = x + ex, uy = y + ey, uz = z + ez;
+            const int r0 = (ex + 4) * 9 + ey + 4;
+            if (g.in_grid(ux, uy, uz) && ((wo[r0] >> (ez + 4)) & 1u) && !((wc[r0] >> (ez + 4)) & 1u)) {
+              const int R2 = ex * ex + ey * ey + ez * ez;
+              int sites = 0;
+              for (int ddx = -2; ddx <= 2; ++ddx)
+                for (int ddy = -2; ddy <= 2; ++ddy) {
+                  const int rem = R2 - ddx * ddx - ddy * ddy;
+                  if (rem < 0) continue;
+                  const int dzm = rem >= 4 ? 2 : (rem >= 1 ? 1 : 0);  // |ddz| <= dzm
+                  const uint32_t win = we[(ex + ddx + 4) * 9 + ey + ddy + 4] >> (ez + 4 - dzm);
+                  uint32_t bits = win & ((1u << (2 * dzm + 1)) - 1u);
+                  if (ddx == 0 && ddy == 0) bits &= ~(1u << dzm);  // (the portal voxel itself does not count)
+                  sites += __popc(bits);
+                }
+              good = sites == 1;
+            }
+          }
+          mask = (uint32_t)__ballot(good) & 0xFFFFFFu;
+        }
+        if (mask && lane == 0) {
+          const vox_t ws = pack_coc(x + g.gx0, y + g.gy0, z + g.gz0);
+          for (uint32_t slot = portal_hash(ws) & a.ptab_mask;; slot = (slot + 1u) & a.ptab_mask) {
+            const uint32_t old = atomicCAS(&a.ptab[slot].x, 0xFFFFFFFFu, ws);
+            if (old == 0xFFFFFFFFu || old == ws) {
+              a.ptab[slot].y = mask;
+              break;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next site's windows overwrite these)
+      }
+    }
+  }
 }
 
 // Chebyshev distance (in cells, capped at 3) from every fully observed cell to the nearest cell that is not, and the 3^3
@@ -392,6 +553,7 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
     unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
     sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
     if (mask_segment_observed(a, vx, vy, vz, sx, sy, sz)) continue;
+    if (mask_portal_certificate(a, vx, vy, vz, sx, sy, sz, e.y & ~kAct)) continue;
     // uncertified: marked for repair (k_mask_cells gives it the word it starts from)
     atomicOr(&a.ubits[g.bitword(vx, vy, vz)], 1u << (vz & 31));
     ++marked;

@@ -5,7 +5,8 @@ any kernel was written (tools/dev/masked_engine_model.py).
 
   1. sites = the obstacles with at least one OBSERVED stencil neighbour (the others can hand their id to nobody,
      src/ESDFMap.cpp:375-391); T = exact feature transform of the sites;
-  2. an observed voxel keeps T iff every voxel of its discrete segment to the winner is observed (certificate);
+  2. an observed voxel keeps T iff every voxel of its discrete segment to the winner is observed (certificate) -- or, second
+     chance, iff the winner has a PORTAL (portal_certificate) the voxel's way to is clear;
   3. every other observed voxel keeps what it held before the update if that obstacle still exists, else "no obstacle", and is
      repaired by 24-neighbour pulls (:349-367: stencil order, strict <) -- block Jacobi: per global iteration every 8^3 cell
      runs up to BLOCK_SUBITERS steps on its own voxels against the other cells as the iteration found them.
@@ -34,6 +35,67 @@ def certificate(obs, V, S):
     return cert
 
 
+RING = {k: np.array([(x, y, z) for x in range(-2, 3) for y in range(-2, 3) for z in range(-2, 3) if 0 < x * x + y * y + z * z <= k]) for k in (1, 2, 4)}
+
+
+def path_in_cell(occ, obs, idx, V, P, S):
+    """every sample of the discrete segment V -> P observed, free, and with S as its own winner"""
+    d = (P - V).astype(np.int64)
+    n = 2 * np.abs(d).max(1) + 1
+    ok = np.ones(len(V), bool)
+    for i in range(1, int(n.max())):
+        act = ok & (i < n)
+        if not act.any():
+            break
+        na = n[act][:, None]
+        p = V[act] + (2 * d[act] * i + na) // (2 * na)
+        good = obs[p[:, 0], p[:, 1], p[:, 2]] & ~occ[p[:, 0], p[:, 1], p[:, 2]]
+        good &= np.all(np.stack([idx[k][p[:, 0], p[:, 1], p[:, 2]] for k in range(3)], 1) == S[act], axis=1)
+        ok[np.flatnonzero(act)[~good]] = False
+    return ok
+
+
+def portal_certificate(occ, obs, eff, idx, V, S):
+    """The second certificate (mask_kernels.hpp: k_mask_walk): a winner s hidden behind an unobserved voxel hands its id to an
+    observed stencil neighbour p -- a portal -- and through it to everybody whose way to p is clear.  Only a HIDDEN winner has
+    portals (one of its 26 neighbours inside the grid was never observed).  v keeps T(v) = s if, for some
+    stencil direction e (in stencil order), p = s + e is inside the grid, observed, free, nearer to v than s, has NO other site
+    within |e| of it (then p can only hold s: s pushes it there itself, src/ESDFMap.cpp:375-391), and every voxel of the discrete
+    segment v -> p is observed, free and has s as its own winner."""
+    G = np.array(occ.shape)
+    cert = np.zeros(len(V), bool)
+    Pe = np.pad(eff, 2)
+    # only a HIDDEN winner has portals: one with a never-observed voxel among its 26 neighbours (inside the grid)
+    Po = np.pad(obs, 1, constant_values=True)
+    hidden = np.zeros(occ.shape, bool)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                hidden |= ~Po[1 + dx:1 + dx + G[0], 1 + dy:1 + dy + G[1], 1 + dz:1 + dz + G[2]]
+    cand = hidden[S[:, 0], S[:, 1], S[:, 2]]
+    for e in DIRS24:
+        todo = np.flatnonzero(~cert & cand)
+        if not len(todo):
+            break
+        A = S[todo] + e
+        ok = np.all((A >= 0) & (A < G), axis=1)
+        Ac = np.where(ok[:, None], A, 0)
+        ok &= obs[Ac[:, 0], Ac[:, 1], Ac[:, 2]] & ~occ[Ac[:, 0], Ac[:, 1], Ac[:, 2]]
+        ok &= ((A - V[todo]) ** 2).sum(1) < ((S[todo] - V[todo]) ** 2).sum(1)
+        sub = np.flatnonzero(ok)
+        if not len(sub):
+            continue
+        riv = np.zeros(len(sub), np.int64)   # sites within |e|^2 of the portal (the winner itself is one of them)
+        for r in RING[int((e ** 2).sum())]:
+            riv += Pe[Ac[sub, 0] + 2 + r[0], Ac[sub, 1] + 2 + r[1], Ac[sub, 2] + 2 + r[2]]
+        sub = sub[riv == 1]
+        if not len(sub):
+            continue
+        good = path_in_cell(occ, obs, idx, V[todo][sub], Ac[sub], S[todo][sub])
+        cert[todo[sub[good]]] = True
+    return cert
+
+
 def effective_sites(occ, obs):
     """obstacles with at least one OBSERVED stencil neighbour: the others can never hand their id to anybody"""
     G = occ.shape
@@ -44,7 +106,7 @@ def effective_sites(occ, obs):
     return occ & any_n
 
 
-def masked_engine(occ, obs, W_old=None, keep_old=True, mask_sites=True, subiters=None):
+def masked_engine(occ, obs, W_old=None, keep_old=True, mask_sites=True, subiters=None, portals=True):
     """occ, obs: bool (G, G, G); W_old: the engine's own previous field (winner coordinates, -1 none).
     Returns d2 (int64; -1 unobserved, D2_INF none), W, stats."""
     G = occ.shape
@@ -54,6 +116,10 @@ def masked_engine(occ, obs, W_old=None, keep_old=True, mask_sites=True, subiters
     V = np.argwhere(obs)
     S = np.stack([idx[k][obs] for k in range(3)], 1)
     cert = certificate(obs, V, S) if eff.any() else np.zeros(len(V), bool)
+    n_straight = int((~cert).sum())
+    if portals and eff.any():
+        u = np.flatnonzero(~cert & ~occ[V[:, 0], V[:, 1], V[:, 2]])
+        cert[u[portal_certificate(occ, obs, eff, idx, V[u], S[u])]] = True
     # field: winner coordinates per voxel; -1 = none
     W = np.full(G + (3,), -1, np.int64)
     W[V[cert, 0], V[cert, 1], V[cert, 2]] = S[cert]
@@ -101,7 +167,7 @@ def masked_engine(occ, obs, W_old=None, keep_old=True, mask_sites=True, subiters
             break
     d2 = np.where(W[..., 0] >= 0, ((np.stack(g, -1) - W) ** 2).sum(-1), D2_INF)
     d2 = np.where(obs, d2, -1)
-    return d2.astype(np.int64), W, {"observed": int(obs.sum()), "uncertified": int((~cert).sum()), "jacobi_iterations": iters,
+    return d2.astype(np.int64), W, {"observed": int(obs.sum()), "uncertified": int((~cert).sum()), "uncertified_by_the_straight_segment": n_straight, "jacobi_iterations": iters,
                                     "isolated_obstacles": int((occ & ~eff).sum())}
 
 
