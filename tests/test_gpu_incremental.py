@@ -101,3 +101,31 @@ def test_other_engines_invalidate_the_lists(hip_lib, oracle_libs, best_oracle_ki
     assert_exact(compare_dense(b.gpu, b.cpu))
     b.gpu.close()
     b.cpu.close()
+
+
+@pytest.mark.parametrize("shape,seed", [((161, 45, 83), 1), ((72, 200, 40), 2), ((130, 66, 97), 3)])
+def test_incremental_updates_on_ragged_maps_are_exact(hip_lib, shape, seed):
+    """grids that are no multiple of the cell edge: a run of small deltas, each served incrementally where the lists allow, every
+    field the exact transform of what is occupied (scipy)"""
+    from test_gpu_cells import check_exact, free, make_map, occupy
+    rng = np.random.RandomState(seed)
+    m = make_map(shape, "cells")
+    V = all_voxels(shape)
+    live = V[rng.choice(len(V), len(V) // 2500, replace=False)]
+    occupy(m, live)
+    st = m.UpdateESDF()
+    assert st["cells"] == 1, st
+    check_exact(m, shape)
+    inc = 0
+    for step in range(6):
+        k = 1   # (one insert + one delete: these maps have ~10^3 cells, a voxel dirties ~10^2 of them)
+        new = V[rng.choice(len(V), k, replace=False)]
+        occupy(m, new)
+        free(m, live[:k])
+        live = np.concatenate([live[k:], new])
+        st = m.UpdateESDF()
+        assert st["bulk"] == 1, st
+        inc += int(st["nn_incremental"])
+        check_exact(m, shape)
+    assert inc >= 3, inc
+    m.close()
