@@ -368,7 +368,7 @@ int fiesta_hip_get_dist_grad_dev(fiesta_hip_map *m, const double *pos_dev, int64
 int fiesta_hip_host_cache_fetches(fiesta_hip_map *m, int64_t *fetches) {
   return guarded([&] {
     need(m && fetches, "bad argument");
-    *fetches = m->dense ? m->dense->host_brick_fetches() : 0;
+    *fetches = m->dense ? m->dense->host_brick_fetches() : m->hash->host_brick_fetches();
   });
 }
 int fiesta_hip_get_occupancy_vox(fiesta_hip_map *m, const int32_t *vox, int64_t n, int32_t *out) {

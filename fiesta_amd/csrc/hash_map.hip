@@ -438,12 +438,11 @@ __global__ void k_h_query_occ(Geom g, const int32_t *dir, PageTable tab, const u
   const int64_t a = h_lookup(g, dir, tab, x, y, z);
   out[i] = a < 0 ? 0 : (int)hbit(occbits, a);
 }
-// GetDistWithGradTrilinear (src/ESDFMap.cpp:481-540), f64 in the reference's operation order
-__global__ void k_h_query_trilinear(Geom g, const int32_t *dir, PageTable tab, const vox_t *coc, const double *pos, int64_t n, double *dist,
-                                    double *grad) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+// GetDistWithGradTrilinear (src/ESDFMap.cpp:481-540), f64 in the reference's operation order -- written once over a source of
+// corner distances D(map voxel x, y, z), compiled for the device (the batch kernel) and for the host (scalar calls from the brick
+// cache): the two are bit-equal
+template <class D>
+__host__ __device__ inline double h_trilinear(const Geom &g, D &&corner, const double *p, double *grad) {
   int b[3];
   double f[3];
   for (int k = 0; k < 3; ++k) {
@@ -455,23 +454,44 @@ __global__ void k_h_query_trilinear(Geom g, const int32_t *dir, PageTable tab, c
   double v[2][2][2];
   for (int ix = 0; ix < 2; ++ix)
     for (int iy = 0; iy < 2; ++iy)
-      for (int iz = 0; iz < 2; ++iz) v[ix][iy][iz] = h_distance(g, dir, tab, coc, b[0] + ix - g.gx0, b[1] + iy - g.gy0, b[2] + iz - g.gz0);
+      for (int iz = 0; iz < 2; ++iz) v[ix][iy][iz] = corner(b[0] + ix, b[1] + iy, b[2] + iz);
   const double v00 = (1 - f[0]) * v[0][0][0] + f[0] * v[1][0][0];
   const double v01 = (1 - f[0]) * v[0][0][1] + f[0] * v[1][0][1];
   const double v10 = (1 - f[0]) * v[0][1][0] + f[0] * v[1][1][0];
   const double v11 = (1 - f[0]) * v[0][1][1] + f[0] * v[1][1][1];
   const double v0 = (1 - f[1]) * v00 + f[1] * v10;
   const double v1 = (1 - f[1]) * v01 + f[1] * v11;
-  dist[i] = (1 - f[2]) * v0 + f[2] * v1;
+  const double d = (1 - f[2]) * v0 + f[2] * v1;
   if (grad) {
-    grad[3 * i + 2] = (v1 - v0) * g.res_inv;
-    grad[3 * i + 1] = ((1 - f[2]) * (v10 - v00) + f[2] * (v11 - v01)) * g.res_inv;
+    grad[2] = (v1 - v0) * g.res_inv;
+    grad[1] = ((1 - f[2]) * (v10 - v00) + f[2] * (v11 - v01)) * g.res_inv;
     double gx = (1 - f[2]) * (1 - f[1]) * (v[1][0][0] - v[0][0][0]);
     gx += (1 - f[2]) * f[1] * (v[1][1][0] - v[0][1][0]);
     gx += f[2] * (1 - f[1]) * (v[1][0][1] - v[0][0][1]);
     gx += f[2] * f[1] * (v[1][1][1] - v[0][1][1]);
-    grad[3 * i] = gx * g.res_inv;
+    grad[0] = gx * g.res_inv;
   }
+  return d;
+}
+__global__ void k_h_query_trilinear(Geom g, const int32_t *dir, PageTable tab, const vox_t *coc, const double *pos, int64_t n, double *dist,
+                                    double *grad) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  auto corner = [&](int vx, int vy, int vz) { return h_distance(g, dir, tab, coc, vx - g.gx0, vy - g.gy0, vz - g.gz0); };
+  dist[i] = h_trilinear(g, corner, p, grad ? grad + 3 * i : nullptr);
+}
+// a brick of the host-side cache: the 16^3 distances and occupancy bits of map brick (bx, by, bz), straight into pinned memory
+__global__ __launch_bounds__(256) void k_h_fetch_brick(Geom g, const int32_t *dir, PageTable tab, const vox_t *coc, const uint32_t *occbits, int bx,
+                                                       int by, int bz, double *dst) {
+  const int t = threadIdx.x, x = 16 * bx + (t >> 4) - g.gx0, y = 16 * by + (t & 15) - g.gy0, z0 = 16 * bz - g.gz0;
+  uint32_t bits = 0;
+  for (int k = 0; k < 16; ++k) {
+    dst[t * 16 + k] = h_distance(g, dir, tab, coc, x, y, z0 + k);
+    const int64_t a = h_lookup(g, dir, tab, x, y, z0 + k);
+    if (a >= 0 && hbit(occbits, a)) bits |= 1u << k;
+  }
+  reinterpret_cast<uint16_t *>(dst + 4096)[t] = (uint16_t)bits;
 }
 
 __global__ void k_h_export(const int32_t *page_gtile, int64_t nvox, const vox_t *coc, const uint32_t *occbits, int32_t *vox,
@@ -547,6 +567,17 @@ __global__ void k_h_slice_marker(Geom g, const int32_t *page_gtile, int64_t npag
 // =====================================================================================================
 void HashMap::use_device() const { FIESTA_HIP_CHECK(hipSetDevice(device_)); }
 
+// (the host-side brick cache of the scalar queries: see host_brick below)
+struct HashMap::HostBricks {
+  static constexpr int kSlots = 1024, kDoubles = 4096 + 64;  // (4096 distances + 256 x 16 occupancy bits: 33 KB a slot, 34 MB)
+  double *pool = nullptr;
+  std::vector<int64_t> tag;
+  std::vector<uint64_t> stamp;
+  int64_t fetches = 0;
+  ~HostBricks() {
+    if (pool) (void)hipHostFree(pool);
+  }
+};
 HashMap::HashMap(const fiesta_hip_config &cfg) {
   device_ = cfg.device;
   int ndev = 0;
@@ -603,6 +634,7 @@ HashMap::~HashMap() {
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
   delete lv_;
+  delete bricks_;
   if (lv_done_) (void)hipEventDestroy(lv_done_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
@@ -657,6 +689,7 @@ void HashMap::pristine_pages(int64_t first, int64_t count) {
 
 // Raw dump (write) / load of the whole map state -- pool, directory, window, queues (checkpoint.hpp).
 void HashMap::checkpoint(const char *path, bool write) {
+  if (!write) ++field_epoch_;  // (a loaded field: the host-side brick cache of the scalar queries is stale)
   use_device();
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   DevFile f(path, write, stream_);
@@ -1009,6 +1042,7 @@ bool HashMap::update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del) 
   }
   const unsigned long long nt = (unsigned long long)touched_upper_;
   if (nt) {
+    ++field_epoch_;  // (occupancy and first observations may change: the host-side brick cache of the scalar queries is stale)
     ins_.ensure(host_ni_ + nt, stream_, host_ni_);
     del_.ensure(host_nd_ + nt, stream_, host_nd_);
     hipLaunchKernelGGL(k_h_fuse, dim3(grid_for((int64_t)nt, 256, 8192)), dim3(256), 0, stream_, g_, pp_, global_map ? 1 : 0,
@@ -1218,6 +1252,7 @@ void HashMap::update_esdf(fiesta_hip_stats *st) {  // UpdateESDF (src/ESDFMap.cp
     st->deleted = (int64_t)nd;
   }
   if (ni || nd || force_scan_) {
+    ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
     ++epoch_;
     static_assert(C_LIST2 == C_LIST0 + 2 && C_INVALIDATED == C_LIST2 + 1, "counter layout");
     const auto d00 = std::chrono::steady_clock::now();
@@ -1302,7 +1337,48 @@ PageTable HashMap::page_table() {
   return PageTable{ptab_keys_.p, ptab_pages_.p, (int)ptab_pages_built_};
 }
 
+// ---- host-side brick cache of the scalar queries (the dense map's, dense_map.hip: HostBricks, for the paged map) -----------
+// The reference's GetDistance is a hash lookup + an array read (src/ESDFMap.cpp:467-479, 732-765); a planner calls it one position
+// at a time.  Through copy-in / launch / copy-out / synchronise such a call cost tens of microseconds.  Now the
+// distances (f64, exactly what the query kernels compute) and occupancy bits of a 16^3-voxel brick are fetched on first touch by
+// one small kernel into pinned host memory, and every further scalar query into that brick is a host read.  Bricks are keyed by
+// MAP coordinates (the window may move; parked pages answer too); whatever can change the field bumps an epoch.
+int64_t HashMap::host_brick_fetches() const { return bricks_ ? bricks_->fetches : 0; }
+const double *HashMap::host_brick(int vx, int vy, int vz) {
+  if (!bricks_) {
+    bricks_ = new HostBricks;
+    FIESTA_HIP_CHECK(hipHostMalloc((void **)&bricks_->pool, (size_t)HostBricks::kSlots * HostBricks::kDoubles * sizeof(double)));
+    bricks_->tag.assign(HostBricks::kSlots, INT64_MIN);
+    bricks_->stamp.assign(HostBricks::kSlots, 0);
+  }
+  const int bx = vx >> 4, by = vy >> 4, bz = vz >> 4;  // (arithmetic shifts: map coordinates may be negative)
+  const int64_t id = ((int64_t)(bx + (1 << 20)) << 42) | ((int64_t)(by + (1 << 20)) << 21) | (int64_t)(bz + (1 << 20));
+  const uint32_t hsh = ((uint32_t)bx * 0x9E3779B1u) ^ ((uint32_t)by * 0x85EBCA77u) ^ ((uint32_t)bz * 0xC2B2AE3Du);
+  const int slot = (int)((hsh ^ (hsh >> 15)) % (uint32_t)HostBricks::kSlots);
+  double *b = bricks_->pool + (size_t)slot * HostBricks::kDoubles;
+  if (bricks_->tag[slot] != id || bricks_->stamp[slot] != field_epoch_) {
+    use_device();
+    hipLaunchKernelGGL(k_h_fetch_brick, dim3(1), dim3(256), 0, stream_, g_, (const int32_t *)dir_, page_table(), (const vox_t *)coc_.p,
+                       (const uint32_t *)occbits_.p, bx, by, bz, b);
+    FIESTA_HIP_CHECK(hipGetLastError());
+    FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+    bricks_->tag[slot] = id, bricks_->stamp[slot] = field_epoch_;
+    ++bricks_->fetches;
+  }
+  return b;
+}
+double HashMap::host_distance(int vx, int vy, int vz) { return host_brick(vx, vy, vz)[((vx & 15) << 8) | ((vy & 15) << 4) | (vz & 15)]; }
+int HashMap::host_occ(int vx, int vy, int vz) {
+  const double *b = host_brick(vx, vy, vz);
+  const int row = ((vx & 15) << 4) | (vy & 15);
+  return (int)((reinterpret_cast<const uint16_t *>(b + 4096)[row] >> (vz & 15)) & 1u);
+}
+
 void HashMap::get_distance_vox(const int32_t *vox, int64_t n, double *out) {
+  if (n > 0 && n <= kHostQueries) {  // a scalar call of the drop-in class: the host-side brick cache
+    for (int64_t i = 0; i < n; ++i) out[i] = host_distance(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]);
+    return;
+  }
   use_device();
   if (n <= 0) return;
   stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
@@ -1314,6 +1390,12 @@ void HashMap::get_distance_vox(const int32_t *vox, int64_t n, double *out) {
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void HashMap::get_distance_pos(const double *pos, int64_t n, double *out) {
+  if (n > 0 && n <= kHostQueries) {
+    for (int64_t i = 0; i < n; ++i)   // (Pos2Vox as k_h_query_dist does it)
+      out[i] = host_distance((int)floor((pos[3 * i] - g_.org[0]) / g_.res), (int)floor((pos[3 * i + 1] - g_.org[1]) / g_.res),
+                             (int)floor((pos[3 * i + 2] - g_.org[2]) / g_.res));
+    return;
+  }
   use_device();
   if (n <= 0) return;
   stage_a_.ensure(n * 3 * sizeof(double), stream_);
@@ -1325,6 +1407,11 @@ void HashMap::get_distance_pos(const double *pos, int64_t n, double *out) {
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void HashMap::get_dist_grad(const double *pos, int64_t n, double *dist, double *grad) {
+  if (n > 0 && n <= kHostQueries) {
+    auto corner = [&](int vx, int vy, int vz) { return host_distance(vx, vy, vz); };
+    for (int64_t i = 0; i < n; ++i) dist[i] = h_trilinear(g_, corner, pos + 3 * i, grad ? grad + 3 * i : nullptr);
+    return;
+  }
   use_device();
   if (n <= 0) return;
   stage_a_.ensure(n * 3 * sizeof(double), stream_);
@@ -1338,6 +1425,10 @@ void HashMap::get_dist_grad(const double *pos, int64_t n, double *dist, double *
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void HashMap::get_occupancy_vox(const int32_t *vox, int64_t n, int32_t *out) {
+  if (n > 0 && n <= kHostQueries) {
+    for (int64_t i = 0; i < n; ++i) out[i] = host_occ(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]);
+    return;
+  }
   use_device();
   if (n <= 0) return;
   stage_a_.ensure(n * 3 * sizeof(int32_t), stream_);
@@ -1349,6 +1440,12 @@ void HashMap::get_occupancy_vox(const int32_t *vox, int64_t n, int32_t *out) {
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void HashMap::get_occupancy_pos(const double *pos, int64_t n, int32_t *out) {
+  if (n > 0 && n <= kHostQueries) {
+    for (int64_t i = 0; i < n; ++i)
+      out[i] = host_occ((int)floor((pos[3 * i] - g_.org[0]) / g_.res), (int)floor((pos[3 * i + 1] - g_.org[1]) / g_.res),
+                        (int)floor((pos[3 * i + 2] - g_.org[2]) / g_.res));
+    return;
+  }
   use_device();
   if (n <= 0) return;
   stage_a_.ensure(n * 3 * sizeof(double), stream_);

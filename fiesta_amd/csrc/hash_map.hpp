@@ -101,6 +101,19 @@ class HashMap {
   void run_rounds(fiesta_hip_stats *st, uint32_t first_count);
   bool run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned long long nd, bool scan);  // false: the rounds finish
   PageTable page_table();  // the map-wide page table of the query kernels (hash_map.hip)
+  // scalar queries (n <= kHostQueries positions per call, host pointers): a host-side cache of 16^3-voxel bricks of DISTANCES (f64,
+  // as the query kernels compute them) and occupancy bits, keyed by map brick coordinates, fetched on first touch (r06: the dense
+  // map's HostBricks for the paged map).  field_epoch_ is bumped by everything that may change the field or what a lookup finds.
+  static constexpr int64_t kHostQueries = 8;
+  struct HostBricks;
+  HostBricks *bricks_ = nullptr;
+  uint64_t field_epoch_ = 1;
+  const double *host_brick(int vx, int vy, int vz);
+  double host_distance(int vx, int vy, int vz);
+  int host_occ(int vx, int vy, int vz);
+ public:
+  int64_t host_brick_fetches() const;
+ private:
   DevBuf<unsigned long long> ptab_keys_;
   DevBuf<int32_t> ptab_pages_;
   int64_t ptab_pages_built_ = -1;

@@ -357,3 +357,43 @@ def test_hash_window_corridor_and_return(hip_lib, oracle_libs, best_oracle_kind)
     assert bad == 0 and n > 150000, (bad, n)
     near = (edge[0] + np.stack(np.meshgrid(np.arange(1, 24), np.arange(-8, 8), np.arange(-6, 6), indexing="ij"), -1).reshape(-1, 3)).astype(np.int32)
     assert np.array_equal(gpu.GetDistance(near), cpu.GetDistanceVox(near))
+
+
+def test_hash_scalar_queries_through_the_host_brick_cache(hip_lib, oracle_libs, best_oracle_kind):
+    """r06: ONE position per call on a hash-block map is answered from a host-side cache of 16^3-voxel bricks
+    (hash_map.hip: HostBricks) instead of a kernel launch per call.  Same bits as the batch kernels and as the reference --
+    allocated space, never-allocated space, negative coordinates --, one fetch per brick, and every call that may change the
+    field invalidates the cache."""
+    gpu, cpu = make(oracle_libs, best_oracle_kind, (0.0, 0.0, 0.0), 0.1, 1000)
+    n = 40
+    g = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3).astype(np.int32) - 7
+    cycles(gpu, cpu, [], g, 1)
+    rng = np.random.RandomState(19)
+    S = (rng.randint(0, n, (250, 3)) - 7).astype(np.int32)
+    cycles(gpu, cpu, S, [], 3)
+    pos = (rng.rand(500, 3) * (n - 4) + 2 - 7) * 0.1
+    vox = (rng.randint(-3, n + 3, (300, 3)) - 7).astype(np.int32)       # some of them in space nobody ever allocated
+    dgb, ggb = gpu.GetDistWithGradTrilinear(pos)                        # the batch kernels ...
+    dc, gc = cpu.GetDistWithGradTrilinear(pos)                          # ... equal the reference
+    assert np.array_equal(dgb, dc) and np.array_equal(ggb, gc)
+    before = gpu.host_cache_fetches
+    for i, p in enumerate(pos):                                         # ONE position per call
+        d, gr = gpu.GetDistWithGradTrilinear(p)
+        assert d == dc[i] and np.array_equal(gr, gc[i]), (i, p)
+        assert gpu.GetDistance(p) == cpu.GetDistancePos(p[None])[0]
+        assert gpu.GetOccupancy(p) == cpu.GetOccupancyPos(p[None])[0]
+    for v in vox:
+        assert gpu.GetDistance(v) == cpu.GetDistanceVox(v[None])[0], v
+        assert gpu.GetOccupancy(v) == cpu.GetOccupancyVox(v[None])[0], v
+    fetched = gpu.host_cache_fetches - before
+    assert 0 < fetched <= 5 ** 3, fetched                               # the queried space spans at most 5 bricks per axis
+    for p in pos[:50]:
+        gpu.GetDistWithGradTrilinear(p)
+    assert gpu.host_cache_fetches - before == fetched                   # nothing fetched twice
+    # the field changes: the cache must not answer from before
+    cycles(gpu, cpu, [], S[:120], 6)
+    for i, p in enumerate(pos[:150]):
+        d, gr = gpu.GetDistWithGradTrilinear(p)
+        d1, g1 = cpu.GetDistWithGradTrilinear(p[None])
+        assert d == d1[0] and np.array_equal(gr, g1[0]), (i, p)
+    assert gpu.host_cache_fetches - before > fetched
