@@ -572,7 +572,8 @@ struct HashMap::HostBricks {
   static constexpr int kSlots = 1024, kDoubles = 4096 + 64;  // (4096 distances + 256 x 16 occupancy bits: 33 KB a slot, 34 MB)
   double *pool = nullptr;
   std::vector<int64_t> tag;
-  std::vector<uint64_t> stamp;
+  std::vector<uint64_t> stamp, used;  // the field epoch a slot was fetched in; the tick it was last read at (two-way: the older one goes)
+  uint64_t tick = 0;
   int64_t fetches = 0;
   ~HostBricks() {
     if (pool) (void)hipHostFree(pool);
@@ -1350,11 +1351,21 @@ const double *HashMap::host_brick(int vx, int vy, int vz) {
     FIESTA_HIP_CHECK(hipHostMalloc((void **)&bricks_->pool, (size_t)HostBricks::kSlots * HostBricks::kDoubles * sizeof(double)));
     bricks_->tag.assign(HostBricks::kSlots, INT64_MIN);
     bricks_->stamp.assign(HostBricks::kSlots, 0);
+    bricks_->used.assign(HostBricks::kSlots, 0);
   }
   const int bx = vx >> 4, by = vy >> 4, bz = vz >> 4;  // (arithmetic shifts: map coordinates may be negative)
   const int64_t id = ((int64_t)(bx + (1 << 20)) << 42) | ((int64_t)(by + (1 << 20)) << 21) | (int64_t)(bz + (1 << 20));
   const uint32_t hsh = ((uint32_t)bx * 0x9E3779B1u) ^ ((uint32_t)by * 0x85EBCA77u) ^ ((uint32_t)bz * 0xC2B2AE3Du);
-  const int slot = (int)((hsh ^ (hsh >> 15)) % (uint32_t)HostBricks::kSlots);
+  // two-way set associative: a planner's working set of a few dozen bricks must not thrash on one unlucky pair (the eight corners
+  // of a trilinear query straddle up to eight bricks, asked for in turn)
+  const int s0 = (int)((hsh ^ (hsh >> 15)) % (uint32_t)(HostBricks::kSlots / 2)) * 2, s1 = s0 + 1;
+  int slot = s0;
+  if (bricks_->tag[s0] == id && bricks_->stamp[s0] == field_epoch_) slot = s0;
+  else if (bricks_->tag[s1] == id && bricks_->stamp[s1] == field_epoch_) slot = s1;
+  else if (bricks_->stamp[s0] != field_epoch_) slot = s0;   // (a stale slot goes first,
+  else if (bricks_->stamp[s1] != field_epoch_) slot = s1;
+  else slot = bricks_->used[s0] <= bricks_->used[s1] ? s0 : s1;   //  else the one read longer ago)
+  bricks_->used[slot] = ++bricks_->tick;
   double *b = bricks_->pool + (size_t)slot * HostBricks::kDoubles;
   if (bricks_->tag[slot] != id || bricks_->stamp[slot] != field_epoch_) {
     use_device();
