@@ -1613,7 +1613,7 @@ bool DenseMap::run_cells(fiesta_hip_stats *st, int margin, bool publish, bool in
   const int lcx = a.g.lx1 - a.g.lx0, lcy = a.g.ly1 - a.g.ly0, lcz = a.g.lz1 - a.g.lz0;  // the cells that get a list
   if (incremental) {
     // which cells a changed voxel can reach, their lists, their fill: three short launches that find their work on the device
-    hipLaunchKernelGGL(k_nn_mark, dim3((unsigned)std::min<unsigned long long>((ni + nd) * 3375 / 256 + 1, 16384)), dim3(256), 0, stream_, a);
+    hipLaunchKernelGGL(k_nn_mark, dim3((unsigned)std::min<unsigned long long>((ni + nd) * 3375 / 1024 + 1, 256)), dim3(1024), 0, stream_, a);
     const unsigned est = (unsigned)std::min<unsigned long long>((ni + nd) * 200 + 256, (unsigned long long)ncells / 2);
     hipLaunchKernelGGL(k_nn_lists_dirty, dim3(std::min(std::max(est / 16u, 64u), 8192u)), dim3(256), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
@@ -1765,6 +1765,7 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
   cellobs_.ensure_exact((size_t)ncells, stream_);
   celldist_.ensure_exact((size_t)ncells, stream_);
   cellnb_.ensure_exact((size_t)ncells, stream_);
+  cellst_.ensure_exact((size_t)ncells, stream_);
   mask_out_.ensure_exact((size_t)g.n, stream_);
   mask_walks_.ensure_exact(seg_cap * kMaskSegs, stream_);
   mask_uq_.ensure_exact((size_t)ncells, stream_);
@@ -1777,6 +1778,7 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
   memset(&ma, 0, sizeof(ma));
   ma.g = g, ma.ncx = ncx, ma.ncy = ncy, ma.ncz = ncz;
   ma.occbits = occbits_, ma.obsbits = obsbits_, ma.effocc = effocc_.p, ma.cellobs = cellobs_.p, ma.celldist = celldist_.p, ma.cellnb = cellnb_.p;
+  ma.cellst = cellst_.p;
   ma.old = coc_, ma.out = mask_out_.p;
   ma.ubits = mask_ubits_.p, ma.walks = reinterpret_cast<uint2 *>(mask_walks_.p), ma.seg_cap = (uint32_t)seg_cap;
   ma.uq = mask_uq_.p, ma.qstamp[0] = mask_qstamp_.p, ma.qstamp[1] = mask_qstamp_.p + ncells;
@@ -1786,7 +1788,7 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
   hipLaunchKernelGGL(k_obs_cells, dim3(grid_for(nquads, 4, 16384)), dim3(256), 0, stream_, g_, ncx, ncy, ncz,
                      (const uint32_t *)obsbits_, cellobs_.p);
   hipLaunchKernelGGL(k_cell_dist, dim3(grid_for(ncells, 256, 4096)), dim3(256), 0, stream_, ncx, ncy, ncz, (const uint8_t *)cellobs_.p, celldist_.p,
-                     cellnb_.p);
+                     cellnb_.p, cellst_.p);
   hipLaunchKernelGGL(k_eff_occ, dim3(grid_for(nbitwords_, 256, 8192)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
                      (const uint32_t *)obsbits_, effocc_.p, nbitwords_);
   {  // the hidden sites' portals: a table of at least four slots per obstacle

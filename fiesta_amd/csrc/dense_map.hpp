@@ -261,6 +261,7 @@ class DenseMap {
   // repair, the walk list, the quads under repair with their stamps, per-cell summaries of obsbits_, its counters (device +
   // pinned host copy)
   DevBuf<uint32_t> effocc_, mask_out_, mask_ubits_, mask_uq_, mask_qstamp_, cellnb_;
+  DevBuf<unsigned long long> cellst_;  // per cell: the 27 cellobs around it, two bits each (the walks' register view)
   DevBuf<unsigned long long> mask_walks_, mask_ptab_;  // (idx, winner) pairs; the hidden sites' portals (site word, direction mask)
   DevBuf<uint8_t> cellobs_, celldist_;
   unsigned long long *mask_ctr_ = nullptr, *h_mask_ctr_ = nullptr;

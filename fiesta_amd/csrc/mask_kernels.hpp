@@ -28,6 +28,8 @@
 // and the side buffer becomes the field (pointer swap).  tools/dev/masked_engine_model.py is the same algorithm in numpy; the
 // GPU field equals it voxel for voxel (tools/dev/masked_gpu_check.py).
 #pragma once
+#include <climits>
+
 #include "common.hpp"
 #include "relax_kernels.hpp"
 
@@ -58,6 +60,7 @@ struct MaskArgs {
   const uint8_t *celldist;   // per cell: 0 not fully observed, k = every cell within k - 1 cells (Chebyshev) is (k <= 3)
   const uint32_t *cellnb;    // per cell: bit (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1) = the neighbour cell (dx, dy, dz) is fully observed
                              // (cells outside the grid count as observed: nothing to cross there)
+  const unsigned long long *cellst;  // per cell: two bits per neighbour cell (same order): its cellobs (a cell outside the grid: 1)
   vox_t *old;                // the field before this update; the repair's second buffer afterwards
   vox_t *out;                // T on entry, the new field on exit
   uint32_t *ubits;           // 1 bit / voxel: marked for repair
@@ -170,18 +173,34 @@ __global__ __launch_bounds__(256) void k_eff_occ(Geom g, const uint32_t *occbits
 // Samples of the segment v -> s: n = 2 max|d| + 1 steps, sample i at v + round(d i / n) (never a tie: n is odd), i = 1 .. n - 1;
 // every voxel of the discrete line is visited, most of them twice -- only a sample that MOVED is looked up.  Walked from the
 // winner's end: more than half of the walks that fail do so next to a winner that sits behind an unobserved voxel.
-__device__ inline bool mask_segment_observed(const MaskArgs &a, int vx, int vy, int vz, int sx, int sy, int sz) {
+// The cells around the voxel a walk starts from: their summaries in a register (a walk rarely leaves the 3^3 cells around its
+// voxel -- a load per cell crossed otherwise, each behind the one before).
+struct CellView {
+  int cx, cy, cz;
+  unsigned long long st;
+};
+__device__ __forceinline__ CellView cell_view(const MaskArgs &a, int vx, int vy, int vz) {
+  CellView cv{vx >> 3, vy >> 3, vz >> 3, 0ull};
+  cv.st = a.cellst[((int64_t)cv.cx * a.ncy + cv.cy) * a.ncz + cv.cz];
+  return cv;
+}
+__device__ __forceinline__ uint32_t cell_state(const MaskArgs &a, const CellView &cv, int ccx, int ccy, int ccz) {
+  const unsigned ox = (unsigned)(ccx - cv.cx + 1), oy = (unsigned)(ccy - cv.cy + 1), oz = (unsigned)(ccz - cv.cz + 1);
+  if (ox < 3u && oy < 3u && oz < 3u) return (uint32_t)(cv.st >> (2u * (ox * 9u + oy * 3u + oz))) & 3u;
+  return a.cellobs[((int64_t)ccx * a.ncy + ccy) * a.ncz + ccz];
+}
+__device__ __forceinline__ bool mask_segment_observed(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int sx, int sy, int sz) {
   const int dx = sx - vx, dy = sy - vy, dz = sz - vz;
   const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
   const int m = max(ax, max(ay, az)), n = 2 * m + 1, n2 = 2 * n;
   const int ix = dx < 0 ? -1 : 1, iy = dy < 0 ? -1 : 1, iz = dz < 0 ? -1 : 1;
-  // sample i: v + sign * floor((2 |d| i + n) / 2n) per axis; start at i = n - 1 and step down
-  int ex = 2 * ax * (n - 1) + n, ey = 2 * ay * (n - 1) + n, ez = 2 * az * (n - 1) + n;
-  int px = vx + ix * (ex / n2), py = vy + iy * (ey / n2), pz = vz + iz * (ez / n2);
-  ex %= n2, ey %= n2, ez %= n2;
-  // the summary of the cell the walk is in stays in a register: a load per cell crossed, not per sample
+  // sample i: v + sign * floor((2 |d| i + n) / 2n) per axis; start at i = n - 1 -- that is s itself: 2 |d| (n - 1) + n =
+  // |d| 2n + (n - 2 |d|) and 0 < n - 2 |d| < 2n -- and step down
+  int ex = n - 2 * ax, ey = n - 2 * ay, ez = n - 2 * az;
+  int px = sx, py = sy, pz = sz;
+  // the summary of the cell the walk is in stays in a register
   int ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
-  uint32_t cst = a.cellobs[((int64_t)ccx * a.ncy + ccy) * a.ncz + ccz];
+  uint32_t cst = cell_state(a, cv, ccx, ccy, ccz);
   if (cst == 0u || (cst == 2u && !bit_test(a.obsbits, a.g, px, py, pz))) return false;
   for (int i = n - 2; i >= 1; --i) {
     ex -= 2 * ax, ey -= 2 * ay, ez -= 2 * az;
@@ -192,7 +211,7 @@ __device__ inline bool mask_segment_observed(const MaskArgs &a, int vx, int vy, 
     if (!moved) continue;
     if ((px >> 3) != ccx || (py >> 3) != ccy || (pz >> 3) != ccz) {
       ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
-      cst = a.cellobs[((int64_t)ccx * a.ncy + ccy) * a.ncz + ccz];
+      cst = cell_state(a, cv, ccx, ccy, ccz);
     }
     if (cst == 0u || (cst == 2u && !bit_test(a.obsbits, a.g, px, py, pz))) return false;
   }
@@ -209,28 +228,76 @@ __device__ inline bool mask_segment_observed(const MaskArgs &a, int vx, int vy, 
 // such a winner; against the envelope of the reference's runs (tests/golden/c2_partial_256_envelope.npz) this certificate takes
 // the voxels closer than every run from 247 / 180 to 0 / 0 -- the straight segment alone repaired those regions by pulls, whose
 // ties fall differently from the reference's arrivals.
-__device__ inline bool mask_path_in_cell(const MaskArgs &a, int vx, int vy, int vz, int px_, int py_, int pz_, vox_t ws) {
+// (walked from the portal's end, where the never-observed voxels are: a path through a cell nothing was observed in is refused
+//  from the cell's summary, before a word of `out` is asked for; the words of the samples go out six at a time)
+__device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int ux, int uy, int uz, vox_t ws) {
   const Geom &g = a.g;
-  const int dx = px_ - vx, dy = py_ - vy, dz = pz_ - vz;
+  const int dx = ux - vx, dy = uy - vy, dz = uz - vz;
   const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
   const int m = max(ax, max(ay, az)), n = 2 * m + 1, n2 = 2 * n;
+  if (m == 0) return true;
   const int ix = dx < 0 ? -1 : 1, iy = dy < 0 ? -1 : 1, iz = dz < 0 ? -1 : 1;
-  int ex = n, ey = n, ez = n, px = vx, py = vy, pz = vz;
-  for (int i = 1; i < n; ++i) {
-    ex += 2 * ax, ey += 2 * ay, ez += 2 * az;
-    bool moved = false;
-    if (ex >= n2) ex -= n2, px += ix, moved = true;
-    if (ey >= n2) ey -= n2, py += iy, moved = true;
-    if (ez >= n2) ez -= n2, pz += iz, moved = true;
-    if (!moved) continue;
-    // (observed and free follow from the word: a never-observed voxel holds 0xFFFFFFFF, an obstacle itself)
-    if ((a.out[g.idx(px, py, pz)] & ~kAct) != ws) return false;
+  int ex = n - 2 * ax, ey = n - 2 * ay, ez = n - 2 * az;  // sample n - 1 is the portal itself (see mask_segment_observed)
+  int px = ux, py = uy, pz = uz;
+  int ccx = INT_MIN, ccy = 0, ccz = 0;
+  uint32_t cst = 1u;
+  int i = n - 1;     // the sample (px, py, pz) is
+  bool pend = true;  // ... and it has not been looked at yet
+  for (;;) {
+    uint32_t w[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      w[k] = ws;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (!pend && i > 1) {
+          --i;
+          ex -= 2 * ax, ey -= 2 * ay, ez -= 2 * az;
+          if (ex < 0) ex += n2, px -= ix, pend = true;
+          if (ey < 0) ey += n2, py -= iy, pend = true;
+          if (ez < 0) ez += n2, pz -= iz, pend = true;
+        }
+      if (pend) {
+        if ((px >> 3) != ccx || (py >> 3) != ccy || (pz >> 3) != ccz) {
+          ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
+          cst = cell_state(a, cv, ccx, ccy, ccz);
+        }
+        if (cst == 0u) return false;
+        // (observed and free follow from the word: a never-observed voxel holds kUnobserved, an obstacle itself)
+        w[k] = a.out[g.idx(px, py, pz)] & ~kAct;
+        pend = false;
+      }
+    }
+    if (w[0] != ws || w[1] != ws || w[2] != ws || w[3] != ws || w[4] != ws || w[5] != ws) return false;
+    if (i <= 1) return true;
   }
-  return true;
 }
 __device__ __forceinline__ uint32_t portal_hash(vox_t w) { return (w * 0x9E3779B1u) ^ (w >> 15); }
-__device__ inline bool mask_portal_certificate(const MaskArgs &a, int vx, int vy, int vz, int sx, int sy, int sz, vox_t ws) {
-  // the winner's portals (none: it is not hidden, or no neighbour qualifies)
+// the stencil's directions by index, from registers: (d + 2) of twelve directions, three bits each, per 64-bit constant
+struct StencilCode {
+  unsigned long long x[2], y[2], z[2];
+};
+constexpr StencilCode stencil_code() {
+  StencilCode c{{0, 0}, {0, 0}, {0, 0}};
+  int k = 0;
+#define FIESTA_CODE(DX, DY, DZ)                                          \
+  c.x[k / 12] |= (unsigned long long)((DX) + 2) << (3 * (k % 12));       \
+  c.y[k / 12] |= (unsigned long long)((DY) + 2) << (3 * (k % 12));       \
+  c.z[k / 12] |= (unsigned long long)((DZ) + 2) << (3 * (k % 12));       \
+  ++k;
+  FIESTA_STENCIL24(FIESTA_CODE)
+#undef FIESTA_CODE
+  return c;
+}
+__device__ __forceinline__ void stencil_dir(int bit, int &dx, int &dy, int &dz) {
+  constexpr StencilCode code = stencil_code();
+  const int hi = bit >= 12, sh = 3 * (bit - 12 * hi);
+  dx = (int)(((hi ? code.x[1] : code.x[0]) >> sh) & 7ull) - 2;
+  dy = (int)(((hi ? code.y[1] : code.y[0]) >> sh) & 7ull) - 2;
+  dz = (int)(((hi ? code.z[1] : code.z[0]) >> sh) & 7ull) - 2;
+}
+// the winner's portals that are nearer to v than the winner (0: it is not hidden, or no neighbour qualifies)
+__device__ inline uint32_t mask_portals_of(const MaskArgs &a, int vx, int vy, int vz, int sx, int sy, int sz, vox_t ws) {
   uint32_t mask = 0;
   for (uint32_t slot = portal_hash(ws) & a.ptab_mask;; slot = (slot + 1u) & a.ptab_mask) {
     const uint2 e = a.ptab[slot];
@@ -240,22 +307,31 @@ __device__ inline bool mask_portal_certificate(const MaskArgs &a, int vx, int vy
     }
     if (e.x == 0xFFFFFFFFu) break;
   }
-  if (!mask) return false;
   const int dvs = (sx - vx) * (sx - vx) + (sy - vy) * (sy - vy) + (sz - vz) * (sz - vz);
-  int bit = 0;
-#define FIESTA_PORTAL(DX, DY, DZ)                                                                                                \
-  {                                                                                                                              \
-    if ((mask >> bit) & 1u) {                                                                                                    \
-      const int ux = sx + (DX), uy = sy + (DY), uz = sz + (DZ);                                                                  \
-      if ((ux - vx) * (ux - vx) + (uy - vy) * (uy - vy) + (uz - vz) * (uz - vz) < dvs &&                                        \
-          mask_path_in_cell(a, vx, vy, vz, ux, uy, uz, ws))                                                                      \
-        return true;                                                                                                             \
-    }                                                                                                                            \
-    ++bit;                                                                                                                       \
+  uint32_t keep = 0;
+  for (uint32_t mm = mask; mm;) {
+    const int bit = __ffs((int)mm) - 1;
+    mm &= mm - 1u;
+    int dx, dy, dz;
+    stencil_dir(bit, dx, dy, dz);
+    const int ux = sx + dx, uy = sy + dy, uz = sz + dz;
+    if ((ux - vx) * (ux - vx) + (uy - vy) * (uy - vy) + (uz - vz) * (uz - vz) < dvs) keep |= 1u << bit;
   }
-  FIESTA_STENCIL24(FIESTA_PORTAL)
-#undef FIESTA_PORTAL
-  return false;
+  return keep;
+}
+// the candidate nearest to v (any order gives the same answer to "does one of them certify v": the nearest does most often)
+__device__ inline int mask_best_portal(uint32_t cand, int vx, int vy, int vz, int sx, int sy, int sz) {
+  int best = -1, bd = INT_MAX;
+  for (uint32_t mm = cand; mm;) {
+    const int bit = __ffs((int)mm) - 1;
+    mm &= mm - 1u;
+    int dx, dy, dz;
+    stencil_dir(bit, dx, dy, dz);
+    const int ux = sx + dx, uy = sy + dy, uz = sz + dz;
+    const int d = (ux - vx) * (ux - vx) + (uy - vy) * (uy - vy) + (uz - vz) * (uz - vz);
+    if (d < bd) bd = d, best = bit;
+  }
+  return best;
 }
 
 // The portals of every HIDDEN site (one with a never-observed voxel among its 26 neighbours inside the grid), once per update: bit k
@@ -359,25 +435,33 @@ __global__ __launch_bounds__(256) void k_portal_sites(MaskArgs a, int64_t nwords
 
 // Chebyshev distance (in cells, capped at 3) from every fully observed cell to the nearest cell that is not, and the 3^3
 // neighbourhood as a bit mask; cells outside the grid do not count (nothing to cross there).
-__global__ __launch_bounds__(256) void k_cell_dist(int ncx, int ncy, int ncz, const uint8_t *cellobs, uint8_t *celldist, uint32_t *cellnb) {
+__global__ __launch_bounds__(256) void k_cell_dist(int ncx, int ncy, int ncz, const uint8_t *cellobs, uint8_t *celldist, uint32_t *cellnb,
+                                                   unsigned long long *cellst) {
   const int64_t n = (int64_t)ncx * ncy * ncz;
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
     const int cz = (int)(c % ncz), cy = (int)((c / ncz) % ncy), cx = (int)(c / ((int64_t)ncz * ncy));
     int d = 3;
     uint32_t nb = 0x7FFFFFFu;
+    unsigned long long st = 0x15555555555555ull;  // (27 x 01)
     for (int dx = -2; dx <= 2; ++dx)
       for (int dy = -2; dy <= 2; ++dy)
         for (int dz = -2; dz <= 2; ++dz) {
           const int ux = cx + dx, uy = cy + dy, uz = cz + dz;
           if ((unsigned)ux >= (unsigned)ncx || (unsigned)uy >= (unsigned)ncy || (unsigned)uz >= (unsigned)ncz) continue;
-          if (cellobs[((int64_t)ux * ncy + uy) * ncz + uz] != 1u) {
+          const uint32_t co = cellobs[((int64_t)ux * ncy + uy) * ncz + uz];
+          if (co != 1u) {
             const int r = max(max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy), dz < 0 ? -dz : dz);
             d = min(d, r);
-            if (r <= 1) nb &= ~(1u << ((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)));
+            if (r <= 1) {
+              const int b = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
+              nb &= ~(1u << b);
+              st = (st & ~(3ull << (2 * b))) | ((unsigned long long)co << (2 * b));
+            }
           }
         }
     celldist[c] = (uint8_t)d;
     cellnb[c] = nb;
+    cellst[c] = st;
   }
 }
 
@@ -532,31 +616,82 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
   if (lane == 0 && nwalk) atomicAdd(&a.ctr[MC_WALKS], (unsigned long long)nwalk);
 }
 
-// The certificate proper: one lane per queued voxel.
+// The certificate proper: one lane per queued voxel.  The straight segment first; the voxels it leaves (one in six on config 2's
+// partially observed scene) wait in an LDS queue of the work-group, and the portal certificate runs in ROUNDS over that queue: a
+// round = every lane takes a waiting voxel and tries ONE portal, the nearest it has not tried; a voxel that fails and has
+// candidates left goes back into the queue.  (One lane trying its up to 24 portals in a row: a wave took as long as its
+// unluckiest lane -- a quarter of the waiting voxels end up uncertified, after nine walks on average -- while three quarters
+// are done after one.)
+constexpr int kWalkQueue = 768;
 __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
-  __shared__ uint32_t s_marked;
+  __shared__ uint32_t s_marked, s_qn;
+  __shared__ uint2 s_q[kWalkQueue];
+  __shared__ uint32_t s_qm[kWalkQueue];  // candidates left (0xFFFFFFFF: not looked up yet)
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;
   if (a.ctr[MC_OVERFLOW]) return;
-  if (threadIdx.x == 0) s_marked = 0;
-  __syncthreads();
+  if (threadIdx.x == 0) s_marked = 0, s_qn = 0;
   unsigned marked = 0;
   // work-group b takes segment b % kMaskSegs, its share of it
   const int seg = (int)(blockIdx.x % kMaskSegs);
   const uint32_t part = blockIdx.x / kMaskSegs, parts = (gridDim.x + kMaskSegs - 1 - seg) / kMaskSegs;
   const uint32_t n = (uint32_t)min(a.ctr[MC_SEG0 + 16 * seg], (unsigned long long)a.seg_cap);
-  for (uint32_t i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
-    const uint2 e = a.walks[(size_t)seg * a.seg_cap + i];
-    const uint32_t idx = e.x;
-    const int vz = (int)(idx % (uint32_t)g.nz), vy = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), vx = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
-    int sx, sy, sz;
-    unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
-    sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
-    if (mask_segment_observed(a, vx, vy, vz, sx, sy, sz)) continue;
-    if (mask_portal_certificate(a, vx, vy, vz, sx, sy, sz, e.y & ~kAct)) continue;
-    // uncertified: marked for repair (k_mask_cells gives it the word it starts from)
-    atomicOr(&a.ubits[g.bitword(vx, vy, vz)], 1u << (vz & 31));
-    ++marked;
+  uint32_t i0 = part * blockDim.x;
+  for (;;) {
+    __syncthreads();
+    const uint32_t qn = s_qn;
+    if (qn < 256u && i0 < n) {  // (uniform) another 256 straight walks
+      const uint32_t i = i0 + threadIdx.x;
+      i0 += parts * blockDim.x;
+      __syncthreads();  // (s_qn is read by everybody before anybody adds to it)
+      if (i < n) {
+        const uint2 e = a.walks[(size_t)seg * a.seg_cap + i];
+        const uint32_t idx = e.x;
+        const int vz = (int)(idx % (uint32_t)g.nz), vy = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), vx = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
+        int sx, sy, sz;
+        unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
+        sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
+        if (!mask_segment_observed(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx, sy, sz)) {
+          const uint32_t at = atomicAdd(&s_qn, 1u);  // (at most 255 + 256 waiting)
+          s_q[at] = e, s_qm[at] = 0xFFFFFFFFu;
+        }
+      }
+      continue;
+    }
+    if (qn == 0u) break;  // (uniform: the list is exhausted too)
+    const uint32_t take = min(qn, 256u);
+    uint2 e{0u, 0u};
+    uint32_t cand = 0;
+    if (threadIdx.x < take) e = s_q[qn - take + threadIdx.x], cand = s_qm[qn - take + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) s_qn = qn - take;
+    __syncthreads();
+    if (threadIdx.x < take) {
+      const uint32_t idx = e.x;
+      const int vz = (int)(idx % (uint32_t)g.nz), vy = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), vx = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
+      int sx, sy, sz;
+      unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
+      sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
+      const vox_t ws = e.y & ~kAct;
+      if (cand == 0xFFFFFFFFu) cand = mask_portals_of(a, vx, vy, vz, sx, sy, sz, ws);
+      bool certified = false;
+      if (cand) {
+        const int bit = mask_best_portal(cand, vx, vy, vz, sx, sy, sz);
+        cand &= ~(1u << bit);
+        int dx, dy, dz;
+        stencil_dir(bit, dx, dy, dz);
+        certified = mask_path_in_cell(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx + dx, sy + dy, sz + dz, ws);
+      }
+      if (!certified) {
+        if (cand) {  // back into the queue (at most 512 + 256 waiting)
+          const uint32_t at = atomicAdd(&s_qn, 1u);
+          s_q[at] = e, s_qm[at] = cand;
+        } else {  // uncertified: marked for repair (k_mask_cells gives it the word it starts from)
+          atomicOr(&a.ubits[g.bitword(vx, vy, vz)], 1u << (vz & 31));
+          ++marked;
+        }
+      }
+    }
   }
   for (int off = 32; off > 0; off >>= 1) marked += (unsigned)__shfl_xor((int)marked, off);
   if ((threadIdx.x & 63) == 0 && marked) atomicAdd(&s_marked, marked);

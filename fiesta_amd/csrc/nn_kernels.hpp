@@ -688,41 +688,49 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnArgs a) {
 // per changed voxel, its threads over the (2 kKmax + 1)^3 cells around it; k_nn_lists_dirty: a team of four lanes per dirty cell,
 // straight from memory (nn::PlainSrc: a few thousand cells do not pay for staging a neighbourhood); k_nn_fill_dirty: a wave per
 // dirty cell.  More dirty cells than the list holds fails the transform (the full one serves the update).
-__global__ __launch_bounds__(256) void k_nn_mark(NnArgs a) {
+constexpr int kMarkQueue = 4096;
+__global__ __launch_bounds__(1024) void k_nn_mark(NnArgs a) {
+  __shared__ uint32_t s_q[kMarkQueue];
+  __shared__ uint32_t s_n;
+  __shared__ unsigned long long s_base;
   const nn::Geom &g = a.g;
   const uint32_t total = a.nchg[0] + a.nchg[1];
   constexpr int E = 2 * nn::kKmax + 1, E3 = E * E * E;
-  // a lane per (changed voxel, cell of the (2 kKmax + 1)^3 around it): every record read of the launch in flight at once
+  // a lane per (changed voxel, cell of the (2 kKmax + 1)^3 around it): every record read of the launch in flight at once.  The
+  // cells found go to a queue in LDS and from there to the list with ONE atomic on the list's cursor per work-group and flush
+  // (an atomic per wave, ~5 000 of them on one address, was 20 of this kernel's 24 us)
   const unsigned long long pairs = (unsigned long long)total * E3;
-  for (unsigned long long p0 = (unsigned long long)blockIdx.x * blockDim.x; p0 < pairs; p0 += (unsigned long long)gridDim.x * blockDim.x) {
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  for (unsigned long long p0 = (unsigned long long)blockIdx.x * blockDim.x; p0 < pairs; p0 += (unsigned long long)gridDim.x * blockDim.x) {  // (uniform)
     const unsigned long long p = p0 + threadIdx.x;
-    const bool live = p < pairs;
-    const uint32_t v = live ? (uint32_t)(p / E3) : 0u;
-    const int o = live ? (int)(p % E3) : 0;
-    const uint32_t idx = v < a.nchg[0] ? a.chg[0][v] : a.chg[1][v - a.nchg[0]];
-    const int z = (int)(idx % (uint32_t)g.nz), y = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), x = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
-    const int sx = x >> 3, sy = y >> 3, sz = z >> 3;
-    {
+    if (p < pairs) {
+      const uint32_t v = (uint32_t)(p / E3);
+      const int o = (int)(p - (unsigned long long)v * E3);
+      const uint32_t idx = v < a.nchg[0] ? a.chg[0][v] : a.chg[1][v - a.nchg[0]];
+      const int z = (int)(idx % (uint32_t)g.nz), y = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), x = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
       const int dz = o % E - nn::kKmax, dy = (o / E) % E - nn::kKmax, dx = o / (E * E) - nn::kKmax;
-      const int cx = sx + dx, cy = sy + dy, cz = sz + dz;
-      bool add = false;
-      int64_t c = 0;
-      if (live && (unsigned)cx < (unsigned)g.ncx && (unsigned)cy < (unsigned)g.ncy && (unsigned)cz < (unsigned)g.ncz) {
-        c = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
+      const int cx = (x >> 3) + dx, cy = (y >> 3) + dy, cz = (z >> 3) + dz;
+      if ((unsigned)cx < (unsigned)g.ncx && (unsigned)cy < (unsigned)g.ncy && (unsigned)cz < (unsigned)g.ncz) {
+        const int64_t c = ((int64_t)cx * g.ncy + cy) * g.ncz + cz;
         const int r = max(max(dx < 0 ? -dx : dx, dy < 0 ? -dy : dy), dz < 0 ? -dz : dz);
-        add = r <= (int)(a.lists[c * nn::kStride + 1] & 255u) && a.dirty_flag[c] == 0u && atomicExch(&a.dirty_flag[c], 1u) == 0u;
-      }
-      // one atomic on the list's cursor per wave
-      const unsigned long long m = __ballot(add);
-      if (m) {
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(a.dirty_count, (unsigned long long)__popcll(m));
-        base = (unsigned long long)__shfl((long long)base, leader);
-        const unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-        if (add && at < a.dirty_cap) a.dirty_list[at] = (uint32_t)c;
+        if (r <= (int)(a.lists[c * nn::kStride + 1] & 255u) && a.dirty_flag[c] == 0u && atomicExch(&a.dirty_flag[c], 1u) == 0u)
+          s_q[atomicAdd(&s_n, 1u)] = (uint32_t)c;  // (at most kMarkQueue - 1024 queued when an iteration starts)
       }
     }
+    __syncthreads();
+    const uint32_t n = s_n;
+    const bool last = p0 + (unsigned long long)gridDim.x * blockDim.x >= pairs;
+    if (n && (last || n > (uint32_t)kMarkQueue - 1024u)) {  // (uniform)
+      if (threadIdx.x == 0) s_base = atomicAdd(a.dirty_count, (unsigned long long)n);
+      __syncthreads();
+      const unsigned long long base = s_base;
+      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (base + i < a.dirty_cap) a.dirty_list[base + i] = s_q[i];
+      __syncthreads();
+      if (threadIdx.x == 0) s_n = 0;
+    }
+    __syncthreads();
   }
 }
 
