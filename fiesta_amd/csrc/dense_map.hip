@@ -1844,6 +1844,12 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
     FIESTA_HIP_CHECK(hipMemcpyAsync(h_mask_ctr_, mask_ctr_, MC_SEG0 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     if (cells) FIESTA_HIP_CHECK(hipMemcpyAsync(&h_counters_[C_FT_OVF0], &counters_[C_FT_OVF0], 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
+#if defined(FIESTA_PROBE)
+    fprintf(stderr, "PROBE walks %llu: straight n-sum %llu, steps %llu | paths %llu, positions loaded %llu, refused by cell %llu, n-sum %llu | entries %llu, candidates %llu, none %llu, certified %llu\n",
+            h_mask_ctr_[MC_WALKS], h_mask_ctr_[MC_CHANGED0 + 12], h_mask_ctr_[MC_CHANGED0 + 13], h_mask_ctr_[MC_CHANGED0 + 14], h_mask_ctr_[MC_CHANGED0 + 15],
+            h_mask_ctr_[MC_CHANGED0 + 16], h_mask_ctr_[MC_CHANGED0 + 17], h_mask_ctr_[MC_CHANGED0 + 18], h_mask_ctr_[MC_CHANGED0 + 19], h_mask_ctr_[MC_CHANGED0 + 20],
+            h_mask_ctr_[MC_CHANGED0 + 21]);
+#endif
     if (!cells || h_counters_[C_NN_FAILED] == 0) {
       if (cells) nn_fail_streak_ = 0;
       break;

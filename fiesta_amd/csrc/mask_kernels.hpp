@@ -189,7 +189,13 @@ __device__ __forceinline__ uint32_t cell_state(const MaskArgs &a, const CellView
   if (ox < 3u && oy < 3u && oz < 3u) return (uint32_t)(cv.st >> (2u * (ox * 9u + oy * 3u + oz))) & 3u;
   return a.cellobs[((int64_t)ccx * a.ncy + ccy) * a.ncz + ccz];
 }
-__device__ __forceinline__ bool mask_segment_observed(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int sx, int sy, int sz) {
+// (a build with -DFIESTA_PROBE counts the walks' work in spare words of the counter block; run_masked prints them)
+#if defined(FIESTA_PROBE)
+#define PROBE_ADD(K, N) atomicAdd(&a.ctr[MC_CHANGED0 + 12 + (K)], (unsigned long long)(N))
+#else
+#define PROBE_ADD(K, N)
+#endif
+__device__ __forceinline__ bool mask_segment_samples(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int sx, int sy, int sz) {
   const int dx = sx - vx, dy = sy - vy, dz = sz - vz;
   const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
   const int m = max(ax, max(ay, az)), n = 2 * m + 1, n2 = 2 * n;
@@ -218,6 +224,57 @@ __device__ __forceinline__ bool mask_segment_observed(const MaskArgs &a, const C
   return true;
 }
 
+// The same answer from the CELLS the samples cross, where that decides it: axis a of sample i is v + sign floor((2 |d_a| i + n) /
+// 2n), so the walk enters its k-th voxel along a at sample ceil(n (2k - 1) / 2 |d_a|) -- the cell boundaries it crosses, in the
+// order it crosses them, cost a division each instead of a step per sample.  A cell nothing was observed in refuses the
+// segment, a fully observed one passes; the first PARTLY observed cell sends the walk to the samples (mask_segment_samples).
+__device__ __forceinline__ uint32_t ceil_div_small(uint32_t num, uint32_t den) {  // ceil(num / den), num < 2^16, 0 < den
+  const uint32_t x = num + den - 1u;
+  uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)den));  // (within one of the quotient: x < 2^17 is exact in a float)
+  int r = (int)(x - q * den);
+  if (r < 0) --q, r += (int)den;
+  if (r >= (int)den) ++q;
+  return q;
+}
+__device__ __forceinline__ int mask_segment_cells(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int sx, int sy, int sz) {
+  const int dx = sx - vx, dy = sy - vy, dz = sz - vz;
+  const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+  const int m = max(ax, max(ay, az)), n = 2 * m + 1;
+  const uint32_t st0 = (uint32_t)(cv.st >> 26) & 3u;  // (v's own cell: the 14th of the 27)
+  if (m > 127 || st0 != 1u) return 2;
+  const int ix = dx < 0 ? -1 : 1, iy = dy < 0 ? -1 : 1, iz = dz < 0 ? -1 : 1;
+  // the next voxel offset along each axis that lies in another cell, and the sample that reaches it
+  int kx = dx < 0 ? (vx & 7) + 1 : 8 - (vx & 7), ky = dy < 0 ? (vy & 7) + 1 : 8 - (vy & 7), kz = dz < 0 ? (vz & 7) + 1 : 8 - (vz & 7);
+  int tx = kx <= ax ? (int)ceil_div_small((uint32_t)(n * (2 * kx - 1)), (uint32_t)(2 * ax)) : INT_MAX;
+  int ty = ky <= ay ? (int)ceil_div_small((uint32_t)(n * (2 * ky - 1)), (uint32_t)(2 * ay)) : INT_MAX;
+  int tz = kz <= az ? (int)ceil_div_small((uint32_t)(n * (2 * kz - 1)), (uint32_t)(2 * az)) : INT_MAX;
+  int ccx = cv.cx, ccy = cv.cy, ccz = cv.cz;
+  for (;;) {
+    const int t = min(tx, min(ty, tz));
+    if (t == INT_MAX) return 1;  // (every crossing lies at a sample <= n - 1, the winner itself)
+    if (tx == t) {
+      ccx += ix, kx += 8;
+      tx = kx <= ax ? (int)ceil_div_small((uint32_t)(n * (2 * kx - 1)), (uint32_t)(2 * ax)) : INT_MAX;
+    }
+    if (ty == t) {
+      ccy += iy, ky += 8;
+      ty = ky <= ay ? (int)ceil_div_small((uint32_t)(n * (2 * ky - 1)), (uint32_t)(2 * ay)) : INT_MAX;
+    }
+    if (tz == t) {
+      ccz += iz, kz += 8;
+      tz = kz <= az ? (int)ceil_div_small((uint32_t)(n * (2 * kz - 1)), (uint32_t)(2 * az)) : INT_MAX;
+    }
+    const uint32_t cst = cell_state(a, cv, ccx, ccy, ccz);
+    if (cst == 0u) return 0;
+    if (cst == 2u) return 2;
+  }
+}
+
+__device__ __forceinline__ bool mask_segment_observed(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int sx, int sy, int sz) {
+  const int r = mask_segment_cells(a, cv, vx, vy, vz, sx, sy, sz);  // 0 refused, 1 observed, 2 ask the samples
+  return r == 2 ? mask_segment_samples(a, cv, vx, vy, vz, sx, sy, sz) : r != 0;
+}
+
 // The second certificate, for a winner s hidden behind an unobserved voxel: s hands its id to an observed stencil neighbour p --
 // a PORTAL -- and through it to everybody whose way to p is clear.  Only a HIDDEN site has portals (a never-observed voxel among its
 // 26 neighbours); they are found once per update (k_portal_sites) and looked up by the walk.  v keeps T(v) = s if for some stencil direction e (in stencil
@@ -241,6 +298,8 @@ __device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, const CellV
   int px = ux, py = uy, pz = uz;
   int ccx = INT_MIN, ccy = 0, ccz = 0;
   uint32_t cst = 1u;
+  PROBE_ADD(2, 1);
+  PROBE_ADD(5, n);
   int i = n - 1;     // the sample (px, py, pz) is
   bool pend = true;  // ... and it has not been looked at yet
   for (;;) {
@@ -262,7 +321,11 @@ __device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, const CellV
           ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
           cst = cell_state(a, cv, ccx, ccy, ccz);
         }
-        if (cst == 0u) return false;
+        if (cst == 0u) {
+          PROBE_ADD(4, 1);
+          return false;
+        }
+        PROBE_ADD(3, 1);
         // (observed and free follow from the word: a never-observed voxel holds kUnobserved, an obstacle itself)
         w[k] = a.out[g.idx(px, py, pz)] & ~kAct;
         pend = false;
@@ -465,6 +528,10 @@ __global__ __launch_bounds__(256) void k_cell_dist(int ncx, int ncy, int ncz, co
   }
 }
 
+#ifndef FIESTA_CLASSIFY_SLABS
+#define FIESTA_CLASSIFY_SLABS 2
+#endif
+constexpr int kClassifySlabs = FIESTA_CLASSIFY_SLABS;  // voxel slabs (x) of a quad whose loads are in flight together
 constexpr int kMaskQueue = 512;  // walks a wave collects before it takes a range of a segment
 
 // One WAVE per quad (four cells along z: 32 voxels = one 128-byte line per voxel row, one bitmap word per row); lane = (y, four
@@ -526,11 +593,12 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
     const uint32_t mycd = cd[z4 >> 1], mycn = cn[z4 >> 1];  // (the cell of this lane's four voxels)
     // the quad's eight slabs: every load of the quad in flight before the first word is looked at (a slab at a time, each wave
     // went through eight dependent round trips to memory per quad)
-    uint32_t ww[8][4], obx[8], ocx[8];
+    for (int xh = 0; xh < 8; xh += kClassifySlabs) {
+    uint32_t ww[kClassifySlabs][4], obx[kClassifySlabs], ocx[kClassifySlabs];
     if (any_obs) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        const int X = 8 * cx + x;
+      for (int x = 0; x < kClassifySlabs; ++x) {
+        const int X = 8 * cx + xh + x;
         const int64_t base = ((int64_t)X * g.ny + Y) * g.nz + Z;
         ww[x][0] = ww[x][1] = ww[x][2] = ww[x][3] = kUnobserved;
         obx[x] = ocx[x] = 0;
@@ -547,8 +615,8 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
       }
     }
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      const int X = 8 * cx + x;
+    for (int x = 0; x < kClassifySlabs; ++x) {
+      const int X = 8 * cx + xh + x;
       if (X >= g.nx) break;  // (wave-uniform)
       const int64_t base = ((int64_t)X * g.ny + Y) * g.nz + Z;
       if (!any_obs) {  // nothing of this quad was ever observed
@@ -610,6 +678,7 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
         }
       }
       if (s_qn[wave] > (uint32_t)(kMaskQueue - 256)) flush((int)(q % kMaskSegs));
+    }
     }
     flush((int)(q % kMaskSegs));
   }
@@ -673,7 +742,12 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
       unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
       sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
       const vox_t ws = e.y & ~kAct;
-      if (cand == 0xFFFFFFFFu) cand = mask_portals_of(a, vx, vy, vz, sx, sy, sz, ws);
+      if (cand == 0xFFFFFFFFu) {
+        cand = mask_portals_of(a, vx, vy, vz, sx, sy, sz, ws);
+        PROBE_ADD(6, 1);
+        PROBE_ADD(7, __popc(cand));
+        if (!cand) PROBE_ADD(8, 1);
+      }
       bool certified = false;
       if (cand) {
         const int bit = mask_best_portal(cand, vx, vy, vz, sx, sy, sz);
@@ -682,6 +756,7 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
         stencil_dir(bit, dx, dy, dz);
         certified = mask_path_in_cell(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx + dx, sy + dy, sz + dz, ws);
       }
+      if (certified) PROBE_ADD(9, 1);
       if (!certified) {
         if (cand) {  // back into the queue (at most 512 + 256 waiting)
           const uint32_t at = atomicAdd(&s_qn, 1u);
