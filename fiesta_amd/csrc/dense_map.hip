@@ -1834,7 +1834,7 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
     FIESTA_HIP_CHECK(hipEventRecord(ev_cert, stream_));
     hipLaunchKernelGGL(k_mask_classify, dim3(classify_blocks), dim3(256), 0, stream_, a);
     hipLaunchKernelGGL(k_mask_walk, dim3(kMaskSegs * 16), dim3(256), 0, stream_, a);
-    hipLaunchKernelGGL(k_mask_cells, dim3(classify_blocks), dim3(256), 0, stream_, a);
+    hipLaunchKernelGGL(k_mask_cells, dim3(std::min(classify_blocks, 1024)), dim3(256), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipEventRecord(ev_rep, stream_));
     gi = 0;

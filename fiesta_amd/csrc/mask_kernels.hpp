@@ -777,53 +777,81 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
 // The CELLS (8^3 voxels) that hold a marked voxel -> the repair list; their marked voxels' words also go into the second buffer
 // (the repair keeps the two buffers equal on marked voxels between iterations).  One wave per quad (four cells along z): lane =
 // voxel row (x = lane / 8, y), one word of marks per row, a byte of it per cell.
+constexpr int kCellsList = 2048;
 __global__ __launch_bounds__(256) void k_mask_cells(MaskArgs a) {
-  __shared__ uint32_t s_n, s_base, s_list[16];
+  __shared__ uint32_t s_n, s_base, s_list[kCellsList];  // the cells this work-group finds: ONE atomic on the list's cursor at its end
+  __shared__ uint16_t s_vox[4][2048];  // a wave's marked voxels of its quad: row << 5 | z
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;
   if (a.ctr[MC_OVERFLOW]) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint16_t *vox = s_vox[wave];
   const int nqz = g.nzw;
   const int64_t nquads = (int64_t)a.ncx * a.ncy * nqz;
-  for (int64_t q0 = blockIdx.x * 4ll; q0 < nquads; q0 += (int64_t)gridDim.x * 4) {
-    const int64_t q = q0 + wave;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    if (q < nquads) {
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  for (int64_t q = blockIdx.x * 4ll + wave; q < nquads; q += (int64_t)gridDim.x * 4) {
+    {
       const int qz = (int)(q % nqz);
       const int cy = (int)((q / nqz) % a.ncy), cx = (int)(q / ((int64_t)nqz * a.ncy));
       const int X = 8 * cx + (lane >> 3), Y = 8 * cy + (lane & 7);
       uint32_t m = (X < g.nx && Y < g.ny) ? a.ubits[((int64_t)X * g.ny + Y) * g.nzw + qz] : 0u;
+      if (__any((int)(m != 0u))) {  // (wave-uniform)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool has = __any((int)(((m >> (8 * k)) & 255u) != 0u));
-        if (has && lane == 0) s_list[atomicAdd(&s_n, 1u)] = (uint32_t)((((int64_t)cx * a.ncy + cy) * a.ncz) + 4 * qz + k);
-      }
-      const int64_t base = ((int64_t)X * g.ny + Y) * g.nz + 32 * qz;
-      while (m) {
-        const int b = __ffs((int)m) - 1;
-        m &= m - 1;
-        // an uncertified voxel keeps what it held before the update if that obstacle still exists, else "no obstacle" -- the
-        // word the repair starts from, in both buffers
-        vox_t o = a.old[base + b] & ~kAct;
-        if (!(o & kNoCoc)) {
-          int ox, oy, oz;
-          unpack_coc(g.wrap, X + g.gx0, Y + g.gy0, 32 * qz + b + g.gz0, o, ox, oy, oz);
-          ox -= g.gx0, oy -= g.gy0, oz -= g.gz0;
-          if (!(g.in_grid(ox, oy, oz) && bit_test(a.occbits, g, ox, oy, oz))) o = kInf;
-        } else {
-          o = kInf;
+        for (int k = 0; k < 4; ++k) {
+          const bool has = __any((int)(((m >> (8 * k)) & 255u) != 0u));
+          if (has && lane == 0) {
+            const uint32_t cell = (uint32_t)((((int64_t)cx * a.ncy + cy) * a.ncz) + 4 * qz + k);
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            if (at < (uint32_t)kCellsList) s_list[at] = cell;
+            else a.uq[atomicAdd(&a.ctr[MC_QUADS], 1ull)] = cell;  // (a map far larger than the launch was sized for)
+          }
         }
-        a.out[base + b] = o;
-        a.old[base + b] = o;
+        // the quad's marked voxels, spread over the lanes: a row's marks one after the other -- each a load of the old word, its
+        // obstacle looked up behind it -- kept a wave as long as its fullest row
+        uint32_t incl = (uint32_t)__popc(m);
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+          if (lane >= off) incl += up;
+        }
+        const uint32_t nm = (uint32_t)__shfl((int)incl, 63);
+        {
+          uint32_t at = incl - (uint32_t)__popc(m);
+          while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            vox[at++] = (uint16_t)((lane << 5) | b);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t i = (uint32_t)lane; i < nm; i += 64u) {
+          const uint32_t code = vox[i];
+          const int row = (int)(code >> 5), b = (int)(code & 31u);
+          const int VX = 8 * cx + (row >> 3), VY = 8 * cy + (row & 7), VZ = 32 * qz + b;
+          const int64_t idx = ((int64_t)VX * g.ny + VY) * g.nz + VZ;
+          // an uncertified voxel keeps what it held before the update if that obstacle still exists, else "no obstacle" -- the
+          // word the repair starts from, in both buffers
+          vox_t o = a.old[idx] & ~kAct;
+          if (!(o & kNoCoc)) {
+            int ox, oy, oz;
+            unpack_coc(g.wrap, VX + g.gx0, VY + g.gy0, VZ + g.gz0, o, ox, oy, oz);
+            ox -= g.gx0, oy -= g.gy0, oz -= g.gz0;
+            if (!(g.in_grid(ox, oy, oz) && bit_test(a.occbits, g, ox, oy, oz))) o = kInf;
+          } else {
+            o = kInf;
+          }
+          a.out[idx] = o;
+          a.old[idx] = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_n) s_base = (uint32_t)atomicAdd(&a.ctr[MC_QUADS], (unsigned long long)s_n);
-    __syncthreads();
-    if (threadIdx.x < s_n) a.uq[s_base + threadIdx.x] = s_list[threadIdx.x];
-    __syncthreads();
   }
+  __syncthreads();
+  const uint32_t n = min(s_n, (uint32_t)kCellsList);
+  if (threadIdx.x == 0 && n) s_base = (uint32_t)atomicAdd(&a.ctr[MC_QUADS], (unsigned long long)n);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a.uq[s_base + i] = s_list[i];
 }
 
 // ---- the repair: block-Jacobi pulls on the marked voxels ------------------------------------------------------------------------------
@@ -886,15 +914,15 @@ __global__ __launch_bounds__(256) void k_repair_cell(MaskArgs a, int it, int rd,
         const int vx = 8 * cx + x + g.gx0, vy = 8 * cy + y + g.gy0, vz = 8 * cz + z + g.gz0;
         const int c0 = ((x + 2) * kTileE + y + 2) * kTileE + z + 2;
         const vox_t cw = tile[c0];
-        int32_t best = (cw & kNoCoc) ? kD2Inf : dist2(g.wrap, vx, vy, vz, cw);
+        int32_t best = (cw & kNoCoc) ? kD2Inf : dist2(0, vx, vy, vz, cw);  // (the masked transform never runs on a map whose ids wrap)
         vox_t bw = cw;
         // (a neighbour's word names the same obstacle for this voxel: ids are global coordinates, modulo 1024 on larger grids)
 #define FIESTA_PULL(DX, DY, DZ)                                                          \
   {                                                                                      \
     const vox_t w = tile[c0 + ((DX) * kTileE + (DY)) * kTileE + (DZ)];                   \
     if (!(w & kNoCoc)) {                                                                 \
-      const int32_t d = dist2(g.wrap, vx, vy, vz, w);                                    \
-      if (d < best && (!g.wrap || d < kD2Cap)) best = d, bw = w;                         \
+      const int32_t d = dist2(0, vx, vy, vz, w);                                         \
+      if (d < best) best = d, bw = w;                                                    \
     }                                                                                    \
   }
         FIESTA_STENCIL24(FIESTA_PULL)
