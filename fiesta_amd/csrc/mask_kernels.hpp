@@ -64,7 +64,7 @@ struct MaskArgs {
   vox_t *old;                // the field before this update; the repair's second buffer afterwards
   vox_t *out;                // T on entry, the new field on exit
   uint32_t *ubits;           // 1 bit / voxel: marked for repair
-  uint2 *walks;              // walk list: (linear voxel index, winner), kMaskSegs segments of seg_cap entries
+  uint2 *walks;              // walk list: (voxel x << 20 | y << 10 | z -- no axis of such a map exceeds 1024 --, winner), kMaskSegs segments of seg_cap entries
   uint32_t seg_cap;
   uint32_t *uq;              // cells that hold a marked voxel
   uint32_t *qstamp[2];       // per cell: tag of the last iteration (by parity) that changed a voxel in or next to it
@@ -157,9 +157,16 @@ __global__ __launch_bounds__(256) void k_eff_occ(Geom g, const uint32_t *occbits
         const int b = __ffs((int)m) - 1;
         m &= m - 1;
         const int z = 32 * zw + b;
-        bool any = false;
+        // (all 24 words asked for at once: a quarter of config 2-partial's obstacles stand inside never-observed blocks, and a lane
+        //  that stops at the first observed neighbour goes through two dozen dependent loads for each of them)
+        uint32_t any = 0;
 #define FIESTA_EFF(DX, DY, DZ)                                                                          \
-  if (!any && g.in_grid(x + (DX), y + (DY), z + (DZ)) && bit_test(obsbits, g, x + (DX), y + (DY), z + (DZ))) any = true;
+  {                                                                                                     \
+    const int ux = x + (DX), uy = y + (DY), uz = z + (DZ);                                              \
+    const bool in = g.in_grid(ux, uy, uz);                                                              \
+    const uint32_t w = obsbits[in ? g.bitword(ux, uy, uz) : wi];                                        \
+    any |= in ? (w >> (uz & 31)) & 1u : 0u;                                                             \
+  }
         FIESTA_STENCIL24(FIESTA_EFF)
 #undef FIESTA_EFF
         if (any) keep |= 1u << b;
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
         const unsigned long long mq = __ballot(want[k]);
         if (mq) {
           const uint32_t at = s_qn[wave];
-          if (want[k]) queue[at + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = uint2{(uint32_t)(base + k), w[k]};
+          if (want[k]) queue[at + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = uint2{((uint32_t)X << 20) | ((uint32_t)Y << 10) | (uint32_t)(Z + k), w[k]};
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           if (lane == 0) s_qn[wave] = at + (uint32_t)__popcll(mq);
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -715,8 +722,7 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
       __syncthreads();  // (s_qn is read by everybody before anybody adds to it)
       if (i < n) {
         const uint2 e = a.walks[(size_t)seg * a.seg_cap + i];
-        const uint32_t idx = e.x;
-        const int vz = (int)(idx % (uint32_t)g.nz), vy = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), vx = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
+        const int vx = (int)(e.x >> 20), vy = (int)((e.x >> 10) & 1023u), vz = (int)(e.x & 1023u);
         int sx, sy, sz;
         unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
         sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
@@ -736,8 +742,7 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
     if (threadIdx.x == 0) s_qn = qn - take;
     __syncthreads();
     if (threadIdx.x < take) {
-      const uint32_t idx = e.x;
-      const int vz = (int)(idx % (uint32_t)g.nz), vy = (int)((idx / (uint32_t)g.nz) % (uint32_t)g.ny), vx = (int)(idx / ((uint32_t)g.nz * (uint32_t)g.ny));
+      const int vx = (int)(e.x >> 20), vy = (int)((e.x >> 10) & 1023u), vz = (int)(e.x & 1023u);
       int sx, sy, sz;
       unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
       sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
@@ -906,9 +911,11 @@ __global__ __launch_bounds__(256) void k_repair_cell(MaskArgs a, int it, int rd,
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t ever = 0;  // bit k: the lane's k-th voxel (lane + 64 k of the list) has changed -- a pull only ever lowers a distance
     for (int sub = 0; sub < kMaskSub; ++sub) {
       bool changed = false;
-      for (uint32_t i = (uint32_t)lane; i < nm; i += 64u) {
+      int k = 0;
+      for (uint32_t i = (uint32_t)lane; i < nm; i += 64u, ++k) {
         const uint32_t code = voxl[i];
         const int x = (int)(code >> 6), y = (int)((code >> 3) & 7u), z = (int)(code & 7u);
         const int vx = 8 * cx + x + g.gx0, vy = 8 * cy + y + g.gy0, vz = 8 * cz + z + g.gz0;
@@ -929,6 +936,7 @@ __global__ __launch_bounds__(256) void k_repair_cell(MaskArgs a, int it, int rd,
 #undef FIESTA_PULL
         newv[i] = bw;
         changed |= bw != cw;
+        ever |= (uint32_t)(bw != cw) << k;
       }
       if (!__any((int)changed)) break;  // (wave-uniform)
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (every pull of this step has read the tile)
@@ -939,24 +947,25 @@ __global__ __launch_bounds__(256) void k_repair_cell(MaskArgs a, int it, int rd,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     // the voxels that differ from what `out` holds -> the second buffer (the two were equal on every marked voxel)
-    for (uint32_t i = (uint32_t)lane; i < nm; i += 64u) {
+    for (uint32_t i = (uint32_t)lane; ever; i += 64u, ever >>= 1) {
+      if (!(ever & 1u)) continue;
       const uint32_t code = voxl[i];
       const int x = (int)(code >> 6), y = (int)((code >> 3) & 7u), z = (int)(code & 7u);
-      const vox_t v = tile[((x + 2) * kTileE + y + 2) * kTileE + z + 2];
-      const int64_t idx = g.idx(8 * cx + x, 8 * cy + y, 8 * cz + z);
-      if (v != (a.out[idx] & ~kAct)) a.old[idx] = v;
+      a.old[g.idx(8 * cx + x, 8 * cy + y, 8 * cz + z)] = tile[((x + 2) * kTileE + y + 2) * kTileE + z + 2];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next cell's staging overwrites the tile)
   }
 }
 
 __global__ __launch_bounds__(256) void k_repair_commit(MaskArgs a, int it, int rd, uint32_t tag_prev, uint32_t tag, int first) {
+  __shared__ uint16_t s_voxl[4][512];  // marked voxels of the wave's cell: x << 6 | y << 3 | z
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;
   if (a.ctr[MC_OVERFLOW]) return;
   if (it > 0 && a.ctr[MC_CHANGED0 + it - 1] == 0) return;
   const uint32_t nuq = (uint32_t)a.ctr[MC_QUADS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // one wave per cell: lane = voxel row (x = lane / 8, y), its 8 z
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // one wave per cell
+  uint16_t *voxl = s_voxl[wave];
   const uint32_t *stamp_r = a.qstamp[rd];
   uint32_t *stamp_w = a.qstamp[rd ^ 1];
   unsigned total = 0;
@@ -965,18 +974,33 @@ __global__ __launch_bounds__(256) void k_repair_commit(MaskArgs a, int it, int r
     if (!first && stamp_r[c] != tag_prev) continue;  // (the cells k_repair_cell worked on)
     const int cz = (int)(c % (uint32_t)a.ncz);
     const int cy = (int)((c / (uint32_t)a.ncz) % (uint32_t)a.ncy), cx = (int)(c / ((uint32_t)a.ncz * (uint32_t)a.ncy));
-    const int x = lane >> 3, y = lane & 7;
-    const int X = 8 * cx + x, Y = 8 * cy + y;
+    // the cell's marks, spread over the lanes (lane = voxel row for the load: x = lane / 8, y = lane % 8, a byte of the row's word)
+    const int X = 8 * cx + (lane >> 3), Y = 8 * cy + (lane & 7);
     uint32_t m = (X < g.nx && Y < g.ny) ? ((a.ubits[((int64_t)X * g.ny + Y) * g.nzw + (cz >> 2)] >> (8 * (cz & 3))) & 255u) : 0u;
-    const int64_t base = ((int64_t)X * g.ny + Y) * g.nz + 8 * cz;
+    uint32_t incl = (uint32_t)__popc(m);
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= off) incl += up;
+    }
+    const uint32_t nm = (uint32_t)__shfl((int)incl, 63);
+    {
+      uint32_t at = incl - (uint32_t)__popc(m);
+      while (m) {
+        const int b = __ffs((int)m) - 1;
+        m &= m - 1;
+        voxl[at++] = (uint16_t)((lane << 3) | b);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     unsigned mine = 0;
     uint32_t near = 0;  // bit (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1): a neighbour cell has a changed voxel in its halo
-    while (m) {
-      const int b = __ffs((int)m) - 1;
-      m &= m - 1;
-      const vox_t nv = a.old[base + b];
-      if (nv == a.out[base + b]) continue;
-      a.out[base + b] = nv;
+    for (uint32_t i = (uint32_t)lane; i < nm; i += 64u) {
+      const uint32_t code = voxl[i];
+      const int x = (int)(code >> 6), y = (int)((code >> 3) & 7u), b = (int)(code & 7u);
+      const int64_t idx = g.idx(8 * cx + x, 8 * cy + y, 8 * cz + b);
+      const vox_t nv = a.old[idx];
+      if (nv == a.out[idx]) continue;
+      a.out[idx] = nv;
       ++mine;
       const int dxl = x < 2 ? -1 : 0, dxh = x > 5 ? 1 : 0, dyl = y < 2 ? -1 : 0, dyh = y > 5 ? 1 : 0, dzl = b < 2 ? -1 : 0, dzh = b > 5 ? 1 : 0;
       for (int dx = dxl; dx <= dxh; ++dx)
@@ -993,6 +1017,7 @@ __global__ __launch_bounds__(256) void k_repair_commit(MaskArgs a, int it, int r
         stamp_w[((int64_t)ux * a.ncy + uy) * a.ncz + uz] = tag;
     }
     total += mine;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next cell's list overwrites this one)
   }
   if (lane == 0 && total) atomicAdd(&a.ctr[MC_CHANGED0 + it], (unsigned long long)total);
 }

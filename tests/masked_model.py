@@ -35,6 +35,38 @@ def certificate(obs, V, S):
     return cert
 
 
+def certificate_by_cells(cellobs, V, S):
+    """The same answer from the 8^3 cells a segment crosses (mask_kernels.hpp: mask_segment_cells), for maps whose cells are all
+    either fully observed (cellobs 1) or never observed (0): axis a of sample i is v + sign floor((2 |d_a| i + n) / 2n), so the
+    walk enters its k-th voxel along a at sample ceil(n (2k - 1) / (2 |d_a|)); the cell boundaries are taken in the order of those
+    samples, the axes that cross at the same sample together.  One voxel pair at a time (a model of the kernel's loop, not fast)."""
+    out = np.ones(len(V), bool)
+    for j, (v, s) in enumerate(zip(np.asarray(V, np.int64), np.asarray(S, np.int64))):
+        d = s - v
+        a = np.abs(d)
+        n = 2 * int(a.max()) + 1
+        sg = np.where(d < 0, -1, 1)
+        k = np.where(d < 0, (v & 7) + 1, 8 - (v & 7))
+        INF = 1 << 60
+        t = [(-(-(n * (2 * int(k[x]) - 1)) // (2 * int(a[x]))) if k[x] <= a[x] else INF) for x in range(3)]
+        c = v >> 3
+        assert cellobs[c[0], c[1], c[2]] == 1
+        while True:
+            tm = min(t)
+            if tm == INF:
+                break
+            assert tm <= n - 1
+            for x in range(3):
+                if t[x] == tm:
+                    c[x] += sg[x]
+                    k[x] += 8
+                    t[x] = -(-(n * (2 * int(k[x]) - 1)) // (2 * int(a[x]))) if k[x] <= a[x] else INF
+            if cellobs[c[0], c[1], c[2]] == 0:
+                out[j] = False
+                break
+    return out
+
+
 RING = {k: np.array([(x, y, z) for x in range(-2, 3) for y in range(-2, 3) for z in range(-2, 3) if 0 < x * x + y * y + z * z <= k]) for k in (1, 2, 4)}
 
 

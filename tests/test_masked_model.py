@@ -83,3 +83,22 @@ def test_model_stays_inside_the_reference_envelope(oracle_libs, best_oracle_kind
         assert rep["inf_where_every_run_is_finite"] == 0 and rep["finite_where_every_run_is_inf"] == 0, rep
         assert_envelope(rep, f"masked model, 96^3 C2-partial, step {step}", strict=True)
     env.close()
+
+
+def test_certificate_from_cell_crossings_equals_the_sample_walk():
+    """k_mask_walk decides the straight certificate from the cells a segment crosses where no cell on its way is partly observed
+    (mask_kernels.hpp: mask_segment_cells); the sample walk is the definition (mask_segment_samples, masked_model.certificate)."""
+    import masked_model
+    rng = np.random.RandomState(5)
+    C = 12
+    for density in (0.1, 0.3, 0.6):
+        cellobs = (rng.rand(C, C, C) >= density).astype(np.uint8)
+        obs = np.repeat(np.repeat(np.repeat(cellobs != 0, 8, 0), 8, 1), 8, 2)
+        V = rng.randint(0, 8 * C, (6000, 3))
+        S = np.clip(V + rng.randint(-40, 41, (6000, 3)), 0, 8 * C - 1)
+        keep = obs[V[:, 0], V[:, 1], V[:, 2]] & (np.abs(S - V).max(1) > 0)
+        V, S = V[keep], S[keep]
+        a = masked_model.certificate(obs, V, S)
+        b = masked_model.certificate_by_cells(cellobs, V, S)
+        assert np.array_equal(a, b), int((a != b).sum())
+        assert 0 < a.sum() < len(a)
