@@ -292,23 +292,24 @@ __device__ __forceinline__ bool mask_segment_observed(const MaskArgs &a, const C
 // such a winner; against the envelope of the reference's runs (tests/golden/c2_partial_256_envelope.npz) this certificate takes
 // the voxels closer than every run from 247 / 180 to 0 / 0 -- the straight segment alone repaired those regions by pulls, whose
 // ties fall differently from the reference's arrivals.
-// (walked from the portal's end, where the never-observed voxels are: a path through a cell nothing was observed in is refused
-//  from the cell's summary, before a word of `out` is asked for; the words of the samples go out six at a time)
-__device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int ux, int uy, int uz, vox_t ws) {
+// (walked from the portal's end, where the never-observed voxels are; the words of the samples go out six at a time.  A check of the
+//  cells' summaries ahead of the loads would spare a refused path its words -- one path in nine -- at a third more instructions
+//  for every path: the walk kernel is bound by its VALU instructions, not by these loads)
+__device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, int vx, int vy, int vz, int ux, int uy, int uz, vox_t ws) {
   const Geom &g = a.g;
   const int dx = ux - vx, dy = uy - vy, dz = uz - vz;
   const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
   const int m = max(ax, max(ay, az)), n = 2 * m + 1, n2 = 2 * n;
   if (m == 0) return true;
   const int ix = dx < 0 ? -1 : 1, iy = dy < 0 ? -1 : 1, iz = dz < 0 ? -1 : 1;
-  int ex = n - 2 * ax, ey = n - 2 * ay, ez = n - 2 * az;  // sample n - 1 is the portal itself (see mask_segment_observed)
-  int px = ux, py = uy, pz = uz;
-  int ccx = INT_MIN, ccy = 0, ccz = 0;
-  uint32_t cst = 1u;
-  PROBE_ADD(2, 1);
-  PROBE_ADD(5, n);
-  int i = n - 1;     // the sample (px, py, pz) is
+  int ex = n - 2 * ax, ey = n - 2 * ay, ez = n - 2 * az;  // sample n - 1 is the portal itself (see mask_segment_samples)
+  // the walk only needs the sample's WORD: its linear index moves by a stride when an axis steps (no axis of such a map exceeds
+  // 1024: the index fits 30 bits)
+  const int stx = ix * g.ny * g.nz, sty = iy * g.nz, stz = iz;
+  int pidx = (ux * g.ny + uy) * g.nz + uz;
+  int i = n - 1;     // the sample pidx is
   bool pend = true;  // ... and it has not been looked at yet
+  PROBE_ADD(2, 1);
   for (;;) {
     uint32_t w[6];
 #pragma unroll
@@ -319,22 +320,15 @@ __device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, const CellV
         if (!pend && i > 1) {
           --i;
           ex -= 2 * ax, ey -= 2 * ay, ez -= 2 * az;
-          if (ex < 0) ex += n2, px -= ix, pend = true;
-          if (ey < 0) ey += n2, py -= iy, pend = true;
-          if (ez < 0) ez += n2, pz -= iz, pend = true;
+          const int mx = ex >> 31, my = ey >> 31, mz = ez >> 31;  // (all ones where the axis steps)
+          ex += mx & n2, ey += my & n2, ez += mz & n2;
+          pidx -= (mx & stx) + (my & sty) + (mz & stz);
+          pend = (mx | my | mz) != 0;
         }
       if (pend) {
-        if ((px >> 3) != ccx || (py >> 3) != ccy || (pz >> 3) != ccz) {
-          ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
-          cst = cell_state(a, cv, ccx, ccy, ccz);
-        }
-        if (cst == 0u) {
-          PROBE_ADD(4, 1);
-          return false;
-        }
         PROBE_ADD(3, 1);
         // (observed and free follow from the word: a never-observed voxel holds kUnobserved, an obstacle itself)
-        w[k] = a.out[g.idx(px, py, pz)] & ~kAct;
+        w[k] = a.out[pidx] & ~kAct;
         pend = false;
       }
     }
@@ -377,30 +371,31 @@ __device__ inline uint32_t mask_portals_of(const MaskArgs &a, int vx, int vy, in
     }
     if (e.x == 0xFFFFFFFFu) break;
   }
-  const int dvs = (sx - vx) * (sx - vx) + (sy - vy) * (sy - vy) + (sz - vz) * (sz - vz);
+  // nearer to v than the winner: |s + e - v|^2 < |s - v|^2, that is 2 e.(s - v) + |e|^2 < 0 -- all 24 at once, no loop
+  const int wx = sx - vx, wy = sy - vy, wz = sz - vz;
   uint32_t keep = 0;
-  for (uint32_t mm = mask; mm;) {
-    const int bit = __ffs((int)mm) - 1;
-    mm &= mm - 1u;
-    int dx, dy, dz;
-    stencil_dir(bit, dx, dy, dz);
-    const int ux = sx + dx, uy = sy + dy, uz = sz + dz;
-    if ((ux - vx) * (ux - vx) + (uy - vy) * (uy - vy) + (uz - vz) * (uz - vz) < dvs) keep |= 1u << bit;
-  }
-  return keep;
+  int bit = 0;
+#define FIESTA_NEARER(DX, DY, DZ)                                                                                  \
+  keep |= (uint32_t)(2 * ((DX) * wx + (DY) * wy + (DZ) * wz) + ((DX) * (DX) + (DY) * (DY) + (DZ) * (DZ)) < 0) << bit; \
+  ++bit;
+  FIESTA_STENCIL24(FIESTA_NEARER)
+#undef FIESTA_NEARER
+  return keep & mask;
 }
-// the candidate nearest to v (any order gives the same answer to "does one of them certify v": the nearest does most often)
+// the candidate nearest to v (any order gives the same answer to "does one of them certify v": the nearest does most often);
+// |s + e - v|^2 - |s - v|^2 = 2 e.(s - v) + |e|^2, the lowest stencil index among equals
 __device__ inline int mask_best_portal(uint32_t cand, int vx, int vy, int vz, int sx, int sy, int sz) {
-  int best = -1, bd = INT_MAX;
-  for (uint32_t mm = cand; mm;) {
-    const int bit = __ffs((int)mm) - 1;
-    mm &= mm - 1u;
-    int dx, dy, dz;
-    stencil_dir(bit, dx, dy, dz);
-    const int ux = sx + dx, uy = sy + dy, uz = sz + dz;
-    const int d = (ux - vx) * (ux - vx) + (uy - vy) * (uy - vy) + (uz - vz) * (uz - vz);
-    if (d < bd) bd = d, best = bit;
+  const int wx = sx - vx, wy = sy - vy, wz = sz - vz;
+  int best = -1, bd = INT_MAX, bit = 0;
+#define FIESTA_BEST(DX, DY, DZ)                                                                           \
+  {                                                                                                       \
+    const int f = 2 * ((DX) * wx + (DY) * wy + (DZ) * wz) + ((DX) * (DX) + (DY) * (DY) + (DZ) * (DZ));    \
+    const bool take = ((cand >> bit) & 1u) && f < bd;                                                     \
+    bd = take ? f : bd, best = take ? bit : best;                                                         \
+    ++bit;                                                                                                \
   }
+  FIESTA_STENCIL24(FIESTA_BEST)
+#undef FIESTA_BEST
   return best;
 }
 
@@ -759,7 +754,7 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
         cand &= ~(1u << bit);
         int dx, dy, dz;
         stencil_dir(bit, dx, dy, dz);
-        certified = mask_path_in_cell(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx + dx, sy + dy, sz + dz, ws);
+        certified = mask_path_in_cell(a, vx, vy, vz, sx + dx, sy + dy, sz + dz, ws);
       }
       if (certified) PROBE_ADD(9, 1);
       if (!certified) {
