@@ -1785,10 +1785,15 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
   ma.ctr = mask_ctr_;
   FIESTA_HIP_CHECK(hipMemsetAsync(mask_ctr_, 0, MC_COUNT * sizeof(unsigned long long), stream_));
   FIESTA_HIP_CHECK(hipMemsetAsync(mask_ubits_.p, 0, (size_t)nbitwords_ * sizeof(uint32_t), stream_));
-  hipLaunchKernelGGL(k_obs_cells, dim3(grid_for(nquads, 4, 16384)), dim3(256), 0, stream_, g_, ncx, ncy, ncz,
-                     (const uint32_t *)obsbits_, cellobs_.p);
-  hipLaunchKernelGGL(k_cell_dist, dim3(grid_for(ncells, 256, 4096)), dim3(256), 0, stream_, ncx, ncy, ncz, (const uint8_t *)cellobs_.p, celldist_.p,
-                     cellnb_.p, cellst_.p);
+  // the cells' summaries follow the observed set alone, and that only grows: as many observed voxels as when they were last
+  // built (and no restore or load since) = the same set
+  if (mask_obs_count_ != (long long)h_counters_[C_OBSERVED]) {
+    hipLaunchKernelGGL(k_obs_cells, dim3(grid_for(nquads, 4, 16384)), dim3(256), 0, stream_, g_, ncx, ncy, ncz,
+                       (const uint32_t *)obsbits_, cellobs_.p);
+    hipLaunchKernelGGL(k_cell_dist, dim3(grid_for(ncells, 256, 4096)), dim3(256), 0, stream_, ncx, ncy, ncz, (const uint8_t *)cellobs_.p, celldist_.p,
+                       cellnb_.p, cellst_.p);
+    mask_obs_count_ = (long long)h_counters_[C_OBSERVED];
+  }
   hipLaunchKernelGGL(k_eff_occ, dim3(grid_for(nbitwords_, 256, 8192)), dim3(256), 0, stream_, g_, (const uint32_t *)occbits_,
                      (const uint32_t *)obsbits_, effocc_.p, nbitwords_);
   {  // the hidden sites' portals: a table of at least four slots per obstacle
@@ -2671,6 +2676,7 @@ void DenseMap::snapshot_restore(int slot) {
   ++field_epoch_;  // (the host-side brick cache of the scalar queries is stale from here on)
   nn_clean_ = false;  // (the counters come back as they were saved)
   nn_valid_ = false;
+  mask_obs_count_ = -1;
   use_device();
   if (slot < 0 || slot >= 4 || !snaps_[slot].valid) throw Error(FIESTA_HIP_ERR_STATE, "no such snapshot");
   Snapshot &s = snaps_[slot];
@@ -2716,7 +2722,7 @@ void DenseMap::snapshot_restore(int slot) {
 // Raw dump (write) / load of the whole map state: one routine for both directions (checkpoint.hpp).
 void DenseMap::checkpoint(const char *path, bool write) {
   nn_clean_ = false;  // (the counters come back as they were saved)
-  if (!write) nn_valid_ = false, ++field_epoch_;  // (a loaded field: the host-side brick cache of the scalar queries is stale)
+  if (!write) nn_valid_ = false, mask_obs_count_ = -1, ++field_epoch_;  // (a loaded field: the host-side brick cache of the scalar queries is stale)
   use_device();
   FIESTA_HIP_CHECK(hipStreamSynchronize(stream_));
   DevFile f(path, write, stream_);

@@ -266,6 +266,7 @@ class DenseMap {
   DevBuf<uint8_t> cellobs_, celldist_;
   unsigned long long *mask_ctr_ = nullptr, *h_mask_ctr_ = nullptr;
   uint32_t mask_serial_ = 0;   // tags of the repair iterations (stamps are never cleared)
+  long long mask_obs_count_ = -1;  // observed voxels when the cells' summaries (cellobs_ ... cellst_) were built; -1: rebuild
   size_t mask_seg_cap_ = 0;    // entries per segment of the walk list (doubles when a scene needs more)
   int mask_chain_hint_ = 10;   // repair iterations launched before the first read-back (the last update's count + 2)
   // while a masked transform runs: what the transforms read and write instead of occbits_ / coc_

@@ -542,7 +542,7 @@ constexpr int kMaskQueue = 512;  // walks a wave collects before it takes a rang
 // on a voxel's word: the cells between a voxel and its winner are judged from the cell's own summaries, held in registers.
 __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
   __shared__ uint2 s_queue[4][kMaskQueue];
-  __shared__ uint32_t s_qn[4];
+  __shared__ uint32_t s_qn[4], s_need[27];
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;  // T was never written (a cell without a list): the host takes the envelope passes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -556,6 +556,13 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
   const bool vec = (g.nz & 3) == 0;
   if (lane == 0) s_qn[wave] = 0;
   unsigned nwalk = 0;
+  // the cells of the 3^3 around a voxel's cell that the box of the cell and a winner's cell (one cell away) covers, by the offset
+  if (threadIdx.x < 27) {
+    const uint32_t mx = 2u | (1u << (threadIdx.x / 9)), my = 2u | (1u << ((threadIdx.x / 3) % 3)), mz = 2u | (1u << (threadIdx.x % 3));
+    const uint32_t pm = ((my & 1u) ? mz : 0u) | ((my & 2u) ? mz << 3 : 0u) | ((my & 4u) ? mz << 6 : 0u);
+    s_need[threadIdx.x] = ((mx & 1u) ? pm : 0u) | ((mx & 2u) ? pm << 9 : 0u) | ((mx & 4u) ? pm << 18 : 0u);
+  }
+  __syncthreads();
 
   // (a quad's walks go to segment quad % kMaskSegs: neighbouring quads feed different segments, the segments fill evenly)
   auto flush = [&](const int seg) {  // the wave's queued walks -> a segment of the list (every lane calls)
@@ -646,18 +653,15 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
         } else if (w[k] & kNoCoc) {
           w[k] = kInf;  // (a map without a site)
         } else {
-          int sx, sy, sz;
-          unpack_coc(g.wrap, X + g.gx0, Y + g.gy0, vz + g.gz0, w[k], sx, sy, sz);
-          sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
+          // (the masked transform never runs on a map whose ids wrap: the word's fields ARE the winner's global coordinates)
+          const int sx = (int)((w[k] >> 20) & 1023u) - g.gx0, sy = (int)((w[k] >> 10) & 1023u) - g.gy0, sz = (int)(w[k] & 1023u) - g.gz0;
           const int cx1 = sx >> 3, cy1 = sy >> 3, cz1 = sz >> 3, cz0 = vz >> 3;
           const int co = max(max(cx1 > cx ? cx1 - cx : cx - cx1, cy1 > cy ? cy1 - cy : cy - cy1), cz1 > cz0 ? cz1 - cz0 : cz0 - cz1);
           // every cell the box of v and its winner touches fully observed -> certified without a walk: from the cell's distance
           // to the nearest cell that is not, else (a box within the 3^3 cells around) from the cell's neighbour mask
           bool full = (uint32_t)co < mycd;
           if (!full && co == 1) {
-            const uint32_t mx = 2u | (1u << (cx1 - cx + 1)), my = 2u | (1u << (cy1 - cy + 1)), mz = 2u | (1u << (cz1 - cz0 + 1));
-            const uint32_t pm = ((my & 1u) ? mz : 0u) | ((my & 2u) ? mz << 3 : 0u) | ((my & 4u) ? mz << 6 : 0u);
-            const uint32_t need = ((mx & 1u) ? pm : 0u) | ((mx & 2u) ? pm << 9 : 0u) | ((mx & 4u) ? pm << 18 : 0u);
+            const uint32_t need = s_need[(cx1 - cx + 1) * 9 + (cy1 - cy + 1) * 3 + (cz1 - cz0 + 1)];
             full = (mycn & need) == need;
           }
           want[k] = !full;
@@ -718,9 +722,7 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
       if (i < n) {
         const uint2 e = a.walks[(size_t)seg * a.seg_cap + i];
         const int vx = (int)(e.x >> 20), vy = (int)((e.x >> 10) & 1023u), vz = (int)(e.x & 1023u);
-        int sx, sy, sz;
-        unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
-        sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
+        const int sx = (int)((e.y >> 20) & 1023u) - g.gx0, sy = (int)((e.y >> 10) & 1023u) - g.gy0, sz = (int)(e.y & 1023u) - g.gz0;
         if (!mask_segment_observed(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx, sy, sz)) {
           const uint32_t at = atomicAdd(&s_qn, 1u);  // (at most 255 + 256 waiting)
           s_q[at] = e, s_qm[at] = 0xFFFFFFFFu;
@@ -738,9 +740,7 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
     __syncthreads();
     if (threadIdx.x < take) {
       const int vx = (int)(e.x >> 20), vy = (int)((e.x >> 10) & 1023u), vz = (int)(e.x & 1023u);
-      int sx, sy, sz;
-      unpack_coc(g.wrap, vx + g.gx0, vy + g.gy0, vz + g.gz0, e.y, sx, sy, sz);
-      sx -= g.gx0, sy -= g.gy0, sz -= g.gz0;
+      const int sx = (int)((e.y >> 20) & 1023u) - g.gx0, sy = (int)((e.y >> 10) & 1023u) - g.gy0, sz = (int)(e.y & 1023u) - g.gz0;
       const vox_t ws = e.y & ~kAct;
       if (cand == 0xFFFFFFFFu) {
         cand = mask_portals_of(a, vx, vy, vz, sx, sy, sz, ws);

@@ -129,3 +129,29 @@ def test_incremental_updates_on_ragged_maps_are_exact(hip_lib, shape, seed):
         check_exact(m, shape)
     assert inc >= 3, inc
     m.close()
+
+
+def test_incremental_update_with_many_dirty_cells_is_exact(hip_lib):
+    """a map large enough for a three-digit delta to stay incremental: tens of thousands of dirty cells, k_nn_mark's work-groups
+    flush their LDS queues more than once (one atomic on the list's cursor per flush)"""
+    from test_gpu_cells import check_exact, free, make_map, occupy
+    shape = (320, 320, 320)
+    rng = np.random.RandomState(11)
+    m = make_map(shape, "cells")
+    n = shape[0] * shape[1] * shape[2]
+    pick = lambda k: np.stack(np.unravel_index(rng.choice(n, k, replace=False), shape), 1).astype(np.int32)  # noqa: E731
+    live = pick(n // 2700)
+    occupy(m, live)
+    st = m.UpdateESDF()
+    assert st["cells"] == 1, st
+    for step in range(2):
+        k = 60
+        new = pick(k)
+        occupy(m, new)
+        free(m, live[:k])
+        live = np.concatenate([live[k:], new])
+        st = m.UpdateESDF()
+        assert st["bulk"] == 1 and st["nn_incremental"] == 1, st
+        assert st["nn_dirty_cells"] > 5000, st
+        check_exact(m, shape)
+    m.close()
