@@ -979,6 +979,8 @@ def main():
         engine_steps["masked"] = sum(int(s.get("masked", 0)) for s in timed)
         engine_steps["cells_incremental"] = sum(int(s.get("nn_incremental", 0)) for s in timed)
         engine_steps["cells_served_by_brute_force_per_update"] = statistics.mean(int(s.get("nn_brute_cells", 0)) for s in timed)
+        # why the updates took the path they took (fiesta_hip_stats.path_notes): note -> timed steps that carried it
+        engine_steps["path_notes"] = {w: sum(1 for s in timed if w in s.get("why", ())) for w in sorted({w for s in timed for w in s.get("why", ())})}
         if n_bulk == len(timed) and 0 < n_cells < len(timed):
             # a mix of the two transforms (a cell transform that met a cell it could not serve hands that update -- and the next
             # few eligible ones -- to the envelope passes): the phases below describe the majority, the counts say so

@@ -37,12 +37,18 @@ class Stats(C.Structure):
                 ("cells", C.c_int64), ("nn_cells_ms", C.c_double), ("nn_lists_ms", C.c_double), ("nn_fill_ms", C.c_double),
                 ("nn_entries", C.c_int64), ("nn_failed", C.c_int64),
                 ("nn_incremental", C.c_int64), ("nn_dirty_cells", C.c_int64), ("nn_brute_cells", C.c_int64), ("masked", C.c_int64), ("mask_uncertified", C.c_int64), ("mask_iterations", C.c_int64), ("mask_walks", C.c_int64), ("mask_quads", C.c_int64),
-                ("mask_certify_ms", C.c_double), ("mask_repair_ms", C.c_double)]
+                ("mask_certify_ms", C.c_double), ("mask_repair_ms", C.c_double), ("path_notes", C.c_int64)]
+
+    # fiesta_hip_stats.path_notes (include/fiesta_hip.h: FIESTA_HIP_NOTE_*): why an update took the path it took
+    NOTES = ("partly_observed", "partial_window", "window_history", "late_observation", "first_wave_pending", "density",
+             "cells_backoff", "cells_failed", "incremental_redone", "small_delta", "masked_gave_up", "levels_gave_up", "sharded",
+             "id_wrap", "engine_pinned")
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["prof"] = list(self.prof)
         d["ft_overflow"] = list(self.ft_overflow)
+        d["why"] = [name for bit, name in enumerate(self.NOTES) if (self.path_notes >> bit) & 1]
         return d
 
 

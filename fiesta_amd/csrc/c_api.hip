@@ -324,10 +324,12 @@ int fiesta_hip_update_occupancy(fiesta_hip_map *m, int32_t global_map, int64_t *
 int fiesta_hip_update_esdf(fiesta_hip_map *m, fiesta_hip_stats *stats) {
   return guarded([&] {
     need(m != nullptr, "null map handle");
-    if (m->dense)
+    if (m->dense) {
       m->dense->update_esdf(stats);
-    else
+      if (stats) stats->path_notes = (int64_t)m->dense->path_notes();
+    } else {
       m->hash->update_esdf(stats);
+    }
   });
 }
 

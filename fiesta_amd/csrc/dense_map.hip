@@ -1520,15 +1520,22 @@ bool DenseMap::cells_wanted() {
   const long long nocc = (long long)h_counters_[C_NOCC];
   // (measured with the cells that get no list served one by one, profiles/r06_density_range.json: 7.5e-5 -- 0.36 against 0.57 ms on
   //  the envelope passes; 5.2e-5 -- two cells scan every site, 0.89 against 0.56; 2.5e-3 -- 0.74 against 0.98; 3.7e-3 -- 1.14 against 1.04)
-  if (nocc * 15000 < g.n || nocc * 400 > g.n) return false;
+  if (nocc * 15000 < g.n || nocc * 400 > g.n) {
+    notes_ |= FIESTA_HIP_NOTE_DENSITY;
+    return false;
+  }
   // a failed attempt (a cell without a list: ~0.2 ms lost before the envelope passes take over) is not repeated at once: the
   // next 8, 16, ... 256 eligible updates go straight to the envelope passes, then it is tried again -- a scene that cannot be
   // served costs 1 % in the long run, one unlucky cell in a scene that can does not switch the transform off for good
   if (nn_skip_ > 0) {
     --nn_skip_;
+    notes_ |= FIESTA_HIP_NOTE_CELLS_BACKOFF;
     return false;
   }
-  if (nn_last_ms_ > 0 && ft_last_ms_ > 0 && nn_last_ms_ > ft_last_ms_ && std::llabs(nocc - nn_last_nocc_) * 4 <= nn_last_nocc_) return false;
+  if (nn_last_ms_ > 0 && ft_last_ms_ > 0 && nn_last_ms_ > ft_last_ms_ && std::llabs(nocc - nn_last_nocc_) * 4 <= nn_last_nocc_) {
+    notes_ |= FIESTA_HIP_NOTE_CELLS_BACKOFF;
+    return false;
+  }
   return true;
 }
 
@@ -1711,6 +1718,7 @@ bool DenseMap::bulk_eligible(unsigned long long ni, unsigned long long nd) {
     const long long before = (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd;
     if (read_counter(C_SCRATCH) == 0 || (!g.sharded && before <= 0)) stale_inf_ = false;
   }
+  if (stale_inf_) notes_ |= FIESTA_HIP_NOTE_FIRST_WAVE_PENDING;
   return !stale_inf_;
 }
 
@@ -1741,6 +1749,7 @@ bool DenseMap::masked_eligible(unsigned long long ni, unsigned long long nd) {
     FIESTA_HIP_CHECK(hipGetLastError());
     h_counters_[C_LATE] = late = read_counter(C_LATE);
   }
+  if (late != 0) notes_ |= FIESTA_HIP_NOTE_LATE_OBSERVATION;
   return late == 0;
 }
 
@@ -2185,6 +2194,7 @@ bool DenseMap::run_levels(fiesta_hip_stats *st, unsigned long long ni, unsigned 
 
 void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESDF (src/ESDFMap.cpp:273-398)
   use_device();
+  notes_ = 0;
   const bool nn_was_clean = nn_clean_;  // (only a cell transform that reports for itself sets it again: bulk_finish)
   nn_clean_ = false;
   const bool nn_was_valid = nn_valid_;  // (set again by a cell transform that succeeds on the map's own field)
@@ -2215,11 +2225,19 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   ++epoch_;
   TileGrid tg{tx_, ty_, ntx_, nty_, ntz_};
   FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
+  {  // why this update will take the path it takes (fiesta_hip_stats.path_notes): the standing conditions here, the rest as they bite
+    const long long owned = (long long)(g_.ox1 - g_.ox0 + 1) * (g_.oy1 - g_.oy0 + 1) * (g_.oz1 - g_.oz0 + 1);
+    if ((long long)h_counters_[C_OBSERVED] != owned) notes_ |= FIESTA_HIP_NOTE_PARTLY_OBSERVED;
+    if (g_.sharded) notes_ |= FIESTA_HIP_NOTE_SHARDED;
+    if (g_.wrap) notes_ |= FIESTA_HIP_NOTE_ID_WRAP;
+    if (update_engine_ != 0) notes_ |= FIESTA_HIP_NOTE_ENGINE_PINNED;
+  }
   const bool full_window = g_.wx0 <= 0 && g_.wy0 <= 0 && g_.wz0 <= 0 && g_.wx1 >= g_.nx - 1 && g_.wy1 >= g_.ny - 1 && g_.wz1 >= g_.nz - 1;
   // (a map that held no obstacle before this update has no history: cleared BEFORE this update's own window is recorded --
   //  the first obstacles inserted under a partial window on an empty map must leave the flag set)
   if (win_dirty_ && !g_.sharded && (long long)h_counters_[C_NOCC] - (long long)ni + (long long)nd <= 0) win_dirty_ = false;
-  if (!full_window) win_dirty_ = true;  // (see bulk_eligible)
+  if (!full_window) win_dirty_ = true, notes_ |= FIESTA_HIP_NOTE_PARTIAL_WINDOW;  // (see bulk_eligible)
+  else if (win_dirty_) notes_ |= FIESTA_HIP_NOTE_WINDOW_HISTORY;
   // Engine choice.  The bulk transform costs one fixed sweep over the grid; the frontier rounds cost in proportion to
   // the voxels whose closest obstacle changes, roughly (inserts + deletes) x (grid / occupied voxels).  The level engine
   // (level_kernels.hpp) takes every update of a few thousand voxels -- a sensor frame -- that the transform does not, and,
@@ -2233,6 +2251,10 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
   const bool try_levels = !seed_only && !g_.sharded && !g_.wrap && update_engine_ != 1 &&
                           (update_engine_ == 3 || (!gate_open && ni + nd <= (unsigned long long)small_update_ && ni <= (unsigned long long)LevelEngine::kInsertCap));
   const bool try_bulk = gate_open && (bulk_pinned() || bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n));
+  if (gate_open && !try_bulk) notes_ |= FIESTA_HIP_NOTE_SMALL_DELTA;
+  if (!gate_open && !seed_only && (long long)h_counters_[C_OBSERVED] < g_.n && !bulk_pinned() &&
+      !bulk_pays((double)(ni + nd), (double)(long long)h_counters_[C_NOCC], (double)g_.n))
+    notes_ |= FIESTA_HIP_NOTE_SMALL_DELTA;
   bool counters_reset = false;
   // A partially observed map (every map a sensor builds): a delta too large for the level engine goes to the masked transform
   // (mask_kernels.hpp) where the map's history allows it -- a fixed sweep like the other transforms -- instead of the rounds.
@@ -2243,6 +2265,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
     reset_stats_counters(/*lists=*/true);
     counters_reset = true;
     if (run_masked(st, h0)) return;
+    notes_ |= FIESTA_HIP_NOTE_MASKED_GAVE_UP;
     if (st) {
       const fiesta_hip_stats keep = *st;
       memset(st, 0, sizeof(*st));
@@ -2279,6 +2302,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
         return;
       }
       // more dirty cells than the list holds, or a cell that lost its last obstacle in reach: the full transform, from scratch
+      notes_ |= FIESTA_HIP_NOTE_INCREMENTAL_REDONE;
       FIESTA_HIP_CHECK(hipMemsetAsync(nn_dirty_flag_.p, 0, nn_dirty_flag_.cap * sizeof(uint32_t), stream_));
       if (st) memset(&st->cells, 0, sizeof(st->cells)), st->nn_incremental = 0;
       FIESTA_HIP_CHECK(hipEventRecord(ev0_, stream_));
@@ -2293,6 +2317,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
       }
       nn_fail_streak_ = std::min(nn_fail_streak_ + 1, 6);
       nn_skip_ = 4 << nn_fail_streak_;
+      notes_ |= FIESTA_HIP_NOTE_CELLS_FAILED;
       const int64_t failed = (int64_t)h_counters_[C_NN_FAILED];
       if (st) {
         memset(&st->cells, 0, sizeof(st->cells));
@@ -2318,6 +2343,7 @@ void DenseMap::update_esdf(fiesta_hip_stats *st, bool seed_only) {  // UpdateESD
       return;
     }
     levels_fell_back = true;
+    notes_ |= FIESTA_HIP_NOTE_LEVELS_GAVE_UP;
     zero_counters(C_INVALIDATED, C_COUNT - C_INVALIDATED);  // (the tile list is set up: its counters stay)
   } else if (!counters_reset) {
     reset_stats_counters(/*lists=*/true);

@@ -116,6 +116,7 @@ class DenseMap {
   bool check_update();
   bool update_occupancy(bool global_map, int64_t *n_ins, int64_t *n_del);
   void update_esdf(fiesta_hip_stats *st, bool seed_only = false);
+  uint32_t path_notes() const { return notes_; }  // FIESTA_HIP_NOTE_* of the last update_esdf
   // the bulk transform, step by step, for the sharded driver (shard_group.hip): probe = queue sizes + local eligibility,
   // try = transform with a margin around the shard (false: region too large), commit = consume the queues
   void bulk_probe(unsigned long long *ni, unsigned long long *nd, long long *nocc, bool *eligible);
@@ -266,6 +267,7 @@ class DenseMap {
   DevBuf<uint8_t> cellobs_, celldist_;
   unsigned long long *mask_ctr_ = nullptr, *h_mask_ctr_ = nullptr;
   uint32_t mask_serial_ = 0;   // tags of the repair iterations (stamps are never cleared)
+  uint32_t notes_ = 0;  // FIESTA_HIP_NOTE_* of the current / last update_esdf (fiesta_hip_stats.path_notes)
   long long mask_obs_count_ = -1;  // observed voxels when the cells' summaries (cellobs_ ... cellst_) were built; -1: rebuild
   size_t mask_seg_cap_ = 0;    // entries per segment of the walk list (doubles when a scene needs more)
   int mask_chain_hint_ = 10;   // repair iterations launched before the first read-back (the last update's count + 2)

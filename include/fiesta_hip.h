@@ -106,7 +106,27 @@ typedef struct fiesta_hip_stats {
   int64_t mask_uncertified, mask_iterations, mask_walks, mask_quads; /* masked: voxels under repair, repair iterations, segment
                                                                         walks, quads (8 x 8 x 32 voxels) under repair */
   double mask_certify_ms, mask_repair_ms;               /* masked: HIP-event time of k_mask_certify / of the repair launches */
+  int64_t path_notes;    /* dense-array maps: WHY this update took the path it took -- FIESTA_HIP_NOTE_* bits (0: nothing stood in the
+                            way of the exact transform, or there was nothing to do) */
 } fiesta_hip_stats;
+
+/* fiesta_hip_stats.path_notes: the gates and back-offs that decided an UpdateESDF's engine (each is a place where the latency of a
+   call changes by a factor; `bulk`, `cells`, `masked`, `levels`, `rounds` say WHAT ran, these say why) */
+#define FIESTA_HIP_NOTE_PARTLY_OBSERVED 0x0001    /* voxels never observed: the exact transforms are gated (src/ESDFMap.cpp:345,382) */
+#define FIESTA_HIP_NOTE_PARTIAL_WINDOW 0x0002     /* the update window is not the whole array (SetUpdateRange) */
+#define FIESTA_HIP_NOTE_WINDOW_HISTORY 0x0004     /* an earlier update ran under a partial window: the field depends on that history */
+#define FIESTA_HIP_NOTE_LATE_OBSERVATION 0x0008   /* voxels first observed free while obstacles stood still wait for a wave (:246-249) */
+#define FIESTA_HIP_NOTE_FIRST_WAVE_PENDING 0x0010 /* ... the same on a fully observed map: the exact transform waits for them too */
+#define FIESTA_HIP_NOTE_DENSITY 0x0020            /* obstacle density outside the cell transform's range: envelope passes */
+#define FIESTA_HIP_NOTE_CELLS_BACKOFF 0x0040      /* the cell transform failed or lost recently and is not retried yet */
+#define FIESTA_HIP_NOTE_CELLS_FAILED 0x0080       /* the cell transform was tried, a cell got no list: the envelope passes served the update */
+#define FIESTA_HIP_NOTE_INCREMENTAL_REDONE 0x0100 /* the incremental cell transform failed and the same call ran it in full */
+#define FIESTA_HIP_NOTE_SMALL_DELTA 0x0200        /* too few changes for a whole-grid transform to pay: level engine / rounds */
+#define FIESTA_HIP_NOTE_MASKED_GAVE_UP 0x0400     /* the masked transform gave the update back (lists or repair outgrew their buffers) */
+#define FIESTA_HIP_NOTE_LEVELS_GAVE_UP 0x0800     /* the level engine handed the update on to the rounds */
+#define FIESTA_HIP_NOTE_SHARDED 0x1000            /* a shard of a larger map: level engine and masked transform excluded */
+#define FIESTA_HIP_NOTE_ID_WRAP 0x2000            /* an extent beyond 1024 voxels: ids wrap, masked transform and incremental lists excluded */
+#define FIESTA_HIP_NOTE_ENGINE_PINNED 0x4000      /* update_engine is not "auto" */
 
 const char *fiesta_hip_last_error(void);
 int fiesta_hip_version(void);
