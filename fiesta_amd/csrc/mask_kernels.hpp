@@ -202,6 +202,11 @@ __device__ __forceinline__ uint32_t cell_state(const MaskArgs &a, const CellView
 #else
 #define PROBE_ADD(K, N)
 #endif
+// (the reference's stencil has no (1, 1, 1) step, src/ESDFMap.cpp:33-60: where two consecutive samples differ along all three axes
+//  an id crosses in two hops, through one of the six voxels between them -- one of those has to be observed as well.  On a map
+//  observed through view cones two voxels in 1.5 million were certified across such a diagonal with nothing observed between, and
+//  the repair carried their ids to 630 voxels no run of the reference gives them to, tests/golden/c2_sensor_256_envelope.npz)
+__device__ __forceinline__ bool vox_observed(const MaskArgs &a, const CellView &, int x, int y, int z) { return bit_test(a.obsbits, a.g, x, y, z); }
 __device__ __forceinline__ bool mask_segment_samples(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int sx, int sy, int sz) {
   const int dx = sx - vx, dy = sy - vy, dz = sz - vz;
   const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
@@ -215,18 +220,36 @@ __device__ __forceinline__ bool mask_segment_samples(const MaskArgs &a, const Ce
   int ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
   uint32_t cst = cell_state(a, cv, ccx, ccy, ccz);
   if (cst == 0u || (cst == 2u && !bit_test(a.obsbits, a.g, px, py, pz))) return false;
+  bool diagonals = false;
   for (int i = n - 2; i >= 1; --i) {
     ex -= 2 * ax, ey -= 2 * ay, ez -= 2 * az;
-    bool moved = false;
-    if (ex < 0) ex += n2, px -= ix, moved = true;
-    if (ey < 0) ey += n2, py -= iy, moved = true;
-    if (ez < 0) ez += n2, pz -= iz, moved = true;
-    if (!moved) continue;
+    const bool mvx = ex < 0, mvy = ey < 0, mvz = ez < 0;
+    if (!(mvx || mvy || mvz)) continue;
+    if (mvx) ex += n2, px -= ix;
+    if (mvy) ey += n2, py -= iy;
+    if (mvz) ez += n2, pz -= iz;
     if ((px >> 3) != ccx || (py >> 3) != ccy || (pz >> 3) != ccz) {
       ccx = px >> 3, ccy = py >> 3, ccz = pz >> 3;
       cst = cell_state(a, cv, ccx, ccy, ccz);
     }
     if (cst == 0u || (cst == 2u && !bit_test(a.obsbits, a.g, px, py, pz))) return false;
+    diagonals |= mvx && mvy && mvz;
+  }
+  if (!diagonals) return true;
+  // every sample is observed; the (1, 1, 1)-diagonals between samples in a walk of their own (few segments have one, fewer fail here)
+  ex = n - 2 * ax, ey = n - 2 * ay, ez = n - 2 * az;
+  px = sx, py = sy, pz = sz;
+  for (int i = n - 2; i >= 1; --i) {
+    ex -= 2 * ax, ey -= 2 * ay, ez -= 2 * az;
+    const bool mvx = ex < 0, mvy = ey < 0, mvz = ez < 0;
+    const int qx = px, qy = py, qz = pz;  // (the sample before)
+    if (mvx) ex += n2, px -= ix;
+    if (mvy) ey += n2, py -= iy;
+    if (mvz) ez += n2, pz -= iz;
+    if (mvx && mvy && mvz &&
+        !(vox_observed(a, cv, px, qy, qz) || vox_observed(a, cv, qx, py, qz) || vox_observed(a, cv, qx, qy, pz) ||
+          vox_observed(a, cv, px, py, qz) || vox_observed(a, cv, px, qy, pz) || vox_observed(a, cv, qx, py, pz)))
+      return false;
   }
   return true;
 }
@@ -259,6 +282,22 @@ __device__ __forceinline__ int mask_segment_cells(const MaskArgs &a, const CellV
   for (;;) {
     const int t = min(tx, min(ty, tz));
     if (t == INT_MAX) return 1;  // (every crossing lies at a sample <= n - 1, the winner itself)
+    PROBE_ADD(0, 1);
+    if (tx == t && ty == t && tz == t) {
+      PROBE_ADD(1, 1);
+      // through the corner of a cell: the two samples lie a (1, 1, 1)-diagonal apart and the six voxels between them in the six
+      // other cells around that corner -- one of them has to be observed (any other diagonal step has such a voxel in the cell it
+      // leaves, fully observed here); one walk in a thousand comes this way
+      uint32_t any1 = 0, any2 = 0;
+#pragma unroll
+      for (int h = 1; h < 7; ++h) {  // the six ways to have moved along one or two of the axes
+        // (from the register alone: a corner beyond the 3^3 cells around the voxel is left to the samples)
+        const unsigned ox = (unsigned)(ccx + ((h & 1) ? ix : 0) - cv.cx + 1), oy = (unsigned)(ccy + ((h & 2) ? iy : 0) - cv.cy + 1), oz = (unsigned)(ccz + ((h & 4) ? iz : 0) - cv.cz + 1);
+        const uint32_t st = (ox < 3u && oy < 3u && oz < 3u) ? (uint32_t)(cv.st >> (2u * (ox * 9u + oy * 3u + oz))) & 3u : 2u;
+        any1 |= (uint32_t)(st == 1u), any2 |= (uint32_t)(st == 2u);
+      }
+      if (!any1) return any2 ? 2 : 0;
+    }
     if (tx == t) {
       ccx += ix, kx += 8;
       tx = kx <= ax ? (int)ceil_div_small((uint32_t)(n * (2 * kx - 1)), (uint32_t)(2 * ax)) : INT_MAX;
@@ -277,11 +316,6 @@ __device__ __forceinline__ int mask_segment_cells(const MaskArgs &a, const CellV
   }
 }
 
-__device__ __forceinline__ bool mask_segment_observed(const MaskArgs &a, const CellView &cv, int vx, int vy, int vz, int sx, int sy, int sz) {
-  const int r = mask_segment_cells(a, cv, vx, vy, vz, sx, sy, sz);  // 0 refused, 1 observed, 2 ask the samples
-  return r == 2 ? mask_segment_samples(a, cv, vx, vy, vz, sx, sy, sz) : r != 0;
-}
-
 // The second certificate, for a winner s hidden behind an unobserved voxel: s hands its id to an observed stencil neighbour p --
 // a PORTAL -- and through it to everybody whose way to p is clear.  Only a HIDDEN site has portals (a never-observed voxel among its
 // 26 neighbours); they are found once per update (k_portal_sites) and looked up by the walk.  v keeps T(v) = s if for some stencil direction e (in stencil
@@ -292,7 +326,9 @@ __device__ __forceinline__ bool mask_segment_observed(const MaskArgs &a, const C
 // such a winner; against the envelope of the reference's runs (tests/golden/c2_partial_256_envelope.npz) this certificate takes
 // the voxels closer than every run from 247 / 180 to 0 / 0 -- the straight segment alone repaired those regions by pulls, whose
 // ties fall differently from the reference's arrivals.
-// (walked from the portal's end, where the never-observed voxels are; the words of the samples go out six at a time.  A check of the
+// (walked from the portal's end, where the never-observed voxels are; the words of the samples go out six at a time.  The straight
+//  certificate's rule for (1, 1, 1)-diagonals is not applied here: every sample of this path holds the winner, each got it from
+//  somewhere, and on the fixtures the rule changes nothing here -- tests/golden/c2_sensor_256_envelope.npz -- at +50 % walk time.  A check of the
 //  cells' summaries ahead of the loads would spare a refused path its words -- one path in nine -- at a third more instructions
 //  for every path: the walk kernel is bound by its VALU instructions, not by these loads)
 __device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, int vx, int vy, int vz, int ux, int uy, int uz, vox_t ws) {
@@ -333,8 +369,9 @@ __device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, int vx, int
       }
     }
     if (w[0] != ws || w[1] != ws || w[2] != ws || w[3] != ws || w[4] != ws || w[5] != ws) return false;
-    if (i <= 1) return true;
+    if (i <= 1) break;
   }
+  return true;
 }
 __device__ __forceinline__ uint32_t portal_hash(vox_t w) { return (w * 0x9E3779B1u) ^ (w >> 15); }
 // the stencil's directions by index, from registers: (d + 2) of twelve directions, three bits each, per 64-bit constant
@@ -540,7 +577,10 @@ constexpr int kMaskQueue = 512;  // walks a wave collects before it takes a rang
 // consecutive z); waves are persistent.  Voxels that need the segment walk go to the walk list, through an LDS queue per wave
 // (one atomic on a segment's cursor per flush: returning atomics on one address serialise at tens of ns each).  No load depends
 // on a voxel's word: the cells between a voxel and its winner are judged from the cell's own summaries, held in registers.
-__global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
+#ifndef FIESTA_CLASSIFY_WAVES
+#define FIESTA_CLASSIFY_WAVES 5  /* (96 VGPRs without a spill; 6 spills 14) */
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FIESTA_CLASSIFY_WAVES, FIESTA_CLASSIFY_WAVES))) void k_mask_classify(MaskArgs a) {
   __shared__ uint2 s_queue[4][kMaskQueue];
   __shared__ uint32_t s_qn[4], s_need[27];
   const Geom &g = a.g;
@@ -691,21 +731,24 @@ __global__ __launch_bounds__(256) void k_mask_classify(MaskArgs a) {
   if (lane == 0 && nwalk) atomicAdd(&a.ctr[MC_WALKS], (unsigned long long)nwalk);
 }
 
-// The certificate proper: one lane per queued voxel.  The straight segment first; the voxels it leaves (one in six on config 2's
-// partially observed scene) wait in an LDS queue of the work-group, and the portal certificate runs in ROUNDS over that queue: a
-// round = every lane takes a waiting voxel and tries ONE portal, the nearest it has not tried; a voxel that fails and has
-// candidates left goes back into the queue.  (One lane trying its up to 24 portals in a row: a wave took as long as its
-// unluckiest lane -- a quarter of the waiting voxels end up uncertified, after nine walks on average -- while three quarters
-// are done after one.)
-constexpr int kWalkQueue = 768;
-__global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
-  __shared__ uint32_t s_marked, s_qn;
+// The certificate proper: one lane per queued voxel, three kinds of batches of 256 per work-group.  STRAIGHT: the segment judged from
+// the cells it crosses (mask_segment_cells); the voxels that need the samples -- a partly observed cell on the way, a step through
+// a cell's corner -- wait in an LDS list and are walked sample by sample 256 at a time (SAMPLES), so that the long walk never
+// runs for one lane of a wave.  The voxels the straight segment refuses wait in an LDS queue, and the portal certificate runs in
+// ROUNDS over that queue: a round = every lane takes a waiting voxel and tries ONE portal, the nearest it has not tried; a voxel
+// that fails and has candidates left goes back into the queue.  (One lane trying its up to 24 portals in a row: a wave took as
+// long as its unluckiest lane -- a quarter of the waiting voxels end up uncertified, after nine walks on average -- while three
+// quarters are done after one.)
+constexpr int kWalkQueue = 768, kWalkDeferred = 512;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_walk(MaskArgs a) {
+  __shared__ uint32_t s_marked, s_qn, s_dn;
   __shared__ uint2 s_q[kWalkQueue];
   __shared__ uint32_t s_qm[kWalkQueue];  // candidates left (0xFFFFFFFF: not looked up yet)
+  __shared__ uint2 s_d[kWalkDeferred];   // voxels whose segment the samples have to judge
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;
   if (a.ctr[MC_OVERFLOW]) return;
-  if (threadIdx.x == 0) s_marked = 0, s_qn = 0;
+  if (threadIdx.x == 0) s_marked = 0, s_qn = 0, s_dn = 0;
   unsigned marked = 0;
   // work-group b takes segment b % kMaskSegs, its share of it
   const int seg = (int)(blockIdx.x % kMaskSegs);
@@ -714,24 +757,43 @@ __global__ __launch_bounds__(256) void k_mask_walk(MaskArgs a) {
   uint32_t i0 = part * blockDim.x;
   for (;;) {
     __syncthreads();
-    const uint32_t qn = s_qn;
-    if (qn < 256u && i0 < n) {  // (uniform) another 256 straight walks
-      const uint32_t i = i0 + threadIdx.x;
-      i0 += parts * blockDim.x;
-      __syncthreads();  // (s_qn is read by everybody before anybody adds to it)
-      if (i < n) {
-        const uint2 e = a.walks[(size_t)seg * a.seg_cap + i];
+    const uint32_t qn = s_qn, dn = s_dn;
+    __syncthreads();  // (both counts are read by everybody before anybody adds to them)
+    if (qn < 256u && (dn >= 256u || (dn > 0u && i0 >= n))) {  // (uniform) SAMPLES: up to 256 deferred voxels
+      const uint32_t take = min(dn, 256u);
+      uint2 e{0u, 0u};
+      if (threadIdx.x < take) e = s_d[dn - take + threadIdx.x];
+      __syncthreads();
+      if (threadIdx.x == 0) s_dn = dn - take;
+      if (threadIdx.x < take) {
         const int vx = (int)(e.x >> 20), vy = (int)((e.x >> 10) & 1023u), vz = (int)(e.x & 1023u);
         const int sx = (int)((e.y >> 20) & 1023u) - g.gx0, sy = (int)((e.y >> 10) & 1023u) - g.gy0, sz = (int)(e.y & 1023u) - g.gz0;
-        if (!mask_segment_observed(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx, sy, sz)) {
+        if (!mask_segment_samples(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx, sy, sz)) {
           const uint32_t at = atomicAdd(&s_qn, 1u);  // (at most 255 + 256 waiting)
           s_q[at] = e, s_qm[at] = 0xFFFFFFFFu;
         }
       }
       continue;
     }
-    if (qn == 0u) break;  // (uniform: the list is exhausted too)
-    const uint32_t take = min(qn, 256u);
+    if (qn < 256u && i0 < n) {  // (uniform) STRAIGHT: another 256 voxels of the list
+      const uint32_t i = i0 + threadIdx.x;
+      i0 += parts * blockDim.x;
+      if (i < n) {
+        const uint2 e = a.walks[(size_t)seg * a.seg_cap + i];
+        const int vx = (int)(e.x >> 20), vy = (int)((e.x >> 10) & 1023u), vz = (int)(e.x & 1023u);
+        const int sx = (int)((e.y >> 20) & 1023u) - g.gx0, sy = (int)((e.y >> 10) & 1023u) - g.gy0, sz = (int)(e.y & 1023u) - g.gz0;
+        const int r = mask_segment_cells(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx, sy, sz);  // 0 refused, 1 observed, 2 ask the samples
+        if (r == 0) {
+          const uint32_t at = atomicAdd(&s_qn, 1u);  // (at most 255 + 256 waiting)
+          s_q[at] = e, s_qm[at] = 0xFFFFFFFFu;
+        } else if (r == 2) {
+          s_d[atomicAdd(&s_dn, 1u)] = e;  // (at most 255 + 256 deferred)
+        }
+      }
+      continue;
+    }
+    if (qn == 0u) break;  // (uniform: the list is exhausted and nothing is deferred)
+    const uint32_t take = min(qn, 256u);  // a ROUND of the portal certificate
     uint2 e{0u, 0u};
     uint32_t cand = 0;
     if (threadIdx.x < take) e = s_q[qn - take + threadIdx.x], cand = s_qm[qn - take + threadIdx.x];

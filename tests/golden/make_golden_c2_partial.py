@@ -16,7 +16,10 @@ obstacles replaced in ONE UpdateESDF):
     <cp>/occ_crc, obs_crc, n_occ, n_obs, finite    CRC32 of the packed occupancy / observed bitmaps (identical in every run), counts
     <cp>/model_idx, model_d2      (with --model) the voxels where the numpy model of the masked transform differs from T, and its value
 
-    python tests/golden/make_golden_c2_partial.py --grid 256 [--runs 4] [--model]
+    python tests/golden/make_golden_c2_partial.py --grid 256 [--runs 4] [--model] [--pattern sensor]
+
+--pattern sensor: the same workload on a map observed through a handful of view cones (c2_sensor_<grid>_envelope.npz): the boundary
+of the observed space cuts cells and bitmap words, which the block pattern never does.
 
 Needs /root/reference (build container only); at 512^3 7.4 GB and ~3 min per run (the runs go side by side: --jobs).
 """
@@ -48,7 +51,7 @@ def d2_of(dist, res):
 
 def one_run(args):
     """One run of the verbatim reference; run 0 in bench.py's order, run r > 0 with every batch shuffled (seed r)."""
-    G, r, tmp = args
+    G, r, tmp, pattern = args
     from oracle import pyoracle
     import bench
     res = 0.1
@@ -58,14 +61,22 @@ def one_run(args):
     assert m.grid_total_size == G ** 3
     m.SetParameters(*P_DEFAULT)
     m.SetOriginalRange()
-    keep = np.random.RandomState(2718).rand(G // 32, G // 32, G // 32) >= UNOBSERVED
-    blocks = np.argwhere(keep)
-    if r:
-        blocks = blocks[rng.permutation(len(blocks))]
-    cube = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(32), indexing="ij"), -1).reshape(-1, 3)
-    for s in range(0, len(blocks), 64):   # the prologue, block by block as bench.py observes it (SetOccupancyBox per block)
-        v = (blocks[s:s + 64, None, :] * 32 + cube[None]).reshape(-1, 3).astype(np.int32)
-        m.SetOccupancyVox(shuf(v), 0)
+    if pattern == "sensor":   # a sensor-shaped observed set (tests/masked_model.py: sensor_mask), voxel by voxel
+        import masked_model
+        v = np.argwhere(masked_model.sensor_mask(G)).astype(np.int32)
+        if r:
+            v = v[rng.permutation(len(v))]
+        for s in range(0, len(v), 1 << 21):
+            m.SetOccupancyVox(v[s:s + (1 << 21)], 0)
+    else:
+        keep = np.random.RandomState(2718).rand(G // 32, G // 32, G // 32) >= UNOBSERVED
+        blocks = np.argwhere(keep)
+        if r:
+            blocks = blocks[rng.permutation(len(blocks))]
+        cube = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(32), indexing="ij"), -1).reshape(-1, 3)
+        for s in range(0, len(blocks), 64):   # the prologue, block by block as bench.py observes it (SetOccupancyBox per block)
+            v = (blocks[s:s + 64, None, :] * 32 + cube[None]).reshape(-1, 3).astype(np.int32)
+            m.SetOccupancyVox(shuf(v), 0)
     m.UpdateOccupancy(True)
     m.UpdateESDF()
     n_obs = max(2, int(round(50000 * (G / 512.0) ** 3)))
@@ -110,12 +121,14 @@ def main():
     ap.add_argument("--tmp", default="/tmp/c2_partial")
     ap.add_argument("--model", action="store_true", help="also store the numpy model's field (tests/masked_model.py)")
     ap.add_argument("--reuse", action="store_true", help="use the runs' dumps already in --tmp")
+    ap.add_argument("--pattern", default="blocks", choices=["blocks", "sensor"],
+                    help="the never-observed space: bench.py's 32^3 blocks, or outside a union of view cones (masked_model.sensor_mask)")
     a = ap.parse_args()
     G = a.grid
     os.makedirs(a.tmp, exist_ok=True)
     if not a.reuse:
         with mp.get_context("spawn").Pool(a.jobs) as pool:
-            info = pool.map(one_run, [(G, r, a.tmp) for r in range(a.runs)])
+            info = pool.map(one_run, [(G, r, a.tmp, a.pattern) for r in range(a.runs)])
         print(info, flush=True)
     import masked_model
     from scipy import ndimage
@@ -159,7 +172,8 @@ def main():
             out[f"{cp}/model_idx"] = mi.astype(np.uint32)
             out[f"{cp}/model_d2"] = d2m[mi]
             print(cp, "model", st, "closer", int((d2m < lo).sum()), "farther", int((d2m > hi).sum()), f"{time.time() - t0:.0f} s", flush=True)
-    path = os.path.join(HERE, f"c2_partial_{G}_envelope.npz")
+    out["pattern"] = np.array(a.pattern)
+    path = os.path.join(HERE, f"c2_{'partial' if a.pattern == 'blocks' else a.pattern}_{G}_envelope.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path))
 

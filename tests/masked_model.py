@@ -17,21 +17,53 @@ from scipy import ndimage
 from scenarios import D2_INF, DIRS24
 
 BLOCK_SUBITERS = 6   # cell-local Jacobi steps per global iteration (mask_kernels.hpp: kMaskSub); 1 = plain Jacobi
+def sensor_mask(G, poses=6, seed=31415):
+    """A sensor-shaped observed set for the parity fixtures (tests/golden/make_golden_c2_partial.py --pattern sensor): the union of
+    `poses` view cones -- apex and axis random, half-angle 33 degrees, range 0.62 G -- so that the boundary of the observed space
+    cuts through cells and words everywhere (the 32^3-block pattern of bench.py --unobserved never does)."""
+    rng = np.random.RandomState(seed)
+    ax = np.arange(G, dtype=np.float32)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    obs = np.zeros((G, G, G), bool)
+    for _ in range(poses):
+        apex = rng.uniform(0.15 * G, 0.85 * G, 3).astype(np.float32)
+        d = rng.normal(size=3)
+        d = (d / np.linalg.norm(d)).astype(np.float32)
+        rx, ry, rz = X - apex[0], Y - apex[1], Z - apex[2]
+        along = rx * d[0] + ry * d[1] + rz * d[2]
+        r2 = rx * rx + ry * ry + rz * rz
+        obs |= (along > 0) & (along * along >= np.float32(np.cos(np.deg2rad(33.0)) ** 2) * r2) & (r2 <= np.float32((0.62 * G) ** 2))
+    return obs
+
+
+# the six voxels between two voxels a (1, 1, 1)-diagonal apart, as choices of the axes that have already moved
+HALFWAY = np.array([(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1)])
+
+
 def certificate(obs, V, S):
     """V, S: (m, 3) voxels and their winners.  True where every sample of the discrete segment is observed: n = 2 max|d| + 1
-    steps, sample i at v + round(d i / n), i = 1 .. n - 1 (mask_kernels.hpp: mask_segment_observed)."""
+    steps, sample i at v + round(d i / n), i = 1 .. n - 1 (mask_kernels.hpp: mask_segment_observed) -- and where two consecutive
+    samples differ along ALL THREE axes, one of the six voxels between them is observed as well: the stencil the reference
+    propagates along (24 directions, src/ESDFMap.cpp:33-60) has no (1, 1, 1) step, an id crosses such a diagonal in two hops."""
     d = (S - V).astype(np.int64)
     n = 2 * np.abs(d).max(1) + 1
     cert = np.ones(len(V), bool)
-    for i in range(1, int(n.max())):
-        act = cert & (i < n)
+    prev = V.astype(np.int64).copy()
+    for i in range(1, int(n.max()) + 1):
+        act = cert & (i <= n)   # (sample n is the winner itself: the last step may be a diagonal too)
         if not act.any():
             break
         ai = np.flatnonzero(act)
         na = n[act][:, None]
         p = V[act] + (2 * d[act] * i + na) // (2 * na)
         ok = obs[p[:, 0], p[:, 1], p[:, 2]]
+        step = p - prev[act]
+        tri = np.flatnonzero(ok & (step != 0).all(1))
+        if len(tri):
+            q = prev[act][tri][:, None, :] + HALFWAY[None] * step[tri][:, None, :]
+            ok[tri] = obs[q[..., 0], q[..., 1], q[..., 2]].any(1)
         cert[ai[~ok]] = False
+        prev[act] = p
     return cert
 
 
@@ -56,6 +88,10 @@ def certificate_by_cells(cellobs, V, S):
             if tm == INF:
                 break
             assert tm <= n - 1
+            if t[0] == tm and t[1] == tm and t[2] == tm:   # through a cell's corner: one of the six other cells around it observed
+                if not any(cellobs[c[0] + sg[0] * h[0], c[1] + sg[1] * h[1], c[2] + sg[2] * h[2]] for h in HALFWAY):
+                    out[j] = False
+                    break
             for x in range(3):
                 if t[x] == tm:
                     c[x] += sg[x]
@@ -71,7 +107,8 @@ RING = {k: np.array([(x, y, z) for x in range(-2, 3) for y in range(-2, 3) for z
 
 
 def path_in_cell(occ, obs, idx, V, P, S):
-    """every sample of the discrete segment V -> P observed, free, and with S as its own winner"""
+    """every sample of the discrete segment V -> P observed, free, and with S as its own winner (the rule for (1, 1, 1)-diagonals of
+    `certificate` is not applied: every sample here holds the winner -- it changes nothing on the fixtures and costs the GPU walk +50 %)"""
     d = (P - V).astype(np.int64)
     n = 2 * np.abs(d).max(1) + 1
     ok = np.ones(len(V), bool)

@@ -84,14 +84,16 @@ def test_masked_equals_its_model_and_stays_inside_the_reference_envelope(hip_lib
     env.close()
 
 
-@pytest.mark.parametrize("G", [256, 512])
-def test_masked_c2_partial_against_the_committed_envelope(hip_lib, G):
+@pytest.mark.parametrize("pattern,G", [("partial", 256), ("partial", 512), ("sensor", 256)])
+def test_masked_c2_partial_against_the_committed_envelope(hip_lib, pattern, G):
     """The benchmark's own inputs (bench.py --unobserved 0.27) at 256^3 and at the FULL 512^3, against the envelope of the verbatim
-    reference's runs on them (tests/golden/make_golden_c2_partial.py): every voxel of both checkpoints."""
+    reference's runs on them (tests/golden/make_golden_c2_partial.py): every voxel of both checkpoints.  "sensor": the same
+    workload on a map observed through six view cones (masked_model.sensor_mask) -- a ragged frontier, a tenth of the cells partly
+    observed: the sample walks and the bit tests of the certificate, which the block pattern never reaches."""
     import fiesta_amd
     import masked_model
     from scipy import ndimage
-    path = os.path.join(GOLD, f"c2_partial_{G}_envelope.npz")
+    path = os.path.join(GOLD, f"c2_{pattern}_{G}_envelope.npz")
     if not os.path.exists(path):
         pytest.skip(f"{path} not generated")
     gold = np.load(path)
@@ -99,7 +101,13 @@ def test_masked_c2_partial_against_the_committed_envelope(hip_lib, G):
     gpu = fiesta_amd.ESDFMap((0, 0, 0), res, ((G - 0.5) * res,) * 3, update_engine="masked")
     gpu.SetParameters(*P_DEFAULT)
     gpu.SetOriginalRange()
-    observe_blocks(gpu, blocks_kept(G))
+    if pattern == "sensor":
+        v = np.argwhere(masked_model.sensor_mask(G)).astype(np.int32)
+        for k in range(0, len(v), 1 << 21):
+            gpu.SetOccupancy(v[k:k + (1 << 21)], 0, want_ret=False)
+        del v
+    else:
+        observe_blocks(gpu, blocks_kept(G))
     gpu.UpdateOccupancy(True)
     gpu.UpdateESDF()
     w = workload(G)
@@ -142,7 +150,7 @@ def test_masked_c2_partial_against_the_committed_envelope(hip_lib, G):
                "outside": closer + farther, "leave_one_out": gold[f"{cp}/leave_one_out"].tolist(),
                "inf_where_every_run_is_finite": int(((g == D2_INF) & (hi < D2_INF) & (hi >= 0)).sum()),
                "mask_uncertified": st["mask_uncertified"], "mask_iterations": st["mask_iterations"]}
-        _log_envelope(dict(env, strict=False, contract=f"max(disagree, {MASKED_ALLOW} x finite)"), f"masked transform, C2-partial {G}^3, {cp}")
+        _log_envelope(dict(env, strict=False, contract=f"max(disagree, {MASKED_ALLOW} x finite)"), f"masked transform, C2-{pattern} {G}^3, {cp}")
         allow = max(disagree, MASKED_ALLOW * finite)
         assert closer <= allow and farther <= allow, env
         assert env["inf_where_every_run_is_finite"] <= allow, env
@@ -152,7 +160,7 @@ def test_masked_c2_partial_against_the_committed_envelope(hip_lib, G):
             # (equal voxel for voxel up to 256^3; at 512^3 a few voxels per million differ: where two sites tie for nearest the
             # model walks its certificate towards scipy's winner and the GPU towards the cell transform's -- TWIN_ALLOW bounds that)
             diff = int((g != m).sum())
-            print(f"masked transform, C2-partial {G}^3, {cp}: GPU vs numpy model: {diff} voxels differ")
+            print(f"masked transform, C2-{pattern} {G}^3, {cp}: GPU vs numpy model: {diff} voxels differ")
             assert diff <= (0 if G <= 256 else TWIN_ALLOW * finite), f"{cp}: the GPU field differs from its model on {diff} voxels"
     gpu.close()
 
