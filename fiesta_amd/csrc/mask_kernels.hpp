@@ -331,12 +331,12 @@ __device__ __forceinline__ int mask_segment_cells(const MaskArgs &a, const CellV
 //  somewhere, and on the fixtures the rule changes nothing here -- tests/golden/c2_sensor_256_envelope.npz -- at +50 % walk time.  A check of the
 //  cells' summaries ahead of the loads would spare a refused path its words -- one path in nine -- at a third more instructions
 //  for every path: the walk kernel is bound by its VALU instructions, not by these loads)
-__device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, int vx, int vy, int vz, int ux, int uy, int uz, vox_t ws) {
+__device__ __forceinline__ int mask_path_in_cell(const MaskArgs &a, int vx, int vy, int vz, int ux, int uy, int uz, vox_t ws) {  // 0 no, 1 yes, 2 yes if its diagonals hold
   const Geom &g = a.g;
   const int dx = ux - vx, dy = uy - vy, dz = uz - vz;
   const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
   const int m = max(ax, max(ay, az)), n = 2 * m + 1, n2 = 2 * n;
-  if (m == 0) return true;
+  if (m == 0) return 1;
   const int ix = dx < 0 ? -1 : 1, iy = dy < 0 ? -1 : 1, iz = dz < 0 ? -1 : 1;
   int ex = n - 2 * ax, ey = n - 2 * ay, ez = n - 2 * az;  // sample n - 1 is the portal itself (see mask_segment_samples)
   // the walk only needs the sample's WORD: its linear index moves by a stride when an axis steps (no axis of such a map exceeds
@@ -345,6 +345,7 @@ __device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, int vx, int
   int pidx = (ux * g.ny + uy) * g.nz + uz;
   int i = n - 1;     // the sample pidx is
   bool pend = true;  // ... and it has not been looked at yet
+  int diagonals = 0;
   PROBE_ADD(2, 1);
   for (;;) {
     uint32_t w[6];
@@ -359,6 +360,7 @@ __device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, int vx, int
           const int mx = ex >> 31, my = ey >> 31, mz = ez >> 31;  // (all ones where the axis steps)
           ex += mx & n2, ey += my & n2, ez += mz & n2;
           pidx -= (mx & stx) + (my & sty) + (mz & stz);
+          diagonals |= mx & my & mz;
           pend = (mx | my | mz) != 0;
         }
       if (pend) {
@@ -368,8 +370,33 @@ __device__ __forceinline__ bool mask_path_in_cell(const MaskArgs &a, int vx, int
         pend = false;
       }
     }
-    if (w[0] != ws || w[1] != ws || w[2] != ws || w[3] != ws || w[4] != ws || w[5] != ws) return false;
-    if (i <= 1) break;
+    if (w[0] != ws || w[1] != ws || w[2] != ws || w[3] != ws || w[4] != ws || w[5] != ws) return 0;
+    if (i <= 1) return diagonals ? 2 : 1;
+  }
+}
+// The (1, 1, 1)-diagonals of a path whose samples all hold the winner: the reference's stencil has no such step (src/ESDFMap.cpp:33-60),
+// the id crosses one in two hops -- one of the six voxels between the two samples has to hold it too (or be the winner itself).
+// A walk of its own, for the third of the paths that have such a step (on config 2-partial at 512^3 two voxels in 2.8 million were
+// certified across a diagonal nobody relays the id over, and the repair carried it on to 700 more).
+__device__ __forceinline__ bool mask_path_diagonals(const MaskArgs &a, int vx, int vy, int vz, int ux, int uy, int uz, vox_t ws) {
+  const Geom &g = a.g;
+  const int dx = ux - vx, dy = uy - vy, dz = uz - vz;
+  const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+  const int m = max(ax, max(ay, az)), n = 2 * m + 1, n2 = 2 * n;
+  const int ix = dx < 0 ? -1 : 1, iy = dy < 0 ? -1 : 1, iz = dz < 0 ? -1 : 1;
+  int ex = n - 2 * ax, ey = n - 2 * ay, ez = n - 2 * az;
+  const int stx = ix * g.ny * g.nz, sty = iy * g.nz, stz = iz;
+  int pidx = (ux * g.ny + uy) * g.nz + uz;
+  for (int i = n - 2; i >= 1; --i) {
+    ex -= 2 * ax, ey -= 2 * ay, ez -= 2 * az;
+    const int mx = ex >> 31, my = ey >> 31, mz = ez >> 31;
+    ex += mx & n2, ey += my & n2, ez += mz & n2;
+    if (mx & my & mz) {
+      const bool via = (a.out[pidx - stx] & ~kAct) == ws || (a.out[pidx - sty] & ~kAct) == ws || (a.out[pidx - stz] & ~kAct) == ws ||
+                       (a.out[pidx - stx - sty] & ~kAct) == ws || (a.out[pidx - stx - stz] & ~kAct) == ws || (a.out[pidx - sty - stz] & ~kAct) == ws;
+      if (!via) return false;
+    }
+    pidx -= (mx & stx) + (my & sty) + (mz & stz);
   }
   return true;
 }
@@ -739,12 +766,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FIESTA_CLAS
 // that fails and has candidates left goes back into the queue.  (One lane trying its up to 24 portals in a row: a wave took as
 // long as its unluckiest lane -- a quarter of the waiting voxels end up uncertified, after nine walks on average -- while three
 // quarters are done after one.)
-constexpr int kWalkQueue = 768, kWalkDeferred = 512;
+constexpr int kWalkQueue = 768, kWalkDeferred = 768;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_walk(MaskArgs a) {
   __shared__ uint32_t s_marked, s_qn, s_dn;
   __shared__ uint2 s_q[kWalkQueue];
-  __shared__ uint32_t s_qm[kWalkQueue];  // candidates left (0xFFFFFFFF: not looked up yet)
-  __shared__ uint2 s_d[kWalkDeferred];   // voxels whose segment the samples have to judge
+  __shared__ uint32_t s_qm[kWalkQueue];     // candidates left (0xFFFFFFFF: not looked up yet)
+  __shared__ uint2 s_d[kWalkDeferred];      // voxels put aside for a long walk
+  __shared__ uint32_t s_dm[kWalkDeferred];  // 0xFFFFFFFF: the samples of its segment; else the diagonals of the path to portal (code >> 24), candidates left in the low 24 bits
   const Geom &g = a.g;
   if (a.failed && *a.failed) return;
   if (a.ctr[MC_OVERFLOW]) return;
@@ -759,23 +787,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __syncthreads();
     const uint32_t qn = s_qn, dn = s_dn;
     __syncthreads();  // (both counts are read by everybody before anybody adds to them)
-    if (qn < 256u && (dn >= 256u || (dn > 0u && i0 >= n))) {  // (uniform) SAMPLES: up to 256 deferred voxels
+    // (room: the queue takes at most 256 more where it is below 512, the list where it is below 512 -- both hold 768)
+    if (qn < 512u && (dn >= 256u || (dn > 0u && i0 >= n && qn < 256u))) {  // (uniform) LONG WALKS: up to 256 voxels put aside
       const uint32_t take = min(dn, 256u);
       uint2 e{0u, 0u};
-      if (threadIdx.x < take) e = s_d[dn - take + threadIdx.x];
+      uint32_t code = 0;
+      if (threadIdx.x < take) e = s_d[dn - take + threadIdx.x], code = s_dm[dn - take + threadIdx.x];
       __syncthreads();
       if (threadIdx.x == 0) s_dn = dn - take;
       if (threadIdx.x < take) {
         const int vx = (int)(e.x >> 20), vy = (int)((e.x >> 10) & 1023u), vz = (int)(e.x & 1023u);
         const int sx = (int)((e.y >> 20) & 1023u) - g.gx0, sy = (int)((e.y >> 10) & 1023u) - g.gy0, sz = (int)(e.y & 1023u) - g.gz0;
-        if (!mask_segment_samples(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx, sy, sz)) {
-          const uint32_t at = atomicAdd(&s_qn, 1u);  // (at most 255 + 256 waiting)
-          s_q[at] = e, s_qm[at] = 0xFFFFFFFFu;
+        if (code == 0xFFFFFFFFu) {  // the samples of the straight segment
+          if (!mask_segment_samples(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx, sy, sz)) {
+            const uint32_t at = atomicAdd(&s_qn, 1u);
+            s_q[at] = e, s_qm[at] = 0xFFFFFFFFu;
+          }
+        } else {  // the diagonals of a path that holds the winner on every sample
+          int dx, dy, dz;
+          stencil_dir((int)(code >> 24), dx, dy, dz);
+          if (!mask_path_diagonals(a, vx, vy, vz, sx + dx, sy + dy, sz + dz, e.y & ~kAct)) {
+            const uint32_t cand = code & 0xFFFFFFu;
+            if (cand) {
+              const uint32_t at = atomicAdd(&s_qn, 1u);
+              s_q[at] = e, s_qm[at] = cand;
+            } else {
+              atomicOr(&a.ubits[g.bitword(vx, vy, vz)], 1u << (vz & 31));
+              ++marked;
+            }
+          }
         }
       }
       continue;
     }
-    if (qn < 256u && i0 < n) {  // (uniform) STRAIGHT: another 256 voxels of the list
+    if (qn < 256u && dn < 256u && i0 < n) {  // (uniform) STRAIGHT: another 256 voxels of the list
       const uint32_t i = i0 + threadIdx.x;
       i0 += parts * blockDim.x;
       if (i < n) {
@@ -784,16 +829,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int sx = (int)((e.y >> 20) & 1023u) - g.gx0, sy = (int)((e.y >> 10) & 1023u) - g.gy0, sz = (int)(e.y & 1023u) - g.gz0;
         const int r = mask_segment_cells(a, cell_view(a, vx, vy, vz), vx, vy, vz, sx, sy, sz);  // 0 refused, 1 observed, 2 ask the samples
         if (r == 0) {
-          const uint32_t at = atomicAdd(&s_qn, 1u);  // (at most 255 + 256 waiting)
+          const uint32_t at = atomicAdd(&s_qn, 1u);
           s_q[at] = e, s_qm[at] = 0xFFFFFFFFu;
         } else if (r == 2) {
-          s_d[atomicAdd(&s_dn, 1u)] = e;  // (at most 255 + 256 deferred)
+          const uint32_t at = atomicAdd(&s_dn, 1u);
+          s_d[at] = e, s_dm[at] = 0xFFFFFFFFu;
         }
       }
       continue;
     }
-    if (qn == 0u) break;  // (uniform: the list is exhausted and nothing is deferred)
+    if (qn == 0u) break;  // (uniform: the list is exhausted and nothing is put aside)
     const uint32_t take = min(qn, 256u);  // a ROUND of the portal certificate
+    const bool aside = dn < 512u;         // (uniform) room to put the paths with diagonals aside
     uint2 e{0u, 0u};
     uint32_t cand = 0;
     if (threadIdx.x < take) e = s_q[qn - take + threadIdx.x], cand = s_qm[qn - take + threadIdx.x];
@@ -816,11 +863,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         cand &= ~(1u << bit);
         int dx, dy, dz;
         stencil_dir(bit, dx, dy, dz);
-        certified = mask_path_in_cell(a, vx, vy, vz, sx + dx, sy + dy, sz + dz, ws);
+        const int r = mask_path_in_cell(a, vx, vy, vz, sx + dx, sy + dy, sz + dz, ws);
+        certified = r == 1;
+        if (r == 2) {  // every sample holds the winner: its (1, 1, 1)-diagonals in a batch of their own
+          if (aside) {
+            const uint32_t at = atomicAdd(&s_dn, 1u);
+            s_d[at] = e, s_dm[at] = ((uint32_t)bit << 24) | cand;
+            certified = true;  // (nothing more to do for it in this round)
+          } else {
+            certified = mask_path_diagonals(a, vx, vy, vz, sx + dx, sy + dy, sz + dz, ws);
+          }
+        }
       }
       if (certified) PROBE_ADD(9, 1);
       if (!certified) {
-        if (cand) {  // back into the queue (at most 512 + 256 waiting)
+        if (cand) {  // back into the queue
           const uint32_t at = atomicAdd(&s_qn, 1u);
           s_q[at] = e, s_qm[at] = cand;
         } else {  // uncertified: marked for repair (k_mask_cells gives it the word it starts from)

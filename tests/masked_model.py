@@ -107,20 +107,32 @@ RING = {k: np.array([(x, y, z) for x in range(-2, 3) for y in range(-2, 3) for z
 
 
 def path_in_cell(occ, obs, idx, V, P, S):
-    """every sample of the discrete segment V -> P observed, free, and with S as its own winner (the rule for (1, 1, 1)-diagonals of
-    `certificate` is not applied: every sample here holds the winner -- it changes nothing on the fixtures and costs the GPU walk +50 %)"""
+    """every sample of the discrete segment V -> P observed, free, and with S as its own winner; where two consecutive samples differ
+    along all three axes, one of the six voxels between them as well, or that voxel is S itself (the stencil has no (1, 1, 1) step:
+    the id crosses in two hops -- mask_kernels.hpp: mask_path_diagonals)"""
     d = (P - V).astype(np.int64)
     n = 2 * np.abs(d).max(1) + 1
     ok = np.ones(len(V), bool)
+    prev = V.astype(np.int64).copy()
+
+    def good_at(p, Sa):
+        g = obs[p[..., 0], p[..., 1], p[..., 2]] & ~occ[p[..., 0], p[..., 1], p[..., 2]]
+        return g & np.all(np.stack([idx[k][p[..., 0], p[..., 1], p[..., 2]] for k in range(3)], -1) == Sa, axis=-1)
+
     for i in range(1, int(n.max())):
         act = ok & (i < n)
         if not act.any():
             break
-        na = n[act][:, None]
-        p = V[act] + (2 * d[act] * i + na) // (2 * na)
-        good = obs[p[:, 0], p[:, 1], p[:, 2]] & ~occ[p[:, 0], p[:, 1], p[:, 2]]
-        good &= np.all(np.stack([idx[k][p[:, 0], p[:, 1], p[:, 2]] for k in range(3)], 1) == S[act], axis=1)
+        p = V[act] + (2 * d[act] * i + n[act][:, None]) // (2 * n[act][:, None])
+        good = good_at(p, S[act])
+        step = p - prev[act]
+        tri = np.flatnonzero(good & (step != 0).all(1))
+        if len(tri):
+            q = prev[act][tri][:, None, :] + HALFWAY[None] * step[tri][:, None, :]
+            Sq = S[act][tri][:, None, :]
+            good[tri] = (good_at(q, Sq) | (q == Sq).all(-1)).any(1)
         ok[np.flatnonzero(act)[~good]] = False
+        prev[act] = p
     return ok
 
 
