@@ -1819,8 +1819,14 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
     ~Restore() { m->tr_occ_ = nullptr, m->tr_out_ = nullptr, m->tr_cellobs_ = nullptr; }
   } restore{this};
   tr_occ_ = effocc_.p, tr_out_ = mask_out_.p, tr_cellobs_ = cellobs_.p;
-  const int classify_blocks = (int)std::min<int64_t>(std::max<int64_t>((nquads + 3) / 4, 1), 8192);
-  const int repair_blocks = (int)std::min<int64_t>(std::max<int64_t>((ncells + 3) / 4, 1), 2048);
+#ifndef FIESTA_CLASSIFY_BLOCKS
+#define FIESTA_CLASSIFY_BLOCKS 4096  /* (persistent waves: 16384 -> 581 us, 8192 -> 436, 4096 -> 393, 2048 -> 392) */
+#endif
+  const int classify_blocks = (int)std::min<int64_t>(std::max<int64_t>((nquads + 3) / 4, 1), FIESTA_CLASSIFY_BLOCKS);
+#ifndef FIESTA_REPAIR_BLOCKS
+#define FIESTA_REPAIR_BLOCKS 4096  /* (k_repair_cell on config 2-partial: 1024 -> 121 us, 2048 -> 124, 4096 -> 116, 8192 -> 124; the commit: 27 / 33 / 43 / 51) */
+#endif
+  const int repair_blocks = (int)std::min<int64_t>(std::max<int64_t>((ncells + 3) / 4, 1), FIESTA_REPAIR_BLOCKS);
   int gi = 0;  // global repair iterations of this update launched so far
   auto launch_chain = [&](const int n, const unsigned long long *failed) {
     MaskArgs a = ma;
@@ -1829,7 +1835,7 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
       const uint32_t tag = ++mask_serial_;
       const int rd = (gi + 1) & 1;
       hipLaunchKernelGGL(k_repair_cell, dim3(repair_blocks), dim3(256), 0, stream_, a, k, rd, tag - 1u, gi == 0 ? 1 : 0);
-      hipLaunchKernelGGL(k_repair_commit, dim3(repair_blocks), dim3(256), 0, stream_, a, k, rd, tag - 1u, tag, gi == 0 ? 1 : 0);
+      hipLaunchKernelGGL(k_repair_commit, dim3(std::min(repair_blocks, 1024)), dim3(256), 0, stream_, a, k, rd, tag - 1u, tag, gi == 0 ? 1 : 0);
     }
     FIESTA_HIP_CHECK(hipGetLastError());
   };
@@ -1847,7 +1853,10 @@ bool DenseMap::run_masked(fiesta_hip_stats *st, std::chrono::steady_clock::time_
     a.failed = failed;
     FIESTA_HIP_CHECK(hipEventRecord(ev_cert, stream_));
     hipLaunchKernelGGL(k_mask_classify, dim3(classify_blocks), dim3(256), 0, stream_, a);
-    hipLaunchKernelGGL(k_mask_walk, dim3(kMaskSegs * 16), dim3(256), 0, stream_, a);
+    #ifndef FIESTA_WALK_PARTS
+#define FIESTA_WALK_PARTS 32  /* (measured on config 2-partial: 8 -> 1.52 ms, 16 -> 1.20, 32 -> 0.98, 64 -> 0.98: short work-groups even out the tail) */
+#endif
+    hipLaunchKernelGGL(k_mask_walk, dim3(kMaskSegs * FIESTA_WALK_PARTS), dim3(256), 0, stream_, a);
     hipLaunchKernelGGL(k_mask_cells, dim3(std::min(classify_blocks, 1024)), dim3(256), 0, stream_, a);
     FIESTA_HIP_CHECK(hipGetLastError());
     FIESTA_HIP_CHECK(hipEventRecord(ev_rep, stream_));
