@@ -459,7 +459,12 @@ __device__ __forceinline__ void nn_dot4_pair(uint32_t a, uint32_t b0, uint32_t b
   asm("v_dot4_i32_i8 %0, %2, %3, 0\n\tv_dot4_i32_i8 %1, %2, %4, 0\n\ts_nop 2" : "=&v"(d0), "=&v"(d1) : "v"(a), "v"(b0), "v"(b1));
 }
 
-constexpr int kFillBlocks = 2048;  // persistent work-groups of four waves: 8 per CU, 8 quads (32 cells) per wave on a 512^3 map
+// persistent work-groups of four waves.  Measured on config 2 (512^3, r06): 1024 -> 162 us, 2048 -> 157 (r05's choice: 8 quads per
+// wave), 4096 -> 148, 8192 -> 145, 16384 -> 136: one quad (four cells) per wave, the tail of the launch evens out
+#ifndef FIESTA_FILL_BLOCKS
+#define FIESTA_FILL_BLOCKS 16384
+#endif
+constexpr int kFillBlocks = FIESTA_FILL_BLOCKS;
 constexpr int kListPad = 256;      // dwords the list array is over-allocated by (the last 128: where masked lanes of the offset fill store)
 
 // A QUAD is four cells adjacent in z: 32 voxels, one 128-byte line per (x, y) row.  ONE WAVE serves a quad -- its four cells
