@@ -957,6 +957,8 @@ def main():
         try:
             all_cells = all(int(s.get("cells", 0)) for s in timed)
             tag = "pmc_traffic_cells" if all_cells else "pmc_traffic_ft" if all_bulk else "pmc_traffic_k_relax_q"
+            if any(int(s.get("masked", 0)) for s in timed):
+                tag = "pmc_traffic_masked"   # (no such collection: the cell transform's traffic is not the masked transform's)
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if tag in f and f.endswith(".json"))
             if cands and world == 1 and args.scene == "scatter" and G == 512:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
