@@ -90,3 +90,18 @@ def test_hand_scheduled_kernels_do_not_spill():
         __graft_entry__.build_hip()
     guarded = check_kernel_resources.check(_lib.LIB_PATH)
     assert any("k_nn_fill_full" in k for k in guarded) and any("k_ft_x" in k for k in guarded)
+
+
+def test_path_note_names_follow_the_header():
+    """fiesta_hip_stats.path_notes: the names the Python statistics give the bits (`why`) are the header's FIESTA_HIP_NOTE_* in
+    bit order, and the struct mirrors end in the same field."""
+    import re
+    from fiesta_amd._lib import Stats
+    text = open(os.path.join(ROOT, "include", "fiesta_hip.h")).read()
+    notes = re.findall(r"#define FIESTA_HIP_NOTE_(\w+) (0x[0-9a-fA-F]+)", text)
+    assert len(notes) == len(Stats.NOTES) >= 10
+    for bit, (name, value) in enumerate(notes):
+        assert int(value, 16) == 1 << bit, (name, value)
+        assert Stats.NOTES[bit] == name.lower(), (bit, name, Stats.NOTES[bit])
+    assert Stats._fields_[-1][0] == "path_notes"
+    assert re.search(r"int64_t path_notes;[^}]*\} fiesta_hip_stats;", text, re.S)
